@@ -1,0 +1,353 @@
+"""TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+
+CPU restatement (NumPy) of the one hot path this repository accelerates: the
+forward / backward / optimiser step of the 2D->3D pose-lifting MLP of
+nulledge/bilinear.  It exists only to *check* the HIP path (tests/,
+``__graft_entry__.smoke()``, and the ``cpu_baseline`` leg of ``bench.py`` may
+import it; nothing under ``bilinear_amd/`` may).
+
+Parity status: PINNED.  Every function below is checked against golden vectors
+captured from the reference itself (``/root/reference/model/bilinear.py`` +
+the step body of ``train_bilinear.py``), see ``tests/golden/make_golden.py``
+and ``tests/test_oracle_golden.py``.
+
+The arithmetic of the reference lives in PyTorch (un-vendored, un-pinned
+dependency; the golden vectors were produced with torch 2.10.0 CPU).  Each
+function cites the reference call-site it restates (paths relative to
+``/root/reference``) and, where the semantics are PyTorch's, the published
+formula it follows.
+
+The restatement is generalised to ``(num_blocks, width)``; the reference only
+expresses ``(2, 1024)`` (``model/bilinear.py:22-29``), which is where it is
+pinned.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+NUM_JOINT = 17 - 1            # model/bilinear.py:20
+IN_FEATURES = 2 * NUM_JOINT   # model/bilinear.py:22
+OUT_FEATURES = 3 * NUM_JOINT  # model/bilinear.py:29
+BN_EPS = 1e-5                 # nn.BatchNorm1d default, model/bilinear.py:10
+BN_MOMENTUM = 0.1             # nn.BatchNorm1d default
+DROPOUT_P = 0.5               # model/bilinear.py:12
+ADAM_BETAS = (0.9, 0.999)     # torch.optim.Adam default, model/bilinear.py:60
+ADAM_EPS = 1e-8
+CLIP_MAX_NORM = 1.0           # train_bilinear.py:81
+
+
+# --------------------------------------------------------------------------
+# structure
+# --------------------------------------------------------------------------
+def heavy_names(num_blocks):
+    """Prefixes of every heavy_linear (Linear->BN->ReLU->Dropout) in forward
+    order: ``encode`` then ``bilinear.{b}.{l}`` (model/bilinear.py:22-27)."""
+    names = ["encode"]
+    for b in range(num_blocks):
+        for l in range(2):
+            names.append("bilinear.%d.%d" % (b, l))
+    return names
+
+
+def state_spec(num_blocks=2, width=1024):
+    """Ordered (key, shape, kind) of the reference ``state_dict`` —
+    37 entries at num_blocks=2 (22 parameters + 15 BN buffers)."""
+    spec = []
+    for i, h in enumerate(heavy_names(num_blocks)):
+        fan_in = IN_FEATURES if i == 0 else width
+        spec += [
+            (h + ".0.weight", (width, fan_in), "param"),
+            (h + ".0.bias", (width,), "param"),
+            (h + ".1.weight", (width,), "param"),
+            (h + ".1.bias", (width,), "param"),
+            (h + ".1.running_mean", (width,), "buffer"),
+            (h + ".1.running_var", (width,), "buffer"),
+            (h + ".1.num_batches_tracked", (), "buffer"),
+        ]
+    spec += [
+        ("decode.weight", (OUT_FEATURES, width), "param"),
+        ("decode.bias", (OUT_FEATURES,), "param"),
+    ]
+    return spec
+
+
+def param_keys(num_blocks=2):
+    """Keys in ``module.parameters()`` order (what Adam / clip iterate)."""
+    return [k for k, _, kind in state_spec(num_blocks, 4) if kind == "param"]
+
+
+def init_state(seed, num_blocks=2, width=1024, dtype=np.float32):
+    """Deterministic initial state with the *distributions* of
+    model/bilinear.py:86-90: Linear.weight ~ kaiming_normal (fan_in, gain
+    sqrt 2 => std = sqrt(2/fan_in)); Linear.bias keeps nn.Linear's default
+    U(-1/sqrt(fan_in), 1/sqrt(fan_in)); BN gamma=1, beta=0, running stats
+    (0, 1), num_batches_tracked=0.  The bit stream is NumPy's legacy
+    ``RandomState`` (stable across NumPy versions), not torch's."""
+    rng = np.random.RandomState(seed)
+    st = OrderedDict()
+    for key, shape, _ in state_spec(num_blocks, width):
+        leaf = key.split(".")[-1]
+        is_linear = key.startswith("decode") or key.split(".")[-2] == "0"
+        if is_linear and leaf == "weight":
+            fan_in = shape[1]
+            st[key] = (rng.standard_normal(shape) * math.sqrt(2.0 / fan_in)).astype(dtype)
+        elif is_linear and leaf == "bias":
+            fan_in = IN_FEATURES if key.startswith("encode") else width
+            bound = 1.0 / math.sqrt(fan_in)
+            st[key] = rng.uniform(-bound, bound, size=shape).astype(dtype)
+        elif leaf == "weight":          # BN gamma
+            st[key] = np.ones(shape, dtype)
+        elif leaf == "bias":            # BN beta
+            st[key] = np.zeros(shape, dtype)
+        elif leaf == "running_mean":
+            st[key] = np.zeros(shape, dtype)
+        elif leaf == "running_var":
+            st[key] = np.ones(shape, dtype)
+        else:
+            st[key] = np.zeros((), np.int64)
+    return st
+
+
+def synthetic_batch(seed, batch, dtype=np.float32):
+    """x ~ N(0,1) [B,32], t ~ N(0,1) [B,48]: the contract of the real loader is
+    per-feature z-scored vectors (H36M/data.py:108-110)."""
+    rng = np.random.RandomState(seed)
+    x = rng.standard_normal((batch, IN_FEATURES)).astype(dtype)
+    t = rng.standard_normal((batch, OUT_FEATURES)).astype(dtype)
+    return x, t
+
+
+def random_masks(seed, batch, num_blocks=2, width=1024):
+    """Bernoulli(0.5) keep-masks, one [B,width] uint8 array per heavy_linear."""
+    rng = np.random.RandomState(seed)
+    return [(rng.random_sample((batch, width)) >= DROPOUT_P).astype(np.uint8)
+            for _ in heavy_names(num_blocks)]
+
+
+# --------------------------------------------------------------------------
+# forward
+# --------------------------------------------------------------------------
+def _heavy_fwd(st, h, a_in, mask, training, dtype, update_running, momentum):
+    """heavy_linear, model/bilinear.py:7-13:
+    Linear (z = a W^T + b) -> BatchNorm1d -> ReLU -> Dropout(0.5).
+
+    BatchNorm1d (training): normalise with the biased batch variance; update
+    running_mean <- (1-m) rm + m mu, running_var <- (1-m) rv + m var*B/(B-1)
+    (unbiased), num_batches_tracked += 1.  ``momentum=None`` is PyTorch's
+    cumulative-average mode (what reset_statistics, model/bilinear.py:43-55,
+    selects): factor = 1/num_batches_tracked.
+    Dropout (training): a = y * mask / (1-p), values exactly {0, 2y}."""
+    W = st[h + ".0.weight"].astype(dtype)
+    b = st[h + ".0.bias"].astype(dtype)
+    gamma = st[h + ".1.weight"].astype(dtype)
+    beta = st[h + ".1.bias"].astype(dtype)
+    z = a_in @ W.T + b
+    n = z.shape[0]
+    if training:
+        mu = z.mean(axis=0, dtype=np.float64)
+        var = ((z.astype(np.float64) - mu) ** 2).mean(axis=0)   # biased
+        if update_running:
+            nbt = int(st[h + ".1.num_batches_tracked"]) + 1
+            st[h + ".1.num_batches_tracked"] = np.asarray(nbt, np.int64)
+            f = (1.0 / nbt) if momentum is None else momentum
+            unbiased = var * (n / max(n - 1, 1))
+            st[h + ".1.running_mean"] = ((1 - f) * st[h + ".1.running_mean"].astype(np.float64)
+                                         + f * mu).astype(st[h + ".1.running_mean"].dtype)
+            st[h + ".1.running_var"] = ((1 - f) * st[h + ".1.running_var"].astype(np.float64)
+                                        + f * unbiased).astype(st[h + ".1.running_var"].dtype)
+        mu = mu.astype(dtype)
+        invstd = (1.0 / np.sqrt(var + BN_EPS)).astype(dtype)
+    else:
+        mu = st[h + ".1.running_mean"].astype(dtype)
+        invstd = (1.0 / np.sqrt(st[h + ".1.running_var"].astype(np.float64) + BN_EPS)).astype(dtype)
+    zhat = (z - mu) * invstd
+    y = zhat * gamma + beta
+    r = np.maximum(y, 0)
+    if training:
+        keep = mask.astype(dtype)
+        a = r * keep * dtype(1.0 / (1.0 - DROPOUT_P))
+    else:
+        keep = None
+        a = r
+    cache = dict(a_in=a_in, z=z, zhat=zhat, invstd=invstd, y=y, keep=keep)
+    return a.astype(dtype), cache
+
+
+def forward(st, x, masks=None, training=True, dtype=np.float32,
+            update_running=True, momentum=BN_MOMENTUM):
+    """BilinearUnit.forward, model/bilinear.py:31-41:
+    encode -> for each block: skip = a; a = block(a); a = a + skip -> decode.
+    Returns (prediction [B,48], cache for backward).  ``st`` running stats are
+    updated in place when training (as nn.BatchNorm1d does)."""
+    dtype = np.dtype(dtype).type
+    num_blocks = (sum(1 for k in st if k.endswith(".0.weight")) - 1) // 2
+    names = heavy_names(num_blocks)
+    a = np.asarray(x, dtype)
+    caches = []
+    a, c = _heavy_fwd(st, names[0], a, None if masks is None else masks[0],
+                      training, dtype, update_running, momentum)
+    caches.append(c)
+    li = 1
+    for _ in range(num_blocks):
+        skip = a
+        for _l in range(2):
+            a, c = _heavy_fwd(st, names[li], a, None if masks is None else masks[li],
+                              training, dtype, update_running, momentum)
+            caches.append(c)
+            li += 1
+        a = a + skip                                   # model/bilinear.py:38
+    Wd = st["decode.weight"].astype(dtype)
+    bd = st["decode.bias"].astype(dtype)
+    pred = a @ Wd.T + bd                               # model/bilinear.py:39
+    return pred, dict(layers=caches, a_last=a, names=names, num_blocks=num_blocks)
+
+
+# --------------------------------------------------------------------------
+# loss
+# --------------------------------------------------------------------------
+def mse_loss(pred, target):
+    """nn.MSELoss() (mean reduction), train_bilinear.py:49,78:
+    loss = sum((p-t)^2)/(B*48); d loss/d p = 2 (p-t)/(B*48)."""
+    diff = pred - target
+    n = diff.size
+    loss = float((diff.astype(np.float64) ** 2).sum() / n)
+    dpred = (diff * pred.dtype.type(2.0 / n)).astype(pred.dtype)
+    return loss, dpred
+
+
+# --------------------------------------------------------------------------
+# backward  (autograd of forward + mse, train_bilinear.py:79)
+# --------------------------------------------------------------------------
+def _heavy_bwd(st, h, c, d_a, dtype, need_dx=True):
+    """Backward of heavy_linear.
+    dropout+relu: dY = dA * keep/(1-p) * [y>0]
+    batchnorm   : dgamma = sum_B dY*zhat ; dbeta = sum_B dY ;
+                  dZ = gamma*invstd * (dY - dbeta/B - zhat*dgamma/B)
+    linear      : dW = dZ^T a_in ; db = sum_B dZ ; dA_in = dZ W."""
+    gamma = st[h + ".1.weight"].astype(dtype)
+    W = st[h + ".0.weight"].astype(dtype)
+    n = d_a.shape[0]
+    dY = d_a * c["keep"].astype(dtype) * dtype(1.0 / (1.0 - DROPOUT_P)) * (c["y"] > 0)
+    dgamma = (dY.astype(np.float64) * c["zhat"]).sum(axis=0)
+    dbeta = dY.astype(np.float64).sum(axis=0)
+    dZ = (gamma * c["invstd"]) * (dY - (dbeta / n).astype(dtype)
+                                  - c["zhat"] * (dgamma / n).astype(dtype))
+    dZ = dZ.astype(dtype)
+    g = {
+        h + ".0.weight": dZ.T @ c["a_in"],
+        h + ".0.bias": dZ.sum(axis=0, dtype=np.float64).astype(dtype),
+        h + ".1.weight": dgamma.astype(dtype),
+        h + ".1.bias": dbeta.astype(dtype),
+    }
+    d_in = (dZ @ W) if need_dx else None
+    return d_in, g
+
+
+def backward(st, cache, dpred, dtype=np.float32):
+    """Gradients of every parameter (dict keyed like state_dict).  The network
+    input gets no gradient (train_bilinear.py:72)."""
+    dtype = np.dtype(dtype).type
+    names, nb = cache["names"], cache["num_blocks"]
+    grads = {}
+    Wd = st["decode.weight"].astype(dtype)
+    grads["decode.weight"] = dpred.T @ cache["a_last"]
+    grads["decode.bias"] = dpred.sum(axis=0, dtype=np.float64).astype(dtype)
+    d_a = dpred @ Wd
+    li = len(names) - 1
+    for _ in range(nb):
+        d_skip = d_a                                    # a = block(a) + skip
+        for _l in range(2):
+            d_a, g = _heavy_bwd(st, names[li], cache["layers"][li], d_a, dtype)
+            grads.update(g)
+            li -= 1
+        d_a = d_a + d_skip
+    _, g = _heavy_bwd(st, names[0], cache["layers"][0], d_a, dtype, need_dx=False)
+    grads.update(g)
+    return grads
+
+
+# --------------------------------------------------------------------------
+# clip + Adam + lr decay  (train_bilinear.py:66-70, 81, 83)
+# --------------------------------------------------------------------------
+def clip_grad_norm(grads, keys, max_norm=CLIP_MAX_NORM):
+    """nn.utils.clip_grad_norm_(params, max_norm=1), train_bilinear.py:81:
+    total = ||all grads||_2 ; coef = min(1, max_norm/(total+1e-6)) ; g *= coef
+    (PyTorch multiplies unconditionally by the clamped coefficient)."""
+    tot = 0.0
+    for k in keys:
+        tot += float((grads[k].astype(np.float64) ** 2).sum())
+    total_norm = math.sqrt(tot)
+    coef = min(1.0, max_norm / (total_norm + 1e-6))
+    for k in keys:
+        grads[k] = (grads[k] * grads[k].dtype.type(coef)).astype(grads[k].dtype)
+    return total_norm, coef
+
+
+def adam_init(st, keys):
+    return dict(step=0,
+                exp_avg={k: np.zeros_like(st[k]) for k in keys},
+                exp_avg_sq={k: np.zeros_like(st[k]) for k in keys})
+
+
+def adam_step(st, grads, opt, keys, lr, betas=ADAM_BETAS, eps=ADAM_EPS):
+    """torch.optim.Adam (lr given, betas (0.9,0.999), eps 1e-8, no weight decay,
+    no amsgrad; model/bilinear.py:60, train_bilinear.py:83):
+      m <- m + (1-b1)(g - m)        (lerp)
+      v <- b2 v + (1-b2) g*g
+      p <- p - (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)"""
+    opt["step"] += 1
+    t = opt["step"]
+    b1, b2 = betas
+    bc1 = 1.0 - b1 ** t
+    bc2 = 1.0 - b2 ** t
+    step_size = lr / bc1
+    bc2_sqrt = math.sqrt(bc2)
+    for k in keys:
+        g = grads[k]
+        dt = g.dtype.type
+        m = opt["exp_avg"][k]
+        v = opt["exp_avg_sq"][k]
+        m += (g - m) * dt(1.0 - b1)
+        v *= dt(b2)
+        v += (g * g) * dt(1.0 - b2)
+        denom = np.sqrt(v) / dt(bc2_sqrt) + dt(eps)
+        st[k] = (st[k] - dt(step_size) * (m / denom)).astype(st[k].dtype)
+
+
+def lr_decay_condition(step):
+    """util/config.py:21."""
+    return step % 100000 == 0 or step == 1
+
+
+def lr_decay_function(step):
+    """util/config.py:22."""
+    return 1.0e-3 * 0.96 ** (step / 100000)
+
+
+def train_step(st, opt, x, t, masks, lr, dtype=np.float32):
+    """The step body of train_bilinear.py:75-83 (zero_grad, forward, MSE,
+    backward, clip_grad_norm_(1), Adam).  Returns a dict of observables."""
+    keys = [k for k in st if not (k.endswith("running_mean") or k.endswith("running_var")
+                                  or k.endswith("num_batches_tracked"))]
+    pred, cache = forward(st, x, masks, training=True, dtype=dtype)
+    loss, dpred = mse_loss(pred, np.asarray(t, pred.dtype))
+    grads = backward(st, cache, dpred, dtype=dtype)
+    raw = {k: v.copy() for k, v in grads.items()}
+    total_norm, coef = clip_grad_norm(grads, keys)
+    adam_step(st, grads, opt, keys, lr)
+    return dict(pred=pred, loss=loss, grads_raw=raw, grads=grads,
+                total_norm=total_norm, clip_coef=coef)
+
+
+# --------------------------------------------------------------------------
+# "next" row: MPJPE of valid_bilinear.py:53-60,76-83
+# --------------------------------------------------------------------------
+def mpjpe_sum(pred, target, mean, stddev):
+    """valid_bilinear.py:53-60: de-normalise both with the train-set mean/std,
+    view as [B,16,3], per-sample sum over joints of the Euclidean distance."""
+    p = (stddev * pred + mean).reshape(-1, NUM_JOINT, 3)
+    g = (stddev * target + mean).reshape(-1, NUM_JOINT, 3)
+    return np.sqrt(((p - g) ** 2).sum(axis=2)).sum(axis=1)
