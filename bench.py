@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Benchmark of the lifter training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is the whole step body of /root/reference/train_bilinear.py:75-83 on one
+synthetic batch resident in HBM: zero_grad, forward, MSELoss, backward,
+[gradient all-reduce when N > 1], clip_grad_norm_(1), Adam.step.  The workload at N=1
+is BASELINE.json configs[1]: 2 residual blocks, width 1024, batch 4096, fp32
+(weak scaling: every GPU processes its own 4096-pose batch).
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline     : achieved fraction of the fp32-MFMA peak of the dominant kernel
+                 (the 1024x1024 Linear forward GEMM), timed live with HIP events;
+  cpu_baseline : oracle/torch_port.py (plain PyTorch on the host cores) on the same
+                 workload, bounded sample, rank 0 at N = 1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
+HBM_PEAK_GBS = 8000.0
+
+
+def flops_per_pose(num_blocks, width):
+    """fwd = 2*32*W + L*2*W^2 + 2*W*48; bwd = 2*32*W + L*4*W^2 + 4*W*48."""
+    L = 2 * num_blocks
+    fwd = 2 * 32 * width + L * 2 * width * width + 2 * width * 48
+    bwd = 2 * 32 * width + L * 4 * width * width + 4 * width * 48
+    return fwd, bwd
+
+
+def time_kernel(fn, reps, warm=3):
+    """Average duration (ms) of one launch, HIP events on the launch stream."""
+    for _ in range(warm):
+        fn()
+    start = torch.cuda.Event(enable_timing=True)
+    stop = torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(reps):
+        fn()
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) / reps
+
+
+def gemm_rooflines(batch, width, reps):
+    """Live timings of the three Linear contractions at the hidden-layer shape."""
+    from bilinear_amd import _native as N
+    lib = N.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    A = torch.randn(batch, width, device=dev)
+    Wt = torch.randn(width, width, device=dev) * 0.03
+    bias = torch.randn(width, device=dev)
+    Z = torch.empty(batch, width, device=dev)
+    stat = torch.empty((batch + 127) // 128, 2, width, device=dev)
+    splits = max(1, min((256 * 128 * 128) // (width * width), batch // 128))
+    slabs = torch.empty(splits, width, width, device=dev)
+    flop = 2.0 * batch * width * width
+    out = {}
+
+    def fwd():
+        N.check(lib.blh_linear_fwd_stats(st, A.data_ptr(), Wt.data_ptr(), bias.data_ptr(),
+                                         Z.data_ptr(), stat.data_ptr(), batch, width, width), "fwd")
+
+    def dgrad():
+        N.check(lib.blh_gemm_f32(st, A.data_ptr(), width, 0, Wt.data_ptr(), width, 1, Z.data_ptr(),
+                                 width, batch, width, width, 1, None, None, 0), "dgrad")
+
+    def wgrad():
+        N.check(lib.blh_gemm_f32(st, A.data_ptr(), width, 1, Z.data_ptr(), width, 1,
+                                 slabs.data_ptr(), width, width, width, batch, splits, None, None,
+                                 0), "wgrad")
+
+    for name, fn in (("linear_fwd", fwd), ("linear_dgrad", dgrad), ("linear_wgrad", wgrad)):
+        ms = time_kernel(fn, reps)
+        out[name] = {"ms": ms, "tflops": flop / ms / 1e9}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch")
+    ap.add_argument("--blocks", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=20)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import bilinear_amd
+    from bilinear_amd.dp import DataParallel
+
+    torch.manual_seed(1)          # identical init on every rank
+    net, opt, step, _ = bilinear_amd.load(dev, num_blocks=args.blocks, width=args.width)
+    net.train()
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    x = torch.randn(args.batch, 32, device=dev, generator=g)
+    t = torch.randn(args.batch, 48, device=dev, generator=g)
+    dp = DataParallel(net, opt) if world > 1 else None
+
+    def one_step():
+        if dp is not None:
+            return dp.train_step(x, t)
+        return net.train_step(opt, x, t, max_norm=1.0)
+
+    for _ in range(args.warmup):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pred, loss = one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    final_loss = float(loss.item())
+
+    # fwd+bwd only (no optimiser), single rank view, for the record
+    def fwd_bwd():
+        opt.zero_grad()
+        p = net(x)
+        l, dpred = net.engine.mse_loss_grad(p.detach(), t)
+        p.backward(dpred)
+    fb_ms = None
+    if rank == 0:
+        fb_ms = time_kernel(fwd_bwd, max(5, args.steps // 4))
+
+    result = None
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        poses = args.batch * world * args.steps / elapsed
+        fwd, bwd = flops_per_pose(args.blocks, args.width)
+        kern = gemm_rooflines(args.batch, args.width, reps=20)
+        dom = kern["linear_fwd"]
+        result = {
+            "metric": "poses/sec (fwd+bwd, 16-joint, batch 4096) at 1/2/4/8 MI355X",
+            "value": poses,
+            "unit": "poses/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: %d-block width %d, batch %d per GPU, fp32, "
+                            "x~N(0,1)[B,32], t~N(0,1)[B,48], Kaiming-normal init" % (
+                                args.blocks, args.width, args.batch),
+                "step": "zero_grad+forward+MSE+backward%s+clip_grad_norm(1)+Adam" % (
+                    "+allreduce(grad)" if world > 1 else ""),
+                "global_batch": args.batch * world,
+                "parallelism": "dp%d" % world,
+                "dropout": "philox",
+            },
+            "final_loss": final_loss,
+            "fwd_bwd_only": {"ms_per_step": fb_ms, "poses_per_s": args.batch / (fb_ms / 1e3)},
+            "step_tflops": poses * (fwd + bwd) / 1e12,
+            "step_frac_of_fp32_mfma_peak": poses * (fwd + bwd) / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
+            "roofline": {
+                "kernel": "gemm_f32_kernel<128,128,2,2,ROWK,ROWK,BIAS_STATS> (Linear %dx%d forward, M=%d)" % (
+                    args.width, args.width, args.batch),
+                "bound": "mfma",
+                "achieved": dom["tflops"],
+                "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": dom["tflops"] / FP32_MFMA_PEAK_TFLOPS,
+                "traffic": None,
+                "avg_launch_ms": dom["ms"],
+                "flop_per_launch": 2.0 * args.batch * args.width * args.width,
+            },
+            "kernels": kern,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import torch_port as TP
+            cores = os.cpu_count() or 1
+            cpu = TP.time_cpu_steps(args.blocks, args.width, args.batch, steps=args.cpu_steps,
+                                    warmup=2, threads=cores)
+            result["cpu_baseline"] = {
+                "value": cpu["poses_per_s"], "unit": "poses/s", "cores": cpu["threads"],
+                "kind": "port",
+                "sample": "%d full steps (fwd+MSE+bwd+clip+Adam) of oracle/torch_port.py, batch %d, "
+                          "fp32, after 2 warm-up steps" % (cpu["steps"], args.batch),
+                "ms_per_step": cpu["ms_per_step"],
+            }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

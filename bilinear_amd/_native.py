@@ -1,0 +1,126 @@
+"""ctypes binding of libbilinear_hip.so (the C ABI declared in include/bilinear_hip.h).
+
+This is the stub a maintainer of the reference would add to
+``model/bilinear.py`` to route ``BilinearUnit`` through the MI355X kernels (see
+INTEGRATION.md).  There is NO fallback: if the library is missing or a call
+fails, a ``RuntimeError`` is raised — results never silently come from another
+code path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64,
+                    c_uint64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbilinear_hip.so")
+
+OK = 0
+
+
+class ModelDesc(Structure):
+    _fields_ = [("num_blocks", c_int32), ("width", c_int32),
+                ("in_features", c_int32), ("out_features", c_int32)]
+
+
+class Dropout(Structure):
+    _fields_ = [("keep_mask", c_void_p), ("seed", c_uint64), ("step", c_uint64),
+                ("row_offset", c_int64)]
+
+
+class AdamHyper(Structure):
+    _fields_ = [("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
+                ("max_norm", c_float), ("step", c_int32)]
+
+
+GradReadyFn = ctypes.CFUNCTYPE(None, c_void_p, c_int64, c_int64)
+
+# name -> (restype, argtypes); mirrors include/bilinear_hip.h one to one
+_SIGNATURES = {
+    "blh_status_string": (c_char_p, [c_int]),
+    "blh_last_hip_error": (c_int, []),
+    "blh_abi_version": (c_int, []),
+    "blh_num_heavy": (c_int32, [POINTER(ModelDesc)]),
+    "blh_param_arena_floats": (c_int64, [POINTER(ModelDesc)]),
+    "blh_num_param_tensors": (c_int32, [POINTER(ModelDesc)]),
+    "blh_param_tensor_info": (c_int, [POINTER(ModelDesc), c_int32, c_char_p, c_int32,
+                                      POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
+    "blh_bn_running_floats": (c_int64, [POINTER(ModelDesc)]),
+    "blh_workspace_bytes": (c_int64, [POINTER(ModelDesc), c_int64]),
+    "blh_forward_train": (c_int, [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, POINTER(Dropout), c_float, c_void_p, c_int64,
+                                  c_void_p, c_int64]),
+    "blh_forward_eval": (c_int, [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_int64, c_void_p, c_int64]),
+    "blh_mse_loss_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double,
+                                  c_float, c_void_p, c_void_p, c_void_p, c_int64]),
+    "blh_backward": (c_int, [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, POINTER(Dropout),
+                             c_void_p, c_int64, c_void_p, c_void_p, c_int64, GradReadyFn,
+                             c_void_p]),
+    "blh_clip_grad_norm": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_int64,
+                                   c_void_p]),
+    "blh_clip_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                   POINTER(AdamHyper), c_void_p, c_int64, c_void_p]),
+    "blh_train_step": (c_int, [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               POINTER(Dropout), c_float, POINTER(AdamHyper), c_void_p, c_int64,
+                               c_void_p, c_void_p, c_void_p, c_int64]),
+    "blh_gemm_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
+                             c_void_p, c_int64, c_int64, c_int64, c_int64, c_int32, c_void_p,
+                             c_void_p, c_int64]),
+    "blh_sum_slabs": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "blh_linear_fwd_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int64, c_int64, c_int64]),
+    "blh_dropout_mask": (c_int, [c_void_p, POINTER(Dropout), c_int32, c_int64, c_int32, c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the library.  torch is imported first so that the
+    library's ``libamdhip64.so.7`` dependency resolves to the HIP runtime already
+    loaded by PyTorch (same soname): streams and device pointers are then shared."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (loads torch's HIP runtime before ours is resolved)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "bilinear_amd: native library %s not found. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C bilinear_amd/csrc`. There is no fallback path." % LIB_PATH)
+    try:
+        handle = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_LOCAL)
+    except OSError as exc:
+        raise RuntimeError("bilinear_amd: cannot load %s: %s" % (LIB_PATH, exc)) from exc
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as exc:
+            raise RuntimeError("bilinear_amd: %s does not export %s" % (LIB_PATH, name)) from exc
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = handle
+    return _lib
+
+
+def exported_names():
+    return sorted(_SIGNATURES)
+
+
+def check(status, what):
+    """Raise RuntimeError for a non-OK blh_status (the reference relies on
+    PyTorch raising RuntimeError on shape/device errors; so do we)."""
+    if status != OK:
+        l = lib()
+        msg = l.blh_status_string(int(status)).decode()
+        if status == -3:
+            msg += " (hipError_t %d)" % l.blh_last_hip_error()
+        raise RuntimeError("bilinear_amd: %s failed: %s" % (what, msg))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())

@@ -1,0 +1,529 @@
+// C ABI of libbilinear_hip.so: arena layout, workspace carving and the fixed kernel
+// DAG of the lifter's forward / backward / optimiser step.  Pure enqueue code: no
+// allocation, no synchronisation, so every entry point is hipGraph-capturable.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+namespace blh {
+
+thread_local int g_last_hip_error = 0;
+
+static constexpr int64_t ARENA_ALIGN = 64;   // floats (256 B)
+static constexpr int64_t WS_ALIGN = 256;     // bytes
+
+struct TensorInfo {
+  char name[64];
+  int64_t offset, rows, cols;
+};
+
+struct HeavyOffsets {
+  int64_t w, b, gamma, beta;
+  int fan_in;
+};
+
+struct ArenaLayout {
+  std::vector<TensorInfo> tensors;
+  std::vector<HeavyOffsets> heavy;
+  int64_t dec_w, dec_b;
+  int64_t total;
+};
+
+static int check_desc(const blh_model_desc* d) {
+  if (!d) return BLH_ERR_INVALID_ARGUMENT;
+  if (d->num_blocks < 0 || d->width <= 0 || d->in_features <= 0 || d->out_features <= 0)
+    return BLH_ERR_INVALID_ARGUMENT;
+  if (d->width % 64 != 0 || d->in_features % 4 != 0 || d->out_features % 4 != 0)
+    return BLH_ERR_SHAPE;
+  if (d->out_features > 64) return BLH_ERR_SHAPE;   // decode uses one 64-wide column tile
+  return BLH_OK;
+}
+
+static void heavy_prefix(int i, char* buf, size_t cap) {
+  if (i == 0) snprintf(buf, cap, "encode");
+  else snprintf(buf, cap, "bilinear.%d.%d", (i - 1) / 2, (i - 1) % 2);
+}
+
+static ArenaLayout make_layout(const blh_model_desc* d) {
+  ArenaLayout L;
+  int64_t off = 0;
+  const int nh = 1 + 2 * d->num_blocks;
+  auto add = [&](const char* prefix, const char* leaf, int64_t rows, int64_t cols) {
+    TensorInfo t;
+    snprintf(t.name, sizeof(t.name), "%s.%s", prefix, leaf);
+    t.offset = off; t.rows = rows; t.cols = cols;
+    L.tensors.push_back(t);
+    const int64_t at = off;
+    off = round_up(off + rows * cols, ARENA_ALIGN);
+    return at;
+  };
+  for (int i = 0; i < nh; ++i) {
+    char pre[48];
+    heavy_prefix(i, pre, sizeof(pre));
+    HeavyOffsets h;
+    h.fan_in = (i == 0) ? d->in_features : d->width;
+    h.w = add(pre, "0.weight", d->width, h.fan_in);
+    h.b = add(pre, "0.bias", d->width, 1);
+    h.gamma = add(pre, "1.weight", d->width, 1);
+    h.beta = add(pre, "1.bias", d->width, 1);
+    L.heavy.push_back(h);
+  }
+  L.dec_w = add("decode", "weight", d->out_features, d->width);
+  L.dec_b = add("decode", "bias", d->out_features, 1);
+  L.total = off;
+  return L;
+}
+
+// ------------------------------------------------------------ workspace ----
+struct Workspace {
+  std::vector<float*> Z, A;       // per heavy: pre-BN output, activation (skip added)
+  std::vector<float*> bn_saved;   // per heavy: [4][W] mean, invstd, scale, shift
+  float* stat_part;               // [tiles_m][2][W]
+  float* G0; float* G1; float* dZ;
+  float* bn_part;                 // [chunks][2][W]
+  float* dz_colsum_part;          // [chunks][W]
+  float* slabs;                   // split-K partial products
+  float* dpred;                   // [B][out]
+  float* loss_part;               // [4096]
+  double* sumsq_part;             // [1024]
+  float* colsum_part;             // [ceil(B/256)][out]
+  int64_t bytes;
+};
+
+struct Splits { int splits, k_per; };
+static Splits pick_splits(int64_t batch, int64_t tiles) {
+  int64_t want = std::max<int64_t>(1, ceil_div(256, tiles));
+  int64_t max_splits = std::max<int64_t>(1, batch / 128);
+  int64_t s = std::min(want, max_splits);
+  int64_t k_per = round_up(ceil_div(batch, s), 32);
+  s = ceil_div(batch, k_per);
+  return Splits{(int)s, (int)k_per};
+}
+
+static int64_t slab_floats(const blh_model_desc* d, int64_t batch) {
+  const int64_t W = d->width;
+  const Splits hs = pick_splits(batch, ceil_div(W, 128) * ceil_div(W, 128));
+  const Splits es = pick_splits(batch, ceil_div(W, 128) * ceil_div(d->in_features, 32));
+  const Splits ds = pick_splits(batch, ceil_div(d->out_features, 64) * ceil_div(W, 128));
+  int64_t m = hs.splits * W * W;
+  m = std::max(m, es.splits * W * (int64_t)d->in_features);
+  m = std::max(m, ds.splits * (int64_t)d->out_features * W);
+  return m;
+}
+
+static Workspace carve(const blh_model_desc* d, int64_t batch, void* base) {
+  Workspace ws;
+  const int nh = 1 + 2 * d->num_blocks;
+  const int64_t W = d->width;
+  char* p = (char*)base;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) {
+    char* r = p ? p + off : nullptr;
+    off += round_up(bytes, WS_ALIGN);
+    return r;
+  };
+  const int64_t act = batch * W * (int64_t)sizeof(float);
+  for (int i = 0; i < nh; ++i) ws.Z.push_back((float*)take(act));
+  for (int i = 0; i < nh; ++i) ws.A.push_back((float*)take(act));
+  for (int i = 0; i < nh; ++i) ws.bn_saved.push_back((float*)take(4 * W * sizeof(float)));
+  ws.stat_part = (float*)take(ceil_div(batch, 64) * 2 * W * sizeof(float));
+  ws.G0 = (float*)take(act);
+  ws.G1 = (float*)take(act);
+  ws.dZ = (float*)take(act);
+  const int64_t chunks = ew_num_row_chunks(batch);
+  ws.bn_part = (float*)take(chunks * 2 * W * sizeof(float));
+  ws.dz_colsum_part = (float*)take(chunks * W * sizeof(float));
+  ws.slabs = (float*)take(slab_floats(d, batch) * sizeof(float));
+  ws.dpred = (float*)take(batch * d->out_features * sizeof(float));
+  ws.loss_part = (float*)take(4096 * sizeof(float));
+  ws.sumsq_part = (double*)take(SUMSQ_MAX_PARTS * sizeof(double));
+  ws.colsum_part = (float*)take(ceil_div(batch, 256) * d->out_features * sizeof(float));
+  ws.bytes = off;
+  return ws;
+}
+
+// small scratch for entry points that take only a workspace pointer (no model)
+struct Scratch {
+  float* loss_part;
+  double* sumsq_part;
+};
+static constexpr int64_t SCRATCH_BYTES = 4096 * sizeof(float) + SUMSQ_MAX_PARTS * sizeof(double);
+static Scratch carve_scratch(void* base) {
+  Scratch s;
+  s.loss_part = (float*)base;
+  s.sumsq_part = (double*)((char*)base + 4096 * sizeof(float));
+  return s;
+}
+
+static DropoutSrc layer_drop(const blh_dropout* drop, int layer, int64_t batch, int W) {
+  DropoutSrc d;
+  d.keep = drop->keep_mask ? drop->keep_mask + (int64_t)layer * batch * W : nullptr;
+  d.seed = drop->seed; d.step = drop->step; d.row_offset = drop->row_offset; d.layer = layer;
+  return d;
+}
+
+// ------------------------------------------------------------- forward -----
+static int forward_impl(const blh_model_desc* d, hipStream_t s, const float* params,
+                        float* bn_running, int64_t* nbt, const float* x, const blh_dropout* drop,
+                        float momentum, const Workspace& ws, float* pred, int64_t batch,
+                        bool train, const float* target, float mse_scale, float* loss_part,
+                        int* loss_nparts) {
+  const ArenaLayout L = make_layout(d);
+  const int nh = (int)L.heavy.size();
+  const int W = d->width;
+  const int tiles_m = (int)ceil_div(batch, 128);
+  for (int i = 0; i < nh; ++i) {
+    const HeavyOffsets& h = L.heavy[i];
+    const float* in = (i == 0) ? x : ws.A[i - 1];
+    GemmParams g{};
+    g.A = in; g.lda = h.fan_in;
+    g.B = params + h.w; g.ldb = h.fan_in;
+    g.C = ws.Z[i]; g.ldc = W;
+    g.M = (int)batch; g.N = W; g.K = h.fan_in; g.k_per_split = h.fan_in;
+    g.bias = params + h.b;
+    g.stat_part = ws.stat_part;
+    BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, train ? EPI_BIAS_STATS : EPI_BIAS, g, 1));
+    // second stage of a block adds the block input (model/bilinear.py:36-38)
+    const float* skip = (i >= 2 && (i % 2) == 0) ? ws.A[i - 2] : nullptr;
+    float* rm = bn_running + ((int64_t)i * 2 + 0) * W;
+    float* rv = bn_running + ((int64_t)i * 2 + 1) * W;
+    if (train) {
+      float* sv = ws.bn_saved[i];
+      BLH_TRY(launch_bn_fwd_finalize(s, ws.stat_part, tiles_m, 128, batch, W, params + h.gamma,
+                                     params + h.beta, rm, rv, nbt + i, momentum, sv, sv + W,
+                                     sv + 2 * W, sv + 3 * W));
+      BLH_TRY(launch_bn_apply_train(s, ws.Z[i], sv + 2 * W, sv + 3 * W, skip, ws.A[i], batch, W,
+                                    layer_drop(drop, i, batch, W), nbt + i));
+    } else {
+      BLH_TRY(launch_bn_apply_eval(s, ws.Z[i], params + h.gamma, params + h.beta, rm, rv, skip,
+                                   ws.A[i], batch, W));
+    }
+  }
+  GemmParams g{};
+  g.A = ws.A[nh - 1]; g.lda = W;
+  g.B = params + L.dec_w; g.ldb = W;
+  g.C = pred; g.ldc = d->out_features;
+  g.M = (int)batch; g.N = d->out_features; g.K = W; g.k_per_split = W;
+  g.bias = params + L.dec_b;
+  if (target) {
+    g.target = target; g.ldt = d->out_features;
+    g.dpred = ws.dpred; g.lddp = d->out_features;
+    g.mse_scale = mse_scale; g.loss_part = loss_part;
+    *loss_nparts = gemm_grid_blocks(TILE_128x64, (int)batch, d->out_features);
+    if (*loss_nparts > 4096) return BLH_ERR_SHAPE;
+    return launch_gemm(s, TILE_128x64, ROWK, ROWK, EPI_MSE, g, 1);
+  }
+  return launch_gemm(s, TILE_128x64, ROWK, ROWK, EPI_BIAS, g, 1);
+}
+
+// ------------------------------------------------------------ backward -----
+static int wgrad(hipStream_t s, GemmTile tile, const float* dZ, int64_t ld_dz, int M,
+                 const float* act, int64_t ld_act, int N, int64_t batch, int64_t tiles,
+                 float* slabs, float* out) {
+  const Splits sp = pick_splits(batch, tiles);
+  GemmParams g{};
+  g.A = dZ; g.lda = ld_dz;
+  g.B = act; g.ldb = ld_act;
+  g.M = M; g.N = N; g.K = (int)batch; g.k_per_split = sp.k_per;
+  g.ldc = N;
+  if (sp.splits == 1) {
+    g.C = out; g.c_split_stride = 0;
+    return launch_gemm(s, tile, KROW, KROW, EPI_STORE, g, 1);
+  }
+  g.C = slabs; g.c_split_stride = (int64_t)M * N;
+  BLH_TRY(launch_gemm(s, tile, KROW, KROW, EPI_STORE, g, sp.splits));
+  return launch_sum_slabs(s, slabs, (int64_t)M * N, sp.splits, out);
+}
+
+static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* params,
+                         const float* x, const blh_dropout* drop, const Workspace& ws,
+                         const float* dpred, float* grads, int64_t batch,
+                         blh_grad_ready_fn on_ready, void* user) {
+  const ArenaLayout L = make_layout(d);
+  const int nh = (int)L.heavy.size();
+  const int W = d->width;
+  const int OF = d->out_features;
+  const int chunks = ew_num_row_chunks(batch);
+
+  // decode: dW = dP^T A_last, db = colsum(dP), dA_last = dP W_d
+  BLH_TRY(wgrad(s, TILE_64x128, dpred, OF, OF, ws.A[nh - 1], W, W, batch,
+                ceil_div(OF, 64) * ceil_div(W, 128), ws.slabs, grads + L.dec_w));
+  BLH_TRY(launch_colsum(s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
+  if (on_ready) on_ready(user, L.dec_w, L.total - L.dec_w);
+  {
+    GemmParams g{};
+    g.A = dpred; g.lda = OF;
+    g.B = params + L.dec_w; g.ldb = W;
+    g.C = ws.G0; g.ldc = W;
+    g.M = (int)batch; g.N = W; g.K = OF; g.k_per_split = OF;
+    BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, 1));
+  }
+
+  for (int i = nh - 1; i >= 0; --i) {
+    const HeavyOffsets& h = L.heavy[i];
+    // gradient w.r.t. this stage's output: block boundaries live in G0, the middle of a
+    // block in G1 (stage i odd = first of a block: its output feeds only stage i+1)
+    const bool first_of_block = (i >= 1) && (i % 2 == 1);
+    const float* dA = first_of_block ? ws.G1 : ws.G0;
+    const float* sv = ws.bn_saved[i];
+    const DropoutSrc ds = layer_drop(drop, i, batch, W);
+    BLH_TRY(launch_bn_bwd_reduce(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W, ws.bn_part,
+                                 batch, W, ds));
+    BLH_TRY(launch_bn_bwd_finalize(s, ws.bn_part, chunks, W, grads + h.gamma, grads + h.beta));
+    BLH_TRY(launch_bn_bwd_apply(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W,
+                                params + h.gamma, grads + h.gamma, grads + h.beta, ws.dZ,
+                                ws.dz_colsum_part, batch, W, ds));
+    // Linear: db = colsum(dZ); dW = dZ^T a_in; d a_in = dZ W
+    BLH_TRY(launch_colreduce(s, ws.dz_colsum_part, chunks, W, W, grads + h.b));
+    if (i == 0) {
+      BLH_TRY(wgrad(s, TILE_128x32, ws.dZ, W, W, x, d->in_features, d->in_features, batch,
+                    ceil_div(W, 128) * ceil_div(d->in_features, 32), ws.slabs, grads + h.w));
+    } else {
+      BLH_TRY(wgrad(s, TILE_128x128, ws.dZ, W, W, ws.A[i - 1], W, W, batch,
+                    ceil_div(W, 128) * ceil_div(W, 128), ws.slabs, grads + h.w));
+      GemmParams g{};
+      g.A = ws.dZ; g.lda = W;
+      g.B = params + h.w; g.ldb = W;
+      g.M = (int)batch; g.N = W; g.K = W; g.k_per_split = W;
+      g.ldc = W;
+      if (first_of_block) {
+        // d(block input) = dZ W + d(block output)   (skip path), in place in G0
+        g.C = ws.G0; g.addend = ws.G0; g.ldadd = W;
+        BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_ADD, g, 1));
+      } else {
+        g.C = ws.G1;
+        BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, 1));
+      }
+    }
+    if (on_ready) {
+      const int64_t end = (i + 1 < nh) ? L.heavy[i + 1].w : L.dec_w;
+      on_ready(user, h.w, end - h.w);
+    }
+  }
+  return BLH_OK;
+}
+
+}  // namespace blh
+
+using namespace blh;
+
+// =============================================================== C ABI =======
+extern "C" {
+
+const char* blh_status_string(int status) {
+  switch (status) {
+    case BLH_OK: return "ok";
+    case BLH_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case BLH_ERR_SHAPE: return "unsupported shape";
+    case BLH_ERR_HIP: return "HIP runtime error";
+    case BLH_ERR_WORKSPACE: return "workspace too small";
+  }
+  return "unknown status";
+}
+
+int blh_last_hip_error(void) { return g_last_hip_error; }
+int blh_abi_version(void) { return BLH_ABI_VERSION; }
+
+int32_t blh_num_heavy(const blh_model_desc* d) { return d ? 1 + 2 * d->num_blocks : 0; }
+
+int64_t blh_param_arena_floats(const blh_model_desc* d) {
+  if (check_desc(d) != BLH_OK) return check_desc(d);
+  return make_layout(d).total;
+}
+
+int32_t blh_num_param_tensors(const blh_model_desc* d) {
+  if (check_desc(d) != BLH_OK) return check_desc(d);
+  return (int32_t)make_layout(d).tensors.size();
+}
+
+int blh_param_tensor_info(const blh_model_desc* d, int32_t index, char* name, int32_t name_cap,
+                          int64_t* offset_floats, int64_t* rows, int64_t* cols) {
+  BLH_TRY(check_desc(d));
+  const ArenaLayout L = make_layout(d);
+  if (index < 0 || index >= (int32_t)L.tensors.size() || !name || name_cap <= 0)
+    return BLH_ERR_INVALID_ARGUMENT;
+  const TensorInfo& t = L.tensors[index];
+  snprintf(name, (size_t)name_cap, "%s", t.name);
+  if (offset_floats) *offset_floats = t.offset;
+  if (rows) *rows = t.rows;
+  if (cols) *cols = t.cols;
+  return BLH_OK;
+}
+
+int64_t blh_bn_running_floats(const blh_model_desc* d) {
+  if (check_desc(d) != BLH_OK) return check_desc(d);
+  return (int64_t)(1 + 2 * d->num_blocks) * 2 * d->width;
+}
+
+int64_t blh_workspace_bytes(const blh_model_desc* d, int64_t batch) {
+  if (check_desc(d) != BLH_OK) return check_desc(d);
+  if (batch <= 0) return BLH_ERR_INVALID_ARGUMENT;
+  return carve(d, batch, nullptr).bytes;
+}
+
+static int check_common(const blh_model_desc* d, const void* ws, int64_t ws_bytes, int64_t batch) {
+  BLH_TRY(check_desc(d));
+  if (batch <= 0 || batch > (1 << 30)) return BLH_ERR_INVALID_ARGUMENT;
+  if (!ws || ((uintptr_t)ws % WS_ALIGN) != 0) return BLH_ERR_INVALID_ARGUMENT;
+  if (ws_bytes < carve(d, batch, nullptr).bytes) return BLH_ERR_WORKSPACE;
+  return BLH_OK;
+}
+
+static int check_drop(const blh_dropout* drop) {
+  if (!drop) return BLH_ERR_INVALID_ARGUMENT;
+  if (!drop->keep_mask && (drop->row_offset % 32) != 0) return BLH_ERR_SHAPE;
+  return BLH_OK;
+}
+
+int blh_forward_train(const blh_model_desc* d, void* stream, const float* params,
+                      float* bn_running, int64_t* bn_nbt, const float* x,
+                      const blh_dropout* drop, float momentum, void* workspace,
+                      int64_t workspace_bytes, float* pred, int64_t batch) {
+  BLH_TRY(check_common(d, workspace, workspace_bytes, batch));
+  BLH_TRY(check_drop(drop));
+  if (!params || !bn_running || !bn_nbt || !x || !pred) return BLH_ERR_INVALID_ARGUMENT;
+  if (batch < 2) return BLH_ERR_SHAPE;   // BatchNorm1d needs > 1 value per channel in training
+  const Workspace ws = carve(d, batch, workspace);
+  return forward_impl(d, (hipStream_t)stream, params, bn_running, bn_nbt, x, drop, momentum, ws,
+                      pred, batch, true, nullptr, 0.f, nullptr, nullptr);
+}
+
+int blh_forward_eval(const blh_model_desc* d, void* stream, const float* params,
+                     const float* bn_running, const float* x, void* workspace,
+                     int64_t workspace_bytes, float* pred, int64_t batch) {
+  BLH_TRY(check_common(d, workspace, workspace_bytes, batch));
+  if (!params || !bn_running || !x || !pred) return BLH_ERR_INVALID_ARGUMENT;
+  const Workspace ws = carve(d, batch, workspace);
+  blh_dropout none{nullptr, 0, 0, 0};
+  return forward_impl(d, (hipStream_t)stream, params, const_cast<float*>(bn_running), nullptr, x,
+                      &none, 0.f, ws, pred, batch, false, nullptr, 0.f, nullptr, nullptr);
+}
+
+int blh_mse_loss_grad(void* stream, const float* pred, const float* target, int64_t batch,
+                      int64_t out_features, double loss_denominator, float grad_scale,
+                      float* loss_out, float* dpred, void* workspace, int64_t workspace_bytes) {
+  if (!pred || !target || !loss_out || !dpred || !workspace) return BLH_ERR_INVALID_ARGUMENT;
+  if (batch <= 0 || out_features <= 0 || loss_denominator <= 0) return BLH_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < SCRATCH_BYTES) return BLH_ERR_WORKSPACE;
+  const Scratch sc = carve_scratch(workspace);
+  int nparts = 0;
+  const float scale = (float)(2.0 * (double)grad_scale / loss_denominator);
+  BLH_TRY(launch_mse((hipStream_t)stream, pred, target, batch * out_features, scale, dpred,
+                     sc.loss_part, &nparts));
+  return launch_loss_finalize((hipStream_t)stream, sc.loss_part, nparts, loss_denominator,
+                              loss_out);
+}
+
+int blh_backward(const blh_model_desc* d, void* stream, const float* params, const float* x,
+                 const blh_dropout* drop, void* workspace, int64_t workspace_bytes,
+                 const float* dpred, float* grads, int64_t batch, blh_grad_ready_fn on_ready,
+                 void* user) {
+  BLH_TRY(check_common(d, workspace, workspace_bytes, batch));
+  BLH_TRY(check_drop(drop));
+  if (!params || !x || !dpred || !grads) return BLH_ERR_INVALID_ARGUMENT;
+  const Workspace ws = carve(d, batch, workspace);
+  return backward_impl(d, (hipStream_t)stream, params, x, drop, ws, dpred, grads, batch,
+                       on_ready, user);
+}
+
+int blh_clip_adam_step(void* stream, float* params, float* grads, float* exp_avg,
+                       float* exp_avg_sq, int64_t count, const blh_adam_hyper* hyper,
+                       void* workspace, int64_t workspace_bytes, float* stats_out) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !hyper || !workspace || count <= 0)
+    return BLH_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < SCRATCH_BYTES) return BLH_ERR_WORKSPACE;
+  const Scratch sc = carve_scratch(workspace);
+  int nparts = 0;
+  BLH_TRY(launch_sumsq((hipStream_t)stream, grads, count, sc.sumsq_part, &nparts));
+  return launch_clip_adam((hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, count, *hyper,
+                          sc.sumsq_part, nparts, stats_out);
+}
+
+int blh_clip_grad_norm(void* stream, float* grads, int64_t count, float max_norm, void* workspace,
+                       int64_t workspace_bytes, float* stats_out) {
+  if (!grads || !workspace || count <= 0 || !(max_norm > 0.f)) return BLH_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < SCRATCH_BYTES) return BLH_ERR_WORKSPACE;
+  const Scratch sc = carve_scratch(workspace);
+  int nparts = 0;
+  BLH_TRY(launch_sumsq((hipStream_t)stream, grads, count, sc.sumsq_part, &nparts));
+  return launch_clip_scale((hipStream_t)stream, grads, count, max_norm, sc.sumsq_part, nparts,
+                           stats_out);
+}
+
+int blh_train_step(const blh_model_desc* d, void* stream, float* params, float* grads,
+                   float* exp_avg, float* exp_avg_sq, float* bn_running, int64_t* bn_nbt,
+                   const float* x, const float* target, const blh_dropout* drop, float momentum,
+                   const blh_adam_hyper* hyper, void* workspace, int64_t workspace_bytes,
+                   float* pred, float* loss_out, float* stats_out, int64_t batch) {
+  BLH_TRY(check_common(d, workspace, workspace_bytes, batch));
+  BLH_TRY(check_drop(drop));
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !bn_running || !bn_nbt || !x || !target ||
+      !hyper || !pred || !loss_out)
+    return BLH_ERR_INVALID_ARGUMENT;
+  if (batch < 2) return BLH_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const Workspace ws = carve(d, batch, workspace);
+  const double denom = (double)batch * d->out_features;
+  int nparts = 0;
+  BLH_TRY(forward_impl(d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
+                       target, (float)(2.0 / denom), ws.loss_part, &nparts));
+  BLH_TRY(launch_loss_finalize(s, ws.loss_part, nparts, denom, loss_out));
+  BLH_TRY(backward_impl(d, s, params, x, drop, ws, ws.dpred, grads, batch, nullptr, nullptr));
+  const int64_t count = make_layout(d).total;
+  int np = 0;
+  BLH_TRY(launch_sumsq(s, grads, count, ws.sumsq_part, &np));
+  return launch_clip_adam(s, params, grads, exp_avg, exp_avg_sq, count, *hyper, ws.sumsq_part, np,
+                          stats_out);
+}
+
+int blh_gemm_f32(void* stream, const float* A, int64_t lda, int32_t a_kmajor, const float* B,
+                 int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc, int64_t M, int64_t N,
+                 int64_t K, int32_t splits, const float* bias, const float* addend,
+                 int64_t ldadd) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || splits < 1) return BLH_ERR_INVALID_ARGUMENT;
+  if (bias && addend) return BLH_ERR_INVALID_ARGUMENT;
+  if (splits > 1 && (bias || addend)) return BLH_ERR_INVALID_ARGUMENT;
+  GemmParams g{};
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.M = (int)M; g.N = (int)N; g.K = (int)K;
+  g.k_per_split = (splits > 1) ? (int)round_up(ceil_div(K, splits), 32) : (int)K;
+  if (splits > 1 && (int64_t)g.k_per_split * (splits - 1) >= K) return BLH_ERR_SHAPE;
+  g.c_split_stride = M * ldc;
+  g.bias = bias; g.addend = addend; g.ldadd = ldadd;
+  const int epi = bias ? EPI_BIAS : (addend ? EPI_ADD : EPI_STORE);
+  GemmTile tile = TILE_128x128;
+  if (N <= 32) tile = TILE_128x32;
+  else if (N <= 64) tile = TILE_128x64;
+  else if (M <= 64) tile = TILE_64x128;
+  return launch_gemm((hipStream_t)stream, tile, a_kmajor ? KROW : ROWK, b_kmajor ? KROW : ROWK,
+                     epi, g, splits);
+}
+
+int blh_linear_fwd_stats(void* stream, const float* A, const float* W, const float* bias, float* Z,
+                         float* stat_part, int64_t M, int64_t N, int64_t K) {
+  if (!A || !W || !bias || !Z || !stat_part || M <= 0 || N <= 0 || K <= 0)
+    return BLH_ERR_INVALID_ARGUMENT;
+  GemmParams g{};
+  g.A = A; g.lda = K; g.B = W; g.ldb = K; g.C = Z; g.ldc = N;
+  g.M = (int)M; g.N = (int)N; g.K = (int)K; g.k_per_split = (int)K;
+  g.bias = bias; g.stat_part = stat_part;
+  return launch_gemm((hipStream_t)stream, TILE_128x128, ROWK, ROWK, EPI_BIAS_STATS, g, 1);
+}
+
+int blh_dropout_mask(void* stream, const blh_dropout* drop, int32_t layer, int64_t batch,
+                     int32_t width, uint8_t* keep_out) {
+  if (!drop || !keep_out || batch <= 0 || width <= 0 || width % 4 != 0 || drop->keep_mask)
+    return BLH_ERR_INVALID_ARGUMENT;
+  BLH_TRY(check_drop(drop));
+  DropoutSrc d{nullptr, drop->seed, drop->step, drop->row_offset, layer};
+  return launch_dropout_mask((hipStream_t)stream, keep_out, batch, width, d);
+}
+
+int blh_sum_slabs(void* stream, const float* slabs, int64_t count, int32_t splits, float* out) {
+  if (!slabs || !out || count <= 0 || splits < 1) return BLH_ERR_INVALID_ARGUMENT;
+  return launch_sum_slabs((hipStream_t)stream, slabs, count, splits, out);
+}
+
+}  // extern "C"

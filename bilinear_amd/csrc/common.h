@@ -1,0 +1,129 @@
+// Shared declarations of the native library (host side).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bilinear_hip.h"
+
+namespace blh {
+
+extern thread_local int g_last_hip_error;
+
+#define BLH_HIP_TRY(expr)                          \
+  do {                                             \
+    hipError_t _e = (expr);                        \
+    if (_e != hipSuccess) {                        \
+      ::blh::g_last_hip_error = (int)_e;           \
+      return BLH_ERR_HIP;                          \
+    }                                              \
+  } while (0)
+
+#define BLH_TRY(expr)            \
+  do {                           \
+    int _s = (expr);             \
+    if (_s != BLH_OK) return _s; \
+  } while (0)
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
+
+// ---------------------------------------------------------------- GEMM -----
+enum Layout : int { ROWK = 0, KROW = 1 };
+enum Epilogue : int {
+  EPI_STORE = 0,       // C = acc                         (split-K slabs, plain)
+  EPI_BIAS = 1,        // C = acc + bias[n]
+  EPI_BIAS_STATS = 2,  // C = acc + bias[n]; per-tile column (mean, M2) partials
+  EPI_ADD = 3,         // C = acc + addend[m][n]
+  EPI_MSE = 4          // C = acc + bias; dpred = scale*(C - target); loss partial
+};
+
+struct GemmParams {
+  const float* A;
+  const float* B;
+  float* C;
+  int64_t lda, ldb, ldc;
+  int M, N, K;
+  int k_per_split;          // multiple of 32 (or == K when splits == 1)
+  int64_t c_split_stride;   // floats between slabs
+  const float* bias;        // [N]
+  const float* addend;      // [M][ldadd]
+  int64_t ldadd;
+  float* stat_part;         // [tiles_m][2][N]  (mean, M2) of each BM-row tile
+  const float* target;      // [M][ldt]
+  int64_t ldt;
+  float* dpred;             // [M][lddp]
+  int64_t lddp;
+  float mse_scale;
+  float* loss_part;         // [gridDim.x] partial sums of squared error
+};
+
+enum GemmTile : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_128x32 = 3 };
+
+// number of BM-row tiles the EPI_BIAS_STATS epilogue produces partials for
+int gemm_stat_tile_rows(GemmTile tile);
+int gemm_grid_blocks(GemmTile tile, int M, int N);
+int launch_gemm(hipStream_t s, GemmTile tile, int la, int lb, int epi, const GemmParams& p,
+                int splits);
+
+// ---------------------------------------------------------- elementwise ----
+struct DropoutSrc {
+  const uint8_t* keep;   // [B][W] for this layer, or nullptr -> Philox
+  uint64_t seed, step;
+  int64_t row_offset;
+  int layer;
+};
+
+static constexpr int EW_COLS_PER_BLOCK = 1024;   // 256 threads x float4
+int ew_row_chunk(int64_t batch);                 // rows handled by one block (multiple of 16)
+int ew_num_row_chunks(int64_t batch);
+
+// forward BN: merge per-tile (mean, M2) -> batch mean / invstd, scale/shift, running stats
+int launch_bn_fwd_finalize(hipStream_t s, const float* stat_part, int tiles, int tile_rows,
+                           int64_t batch, int W, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, int64_t* nbt,
+                           float momentum, float* saved_mean, float* saved_invstd,
+                           float* scale, float* shift);
+// A = dropout(relu(Z*scale+shift)) (+ skip)
+// (nbt, if not null, is incremented once: num_batches_tracked of this BN layer)
+int launch_bn_apply_train(hipStream_t s, const float* Z, const float* scale, const float* shift,
+                          const float* skip, float* A, int64_t batch, int W,
+                          const DropoutSrc& drop, int64_t* nbt);
+// eval: scale/shift from running stats, no dropout
+int launch_bn_apply_eval(hipStream_t s, const float* Z, const float* gamma, const float* beta,
+                         const float* running_mean, const float* running_var,
+                         const float* skip, float* A, int64_t batch, int W);
+// backward pass 1: partial column sums of dY and dY*zhat
+int launch_bn_bwd_reduce(hipStream_t s, const float* dA, const float* Z, const float* scale,
+                         const float* shift, const float* mean, const float* invstd,
+                         float* part, int64_t batch, int W, const DropoutSrc& drop);
+// finalize: dgamma, dbeta (into the grad arena) from partials
+int launch_bn_bwd_finalize(hipStream_t s, const float* part, int chunks, int W, float* dgamma,
+                           float* dbeta);
+// backward pass 2: dZ = gamma*invstd*(dY - dbeta/B - zhat*dgamma/B); partial column sums of dZ
+int launch_bn_bwd_apply(hipStream_t s, const float* dA, const float* Z, const float* scale,
+                        const float* shift, const float* mean, const float* invstd,
+                        const float* gamma, const float* dgamma, const float* dbeta, float* dZ,
+                        float* dz_colsum_part, int64_t batch, int W, const DropoutSrc& drop);
+// out[c] = sum_s in[s][c] for c < ncols (rows of `ld` floats), fp64 accumulation
+int launch_colreduce(hipStream_t s, const float* in, int S, int64_t ld, int ncols, float* out);
+// out[i] = sum_s in[s][i]   (slabs of `count` floats)
+int launch_sum_slabs(hipStream_t s, const float* slabs, int64_t count, int splits, float* out);
+// out[c] = sum over rows of X[rows][ld] columns [0,cols)
+int launch_colsum(hipStream_t s, const float* X, int64_t rows, int cols, int64_t ld, float* part,
+                  float* out);
+// loss = sum(part[0..n)) / denom
+int launch_loss_finalize(hipStream_t s, const float* part, int n, double denom, float* loss_out);
+// dpred = scale*(pred-target), loss partials (stand-alone MSE for the autograd path)
+int launch_mse(hipStream_t s, const float* pred, const float* target, int64_t n, float scale,
+               float* dpred, float* part, int* nparts);
+// optimiser
+int launch_sumsq(hipStream_t s, const float* g, int64_t count, double* part, int* nparts);
+int launch_clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count,
+                     const blh_adam_hyper& h, const double* sumsq_part, int nparts,
+                     float* stats_out);
+int launch_clip_scale(hipStream_t s, float* g, int64_t count, float max_norm,
+                      const double* sumsq_part, int nparts, float* stats_out);
+int launch_dropout_mask(hipStream_t s, uint8_t* out, int64_t batch, int W, const DropoutSrc& drop);
+static constexpr int SUMSQ_MAX_PARTS = 1024;
+
+}  // namespace blh

@@ -1,0 +1,615 @@
+// HBM-bound kernels of the lifter step: BatchNorm statistics / apply / backward
+// fused with ReLU + Dropout + residual add, reductions, MSE, fused clip + Adam.
+// (/root/reference/model/bilinear.py:10-12,38; train_bilinear.py:78-83.)
+//
+// Layout: every [B,W] tensor is row-major; a thread owns 4 consecutive columns
+// (one float4 = 16 B per lane, a wave reads 1 KiB contiguous) and walks down the
+// rows of its row-chunk, so column reductions need no cross-thread traffic and a
+// Philox call (128 keep-bits = 32 rows x 4 columns) is shared by a whole patch.
+#include "common.h"
+#include "philox.h"
+
+namespace blh {
+
+static constexpr int EW_THREADS = 256;
+static constexpr float BN_EPS = 1e-5f;
+
+int ew_row_chunk(int64_t batch) {
+  // <= 512 row chunks; 16 rows minimum (half a Philox patch), multiples of 32 above
+  if (batch <= 16 * 512) return 16;
+  return (int)round_up(ceil_div(batch, 512), 32);
+}
+int ew_num_row_chunks(int64_t batch) { return (int)ceil_div(batch, ew_row_chunk(batch)); }
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+struct DropState {
+  Philox128 patch;
+};
+
+// keep nibble (bit i = keep column col+i) for row r
+__device__ __forceinline__ uint32_t keep_nibble(const DropoutSrc& d, DropState& st, int64_t r,
+                                                int col, int W, bool first) {
+  if (d.keep) {
+    const uchar4 k = *reinterpret_cast<const uchar4*>(d.keep + r * (int64_t)W + col);
+    return (k.x ? 1u : 0u) | (k.y ? 2u : 0u) | (k.z ? 4u : 0u) | (k.w ? 8u : 0u);
+  }
+  const int64_t grow = r + d.row_offset;
+  if (first || (grow & 31) == 0) st.patch = dropout_patch(d.seed, d.step, d.layer, grow, col);
+  return patch_nibble(st.patch, (int)(grow & 31));
+}
+
+// ---------------------------------------------------------------------------
+// forward BN finalize: merge per-tile (mean, M2) partials (Chan et al.) into the
+// batch mean / biased variance; emit scale = gamma*invstd, shift = beta - mean*scale;
+// update running stats (unbiased variance, PyTorch BatchNorm1d semantics).
+// block = 32 columns x 8 tile-slices.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
+    const float* __restrict__ part, int tiles, int tile_rows, int64_t batch, int W,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+    float* running_var, const int64_t* nbt, float momentum, float* saved_mean,
+    float* saved_invstd, float* scale, float* shift) {
+  __shared__ double red[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cl;
+  const bool ok = col < W;
+  double acc = 0.0;
+  if (ok)
+    for (int t = sl; t < tiles; t += 8) {
+      const double n = (double)min((int64_t)tile_rows, batch - (int64_t)t * tile_rows);
+      acc += n * (double)part[((int64_t)t * 2 + 0) * W + col];
+    }
+  red[sl][cl] = acc;
+  __syncthreads();
+  double mean = 0.0;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) mean += red[s][cl];
+  mean /= (double)batch;
+  __syncthreads();
+  acc = 0.0;
+  if (ok)
+    for (int t = sl; t < tiles; t += 8) {
+      const double n = (double)min((int64_t)tile_rows, batch - (int64_t)t * tile_rows);
+      const double d = (double)part[((int64_t)t * 2 + 0) * W + col] - mean;
+      acc += (double)part[((int64_t)t * 2 + 1) * W + col] + n * d * d;
+    }
+  red[sl][cl] = acc;
+  __syncthreads();
+  if (sl == 0 && ok) {
+    double m2 = 0.0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) m2 += red[s][cl];
+    const double var = m2 / (double)batch;
+    const float invstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
+    const float mu = (float)mean;
+    const float sc = gamma[col] * invstd;
+    saved_mean[col] = mu;
+    saved_invstd[col] = invstd;
+    scale[col] = sc;
+    shift[col] = beta[col] - mu * sc;
+    const double f = (momentum >= 0.f) ? (double)momentum : 1.0 / (double)(nbt[0] + 1);
+    const double unbiased = m2 / (double)(batch > 1 ? batch - 1 : 1);
+    running_mean[col] = (float)((1.0 - f) * (double)running_mean[col] + f * mean);
+    running_var[col] = (float)((1.0 - f) * (double)running_var[col] + f * unbiased);
+  }
+}
+
+int launch_bn_fwd_finalize(hipStream_t s, const float* stat_part, int tiles, int tile_rows,
+                           int64_t batch, int W, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, int64_t* nbt,
+                           float momentum, float* saved_mean, float* saved_invstd, float* scale,
+                           float* shift) {
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((unsigned)ceil_div(W, 32)), dim3(256), 0, s,
+                     stat_part, tiles, tile_rows, batch, W, gamma, beta, running_mean,
+                     running_var, nbt, momentum, saved_mean, saved_invstd, scale, shift);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// A = dropout(relu(Z*scale + shift)) (+ skip)
+// ---------------------------------------------------------------------------
+template <bool TRAIN>
+__global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(
+    const float* __restrict__ Z, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ running_mean, const float* __restrict__ running_var,
+    const float* __restrict__ skip, float* __restrict__ A, int64_t batch, int W, int row_chunk,
+    DropoutSrc drop, int64_t* nbt) {
+  const int col = blockIdx.x * EW_COLS_PER_BLOCK + threadIdx.x * 4;
+  if (TRAIN && nbt && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) nbt[0] += 1;
+  if (col >= W) return;
+  float4 sc, sh;
+  if (TRAIN) {
+    sc = ld4(scale + col);
+    sh = ld4(shift + col);
+  } else {
+    const float4 g = ld4(gamma + col), b = ld4(beta + col), rm = ld4(running_mean + col),
+                 rv = ld4(running_var + col);
+    sc.x = g.x * (1.0f / sqrtf(rv.x + BN_EPS)); sc.y = g.y * (1.0f / sqrtf(rv.y + BN_EPS));
+    sc.z = g.z * (1.0f / sqrtf(rv.z + BN_EPS)); sc.w = g.w * (1.0f / sqrtf(rv.w + BN_EPS));
+    sh.x = b.x - rm.x * sc.x; sh.y = b.y - rm.y * sc.y;
+    sh.z = b.z - rm.z * sc.z; sh.w = b.w - rm.w * sc.w;
+  }
+  const int64_t r0 = (int64_t)blockIdx.y * row_chunk;
+  const int64_t r1 = min(batch, r0 + row_chunk);
+  DropState ds;
+#pragma unroll 4
+  for (int64_t r = r0; r < r1; ++r) {
+    const float4 z = ld4(Z + r * W + col);
+    float4 a;
+    a.x = fmaxf(fmaf(z.x, sc.x, sh.x), 0.f); a.y = fmaxf(fmaf(z.y, sc.y, sh.y), 0.f);
+    a.z = fmaxf(fmaf(z.z, sc.z, sh.z), 0.f); a.w = fmaxf(fmaf(z.w, sc.w, sh.w), 0.f);
+    if (TRAIN) {
+      const uint32_t nib = keep_nibble(drop, ds, r, col, W, r == r0);
+      a.x = (nib & 1u) ? a.x * 2.f : 0.f; a.y = (nib & 2u) ? a.y * 2.f : 0.f;
+      a.z = (nib & 4u) ? a.z * 2.f : 0.f; a.w = (nib & 8u) ? a.w * 2.f : 0.f;
+    }
+    if (skip) {
+      const float4 k = ld4(skip + r * W + col);
+      a.x += k.x; a.y += k.y; a.z += k.z; a.w += k.w;
+    }
+    st4(A + r * W + col, a);
+  }
+}
+
+static dim3 ew_grid(int64_t batch, int W) {
+  return dim3((unsigned)ceil_div(W, EW_COLS_PER_BLOCK), (unsigned)ew_num_row_chunks(batch));
+}
+
+int launch_bn_apply_train(hipStream_t s, const float* Z, const float* scale, const float* shift,
+                          const float* skip, float* A, int64_t batch, int W,
+                          const DropoutSrc& drop, int64_t* nbt) {
+  hipLaunchKernelGGL(bn_apply_kernel<true>, ew_grid(batch, W), dim3(EW_THREADS), 0, s, Z, scale,
+                     shift, nullptr, nullptr, nullptr, nullptr, skip, A, batch, W,
+                     ew_row_chunk(batch), drop, nbt);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+int launch_bn_apply_eval(hipStream_t s, const float* Z, const float* gamma, const float* beta,
+                         const float* running_mean, const float* running_var, const float* skip,
+                         float* A, int64_t batch, int W) {
+  DropoutSrc none{nullptr, 0, 0, 0, 0};
+  hipLaunchKernelGGL(bn_apply_kernel<false>, ew_grid(batch, W), dim3(EW_THREADS), 0, s, Z,
+                     nullptr, nullptr, gamma, beta, running_mean, running_var, skip, A, batch, W,
+                     ew_row_chunk(batch), none, nullptr);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// backward pass 1: dY = dA * 2*keep * [y>0]; per-chunk column sums of dY*zhat, dY
+// part layout [chunk][2][W]: row 0 -> dgamma partial, row 1 -> dbeta partial
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
+    const float* __restrict__ dA, const float* __restrict__ Z, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, float* __restrict__ part, int64_t batch, int W,
+    int row_chunk, DropoutSrc drop) {
+  const int col = blockIdx.x * EW_COLS_PER_BLOCK + threadIdx.x * 4;
+  if (col >= W) return;
+  const float4 sc = ld4(scale + col), sh = ld4(shift + col), mu = ld4(mean + col),
+               is = ld4(invstd + col);
+  const int64_t r0 = (int64_t)blockIdx.y * row_chunk;
+  const int64_t r1 = min(batch, r0 + row_chunk);
+  float4 sg = make_float4(0, 0, 0, 0), sb = make_float4(0, 0, 0, 0);
+  DropState ds;
+#pragma unroll 4
+  for (int64_t r = r0; r < r1; ++r) {
+    const float4 z = ld4(Z + r * W + col);
+    const float4 g = ld4(dA + r * W + col);
+    const uint32_t nib = keep_nibble(drop, ds, r, col, W, r == r0);
+    float4 dy;
+    dy.x = ((nib & 1u) && (fmaf(z.x, sc.x, sh.x) > 0.f)) ? g.x * 2.f : 0.f;
+    dy.y = ((nib & 2u) && (fmaf(z.y, sc.y, sh.y) > 0.f)) ? g.y * 2.f : 0.f;
+    dy.z = ((nib & 4u) && (fmaf(z.z, sc.z, sh.z) > 0.f)) ? g.z * 2.f : 0.f;
+    dy.w = ((nib & 8u) && (fmaf(z.w, sc.w, sh.w) > 0.f)) ? g.w * 2.f : 0.f;
+    sb.x += dy.x; sb.y += dy.y; sb.z += dy.z; sb.w += dy.w;
+    sg.x += dy.x * ((z.x - mu.x) * is.x); sg.y += dy.y * ((z.y - mu.y) * is.y);
+    sg.z += dy.z * ((z.z - mu.z) * is.z); sg.w += dy.w * ((z.w - mu.w) * is.w);
+  }
+  st4(part + ((int64_t)blockIdx.y * 2 + 0) * W + col, sg);
+  st4(part + ((int64_t)blockIdx.y * 2 + 1) * W + col, sb);
+}
+
+int launch_bn_bwd_reduce(hipStream_t s, const float* dA, const float* Z, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, float* part,
+                         int64_t batch, int W, const DropoutSrc& drop) {
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, ew_grid(batch, W), dim3(EW_THREADS), 0, s, dA, Z,
+                     scale, shift, mean, invstd, part, batch, W, ew_row_chunk(batch), drop);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// out[c] = sum_s in[s][c], c < ncols.  block = 32 columns x 8 slices, fp64 sums.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ in, int S,
+                                                        int64_t ld, int ncols,
+                                                        float* __restrict__ out) {
+  __shared__ double red[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cl;
+  double acc = 0.0;
+  if (col < ncols)
+    for (int s = sl; s < S; s += 8) acc += (double)in[(int64_t)s * ld + col];
+  red[sl][cl] = acc;
+  __syncthreads();
+  if (sl == 0 && col < ncols) {
+    double t = 0.0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) t += red[s][cl];
+    out[col] = (float)t;
+  }
+}
+
+int launch_colreduce(hipStream_t s, const float* in, int S, int64_t ld, int ncols, float* out) {
+  hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)ceil_div(ncols, 32)), dim3(256), 0, s, in,
+                     S, ld, ncols, out);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+int launch_bn_bwd_finalize(hipStream_t s, const float* part, int chunks, int W, float* dgamma,
+                           float* dbeta) {
+  // part is [chunks][2][W]; dgamma and dbeta are adjacent in the arena when W % 64 == 0
+  if (dbeta == dgamma + W) return launch_colreduce(s, part, chunks, 2 * (int64_t)W, 2 * W, dgamma);
+  BLH_TRY(launch_colreduce(s, part, chunks, 2 * (int64_t)W, W, dgamma));
+  return launch_colreduce(s, part + W, chunks, 2 * (int64_t)W, W, dbeta);
+}
+
+// ---------------------------------------------------------------------------
+// backward pass 2: dZ = gamma*invstd*(dY - dbeta/B - zhat*dgamma/B)
+// plus per-chunk column sums of dZ (the Linear bias gradient)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
+    const float* __restrict__ dA, const float* __restrict__ Z, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ dgamma,
+    const float* __restrict__ dbeta, float* __restrict__ dZ, float* __restrict__ colsum_part,
+    int64_t batch, int W, int row_chunk, DropoutSrc drop) {
+  const int col = blockIdx.x * EW_COLS_PER_BLOCK + threadIdx.x * 4;
+  if (col >= W) return;
+  const float4 sc = ld4(scale + col), sh = ld4(shift + col), mu = ld4(mean + col),
+               is = ld4(invstd + col);
+  const float inv_b = 1.0f / (float)batch;
+  float4 c1 = ld4(dbeta + col), c2 = ld4(dgamma + col);
+  c1.x *= inv_b; c1.y *= inv_b; c1.z *= inv_b; c1.w *= inv_b;
+  c2.x *= inv_b; c2.y *= inv_b; c2.z *= inv_b; c2.w *= inv_b;
+  const int64_t r0 = (int64_t)blockIdx.y * row_chunk;
+  const int64_t r1 = min(batch, r0 + row_chunk);
+  float4 cs = make_float4(0, 0, 0, 0);
+  DropState ds;
+#pragma unroll 4
+  for (int64_t r = r0; r < r1; ++r) {
+    const float4 z = ld4(Z + r * W + col);
+    const float4 g = ld4(dA + r * W + col);
+    const uint32_t nib = keep_nibble(drop, ds, r, col, W, r == r0);
+    float4 dy, o;
+    dy.x = ((nib & 1u) && (fmaf(z.x, sc.x, sh.x) > 0.f)) ? g.x * 2.f : 0.f;
+    dy.y = ((nib & 2u) && (fmaf(z.y, sc.y, sh.y) > 0.f)) ? g.y * 2.f : 0.f;
+    dy.z = ((nib & 4u) && (fmaf(z.z, sc.z, sh.z) > 0.f)) ? g.z * 2.f : 0.f;
+    dy.w = ((nib & 8u) && (fmaf(z.w, sc.w, sh.w) > 0.f)) ? g.w * 2.f : 0.f;
+    // scale = gamma*invstd
+    o.x = sc.x * (dy.x - c1.x - ((z.x - mu.x) * is.x) * c2.x);
+    o.y = sc.y * (dy.y - c1.y - ((z.y - mu.y) * is.y) * c2.y);
+    o.z = sc.z * (dy.z - c1.z - ((z.z - mu.z) * is.z) * c2.z);
+    o.w = sc.w * (dy.w - c1.w - ((z.w - mu.w) * is.w) * c2.w);
+    cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
+    st4(dZ + r * W + col, o);
+  }
+  st4(colsum_part + (int64_t)blockIdx.y * W + col, cs);
+}
+
+int launch_bn_bwd_apply(hipStream_t s, const float* dA, const float* Z, const float* scale,
+                        const float* shift, const float* mean, const float* invstd,
+                        const float* gamma, const float* dgamma, const float* dbeta, float* dZ,
+                        float* dz_colsum_part, int64_t batch, int W, const DropoutSrc& drop) {
+  (void)gamma;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, ew_grid(batch, W), dim3(EW_THREADS), 0, s, dA, Z, scale,
+                     shift, mean, invstd, dgamma, dbeta, dZ, dz_colsum_part, batch, W,
+                     ew_row_chunk(batch), drop);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// out = sum of `splits` slabs (split-K partial products of the wgrad GEMM)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ slabs,
+                                                        int64_t count, int splits,
+                                                        float* __restrict__ out) {
+  const int64_t n4 = count >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float4 a = ld4(slabs + i * 4);
+    for (int s = 1; s < splits; ++s) {
+      const float4 b = ld4(slabs + (int64_t)s * count + i * 4);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    st4(out + i * 4, a);
+  }
+}
+
+int launch_sum_slabs(hipStream_t s, const float* slabs, int64_t count, int splits, float* out) {
+  if (count % 4 != 0) return BLH_ERR_SHAPE;
+  const int64_t blocks = std::min<int64_t>(ceil_div(count / 4, 256), 2048);
+  hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs, count,
+                     splits, out);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// column sums of a narrow matrix X[rows][ld] (decode bias gradient: 48 columns)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X,
+                                                             int64_t rows, int cols, int64_t ld,
+                                                             int rows_per_block,
+                                                             float* __restrict__ part) {
+  extern __shared__ float4 sred[];   // [slots][cg]
+  const int cg = cols >> 2;
+  const int slots = 256 / cg;
+  const int c = threadIdx.x % cg, slot = threadIdx.x / cg;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(rows, r0 + rows_per_block);
+  float4 a = make_float4(0, 0, 0, 0);
+  if (slot < slots)
+    for (int64_t r = r0 + slot; r < r1; r += slots) {
+      const float4 v = ld4(X + r * ld + c * 4);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  if (slot < slots) sred[slot * cg + c] = a;
+  __syncthreads();
+  if (threadIdx.x < cg) {
+    float4 t = make_float4(0, 0, 0, 0);
+    for (int sidx = 0; sidx < slots; ++sidx) {
+      const float4 v = sred[sidx * cg + threadIdx.x];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    st4(part + (int64_t)blockIdx.x * cols + threadIdx.x * 4, t);
+  }
+}
+
+int launch_colsum(hipStream_t s, const float* X, int64_t rows, int cols, int64_t ld, float* part,
+                  float* out) {
+  if (cols % 4 != 0 || cols > 1024 || cols <= 0) return BLH_ERR_SHAPE;
+  const int rpb = 256;
+  const int blocks = (int)ceil_div(rows, rpb);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks), dim3(256), 256 * sizeof(float4), s, X,
+                     rows, cols, ld, rpb, part);
+  BLH_HIP_TRY(hipGetLastError());
+  return launch_colreduce(s, part, blocks, cols, cols, out);
+}
+
+// ---------------------------------------------------------------------------
+// MSE: dpred = scale*(pred-target); per-block partial sums of squared error
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_f32(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+  return t;
+}
+
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred,
+                                                  const float* __restrict__ target, int64_t n,
+                                                  float scale, float* __restrict__ dpred,
+                                                  float* __restrict__ part) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 p = ld4(pred + i * 4), t = ld4(target + i * 4);
+    float4 d;
+    d.x = p.x - t.x; d.y = p.y - t.y; d.z = p.z - t.z; d.w = p.w - t.w;
+    acc += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+    d.x *= scale; d.y *= scale; d.z *= scale; d.w *= scale;
+    st4(dpred + i * 4, d);
+  }
+  const float t = block_sum_f32(acc, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+int launch_mse(hipStream_t s, const float* pred, const float* target, int64_t n, float scale,
+               float* dpred, float* part, int* nparts) {
+  if (n % 4 != 0) return BLH_ERR_SHAPE;
+  const int blocks = (int)std::min<int64_t>(ceil_div(n / 4, 256), 1024);
+  hipLaunchKernelGGL(mse_kernel, dim3(blocks), dim3(256), 0, s, pred, target, n, scale, dpred,
+                     part);
+  BLH_HIP_TRY(hipGetLastError());
+  *nparts = blocks;
+  return BLH_OK;
+}
+
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ part, int n,
+                                                            double denom, float* loss_out) {
+  __shared__ double sh[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) a += (double)part[i];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_out[0] = (float)(sh[0] / denom);
+}
+
+int launch_loss_finalize(hipStream_t s, const float* part, int n, double denom, float* loss_out) {
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, part, n, denom, loss_out);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// optimiser: global L2 norm partials, then fused clip + Adam over the flat arena
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t count,
+                                                    double* __restrict__ part) {
+  __shared__ double sh[256];
+  double acc = 0.0;
+  const int64_t n4 = count >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = ld4(g + i * 4);
+    acc += (double)(v.x * v.x + v.y * v.y) + (double)(v.z * v.z + v.w * v.w);
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+int launch_sumsq(hipStream_t s, const float* g, int64_t count, double* part, int* nparts) {
+  if (count % 4 != 0) return BLH_ERR_SHAPE;
+  const int blocks = (int)std::min<int64_t>(ceil_div(count / 4, 256 * 4), SUMSQ_MAX_PARTS);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, s, g, count, part);
+  BLH_HIP_TRY(hipGetLastError());
+  *nparts = blocks;
+  return BLH_OK;
+}
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(
+    float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+    int64_t count, float one_minus_b1, float b2, float one_minus_b2, float step_size,
+    float bc2_sqrt, float eps, float max_norm, const double* __restrict__ sumsq_part, int nparts,
+    float* stats_out) {
+  __shared__ double sh[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) a += sumsq_part[i];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float total_norm = (float)sqrt(sh[0]);
+  float coef = 1.0f;
+  if (max_norm > 0.f) coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);
+  if (stats_out && blockIdx.x == 0 && threadIdx.x == 0) {
+    stats_out[0] = total_norm;
+    stats_out[1] = coef;
+  }
+  const int64_t n4 = count >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float4 gv = ld4(g + i * 4), mv = ld4(m + i * 4), vv = ld4(v + i * 4), pv = ld4(p + i * 4);
+    float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x; float* pp = &pv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gg = gp[k] * coef;
+      gp[k] = gg;
+      mp[k] = mp[k] + (gg - mp[k]) * one_minus_b1;
+      vp[k] = vp[k] * b2 + (one_minus_b2 * gg) * gg;
+      const float denom = sqrtf(vp[k]) / bc2_sqrt + eps;
+      pp[k] = pp[k] - step_size * (mp[k] / denom);
+    }
+    st4(g + i * 4, gv); st4(m + i * 4, mv); st4(v + i * 4, vv); st4(p + i * 4, pv);
+  }
+}
+
+int launch_clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count,
+                     const blh_adam_hyper& h, const double* sumsq_part, int nparts,
+                     float* stats_out) {
+  if (count % 4 != 0) return BLH_ERR_SHAPE;
+  if (h.step < 1) return BLH_ERR_INVALID_ARGUMENT;
+  const double bc1 = 1.0 - pow((double)h.beta1, (double)h.step);
+  const double bc2 = 1.0 - pow((double)h.beta2, (double)h.step);
+  const float step_size = (float)((double)h.lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  const int blocks = (int)std::min<int64_t>(ceil_div(count / 4, 256), 2048);
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, count,
+                     (float)(1.0 - (double)h.beta1), h.beta2, (float)(1.0 - (double)h.beta2),
+                     step_size, bc2_sqrt, h.eps, h.max_norm, sumsq_part, nparts, stats_out);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+}  // namespace blh
+
+// ---------------------------------------------------------------------------
+// stand-alone nn.utils.clip_grad_norm_ (drop-in path; the fast path fuses it into Adam)
+// ---------------------------------------------------------------------------
+namespace blh {
+
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, int64_t count,
+                                                         float max_norm,
+                                                         const double* __restrict__ sumsq_part,
+                                                         int nparts, float* stats_out) {
+  __shared__ double sh[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) a += sumsq_part[i];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float total_norm = (float)sqrt(sh[0]);
+  const float coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);
+  if (stats_out && blockIdx.x == 0 && threadIdx.x == 0) {
+    stats_out[0] = total_norm;
+    stats_out[1] = coef;
+  }
+  const int64_t n4 = count >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float4 v = ld4(g + i * 4);
+    v.x *= coef; v.y *= coef; v.z *= coef; v.w *= coef;
+    st4(g + i * 4, v);
+  }
+}
+
+int launch_clip_scale(hipStream_t s, float* g, int64_t count, float max_norm,
+                      const double* sumsq_part, int nparts, float* stats_out) {
+  if (count % 4 != 0) return BLH_ERR_SHAPE;
+  const int blocks = (int)std::min<int64_t>(ceil_div(count / 4, 256), 2048);
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(blocks), dim3(256), 0, s, g, count, max_norm,
+                     sumsq_part, nparts, stats_out);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+}  // namespace blh
+
+// ---------------------------------------------------------------------------
+// materialise the Philox keep-mask (tests: feed the oracle the mask the kernels used)
+// ---------------------------------------------------------------------------
+namespace blh {
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ out,
+                                                           int64_t batch, int W, DropoutSrc drop) {
+  const int64_t n4 = batch * (int64_t)(W / 4);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / (W / 4);
+    const int col = (int)(i % (W / 4)) * 4;
+    DropState st;
+    const uint32_t nib = keep_nibble(drop, st, r, col, W, true);
+    uchar4 k;
+    k.x = nib & 1u; k.y = (nib >> 1) & 1u; k.z = (nib >> 2) & 1u; k.w = (nib >> 3) & 1u;
+    *reinterpret_cast<uchar4*>(out + r * (int64_t)W + col) = k;
+  }
+}
+
+int launch_dropout_mask(hipStream_t s, uint8_t* out, int64_t batch, int W, const DropoutSrc& drop) {
+  const int64_t blocks = std::min<int64_t>(ceil_div(batch * (W / 4), 256), 4096);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, batch, W,
+                     drop);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+}  // namespace blh

@@ -1,0 +1,308 @@
+"""Host-side owner of the device state the native kernels work on.
+
+One flat fp32 arena each for parameters and gradients (plus Adam's two, owned by
+``bilinear_amd.optim.Adam``), BatchNorm running statistics, and a per-batch-size
+workspace.  The ``nn.Parameter`` / buffer objects of ``BilinearUnit`` are *views*
+into these arenas, so ``state_dict`` / ``load_state_dict`` / ``.apply(init)`` of
+the reference surface (/root/reference/model/bilinear.py:58-92,
+train_bilinear.py:92-104) keep working while the kernels see contiguous memory.
+
+PyTorch is plumbing here: it allocates device memory and provides the stream.
+All arithmetic is done by libbilinear_hip.so through ``_native``.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _native as N
+
+IN_FEATURES = 32    # 2 * 16 joints, /root/reference/model/bilinear.py:20-22
+OUT_FEATURES = 48   # 3 * 16 joints, /root/reference/model/bilinear.py:29
+
+
+def _require_hip(device):
+    if device.type != "cuda":
+        raise RuntimeError(
+            "bilinear_amd runs only on a HIP device (MI355X); got a tensor on '%s'. "
+            "There is no CPU path in the product." % device)
+
+
+class ArenaLayout:
+    """Names / offsets / shapes of the flat parameter arena, as the library lays it out."""
+
+    def __init__(self, num_blocks, width):
+        lib = N.lib()
+        self.desc = N.ModelDesc(num_blocks, width, IN_FEATURES, OUT_FEATURES)
+        total = lib.blh_param_arena_floats(ctypes.byref(self.desc))
+        if total < 0:
+            N.check(int(total), "blh_param_arena_floats(num_blocks=%d, width=%d)" % (num_blocks, width))
+        self.total = int(total)
+        self.num_heavy = int(lib.blh_num_heavy(ctypes.byref(self.desc)))
+        self.entries = []          # (name, offset, shape)
+        n = lib.blh_num_param_tensors(ctypes.byref(self.desc))
+        buf = ctypes.create_string_buffer(64)
+        off, rows, cols = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        for i in range(n):
+            N.check(lib.blh_param_tensor_info(ctypes.byref(self.desc), i, buf, 64,
+                                              ctypes.byref(off), ctypes.byref(rows),
+                                              ctypes.byref(cols)), "blh_param_tensor_info")
+            name = buf.value.decode()
+            shape = (rows.value, cols.value) if cols.value > 1 else (rows.value,)
+            self.entries.append((name, off.value, shape))
+        self.bn_floats = int(lib.blh_bn_running_floats(ctypes.byref(self.desc)))
+
+    def workspace_bytes(self, batch):
+        b = N.lib().blh_workspace_bytes(ctypes.byref(self.desc), batch)
+        if b < 0:
+            N.check(int(b), "blh_workspace_bytes")
+        return int(b)
+
+
+class Engine:
+    """Device arenas + calls into the native library for one BilinearUnit."""
+
+    def __init__(self, module, num_blocks, width):
+        self.layout = ArenaLayout(num_blocks, width)
+        self.module = module
+        self.width = width
+        self.device = None
+        self.params = None
+        self.grads = None
+        self.bn_running = None
+        self.bn_nbt = None
+        self._workspace = None
+        self._scratch = None
+        self.masks = None              # explicit keep-masks (parity tests), uint8 [nh,B,W]
+        self.seed = int(torch.initial_seed()) & ((1 << 63) - 1)
+        self.rng_step = 0
+        self.row_offset = 0
+        self._saved_batch = None       # batch of the forward whose state sits in the workspace
+        self._saved_drop = None
+        self._grad_ready_cb = None
+        self.grad_ready_hook = None    # callable(offset, count): data-parallel bucket hook
+
+    # ---------------------------------------------------------------- arenas --
+    def _named_params(self):
+        named = dict(self.module.named_parameters())
+        return [(name, named[name], off, shape) for name, off, shape in self.layout.entries]
+
+    def _bn_modules(self):
+        mods = [self.module.encode[1]]
+        for pair in self.module.bilinear:
+            mods += [pair[0][1], pair[1][1]]
+        return mods
+
+    def is_packed(self, device):
+        if self.params is None or self.device != device:
+            return False
+        base = self.params.data_ptr()
+        for _, p, off, _ in self._named_params():
+            if p.data_ptr() != base + 4 * off or p.device != device:
+                return False
+        W = self.width
+        rbase = self.bn_running.data_ptr()
+        for i, bn in enumerate(self._bn_modules()):
+            if bn.running_mean.data_ptr() != rbase + 4 * (2 * i) * W:
+                return False
+            if bn.running_var.data_ptr() != rbase + 4 * (2 * i + 1) * W:
+                return False
+            if bn.num_batches_tracked.data_ptr() != self.bn_nbt.data_ptr() + 8 * i:
+                return False
+        return True
+
+    def pack(self, device):
+        """(Re)build the arenas on ``device`` from the module's current tensors and
+        re-point every Parameter / BN buffer at its arena slot."""
+        _require_hip(device)
+        lay = self.layout
+        params = torch.zeros(lay.total, dtype=torch.float32, device=device)
+        grads = torch.zeros(lay.total, dtype=torch.float32, device=device)
+        for _, p, off, shape in self._named_params():
+            if tuple(p.shape) != tuple(shape):
+                raise RuntimeError("parameter shape %s does not match arena slot %s"
+                                   % (tuple(p.shape), tuple(shape)))
+            slot = params[off:off + p.numel()].view(shape)
+            slot.copy_(p.data.to(device=device, dtype=torch.float32))
+            p.data = slot
+            p.grad = None
+        W = self.width
+        running = torch.zeros(lay.num_heavy, 2, W, dtype=torch.float32, device=device)
+        nbt = torch.zeros(lay.num_heavy, dtype=torch.int64, device=device)
+        for i, bn in enumerate(self._bn_modules()):
+            running[i, 0].copy_(bn.running_mean.to(device))
+            running[i, 1].copy_(bn.running_var.to(device))
+            nbt[i].copy_(bn.num_batches_tracked.to(device))
+            bn._buffers["running_mean"] = running[i, 0]
+            bn._buffers["running_var"] = running[i, 1]
+            bn._buffers["num_batches_tracked"] = nbt[i]
+        self.params, self.grads, self.bn_running, self.bn_nbt = params, grads, running, nbt
+        self.device = device
+        self._workspace = None
+        self._saved_batch = None
+
+    def ensure(self, device):
+        _require_hip(device)
+        if not self.is_packed(device):
+            self.pack(device)
+
+    def grad_view(self, off, shape):
+        n = 1
+        for s in shape:
+            n *= s
+        return self.grads[off:off + n].view(shape)
+
+    def workspace(self, batch):
+        need = self.layout.workspace_bytes(batch)
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = None
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._saved_batch = None
+        return self._workspace
+
+    def scratch(self):
+        if self._scratch is None or self._scratch.device != self.device:
+            self._scratch = torch.empty(1 << 16, dtype=torch.uint8, device=self.device)
+        return self._scratch
+
+    @staticmethod
+    def _stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _momentum(self):
+        m = self.module.encode[1].momentum
+        return -1.0 if m is None else float(m)
+
+    # --------------------------------------------------------------- dropout --
+    def set_dropout_masks(self, masks):
+        """Parity-test hook: replay explicit keep-masks (list of [B,W] arrays/tensors,
+        one per heavy_linear) instead of the Philox stream.  ``None`` restores Philox."""
+        if masks is None:
+            self.masks = None
+            return
+        ms = [torch.as_tensor(m).to(torch.uint8) for m in masks]
+        if len(ms) != self.layout.num_heavy:
+            raise RuntimeError("need %d masks" % self.layout.num_heavy)
+        self.masks = torch.stack(ms).contiguous()
+
+    def _drop_struct(self, batch):
+        if self.masks is not None:
+            if self.masks.device != self.device:
+                self.masks = self.masks.to(self.device)
+            if tuple(self.masks.shape) != (self.layout.num_heavy, batch, self.width):
+                raise RuntimeError("dropout masks have shape %s, expected %s" % (
+                    tuple(self.masks.shape), (self.layout.num_heavy, batch, self.width)))
+            return N.Dropout(self.masks.data_ptr(), 0, 0, 0)
+        return N.Dropout(None, self.seed, self.rng_step, self.row_offset)
+
+    # ---------------------------------------------------------------- compute --
+    def _check_input(self, x):
+        _require_hip(x.device)
+        if x.dim() != 2 or x.shape[1] != IN_FEATURES:
+            raise RuntimeError("expected input of shape [B, %d], got %s" % (IN_FEATURES, tuple(x.shape)))
+        if x.dtype != torch.float32:
+            raise RuntimeError("expected a float32 input, got %s" % x.dtype)
+        return x.contiguous()
+
+    def forward_train(self, x):
+        x = self._check_input(x)
+        self.ensure(x.device)
+        batch = x.shape[0]
+        if batch < 2:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s"
+                             % (tuple(x.shape),))
+        ws = self.workspace(batch)
+        pred = torch.empty(batch, OUT_FEATURES, dtype=torch.float32, device=x.device)
+        drop = self._drop_struct(batch)
+        N.check(N.lib().blh_forward_train(
+            ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params),
+            N.ptr(self.bn_running), N.ptr(self.bn_nbt), N.ptr(x), ctypes.byref(drop),
+            self._momentum(), N.ptr(ws), ws.numel(), N.ptr(pred), batch), "blh_forward_train")
+        self._saved_batch = batch
+        self._saved_drop = drop
+        if self.masks is None:
+            self.rng_step += 1
+        return pred
+
+    def forward_eval(self, x):
+        x = self._check_input(x)
+        self.ensure(x.device)
+        batch = x.shape[0]
+        ws = self.workspace(batch)
+        self._saved_batch = None       # eval overwrites the saved activations
+        pred = torch.empty(batch, OUT_FEATURES, dtype=torch.float32, device=x.device)
+        N.check(N.lib().blh_forward_eval(
+            ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params),
+            N.ptr(self.bn_running), N.ptr(x), N.ptr(ws), ws.numel(), N.ptr(pred), batch),
+            "blh_forward_eval")
+        return pred
+
+    def backward(self, x, dpred, on_ready=None):
+        """Gradients of every parameter into the grad arena (overwritten)."""
+        batch = x.shape[0]
+        if self._saved_batch != batch:
+            raise RuntimeError("backward called without a matching train-mode forward "
+                               "(the workspace holds the activations of the last forward only)")
+        dpred = dpred.contiguous()
+        if tuple(dpred.shape) != (batch, OUT_FEATURES) or dpred.dtype != torch.float32:
+            raise RuntimeError("bad output gradient: %s %s" % (tuple(dpred.shape), dpred.dtype))
+        ws = self.workspace(batch)
+        if on_ready is not None:
+            cb = N.GradReadyFn(lambda user, off, cnt: on_ready(int(off), int(cnt)))
+        else:
+            cb = ctypes.cast(None, N.GradReadyFn)
+        self._grad_ready_cb = cb       # keep alive during the call
+        N.check(N.lib().blh_backward(
+            ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params), N.ptr(x),
+            ctypes.byref(self._saved_drop), N.ptr(ws), ws.numel(), N.ptr(dpred),
+            N.ptr(self.grads), batch, cb, None), "blh_backward")
+        self._saved_batch = None
+
+    def mse_loss_grad(self, pred, target, denominator=None, grad_scale=1.0):
+        """(loss scalar tensor, dpred) of nn.MSELoss — train_bilinear.py:49,78."""
+        batch, of = pred.shape
+        if denominator is None:
+            denominator = float(batch * of)
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        dpred = torch.empty_like(pred)
+        sc = self.scratch()
+        N.check(N.lib().blh_mse_loss_grad(
+            self._stream(), N.ptr(pred.contiguous()), N.ptr(target.contiguous()), batch, of,
+            denominator, grad_scale, N.ptr(loss), N.ptr(dpred), N.ptr(sc), sc.numel()),
+            "blh_mse_loss_grad")
+        return loss, dpred
+
+    def clip_adam(self, exp_avg, exp_avg_sq, lr, betas, eps, max_norm, step, stats=None):
+        hyper = N.AdamHyper(lr, betas[0], betas[1], eps, 0.0 if max_norm is None else max_norm, step)
+        sc = self.scratch()
+        N.check(N.lib().blh_clip_adam_step(
+            self._stream(), N.ptr(self.params), N.ptr(self.grads), N.ptr(exp_avg),
+            N.ptr(exp_avg_sq), self.layout.total, ctypes.byref(hyper), N.ptr(sc), sc.numel(),
+            N.ptr(stats)), "blh_clip_adam_step")
+
+    def train_step(self, x, target, exp_avg, exp_avg_sq, lr, betas, eps, max_norm, step, stats=None):
+        """Whole step body of train_bilinear.py:75-83 as one native enqueue."""
+        x = self._check_input(x)
+        self.ensure(x.device)
+        batch = x.shape[0]
+        if batch < 2:
+            raise ValueError("Expected more than 1 value per channel when training")
+        target = target.contiguous()
+        if tuple(target.shape) != (batch, OUT_FEATURES) or target.dtype != torch.float32:
+            raise RuntimeError("bad target: %s %s" % (tuple(target.shape), target.dtype))
+        ws = self.workspace(batch)
+        pred = torch.empty(batch, OUT_FEATURES, dtype=torch.float32, device=x.device)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        drop = self._drop_struct(batch)
+        hyper = N.AdamHyper(lr, betas[0], betas[1], eps, 0.0 if max_norm is None else max_norm, step)
+        N.check(N.lib().blh_train_step(
+            ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params), N.ptr(self.grads),
+            N.ptr(exp_avg), N.ptr(exp_avg_sq), N.ptr(self.bn_running), N.ptr(self.bn_nbt),
+            N.ptr(x), N.ptr(target), ctypes.byref(drop), self._momentum(), ctypes.byref(hyper),
+            N.ptr(ws), ws.numel(), N.ptr(pred), N.ptr(loss), N.ptr(stats), batch),
+            "blh_train_step")
+        self._saved_batch = None
+        if self.masks is None:
+            self.rng_step += 1
+        return pred, loss

@@ -1,0 +1,181 @@
+"""Drop-in for the reference's ``model.bilinear`` (/root/reference/model/bilinear.py):
+the same three exports — ``heavy_linear``, ``BilinearUnit``, ``load`` — with the
+same signatures, submodule names and ``state_dict`` keys, but every forward /
+backward runs on hand-written gfx950 kernels through libbilinear_hip.so.
+
+Differences a caller can see:
+  * tensors must live on a HIP device (no CPU path: a CPU input raises);
+  * ``BilinearUnit(num_blocks=2, width=1024)`` is parameterised (the reference
+    hard-codes (2, 1024), model/bilinear.py:22-29);
+  * ``load`` returns ``bilinear_amd.optim.Adam`` (same interface and
+    ``state_dict`` format as ``torch.optim.Adam``; fused kernel underneath).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+
+from ..engine import IN_FEATURES, OUT_FEATURES, Engine
+from ..optim import Adam
+
+__all__ = ["heavy_linear", "BilinearUnit", "Bilinear", "load"]
+
+
+class _HeavyLinear(nn.Sequential):
+    """Linear -> BatchNorm1d -> ReLU -> Dropout(0.5) as ONE fused stage.
+
+    Inside ``BilinearUnit`` the children only hold parameters and buffers (the
+    unit drives all stages natively, fused across stage boundaries).  The C ABI
+    has no single-stage entry point, so calling a stage on its own is rejected
+    loudly instead of silently running ATen ops."""
+
+    def forward(self, in_tensor):   # noqa: D401
+        raise RuntimeError(
+            "bilinear_amd.heavy_linear stages are executed by BilinearUnit's native engine; "
+            "a stand-alone stage has no HIP entry point (and there is no ATen fallback).")
+
+
+def heavy_linear(in_features, out_features, bias=True):
+    """/root/reference/model/bilinear.py:7-13 — same container layout
+    (index 0 Linear, 1 BatchNorm1d, 2 ReLU, 3 Dropout(p=0.5))."""
+    if not bias:
+        raise RuntimeError("bilinear_amd kernels assume Linear(bias=True), as the reference uses")
+    return _HeavyLinear(
+        nn.Linear(in_features, out_features, bias=True),
+        nn.BatchNorm1d(out_features),
+        nn.ReLU(),
+        nn.Dropout(p=0.5),
+    )
+
+
+class _LifterFunction(torch.autograd.Function):
+    """Autograd bridge for the drop-in surface: ``loss.backward()``
+    (train_bilinear.py:79) lands in Engine.backward, which fills the flat gradient
+    arena; each Parameter's ``.grad`` becomes a view of its arena slot."""
+
+    @staticmethod
+    def forward(ctx, x, engine, *params):
+        pred = engine.forward_train(x)
+        ctx.engine = engine
+        ctx.x = x
+        ctx.params = params
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        engine = ctx.engine
+        accumulate = any(p.grad is not None for p in ctx.params)
+        old = engine.grads.clone() if accumulate else None
+        hook = engine.grad_ready_hook
+        engine.backward(ctx.x, dpred, on_ready=hook)
+        for (_, p, off, shape) in engine._named_params():
+            view = engine.grad_view(off, shape)
+            if p.grad is None:
+                p.grad = view
+            elif p.grad.data_ptr() == view.data_ptr():
+                view.add_(old[off:off + view.numel()].view(shape))
+            else:
+                p.grad.add_(view)
+        return (None, None) + tuple(None for _ in ctx.params)
+
+
+class BilinearUnit(nn.Module):
+    """/root/reference/model/bilinear.py:16-55."""
+
+    def __init__(self, num_blocks=2, width=1024):
+        super().__init__()
+        self.num_blocks = int(num_blocks)
+        self.width = int(width)
+        self.encode = heavy_linear(in_features=IN_FEATURES, out_features=self.width)
+        self.bilinear = nn.ModuleList([
+            nn.Sequential(
+                heavy_linear(in_features=self.width, out_features=self.width),
+                heavy_linear(in_features=self.width, out_features=self.width),
+            ) for _ in range(self.num_blocks)
+        ])
+        self.decode = nn.Linear(in_features=self.width, out_features=OUT_FEATURES, bias=True)
+        # not a submodule / parameter: excluded from state_dict
+        object.__setattr__(self, "_engine", None)
+
+    # -- native engine ---------------------------------------------------------
+    @property
+    def engine(self):
+        if self._engine is None:
+            eng = Engine(self, self.num_blocks, self.width)
+            object.__setattr__(self, "_engine", eng)
+        return self._engine
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_engine"] = None          # device arenas are rebuilt lazily
+        return state
+
+    def forward(self, in_tensor):
+        """model/bilinear.py:31-41.  train mode: batch statistics + dropout;
+        eval mode (valid_bilinear.py:31): running statistics, no dropout."""
+        eng = self.engine
+        if in_tensor.device.type != "cuda":
+            raise RuntimeError(
+                "bilinear_amd.BilinearUnit runs only on a HIP device (MI355X); input is on '%s' "
+                "and there is no CPU fallback." % in_tensor.device)
+        eng.ensure(in_tensor.device)
+        if not self.training:
+            return eng.forward_eval(in_tensor)
+        if torch.is_grad_enabled():
+            params = [p for _, p, _, _ in eng._named_params()]
+            return _LifterFunction.apply(in_tensor, eng, *params)
+        return eng.forward_train(in_tensor)
+
+    def reset_statistics(self):
+        """model/bilinear.py:43-55: reset every BN's running stats and switch it to
+        the cumulative moving average (momentum=None)."""
+        for key in self.state_dict().keys():
+            if "running_mean" in key:
+                layer = self
+                for part in key.split(".")[:-1]:
+                    layer = layer[int(part)] if part.isdigit() else getattr(layer, part)
+                layer.reset_running_stats()
+                layer.momentum = None
+
+    def train_step(self, optimizer, x, target, max_norm=1.0):
+        """Fast path for the step body of train_bilinear.py:75-83: zero_grad, forward,
+        MSELoss, backward, clip_grad_norm_(max_norm), Adam.step as ONE native enqueue
+        (no autograd graph, no host synchronisation).  Returns (prediction, loss)."""
+        return optimizer.fused_train_step(self, x, target, max_norm)
+
+
+Bilinear = BilinearUnit   # BASELINE.json names the class `Bilinear`; the reference calls it BilinearUnit
+
+
+def load(device, parameter_dir=None, learning_rate=1.0e-3, num_blocks=2, width=1024):
+    """/root/reference/model/bilinear.py:58-92 — build the module on ``device``,
+    an Adam optimiser, and either restore the newest ``{epoch}.save`` checkpoint
+    under ``parameter_dir`` or Kaiming-initialise every Linear weight.
+    Returns (module, optimizer, step, epoch_to_load)."""
+    bilinear = BilinearUnit(num_blocks=num_blocks, width=width).to(device)
+    optimizer = Adam(bilinear.parameters(), lr=learning_rate, module=bilinear)
+    step = 1
+
+    epoch_to_load = 0
+    if parameter_dir is not None:
+        for _, _, files in os.walk(parameter_dir):
+            for file in files:
+                name, extension = file.split(".")     # "{epoch}.save"
+                epoch_to_load = max(epoch_to_load, int(name))
+
+    if epoch_to_load != 0:
+        parameter_file = "{parameter_dir}/{epoch}.save".format(
+            parameter_dir=parameter_dir, epoch=epoch_to_load)
+        parameter = torch.load(parameter_file, map_location=device, weights_only=False)
+        bilinear.load_state_dict(parameter["state"])
+        optimizer.load_state_dict(parameter["optimizer"])
+        step = parameter["step"]
+    else:
+        def weight_init(m):
+            if isinstance(m, nn.Linear):
+                nn.init.kaiming_normal_(m.weight)
+        bilinear.apply(weight_init)
+
+    return bilinear, optimizer, step, epoch_to_load

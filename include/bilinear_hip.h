@@ -1,0 +1,204 @@
+/*
+ * bilinear_hip.h — C ABI of libbilinear_hip.so, the MI355X (gfx950) native
+ * implementation of the one hot path of nulledge/bilinear: forward / backward /
+ * optimiser step of the 2D->3D pose-lifting MLP.
+ *
+ * The reference has no FFI for this path: its boundary is the Python
+ * torch.nn.Module / torch.optim.Optimizer surface consumed by
+ *   /root/reference/train_bilinear.py:75-83   (zero_grad, forward, MSELoss,
+ *                                              backward, clip_grad_norm_, step)
+ *   /root/reference/valid_bilinear.py:31,52   (eval-mode forward)
+ * and produced by
+ *   /root/reference/model/bilinear.py:7-13    heavy_linear
+ *   /root/reference/model/bilinear.py:16-55   BilinearUnit
+ *   /root/reference/model/bilinear.py:58-92   load()
+ * Each entry point below names the reference call-site it replaces.  The
+ * reference-side binding (a ctypes stub inside model/bilinear.py) is shown in
+ * INTEGRATION.md; bilinear_amd/_native.py is that stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes; no torch types.  Every pointer marked "device"
+ *     is a HIP device pointer owned by the caller (PyTorch allocations in the
+ *     shipped host code); the library never frees or retains caller memory
+ *     beyond the call, and allocates nothing on the device.
+ *   - `stream` is a hipStream_t passed as void*; every entry point only
+ *     enqueues work on it (no host synchronisation, no allocation), so calls
+ *     are asynchronous and hipGraph-capturable.
+ *   - all tensors are row-major fp32 unless stated; a "[B,W]" tensor has the
+ *     batch as the slow index, exactly like the reference's torch tensors.
+ *   - return value: BLH_OK (0) or a negative blh_status; never aborts.
+ *     blh_status_string() gives the text; HIP errors are reported as
+ *     BLH_ERR_HIP and the hipError_t is available via blh_last_hip_error().
+ */
+#ifndef BILINEAR_HIP_H
+#define BILINEAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLH_ABI_VERSION 1
+
+typedef enum {
+  BLH_OK = 0,
+  BLH_ERR_INVALID_ARGUMENT = -1, /* NULL pointer, non-positive size, bad enum   */
+  BLH_ERR_SHAPE = -2,            /* shape the kernels do not support            */
+  BLH_ERR_HIP = -3,              /* a HIP runtime call failed                   */
+  BLH_ERR_WORKSPACE = -4         /* workspace smaller than blh_workspace_bytes  */
+} blh_status;
+
+const char* blh_status_string(int status);
+int blh_last_hip_error(void);
+int blh_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * Model description.  The reference hard-codes num_blocks=2, width=1024,
+ * in_features=32, out_features=48 (model/bilinear.py:20-29); the build
+ * generalises (num_blocks, width).  width must be a multiple of 32.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  int32_t num_blocks;   /* residual blocks, each = 2 heavy_linear            */
+  int32_t width;        /* hidden width W                                    */
+  int32_t in_features;  /* 2*16 = 32                                         */
+  int32_t out_features; /* 3*16 = 48                                         */
+} blh_model_desc;
+
+/* Number of heavy_linear stages = 1 + 2*num_blocks (encode + hidden). */
+int32_t blh_num_heavy(const blh_model_desc* d);
+
+/* ---- flat parameter arena ------------------------------------------------
+ * Parameters live in ONE flat fp32 arena in `module.parameters()` order
+ * (model/bilinear.py:22-29): per heavy_linear {Linear.weight [out,in],
+ * Linear.bias [out], BN.weight [out], BN.bias [out]}, then decode.weight
+ * [48,W], decode.bias [48].  Gradients, Adam exp_avg and exp_avg_sq use arenas
+ * of the same layout.  Every tensor starts on a 64-float boundary; padding is
+ * zero and stays zero.                                                      */
+int64_t blh_param_arena_floats(const blh_model_desc* d);
+int32_t blh_num_param_tensors(const blh_model_desc* d);
+/* index in [0, blh_num_param_tensors): name is the reference state_dict key. */
+int blh_param_tensor_info(const blh_model_desc* d, int32_t index, char* name, int32_t name_cap,
+                          int64_t* offset_floats, int64_t* rows, int64_t* cols);
+
+/* BatchNorm buffers: running stats fp32 [num_heavy][2][W] (mean, var) and
+ * num_batches_tracked int64 [num_heavy].                                    */
+int64_t blh_bn_running_floats(const blh_model_desc* d);
+
+/* Workspace (activations saved for backward, gradient staging, split-K slabs,
+ * reduction partials) for a given batch; 256-byte aligned base required.    */
+int64_t blh_workspace_bytes(const blh_model_desc* d, int64_t batch);
+
+/* ---- dropout source --------------------------------------------------------
+ * Either an explicit keep-mask (parity tests replay the reference's masks):
+ *   keep_mask = device uint8 [num_heavy][B][W], 1 = keep;
+ * or keep_mask == NULL: counter-based Philox4x32-10 keyed by (seed, step,
+ * layer, global row, column); the mask is regenerated in backward, never
+ * stored.  row_offset is the global index of local row 0 (data parallel:
+ * rank * per-rank batch), and must be a multiple of 32.                     */
+typedef struct {
+  const uint8_t* keep_mask; /* device, or NULL for Philox                    */
+  uint64_t seed;
+  uint64_t step;
+  int64_t row_offset;
+} blh_dropout;
+
+/* ---- forward ---------------------------------------------------------------
+ * Replaces BilinearUnit.forward (model/bilinear.py:31-41) in train mode
+ * (train_bilinear.py:54,76): Linear -> BatchNorm1d(batch stats; running stats
+ * updated with `momentum`, unbiased variance; num_batches_tracked += 1) ->
+ * ReLU -> Dropout(0.5), residual adds, decode.  momentum < 0 selects
+ * PyTorch's cumulative average (reset_statistics, model/bilinear.py:43-55).
+ * Saves pre-BN outputs, activations and batch statistics in `workspace` for
+ * blh_backward.  x: device [B,32]; pred: device [B,48] (written).           */
+int blh_forward_train(const blh_model_desc* d, void* stream, const float* params,
+                      float* bn_running, int64_t* bn_num_batches_tracked, const float* x,
+                      const blh_dropout* drop, float momentum, void* workspace,
+                      int64_t workspace_bytes, float* pred, int64_t batch);
+
+/* Eval-mode forward (valid_bilinear.py:31,52): BN uses running stats, dropout
+ * is the identity, nothing is saved.                                        */
+int blh_forward_eval(const blh_model_desc* d, void* stream, const float* params,
+                     const float* bn_running, const float* x, void* workspace,
+                     int64_t workspace_bytes, float* pred, int64_t batch);
+
+/* ---- loss -------------------------------------------------------------------
+ * nn.MSELoss() (train_bilinear.py:49,78) and its gradient:
+ * loss = sum((pred-target)^2)/(B*48) -> *loss_out (device scalar);
+ * dpred = grad_scale * 2 (pred-target)/(B*48) (device [B,48]).
+ * `loss_denominator` is B*48 of the GLOBAL batch under data parallelism.    */
+int blh_mse_loss_grad(void* stream, const float* pred, const float* target, int64_t batch,
+                      int64_t out_features, double loss_denominator, float grad_scale,
+                      float* loss_out, float* dpred, void* workspace, int64_t workspace_bytes);
+
+/* ---- backward ----------------------------------------------------------------
+ * Replaces loss.backward() (train_bilinear.py:79) from d(loss)/d(pred) down:
+ * writes (not accumulates) every parameter gradient into `grads` (arena
+ * layout).  No input gradient (train_bilinear.py:72).  `on_ready`, if not
+ * NULL, is called on the host right after the kernels that complete a
+ * contiguous arena range [offset, offset+count) have been enqueued, in
+ * decode -> encode order: the data-parallel host code launches the RCCL
+ * all-reduce of that bucket from it, overlapping the rest of backward.      */
+typedef void (*blh_grad_ready_fn)(void* user, int64_t offset_floats, int64_t count_floats);
+int blh_backward(const blh_model_desc* d, void* stream, const float* params, const float* x,
+                 const blh_dropout* drop, void* workspace, int64_t workspace_bytes,
+                 const float* dpred, float* grads, int64_t batch, blh_grad_ready_fn on_ready,
+                 void* user);
+
+/* ---- clip + Adam ---------------------------------------------------------------
+ * nn.utils.clip_grad_norm_(params, max_norm) (train_bilinear.py:81) fused with
+ * torch.optim.Adam.step() (model/bilinear.py:60, train_bilinear.py:83):
+ *   total = ||grads||_2 ; coef = min(1, max_norm/(total+1e-6)) ; g *= coef
+ *   m += (1-b1)(g-m) ; v = b2 v + (1-b2) g^2
+ *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * `step` is t (1-based, after increment).  max_norm <= 0 disables clipping.
+ * grads are rewritten with the clipped values (as the reference's .grad is).
+ * stats_out (device float[2], optional): total_norm, clip coefficient.      */
+typedef struct {
+  float lr, beta1, beta2, eps, max_norm;
+  int32_t step;
+} blh_adam_hyper;
+/* nn.utils.clip_grad_norm_ alone (train_bilinear.py:81): scales `grads` in place;
+ * stats_out (device float[2], optional) = total_norm, coefficient.           */
+int blh_clip_grad_norm(void* stream, float* grads, int64_t count, float max_norm, void* workspace,
+                       int64_t workspace_bytes, float* stats_out);
+int blh_clip_adam_step(void* stream, float* params, float* grads, float* exp_avg,
+                       float* exp_avg_sq, int64_t count, const blh_adam_hyper* hyper,
+                       void* workspace, int64_t workspace_bytes, float* stats_out);
+
+/* ---- whole training step (single GPU) --------------------------------------------
+ * The step body of train_bilinear.py:75-83 as one enqueue: forward_train, MSE,
+ * backward, clip, Adam.  loss_out: device scalar.                            */
+int blh_train_step(const blh_model_desc* d, void* stream, float* params, float* grads,
+                   float* exp_avg, float* exp_avg_sq, float* bn_running,
+                   int64_t* bn_num_batches_tracked, const float* x, const float* target,
+                   const blh_dropout* drop, float momentum, const blh_adam_hyper* hyper,
+                   void* workspace, int64_t workspace_bytes, float* pred, float* loss_out,
+                   float* stats_out, int64_t batch);
+
+/* ---- kernel-level entry points (unit tests, profiling) ---------------------------
+ * C[M,N] = op(A) * op(B) with fp32 MFMA.  a_kmajor=0: A is [M,K] (K
+ * contiguous); 1: A is [K,M].  b_kmajor=0: B is [N,K] (K contiguous, i.e. a
+ * Linear weight); 1: B is [K,N].  K and every contiguous dimension must be
+ * multiples of 4.  splits>1 writes `splits` partial slabs [splits][M][N]
+ * (reduction dimension cut in equal parts) that blh_sum_slabs adds up.      */
+int blh_gemm_f32(void* stream, const float* A, int64_t lda, int32_t a_kmajor, const float* B,
+                 int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc, int64_t M, int64_t N,
+                 int64_t K, int32_t splits, const float* bias, const float* addend,
+                 int64_t ldadd);
+int blh_sum_slabs(void* stream, const float* slabs, int64_t count, int32_t splits, float* out);
+/* The forward kernel of one heavy_linear exactly as blh_forward_train launches it:
+ * Z[M,N] = A[M,K] W[N,K]^T + bias, plus per-128-row-tile column statistics
+ * stat_part[ceil(M/128)][2][N] = (tile mean, tile sum of squared deviations).  */
+int blh_linear_fwd_stats(void* stream, const float* A, const float* W, const float* bias, float* Z,
+                         float* stat_part, int64_t M, int64_t N, int64_t K);
+/* Materialise the Philox keep-mask of one stage (uint8 [B,W], 1 = keep) exactly as the
+ * forward/backward kernels regenerate it; drop->keep_mask must be NULL.         */
+int blh_dropout_mask(void* stream, const blh_dropout* drop, int32_t layer, int64_t batch,
+                     int32_t width, uint8_t* keep_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BILINEAR_HIP_H */

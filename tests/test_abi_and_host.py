@@ -1,0 +1,136 @@
+"""CPU-side checks (no GPU, no compute calls): the C-ABI library loads and exports
+every symbol include/bilinear_hip.h declares; the host-side mirror of the reference
+interface (model.bilinear.{heavy_linear, BilinearUnit, load}) has the reference's
+names, state_dict keys and checkpoint discovery; the product refuses to run without
+a HIP device instead of falling back."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import numpy_oracle as O
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "bilinear_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(blh_[a-z0-9_]+)\s*\(", text))
+    names -= {"blh_grad_ready_fn"}
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol(native):
+    decl = _declared_symbols()
+    assert len(decl) >= 18
+    for name in decl:
+        assert hasattr(native, name), "libbilinear_hip.so does not export %s" % name
+    from bilinear_amd import _native
+    assert sorted(_native.exported_names()) == decl, "ctypes table and header disagree"
+    assert native.blh_abi_version() == 1
+    assert native.blh_status_string(0) == b"ok"
+    assert native.blh_status_string(-4) == b"workspace too small"
+
+
+def test_arena_layout_matches_reference_parameter_order(native):
+    from bilinear_amd import _native as N
+    from bilinear_amd.engine import ArenaLayout
+    for nb, width, nparams in [(2, 1024, 4291632), (4, 1024, 8498224), (8, 2048, 67377200)]:
+        lay = ArenaLayout(nb, width)
+        names = [n for n, _, _ in lay.entries]
+        assert names == O.param_keys(nb)                       # module.parameters() order
+        spec = {k: s for k, s, kind in O.state_spec(nb, width) if kind == "param"}
+        assert all(tuple(s) == tuple(spec[n]) for n, _, s in lay.entries)
+        assert sum(int(np.prod(s)) for _, _, s in lay.entries) == nparams
+        offs = [o for _, o, _ in lay.entries]
+        assert offs == sorted(offs) and all(o % 64 == 0 for o in offs)
+        assert lay.total >= nparams and lay.total % 64 == 0
+        assert lay.bn_floats == (1 + 2 * nb) * 2 * width
+        assert lay.workspace_bytes(4096) > 0
+    # invalid descriptions are refused with a status, not a crash
+    bad = N.ModelDesc(2, 1000, 32, 48)
+    assert native.blh_param_arena_floats(ctypes.byref(bad)) == -2
+
+
+def test_argument_validation_without_gpu(native):
+    from bilinear_amd import _native as N
+    d = N.ModelDesc(2, 1024, 32, 48)
+    drop = N.Dropout(None, 1, 0, 0)
+    # NULL pointers / bad sizes are rejected before any HIP call
+    assert native.blh_forward_train(ctypes.byref(d), None, None, None, None, None, ctypes.byref(drop),
+                                    0.1, None, 0, None, 64) == -1
+    assert native.blh_gemm_f32(None, None, 0, 0, None, 0, 0, None, 0, 0, 0, 0, 1, None, None, 0) == -1
+    drop_bad = N.Dropout(None, 1, 0, 5)          # Philox needs row_offset % 32 == 0
+    ws = ctypes.create_string_buffer(512)
+    assert native.blh_dropout_mask(None, ctypes.byref(drop_bad), 0, 64, 64, ws) == -2
+
+
+def test_module_surface_matches_reference():
+    import bilinear_amd
+    import model                                   # top-level alias used by reference scripts
+    assert model.bilinear.BilinearUnit is bilinear_amd.BilinearUnit
+    assert {"heavy_linear", "BilinearUnit", "load"} <= set(dir(model.bilinear))
+    net = bilinear_amd.BilinearUnit()
+    sd = net.state_dict()
+    assert list(sd.keys()) == [k for k, _, _ in O.state_spec(2, 1024)]
+    assert len(sd) == 37 and sum(p.numel() for p in net.parameters()) == 4291632
+    h = bilinear_amd.heavy_linear(32, 64)
+    assert [type(m).__name__ for m in h] == ["Linear", "BatchNorm1d", "ReLU", "Dropout"]
+    assert h[3].p == 0.5 and h[1].eps == 1e-5 and h[1].momentum == 0.1
+    # reset_statistics (model/bilinear.py:43-55): cumulative average mode
+    net.encode[1].running_mean.fill_(3.0)
+    net.reset_statistics()
+    assert net.encode[1].momentum is None and float(net.encode[1].running_mean.abs().max()) == 0.0
+
+
+def test_no_cpu_fallback():
+    import bilinear_amd
+    net = bilinear_amd.BilinearUnit(1, 64)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        net(torch.zeros(8, 32))
+    net.eval()
+    with pytest.raises(RuntimeError, match="HIP device"):
+        net(torch.zeros(8, 32))
+    with pytest.raises(RuntimeError):
+        bilinear_amd.heavy_linear(32, 64)(torch.zeros(8, 32))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from bilinear_amd import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no fallback"):
+        _native.lib()
+
+
+def test_load_initialises_and_discovers_checkpoints(tmp_path):
+    import bilinear_amd
+    torch.manual_seed(0)
+    net, opt, step, epoch = bilinear_amd.load(torch.device("cpu"))
+    assert (step, epoch) == (1, 0)
+    assert isinstance(opt, torch.optim.Optimizer) and opt.param_groups[0]["lr"] == 1e-3
+    # kaiming_normal (fan_in, gain sqrt 2): std 0.25 for encode, 0.0442 for hidden
+    assert abs(net.encode[0].weight.std().item() - 0.25) < 0.01
+    assert abs(net.bilinear[0][0][0].weight.std().item() - (2 / 1024) ** 0.5) < 0.001
+    assert float(net.encode[1].weight.min()) == 1.0 and float(net.encode[1].bias.abs().max()) == 0.0
+    # checkpoint in the reference's format and naming (train_bilinear.py:92-104)
+    d = tmp_path / "parameter"
+    d.mkdir()
+    for e in (3, 12):
+        torch.save({"epoch": e, "step": 100 * e, "state": net.state_dict(),
+                    "optimizer": torch.optim.Adam(net.parameters(), lr=5e-4).state_dict()},
+                   str(d / ("%d.save" % e)))
+    net2, opt2, step2, epoch2 = bilinear_amd.load(torch.device("cpu"), parameter_dir=str(d))
+    assert (step2, epoch2) == (1200, 12)
+    assert opt2.param_groups[0]["lr"] == 5e-4
+    assert torch.equal(net2.decode.weight, net.decode.weight)
+    for pg in opt2.param_groups:                   # lr-decay hook of train_bilinear.py:66-70
+        pg["lr"] = O.lr_decay_function(step2)
+    assert opt2.param_groups[0]["lr"] == O.lr_decay_function(1200)
+    (d / "notes.txt.bak").write_text("x")         # the reference raises on names with != 1 dot
+    with pytest.raises(ValueError):
+        bilinear_amd.load(torch.device("cpu"), parameter_dir=str(d))

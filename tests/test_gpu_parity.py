@@ -1,0 +1,379 @@
+"""GPU parity tests (run on the MI355X box: ``pytest -m gpu``).
+
+Every test drives the HIP path through the C ABI (ctypes, bilinear_amd._native)
+and compares with
+  * the golden vectors captured from the reference itself (tests/golden/*.npz), and
+  * the NumPy oracle (oracle/numpy_oracle.py, fp64 arbiter) on the same seeded inputs.
+
+Tolerance: BASELINE.json north_star states "within 1e-3 rel fp32".  The tests
+use RTOL = 1e-3 on |a-b| <= RTOL*(|b| + rms(b)); the kernels actually land
+around 1e-5 (printed by -s).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import FIXTURES, Golden, is_prebn_bias
+from oracle import numpy_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-3          # north_star tolerance
+TIGHT = 1e-4         # what fp32 kernels should comfortably meet
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _close(got, ref, rtol, what):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    rms = np.sqrt((ref ** 2).mean()) if ref.size else 0.0
+    bound = rtol * (np.abs(ref) + rms)
+    err = np.abs(got - ref)
+    worst = np.unravel_index(np.argmax(err - bound), err.shape) if ref.size else ()
+    assert (err <= bound).all(), "%s: |err|=%.3e > %.3e at %s (ref %.3e rms %.3e)" % (
+        what, err[worst], bound[worst], worst, ref[worst], rms)
+    return float((err / np.maximum(bound, 1e-300)).max()) * rtol if ref.size else 0.0
+
+
+# ----------------------------------------------------------------------------
+# kernel level: the fp32 MFMA GEMM in its four operand layouts
+# ----------------------------------------------------------------------------
+GEMM_CASES = [
+    # M, N, K, a_kmajor, b_kmajor, splits
+    (256, 256, 64, 0, 0, 1),          # forward layout, full tiles
+    (300, 1024, 32, 0, 0, 1),         # encode forward: K = 32, ragged M
+    (4096, 48, 1024, 0, 0, 1),        # decode forward: N = 48
+    (200, 1024, 1024, 0, 1, 1),       # dgrad
+    (64, 1024, 48, 0, 1, 1),          # decode dgrad: K = 48 (ragged K tile)
+    (1024, 1024, 512, 1, 1, 4),       # wgrad, split over the batch
+    (1024, 32, 1000, 1, 1, 8),        # encode wgrad: N = 32, ragged reduction
+    (48, 1024, 777, 1, 1, 1),         # decode wgrad: M = 48, odd batch
+    (130, 200, 36, 1, 0, 1),
+]
+
+
+@pytest.mark.parametrize("M,N,K,ak,bk,splits", GEMM_CASES)
+def test_gemm_f32_layouts(native, M, N, K, ak, bk, splits):
+    dev = _dev()
+    rng = np.random.RandomState(M + 3 * N + 7 * K)
+    # asymmetric, non-trivial operands (a transposed output or a swapped fragment map shows)
+    A = rng.standard_normal((K, M) if ak else (M, K)).astype(np.float32)
+    B = rng.standard_normal((K, N) if bk else (N, K)).astype(np.float32)
+    A[0] += 3.0
+    ref = (A.T if ak else A).astype(np.float64) @ (B if bk else B.T).astype(np.float64)
+    a, b = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+    c = torch.full((splits, M, N), float("nan"), device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = native.blh_gemm_f32(st, a.data_ptr(), A.shape[1], ak, b.data_ptr(), B.shape[1], bk,
+                             c.data_ptr(), N, M, N, K, splits, None, None, 0)
+    assert rc == 0, native.blh_status_string(rc)
+    if splits > 1:
+        out = torch.empty(M, N, device=dev)
+        rc = native.blh_sum_slabs(st, c.data_ptr(), M * N, splits, out.data_ptr())
+        assert rc == 0
+    else:
+        out = c[0]
+    torch.cuda.synchronize()
+    _close(out.cpu().numpy(), ref, 2e-5, "gemm")
+
+
+def test_gemm_bias_and_addend(native):
+    dev = _dev()
+    rng = np.random.RandomState(5)
+    M, N, K = 260, 384, 96
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Wt = rng.standard_normal((N, K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    add = rng.standard_normal((M, N)).astype(np.float32)
+    a, w = torch.from_numpy(A).to(dev), torch.from_numpy(Wt).to(dev)
+    bt, at = torch.from_numpy(bias).to(dev), torch.from_numpy(add).to(dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    c = torch.empty(M, N, device=dev)
+    assert native.blh_gemm_f32(st, a.data_ptr(), K, 0, w.data_ptr(), K, 0, c.data_ptr(), N, M, N, K,
+                               1, bt.data_ptr(), None, 0) == 0
+    torch.cuda.synchronize()
+    _close(c.cpu().numpy(), A.astype(np.float64) @ Wt.T.astype(np.float64) + bias, 2e-5, "bias")
+    # dgrad-with-residual form: C = A * B[K,N] + addend, in place on the addend buffer
+    Bk = rng.standard_normal((K, N)).astype(np.float32)
+    bk = torch.from_numpy(Bk).to(dev)
+    assert native.blh_gemm_f32(st, a.data_ptr(), K, 0, bk.data_ptr(), N, 1, at.data_ptr(), N, M, N, K,
+                               1, None, at.data_ptr(), N) == 0
+    torch.cuda.synchronize()
+    _close(at.cpu().numpy(), A.astype(np.float64) @ Bk.astype(np.float64) + add, 2e-5, "addend")
+
+
+# ----------------------------------------------------------------------------
+# module level against the reference's golden vectors
+# ----------------------------------------------------------------------------
+def _build(g, dev, num_blocks=2, width=1024, state=None):
+    import bilinear_amd
+    net = bilinear_amd.BilinearUnit(num_blocks=num_blocks, width=width)
+    st = state if state is not None else g.init_state()
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(st.keys())
+    net.load_state_dict({k: torch.from_numpy(np.array(st[k])).reshape(sd[k].shape) for k in sd})
+    net = net.to(dev)
+    opt = bilinear_amd.Adam(net.parameters(), lr=1e-3, module=net)
+    net.train()
+    return net, opt
+
+
+def _compare_step(g, s, net, opt, raw, clipped, pred, loss, total_norm, rtol):
+    worst = 0.0
+    worst = max(worst, _close(pred.detach().cpu().numpy(), g.arr("step%d/pred" % s), rtol, "pred"))
+    assert abs(float(loss) - g.scalar("step%d/loss" % s)) <= rtol * g.scalar("step%d/loss" % s)
+    tn = g.scalar("step%d/total_norm" % s)
+    assert abs(float(total_norm) - tn) <= rtol * tn
+    for k, p in net.named_parameters():
+        if is_prebn_bias(k):
+            if raw is not None:
+                assert np.abs(raw[k]).max() < 1e-5, k      # hazard H2: mathematically zero
+            continue
+        if raw is not None:
+            worst = max(worst, g.compare("step%d/grad_raw" % s, k, raw[k], rtol) * rtol)
+        worst = max(worst, g.compare("step%d/grad_clipped" % s, k, clipped[k], rtol) * rtol)
+        stp = opt.state[p]
+        g.compare("step%d/exp_avg" % s, k, stp["exp_avg"].cpu().numpy(), rtol)
+        g.compare("step%d/exp_avg_sq" % s, k, stp["exp_avg_sq"].cpu().numpy(), 2 * rtol)
+        g.compare("step%d/state" % s, k, p.detach().cpu().numpy(), rtol,
+                  atol_abs=g.adam_atol(s, k, rtol, p.numel()))
+    sd = net.state_dict()
+    for k in sd:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            g.compare("step%d/state" % s, k, sd[k].cpu().numpy(), rtol)
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(g.arr("step%d/state/%s/full" % (s, k)))
+    return worst
+
+
+@pytest.mark.parametrize("fname", FIXTURES)
+def test_dropin_steps_match_reference(fname):
+    """The reference's own step body (train_bilinear.py:66-83) on the drop-in surface:
+    zero_grad, forward, nn.MSELoss, backward, clip_grad_norm_, Adam.step."""
+    import bilinear_amd
+    dev = _dev()
+    g = Golden(fname)
+    net, opt = _build(g, dev)
+    criterion = torch.nn.MSELoss()
+    step = 1
+    for s in range(g.steps):
+        x, t = g.batch_xy(s)
+        if O.lr_decay_condition(step):
+            for pg in opt.param_groups:
+                pg["lr"] = O.lr_decay_function(step)
+        net.engine.set_dropout_masks(g.masks(s))
+        xt, tt = torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev)
+        opt.zero_grad()
+        pred = net(xt)
+        loss = criterion(pred, tt)
+        loss.backward()
+        raw = {k: p.grad.detach().cpu().numpy().copy() for k, p in net.named_parameters()}
+        total_norm = bilinear_amd.clip_grad_norm_(net.parameters(), max_norm=1, module=net)
+        clipped = {k: p.grad.detach().cpu().numpy().copy() for k, p in net.named_parameters()}
+        opt.step()
+        step += 1
+        rtol = RTOL if s else TIGHT
+        worst = _compare_step(g, s, net, opt, raw, clipped, pred, loss.item(), total_norm.item(), rtol)
+        print("step %d worst normalised error %.2e" % (s, worst))
+    net.eval()
+    with torch.set_grad_enabled(False):
+        pe = net(torch.from_numpy(g.arr("eval/x")).to(dev))
+    ref = g.arr("eval/pred")
+    assert np.abs(pe.cpu().numpy() - ref).max() <= 5e-3 * np.sqrt((ref ** 2).mean()) + 5e-3
+
+
+@pytest.mark.parametrize("fname", FIXTURES)
+def test_fused_train_step_matches_reference(fname):
+    """The same steps through the one-enqueue fast path (blh_train_step)."""
+    dev = _dev()
+    g = Golden(fname)
+    net, opt = _build(g, dev)
+    step = 1
+    for s in range(g.steps):
+        x, t = g.batch_xy(s)
+        if O.lr_decay_condition(step):
+            for pg in opt.param_groups:
+                pg["lr"] = O.lr_decay_function(step)
+        net.engine.set_dropout_masks(g.masks(s))
+        pred, loss = net.train_step(opt, torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev),
+                                    max_norm=1.0)
+        step += 1
+        clipped = {k: p.grad.detach().cpu().numpy().copy() for k, p in net.named_parameters()}
+        stats = opt.last_grad_norm_stats.cpu().numpy()
+        _compare_step(g, s, net, opt, None, clipped, pred, loss.item(), stats[0], RTOL if s else TIGHT)
+
+
+def test_eval_forward_matches_oracle():
+    """valid_bilinear.py:31,52 — eval mode uses running statistics, no dropout."""
+    dev = _dev()
+    g = Golden(FIXTURES[0])
+    st = g.init_state()
+    rng = np.random.RandomState(3)
+    for k in st:        # non-trivial running statistics
+        if k.endswith("running_mean"):
+            st[k] = rng.standard_normal(st[k].shape).astype(np.float32) * 0.3
+        if k.endswith("running_var"):
+            st[k] = (0.5 + rng.random_sample(st[k].shape)).astype(np.float32)
+    net, _ = _build(g, dev, state=st)
+    net.eval()
+    x, _ = O.synthetic_batch(77, 333)
+    with torch.no_grad():
+        pred = net(torch.from_numpy(x).to(dev))
+    ref, _ = O.forward(st, x, None, training=False, dtype=np.float64)
+    _close(pred.cpu().numpy(), ref, TIGHT, "eval pred")
+
+
+# ----------------------------------------------------------------------------
+# other shapes against the oracle (the reference cannot express them)
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("nb,width,batch", [(1, 256, 100), (3, 512, 257), (2, 1024, 30), (0, 128, 64)])
+def test_general_shapes_against_oracle(nb, width, batch):
+    dev = _dev()
+    st = O.init_state(100 + nb, nb, width)
+    rng = np.random.RandomState(nb * 7 + 1)
+    for k in st:        # make gamma/beta non-trivial so their gradients are exercised
+        if k.endswith(".1.weight"):
+            st[k] = (1.0 + 0.2 * rng.standard_normal(st[k].shape)).astype(np.float32)
+        if k.endswith(".1.bias"):
+            st[k] = (0.1 * rng.standard_normal(st[k].shape)).astype(np.float32)
+    net, opt = _build(None, dev, nb, width, state={k: v.copy() for k, v in st.items()})
+    x, t = O.synthetic_batch(5, batch)
+    masks = O.random_masks(9, batch, nb, width)
+    net.engine.set_dropout_masks(masks)
+    xt, tt = torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev)
+    pred = net(xt)
+    loss = torch.nn.functional.mse_loss(pred, tt)
+    loss.backward()
+    ref_pred, cache = O.forward(st, x, masks, training=True, dtype=np.float64)
+    ref_loss, dpred = O.mse_loss(ref_pred, t.astype(np.float64))
+    ref_grads = O.backward(st, cache, dpred, dtype=np.float64)
+    _close(pred.detach().cpu().numpy(), ref_pred, TIGHT, "pred")
+    assert abs(loss.item() - ref_loss) <= TIGHT * ref_loss
+    for k, p in net.named_parameters():
+        if is_prebn_bias(k):
+            continue
+        _close(p.grad.cpu().numpy(), ref_grads[k], TIGHT * 3, "grad " + k)
+    sd = net.state_dict()
+    for k in sd:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            _close(sd[k].cpu().numpy(), st[k], TIGHT, k)     # O.forward updated st in place
+
+
+# ----------------------------------------------------------------------------
+# Philox dropout: the mask backward regenerates is the one forward applied
+# ----------------------------------------------------------------------------
+def _philox_masks(native, net, step, batch):
+    from bilinear_amd import _native as N
+    eng = net.engine
+    out = []
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for layer in range(eng.layout.num_heavy):
+        m = torch.empty(batch, eng.width, dtype=torch.uint8, device=eng.device)
+        d = N.Dropout(None, eng.seed, step, eng.row_offset)
+        assert native.blh_dropout_mask(st, ctypes.byref(d), layer, batch, eng.width, m.data_ptr()) == 0
+        out.append(m.cpu().numpy())
+    return out
+
+
+def test_philox_dropout_forward_backward_consistent(native):
+    dev = _dev()
+    nb, width, batch = 2, 1024, 96
+    st = O.init_state(41, nb, width)
+    net, opt = _build(None, dev, nb, width, state={k: v.copy() for k, v in st.items()})
+    net.engine.seed = 1234567
+    x, t = O.synthetic_batch(8, batch)
+    xt, tt = torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev)
+    step0 = net.engine.rng_step
+    pred = net(xt)
+    torch.nn.functional.mse_loss(pred, tt).backward()
+    masks = _philox_masks(native, net, step0, batch)
+    rate = np.mean([m.mean() for m in masks])
+    assert abs(rate - 0.5) < 0.01, rate
+    assert not np.array_equal(masks[0], masks[1])
+    ref_pred, cache = O.forward(st, x, masks, training=True, dtype=np.float64)
+    _, dpred = O.mse_loss(ref_pred, t.astype(np.float64))
+    ref_grads = O.backward(st, cache, dpred, dtype=np.float64)
+    _close(pred.detach().cpu().numpy(), ref_pred, TIGHT, "pred (philox)")
+    for k, p in net.named_parameters():
+        if not is_prebn_bias(k):
+            _close(p.grad.cpu().numpy(), ref_grads[k], TIGHT * 3, "grad " + k)
+    # next step draws a different mask; same step + seed reproduces it
+    m2 = _philox_masks(native, net, step0 + 1, batch)
+    assert not np.array_equal(m2[0], masks[0])
+    again = _philox_masks(native, net, step0, batch)
+    assert all(np.array_equal(a, b) for a, b in zip(again, masks))
+
+
+def test_philox_mask_independent_of_sharding(native):
+    """Rows [64,128) generated with row_offset=64 equal rows 64.. of the unsharded mask
+    (data-parallel ranks see the mask of the global batch)."""
+    from bilinear_amd import _native as N
+    dev = _dev()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    full = torch.empty(128, 256, dtype=torch.uint8, device=dev)
+    part = torch.empty(64, 256, dtype=torch.uint8, device=dev)
+    assert native.blh_dropout_mask(st, ctypes.byref(N.Dropout(None, 9, 3, 0)), 2, 128, 256, full.data_ptr()) == 0
+    assert native.blh_dropout_mask(st, ctypes.byref(N.Dropout(None, 9, 3, 64)), 2, 64, 256, part.data_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(full[64:], part)
+
+
+# ----------------------------------------------------------------------------
+# full benchmark size (B = 4096): size-independent properties
+# ----------------------------------------------------------------------------
+def test_full_size_properties():
+    dev = _dev()
+    import bilinear_amd
+    torch.manual_seed(0)
+    net, opt, step, _ = bilinear_amd.load(dev)
+    net.train()
+    B = 4096
+    x = torch.randn(B, 32, device=dev)
+    t = torch.randn(B, 48, device=dev)
+    # (1) backward is linear in d(pred): grads(2*dpred) == 2*grads(dpred)
+    net.engine.seed = 5
+    net.engine.rng_step = 0
+    pred = net(x)
+    dp = torch.randn_like(pred) / B
+    pred.backward(dp)
+    g1 = net.engine.grads.clone()
+    opt.zero_grad()
+    net.engine.rng_step = 0
+    pred2 = net(x)
+    assert torch.equal(pred, pred2)                  # same seed/step -> same dropout -> bit-equal
+    pred2.backward(2 * dp)
+    g2 = net.engine.grads.clone()
+    rel = ((g2 - 2 * g1).norm() / g2.norm()).item()
+    assert rel < 1e-5, rel
+    # (2) batch-norm outputs: every pre-activation column has zero mean/unit variance, so the
+    #     gradient of each pre-BN Linear bias is (numerically) zero
+    lay = net.engine.layout
+    for name, off, shape in lay.entries:
+        if is_prebn_bias(name):
+            assert net.engine.grads[off:off + shape[0]].abs().max().item() < 1e-6
+    # (3) the fused step learns: loss on a fixed batch goes down
+    opt.zero_grad()
+    losses = []
+    for _ in range(30):
+        _, loss = net.train_step(opt, x, t, max_norm=1.0)
+        losses.append(loss.item())
+    assert losses[-1] < losses[0] * 0.9, losses
+    assert all(np.isfinite(losses))
+    # (4) eval after training is finite and deterministic
+    net.eval()
+    with torch.no_grad():
+        a, b = net(x), net(x)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
+def test_cpu_input_is_rejected():
+    import bilinear_amd
+    net = bilinear_amd.BilinearUnit()
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(4, 32))
