@@ -90,6 +90,28 @@ def gemm_rooflines(batch, width, reps):
     return out
 
 
+def log(msg):
+    print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def host_cores():
+    """CPU share of this process (the GPU box gives one GPU's share of a bigger host)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:   # cgroup v2 quota
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,7 +121,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=2)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=20)
+    ap.add_argument("--cpu-steps", type=int, default=12)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,6 +151,7 @@ def main():
             return dp.train_step(x, t)
         return net.train_step(opt, x, t, max_norm=1.0)
 
+    log("model built, warm-up")
     for _ in range(args.warmup):
         one_step()
     if world > 1:
@@ -146,6 +169,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     final_loss = float(loss.item())
+    log("timed %d steps: %.3f ms/step" % (args.steps, 1e3 * elapsed / args.steps))
 
     # fwd+bwd only (no optimiser), single rank view, for the record
     def fwd_bwd():
@@ -162,7 +186,9 @@ def main():
         ms = 1e3 * elapsed / args.steps
         poses = args.batch * world * args.steps / elapsed
         fwd, bwd = flops_per_pose(args.blocks, args.width)
+        log("fwd+bwd only: %.3f ms" % fb_ms)
         kern = gemm_rooflines(args.batch, args.width, reps=20)
+        log("kernel timings: %s" % json.dumps(kern))
         dom = kern["linear_fwd"]
         result = {
             "metric": "poses/sec (fwd+bwd, 16-joint, batch 4096) at 1/2/4/8 MI355X",
@@ -207,7 +233,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import torch_port as TP
-            cores = os.cpu_count() or 1
+            cores = host_cores()
+            log("cpu baseline on %d threads" % cores)
             cpu = TP.time_cpu_steps(args.blocks, args.width, args.batch, steps=args.cpu_steps,
                                     warmup=2, threads=cores)
             result["cpu_baseline"] = {
