@@ -1,0 +1,308 @@
+// fp32 MFMA GEMM for gfx950 — device templates (included by gemm_f32.hip and tools/) (MI355X), the dominant kernel of the lifter MLP.
+//
+//   C[M,N] = A (M x K) * B (K x N), fp32 in / fp32 accumulate on
+//   v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain, no TF32 exists
+//   on gfx950).  Peak 157.3 TFLOP/s (64 FLOP/clk/SIMD).
+//
+// One kernel template serves the three contractions of a Linear layer
+// (reference call-sites: nn.Linear in /root/reference/model/bilinear.py:9,29 and
+// its autograd, train_bilinear.py:79):
+//   forward  Z  = A  W^T        A=[B,K] ROWK , W=[N,K]  ROWK
+//   dgrad    dA = dZ W          dZ=[B,N'] ROWK, W=[N',K'] KROW (reduction index is W's row)
+//   wgrad    dW = dZ^T A        dZ=[B,N'] KROW, A=[B,K'] KROW (reduction over the batch)
+// ROWK = the reduction index is the contiguous one in memory; KROW = the
+// output index is contiguous.
+//
+// Data movement per workgroup (256 threads = 4 waves of 64):
+//   HBM/L2 --global_load_dwordx4 (16 B/lane, coalesced along the contiguous
+//   axis)--> VGPR --ds_write_b128--> LDS tile (double buffered, one barrier per
+//   32-deep K tile) --ds_read_b128 (ROWK, 36-float padded rows: conflict-free)
+//   or ds_read_b32 (KROW, 32 consecutive lanes = 32 consecutive banks)--> MFMA.
+//   The next K tile's global loads are issued before the current tile's MFMAs
+//   and written to the other LDS stage after them, so HBM/L2 latency hides
+//   under 64 MFMAs (4096 cycles) per wave.
+// Each wave owns a (BM/WM) x (BN/WN) sub-tile as TM x TN accumulators of 32x32.
+//
+// Fragment/k ordering: a lane of half h = lane>>5 reads 4 consecutive k
+// (8s+4h .. 8s+4h+3) of its row; MFMA j of group s therefore contracts
+// k = 8s+j (half 0) and 8s+4+j (half 1).  Both operands use the same map, so
+// the permutation of k inside a group is immaterial.
+#pragma once
+#include "common.h"
+
+namespace blh {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int BK = 32;
+static constexpr int ROWK_PITCH = BK + 4;   // floats; 36*4 B rows -> ds_read_b128 conflict-free
+
+template <int LAYOUT, int R>
+struct TileGeom {
+  static constexpr int LDS_FLOATS = (LAYOUT == ROWK) ? R * ROWK_PITCH : BK * R;
+};
+
+// ---- global -> registers ----------------------------------------------------
+template <int LAYOUT, int R, int NT>
+struct TileIO {
+  static constexpr int CHUNKS = (R * BK / 4) / NT;   // float4 chunks per thread
+  static_assert((R * BK / 4) % NT == 0, "tile not divisible among threads");
+
+  // rows_limit: number of valid rows of this operand (M or N); k_end: end of the
+  // reduction range of this workgroup.
+  __device__ static inline void load(float4 (&reg)[CHUNKS], const float* __restrict__ base,
+                                     int64_t ld, int row0, int rows_limit, int k0, int k_end,
+                                     int tid) {
+#pragma unroll
+    for (int p = 0; p < CHUNKS; ++p) {
+      const int q = tid + p * NT;
+      int row, k;
+      if (LAYOUT == ROWK) {
+        row = row0 + (q >> 3);
+        k = k0 + ((q & 7) << 2);
+      } else {
+        constexpr int CPR = R / 4;
+        row = row0 + ((q % CPR) << 2);
+        k = k0 + (q / CPR);
+      }
+      const bool ok = (row < rows_limit) && (k < k_end);
+      const int64_t off = (LAYOUT == ROWK) ? ((int64_t)row * ld + k) : ((int64_t)k * ld + row);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) v = *reinterpret_cast<const float4*>(base + off);
+      reg[p] = v;
+    }
+  }
+
+  __device__ static inline void store(const float4 (&reg)[CHUNKS], float* lds, int tid) {
+#pragma unroll
+    for (int p = 0; p < CHUNKS; ++p) {
+      const int q = tid + p * NT;
+      int idx;
+      if (LAYOUT == ROWK) {
+        idx = (q >> 3) * ROWK_PITCH + ((q & 7) << 2);
+      } else {
+        constexpr int CPR = R / 4;
+        idx = (q / CPR) * R + ((q % CPR) << 2);
+      }
+      *reinterpret_cast<float4*>(lds + idx) = reg[p];
+    }
+  }
+};
+
+// ---- LDS -> MFMA fragments for k-group s (8 consecutive k) -----------------
+// frag[t][j]: operand value of 32-row sub-tile t for MFMA j of the group.
+template <int LAYOUT, int R, int T>
+__device__ inline void read_frags(float (&frag)[T][4], const float* lds, int row_base, int s,
+                                  int lane) {
+  const int h = lane >> 5, lr = lane & 31;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    if (LAYOUT == ROWK) {
+      const float4 v = *reinterpret_cast<const float4*>(
+          lds + (row_base + t * 32 + lr) * ROWK_PITCH + 8 * s + 4 * h);
+      frag[t][0] = v.x; frag[t][1] = v.y; frag[t][2] = v.z; frag[t][3] = v.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        frag[t][j] = lds[(8 * s + 4 * h + j) * R + row_base + t * 32 + lr];
+    }
+  }
+}
+
+// XCD-aware, bijective remap of the linear workgroup id: workgroups b, b+8, ...
+// share an XCD (and its 4 MiB L2); give each XCD a contiguous range of tiles so
+// neighbouring tiles (same A row panel) hit the same L2.
+__device__ inline int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmParams p) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static_assert(TM >= 1 && TN >= 1, "wave tile must be at least 32x32");
+  constexpr int A_FLOATS = TileGeom<LA, BM>::LDS_FLOATS;
+  constexpr int B_FLOATS = TileGeom<LB, BN>::LDS_FLOATS;
+  constexpr int STAGE = A_FLOATS + B_FLOATS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kz0 = blockIdx.z * p.k_per_split;
+  const int k_end = min(p.K, kz0 + p.k_per_split);
+  float* __restrict__ C = p.C + (int64_t)blockIdx.z * p.c_split_stride;
+
+  using IOA = TileIO<LA, BM, NT>;
+  using IOB = TileIO<LB, BN, NT>;
+  float4 ra[IOA::CHUNKS], rb[IOB::CHUNKS];
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nkt = (k_end - kz0 + BK - 1) / BK;
+  if (nkt > 0) {
+    IOA::load(ra, p.A, p.lda, m0, p.M, kz0, k_end, tid);
+    IOB::load(rb, p.B, p.ldb, n0, p.N, kz0, k_end, tid);
+    IOA::store(ra, smem, tid);
+    IOB::store(rb, smem + A_FLOATS, tid);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const float* sA = smem + (kt & 1) * STAGE;
+    const float* sB = sA + A_FLOATS;
+    const bool more = (kt + 1 < nkt);
+    if (more) {
+      const int k0 = kz0 + (kt + 1) * BK;
+      IOA::load(ra, p.A, p.lda, m0, p.M, k0, k_end, tid);
+      IOB::load(rb, p.B, p.ldb, n0, p.N, k0, k_end, tid);
+    }
+#pragma unroll
+    for (int s = 0; s < BK / 8; ++s) {
+      float fa[TM][4], fb[TN][4];
+      read_frags<LA, BM, TM>(fa, sA, wm * (TM * 32), s, lane);
+      read_frags<LB, BN, TN>(fb, sB, wn * (TN * 32), s, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn)
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[jn][j], acc[i][jn], 0, 0, 0);
+      if (s == 1 && more) {
+        // the other stage was last read in iteration kt-1 (a barrier ago): safe to fill now,
+        // while this tile's remaining MFMAs cover the LDS write latency
+        float* dA = smem + ((kt + 1) & 1) * STAGE;
+        IOA::store(ra, dA, tid);
+        IOB::store(rb, dA + A_FLOATS, tid);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------- epilogue --
+  const int h = lane >> 5, lc = lane & 31;
+  const int row_w = m0 + wm * (TM * 32) + 4 * h;   // + tm*32 + (r&3) + 8*(r>>2)
+  const int col_w = n0 + wn * (TN * 32) + lc;      // + tn*32
+
+  if (EPI == EPI_BIAS || EPI == EPI_BIAS_STATS || EPI == EPI_MSE) {
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+      const int col = col_w + jn * 32;
+      const float bv = (col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][jn][r] += bv;
+    }
+  }
+
+  if (EPI == EPI_BIAS_STATS) {
+    // Per-tile column statistics in the shifted (Welford/Chan) form: tile mean and
+    // M2 = sum (z - tile_mean)^2, merged across tiles by bn_fwd_finalize.  Avoids the
+    // cancellation of sum(z^2) - sum(z)^2/n at large batch (SURVEY.md hazard H1).
+    float* red = smem;   // [WM][BN]; stage buffers are dead (barrier closed the main loop)
+    const int cnt = min(BM, p.M - m0);
+    float mean[TN];
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2);
+          if (row < p.M) s += acc[i][jn][r];
+        }
+      s += __shfl_xor(s, 32);
+      if (h == 0) red[wm * BN + wn * (TN * 32) + jn * 32 + lc] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) t += red[w * BN + wn * (TN * 32) + jn * 32 + lc];
+      mean[jn] = t / (float)cnt;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2);
+          const float dlt = acc[i][jn][r] - mean[jn];
+          if (row < p.M) s += dlt * dlt;
+        }
+      s += __shfl_xor(s, 32);
+      if (h == 0) red[wm * BN + wn * (TN * 32) + jn * 32 + lc] = s;
+    }
+    __syncthreads();
+    if (wm == 0 && h == 0) {
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) {
+        const int col = col_w + jn * 32;
+        float m2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) m2 += red[w * BN + wn * (TN * 32) + jn * 32 + lc];
+        if (col < p.N) {
+          p.stat_part[((int64_t)tile_m * 2 + 0) * p.N + col] = mean[jn];
+          p.stat_part[((int64_t)tile_m * 2 + 1) * p.N + col] = m2;
+        }
+      }
+    }
+  }
+
+  float lsum = 0.f;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) {
+        const int col = col_w + jn * 32;
+        if (row < p.M && col < p.N) {
+          float v = acc[i][jn][r];
+          if (EPI == EPI_ADD) v += p.addend[(int64_t)row * p.ldadd + col];
+          C[(int64_t)row * p.ldc + col] = v;
+          if (EPI == EPI_MSE) {
+            const float d = v - p.target[(int64_t)row * p.ldt + col];
+            p.dpred[(int64_t)row * p.lddp + col] = d * p.mse_scale;
+            lsum += d * d;
+          }
+        }
+      }
+    }
+
+  if (EPI == EPI_MSE) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) lsum += __shfl_xor(lsum, o);
+    float* red = smem;
+    __syncthreads();
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+      for (int w = 0; w < WM * WN; ++w) t += red[w];
+      p.loss_part[blockIdx.x] = t;
+    }
+  }
+}
+
+}  // namespace blh

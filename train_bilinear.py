@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Counterpart of the reference's training script (/root/reference/train_bilinear.py) on
+the MI355X implementation.  Same step order — lr-decay check on the pre-increment
+step (:66-70), zero_grad, forward, MSELoss, backward, clip_grad_norm_(1), Adam.step
+(:75-83) — same checkpoint dict and path (:92-104), 10 epochs per invocation (:56).
+
+Human3.6M, dotmap, tensorboardX and vectormath are not available here, so the data
+come from a synthetic loader with the real loader's output contract (z-scored fp32
+[B,32] / [B,48], H36M/data.py:108-110) and the config values of util/config.py:13-25
+are plain constants below.
+
+    python train_bilinear.py [--fast] [--epochs N] [--steps-per-epoch N]
+
+--fast uses BilinearUnit.train_step (one native enqueue per step) instead of the
+reference's five separate calls; the numerics are the same.
+"""
+import argparse
+import logging
+import os
+
+import torch
+import torch.nn as nn
+
+import bilinear_amd
+from bilinear_amd.data import SyntheticPoses
+
+# util/config.py:13-25
+COMMENT = "Bilinear GT"
+BATCH_SIZE = 64
+LR_DECAY_ACTIVATE = True
+
+
+def lr_decay_condition(step):
+    return step % 100000 == 0 or step == 1
+
+
+def lr_decay_function(step):
+    return 1.0e-3 * 0.96 ** (step / 100000)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fast", action="store_true")
+    ap.add_argument("--epochs", type=int, default=10)
+    ap.add_argument("--steps-per-epoch", type=int, default=200)
+    ap.add_argument("--batch-size", type=int, default=BATCH_SIZE)
+    ap.add_argument("--save-root", default="save")
+    args = ap.parse_args()
+
+    logging.basicConfig(level=logging.INFO, format="[%(levelname)s|%(filename)s:%(lineno)s] %(asctime)s > %(message)s")
+    logger = logging.getLogger("train_bilinear")
+    if not torch.cuda.is_available():
+        raise SystemExit("train_bilinear.py needs a HIP device (MI355X); there is no CPU path")
+    device = torch.device("cuda")
+    log_dir = os.path.join(args.save_root, COMMENT)
+    parameter_dir = os.path.join(log_dir, "parameter")
+
+    data = SyntheticPoses(args.steps_per_epoch, args.batch_size, device)
+    bilinear, optimizer, step, train_epoch = bilinear_amd.load(
+        device=device, parameter_dir=parameter_dir if os.path.exists(parameter_dir) else None)
+    criterion = nn.MSELoss()
+    bilinear.train()
+
+    for epoch in range(train_epoch + 1, train_epoch + args.epochs + 1):
+        loss = None
+        for in_image_space, in_camera_space in data.epoch(epoch):
+            if LR_DECAY_ACTIVATE and lr_decay_condition(step):
+                lr = lr_decay_function(step)
+                logger.info("Learning rate decay to %s (step: %d)", lr, step)
+                for param_group in optimizer.param_groups:
+                    param_group["lr"] = lr
+            if args.fast:
+                _, loss = bilinear.train_step(optimizer, in_image_space, in_camera_space, max_norm=1.0)
+            else:
+                optimizer.zero_grad()
+                prediction = bilinear(in_image_space)
+                loss = criterion(prediction, in_camera_space)
+                loss.backward()
+                bilinear_amd.clip_grad_norm_(bilinear.parameters(), max_norm=1, module=bilinear)
+                optimizer.step()
+            step = step + 1
+        os.makedirs(parameter_dir, exist_ok=True)
+        torch.save({"epoch": epoch, "step": step, "state": bilinear.state_dict(),
+                    "optimizer": optimizer.state_dict()},
+                   os.path.join(parameter_dir, "%d.save" % epoch))
+        logger.info("Epoch %d saved (loss: %f)", epoch, float(loss.item()))
+
+
+if __name__ == "__main__":
+    main()
