@@ -102,6 +102,15 @@ static Splits pick_splits(int64_t batch, int64_t tiles) {
   return Splits{(int)s, (int)k_per};
 }
 
+// decode forward: split W so that (B/128) * splits is about one workgroup per CU
+static Splits decode_fwd_splits(int64_t batch, int W) {
+  int64_t want = std::max<int64_t>(1, ceil_div(256, ceil_div(batch, 128)));
+  int64_t s = std::min<int64_t>(want, std::max<int64_t>(1, W / 128));
+  int64_t k_per = round_up(ceil_div(W, s), 32);
+  s = ceil_div(W, k_per);
+  return Splits{(int)s, (int)k_per};
+}
+
 static int64_t slab_floats(const blh_model_desc* d, int64_t batch) {
   const int64_t W = d->width;
   const Splits hs = pick_splits(batch, ceil_div(W, 128) * ceil_div(W, 128));
@@ -110,6 +119,7 @@ static int64_t slab_floats(const blh_model_desc* d, int64_t batch) {
   int64_t m = hs.splits * W * W;
   m = std::max(m, es.splits * W * (int64_t)d->in_features);
   m = std::max(m, ds.splits * (int64_t)d->out_features * W);
+  m = std::max(m, decode_fwd_splits(batch, d->width).splits * batch * d->out_features);
   return m;
 }
 
@@ -201,21 +211,19 @@ static int forward_impl(const blh_model_desc* d, hipStream_t s, const float* par
                                    ws.A[i], batch, W));
     }
   }
+  // decode (model/bilinear.py:39): N = 48 gives only B/128 output tiles, so the reduction
+  // over W is split across workgroups (slabs) and a small kernel adds the slabs, the bias and,
+  // in the fused step, the MSE loss / gradient (train_bilinear.py:78).
+  const int OF = d->out_features;
+  const Splits sp = decode_fwd_splits(batch, W);
   GemmParams g{};
   g.A = ws.A[nh - 1]; g.lda = W;
   g.B = params + L.dec_w; g.ldb = W;
-  g.C = pred; g.ldc = d->out_features;
-  g.M = (int)batch; g.N = d->out_features; g.K = W; g.k_per_split = W;
-  g.bias = params + L.dec_b;
-  if (target) {
-    g.target = target; g.ldt = d->out_features;
-    g.dpred = ws.dpred; g.lddp = d->out_features;
-    g.mse_scale = mse_scale; g.loss_part = loss_part;
-    *loss_nparts = gemm_grid_blocks(TILE_128x64, (int)batch, d->out_features);
-    if (*loss_nparts > 4096) return BLH_ERR_SHAPE;
-    return launch_gemm(s, TILE_128x64, ROWK, ROWK, EPI_MSE, g, 1);
-  }
-  return launch_gemm(s, TILE_128x64, ROWK, ROWK, EPI_BIAS, g, 1);
+  g.C = ws.slabs; g.ldc = OF; g.c_split_stride = batch * OF;
+  g.M = (int)batch; g.N = OF; g.K = W; g.k_per_split = sp.k_per;
+  BLH_TRY(launch_gemm(s, TILE_128x64, ROWK, ROWK, EPI_STORE, g, sp.splits));
+  return launch_decode_finish(s, ws.slabs, sp.splits, batch, OF, params + L.dec_b, pred, target,
+                              mse_scale, target ? ws.dpred : nullptr, loss_part, loss_nparts);
 }
 
 // ------------------------------------------------------------ backward -----

@@ -73,8 +73,8 @@ struct DropoutSrc {
   int layer;
 };
 
-static constexpr int EW_COLS_PER_BLOCK = 1024;   // 256 threads x float4
-int ew_row_chunk(int64_t batch);                 // rows handled by one block (multiple of 16)
+static constexpr int EW_COLS_PER_BLOCK = 256;    // 64 lanes x float4, 4 waves share the rows
+int ew_row_chunk(int64_t batch);                 // rows handled by one block (multiple of 32)
 int ew_num_row_chunks(int64_t batch);
 
 // forward BN: merge per-tile (mean, M2) -> batch mean / invstd, scale/shift, running stats
@@ -123,6 +123,10 @@ int launch_clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int6
                      float* stats_out);
 int launch_clip_scale(hipStream_t s, float* g, int64_t count, float max_norm,
                       const double* sumsq_part, int nparts, float* stats_out);
+// pred = sum(slabs) + bias (+ fused MSE when target != nullptr)
+int launch_decode_finish(hipStream_t s, const float* slabs, int splits, int64_t batch,
+                         int out_features, const float* bias, float* pred, const float* target,
+                         float scale, float* dpred, float* loss_part, int* nparts);
 int launch_dropout_mask(hipStream_t s, uint8_t* out, int64_t batch, int W, const DropoutSrc& drop);
 static constexpr int SUMSQ_MAX_PARTS = 1024;
 

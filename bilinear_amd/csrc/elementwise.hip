@@ -15,9 +15,8 @@ static constexpr int EW_THREADS = 256;
 static constexpr float BN_EPS = 1e-5f;
 
 int ew_row_chunk(int64_t batch) {
-  // <= 512 row chunks; 16 rows minimum (half a Philox patch), multiples of 32 above
-  if (batch <= 16 * 512) return 16;
-  return (int)round_up(ceil_div(batch, 512), 32);
+  // whole 32-row Philox patches; at most 128 row chunks (partials of the column sums)
+  return (int)(32 * std::max<int64_t>(1, ceil_div(batch, 32 * 128)));
 }
 int ew_num_row_chunks(int64_t batch) { return (int)ceil_div(batch, ew_row_chunk(batch)); }
 
@@ -109,6 +108,62 @@ int launch_bn_fwd_finalize(hipStream_t s, const float* stat_part, int tiles, int
 }
 
 // ---------------------------------------------------------------------------
+// Streaming kernels over [B,W] tensors.  Block = 256 threads = 4 waves; a block owns a
+// tile of 256 columns (64 lanes x float4: a wave reads 1 KiB contiguous per row) x
+// `row_chunk` rows (a multiple of 32).  Inside each 32-row patch wave w takes rows
+// w, w+4, ..., w+28: eight independent 16-B loads per tensor in flight per lane
+// (>= 32 KiB per block), and one Philox call (32 rows x 4 columns) per lane per patch.
+// ---------------------------------------------------------------------------
+static constexpr int PATCH_ROWS = 32;
+static constexpr int ROWS_PER_LANE = 8;     // PATCH_ROWS / 4 waves
+
+struct PatchMask {
+  uint32_t nib[ROWS_PER_LANE];
+};
+
+// keep nibbles of this lane's 8 rows of the patch starting at local row `base`
+__device__ __forceinline__ PatchMask patch_mask(const DropoutSrc& d, int64_t base, int w, int col,
+                                                int W, int64_t batch) {
+  PatchMask m;
+  if (d.keep) {
+#pragma unroll
+    for (int i = 0; i < ROWS_PER_LANE; ++i) {
+      const int64_t r = base + w + 4 * i;
+      uint32_t n = 0;
+      if (r < batch) {
+        const uchar4 k = *reinterpret_cast<const uchar4*>(d.keep + r * (int64_t)W + col);
+        n = (k.x ? 1u : 0u) | (k.y ? 2u : 0u) | (k.z ? 4u : 0u) | (k.w ? 8u : 0u);
+      }
+      m.nib[i] = n;
+    }
+  } else {
+    const Philox128 p = dropout_patch(d.seed, d.step, d.layer, base + d.row_offset, col);
+    // row w + 4i (w < 4): word i>>1 (compile-time), nibble w + 4*(i&1)
+#pragma unroll
+    for (int i = 0; i < ROWS_PER_LANE; ++i) m.nib[i] = (p.w[i >> 1] >> (4 * (w + 4 * (i & 1)))) & 0xFu;
+  }
+  return m;
+}
+
+__device__ __forceinline__ float4 relu_bn(float4 z, float4 sc, float4 sh) {
+  float4 a;
+  a.x = fmaxf(fmaf(z.x, sc.x, sh.x), 0.f); a.y = fmaxf(fmaf(z.y, sc.y, sh.y), 0.f);
+  a.z = fmaxf(fmaf(z.z, sc.z, sh.z), 0.f); a.w = fmaxf(fmaf(z.w, sc.w, sh.w), 0.f);
+  return a;
+}
+
+// dY = dA * 2*keep * [y > 0]
+__device__ __forceinline__ float4 dropout_relu_bwd(float4 g, float4 z, float4 sc, float4 sh,
+                                                   uint32_t nib) {
+  float4 dy;
+  dy.x = ((nib & 1u) && (fmaf(z.x, sc.x, sh.x) > 0.f)) ? g.x * 2.f : 0.f;
+  dy.y = ((nib & 2u) && (fmaf(z.y, sc.y, sh.y) > 0.f)) ? g.y * 2.f : 0.f;
+  dy.z = ((nib & 4u) && (fmaf(z.z, sc.z, sh.z) > 0.f)) ? g.z * 2.f : 0.f;
+  dy.w = ((nib & 8u) && (fmaf(z.w, sc.w, sh.w) > 0.f)) ? g.w * 2.f : 0.f;
+  return dy;
+}
+
+// ---------------------------------------------------------------------------
 // A = dropout(relu(Z*scale + shift)) (+ skip)
 // ---------------------------------------------------------------------------
 template <bool TRAIN>
@@ -118,7 +173,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(
     const float* __restrict__ running_mean, const float* __restrict__ running_var,
     const float* __restrict__ skip, float* __restrict__ A, int64_t batch, int W, int row_chunk,
     DropoutSrc drop, int64_t* nbt) {
-  const int col = blockIdx.x * EW_COLS_PER_BLOCK + threadIdx.x * 4;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col = blockIdx.x * EW_COLS_PER_BLOCK + lane * 4;
   if (TRAIN && nbt && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) nbt[0] += 1;
   if (col >= W) return;
   float4 sc, sh;
@@ -135,23 +191,28 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(
   }
   const int64_t r0 = (int64_t)blockIdx.y * row_chunk;
   const int64_t r1 = min(batch, r0 + row_chunk);
-  DropState ds;
-#pragma unroll 4
-  for (int64_t r = r0; r < r1; ++r) {
-    const float4 z = ld4(Z + r * W + col);
-    float4 a;
-    a.x = fmaxf(fmaf(z.x, sc.x, sh.x), 0.f); a.y = fmaxf(fmaf(z.y, sc.y, sh.y), 0.f);
-    a.z = fmaxf(fmaf(z.z, sc.z, sh.z), 0.f); a.w = fmaxf(fmaf(z.w, sc.w, sh.w), 0.f);
-    if (TRAIN) {
-      const uint32_t nib = keep_nibble(drop, ds, r, col, W, r == r0);
-      a.x = (nib & 1u) ? a.x * 2.f : 0.f; a.y = (nib & 2u) ? a.y * 2.f : 0.f;
-      a.z = (nib & 4u) ? a.z * 2.f : 0.f; a.w = (nib & 8u) ? a.w * 2.f : 0.f;
+  for (int64_t base = r0; base < r1; base += PATCH_ROWS) {
+    float4 z[ROWS_PER_LANE], k[ROWS_PER_LANE];
+#pragma unroll
+    for (int i = 0; i < ROWS_PER_LANE; ++i) {
+      const int64_t r = base + w + 4 * i;
+      z[i] = (r < batch) ? ld4(Z + r * W + col) : make_float4(0, 0, 0, 0);
+      k[i] = (skip && r < batch) ? ld4(skip + r * W + col) : make_float4(0, 0, 0, 0);
     }
-    if (skip) {
-      const float4 k = ld4(skip + r * W + col);
-      a.x += k.x; a.y += k.y; a.z += k.z; a.w += k.w;
+    PatchMask pm;
+    if (TRAIN) pm = patch_mask(drop, base, w, col, W, batch);
+#pragma unroll
+    for (int i = 0; i < ROWS_PER_LANE; ++i) {
+      const int64_t r = base + w + 4 * i;
+      float4 a = relu_bn(z[i], sc, sh);
+      if (TRAIN) {
+        const uint32_t nib = pm.nib[i];
+        a.x = (nib & 1u) ? a.x * 2.f : 0.f; a.y = (nib & 2u) ? a.y * 2.f : 0.f;
+        a.z = (nib & 4u) ? a.z * 2.f : 0.f; a.w = (nib & 8u) ? a.w * 2.f : 0.f;
+      }
+      a.x += k[i].x; a.y += k[i].y; a.z += k[i].z; a.w += k[i].w;
+      if (r < batch) st4(A + r * W + col, a);
     }
-    st4(A + r * W + col, a);
   }
 }
 
@@ -180,6 +241,17 @@ int launch_bn_apply_eval(hipStream_t s, const float* Z, const float* gamma, cons
   return BLH_OK;
 }
 
+// sum the per-lane float4 partials of the block's 4 waves and write one row of
+// `out` (256 floats at out[col0 .. col0+255]); red = [4][256] floats of LDS
+__device__ __forceinline__ void block_colsum_store(float4 v, float* red, float* out, int col0, int W) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  reinterpret_cast<float4*>(red)[w * 64 + lane] = v;
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (col0 + t < W) out[col0 + t] = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
+}
+
 // ---------------------------------------------------------------------------
 // backward pass 1: dY = dA * 2*keep * [y>0]; per-chunk column sums of dY*zhat, dY
 // part layout [chunk][2][W]: row 0 -> dgamma partial, row 1 -> dbeta partial
@@ -189,30 +261,37 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
     const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ invstd, float* __restrict__ part, int64_t batch, int W,
     int row_chunk, DropoutSrc drop) {
-  const int col = blockIdx.x * EW_COLS_PER_BLOCK + threadIdx.x * 4;
-  if (col >= W) return;
-  const float4 sc = ld4(scale + col), sh = ld4(shift + col), mu = ld4(mean + col),
-               is = ld4(invstd + col);
+  __shared__ __attribute__((aligned(16))) float red[4 * 256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col0 = blockIdx.x * EW_COLS_PER_BLOCK;
+  const int col = col0 + lane * 4;
+  const bool ok = col < W;
+  const int cc = ok ? col : 0;
+  const float4 sc = ld4(scale + cc), sh = ld4(shift + cc), mu = ld4(mean + cc),
+               is = ld4(invstd + cc);
   const int64_t r0 = (int64_t)blockIdx.y * row_chunk;
   const int64_t r1 = min(batch, r0 + row_chunk);
   float4 sg = make_float4(0, 0, 0, 0), sb = make_float4(0, 0, 0, 0);
-  DropState ds;
-#pragma unroll 4
-  for (int64_t r = r0; r < r1; ++r) {
-    const float4 z = ld4(Z + r * W + col);
-    const float4 g = ld4(dA + r * W + col);
-    const uint32_t nib = keep_nibble(drop, ds, r, col, W, r == r0);
-    float4 dy;
-    dy.x = ((nib & 1u) && (fmaf(z.x, sc.x, sh.x) > 0.f)) ? g.x * 2.f : 0.f;
-    dy.y = ((nib & 2u) && (fmaf(z.y, sc.y, sh.y) > 0.f)) ? g.y * 2.f : 0.f;
-    dy.z = ((nib & 4u) && (fmaf(z.z, sc.z, sh.z) > 0.f)) ? g.z * 2.f : 0.f;
-    dy.w = ((nib & 8u) && (fmaf(z.w, sc.w, sh.w) > 0.f)) ? g.w * 2.f : 0.f;
-    sb.x += dy.x; sb.y += dy.y; sb.z += dy.z; sb.w += dy.w;
-    sg.x += dy.x * ((z.x - mu.x) * is.x); sg.y += dy.y * ((z.y - mu.y) * is.y);
-    sg.z += dy.z * ((z.z - mu.z) * is.z); sg.w += dy.w * ((z.w - mu.w) * is.w);
-  }
-  st4(part + ((int64_t)blockIdx.y * 2 + 0) * W + col, sg);
-  st4(part + ((int64_t)blockIdx.y * 2 + 1) * W + col, sb);
+  if (ok)
+    for (int64_t base = r0; base < r1; base += PATCH_ROWS) {
+      float4 z[ROWS_PER_LANE], g[ROWS_PER_LANE];
+#pragma unroll
+      for (int i = 0; i < ROWS_PER_LANE; ++i) {
+        const int64_t r = base + w + 4 * i;
+        z[i] = (r < batch) ? ld4(Z + r * W + col) : make_float4(0, 0, 0, 0);
+        g[i] = (r < batch) ? ld4(dA + r * W + col) : make_float4(0, 0, 0, 0);
+      }
+      const PatchMask pm = patch_mask(drop, base, w, col, W, batch);
+#pragma unroll
+      for (int i = 0; i < ROWS_PER_LANE; ++i) {
+        const float4 dy = dropout_relu_bwd(g[i], z[i], sc, sh, pm.nib[i]);
+        sb.x += dy.x; sb.y += dy.y; sb.z += dy.z; sb.w += dy.w;
+        sg.x += dy.x * ((z[i].x - mu.x) * is.x); sg.y += dy.y * ((z[i].y - mu.y) * is.y);
+        sg.z += dy.z * ((z[i].z - mu.z) * is.z); sg.w += dy.w * ((z[i].w - mu.w) * is.w);
+      }
+    }
+  block_colsum_store(sg, red, part + ((int64_t)blockIdx.y * 2 + 0) * W, col0, W);
+  block_colsum_store(sb, red, part + ((int64_t)blockIdx.y * 2 + 1) * W, col0, W);
 }
 
 int launch_bn_bwd_reduce(hipStream_t s, const float* dA, const float* Z, const float* scale,
@@ -271,37 +350,47 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
     const float* __restrict__ invstd, const float* __restrict__ dgamma,
     const float* __restrict__ dbeta, float* __restrict__ dZ, float* __restrict__ colsum_part,
     int64_t batch, int W, int row_chunk, DropoutSrc drop) {
-  const int col = blockIdx.x * EW_COLS_PER_BLOCK + threadIdx.x * 4;
-  if (col >= W) return;
-  const float4 sc = ld4(scale + col), sh = ld4(shift + col), mu = ld4(mean + col),
-               is = ld4(invstd + col);
+  __shared__ __attribute__((aligned(16))) float red[4 * 256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col0 = blockIdx.x * EW_COLS_PER_BLOCK;
+  const int col = col0 + lane * 4;
+  const bool ok = col < W;
+  const int cc = ok ? col : 0;
+  const float4 sc = ld4(scale + cc), sh = ld4(shift + cc), mu = ld4(mean + cc),
+               is = ld4(invstd + cc);
   const float inv_b = 1.0f / (float)batch;
-  float4 c1 = ld4(dbeta + col), c2 = ld4(dgamma + col);
+  float4 c1 = ld4(dbeta + cc), c2 = ld4(dgamma + cc);
   c1.x *= inv_b; c1.y *= inv_b; c1.z *= inv_b; c1.w *= inv_b;
   c2.x *= inv_b; c2.y *= inv_b; c2.z *= inv_b; c2.w *= inv_b;
   const int64_t r0 = (int64_t)blockIdx.y * row_chunk;
   const int64_t r1 = min(batch, r0 + row_chunk);
   float4 cs = make_float4(0, 0, 0, 0);
-  DropState ds;
-#pragma unroll 4
-  for (int64_t r = r0; r < r1; ++r) {
-    const float4 z = ld4(Z + r * W + col);
-    const float4 g = ld4(dA + r * W + col);
-    const uint32_t nib = keep_nibble(drop, ds, r, col, W, r == r0);
-    float4 dy, o;
-    dy.x = ((nib & 1u) && (fmaf(z.x, sc.x, sh.x) > 0.f)) ? g.x * 2.f : 0.f;
-    dy.y = ((nib & 2u) && (fmaf(z.y, sc.y, sh.y) > 0.f)) ? g.y * 2.f : 0.f;
-    dy.z = ((nib & 4u) && (fmaf(z.z, sc.z, sh.z) > 0.f)) ? g.z * 2.f : 0.f;
-    dy.w = ((nib & 8u) && (fmaf(z.w, sc.w, sh.w) > 0.f)) ? g.w * 2.f : 0.f;
-    // scale = gamma*invstd
-    o.x = sc.x * (dy.x - c1.x - ((z.x - mu.x) * is.x) * c2.x);
-    o.y = sc.y * (dy.y - c1.y - ((z.y - mu.y) * is.y) * c2.y);
-    o.z = sc.z * (dy.z - c1.z - ((z.z - mu.z) * is.z) * c2.z);
-    o.w = sc.w * (dy.w - c1.w - ((z.w - mu.w) * is.w) * c2.w);
-    cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
-    st4(dZ + r * W + col, o);
-  }
-  st4(colsum_part + (int64_t)blockIdx.y * W + col, cs);
+  if (ok)
+    for (int64_t base = r0; base < r1; base += PATCH_ROWS) {
+      float4 z[ROWS_PER_LANE], g[ROWS_PER_LANE];
+#pragma unroll
+      for (int i = 0; i < ROWS_PER_LANE; ++i) {
+        const int64_t r = base + w + 4 * i;
+        z[i] = (r < batch) ? ld4(Z + r * W + col) : make_float4(0, 0, 0, 0);
+        g[i] = (r < batch) ? ld4(dA + r * W + col) : make_float4(0, 0, 0, 0);
+      }
+      const PatchMask pm = patch_mask(drop, base, w, col, W, batch);
+#pragma unroll
+      for (int i = 0; i < ROWS_PER_LANE; ++i) {
+        const int64_t r = base + w + 4 * i;
+        const float4 dy = dropout_relu_bwd(g[i], z[i], sc, sh, pm.nib[i]);
+        float4 o;   // scale = gamma*invstd
+        o.x = sc.x * (dy.x - c1.x - ((z[i].x - mu.x) * is.x) * c2.x);
+        o.y = sc.y * (dy.y - c1.y - ((z[i].y - mu.y) * is.y) * c2.y);
+        o.z = sc.z * (dy.z - c1.z - ((z[i].z - mu.z) * is.z) * c2.z);
+        o.w = sc.w * (dy.w - c1.w - ((z[i].w - mu.w) * is.w) * c2.w);
+        if (r < batch) {
+          cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
+          st4(dZ + r * W + col, o);
+        }
+      }
+    }
+  block_colsum_store(cs, red, colsum_part + (int64_t)blockIdx.y * W, col0, W);
 }
 
 int launch_bn_bwd_apply(hipStream_t s, const float* dA, const float* Z, const float* scale,
@@ -609,6 +698,59 @@ int launch_dropout_mask(hipStream_t s, uint8_t* out, int64_t batch, int W, const
   hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, batch, W,
                      drop);
   BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+}  // namespace blh
+
+// ---------------------------------------------------------------------------
+// decode epilogue: pred = sum of split-K slabs + bias; optionally the fused MSE
+// (dpred = scale*(pred-target), per-block partial sums of squared error)
+// ---------------------------------------------------------------------------
+namespace blh {
+
+__global__ __launch_bounds__(256) void decode_finish_kernel(
+    const float* __restrict__ slabs, int splits, int64_t n, int out_features,
+    const float* __restrict__ bias, float* __restrict__ pred, const float* __restrict__ target,
+    float scale, float* __restrict__ dpred, float* __restrict__ loss_part) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float4 v = ld4(slabs + i * 4);
+    for (int s = 1; s < splits; ++s) {
+      const float4 u = ld4(slabs + (int64_t)s * n + i * 4);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    const float4 b = ld4(bias + (int)((i * 4) % out_features));
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    st4(pred + i * 4, v);
+    if (target) {
+      const float4 t = ld4(target + i * 4);
+      float4 d;
+      d.x = v.x - t.x; d.y = v.y - t.y; d.z = v.z - t.z; d.w = v.w - t.w;
+      acc += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+      d.x *= scale; d.y *= scale; d.z *= scale; d.w *= scale;
+      st4(dpred + i * 4, d);
+    }
+  }
+  if (target) {
+    const float t = block_sum_f32(acc, sh);
+    if (threadIdx.x == 0) loss_part[blockIdx.x] = t;
+  }
+}
+
+int launch_decode_finish(hipStream_t s, const float* slabs, int splits, int64_t batch,
+                         int out_features, const float* bias, float* pred, const float* target,
+                         float scale, float* dpred, float* loss_part, int* nparts) {
+  const int64_t n = batch * out_features;
+  if (out_features % 4 != 0) return BLH_ERR_SHAPE;
+  const int blocks = (int)std::min<int64_t>(ceil_div(n / 4, 256), 1024);
+  hipLaunchKernelGGL(decode_finish_kernel, dim3(blocks), dim3(256), 0, s, slabs, splits, n,
+                     out_features, bias, pred, target, scale, dpred, loss_part);
+  BLH_HIP_TRY(hipGetLastError());
+  if (nparts) *nparts = blocks;
   return BLH_OK;
 }
 

@@ -1,15 +1,17 @@
 // Host-side dispatch of the fp32 MFMA GEMM (kernel templates: gemm_f32_kernel.h).
+#include <cstdlib>
+
 #include "gemm_f32_kernel.h"
 
 namespace blh {
 
 // ------------------------------------------------------------------ host ----
-template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI>
+template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int PIPE>
 static int launch_cfg(hipStream_t s, const GemmParams& p, int splits) {
   constexpr int NT = 64 * WM * WN;
-  constexpr size_t lds = 2 * (TileGeom<LA, BM>::LDS_FLOATS + TileGeom<LB, BN>::LDS_FLOATS) * sizeof(float);
+  constexpr size_t lds = gemm_lds_bytes<BM, BN, LA, LB, PIPE>();
   static bool attr_set = false;
-  auto kern = gemm_f32_kernel<BM, BN, WM, WN, LA, LB, EPI>;
+  auto kern = gemm_f32_kernel<BM, BN, WM, WN, LA, LB, EPI, PIPE>;
   if (!attr_set) {
     BLH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -22,18 +24,26 @@ static int launch_cfg(hipStream_t s, const GemmParams& p, int splits) {
   return BLH_OK;
 }
 
+// Main-loop structure used by the library: 3 = three-stage LDS ring filled by LDS-DMA issued
+// from inline asm (see gemm_f32_kernel.h); 1 = register-staged double buffer.
+static int gemm_pipe() {   // developer knob for on-box A/B runs: BLH_GEMM_PIPE=1|3
+  static const int v = [] { const char* e = getenv("BLH_GEMM_PIPE"); return (e && e[0] == '1') ? 1 : 3; }();
+  return v;
+}
+
 #define BLH_CASE(BM_, BN_, WM_, WN_, LA_, LB_, EPI_) \
   if (la == LA_ && lb == LB_ && epi == EPI_)         \
-    return launch_cfg<BM_, BN_, WM_, WN_, LA_, LB_, EPI_>(s, p, splits);
+    return gemm_pipe() == 1 ? launch_cfg<BM_, BN_, WM_, WN_, LA_, LB_, EPI_, 1>(s, p, splits) \
+                            : launch_cfg<BM_, BN_, WM_, WN_, LA_, LB_, EPI_, 3>(s, p, splits);
 
 // Only the (tile, layout, epilogue) combinations the network and the unit tests use are
 // instantiated (each is a separate gfx950 kernel).
 static int launch_128x128(hipStream_t s, int la, int lb, int epi, const GemmParams& p, int splits) {
-  BLH_CASE(128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS)   // hidden / encode forward (train)
-  BLH_CASE(128, 128, 4, 2, ROWK, ROWK, EPI_BIAS)         // forward (eval)
-  BLH_CASE(128, 128, 4, 2, ROWK, ROWK, EPI_STORE)
-  BLH_CASE(128, 128, 4, 2, ROWK, KROW, EPI_STORE)        // dgrad
-  BLH_CASE(128, 128, 4, 2, ROWK, KROW, EPI_ADD)          // dgrad + residual gradient
+  BLH_CASE(128, 128, 2, 4, ROWK, ROWK, EPI_BIAS_STATS)   // hidden / encode forward (train)
+  BLH_CASE(128, 128, 2, 4, ROWK, ROWK, EPI_BIAS)         // forward (eval)
+  BLH_CASE(128, 128, 2, 4, ROWK, ROWK, EPI_STORE)
+  BLH_CASE(128, 128, 2, 4, ROWK, KROW, EPI_STORE)        // dgrad
+  BLH_CASE(128, 128, 2, 4, ROWK, KROW, EPI_ADD)          // dgrad + residual gradient
   BLH_CASE(128, 128, 4, 2, KROW, KROW, EPI_STORE)        // wgrad (split over the batch)
   BLH_CASE(128, 128, 4, 2, KROW, ROWK, EPI_STORE)
   return BLH_ERR_INVALID_ARGUMENT;

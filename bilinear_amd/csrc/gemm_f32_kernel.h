@@ -109,6 +109,92 @@ __device__ inline void read_frags(float (&frag)[T][4], const float* lds, int row
   }
 }
 
+// ---- global -> LDS by LDS-DMA (global_load_lds_dwordx4), PIPE == 2 ---------------------
+// The DMA writes LDS linearly (wave-uniform base + lane*16 B), so tiles are unpadded and the
+// bank-conflict fix for the ROWK fragment reads is an XOR swizzle applied to the per-lane
+// SOURCE address (chunk c of row r lands in slot c ^ (r & 7)) and again on the read.
+// Out-of-range chunks read a 16-byte zero page instead of being masked (a masked lane would
+// leave stale LDS bytes).
+static __device__ float4 g_zero16;
+
+// One LDS-DMA of 16 B per lane issued from inline asm, so that hipcc does not know a DMA is in
+// flight: with the builtin it inserts a conservative `s_waitcnt vmcnt(0)` in front of every
+// ds_read that might alias the DMA destination, which drains the ring each K tile.  M0 (LDS
+// base of the wave's 1 KiB piece) is written in the same statement that uses it and restored.
+__device__ __forceinline__ void lds_dma16_asm(const float* gsrc, uint32_t lds_byte_addr_uniform) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_byte_addr_uniform)
+      : "memory");
+}
+
+template <int LAYOUT, int R, int NT, bool ASM = false>
+struct TileDMA {
+  static constexpr int CHUNKS = (R * BK / 4) / NT;
+  static constexpr int FLOATS = R * BK;
+  static_assert((R * BK / 4) % NT == 0, "tile not divisible among threads");
+
+  __device__ static inline void issue(float* lds_tile, const float* __restrict__ base, int64_t ld,
+                                      int row0, int rows_limit, int k0, int k_end, int tid) {
+#pragma unroll
+    for (int p = 0; p < CHUNKS; ++p) {
+      const int q = tid + p * NT;
+      int row, k;
+      if (LAYOUT == ROWK) {
+        const int r = q >> 3;
+        row = row0 + r;
+        k = k0 + ((((q & 7) ^ (r & 7))) << 2);
+      } else {
+        constexpr int CPR = R / 4;
+        row = row0 + ((q % CPR) << 2);
+        k = k0 + (q / CPR);
+      }
+      const bool ok = (row < rows_limit) && (k < k_end);
+      const int64_t off = (LAYOUT == ROWK) ? ((int64_t)row * ld + k) : ((int64_t)k * ld + row);
+      const float* src = ok ? (base + off) : reinterpret_cast<const float*>(&g_zero16);
+      float* dst = lds_tile + (p * NT + (tid & ~63)) * 4;   // wave-uniform; HW adds lane*16
+      if (ASM) {
+        const uint32_t a = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) float*)dst);
+        lds_dma16_asm(src, __builtin_amdgcn_readfirstlane(a));
+      } else {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    }
+  }
+};
+
+template <int LAYOUT, int R, int T>
+__device__ inline void read_frags_dma(float (&frag)[T][4], const float* lds, int row_base, int s,
+                                      int lane) {
+  const int h = lane >> 5, lr = lane & 31;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    if (LAYOUT == ROWK) {
+      const int row = row_base + t * 32 + lr;
+      const float4 v = *reinterpret_cast<const float4*>(
+          lds + row * BK + (((2 * s + h) ^ (row & 7)) << 2));
+      frag[t][0] = v.x; frag[t][1] = v.y; frag[t][2] = v.z; frag[t][3] = v.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        frag[t][j] = lds[(8 * s + 4 * h + j) * R + row_base + t * 32 + lr];
+    }
+  }
+}
+
+template <int BM, int BN, int LA, int LB, int PIPE>
+constexpr size_t gemm_lds_bytes() {
+  return PIPE >= 2 ? 3 * (size_t)(BM + BN) * BK * sizeof(float)
+                   : 2 * (size_t)(TileGeom<LA, BM>::LDS_FLOATS + TileGeom<LB, BN>::LDS_FLOATS) * sizeof(float);
+}
+
 // XCD-aware, bijective remap of the linear workgroup id: workgroups b, b+8, ...
 // share an XCD (and its 4 MiB L2); give each XCD a contiguous range of tiles so
 // neighbouring tiles (same A row panel) hit the same L2.
@@ -118,7 +204,7 @@ __device__ inline int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
-template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI>
+template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int PIPE = 1, int STAMP = 0, int ABLATE = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmParams p) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -127,6 +213,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmParams p) {
   constexpr int B_FLOATS = TileGeom<LB, BN>::LDS_FLOATS;
   constexpr int STAGE = A_FLOATS + B_FLOATS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned long long stamp_entry = 0;
+  if (STAMP) stamp_entry = __builtin_amdgcn_s_memrealtime();
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -152,46 +240,174 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nkt = (k_end - kz0 + BK - 1) / BK;
-  if (nkt > 0) {
-    IOA::load(ra, p.A, p.lda, m0, p.M, kz0, k_end, tid);
-    IOB::load(rb, p.B, p.ldb, n0, p.N, kz0, k_end, tid);
-    IOA::store(ra, smem, tid);
-    IOB::store(rb, smem + A_FLOATS, tid);
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    const float* sA = smem + (kt & 1) * STAGE;
-    const float* sB = sA + A_FLOATS;
-    const bool more = (kt + 1 < nkt);
-    if (more) {
-      const int k0 = kz0 + (kt + 1) * BK;
-      IOA::load(ra, p.A, p.lda, m0, p.M, k0, k_end, tid);
-      IOB::load(rb, p.B, p.ldb, n0, p.N, k0, k_end, tid);
+  // STAMP: diagnostic builds only (tools/gemm_bench): shader clock vs 100 MHz real-time clock
+  unsigned long long stamp_c0 = 0, stamp_r0 = 0;
+  if (STAMP) { stamp_c0 = __builtin_amdgcn_s_memtime(); stamp_r0 = __builtin_amdgcn_s_memrealtime(); }
+  if (PIPE < 2) {
+    if (nkt > 0) {
+      IOA::load(ra, p.A, p.lda, m0, p.M, kz0, k_end, tid);
+      IOB::load(rb, p.B, p.ldb, n0, p.N, kz0, k_end, tid);
+      IOA::store(ra, smem, tid);
+      IOB::store(rb, smem + A_FLOATS, tid);
     }
+    __syncthreads();
+  }
+
+  if (PIPE >= 2) {
+    // LDS-DMA pipeline (PIPE 2: builtin DMA; PIPE 3: DMA issued from inline asm): a 3-stage ring of unpadded tiles filled by global_load_lds (no VGPR
+    // staging, no ds_write); tile kt+2 is in flight while tile kt is multiplied.  One raw
+    // s_barrier per K tile, behind a COUNTED vmcnt that retires only tile kt+1's DMAs (a
+    // __syncthreads() would drain the ring) and lgkmcnt(0) (this wave's reads of the stage
+    // that the next iteration's DMA overwrites are complete).
+    using DA = TileDMA<LA, BM, NT, PIPE == 3>;
+    using DB = TileDMA<LB, BN, NT, PIPE == 3>;
+    constexpr int RING = (BM + BN) * BK;          // floats per stage
+    constexpr int G = DA::CHUNKS + DB::CHUNKS;    // DMA instructions per thread per tile
+    float fa[2][TM][4], fb[2][TN][4];
+    if (nkt > 0) {
+      DA::issue(smem, p.A, p.lda, m0, p.M, kz0, k_end, tid);
+      DB::issue(smem + BM * BK, p.B, p.ldb, n0, p.N, kz0, k_end, tid);
+      if (nkt > 1) {
+        DA::issue(smem + RING, p.A, p.lda, m0, p.M, kz0 + BK, k_end, tid);
+        DB::issue(smem + RING + BM * BK, p.B, p.ldb, n0, p.N, kz0 + BK, k_end, tid);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      read_frags_dma<LA, BM, TM>(fa[0], smem, wm * (TM * 32), 0, lane);
+      read_frags_dma<LB, BN, TN>(fb[0], smem + BM * BK, wn * (TN * 32), 0, lane);
+    }
+    int st_cur = 0;                                // kt % 3
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int st_nxt = (st_cur == 2) ? 0 : st_cur + 1;
+      const int st_nn = (st_nxt == 2) ? 0 : st_nxt + 1;
+      const float* sA = smem + st_cur * RING;
+      const float* sB = sA + BM * BK;
+      const float* nA = smem + st_nxt * RING;
+      const bool more = (kt + 1 < nkt), more2 = (kt + 2 < nkt);
+      if (more2) {
+        const int k0 = kz0 + (kt + 2) * BK;
+        DA::issue(smem + st_nn * RING, p.A, p.lda, m0, p.M, k0, k_end, tid);
+        DB::issue(smem + st_nn * RING + BM * BK, p.B, p.ldb, n0, p.N, k0, k_end, tid);
+      }
 #pragma unroll
-    for (int s = 0; s < BK / 8; ++s) {
-      float fa[TM][4], fb[TN][4];
-      read_frags<LA, BM, TM>(fa, sA, wm * (TM * 32), s, lane);
-      read_frags<LB, BN, TN>(fb, sB, wn * (TN * 32), s, lane);
+      for (int s = 0; s < BK / 8; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s < BK / 8 - 1) {
+          read_frags_dma<LA, BM, TM>(fa[nxt], sA, wm * (TM * 32), s + 1, lane);
+          read_frags_dma<LB, BN, TN>(fb[nxt], sB, wn * (TN * 32), s + 1, lane);
+        } else if (more) {
+          read_frags_dma<LA, BM, TM>(fa[nxt], nA, wm * (TM * 32), 0, lane);
+          read_frags_dma<LB, BN, TN>(fb[nxt], nA + BM * BK, wn * (TN * 32), 0, lane);
+        }
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int jn = 0; jn < TN; ++jn)
-            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[jn][j], acc[i][jn], 0, 0, 0);
-      if (s == 1 && more) {
-        // the other stage was last read in iteration kt-1 (a barrier ago): safe to fill now,
-        // while this tile's remaining MFMAs cover the LDS write latency
-        float* dA = smem + ((kt + 1) & 1) * STAGE;
-        IOA::store(ra, dA, tid);
-        IOB::store(rb, dA + A_FLOATS, tid);
+            for (int jn = 0; jn < TN; ++jn)
+              acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][j], fb[cur][jn][j],
+                                                                acc[i][jn], 0, 0, 0);
+        if (s == BK / 8 - 2 && more) {
+          if (more2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
+      }
+      st_cur = st_nxt;
+    }
+    __syncthreads();
+  } else if (PIPE == 0) {
+    // reference structure (kept for A/B timing in tools/gemm_bench): fragments are read
+    // group by group in front of their MFMAs, one barrier at the end of the K tile
+    for (int kt = 0; kt < nkt; ++kt) {
+      const float* sA = smem + (kt & 1) * STAGE;
+      const float* sB = sA + A_FLOATS;
+      const bool more = (kt + 1 < nkt);
+      if (more) {
+        const int k0 = kz0 + (kt + 1) * BK;
+        IOA::load(ra, p.A, p.lda, m0, p.M, k0, k_end, tid);
+        IOB::load(rb, p.B, p.ldb, n0, p.N, k0, k_end, tid);
+      }
+#pragma unroll
+      for (int s = 0; s < BK / 8; ++s) {
+        float fa[TM][4], fb[TN][4];
+        read_frags<LA, BM, TM>(fa, sA, wm * (TM * 32), s, lane);
+        read_frags<LB, BN, TN>(fb, sB, wn * (TN * 32), s, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+              acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[jn][j], acc[i][jn], 0, 0, 0);
+        if (s == 1 && more) {
+          float* dA = smem + ((kt + 1) & 1) * STAGE;
+          IOA::store(ra, dA, tid);
+          IOB::store(rb, dA + A_FLOATS, tid);
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+    // Software-pipelined main loop.  The fragments of k-group s+1 are read from LDS while the
+    // MFMAs of group s execute (two register sets, static indices), so a wave never waits on
+    // LDS between MFMA groups; the next K tile goes global -> VGPR at the top of the tile,
+    // VGPR -> other LDS stage after group 1, and the single barrier sits after group 2, so
+    // that group 3 already prefetches group 0 of the next stage.
+    float fa[2][TM][4], fb[2][TN][4];
+    if (nkt > 0) {
+      read_frags<LA, BM, TM>(fa[0], smem, wm * (TM * 32), 0, lane);
+      read_frags<LB, BN, TN>(fb[0], smem + A_FLOATS, wn * (TN * 32), 0, lane);
+    }
+    for (int kt = 0; kt < nkt; ++kt) {
+      const float* sA = smem + (kt & 1) * STAGE;
+      const float* sB = sA + A_FLOATS;
+      float* nA = smem + ((kt + 1) & 1) * STAGE;
+      const bool more = (kt + 1 < nkt);
+      if (more && !(ABLATE & 1)) {   // ABLATE: timing-only diagnostic builds (wrong results)
+        const int k0 = kz0 + (kt + 1) * BK;
+        IOA::load(ra, p.A, p.lda, m0, p.M, k0, k_end, tid);
+        IOB::load(rb, p.B, p.ldb, n0, p.N, k0, k_end, tid);
+      }
+#pragma unroll
+      for (int s = 0; s < BK / 8; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s < BK / 8 - 1) {
+          read_frags<LA, BM, TM>(fa[nxt], sA, wm * (TM * 32), s + 1, lane);
+          read_frags<LB, BN, TN>(fb[nxt], sB, wn * (TN * 32), s + 1, lane);
+        } else if (more) {
+          read_frags<LA, BM, TM>(fa[nxt], nA, wm * (TM * 32), 0, lane);
+          read_frags<LB, BN, TN>(fb[nxt], nA + A_FLOATS, wn * (TN * 32), 0, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+              acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][j], fb[cur][jn][j],
+                                                                acc[i][jn], 0, 0, 0);
+        if (s == 1 && more && !(ABLATE & 2)) {
+          IOA::store(ra, nA, tid);
+          IOB::store(rb, nA + A_FLOATS, tid);
+        }
+        if (s == BK / 8 - 2 && !(ABLATE & 4)) __syncthreads();
       }
     }
     __syncthreads();
   }
 
+  if (STAMP) {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.loss_part) + 8 * (blockIdx.x + gridDim.x * blockIdx.z);
+      o[0] = c1 - stamp_c0; o[1] = r1 - stamp_r0; o[2] = stamp_entry; o[3] = stamp_r0; o[4] = r1;
+    }
+  }
   // ------------------------------------------------------------- epilogue --
   const int h = lane >> 5, lc = lane & 31;
   const int row_w = m0 + wm * (TM * 32) + 4 * h;   // + tm*32 + (r&3) + 8*(r>>2)
@@ -302,6 +518,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmParams p) {
       for (int w = 0; w < WM * WN; ++w) t += red[w];
       p.loss_part[blockIdx.x] = t;
     }
+  }
+  if (STAMP) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long r2 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0)
+      (reinterpret_cast<unsigned long long*>(p.loss_part) + 8 * (blockIdx.x + gridDim.x * blockIdx.z))[5] = r2;
   }
 }
 

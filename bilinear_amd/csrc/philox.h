@@ -42,8 +42,12 @@ __device__ __forceinline__ Philox128 dropout_patch(uint64_t seed, uint64_t step,
 }
 
 // keep-bit of element (global_row, col) inside its patch: bit (row%32)*4 + col%4
+// (select chain, not p.w[runtime]: a runtime-indexed register array is lowered to a very
+//  slow indirect access — measured 14 us on a 6 us kernel)
 __device__ __forceinline__ uint32_t patch_nibble(const Philox128& p, int row_in_patch) {
-  return (p.w[row_in_patch >> 3] >> ((row_in_patch & 7) * 4)) & 0xFu;
+  const int wi = row_in_patch >> 3;
+  const uint32_t word = wi == 0 ? p.w[0] : (wi == 1 ? p.w[1] : (wi == 2 ? p.w[2] : p.w[3]));
+  return (word >> ((row_in_patch & 7) * 4)) & 0xFu;
 }
 
 }  // namespace blh

@@ -2,6 +2,7 @@
 // at the hidden-layer shape.   hipcc -O3 --offload-arch=gfx950 tools/gemm_bench.hip -o gemm_bench
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../gemm_f32_kernel.h"
@@ -11,11 +12,11 @@ thread_local int blh::g_last_hip_error = 0;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI>
+template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int PIPE>
 float run(const GemmParams& p, int splits, int reps) {
   constexpr int NT = 64 * WM * WN;
-  constexpr size_t lds = 2 * (TileGeom<LA, BM>::LDS_FLOATS + TileGeom<LB, BN>::LDS_FLOATS) * sizeof(float);
-  auto kern = gemm_f32_kernel<BM, BN, WM, WN, LA, LB, EPI>;
+  constexpr size_t lds = gemm_lds_bytes<BM, BN, LA, LB, PIPE>();
+  auto kern = gemm_f32_kernel<BM, BN, WM, WN, LA, LB, EPI, PIPE>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N, BN));
   dim3 grid(tiles, 1, splits);
@@ -32,9 +33,34 @@ float run(const GemmParams& p, int splits, int reps) {
   return ms / reps;
 }
 
+// spot-check 64 output elements against a host fp64 dot product
+static double g_maxerr;
+void verify(const char* what, const std::vector<float>& hA, const std::vector<float>& hB, const std::vector<float>& hbias,
+            const float* dC, int M, int N, int K, int W, int kind, int splits) {
+  std::vector<float> c((size_t)M * N * splits);
+  CK(hipMemcpy(c.data(), dC, c.size() * 4, hipMemcpyDeviceToHost));
+  double maxerr = 0;
+  for (int t = 0; t < 64; ++t) {
+    int i = (t * 7919 + 13) % M, j = (t * 104729 + 7) % N;
+    double ref = 0;
+    for (int k = 0; k < K; ++k) {
+      double a = (kind == 2) ? hA[(size_t)k * W + i] : hA[(size_t)i * W + k];
+      double b = (kind == 0) ? hB[(size_t)j * W + k] : (kind == 1 ? hB[(size_t)k * W + j] : hA[(size_t)k * W + j]);
+      ref += a * b;
+    }
+    if (kind == 0) ref += hbias[j];
+    double got = 0;
+    for (int s = 0; s < splits; ++s) got += c[(size_t)s * M * N + (size_t)i * N + j];
+    maxerr = std::max(maxerr, std::abs(got - ref));
+  }
+  if (maxerr > 1e-3) printf("   !! %s MISMATCH max err %g\n", what, maxerr);
+  g_maxerr = std::max(g_maxerr, maxerr);
+}
+
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 4096, W = argc > 2 ? atoi(argv[2]) : 1024;
-  const int reps = 20;
+  const char* filter = argc > 3 ? argv[3] : nullptr;
+  const int reps = argc > 4 ? atoi(argv[4]) : 20;
   float *A, *B, *C, *bias, *stat;
   const size_t act = (size_t)M * W;
   CK(hipMalloc(&A, act * 4)); CK(hipMalloc(&B, (size_t)W * W * 4)); CK(hipMalloc(&C, std::max(act, (size_t)16 * W * W) * 4));
@@ -53,26 +79,85 @@ int main(int argc, char** argv) {
   GemmParams w{};    // wgrad: dW = dZ^T A, split over the batch
   w.A = A; w.lda = W; w.B = A; w.ldb = W; w.C = C; w.ldc = W; w.M = W; w.N = W; w.K = M;
 
-#define ROW(name, BM, BN, WM, WN)                                                              \
+#define ROW(name, BM, BN, WM, WN, PIPE) if (!filter || strstr(name, filter))                                                              \
   {                                                                                            \
-    float t1 = run<BM, BN, WM, WN, ROWK, ROWK, EPI_BIAS_STATS>(f, 1, reps);                    \
-    float t2 = run<BM, BN, WM, WN, ROWK, KROW, EPI_STORE>(d, 1, reps);                         \
+    float t1 = run<BM, BN, WM, WN, ROWK, ROWK, EPI_BIAS_STATS, PIPE>(f, 1, reps);                    \
+    verify("fwd", h, h, h, C, M, W, W, W, 0, 1);                                               \
+    float t2 = run<BM, BN, WM, WN, ROWK, KROW, EPI_STORE, PIPE>(d, 1, reps);                         \
+    verify("dgrad", h, h, h, C, M, W, W, W, 1, 1);                                             \
     int tiles = (int)(ceil_div(W, BM) * ceil_div(W, BN));                                      \
     int splits = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(256, tiles), 16));      \
     if (BM * BN <= 64 * 128) splits = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(512, tiles), 16)); \
     w.k_per_split = (int)round_up(ceil_div(M, splits), 32); w.c_split_stride = (int64_t)W * W; \
-    float t3 = run<BM, BN, WM, WN, KROW, KROW, EPI_STORE>(w, splits, reps);                    \
+    float t3 = run<BM, BN, WM, WN, KROW, KROW, EPI_STORE, PIPE>(w, splits, reps);                    \
+    verify("wgrad", h, h, h, C, W, W, M, W, 2, splits);                                        \
     printf("%-22s fwd %7.1f us %6.1f TF | dgrad %7.1f us %6.1f TF | wgrad(x%d) %7.1f us %6.1f TF\n", name, \
            t1 * 1e3, flop / t1 / 1e9, t2 * 1e3, flop / t2 / 1e9, splits, t3 * 1e3, flop / t3 / 1e9); \
   }
 
-  ROW("128x128 w2x2 (base)", 128, 128, 2, 2)
-  ROW("128x128 w2x4", 128, 128, 2, 4)
-  ROW("128x128 w4x2", 128, 128, 4, 2)
-  ROW("128x64  w2x2", 128, 64, 2, 2)
-  ROW("64x128  w2x2", 64, 128, 2, 2)
-  ROW("128x64  w4x1", 128, 64, 4, 1)
-  ROW("256x128 w4x2", 256, 128, 4, 2)
-  ROW("64x64   w2x2", 64, 64, 2, 2)
+  ROW("128x128 w4x2 pipe1", 128, 128, 4, 2, 1)
+  ROW("128x128 w4x2 pipe2", 128, 128, 4, 2, 2)
+  ROW("128x128 w4x2 pipe3", 128, 128, 4, 2, 3)
+  ROW("128x128 w2x4 pipe3", 128, 128, 2, 4, 3)
+  ROW("128x128 w2x2 pipe3", 128, 128, 2, 2, 3)
+  ROW("128x128 w2x4 pipe2", 128, 128, 2, 4, 2)
+  ROW("128x128 w2x2 pipe2", 128, 128, 2, 2, 2)
+  ROW("128x64  w4x2 pipe2", 128, 64, 4, 2, 2)
+  ROW("256x128 w4x2 pipe2", 256, 128, 4, 2, 2)
+  {  // ablations of the PIPE=1 main loop (timing only; results are wrong)
+    auto abl = [&](const char* name, auto kern) {
+      constexpr size_t lds = gemm_lds_bytes<128, 128, ROWK, ROWK, 1>();
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const int tiles = (int)(ceil_div(M, 128) * ceil_div(W, 128));
+      hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+      for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, 0, f);
+      CK(hipEventRecord(a, 0));
+      for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, 0, f);
+      CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+      float ms; CK(hipEventElapsedTime(&ms, a, b));
+      printf("  ablate %-34s %.1f us\n", name, ms / 50 * 1e3);
+    };
+    abl("none", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 1, 0, 0>);
+    abl("no global loads", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 1, 0, 1>);
+    abl("no ds_write (loads unused)", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 1, 0, 2>);
+    abl("no loads, no ds_write", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 1, 0, 3>);
+    abl("no loads/ds_write/barrier", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 1, 0, 7>);
+  }
+  {  // fixed per-launch cost: same kernel, K = 32 (one K tile), and without the output store traffic
+    GemmParams f1 = f; f1.K = 32; f1.k_per_split = 32;
+    float t1 = run<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 1>(f1, 1, 50);
+    GemmParams f2 = f1; f2.M = 128;   // a single row of tiles: 8 workgroups
+    float t2 = run<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 1>(f2, 1, 50);
+    printf("K=32 launch: %d tiles %.1f us ; 8 tiles %.1f us\n", (int)(ceil_div(M, 128) * ceil_div(W, 128)), t1 * 1e3, t2 * 1e3);
+  }
+  {  // in-kernel clock of the main loop (diagnostic STAMP build of the forward kernel)
+    unsigned long long* st; CK(hipMalloc(&st, 4096 * 64));
+    GemmParams fs = f; fs.loss_part = reinterpret_cast<float*>(st);
+    auto kern = gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 1, 1>;
+    constexpr size_t lds = gemm_lds_bytes<128, 128, ROWK, ROWK, 1>();
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int tiles = (int)(ceil_div(M, 128) * ceil_div(W, 128));
+    hipEvent_t e0v, e1v; CK(hipEventCreate(&e0v)); CK(hipEventCreate(&e1v));
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, 0, fs);
+    CK(hipEventRecord(e0v, 0));
+    for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, 0, fs);
+    CK(hipEventRecord(e1v, 0));
+    CK(hipDeviceSynchronize());
+    float msv; CK(hipEventElapsedTime(&msv, e0v, e1v));
+    printf("stamped kernel, events: %.1f us per launch\n", msv / 200 * 1e3);
+    std::vector<unsigned long long> hs(8 * tiles);
+    CK(hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost));
+    double cs = 0, rs = 0, pro = 0, epi = 0; unsigned long long e0 = ~0ull, e1 = 0, l1max = 0, emax = 0;
+    for (int i = 0; i < tiles; ++i) {
+      const unsigned long long* o = &hs[8 * i];
+      cs += o[0]; rs += o[1]; pro += o[3] - o[2]; epi += o[5] - o[4];
+      e0 = std::min(e0, o[2]); e1 = std::max(e1, o[5]); l1max = std::max(l1max, o[4]); emax = std::max(emax, o[2]);
+    }
+    printf("per WG: entry->loop %.2f us | main loop %.1f us (%.0f cycles, clock %.3f GHz, MFMA-ideal 131072) | epilogue %.2f us\n",
+           pro / tiles / 100.0, rs / tiles / 100.0, cs / tiles, cs / rs * 0.1, epi / tiles / 100.0);
+    printf("kernel span first entry -> last exit %.1f us; last WG entry at +%.2f us; last loop end at +%.1f us\n",
+           (e1 - e0) / 100.0, (emax - e0) / 100.0, (l1max - e0) / 100.0);
+  }
+  printf("max spot-check error %g\n", g_maxerr);
   return 0;
 }
