@@ -90,6 +90,20 @@ def gemm_rooflines(batch, width, reps):
     return out
 
 
+def recorded_traffic(batch, width):
+    """HBM traffic of the dominant kernel (bytes per launch).  bench.py cannot run the PMC
+    passes itself; the figure comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    runs of this very command (profiles/r01_traffic.json, gfx950 correction applied there) and
+    is only reported for the shape it was measured on."""
+    if (batch, width) != (4096, 1024):
+        return None
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as f:
+            return json.load(f)["kernels"]["linear_fwd"]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def log(msg):
     print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
@@ -218,14 +232,15 @@ def main():
             "step_tflops": poses * (fwd + bwd) / 1e12,
             "step_frac_of_fp32_mfma_peak": poses * (fwd + bwd) / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
             "roofline": {
-                "kernel": "gemm_f32_kernel<128,128,2,2,ROWK,ROWK,BIAS_STATS> (Linear %dx%d forward, M=%d)" % (
+                "kernel": "gemm_f32_kernel<128,128,4,2,ROWK,ROWK,BIAS_STATS,PIPE=3> (Linear %dx%d forward, M=%d)" % (
                     args.width, args.width, args.batch),
                 "bound": "mfma",
                 "achieved": dom["tflops"],
                 "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": dom["tflops"] / FP32_MFMA_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": recorded_traffic(args.batch, args.width),
+                "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json)",
                 "avg_launch_ms": dom["ms"],
                 "flop_per_launch": 2.0 * args.batch * args.width * args.width,
             },

@@ -83,7 +83,7 @@ struct Workspace {
   float* stat_part;               // [tiles_m][2][W]
   float* G0; float* G1; float* dZ;
   float* bn_part;                 // [chunks][2][W]
-  float* dz_colsum_part;          // [chunks][W]
+  float* dz_colsum_part;          // [stage][chunks][W]
   float* slabs;                   // split-K partial products
   float* dpred;                   // [B][out]
   float* loss_part;               // [4096]
@@ -144,7 +144,7 @@ static Workspace carve(const blh_model_desc* d, int64_t batch, void* base) {
   ws.dZ = (float*)take(act);
   const int64_t chunks = ew_num_row_chunks(batch);
   ws.bn_part = (float*)take(chunks * 2 * W * sizeof(float));
-  ws.dz_colsum_part = (float*)take(chunks * W * sizeof(float));
+  ws.dz_colsum_part = (float*)take((int64_t)nh * chunks * W * sizeof(float));
   ws.slabs = (float*)take(slab_floats(d, batch) * sizeof(float));
   ws.dpred = (float*)take(batch * d->out_features * sizeof(float));
   ws.loss_part = (float*)take(4096 * sizeof(float));
@@ -282,9 +282,13 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
     BLH_TRY(launch_bn_bwd_finalize(s, ws.bn_part, chunks, W, grads + h.gamma, grads + h.beta));
     BLH_TRY(launch_bn_bwd_apply(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W,
                                 params + h.gamma, grads + h.gamma, grads + h.beta, ws.dZ,
-                                ws.dz_colsum_part, batch, W, ds));
+                                ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W, ds));
     // Linear: db = colsum(dZ); dW = dZ^T a_in; d a_in = dZ W
-    BLH_TRY(launch_colreduce(s, ws.dz_colsum_part, chunks, W, W, grads + h.b));
+    // (data parallel: the bucket hook needs this stage's bias gradient now; otherwise all
+    //  stages are reduced by one launch after the loop)
+    if (on_ready)
+      BLH_TRY(launch_colreduce(s, ws.dz_colsum_part + (int64_t)i * chunks * W, chunks, W, W,
+                               grads + h.b));
     if (i == 0) {
       BLH_TRY(wgrad(s, TILE_128x32, ws.dZ, W, W, x, d->in_features, d->in_features, batch,
                     ceil_div(W, 128) * ceil_div(d->in_features, 32), ws.slabs, grads + h.w));
@@ -309,6 +313,13 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
       const int64_t end = (i + 1 < nh) ? L.heavy[i + 1].w : L.dec_w;
       on_ready(user, h.w, end - h.w);
     }
+  }
+  if (!on_ready) {
+    int64_t offs[32];
+    if (nh > 32) return BLH_ERR_SHAPE;
+    for (int i = 0; i < nh; ++i) offs[i] = L.heavy[i].b;
+    BLH_TRY(launch_bias_colreduce(s, ws.dz_colsum_part, (int64_t)chunks * W, chunks, W, nh, offs,
+                                  grads));
   }
   return BLH_OK;
 }

@@ -106,6 +106,9 @@ int launch_bn_bwd_apply(hipStream_t s, const float* dA, const float* Z, const fl
                         float* dz_colsum_part, int64_t batch, int W, const DropoutSrc& drop);
 // out[c] = sum_s in[s][c] for c < ncols (rows of `ld` floats), fp64 accumulation
 int launch_colreduce(hipStream_t s, const float* in, int S, int64_t ld, int ncols, float* out);
+// Linear-bias gradients of all stages in one launch (partials [stage][S][W])
+int launch_bias_colreduce(hipStream_t s, const float* part, int64_t stage_stride, int S, int W,
+                          int num_stages, const int64_t* out_offsets, float* grads);
 // out[i] = sum_s in[s][i]   (slabs of `count` floats)
 int launch_sum_slabs(hipStream_t s, const float* slabs, int64_t count, int splits, float* out);
 // out[c] = sum over rows of X[rows][ld] columns [0,cols)

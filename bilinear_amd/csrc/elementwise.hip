@@ -332,6 +332,40 @@ int launch_colreduce(hipStream_t s, const float* in, int S, int64_t ld, int ncol
   return BLH_OK;
 }
 
+// all stages' Linear-bias gradients in one launch: out[stage][c] = sum_s part[stage][s][c]
+struct BiasOffsets { int64_t off[32]; };
+__global__ __launch_bounds__(256) void bias_colreduce_kernel(const float* __restrict__ part,
+                                                             int64_t stage_stride, int S, int W,
+                                                             float* __restrict__ grads,
+                                                             BiasOffsets offs) {
+  __shared__ double red[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cl;
+  const float* in = part + (int64_t)blockIdx.y * stage_stride;
+  double acc = 0.0;
+  if (col < W)
+    for (int s = sl; s < S; s += 8) acc += (double)in[(int64_t)s * W + col];
+  red[sl][cl] = acc;
+  __syncthreads();
+  if (sl == 0 && col < W) {
+    double t = 0.0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) t += red[s][cl];
+    grads[offs.off[blockIdx.y] + col] = (float)t;
+  }
+}
+
+int launch_bias_colreduce(hipStream_t s, const float* part, int64_t stage_stride, int S, int W,
+                          int num_stages, const int64_t* out_offsets, float* grads) {
+  if (num_stages > 32) return BLH_ERR_SHAPE;
+  BiasOffsets o{};
+  for (int i = 0; i < num_stages; ++i) o.off[i] = out_offsets[i];
+  hipLaunchKernelGGL(bias_colreduce_kernel, dim3((unsigned)ceil_div(W, 32), num_stages), dim3(256),
+                     0, s, part, stage_stride, S, W, grads, o);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
 int launch_bn_bwd_finalize(hipStream_t s, const float* part, int chunks, int W, float* dgamma,
                            float* dbeta) {
   // part is [chunks][2][W]; dgamma and dbeta are adjacent in the arena when W % 64 == 0

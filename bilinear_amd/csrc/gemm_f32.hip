@@ -39,11 +39,11 @@ static int gemm_pipe() {   // developer knob for on-box A/B runs: BLH_GEMM_PIPE=
 // Only the (tile, layout, epilogue) combinations the network and the unit tests use are
 // instantiated (each is a separate gfx950 kernel).
 static int launch_128x128(hipStream_t s, int la, int lb, int epi, const GemmParams& p, int splits) {
-  BLH_CASE(128, 128, 2, 4, ROWK, ROWK, EPI_BIAS_STATS)   // hidden / encode forward (train)
-  BLH_CASE(128, 128, 2, 4, ROWK, ROWK, EPI_BIAS)         // forward (eval)
-  BLH_CASE(128, 128, 2, 4, ROWK, ROWK, EPI_STORE)
-  BLH_CASE(128, 128, 2, 4, ROWK, KROW, EPI_STORE)        // dgrad
-  BLH_CASE(128, 128, 2, 4, ROWK, KROW, EPI_ADD)          // dgrad + residual gradient
+  BLH_CASE(128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS)   // hidden / encode forward (train)
+  BLH_CASE(128, 128, 4, 2, ROWK, ROWK, EPI_BIAS)         // forward (eval)
+  BLH_CASE(128, 128, 4, 2, ROWK, ROWK, EPI_STORE)
+  BLH_CASE(128, 128, 4, 2, ROWK, KROW, EPI_STORE)        // dgrad
+  BLH_CASE(128, 128, 4, 2, ROWK, KROW, EPI_ADD)          // dgrad + residual gradient
   BLH_CASE(128, 128, 4, 2, KROW, KROW, EPI_STORE)        // wgrad (split over the batch)
   BLH_CASE(128, 128, 4, 2, KROW, ROWK, EPI_STORE)
   return BLH_ERR_INVALID_ARGUMENT;

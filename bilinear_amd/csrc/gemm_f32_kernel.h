@@ -120,18 +120,16 @@ static __device__ float4 g_zero16;
 // One LDS-DMA of 16 B per lane issued from inline asm, so that hipcc does not know a DMA is in
 // flight: with the builtin it inserts a conservative `s_waitcnt vmcnt(0)` in front of every
 // ds_read that might alias the DMA destination, which drains the ring each K tile.  M0 (LDS
-// base of the wave's 1 KiB piece) is written in the same statement that uses it and restored.
+// base of the wave's 1 KiB piece) is written in the same statement that uses it; nothing else
+// in these kernels reads M0, so it is declared clobbered rather than saved and restored.
 __device__ __forceinline__ void lds_dma16_asm(const float* gsrc, uint32_t lds_byte_addr_uniform) {
-  uint32_t keep;
   asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
+      "s_mov_b32 m0, %1\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
+      "global_load_lds_dwordx4 %0, off"
+      :
       : "v"(gsrc), "s"(lds_byte_addr_uniform)
-      : "memory");
+      : "memory", "m0");
 }
 
 template <int LAYOUT, int R, int NT, bool ASM = false>
@@ -166,6 +164,59 @@ struct TileDMA {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       }
+    }
+  }
+};
+
+// Loop-invariant part of a thread's DMA work hoisted out of the K loop: source pointers at
+// the first tile (advanced by a constant stride per tile), row validity, and the wave-uniform
+// LDS byte offsets.  What is left per DMA is a pointer add, a k-range compare + select of the
+// zero page, two SALU adds and the 5-instruction M0 sequence.
+template <int LAYOUT, int R, int NT>
+struct DmaPlan {
+  static constexpr int CHUNKS = (R * BK / 4) / NT;
+  static_assert((R * BK / 4) % NT == 0, "tile not divisible among threads");
+  const float* src[CHUNKS];   // chunk source at the current tile (zero page for invalid rows)
+  int koff[CHUNKS];
+  int64_t step[CHUNKS];       // floats per K tile (0 for invalid rows: they stay on the zero page)
+  uint32_t wave_off;          // (tid & ~63) * 16, wave-uniform (SGPR)
+  bool ragged_k;              // the reduction range is not a multiple of BK (kernel-uniform)
+
+  __device__ inline void init(const float* __restrict__ base, int64_t ld, int row0, int rows_limit,
+                              int k_first, int k_end, int tid) {
+    const int64_t tile_step = (LAYOUT == ROWK) ? (int64_t)BK : (int64_t)BK * ld;
+    ragged_k = ((k_end - k_first) % BK) != 0;
+    wave_off = __builtin_amdgcn_readfirstlane((uint32_t)(tid & ~63) * 16u);
+#pragma unroll
+    for (int p = 0; p < CHUNKS; ++p) {
+      const int q = tid + p * NT;
+      int row, kk;
+      if (LAYOUT == ROWK) {
+        const int r = q >> 3;
+        row = row0 + r;
+        kk = (((q & 7) ^ (r & 7))) << 2;
+      } else {
+        constexpr int CPR = R / 4;
+        row = row0 + ((q % CPR) << 2);
+        kk = q / CPR;
+      }
+      const bool rowok = row < rows_limit;
+      koff[p] = kk;
+      const int64_t off = (LAYOUT == ROWK) ? ((int64_t)row * ld + k_first + kk)
+                                           : ((int64_t)(k_first + kk) * ld + row);
+      src[p] = rowok ? (base + off) : reinterpret_cast<const float*>(&g_zero16);
+      step[p] = rowok ? tile_step : 0;
+    }
+  }
+
+  // DMA tile whose first k is k0 into the LDS tile at byte address lds_tile (wave-uniform)
+  __device__ inline void issue(uint32_t lds_tile, int k0, int k_end) {
+#pragma unroll
+    for (int p = 0; p < CHUNKS; ++p) {
+      const float* g = src[p];
+      if (ragged_k && !(k0 + koff[p] < k_end)) g = reinterpret_cast<const float*>(&g_zero16);
+      lds_dma16_asm(g, lds_tile + wave_off + (uint32_t)(p * NT * 16));
+      src[p] += step[p];
     }
   }
 };
@@ -205,8 +256,8 @@ __device__ inline int xcd_remap(int bid, int nwg) {
 }
 
 template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int PIPE = 1, int STAMP = 0, int ABLATE = 0>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmParams p) {
-  constexpr int NT = 64 * WM * WN;
+__global__ __launch_bounds__(64 * WM * WN + (PIPE == 4 ? 64 : 0)) void gemm_f32_kernel(GemmParams p) {
+  constexpr int NT = 64 * WM * WN;   // MFMA (consumer) threads; PIPE 4 adds one DMA (producer) wave
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile must be at least 32x32");
   constexpr int A_FLOATS = TileGeom<LA, BM>::LDS_FLOATS;
@@ -218,6 +269,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
+  const bool is_cons = wave < WM * WN;   // false only for the PIPE 4 producer wave
   const int tiles_n = (p.N + BN - 1) / BN;
   const int nwg = gridDim.x;
   const int tile = xcd_remap(blockIdx.x, nwg);
@@ -253,23 +305,123 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  if (PIPE >= 2) {
+  if (PIPE == 4) {
+    // Wave-specialised LDS-DMA pipeline: wave WM*WN (the producer) issues every global->LDS
+    // DMA of the 3-stage ring (tile kt+2 while tile kt is multiplied) and does the counted
+    // vmcnt wait; the WM*WN consumer waves run nothing but ds_read + MFMA.  One s_barrier per
+    // K tile, executed by all waves: the producer arrives once tile kt+1 has landed, the
+    // consumers once their reads of tile kt are complete (lgkmcnt(0)), so after it tile kt+1
+    // may be read and the stage of tile kt may be overwritten (by the DMA of tile kt+3).
+    using DA = TileDMA<LA, BM, 64, true>;
+    using DB = TileDMA<LB, BN, 64, true>;
+    constexpr int RING = (BM + BN) * BK;
+    constexpr int G = DA::CHUNKS + DB::CHUNKS;
+    static_assert(G <= 60, "vmcnt is a 6-bit counter");
+    if (!is_cons) {
+      if (nkt > 0) {
+        DA::issue(smem, p.A, p.lda, m0, p.M, kz0, k_end, lane);
+        DB::issue(smem + BM * BK, p.B, p.ldb, n0, p.N, kz0, k_end, lane);
+        if (nkt > 1) {
+          DA::issue(smem + RING, p.A, p.lda, m0, p.M, kz0 + BK, k_end, lane);
+          DB::issue(smem + RING + BM * BK, p.B, p.ldb, n0, p.N, kz0 + BK, k_end, lane);
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+      }
+      int st_nn = 2;                                 // (kt + 2) % 3
+      for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = (kt + 1 < nkt), more2 = (kt + 2 < nkt);
+        if (more2) {
+          const int k0 = kz0 + (kt + 2) * BK;
+          DA::issue(smem + st_nn * RING, p.A, p.lda, m0, p.M, k0, k_end, lane);
+          DB::issue(smem + st_nn * RING + BM * BK, p.B, p.ldb, n0, p.N, k0, k_end, lane);
+        }
+        if (more) {
+          if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+        st_nn = (st_nn == 2) ? 0 : st_nn + 1;
+      }
+    } else {
+      float fa[2][TM][4], fb[2][TN][4];
+      if (nkt > 0) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read_frags_dma<LA, BM, TM>(fa[0], smem, wm * (TM * 32), 0, lane);
+        read_frags_dma<LB, BN, TN>(fb[0], smem + BM * BK, wn * (TN * 32), 0, lane);
+      }
+      int st_cur = 0;
+      for (int kt = 0; kt < nkt; ++kt) {
+        const int st_nxt = (st_cur == 2) ? 0 : st_cur + 1;
+        const float* sA = smem + st_cur * RING;
+        const float* sB = sA + BM * BK;
+        const float* nA = smem + st_nxt * RING;
+        const bool more = (kt + 1 < nkt);
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s) {
+          const int cur = s & 1, nxt = cur ^ 1;
+          if (s < BK / 8 - 1) {
+            read_frags_dma<LA, BM, TM>(fa[nxt], sA, wm * (TM * 32), s + 1, lane);
+            read_frags_dma<LB, BN, TN>(fb[nxt], sB, wn * (TN * 32), s + 1, lane);
+          } else if (more) {
+            read_frags_dma<LA, BM, TM>(fa[nxt], nA, wm * (TM * 32), 0, lane);
+            read_frags_dma<LB, BN, TN>(fb[nxt], nA + BM * BK, wn * (TN * 32), 0, lane);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int jn = 0; jn < TN; ++jn)
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][j], fb[cur][jn][j],
+                                                                  acc[i][jn], 0, 0, 0);
+          if (s == BK / 8 - 2 && more) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+          }
+        }
+        st_cur = st_nxt;
+      }
+    }
+    __syncthreads();
+  } else if (PIPE >= 2) {
     // LDS-DMA pipeline (PIPE 2: builtin DMA; PIPE 3: DMA issued from inline asm): a 3-stage ring of unpadded tiles filled by global_load_lds (no VGPR
     // staging, no ds_write); tile kt+2 is in flight while tile kt is multiplied.  One raw
     // s_barrier per K tile, behind a COUNTED vmcnt that retires only tile kt+1's DMAs (a
     // __syncthreads() would drain the ring) and lgkmcnt(0) (this wave's reads of the stage
     // that the next iteration's DMA overwrites are complete).
-    using DA = TileDMA<LA, BM, NT, PIPE == 3>;
-    using DB = TileDMA<LB, BN, NT, PIPE == 3>;
+    using DA = TileDMA<LA, BM, NT, false>;
+    using DB = TileDMA<LB, BN, NT, false>;
+    DmaPlan<LA, BM, NT> planA;
+    DmaPlan<LB, BN, NT> planB;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) float*)smem);
+    if (PIPE == 3) {
+      planA.init(p.A, p.lda, m0, p.M, kz0, k_end, tid);
+      planB.init(p.B, p.ldb, n0, p.N, kz0, k_end, tid);
+    }
     constexpr int RING = (BM + BN) * BK;          // floats per stage
     constexpr int G = DA::CHUNKS + DB::CHUNKS;    // DMA instructions per thread per tile
     float fa[2][TM][4], fb[2][TN][4];
     if (nkt > 0) {
-      DA::issue(smem, p.A, p.lda, m0, p.M, kz0, k_end, tid);
-      DB::issue(smem + BM * BK, p.B, p.ldb, n0, p.N, kz0, k_end, tid);
+      if (PIPE == 3) {
+        planA.issue(lds0, kz0, k_end);
+        planB.issue(lds0 + BM * BK * 4, kz0, k_end);
+      } else {
+        DA::issue(smem, p.A, p.lda, m0, p.M, kz0, k_end, tid);
+        DB::issue(smem + BM * BK, p.B, p.ldb, n0, p.N, kz0, k_end, tid);
+      }
       if (nkt > 1) {
-        DA::issue(smem + RING, p.A, p.lda, m0, p.M, kz0 + BK, k_end, tid);
-        DB::issue(smem + RING + BM * BK, p.B, p.ldb, n0, p.N, kz0 + BK, k_end, tid);
+        if (PIPE == 3) {
+          planA.issue(lds0 + RING * 4, kz0 + BK, k_end);
+          planB.issue(lds0 + (RING + BM * BK) * 4, kz0 + BK, k_end);
+        } else {
+          DA::issue(smem + RING, p.A, p.lda, m0, p.M, kz0 + BK, k_end, tid);
+          DB::issue(smem + RING + BM * BK, p.B, p.ldb, n0, p.N, kz0 + BK, k_end, tid);
+        }
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -289,8 +441,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmParams p) {
       const bool more = (kt + 1 < nkt), more2 = (kt + 2 < nkt);
       if (more2) {
         const int k0 = kz0 + (kt + 2) * BK;
-        DA::issue(smem + st_nn * RING, p.A, p.lda, m0, p.M, k0, k_end, tid);
-        DB::issue(smem + st_nn * RING + BM * BK, p.B, p.ldb, n0, p.N, k0, k_end, tid);
+        if (PIPE == 3) {
+          planA.issue(lds0 + st_nn * (RING * 4), k0, k_end);
+          planB.issue(lds0 + st_nn * (RING * 4) + BM * BK * 4, k0, k_end);
+        } else {
+          DA::issue(smem + st_nn * RING, p.A, p.lda, m0, p.M, k0, k_end, tid);
+          DB::issue(smem + st_nn * RING + BM * BK, p.B, p.ldb, n0, p.N, k0, k_end, tid);
+        }
       }
 #pragma unroll
       for (int s = 0; s < BK / 8; ++s) {
@@ -443,7 +600,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmParams p) {
           if (row < p.M) s += acc[i][jn][r];
         }
       s += __shfl_xor(s, 32);
-      if (h == 0) red[wm * BN + wn * (TN * 32) + jn * 32 + lc] = s;
+      if (h == 0 && is_cons) red[wm * BN + wn * (TN * 32) + jn * 32 + lc] = s;
     }
     __syncthreads();
 #pragma unroll
@@ -466,10 +623,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmParams p) {
           if (row < p.M) s += dlt * dlt;
         }
       s += __shfl_xor(s, 32);
-      if (h == 0) red[wm * BN + wn * (TN * 32) + jn * 32 + lc] = s;
+      if (h == 0 && is_cons) red[wm * BN + wn * (TN * 32) + jn * 32 + lc] = s;
     }
     __syncthreads();
-    if (wm == 0 && h == 0) {
+    if (wm == 0 && h == 0 && is_cons) {
 #pragma unroll
       for (int jn = 0; jn < TN; ++jn) {
         const int col = col_w + jn * 32;
@@ -493,7 +650,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
       for (int jn = 0; jn < TN; ++jn) {
         const int col = col_w + jn * 32;
-        if (row < p.M && col < p.N) {
+        if (row < p.M && col < p.N && is_cons) {
           float v = acc[i][jn][r];
           if (EPI == EPI_ADD) v += p.addend[(int64_t)row * p.ldadd + col];
           C[(int64_t)row * p.ldc + col] = v;
@@ -511,7 +668,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmParams p) {
     for (int o = 32; o >= 1; o >>= 1) lsum += __shfl_xor(lsum, o);
     float* red = smem;
     __syncthreads();
-    if (lane == 0) red[wave] = lsum;
+    if (lane == 0 && is_cons) red[wave] = lsum;
     __syncthreads();
     if (tid == 0) {
       float t = 0.f;

@@ -14,7 +14,7 @@ thread_local int blh::g_last_hip_error = 0;
 
 template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int PIPE>
 float run(const GemmParams& p, int splits, int reps) {
-  constexpr int NT = 64 * WM * WN;
+  constexpr int NT = 64 * WM * WN + (PIPE == 4 ? 64 : 0);
   constexpr size_t lds = gemm_lds_bytes<BM, BN, LA, LB, PIPE>();
   auto kern = gemm_f32_kernel<BM, BN, WM, WN, LA, LB, EPI, PIPE>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -66,7 +66,11 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&A, act * 4)); CK(hipMalloc(&B, (size_t)W * W * 4)); CK(hipMalloc(&C, std::max(act, (size_t)16 * W * W) * 4));
   CK(hipMalloc(&bias, W * 4)); CK(hipMalloc(&stat, (size_t)(M / 32 + 1) * 2 * W * 4));
   std::vector<float> h(act);
-  for (size_t i = 0; i < act; ++i) h[i] = (float)((double)rand() / RAND_MAX - 0.5);
+  const bool normal = getenv("BENCH_NORMAL") != nullptr;
+  for (size_t i = 0; i < act; ++i) {
+    if (normal) { double u = 0; for (int k = 0; k < 12; ++k) u += (double)rand() / RAND_MAX; h[i] = (float)(u - 6.0); }
+    else h[i] = (float)((double)rand() / RAND_MAX - 0.5);
+  }
   CK(hipMemcpy(A, h.data(), act * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(B, h.data(), (size_t)W * W * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(bias, h.data(), W * 4, hipMemcpyHostToDevice));
@@ -97,6 +101,9 @@ int main(int argc, char** argv) {
 
   ROW("128x128 w4x2 pipe1", 128, 128, 4, 2, 1)
   ROW("128x128 w4x2 pipe2", 128, 128, 4, 2, 2)
+  ROW("128x128 w4x2 pipe4", 128, 128, 4, 2, 4)
+  ROW("128x128 w2x4 pipe4", 128, 128, 2, 4, 4)
+  ROW("128x128 w2x2 pipe4", 128, 128, 2, 2, 4)
   ROW("128x128 w4x2 pipe3", 128, 128, 4, 2, 3)
   ROW("128x128 w2x4 pipe3", 128, 128, 2, 4, 3)
   ROW("128x128 w2x2 pipe3", 128, 128, 2, 2, 3)

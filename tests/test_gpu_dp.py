@@ -1,0 +1,116 @@
+"""Data-parallel step on the GPU box (one GPU: two ranks share cuda:0 over gloo; RCCL
+itself needs one device per rank and is exercised by bench.py --gpus N on the 8-GPU
+node).  Checks the whole DataParallel.train_step path — per-rank forward with
+global-row Philox offsets, backward with the on_ready bucket hook firing from inside
+blh_backward, averaged gradients, replicated clip + Adam — against a single-process
+run that computes the two shards' gradients separately and averages them."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+NB, WIDTH, LOCAL_B = 2, 256, 96
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(dev):
+    import bilinear_amd
+    torch.manual_seed(123)
+    net, opt, _, _ = bilinear_amd.load(dev, num_blocks=NB, width=WIDTH)
+    net.train()
+    net.engine.seed = 4242
+    return net, opt
+
+
+def _data(dev):
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2 * LOCAL_B, 32, generator=g).to(dev)
+    t = torch.randn(2 * LOCAL_B, 48, generator=g).to(dev)
+    return x, t
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bilinear_amd.dp import DataParallel
+        dev = torch.device("cuda:0")
+        net, opt = _make(dev)
+        x, t = _data(dev)
+        dp = DataParallel(net, opt, bucket_floats=50000)
+        sl = slice(rank * LOCAL_B, (rank + 1) * LOCAL_B)
+        for _ in range(2):
+            pred, loss = dp.train_step(x[sl], t[sl])
+        torch.cuda.synchronize()
+        assert len(dp._reducer.launched) >= 2            # several buckets, overlapped with backward
+        np.save(os.path.join(out_dir, "params%d.npy" % rank), net.engine.params.cpu().numpy())
+        np.save(os.path.join(out_dir, "grads%d.npy" % rank), net.engine.grads.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_match_manual_average(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = np.load(tmp_path / "params0.npy"), np.load(tmp_path / "params1.npy")
+    g0, g1 = np.load(tmp_path / "grads0.npy"), np.load(tmp_path / "grads1.npy")
+    assert np.array_equal(p0, p1), "replicas diverged"
+    assert np.array_equal(g0, g1)
+
+    # single process: same two steps, gradients of the two shards computed one after the
+    # other (per-shard BN statistics, global-row dropout offsets) and averaged by hand
+    dev = torch.device("cuda:0")
+    net, opt = _make(dev)
+    x, t = _data(dev)
+    eng = net.engine
+    eng.ensure(dev)
+    opt._ensure_moments(eng)
+    for step in range(2):
+        acc = torch.zeros_like(eng.grads)
+        bn0 = eng.bn_running.clone()
+        nbt0 = eng.bn_nbt.clone()
+        for r in range(2):
+            sl = slice(r * LOCAL_B, (r + 1) * LOCAL_B)
+            eng.row_offset = r * LOCAL_B
+            eng.rng_step = step
+            if r == 1:                       # each rank updates its own copy of the BN buffers
+                eng.bn_running.copy_(bn0)
+                eng.bn_nbt.copy_(nbt0)
+            pred = eng.forward_train(x[sl].contiguous())
+            _, dpred = eng.mse_loss_grad(pred, t[sl].contiguous())
+            eng.backward(x[sl].contiguous(), dpred)
+            acc += eng.grads
+        eng.grads.copy_(acc / 2)
+        g = opt.param_groups[0]
+        opt._t += 1
+        eng.clip_adam(opt._exp_avg, opt._exp_avg_sq, float(g["lr"]), g["betas"], g["eps"], 1.0,
+                      opt._t, opt._stats)
+    torch.cuda.synchronize()
+    ref = eng.params.cpu().numpy()
+    # rank 0's BN running stats come from shard 0; the parameters must agree to fp32 rounding
+    # (gloo sums in a different order than acc/2)
+    # (pre-BN Linear biases excluded: their gradient is rounding noise that Adam turns into
+    #  +-lr updates; elsewhere an ulp-level gradient difference moves a
+    #  parameter by at most a small fraction of lr)
+    from golden_util import is_prebn_bias
+    for name, off, shape in eng.layout.entries:
+        n = int(np.prod(shape))
+        if is_prebn_bias(name):
+            assert np.abs(p0[off:off + n] - ref[off:off + n]).max() <= 2.1e-3 * 2, name
+            continue
+        err = np.abs(p0[off:off + n] - ref[off:off + n]).max()
+        assert err <= 5e-5, (name, err)
