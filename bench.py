@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=2)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="N=1: launch the step eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--cpu-steps", type=int, default=12)
     args = ap.parse_args()
 
@@ -159,10 +161,14 @@ def main():
     x = torch.randn(args.batch, 32, device=dev, generator=g)
     t = torch.randn(args.batch, 48, device=dev, generator=g)
     dp = DataParallel(net, opt) if world > 1 else None
+    use_graph = (world == 1) and not args.no_graph
+    captured = bilinear_amd.CapturedTrainStep(net, opt, args.batch, max_norm=1.0) if use_graph else None
 
     def one_step():
         if dp is not None:
             return dp.train_step(x, t)
+        if captured is not None:
+            return captured(x, t)
         return net.train_step(opt, x, t, max_norm=1.0)
 
     log("model built, warm-up")
@@ -226,6 +232,7 @@ def main():
                 "global_batch": args.batch * world,
                 "parallelism": "dp%d" % world,
                 "dropout": "philox",
+                "launch": "hipGraph replay (1 launch/step)" if use_graph else "eager (~50 launches/step)",
             },
             "final_loss": final_loss,
             "fwd_bwd_only": {"ms_per_step": fb_ms, "poses_per_s": args.batch / (fb_ms / 1e3)},

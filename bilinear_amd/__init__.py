@@ -10,6 +10,8 @@ is no CPU or ATen fallback.
 """
 from . import _native  # noqa: F401
 from .model.bilinear import Bilinear, BilinearUnit, heavy_linear, load  # noqa: F401
+from .graph import CapturedTrainStep  # noqa: F401
 from .optim import Adam, clip_grad_norm_  # noqa: F401
 
-__all__ = ["BilinearUnit", "Bilinear", "heavy_linear", "load", "Adam", "clip_grad_norm_"]
+__all__ = ["BilinearUnit", "Bilinear", "heavy_linear", "load", "Adam", "clip_grad_norm_",
+           "CapturedTrainStep"]

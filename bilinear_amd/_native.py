@@ -34,6 +34,12 @@ class AdamHyper(Structure):
                 ("max_norm", c_float), ("step", c_int32)]
 
 
+class StepState(Structure):
+    _fields_ = [("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
+                ("max_norm", c_float), ("step", c_int32), ("rng_step", c_uint64),
+                ("step_size", c_float), ("bc2_sqrt", c_float)]
+
+
 GradReadyFn = ctypes.CFUNCTYPE(None, c_void_p, c_int64, c_int64)
 
 # name -> (restype, argtypes); mirrors include/bilinear_hip.h one to one
@@ -66,6 +72,11 @@ _SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                POINTER(Dropout), c_float, POINTER(AdamHyper), c_void_p, c_int64,
                                c_void_p, c_void_p, c_void_p, c_int64]),
+    "blh_step_state_advance": (c_int, [c_void_p, c_void_p]),
+    "blh_train_step_captured": (c_int, [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        POINTER(Dropout), c_float, c_void_p, c_void_p, c_int64,
+                                        c_void_p, c_void_p, c_void_p, c_int64]),
     "blh_gemm_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
                              c_void_p, c_int64, c_int64, c_int64, c_int64, c_int32, c_void_p,
                              c_void_p, c_int64]),

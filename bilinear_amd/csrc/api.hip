@@ -102,6 +102,18 @@ static Splits pick_splits(int64_t batch, int64_t tiles) {
   return Splits{(int)s, (int)k_per};
 }
 
+// Small-batch Linear forward / dgrad (M = batch rows, N = W columns, reduction K): when the
+// 128x128 output tiles cover less than half of the 256 CUs, split the reduction so that about
+// one workgroup per CU is in flight.  Returns splits == 1 for the ordinary path.
+static Splits small_m_splits(int64_t batch, int W, int K) {
+  const int64_t tiles = ceil_div(batch, 128) * ceil_div(W, 128);
+  if (tiles >= 128 || K < 64) return Splits{1, K};
+  int64_t s = std::min<int64_t>(ceil_div(256, tiles), K / 32);
+  int64_t k_per = round_up(ceil_div(K, s), 32);
+  s = ceil_div(K, k_per);
+  return Splits{(int)s, (int)k_per};
+}
+
 // decode forward: split W so that (B/128) * splits is about one workgroup per CU
 static Splits decode_fwd_splits(int64_t batch, int W) {
   int64_t want = std::max<int64_t>(1, ceil_div(256, ceil_div(batch, 128)));
@@ -120,6 +132,7 @@ static int64_t slab_floats(const blh_model_desc* d, int64_t batch) {
   m = std::max(m, es.splits * W * (int64_t)d->in_features);
   m = std::max(m, ds.splits * (int64_t)d->out_features * W);
   m = std::max(m, decode_fwd_splits(batch, d->width).splits * batch * d->out_features);
+  m = std::max(m, small_m_splits(batch, d->width, d->width).splits * batch * W);
   return m;
 }
 
@@ -167,8 +180,12 @@ static Scratch carve_scratch(void* base) {
   return s;
 }
 
+// device address of blh_step_state.rng_step for the current call (graph-captured step), else null
+static thread_local const uint64_t* g_step_dev = nullptr;
+
 static DropoutSrc layer_drop(const blh_dropout* drop, int layer, int64_t batch, int W) {
   DropoutSrc d;
+  d.step_dev = g_step_dev;
   d.keep = drop->keep_mask ? drop->keep_mask + (int64_t)layer * batch * W : nullptr;
   d.seed = drop->seed; d.step = drop->step; d.row_offset = drop->row_offset; d.layer = layer;
   return d;
@@ -194,14 +211,29 @@ static int forward_impl(const blh_model_desc* d, hipStream_t s, const float* par
     g.M = (int)batch; g.N = W; g.K = h.fan_in; g.k_per_split = h.fan_in;
     g.bias = params + h.b;
     g.stat_part = ws.stat_part;
-    BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, train ? EPI_BIAS_STATS : EPI_BIAS, g, 1));
+    const Splits fs = small_m_splits(batch, W, h.fan_in);
+    if (fs.splits > 1) {
+      // small batch: too few 128x128 output tiles to fill the chip and each would walk the
+      // whole reduction alone (latency-bound), so cut the reduction across workgroups and
+      // finish (slab sum + bias + BN tile statistics) in a streaming kernel
+      g.C = ws.slabs; g.c_split_stride = batch * (int64_t)W; g.k_per_split = fs.k_per;
+      BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, EPI_STORE, g, fs.splits));
+      BLH_TRY(launch_fwd_finish(s, ws.slabs, fs.splits, batch, W, params + h.b, ws.Z[i],
+                                train ? ws.stat_part : nullptr));
+    } else {
+      BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, train ? EPI_BIAS_STATS : EPI_BIAS, g, 1));
+    }
     // second stage of a block adds the block input (model/bilinear.py:36-38)
     const float* skip = (i >= 2 && (i % 2) == 0) ? ws.A[i - 2] : nullptr;
     float* rm = bn_running + ((int64_t)i * 2 + 0) * W;
     float* rv = bn_running + ((int64_t)i * 2 + 1) * W;
     if (train) {
       float* sv = ws.bn_saved[i];
-      BLH_TRY(launch_bn_fwd_finalize(s, ws.stat_part, tiles_m, 128, batch, W, params + h.gamma,
+      // (the small-batch path produced one statistics tile covering all rows)
+      const int st_tiles = fs.splits > 1 ? 1 : tiles_m;
+      const int st_rows = fs.splits > 1 ? (int)batch : 128;
+      BLH_TRY(launch_bn_fwd_finalize(s, ws.stat_part, st_tiles, st_rows, batch, W,
+                                     params + h.gamma,
                                      params + h.beta, rm, rv, nbt + i, momentum, sv, sv + W,
                                      sv + 2 * W, sv + 3 * W));
       BLH_TRY(launch_bn_apply_train(s, ws.Z[i], sv + 2 * W, sv + 3 * W, skip, ws.A[i], batch, W,
@@ -300,7 +332,14 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
       g.B = params + h.w; g.ldb = W;
       g.M = (int)batch; g.N = W; g.K = W; g.k_per_split = W;
       g.ldc = W;
-      if (first_of_block) {
+      const Splits ds2 = small_m_splits(batch, W, W);
+      float* dst = first_of_block ? ws.G0 : ws.G1;
+      if (ds2.splits > 1) {
+        g.C = ws.slabs; g.c_split_stride = batch * (int64_t)W; g.k_per_split = ds2.k_per;
+        BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, ds2.splits));
+        BLH_TRY(launch_sum_slabs_add(s, ws.slabs, batch * (int64_t)W, ds2.splits,
+                                     first_of_block ? ws.G0 : nullptr, dst));
+      } else if (first_of_block) {
         // d(block input) = dZ W + d(block output)   (skip path), in place in G0
         g.C = ws.G0; g.addend = ws.G0; g.ldadd = W;
         BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_ADD, g, 1));
@@ -497,6 +536,42 @@ int blh_train_step(const blh_model_desc* d, void* stream, float* params, float* 
                           stats_out);
 }
 
+int blh_step_state_advance(void* stream, blh_step_state* dev_state) {
+  if (!dev_state) return BLH_ERR_INVALID_ARGUMENT;
+  return launch_step_state_advance((hipStream_t)stream, dev_state);
+}
+
+int blh_train_step_captured(const blh_model_desc* d, void* stream, float* params, float* grads,
+                            float* exp_avg, float* exp_avg_sq, float* bn_running,
+                            int64_t* bn_nbt, const float* x, const float* target,
+                            const blh_dropout* drop, float momentum, blh_step_state* dev_state,
+                            void* workspace, int64_t workspace_bytes, float* pred,
+                            float* loss_out, float* stats_out, int64_t batch) {
+  BLH_TRY(check_common(d, workspace, workspace_bytes, batch));
+  BLH_TRY(check_drop(drop));
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !bn_running || !bn_nbt || !x || !target ||
+      !dev_state || !pred || !loss_out)
+    return BLH_ERR_INVALID_ARGUMENT;
+  if (batch < 2) return BLH_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const Workspace ws = carve(d, batch, workspace);
+  const double denom = (double)batch * d->out_features;
+  int nparts = 0, np = 0;
+  BLH_TRY(launch_step_state_advance(s, dev_state));
+  struct StepDevGuard {   // kernels of this call add dev_state->rng_step to the dropout step
+    StepDevGuard(const uint64_t* p) { g_step_dev = p; }
+    ~StepDevGuard() { g_step_dev = nullptr; }
+  } guard(&dev_state->rng_step);
+  BLH_TRY(forward_impl(d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
+                       target, (float)(2.0 / denom), ws.loss_part, &nparts));
+  BLH_TRY(launch_loss_finalize(s, ws.loss_part, nparts, denom, loss_out));
+  BLH_TRY(backward_impl(d, s, params, x, drop, ws, ws.dpred, grads, batch, nullptr, nullptr));
+  const int64_t count = make_layout(d).total;
+  BLH_TRY(launch_sumsq(s, grads, count, ws.sumsq_part, &np));
+  return launch_clip_adam_dev(s, params, grads, exp_avg, exp_avg_sq, count, dev_state,
+                              ws.sumsq_part, np, stats_out);
+}
+
 int blh_gemm_f32(void* stream, const float* A, int64_t lda, int32_t a_kmajor, const float* B,
                  int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc, int64_t M, int64_t N,
                  int64_t K, int32_t splits, const float* bias, const float* addend,
@@ -536,7 +611,7 @@ int blh_dropout_mask(void* stream, const blh_dropout* drop, int32_t layer, int64
   if (!drop || !keep_out || batch <= 0 || width <= 0 || width % 4 != 0 || drop->keep_mask)
     return BLH_ERR_INVALID_ARGUMENT;
   BLH_TRY(check_drop(drop));
-  DropoutSrc d{nullptr, drop->seed, drop->step, drop->row_offset, layer};
+  DropoutSrc d{nullptr, drop->seed, drop->step, drop->row_offset, layer, nullptr};
   return launch_dropout_mask((hipStream_t)stream, keep_out, batch, width, d);
 }
 

@@ -71,7 +71,17 @@ struct DropoutSrc {
   uint64_t seed, step;
   int64_t row_offset;
   int layer;
+  // hipGraph replay: the dropout step lives in device memory (blh_step_state.rng_step) and is
+  // added to `step`, so that a captured launch draws a fresh mask on every replay
+  const uint64_t* step_dev;
 };
+__host__ __device__ inline uint64_t dropout_step(const DropoutSrc& d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return d.step + (d.step_dev ? *d.step_dev : 0ull);
+#else
+  return d.step;
+#endif
+}
 
 static constexpr int EW_COLS_PER_BLOCK = 256;    // 64 lanes x float4, 4 waves share the rows
 int ew_row_chunk(int64_t batch);                 // rows handled by one block (multiple of 32)
@@ -111,6 +121,12 @@ int launch_bias_colreduce(hipStream_t s, const float* part, int64_t stage_stride
                           int num_stages, const int64_t* out_offsets, float* grads);
 // out[i] = sum_s in[s][i]   (slabs of `count` floats)
 int launch_sum_slabs(hipStream_t s, const float* slabs, int64_t count, int splits, float* out);
+int launch_sum_slabs_add(hipStream_t s, const float* slabs, int64_t count, int splits,
+                         const float* addend, float* out);
+// small-batch forward: Z = sum(slabs) + bias; stat_part (may be null) receives the column
+// (mean, M2) over ALL M rows as a single statistics tile: [2][N]
+int launch_fwd_finish(hipStream_t s, const float* slabs, int splits, int64_t M, int N,
+                      const float* bias, float* Z, float* stat_part);
 // out[c] = sum over rows of X[rows][ld] columns [0,cols)
 int launch_colsum(hipStream_t s, const float* X, int64_t rows, int cols, int64_t ld, float* part,
                   float* out);
@@ -124,6 +140,11 @@ int launch_sumsq(hipStream_t s, const float* g, int64_t count, double* part, int
 int launch_clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count,
                      const blh_adam_hyper& h, const double* sumsq_part, int nparts,
                      float* stats_out);
+// device-state variants (graph replay): hyper-parameters and step counters read on the device
+int launch_step_state_advance(hipStream_t s, blh_step_state* st);
+int launch_clip_adam_dev(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count,
+                         const blh_step_state* st, const double* sumsq_part, int nparts,
+                         float* stats_out);
 int launch_clip_scale(hipStream_t s, float* g, int64_t count, float max_norm,
                       const double* sumsq_part, int nparts, float* stats_out);
 // pred = sum(slabs) + bias (+ fused MSE when target != nullptr)

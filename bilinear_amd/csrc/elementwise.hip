@@ -35,7 +35,7 @@ __device__ __forceinline__ uint32_t keep_nibble(const DropoutSrc& d, DropState& 
     return (k.x ? 1u : 0u) | (k.y ? 2u : 0u) | (k.z ? 4u : 0u) | (k.w ? 8u : 0u);
   }
   const int64_t grow = r + d.row_offset;
-  if (first || (grow & 31) == 0) st.patch = dropout_patch(d.seed, d.step, d.layer, grow, col);
+  if (first || (grow & 31) == 0) st.patch = dropout_patch(d.seed, dropout_step(d), d.layer, grow, col);
   return patch_nibble(st.patch, (int)(grow & 31));
 }
 
@@ -137,7 +137,7 @@ __device__ __forceinline__ PatchMask patch_mask(const DropoutSrc& d, int64_t bas
       m.nib[i] = n;
     }
   } else {
-    const Philox128 p = dropout_patch(d.seed, d.step, d.layer, base + d.row_offset, col);
+    const Philox128 p = dropout_patch(d.seed, dropout_step(d), d.layer, base + d.row_offset, col);
     // row w + 4i (w < 4): word i>>1 (compile-time), nibble w + 4*(i&1)
 #pragma unroll
     for (int i = 0; i < ROWS_PER_LANE; ++i) m.nib[i] = (p.w[i >> 1] >> (4 * (w + 4 * (i & 1)))) & 0xFu;
@@ -233,7 +233,7 @@ int launch_bn_apply_train(hipStream_t s, const float* Z, const float* scale, con
 int launch_bn_apply_eval(hipStream_t s, const float* Z, const float* gamma, const float* beta,
                          const float* running_mean, const float* running_var, const float* skip,
                          float* A, int64_t batch, int W) {
-  DropoutSrc none{nullptr, 0, 0, 0, 0};
+  DropoutSrc none{nullptr, 0, 0, 0, 0, nullptr};
   hipLaunchKernelGGL(bn_apply_kernel<false>, ew_grid(batch, W), dim3(EW_THREADS), 0, s, Z,
                      nullptr, nullptr, gamma, beta, running_mean, running_var, skip, A, batch, W,
                      ew_row_chunk(batch), none, nullptr);
@@ -444,7 +444,8 @@ int launch_bn_bwd_apply(hipStream_t s, const float* dA, const float* Z, const fl
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ slabs,
                                                         int64_t count, int splits,
-                                                        float* __restrict__ out) {
+                                                        const float* addend,
+                                                        float* out) {
   const int64_t n4 = count >> 2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -453,16 +454,105 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
       const float4 b = ld4(slabs + (int64_t)s * count + i * 4);
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
+    if (addend) {     // may alias out (element-wise read-then-write by the same thread)
+      const float4 b = ld4(addend + i * 4);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
     st4(out + i * 4, a);
   }
 }
 
-int launch_sum_slabs(hipStream_t s, const float* slabs, int64_t count, int splits, float* out) {
+int launch_sum_slabs_add(hipStream_t s, const float* slabs, int64_t count, int splits,
+                         const float* addend, float* out) {
   if (count % 4 != 0) return BLH_ERR_SHAPE;
   const int64_t blocks = std::min<int64_t>(ceil_div(count / 4, 256), 2048);
   hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs, count,
-                     splits, out);
+                     splits, addend, out);
   BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+int launch_sum_slabs(hipStream_t s, const float* slabs, int64_t count, int splits, float* out) {
+  return launch_sum_slabs_add(s, slabs, count, splits, nullptr, out);
+}
+
+// ---------------------------------------------------------------------------
+// small-batch forward: Z = sum of split-K slabs + bias (streaming, fully parallel), then the
+// column (mean, M2) over all M rows as ONE statistics tile (Welford per thread, Chan merge
+// across the 8 row lanes).  block = 32 columns x 8 row lanes.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sum_slabs_bias_kernel(const float* __restrict__ slabs,
+                                                             int64_t count, int splits, int N,
+                                                             const float* __restrict__ bias,
+                                                             float* __restrict__ out) {
+  const int64_t n4 = count >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float4 a = ld4(bias + (int)((i * 4) % N));
+    int s = 0;
+    for (; s + 4 <= splits; s += 4) {
+      const float4 b0 = ld4(slabs + (int64_t)(s + 0) * count + i * 4);
+      const float4 b1 = ld4(slabs + (int64_t)(s + 1) * count + i * 4);
+      const float4 b2 = ld4(slabs + (int64_t)(s + 2) * count + i * 4);
+      const float4 b3 = ld4(slabs + (int64_t)(s + 3) * count + i * 4);
+      a.x += (b0.x + b1.x) + (b2.x + b3.x); a.y += (b0.y + b1.y) + (b2.y + b3.y);
+      a.z += (b0.z + b1.z) + (b2.z + b3.z); a.w += (b0.w + b1.w) + (b2.w + b3.w);
+    }
+    for (; s < splits; ++s) {
+      const float4 b = ld4(slabs + (int64_t)s * count + i * 4);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    st4(out + i * 4, a);
+  }
+}
+
+__global__ __launch_bounds__(256) void col_stats_direct_kernel(const float* __restrict__ Z,
+                                                               int64_t M, int N,
+                                                               float* __restrict__ stat_part) {
+  __shared__ float s_n[8][32], s_mean[8][32], s_m2[8][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cl;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  if (col < N)
+    for (int64_t r = rl; r < M; r += 8) {
+      const float x = Z[r * N + col];
+      n += 1.f;
+      const float d = x - mean;
+      mean += d / n;
+      m2 += d * (x - mean);
+    }
+  s_n[rl][cl] = n; s_mean[rl][cl] = mean; s_m2[rl][cl] = m2;
+  __syncthreads();
+  if (rl == 0 && col < N) {
+    float tn = 0.f, tm = 0.f, tm2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      const float bn = s_n[w][cl];
+      if (bn > 0.f) {
+        const float d = s_mean[w][cl] - tm, nn = tn + bn;
+        tm += d * (bn / nn);
+        tm2 += s_m2[w][cl] + d * d * (tn * bn / nn);
+        tn = nn;
+      }
+    }
+    stat_part[col] = tm;
+    stat_part[N + col] = tm2;
+  }
+}
+
+int launch_fwd_finish(hipStream_t s, const float* slabs, int splits, int64_t M, int N,
+                      const float* bias, float* Z, float* stat_part) {
+  const int64_t count = M * N;
+  if (count % 4 != 0 || N % 4 != 0) return BLH_ERR_SHAPE;
+  const int64_t blocks = std::min<int64_t>(ceil_div(count / 4, 256), 2048);
+  hipLaunchKernelGGL(sum_slabs_bias_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs, count,
+                     splits, N, bias, Z);
+  BLH_HIP_TRY(hipGetLastError());
+  if (stat_part) {
+    hipLaunchKernelGGL(col_stats_direct_kernel, dim3((unsigned)ceil_div(N, 32)), dim3(256), 0, s, Z,
+                       M, N, stat_part);
+    BLH_HIP_TRY(hipGetLastError());
+  }
   return BLH_OK;
 }
 
@@ -785,6 +875,84 @@ int launch_decode_finish(hipStream_t s, const float* slabs, int splits, int64_t 
                      out_features, bias, pred, target, scale, dpred, loss_part);
   BLH_HIP_TRY(hipGetLastError());
   if (nparts) *nparts = blocks;
+  return BLH_OK;
+}
+
+}  // namespace blh
+
+// ---------------------------------------------------------------------------
+// device-resident step state (hipGraph replay)
+// ---------------------------------------------------------------------------
+namespace blh {
+
+__global__ void step_state_advance_kernel(blh_step_state* st) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int t = st->step + 1;
+    st->step = t;
+    st->rng_step += 1;
+    const double bc1 = 1.0 - pow((double)st->beta1, (double)t);
+    const double bc2 = 1.0 - pow((double)st->beta2, (double)t);
+    st->step_size = (float)((double)st->lr / bc1);
+    st->bc2_sqrt = (float)sqrt(bc2);
+  }
+}
+
+int launch_step_state_advance(hipStream_t s, blh_step_state* st) {
+  hipLaunchKernelGGL(step_state_advance_kernel, dim3(1), dim3(64), 0, s, st);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+__global__ __launch_bounds__(256) void clip_adam_dev_kernel(
+    float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+    int64_t count, const blh_step_state* __restrict__ st, const double* __restrict__ sumsq_part,
+    int nparts, float* stats_out) {
+  __shared__ double sh[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) a += sumsq_part[i];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float total_norm = (float)sqrt(sh[0]);
+  const float max_norm = st->max_norm;
+  float coef = 1.0f;
+  if (max_norm > 0.f) coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);
+  if (stats_out && blockIdx.x == 0 && threadIdx.x == 0) {
+    stats_out[0] = total_norm;
+    stats_out[1] = coef;
+  }
+  const float one_minus_b1 = (float)(1.0 - (double)st->beta1), b2 = st->beta2,
+              one_minus_b2 = (float)(1.0 - (double)st->beta2), step_size = st->step_size,
+              bc2_sqrt = st->bc2_sqrt, eps = st->eps;
+  const int64_t n4 = count >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float4 gv = ld4(g + i * 4), mv = ld4(m + i * 4), vv = ld4(v + i * 4), pv = ld4(p + i * 4);
+    float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x; float* pp = &pv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gg = gp[k] * coef;
+      gp[k] = gg;
+      mp[k] = mp[k] + (gg - mp[k]) * one_minus_b1;
+      vp[k] = vp[k] * b2 + (one_minus_b2 * gg) * gg;
+      const float denom = sqrtf(vp[k]) / bc2_sqrt + eps;
+      pp[k] = pp[k] - step_size * (mp[k] / denom);
+    }
+    st4(g + i * 4, gv); st4(m + i * 4, mv); st4(v + i * 4, vv); st4(p + i * 4, pv);
+  }
+}
+
+int launch_clip_adam_dev(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count,
+                         const blh_step_state* st, const double* sumsq_part, int nparts,
+                         float* stats_out) {
+  if (count % 4 != 0) return BLH_ERR_SHAPE;
+  const int blocks = (int)std::min<int64_t>(ceil_div(count / 4, 256), 2048);
+  hipLaunchKernelGGL(clip_adam_dev_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, count, st,
+                     sumsq_part, nparts, stats_out);
+  BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
 

@@ -248,8 +248,17 @@ class Engine:
         if tuple(dpred.shape) != (batch, OUT_FEATURES) or dpred.dtype != torch.float32:
             raise RuntimeError("bad output gradient: %s %s" % (tuple(dpred.shape), dpred.dtype))
         ws = self.workspace(batch)
+        errors = []
         if on_ready is not None:
-            cb = N.GradReadyFn(lambda user, off, cnt: on_ready(int(off), int(cnt)))
+            def _hook(user, off, cnt):
+                # an exception must not unwind through the C frames of blh_backward:
+                # remember it and re-raise once the call has returned
+                if not errors:
+                    try:
+                        on_ready(int(off), int(cnt))
+                    except BaseException as exc:   # noqa: BLE001
+                        errors.append(exc)
+            cb = N.GradReadyFn(_hook)
         else:
             cb = ctypes.cast(None, N.GradReadyFn)
         self._grad_ready_cb = cb       # keep alive during the call
@@ -258,6 +267,8 @@ class Engine:
             ctypes.byref(self._saved_drop), N.ptr(ws), ws.numel(), N.ptr(dpred),
             N.ptr(self.grads), batch, cb, None), "blh_backward")
         self._saved_batch = None
+        if errors:
+            raise errors[0]
 
     def mse_loss_grad(self, pred, target, denominator=None, grad_scale=1.0):
         """(loss scalar tensor, dpred) of nn.MSELoss — train_bilinear.py:49,78."""

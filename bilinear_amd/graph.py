@@ -1,0 +1,109 @@
+"""hipGraph-captured training step.
+
+The whole step body of /root/reference/train_bilinear.py:75-83 is a fixed DAG of ~50
+kernels with no host synchronisation and no allocation, so it is captured
+once into a HIP graph and replayed with one launch per step.  Everything that changes
+from step to step lives in device memory: the Adam step count, the learning rate and the
+dropout step are fields of a ``blh_step_state`` that the first node of the graph advances
+(include/bilinear_hip.h), the batch is copied into static input buffers.  This is what
+makes the reference's own batch size (64, util/config.py:15) launch-latency free.
+
+PyTorch provides the capture machinery (``torch.cuda.CUDAGraph`` is hipGraph on ROCm);
+every node of the graph is a kernel of libbilinear_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _native as N
+
+
+class CapturedTrainStep:
+    """``step = CapturedTrainStep(net, opt, batch); pred, loss = step(x, target)``.
+
+    ``pred`` / ``loss`` are static device tensors overwritten by every replay.  The
+    learning rate is read from ``opt.param_groups[0]['lr']`` before each replay (the
+    lr-decay hook keeps working); ``opt`` state (exp_avg, exp_avg_sq, step) stays in sync.
+    """
+
+    def __init__(self, module, optimizer, batch, max_norm=1.0, device=None):
+        eng = module.engine
+        dev = torch.device(device) if device is not None else next(module.parameters()).device
+        eng.ensure(dev)
+        optimizer._ensure_moments(eng)
+        if eng.masks is not None:
+            raise RuntimeError("explicit dropout masks cannot be captured; use the Philox stream")
+        self.module, self.opt, self.eng, self.batch = module, optimizer, eng, int(batch)
+        self.max_norm = 0.0 if max_norm is None else float(max_norm)
+        self.x = torch.zeros(batch, 32, dtype=torch.float32, device=dev)
+        self.t = torch.zeros(batch, 48, dtype=torch.float32, device=dev)
+        self.pred = torch.empty(batch, 48, dtype=torch.float32, device=dev)
+        self.loss = torch.empty((), dtype=torch.float32, device=dev)
+        self.ws = eng.workspace(batch)
+        self.state = torch.zeros(ctypes.sizeof(N.StepState), dtype=torch.uint8, device=dev)
+        self._host_state = torch.zeros(ctypes.sizeof(N.StepState), dtype=torch.uint8).pin_memory()
+        self._lr = None
+        self._write_state()
+        self._drop = N.Dropout(None, eng.seed, 0, eng.row_offset)
+        # Warm-up on a side stream (sets kernel attributes, touches every buffer) on a snapshot
+        # of the training state, which is restored afterwards: building the graph must not
+        # move the model.  Capture itself executes nothing.
+        snap = [t.clone() for t in (eng.params, optimizer._exp_avg, optimizer._exp_avg_sq,
+                                    eng.bn_running, eng.bn_nbt)]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self._enqueue()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        for dst, src in zip((eng.params, optimizer._exp_avg, optimizer._exp_avg_sq,
+                             eng.bn_running, eng.bn_nbt), snap):
+            dst.copy_(src)
+        self._write_state()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._enqueue()
+
+    # -- device step state ------------------------------------------------------
+    def _write_state(self):
+        g = self.opt.param_groups[0]
+        st = N.StepState(float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], self.max_norm,
+                         int(self.opt._t), int(self.eng.rng_step) - 1 if self.eng.rng_step > 0 else 2 ** 64 - 1,
+                         0.0, 0.0)
+        # rng_step holds (next dropout step - 1): blh_step_state_advance adds 1 before use
+        raw = bytes(st)
+        self._host_state.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+        self.state.copy_(self._host_state, non_blocking=True)
+        self._lr = float(g["lr"])
+
+    def _enqueue(self):
+        eng, opt = self.eng, self.opt
+        N.check(N.lib().blh_train_step_captured(
+            ctypes.byref(eng.layout.desc), eng._stream(), N.ptr(eng.params), N.ptr(eng.grads),
+            N.ptr(opt._exp_avg), N.ptr(opt._exp_avg_sq), N.ptr(eng.bn_running), N.ptr(eng.bn_nbt),
+            N.ptr(self.x), N.ptr(self.t), ctypes.byref(self._drop), eng._momentum(),
+            N.ptr(self.state), N.ptr(self.ws), self.ws.numel(), N.ptr(self.pred),
+            N.ptr(self.loss), N.ptr(opt._stats), self.batch), "blh_train_step_captured")
+
+    def _after_step(self):
+        self.opt._t += 1
+        self.opt._sync_step_state(self.eng)
+        self.eng.rng_step += 1
+        self.eng._saved_batch = None
+
+    @torch.no_grad()
+    def __call__(self, x, target):
+        if x.shape[0] != self.batch:
+            raise RuntimeError("captured for batch %d, got %d" % (self.batch, x.shape[0]))
+        if not self.eng.is_packed(self.x.device) or self.eng.workspace(self.batch) is not self.ws:
+            raise RuntimeError("the module's device arenas changed after capture; re-capture")
+        lr = float(self.opt.param_groups[0]["lr"])
+        if lr != self._lr:
+            self._write_state()
+        self.x.copy_(x, non_blocking=True)
+        self.t.copy_(target, non_blocking=True)
+        self.graph.replay()
+        self._after_step()
+        return self.pred, self.loss

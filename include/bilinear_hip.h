@@ -104,6 +104,19 @@ typedef struct {
   int64_t row_offset;
 } blh_dropout;
 
+/* Device-resident step state for hipGraph replay.  A captured launch freezes by-value
+ * arguments, so blh_train_step_captured reads the Adam step count t, the learning rate and
+ * the dropout step from this struct in device memory; blh_step_state_advance (a one-thread
+ * kernel, first node of the captured step) increments `step` and `rng_step` and derives
+ * step_size = lr/(1-beta1^t) and bc2_sqrt = sqrt(1-beta2^t).  The host rewrites `lr`
+ * (the lr-decay hook, train_bilinear.py:66-70) with a plain async copy between replays.   */
+typedef struct {
+  float lr, beta1, beta2, eps, max_norm;
+  int32_t step;      /* number of completed Adam updates                  */
+  uint64_t rng_step; /* dropout step used by the NEXT forward minus one   */
+  float step_size, bc2_sqrt;
+} blh_step_state;
+
 /* ---- forward ---------------------------------------------------------------
  * Replaces BilinearUnit.forward (model/bilinear.py:31-41) in train mode
  * (train_bilinear.py:54,76): Linear -> BatchNorm1d(batch stats; running stats
@@ -176,6 +189,17 @@ int blh_train_step(const blh_model_desc* d, void* stream, float* params, float* 
                    const blh_dropout* drop, float momentum, const blh_adam_hyper* hyper,
                    void* workspace, int64_t workspace_bytes, float* pred, float* loss_out,
                    float* stats_out, int64_t batch);
+
+/* The same step with every per-step scalar read from `dev_state` (device): safe to capture
+ * into a hipGraph and replay; drop->step is added to dev_state->rng_step.  Enqueues
+ * blh_step_state_advance first.                                                        */
+int blh_step_state_advance(void* stream, blh_step_state* dev_state);
+int blh_train_step_captured(const blh_model_desc* d, void* stream, float* params, float* grads,
+                            float* exp_avg, float* exp_avg_sq, float* bn_running,
+                            int64_t* bn_num_batches_tracked, const float* x, const float* target,
+                            const blh_dropout* drop, float momentum, blh_step_state* dev_state,
+                            void* workspace, int64_t workspace_bytes, float* pred,
+                            float* loss_out, float* stats_out, int64_t batch);
 
 /* ---- kernel-level entry points (unit tests, profiling) ---------------------------
  * C[M,N] = op(A) * op(B) with fp32 MFMA.  a_kmajor=0: A is [M,K] (K

@@ -377,3 +377,42 @@ def test_cpu_input_is_rejected():
     net = bilinear_amd.BilinearUnit()
     with pytest.raises(RuntimeError):
         net(torch.zeros(4, 32))
+
+
+# ----------------------------------------------------------------------------
+# hipGraph-captured step == eager fused step
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("batch", [64, 512])
+def test_captured_step_matches_eager(batch):
+    import bilinear_amd
+    dev = _dev()
+
+    def make():
+        torch.manual_seed(5)
+        net, opt, _, _ = bilinear_amd.load(dev)
+        net.train()
+        net.engine.seed = 99
+        return net, opt
+
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(batch, 32, generator=g).to(dev) for _ in range(4)]
+    ts = [torch.randn(batch, 48, generator=g).to(dev) for _ in range(4)]
+    net_a, opt_a = make()
+    net_b, opt_b = make()
+    net_a.engine.ensure(dev)
+    step = bilinear_amd.CapturedTrainStep(net_b, opt_b, batch)
+    assert torch.equal(net_a.engine.params, net_b.engine.params)   # capture did not move the model
+    for i in range(4):
+        if i == 2:                               # lr-decay hook between replays
+            for o in (opt_a, opt_b):
+                o.param_groups[0]["lr"] = 5e-4
+        pa, la = net_a.train_step(opt_a, xs[i], ts[i])
+        pb, lb = step(xs[i], ts[i])
+        assert torch.equal(pa, pb), "prediction differs at step %d" % i
+        assert la.item() == lb.item()
+    torch.cuda.synchronize()
+    assert torch.equal(net_a.engine.params, net_b.engine.params)
+    assert torch.equal(opt_a._exp_avg_sq, opt_b._exp_avg_sq)
+    assert torch.equal(net_a.engine.bn_running, net_b.engine.bn_running)
+    assert int(net_b.encode[1].num_batches_tracked) == 4
+    assert opt_b.state_dict()["state"][0]["step"] == 4
