@@ -72,6 +72,8 @@ _SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                POINTER(Dropout), c_float, POINTER(AdamHyper), c_void_p, c_int64,
                                c_void_p, c_void_p, c_void_p, c_int64]),
+    "blh_mpjpe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                          c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "blh_step_state_advance": (c_int, [c_void_p, c_void_p]),
     "blh_train_step_captured": (c_int, [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

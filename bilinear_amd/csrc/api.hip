@@ -536,6 +536,21 @@ int blh_train_step(const blh_model_desc* d, void* stream, float* params, float* 
                           stats_out);
 }
 
+int blh_mpjpe(void* stream, const float* pred, const float* target, const float* mean,
+              const float* stddev, int64_t batch, int32_t joints, float* dist_out,
+              const int32_t* action_ids, int32_t num_actions, double* action_sum,
+              int64_t* action_count) {
+  if (!pred || !target || !mean || !stddev || !dist_out || batch <= 0 || joints <= 0)
+    return BLH_ERR_INVALID_ARGUMENT;
+  BLH_TRY(launch_mpjpe((hipStream_t)stream, pred, target, mean, stddev, batch, joints, dist_out));
+  if (action_ids) {
+    if (num_actions <= 0 || !action_sum || !action_count) return BLH_ERR_INVALID_ARGUMENT;
+    BLH_TRY(launch_segment_sum((hipStream_t)stream, dist_out, action_ids, batch, num_actions,
+                               action_sum, action_count));
+  }
+  return BLH_OK;
+}
+
 int blh_step_state_advance(void* stream, blh_step_state* dev_state) {
   if (!dev_state) return BLH_ERR_INVALID_ARGUMENT;
   return launch_step_state_advance((hipStream_t)stream, dev_state);

@@ -151,6 +151,10 @@ int launch_clip_scale(hipStream_t s, float* g, int64_t count, float max_norm,
 int launch_decode_finish(hipStream_t s, const float* slabs, int splits, int64_t batch,
                          int out_features, const float* bias, float* pred, const float* target,
                          float scale, float* dpred, float* loss_part, int* nparts);
+int launch_mpjpe(hipStream_t s, const float* pred, const float* target, const float* mean,
+                 const float* stddev, int64_t batch, int joints, float* dist);
+int launch_segment_sum(hipStream_t s, const float* dist, const int32_t* ids, int64_t batch,
+                       int segments, double* sum, int64_t* count);
 int launch_dropout_mask(hipStream_t s, uint8_t* out, int64_t batch, int W, const DropoutSrc& drop);
 static constexpr int SUMSQ_MAX_PARTS = 1024;
 

@@ -957,3 +957,74 @@ int launch_clip_adam_dev(hipStream_t s, float* p, float* g, float* m, float* v, 
 }
 
 }  // namespace blh
+
+// ---------------------------------------------------------------------------
+// validation metric (/root/reference/valid_bilinear.py:53-70): de-normalise prediction and
+// ground truth with the train-set mean / stddev, per-sample sum over the 16 joints of the
+// Euclidean distance, then per-action sums (replaces the reference's per-sample Python loop)
+// ---------------------------------------------------------------------------
+namespace blh {
+
+__global__ __launch_bounds__(256) void mpjpe_kernel(const float* __restrict__ pred,
+                                                    const float* __restrict__ target,
+                                                    const float* __restrict__ mean,
+                                                    const float* __restrict__ stddev,
+                                                    int64_t batch, int joints,
+                                                    float* __restrict__ dist) {
+  const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const int F = joints * 3;
+  float acc = 0.f;
+  for (int j = 0; j < joints; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int f = j * 3 + c;
+      const float p = stddev[f] * pred[b * F + f] + mean[f];
+      const float g = stddev[f] * target[b * F + f] + mean[f];
+      const float d = p - g;
+      s += d * d;
+    }
+    acc += sqrtf(s);
+  }
+  dist[b] = acc;
+}
+
+// one block per segment: sum (fp64) and count of dist[b] with ids[b] == segment
+__global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restrict__ dist,
+                                                          const int32_t* __restrict__ ids,
+                                                          int64_t batch, double* __restrict__ sum,
+                                                          int64_t* __restrict__ count) {
+  __shared__ double sh[256];
+  __shared__ int sc[256];
+  const int seg = blockIdx.x;
+  double a = 0.0;
+  int c = 0;
+  for (int64_t b = threadIdx.x; b < batch; b += 256)
+    if (ids[b] == seg) { a += (double)dist[b]; ++c; }
+  sh[threadIdx.x] = a; sc[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) { sh[threadIdx.x] += sh[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { sum[seg] += sh[0]; count[seg] += sc[0]; }
+}
+
+int launch_mpjpe(hipStream_t s, const float* pred, const float* target, const float* mean,
+                 const float* stddev, int64_t batch, int joints, float* dist) {
+  hipLaunchKernelGGL(mpjpe_kernel, dim3((unsigned)ceil_div(batch, 256)), dim3(256), 0, s, pred,
+                     target, mean, stddev, batch, joints, dist);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+int launch_segment_sum(hipStream_t s, const float* dist, const int32_t* ids, int64_t batch,
+                       int segments, double* sum, int64_t* count) {
+  hipLaunchKernelGGL(segment_sum_kernel, dim3(segments), dim3(256), 0, s, dist, ids, batch, sum,
+                     count);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+}  // namespace blh

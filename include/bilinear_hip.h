@@ -201,6 +201,17 @@ int blh_train_step_captured(const blh_model_desc* d, void* stream, float* params
                             void* workspace, int64_t workspace_bytes, float* pred,
                             float* loss_out, float* stats_out, int64_t batch);
 
+/* ---- validation metric ----------------------------------------------------------------
+ * valid_bilinear.py:53-70: pred/target [B, joints*3] are de-normalised with the train-set
+ * mean/stddev [joints*3]; dist_out[b] = sum over joints of the Euclidean distance (mm).
+ * If action_ids (device int32 [B], values in [0,num_actions)) is given, action_sum (fp64)
+ * and action_count (int64) are ACCUMULATED per action (zero them before the first batch):
+ * MPJPE(action) = action_sum / (action_count * joints), as valid_bilinear.py:76-83.   */
+int blh_mpjpe(void* stream, const float* pred, const float* target, const float* mean,
+              const float* stddev, int64_t batch, int32_t joints, float* dist_out,
+              const int32_t* action_ids, int32_t num_actions, double* action_sum,
+              int64_t* action_count);
+
 /* ---- kernel-level entry points (unit tests, profiling) ---------------------------
  * C[M,N] = op(A) * op(B) with fp32 MFMA.  a_kmajor=0: A is [M,K] (K
  * contiguous); 1: A is [K,M].  b_kmajor=0: B is [N,K] (K contiguous, i.e. a

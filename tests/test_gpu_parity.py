@@ -416,3 +416,30 @@ def test_captured_step_matches_eager(batch):
     assert torch.equal(net_a.engine.bn_running, net_b.engine.bn_running)
     assert int(net_b.encode[1].num_batches_tracked) == 4
     assert opt_b.state_dict()["state"][0]["step"] == 4
+
+
+# ----------------------------------------------------------------------------
+# "next" row: MPJPE of valid_bilinear.py:53-83 on the device
+# ----------------------------------------------------------------------------
+def test_mpjpe_matches_oracle():
+    from bilinear_amd.metrics import MPJPE
+    dev = _dev()
+    rng = np.random.RandomState(12)
+    B = 777
+    pred = rng.standard_normal((B, 48)).astype(np.float32)
+    tgt = rng.standard_normal((B, 48)).astype(np.float32)
+    mean = (rng.standard_normal(48) * 100).astype(np.float32)
+    std = (50 + 200 * rng.random_sample(48)).astype(np.float32)
+    ids = rng.randint(0, 15, size=B).astype(np.int32)
+    names = ["a%d" % i for i in range(15)]
+    m = MPJPE(names, torch.from_numpy(mean), torch.from_numpy(std), dev)
+    d1 = m.update(torch.from_numpy(pred[:400]).to(dev), torch.from_numpy(tgt[:400]).to(dev), torch.from_numpy(ids[:400]))
+    d2 = m.update(torch.from_numpy(pred[400:]).to(dev), torch.from_numpy(tgt[400:]).to(dev), torch.from_numpy(ids[400:]))
+    ref = O.mpjpe_sum(pred.astype(np.float64), tgt.astype(np.float64), mean.astype(np.float64), std.astype(np.float64))
+    got = np.concatenate([d1.cpu().numpy(), d2.cpu().numpy()])
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+    per_action, avg = m.result()
+    for i, n in enumerate(names):
+        sel = ids == i
+        assert abs(per_action[n] - ref[sel].sum() / (sel.sum() * 16)) <= 1e-5 * per_action[n]
+    assert abs(avg - ref.sum() / (B * 16)) <= 1e-5 * avg

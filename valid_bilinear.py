@@ -7,11 +7,11 @@ import argparse
 import logging
 import os
 
-import numpy as np
 import torch
 
 import bilinear_amd
-from bilinear_amd.data import SyntheticPoses
+from bilinear_amd.data import ACTIONS, SyntheticPoses
+from bilinear_amd.metrics import MPJPE
 
 COMMENT = "Bilinear GT"
 
@@ -32,24 +32,16 @@ def main():
     bilinear.eval()
 
     data = SyntheticPoses(args.steps, args.batch_size, device, seed=999)
-    total_dist, total = {}, {}
+    metric = MPJPE(ACTIONS, data.mean, data.stddev, device)   # per-action sums stay on the device
     with torch.set_grad_enabled(False):
         for in_image_space, in_camera_space, mean, stddev, action in data.epoch(0, with_stats=True):
             prediction = bilinear(in_image_space)
-            prediction = (stddev * prediction + mean).view(-1, 16, 3)
-            ground_truth = (stddev * in_camera_space + mean).view(-1, 16, 3)
-            dist = torch.sum(torch.sqrt(torch.sum((prediction - ground_truth) ** 2, dim=2)), dim=1)
-            dist = dist.double().cpu().numpy()
-            for name in sorted(set(action)):
-                sel = np.array([a == name for a in action])
-                total_dist[name] = total_dist.get(name, 0.0) + float(dist[sel].sum())
-                total[name] = total.get(name, 0) + int(sel.sum())
-    dist_sum, cnt = 0.0, 0
-    for key, value in total_dist.items():
-        logger.info("%s: %f", key, value / (total[key] * 16))
-        dist_sum += value
-        cnt += total[key] * 16
-    logger.info("avg: %f", dist_sum / cnt)
+            ids = torch.tensor([ACTIONS.index(a.split("_")[0]) for a in action], dtype=torch.int32)
+            metric.update(prediction, in_camera_space, ids)
+    per_action, average = metric.result()
+    for key, value in per_action.items():
+        logger.info("%s: %f", key, value)
+    logger.info("avg: %f", average)
 
 
 if __name__ == "__main__":
