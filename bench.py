@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=2)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="N>1: BatchNorm statistics over the global batch (exact reference semantics)")
     ap.add_argument("--no-graph", action="store_true",
                     help="N=1: launch the step eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--cpu-steps", type=int, default=12)
@@ -160,7 +162,7 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     x = torch.randn(args.batch, 32, device=dev, generator=g)
     t = torch.randn(args.batch, 48, device=dev, generator=g)
-    dp = DataParallel(net, opt) if world > 1 else None
+    dp = DataParallel(net, opt, sync_bn=args.sync_bn) if world > 1 else None
     use_graph = (world == 1) and not args.no_graph
     captured = bilinear_amd.CapturedTrainStep(net, opt, args.batch, max_norm=1.0) if use_graph else None
 
@@ -232,6 +234,7 @@ def main():
                 "global_batch": args.batch * world,
                 "parallelism": "dp%d" % world,
                 "dropout": "philox",
+                "batchnorm": ("sync (global batch)" if args.sync_bn else "per-rank statistics") if world > 1 else "single device",
                 "launch": "hipGraph replay (1 launch/step)" if use_graph else "eager (~50 launches/step)",
             },
             "final_loss": final_loss,

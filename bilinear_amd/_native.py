@@ -41,6 +41,7 @@ class StepState(Structure):
 
 
 GradReadyFn = ctypes.CFUNCTYPE(None, c_void_p, c_int64, c_int64)
+SyncFn = ctypes.CFUNCTYPE(None, c_void_p, c_void_p, c_int64, c_int32)
 
 # name -> (restype, argtypes); mirrors include/bilinear_hip.h one to one
 _SIGNATURES = {
@@ -64,6 +65,12 @@ _SIGNATURES = {
     "blh_backward": (c_int, [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, POINTER(Dropout),
                              c_void_p, c_int64, c_void_p, c_void_p, c_int64, GradReadyFn,
                              c_void_p]),
+    "blh_forward_train_sync": (c_int, [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, POINTER(Dropout), c_float, c_void_p, c_int64,
+                                       c_void_p, c_int64, c_int64, SyncFn, c_void_p]),
+    "blh_backward_sync": (c_int, [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p,
+                                  POINTER(Dropout), c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                  GradReadyFn, c_void_p, c_int64, SyncFn, c_void_p]),
     "blh_clip_grad_norm": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_int64,
                                    c_void_p]),
     "blh_clip_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,

@@ -89,6 +89,7 @@ struct Workspace {
   float* loss_part;               // [4096]
   double* sumsq_part;             // [1024]
   float* colsum_part;             // [ceil(B/256)][out]
+  double* sync_buf;               // [2][W] fp64 (SyncBN exchange; also used as float [2][W])
   int64_t bytes;
 };
 
@@ -163,6 +164,7 @@ static Workspace carve(const blh_model_desc* d, int64_t batch, void* base) {
   ws.loss_part = (float*)take(4096 * sizeof(float));
   ws.sumsq_part = (double*)take(SUMSQ_MAX_PARTS * sizeof(double));
   ws.colsum_part = (float*)take(ceil_div(batch, 256) * d->out_features * sizeof(float));
+  ws.sync_buf = (double*)take(2 * W * sizeof(double));
   ws.bytes = off;
   return ws;
 }
@@ -179,6 +181,11 @@ static Scratch carve_scratch(void* base) {
   s.sumsq_part = (double*)((char*)base + 4096 * sizeof(float));
   return s;
 }
+
+// SyncBN context of the current call (data parallel): statistics over `global_batch` rows,
+// exchanged by the host callback
+struct SyncCtx { blh_sync_fn fn; void* user; int64_t global_batch; };
+static thread_local SyncCtx g_sync = {nullptr, nullptr, 0};
 
 // device address of blh_step_state.rng_step for the current call (graph-captured step), else null
 static thread_local const uint64_t* g_step_dev = nullptr;
@@ -232,10 +239,17 @@ static int forward_impl(const blh_model_desc* d, hipStream_t s, const float* par
       // (the small-batch path produced one statistics tile covering all rows)
       const int st_tiles = fs.splits > 1 ? 1 : tiles_m;
       const int st_rows = fs.splits > 1 ? (int)batch : 128;
-      BLH_TRY(launch_bn_fwd_finalize(s, ws.stat_part, st_tiles, st_rows, batch, W,
-                                     params + h.gamma,
-                                     params + h.beta, rm, rv, nbt + i, momentum, sv, sv + W,
-                                     sv + 2 * W, sv + 3 * W));
+      if (g_sync.fn) {
+        BLH_TRY(launch_bn_fwd_local_sums(s, ws.stat_part, st_tiles, st_rows, batch, W, ws.sync_buf));
+        g_sync.fn(g_sync.user, ws.sync_buf, 2 * (int64_t)W, 1);
+        BLH_TRY(launch_bn_fwd_finalize_sums(s, ws.sync_buf, g_sync.global_batch, W,
+                                            params + h.gamma, params + h.beta, rm, rv, nbt + i,
+                                            momentum, sv, sv + W, sv + 2 * W, sv + 3 * W));
+      } else {
+        BLH_TRY(launch_bn_fwd_finalize(s, ws.stat_part, st_tiles, st_rows, batch, W,
+                                       params + h.gamma, params + h.beta, rm, rv, nbt + i,
+                                       momentum, sv, sv + W, sv + 2 * W, sv + 3 * W));
+      }
       BLH_TRY(launch_bn_apply_train(s, ws.Z[i], sv + 2 * W, sv + 3 * W, skip, ws.A[i], batch, W,
                                     layer_drop(drop, i, batch, W), nbt + i));
     } else {
@@ -312,9 +326,22 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
     BLH_TRY(launch_bn_bwd_reduce(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W, ws.bn_part,
                                  batch, W, ds));
     BLH_TRY(launch_bn_bwd_finalize(s, ws.bn_part, chunks, W, grads + h.gamma, grads + h.beta));
+    const float* dg = grads + h.gamma;
+    const float* db = grads + h.beta;
+    int64_t norm_batch = batch;
+    if (g_sync.fn) {
+      // the parameter gradients keep the LOCAL sums (averaged later with the rest of the
+      // arena); the BN backward itself needs the sums over the global batch
+      float* sb = reinterpret_cast<float*>(ws.sync_buf);
+      BLH_HIP_TRY(hipMemcpyAsync(sb, grads + h.gamma, W * sizeof(float), hipMemcpyDeviceToDevice, s));
+      BLH_HIP_TRY(hipMemcpyAsync(sb + W, grads + h.beta, W * sizeof(float), hipMemcpyDeviceToDevice, s));
+      g_sync.fn(g_sync.user, sb, 2 * (int64_t)W, 0);
+      dg = sb; db = sb + W; norm_batch = g_sync.global_batch;
+    }
     BLH_TRY(launch_bn_bwd_apply(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W,
-                                params + h.gamma, grads + h.gamma, grads + h.beta, ws.dZ,
-                                ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W, ds));
+                                params + h.gamma, dg, db, ws.dZ,
+                                ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W, ds,
+                                norm_batch));
     // Linear: db = colsum(dZ); dW = dZ^T a_in; d a_in = dZ W
     // (data parallel: the bucket hook needs this stage's bias gradient now; otherwise all
     //  stages are reduced by one launch after the loop)
@@ -534,6 +561,33 @@ int blh_train_step(const blh_model_desc* d, void* stream, float* params, float* 
   BLH_TRY(launch_sumsq(s, grads, count, ws.sumsq_part, &np));
   return launch_clip_adam(s, params, grads, exp_avg, exp_avg_sq, count, *hyper, ws.sumsq_part, np,
                           stats_out);
+}
+
+int blh_forward_train_sync(const blh_model_desc* d, void* stream, const float* params,
+                           float* bn_running, int64_t* bn_nbt, const float* x,
+                           const blh_dropout* drop, float momentum, void* workspace,
+                           int64_t workspace_bytes, float* pred, int64_t batch,
+                           int64_t global_batch, blh_sync_fn sync, void* user) {
+  if (!sync || global_batch < batch) return BLH_ERR_INVALID_ARGUMENT;
+  struct Guard {
+    Guard(blh_sync_fn f, void* u, int64_t g) { g_sync = SyncCtx{f, u, g}; }
+    ~Guard() { g_sync = SyncCtx{nullptr, nullptr, 0}; }
+  } guard(sync, user, global_batch);
+  return blh_forward_train(d, stream, params, bn_running, bn_nbt, x, drop, momentum, workspace,
+                           workspace_bytes, pred, batch);
+}
+
+int blh_backward_sync(const blh_model_desc* d, void* stream, const float* params, const float* x,
+                      const blh_dropout* drop, void* workspace, int64_t workspace_bytes,
+                      const float* dpred, float* grads, int64_t batch, blh_grad_ready_fn on_ready,
+                      void* user, int64_t global_batch, blh_sync_fn sync, void* sync_user) {
+  if (!sync || global_batch < batch) return BLH_ERR_INVALID_ARGUMENT;
+  struct Guard {
+    Guard(blh_sync_fn f, void* u, int64_t g) { g_sync = SyncCtx{f, u, g}; }
+    ~Guard() { g_sync = SyncCtx{nullptr, nullptr, 0}; }
+  } guard(sync, sync_user, global_batch);
+  return blh_backward(d, stream, params, x, drop, workspace, workspace_bytes, dpred, grads, batch,
+                      on_ready, user);
 }
 
 int blh_mpjpe(void* stream, const float* pred, const float* target, const float* mean,

@@ -113,7 +113,16 @@ int launch_bn_bwd_finalize(hipStream_t s, const float* part, int chunks, int W, 
 int launch_bn_bwd_apply(hipStream_t s, const float* dA, const float* Z, const float* scale,
                         const float* shift, const float* mean, const float* invstd,
                         const float* gamma, const float* dgamma, const float* dbeta, float* dZ,
-                        float* dz_colsum_part, int64_t batch, int W, const DropoutSrc& drop);
+                        float* dz_colsum_part, int64_t batch, int W, const DropoutSrc& drop,
+                        int64_t norm_batch);
+// SyncBN: local fp64 column sums [sum z | sum z^2] -> (host all-reduce) -> finalize
+int launch_bn_fwd_local_sums(hipStream_t s, const float* stat_part, int tiles, int tile_rows,
+                             int64_t batch, int W, double* sums);
+int launch_bn_fwd_finalize_sums(hipStream_t s, const double* sums, int64_t n_global, int W,
+                                const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, int64_t* nbt, float momentum,
+                                float* saved_mean, float* saved_invstd, float* scale,
+                                float* shift);
 // out[c] = sum_s in[s][c] for c < ncols (rows of `ld` floats), fp64 accumulation
 int launch_colreduce(hipStream_t s, const float* in, int S, int64_t ld, int ncols, float* out);
 // Linear-bias gradients of all stages in one launch (partials [stage][S][W])

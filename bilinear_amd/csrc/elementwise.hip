@@ -383,7 +383,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
     const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ dgamma,
     const float* __restrict__ dbeta, float* __restrict__ dZ, float* __restrict__ colsum_part,
-    int64_t batch, int W, int row_chunk, DropoutSrc drop) {
+    int64_t batch, int W, int row_chunk, DropoutSrc drop, int64_t norm_batch) {
   __shared__ __attribute__((aligned(16))) float red[4 * 256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col0 = blockIdx.x * EW_COLS_PER_BLOCK;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
   const int cc = ok ? col : 0;
   const float4 sc = ld4(scale + cc), sh = ld4(shift + cc), mu = ld4(mean + cc),
                is = ld4(invstd + cc);
-  const float inv_b = 1.0f / (float)batch;
+  const float inv_b = 1.0f / (float)norm_batch;   // rows the statistics were taken over
   float4 c1 = ld4(dbeta + cc), c2 = ld4(dgamma + cc);
   c1.x *= inv_b; c1.y *= inv_b; c1.z *= inv_b; c1.w *= inv_b;
   c2.x *= inv_b; c2.y *= inv_b; c2.z *= inv_b; c2.w *= inv_b;
@@ -430,11 +430,12 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
 int launch_bn_bwd_apply(hipStream_t s, const float* dA, const float* Z, const float* scale,
                         const float* shift, const float* mean, const float* invstd,
                         const float* gamma, const float* dgamma, const float* dbeta, float* dZ,
-                        float* dz_colsum_part, int64_t batch, int W, const DropoutSrc& drop) {
+                        float* dz_colsum_part, int64_t batch, int W, const DropoutSrc& drop,
+                        int64_t norm_batch) {
   (void)gamma;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, ew_grid(batch, W), dim3(EW_THREADS), 0, s, dA, Z, scale,
                      shift, mean, invstd, dgamma, dbeta, dZ, dz_colsum_part, batch, W,
-                     ew_row_chunk(batch), drop);
+                     ew_row_chunk(batch), drop, norm_batch);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
@@ -1023,6 +1024,85 @@ int launch_segment_sum(hipStream_t s, const float* dist, const int32_t* ids, int
                        int segments, double* sum, int64_t* count) {
   hipLaunchKernelGGL(segment_sum_kernel, dim3(segments), dim3(256), 0, s, dist, ids, batch, sum,
                      count);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+}  // namespace blh
+
+// ---------------------------------------------------------------------------
+// SyncBN (data parallel, statistics over the GLOBAL batch): the local tile partials are
+// reduced to fp64 column sums [sum z | sum z^2] that the host all-reduces across ranks; the
+// finalize then works from the global sums.  (fp64 keeps sum z^2 - (sum z)^2/n benign.)
+// ---------------------------------------------------------------------------
+namespace blh {
+
+__global__ __launch_bounds__(256) void bn_fwd_local_sums_kernel(const float* __restrict__ part,
+                                                                int tiles, int tile_rows,
+                                                                int64_t batch, int W,
+                                                                double* __restrict__ sums) {
+  __shared__ double r1[8][32], r2[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cl;
+  double a1 = 0.0, a2 = 0.0;
+  if (col < W)
+    for (int t = sl; t < tiles; t += 8) {
+      const double n = (double)min((int64_t)tile_rows, batch - (int64_t)t * tile_rows);
+      const double mu = (double)part[((int64_t)t * 2 + 0) * W + col];
+      a1 += n * mu;
+      a2 += (double)part[((int64_t)t * 2 + 1) * W + col] + n * mu * mu;
+    }
+  r1[sl][cl] = a1; r2[sl][cl] = a2;
+  __syncthreads();
+  if (sl == 0 && col < W) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { t1 += r1[s][cl]; t2 += r2[s][cl]; }
+    sums[col] = t1;
+    sums[W + col] = t2;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_fwd_finalize_sums_kernel(
+    const double* __restrict__ sums, int64_t n_global, int W, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* running_mean, float* running_var, const int64_t* nbt,
+    float momentum, float* saved_mean, float* saved_invstd, float* scale, float* shift) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= W) return;
+  const double n = (double)n_global;
+  const double mean = sums[col] / n;
+  double m2 = sums[W + col] - n * mean * mean;
+  if (m2 < 0.0) m2 = 0.0;
+  const double var = m2 / n;
+  const float invstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
+  const float mu = (float)mean;
+  const float sc = gamma[col] * invstd;
+  saved_mean[col] = mu;
+  saved_invstd[col] = invstd;
+  scale[col] = sc;
+  shift[col] = beta[col] - mu * sc;
+  const double f = (momentum >= 0.f) ? (double)momentum : 1.0 / (double)(nbt[0] + 1);
+  const double unbiased = m2 / (double)(n_global > 1 ? n_global - 1 : 1);
+  running_mean[col] = (float)((1.0 - f) * (double)running_mean[col] + f * mean);
+  running_var[col] = (float)((1.0 - f) * (double)running_var[col] + f * unbiased);
+}
+
+int launch_bn_fwd_local_sums(hipStream_t s, const float* stat_part, int tiles, int tile_rows,
+                             int64_t batch, int W, double* sums) {
+  hipLaunchKernelGGL(bn_fwd_local_sums_kernel, dim3((unsigned)ceil_div(W, 32)), dim3(256), 0, s,
+                     stat_part, tiles, tile_rows, batch, W, sums);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+int launch_bn_fwd_finalize_sums(hipStream_t s, const double* sums, int64_t n_global, int W,
+                                const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, int64_t* nbt, float momentum,
+                                float* saved_mean, float* saved_invstd, float* scale,
+                                float* shift) {
+  hipLaunchKernelGGL(bn_fwd_finalize_sums_kernel, dim3((unsigned)ceil_div(W, 256)), dim3(256), 0, s,
+                     sums, n_global, W, gamma, beta, running_mean, running_var, nbt, momentum,
+                     saved_mean, saved_invstd, scale, shift);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }

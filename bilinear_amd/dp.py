@@ -12,7 +12,10 @@ backward GEMMs of layers < l.  ``finish()`` makes the compute stream wait for al
 buckets and the (already averaged) gradients then feed the fused clip + Adam, which
 every rank runs identically (no parameter broadcast).
 
-BatchNorm statistics are per-rank (the usual DDP semantics); see DESIGN.md.
+BatchNorm statistics are per-rank by default (the usual DDP semantics).  ``sync_bn=True``
+exchanges every stage's statistics across ranks (2W-element all-reduces, forward and
+backward), which reproduces the reference's single-device result on the concatenated
+batch exactly (SURVEY.md hazard H5) at the price of 2*(1+L) latency-bound collectives.
 """
 from __future__ import annotations
 
@@ -92,15 +95,20 @@ class DataParallel:
     global row index (rank * local_batch), so the Philox mask of a row does not
     depend on the number of GPUs."""
 
-    def __init__(self, module, optimizer, group=None, bucket_floats=1 << 20, max_norm=1.0):
+    def __init__(self, module, optimizer, group=None, bucket_floats=1 << 20, max_norm=1.0,
+                 sync_bn=False):
         self.module = module
         self.optimizer = optimizer
         self.group = group
         self.max_norm = max_norm
         self.bucket_floats = bucket_floats
+        self.sync_bn = bool(sync_bn)
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._reducer = None
+
+    def _all_reduce_sum(self, tensor):
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
 
     def broadcast_parameters(self):
         eng = self.module.engine
@@ -117,10 +125,12 @@ class DataParallel:
             self._reducer = GradBucketReducer(eng.grads, self.group, self.bucket_floats)
         batch = x.shape[0]
         eng.row_offset = self.rank * batch
-        pred = eng.forward_train(x)
+        sync = self._all_reduce_sum if (self.sync_bn and self.world > 1) else None
+        gb = batch * self.world
+        pred = eng.forward_train(x, sync=sync, global_batch=gb)
         loss, dpred = eng.mse_loss_grad(pred, target)
         self._reducer.begin()
-        eng.backward(x, dpred, on_ready=self._reducer.on_ready)
+        eng.backward(x, dpred, on_ready=self._reducer.on_ready, sync=sync, global_batch=gb)
         self._reducer.finish()
         opt._ensure_moments(eng)
         g = opt.param_groups[0]

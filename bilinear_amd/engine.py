@@ -205,7 +205,26 @@ class Engine:
             raise RuntimeError("expected a float32 input, got %s" % x.dtype)
         return x.contiguous()
 
-    def forward_train(self, x):
+    def _sync_callback(self, ws, all_reduce_sum, errors):
+        """ctypes callback for the SyncBN variants: wraps the exchange buffer (which lives in
+        the workspace) as a tensor and hands it to ``all_reduce_sum`` (stream-ordered)."""
+        base = ws.data_ptr()
+
+        def _cb(user, ptr, count, dtype):
+            if errors:
+                return
+            try:
+                dt = torch.float64 if dtype == 1 else torch.float32
+                nbytes = int(count) * (8 if dtype == 1 else 4)
+                off = int(ptr) - base
+                all_reduce_sum(ws[off:off + nbytes].view(dt))
+            except BaseException as exc:   # noqa: BLE001  (must not unwind through C frames)
+                errors.append(exc)
+        return N.SyncFn(_cb)
+
+    def forward_train(self, x, sync=None, global_batch=None):
+        """``sync`` (callable(tensor) -> in-place SUM all-reduce) selects SyncBN: batch
+        statistics over ``global_batch`` rows across ranks."""
         x = self._check_input(x)
         self.ensure(x.device)
         batch = x.shape[0]
@@ -215,10 +234,21 @@ class Engine:
         ws = self.workspace(batch)
         pred = torch.empty(batch, OUT_FEATURES, dtype=torch.float32, device=x.device)
         drop = self._drop_struct(batch)
-        N.check(N.lib().blh_forward_train(
-            ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params),
-            N.ptr(self.bn_running), N.ptr(self.bn_nbt), N.ptr(x), ctypes.byref(drop),
-            self._momentum(), N.ptr(ws), ws.numel(), N.ptr(pred), batch), "blh_forward_train")
+        if sync is None:
+            N.check(N.lib().blh_forward_train(
+                ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params),
+                N.ptr(self.bn_running), N.ptr(self.bn_nbt), N.ptr(x), ctypes.byref(drop),
+                self._momentum(), N.ptr(ws), ws.numel(), N.ptr(pred), batch), "blh_forward_train")
+        else:
+            errors = []
+            cb = self._sync_callback(ws, sync, errors)
+            N.check(N.lib().blh_forward_train_sync(
+                ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params),
+                N.ptr(self.bn_running), N.ptr(self.bn_nbt), N.ptr(x), ctypes.byref(drop),
+                self._momentum(), N.ptr(ws), ws.numel(), N.ptr(pred), batch, int(global_batch),
+                cb, None), "blh_forward_train_sync")
+            if errors:
+                raise errors[0]
         self._saved_batch = batch
         self._saved_drop = drop
         if self.masks is None:
@@ -238,7 +268,7 @@ class Engine:
             "blh_forward_eval")
         return pred
 
-    def backward(self, x, dpred, on_ready=None):
+    def backward(self, x, dpred, on_ready=None, sync=None, global_batch=None):
         """Gradients of every parameter into the grad arena (overwritten)."""
         batch = x.shape[0]
         if self._saved_batch != batch:
@@ -262,10 +292,18 @@ class Engine:
         else:
             cb = ctypes.cast(None, N.GradReadyFn)
         self._grad_ready_cb = cb       # keep alive during the call
-        N.check(N.lib().blh_backward(
-            ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params), N.ptr(x),
-            ctypes.byref(self._saved_drop), N.ptr(ws), ws.numel(), N.ptr(dpred),
-            N.ptr(self.grads), batch, cb, None), "blh_backward")
+        if sync is None:
+            N.check(N.lib().blh_backward(
+                ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params), N.ptr(x),
+                ctypes.byref(self._saved_drop), N.ptr(ws), ws.numel(), N.ptr(dpred),
+                N.ptr(self.grads), batch, cb, None), "blh_backward")
+        else:
+            scb = self._sync_callback(ws, sync, errors)
+            N.check(N.lib().blh_backward_sync(
+                ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params), N.ptr(x),
+                ctypes.byref(self._saved_drop), N.ptr(ws), ws.numel(), N.ptr(dpred),
+                N.ptr(self.grads), batch, cb, None, int(global_batch), scb, None),
+                "blh_backward_sync")
         self._saved_batch = None
         if errors:
             raise errors[0]

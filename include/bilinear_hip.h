@@ -159,6 +159,25 @@ int blh_backward(const blh_model_desc* d, void* stream, const float* params, con
                  const float* dpred, float* grads, int64_t batch, blh_grad_ready_fn on_ready,
                  void* user);
 
+/* ---- SyncBN variants (data parallel with statistics over the GLOBAL batch) -------------
+ * Same as blh_forward_train / blh_backward, except that every BatchNorm's statistics are
+ * exchanged across ranks: `sync` is called on the host, once per stage, right after the
+ * kernels that produce this rank's partial sums have been enqueued; it must enqueue a SUM
+ * all-reduce of `count` elements at `device_buf` (dtype 0 = fp32, 1 = fp64) on `stream`
+ * (RCCL in the shipped host code).  Forward exchanges [sum z | sum z^2] (fp64, 2W), backward
+ * [sum dY*zhat | sum dY] (fp32, 2W).  With equal per-rank batches the result equals the
+ * reference's single-device run on the concatenated batch (SURVEY.md hazard H5).        */
+typedef void (*blh_sync_fn)(void* user, void* device_buf, int64_t count, int32_t dtype);
+int blh_forward_train_sync(const blh_model_desc* d, void* stream, const float* params,
+                           float* bn_running, int64_t* bn_num_batches_tracked, const float* x,
+                           const blh_dropout* drop, float momentum, void* workspace,
+                           int64_t workspace_bytes, float* pred, int64_t batch,
+                           int64_t global_batch, blh_sync_fn sync, void* user);
+int blh_backward_sync(const blh_model_desc* d, void* stream, const float* params, const float* x,
+                      const blh_dropout* drop, void* workspace, int64_t workspace_bytes,
+                      const float* dpred, float* grads, int64_t batch, blh_grad_ready_fn on_ready,
+                      void* user, int64_t global_batch, blh_sync_fn sync, void* sync_user);
+
 /* ---- clip + Adam ---------------------------------------------------------------
  * nn.utils.clip_grad_norm_(params, max_norm) (train_bilinear.py:81) fused with
  * torch.optim.Adam.step() (model/bilinear.py:60, train_bilinear.py:83):

@@ -114,3 +114,59 @@ def test_data_parallel_two_ranks_match_manual_average(tmp_path):
             continue
         err = np.abs(p0[off:off + n] - ref[off:off + n]).max()
         assert err <= 5e-5, (name, err)
+
+
+# ----------------------------------------------------------------------------
+# SyncBN: two ranks == one device on the concatenated batch (the reference's semantics)
+# ----------------------------------------------------------------------------
+def _worker_sync(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bilinear_amd.dp import DataParallel
+        dev = torch.device("cuda:0")
+        net, opt = _make(dev)
+        x, t = _data(dev)
+        dp = DataParallel(net, opt, bucket_floats=50000, sync_bn=True)
+        sl = slice(rank * LOCAL_B, (rank + 1) * LOCAL_B)
+        preds = []
+        for _ in range(2):
+            pred, loss = dp.train_step(x[sl], t[sl])
+            preds.append(pred.cpu().numpy())
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, "sparams%d.npy" % rank), net.engine.params.cpu().numpy())
+        np.save(os.path.join(out_dir, "sbn%d.npy" % rank), net.engine.bn_running.cpu().numpy())
+        np.save(os.path.join(out_dir, "spred%d.npy" % rank), np.stack(preds))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_bn_two_ranks_equal_single_device_on_full_batch(tmp_path):
+    from golden_util import is_prebn_bias
+    port = _free_port()
+    mp.spawn(_worker_sync, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = np.load(tmp_path / "sparams0.npy"), np.load(tmp_path / "sparams1.npy")
+    assert np.array_equal(p0, p1), "replicas diverged"
+    assert np.array_equal(np.load(tmp_path / "sbn0.npy"), np.load(tmp_path / "sbn1.npy"))
+
+    dev = torch.device("cuda:0")
+    net, opt = _make(dev)
+    x, t = _data(dev)
+    preds = []
+    for _ in range(2):
+        pred, loss = net.train_step(opt, x, t, max_norm=1.0)      # one device, full batch
+        preds.append(pred.cpu().numpy())
+    torch.cuda.synchronize()
+    eng = net.engine
+    both = np.concatenate([np.load(tmp_path / "spred0.npy"), np.load(tmp_path / "spred1.npy")], axis=1)
+    ref = np.stack(preds)
+    assert np.abs(both - ref).max() <= 1e-4 * (1 + np.abs(ref).max()), np.abs(both - ref).max()
+    rbn = eng.bn_running.cpu().numpy()
+    assert np.abs(np.load(tmp_path / "sbn0.npy") - rbn).max() <= 1e-5 * (1 + np.abs(rbn).max())
+    refp = eng.params.cpu().numpy()
+    for name, off, shape in eng.layout.entries:
+        n = int(np.prod(shape))
+        tol = 4.2e-3 if is_prebn_bias(name) else 1e-4
+        err = np.abs(p0[off:off + n] - refp[off:off + n]).max()
+        assert err <= tol, (name, err)
