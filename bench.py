@@ -41,7 +41,7 @@ def flops_per_pose(num_blocks, width):
     return fwd, bwd
 
 
-def time_kernel(fn, reps, warm=3):
+def time_kernel(fn, reps, warm=50):
     """Average duration (ms) of one launch, HIP events on the launch stream."""
     for _ in range(warm):
         fn()
@@ -129,8 +129,8 @@ def host_cores():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch")
     ap.add_argument("--blocks", type=int, default=2)
     ap.add_argument("--width", type=int, default=1024)
@@ -201,7 +201,7 @@ def main():
         p.backward(dpred)
     fb_ms = None
     if rank == 0:
-        fb_ms = time_kernel(fwd_bwd, max(5, args.steps // 4))
+        fb_ms = time_kernel(fwd_bwd, max(5, args.steps // 4), warm=5)
 
     result = None
     if rank == 0:
@@ -209,7 +209,9 @@ def main():
         poses = args.batch * world * args.steps / elapsed
         fwd, bwd = flops_per_pose(args.blocks, args.width)
         log("fwd+bwd only: %.3f ms" % fb_ms)
-        kern = gemm_rooflines(args.batch, args.width, reps=20)
+        # (long enough for the clocks to settle: the first ~50 ms after an idle period run at a
+        #  lower DVFS state and read 10-15 % slow)
+        kern = gemm_rooflines(args.batch, args.width, reps=500)
         log("kernel timings: %s" % json.dumps(kern))
         dom = kern["linear_fwd"]
         result = {

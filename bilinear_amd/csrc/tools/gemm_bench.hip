@@ -140,8 +140,8 @@ int main(int argc, char** argv) {
   {  // in-kernel clock of the main loop (diagnostic STAMP build of the forward kernel)
     unsigned long long* st; CK(hipMalloc(&st, 4096 * 64));
     GemmParams fs = f; fs.loss_part = reinterpret_cast<float*>(st);
-    auto kern = gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 1, 1>;
-    constexpr size_t lds = gemm_lds_bytes<128, 128, ROWK, ROWK, 1>();
+    auto kern = gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 3, 1>;
+    constexpr size_t lds = gemm_lds_bytes<128, 128, ROWK, ROWK, 3>();
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int tiles = (int)(ceil_div(M, 128) * ceil_div(W, 128));
     hipEvent_t e0v, e1v; CK(hipEventCreate(&e0v)); CK(hipEventCreate(&e1v));
