@@ -30,6 +30,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA
 HBM_PEAK_GBS = 8000.0
 
 
@@ -55,10 +56,11 @@ def time_kernel(fn, reps, warm=50):
     return start.elapsed_time(stop) / reps
 
 
-def gemm_rooflines(batch, width, reps):
+def gemm_rooflines(batch, width, reps, dtype="fp32"):
     """Live timings of the three Linear contractions at the hidden-layer shape."""
     from bilinear_amd import _native as N
     lib = N.lib()
+    gemm = lib.blh_gemm_bf16 if dtype == "bf16" else lib.blh_gemm_f32
     dev = torch.device("cuda", torch.cuda.current_device())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     A = torch.randn(batch, width, device=dev)
@@ -72,15 +74,19 @@ def gemm_rooflines(batch, width, reps):
     out = {}
 
     def fwd():
-        N.check(lib.blh_linear_fwd_stats(st, A.data_ptr(), Wt.data_ptr(), bias.data_ptr(),
-                                         Z.data_ptr(), stat.data_ptr(), batch, width, width), "fwd")
+        if dtype == "bf16":
+            N.check(gemm(st, A.data_ptr(), width, 0, Wt.data_ptr(), width, 0, Z.data_ptr(), width,
+                         batch, width, width, 1, bias.data_ptr(), None, 0), "fwd")
+        else:
+            N.check(lib.blh_linear_fwd_stats(st, A.data_ptr(), Wt.data_ptr(), bias.data_ptr(),
+                                             Z.data_ptr(), stat.data_ptr(), batch, width, width), "fwd")
 
     def dgrad():
-        N.check(lib.blh_gemm_f32(st, A.data_ptr(), width, 0, Wt.data_ptr(), width, 1, Z.data_ptr(),
+        N.check(gemm(st, A.data_ptr(), width, 0, Wt.data_ptr(), width, 1, Z.data_ptr(),
                                  width, batch, width, width, 1, None, None, 0), "dgrad")
 
     def wgrad():
-        N.check(lib.blh_gemm_f32(st, A.data_ptr(), width, 1, Z.data_ptr(), width, 1,
+        N.check(gemm(st, A.data_ptr(), width, 1, Z.data_ptr(), width, 1,
                                  slabs.data_ptr(), width, width, width, batch, splits, None, None,
                                  0), "wgrad")
 
@@ -102,6 +108,33 @@ def recorded_traffic(batch, width):
             return json.load(f)["kernels"]["linear_fwd"]["traffic_bytes"]
     except (OSError, KeyError, ValueError):
         return None
+
+
+def roofline_block(args, dom):
+    """Roofline of the dominant kernel (the WxW Linear forward GEMM at M = batch)."""
+    flop = 2.0 * args.batch * args.width * args.width
+    if args.dtype == "fp32":
+        return {
+            "kernel": "gemm_f32_kernel<128,128,4,2,ROWK,ROWK,BIAS_STATS,PIPE=3> (Linear %dx%d forward, M=%d)" % (
+                args.width, args.width, args.batch),
+            "bound": "mfma", "achieved": dom["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": dom["tflops"] / FP32_MFMA_PEAK_TFLOPS,
+            "traffic": recorded_traffic(args.batch, args.width),
+            "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json)",
+            "avg_launch_ms": dom["ms"], "flop_per_launch": flop,
+        }
+    # mixed mode keeps fp32 tensors in memory: the bf16 MFMA (2.5 PF) is fed at most at the
+    # memory rate, so the kernel is priced against HBM with its algorithmic bytes A + W + Z
+    alg = 4.0 * (args.batch * args.width * 2 + args.width * args.width)
+    gbs = alg / (dom["ms"] * 1e-3) / 1e9
+    return {
+        "kernel": "gemm_bf16_kernel<128,128,2,2,ROWK,ROWK,BIAS> (Linear %dx%d forward, M=%d, fp32 storage)" % (
+            args.width, args.width, args.batch),
+        "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": dom["ms"],
+        "algorithmic_bytes_per_launch": alg, "tflops": dom["tflops"],
+        "frac_of_bf16_mfma_peak": dom["tflops"] / BF16_MFMA_PEAK_TFLOPS,
+    }
 
 
 def log(msg):
@@ -135,6 +168,9 @@ def main():
     ap.add_argument("--blocks", type=int, default=2)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="GEMM arithmetic: fp32 MFMA (BASELINE configs[1], default) or bf16 MFMA "
+                         "inputs with fp32 accumulation and fp32 storage (configs 3-5)")
     ap.add_argument("--sync-bn", action="store_true",
                     help="N>1: BatchNorm statistics over the global batch (exact reference semantics)")
     ap.add_argument("--no-graph", action="store_true",
@@ -157,7 +193,8 @@ def main():
     from bilinear_amd.dp import DataParallel
 
     torch.manual_seed(1)          # identical init on every rank
-    net, opt, step, _ = bilinear_amd.load(dev, num_blocks=args.blocks, width=args.width)
+    net, opt, step, _ = bilinear_amd.load(dev, num_blocks=args.blocks, width=args.width,
+                                          gemm_dtype=args.dtype)
     net.train()
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     x = torch.randn(args.batch, 32, device=dev, generator=g)
@@ -211,7 +248,7 @@ def main():
         log("fwd+bwd only: %.3f ms" % fb_ms)
         # (long enough for the clocks to settle: the first ~50 ms after an idle period run at a
         #  lower DVFS state and read 10-15 % slow)
-        kern = gemm_rooflines(args.batch, args.width, reps=500)
+        kern = gemm_rooflines(args.batch, args.width, reps=500, dtype=args.dtype)
         log("kernel timings: %s" % json.dumps(kern))
         dom = kern["linear_fwd"]
         result = {
@@ -225,7 +262,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.dtype == "fp32" else "bf16 (MFMA inputs; fp32 accumulate and storage)",
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[1]: %d-block width %d, batch %d per GPU, fp32, "
@@ -243,19 +280,7 @@ def main():
             "fwd_bwd_only": {"ms_per_step": fb_ms, "poses_per_s": args.batch / (fb_ms / 1e3)},
             "step_tflops": poses * (fwd + bwd) / 1e12,
             "step_frac_of_fp32_mfma_peak": poses * (fwd + bwd) / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
-            "roofline": {
-                "kernel": "gemm_f32_kernel<128,128,4,2,ROWK,ROWK,BIAS_STATS,PIPE=3> (Linear %dx%d forward, M=%d)" % (
-                    args.width, args.width, args.batch),
-                "bound": "mfma",
-                "achieved": dom["tflops"],
-                "peak": FP32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": dom["tflops"] / FP32_MFMA_PEAK_TFLOPS,
-                "traffic": recorded_traffic(args.batch, args.width),
-                "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json)",
-                "avg_launch_ms": dom["ms"],
-                "flop_per_launch": 2.0 * args.batch * args.width * args.width,
-            },
+            "roofline": roofline_block(args, dom),
             "kernels": kern,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -21,7 +21,7 @@ OK = 0
 
 class ModelDesc(Structure):
     _fields_ = [("num_blocks", c_int32), ("width", c_int32),
-                ("in_features", c_int32), ("out_features", c_int32)]
+                ("in_features", c_int32), ("out_features", c_int32), ("gemm_dtype", c_int32)]
 
 
 class Dropout(Structure):
@@ -89,6 +89,9 @@ _SIGNATURES = {
     "blh_gemm_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
                              c_void_p, c_int64, c_int64, c_int64, c_int64, c_int32, c_void_p,
                              c_void_p, c_int64]),
+    "blh_gemm_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
+                              c_void_p, c_int64, c_int64, c_int64, c_int64, c_int32, c_void_p,
+                              c_void_p, c_int64]),
     "blh_sum_slabs": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "blh_linear_fwd_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int64, c_int64, c_int64]),

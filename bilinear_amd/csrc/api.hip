@@ -38,6 +38,8 @@ static int check_desc(const blh_model_desc* d) {
   if (d->width % 64 != 0 || d->in_features % 4 != 0 || d->out_features % 4 != 0)
     return BLH_ERR_SHAPE;
   if (d->out_features > 64) return BLH_ERR_SHAPE;   // decode uses one 64-wide column tile
+  if (1 + 2 * d->num_blocks > 32) return BLH_ERR_SHAPE;
+  if (d->gemm_dtype != 0 && d->gemm_dtype != 1) return BLH_ERR_INVALID_ARGUMENT;
   return BLH_OK;
 }
 
@@ -224,11 +226,12 @@ static int forward_impl(const blh_model_desc* d, hipStream_t s, const float* par
       // whole reduction alone (latency-bound), so cut the reduction across workgroups and
       // finish (slab sum + bias + BN tile statistics) in a streaming kernel
       g.C = ws.slabs; g.c_split_stride = batch * (int64_t)W; g.k_per_split = fs.k_per;
-      BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, EPI_STORE, g, fs.splits));
+      BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, EPI_STORE, g, fs.splits, d->gemm_dtype));
       BLH_TRY(launch_fwd_finish(s, ws.slabs, fs.splits, batch, W, params + h.b, ws.Z[i],
                                 train ? ws.stat_part : nullptr));
     } else {
-      BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, train ? EPI_BIAS_STATS : EPI_BIAS, g, 1));
+      BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, train ? EPI_BIAS_STATS : EPI_BIAS, g, 1,
+                          d->gemm_dtype));
     }
     // second stage of a block adds the block input (model/bilinear.py:36-38)
     const float* skip = (i >= 2 && (i % 2) == 0) ? ws.A[i - 2] : nullptr;
@@ -267,13 +270,13 @@ static int forward_impl(const blh_model_desc* d, hipStream_t s, const float* par
   g.B = params + L.dec_w; g.ldb = W;
   g.C = ws.slabs; g.ldc = OF; g.c_split_stride = batch * OF;
   g.M = (int)batch; g.N = OF; g.K = W; g.k_per_split = sp.k_per;
-  BLH_TRY(launch_gemm(s, TILE_128x64, ROWK, ROWK, EPI_STORE, g, sp.splits));
+  BLH_TRY(launch_gemm(s, TILE_128x64, ROWK, ROWK, EPI_STORE, g, sp.splits, d->gemm_dtype));
   return launch_decode_finish(s, ws.slabs, sp.splits, batch, OF, params + L.dec_b, pred, target,
                               mse_scale, target ? ws.dpred : nullptr, loss_part, loss_nparts);
 }
 
 // ------------------------------------------------------------ backward -----
-static int wgrad(hipStream_t s, GemmTile tile, const float* dZ, int64_t ld_dz, int M,
+static int wgrad(int dtype, hipStream_t s, GemmTile tile, const float* dZ, int64_t ld_dz, int M,
                  const float* act, int64_t ld_act, int N, int64_t batch, int64_t tiles,
                  float* slabs, float* out) {
   const Splits sp = pick_splits(batch, tiles);
@@ -284,10 +287,10 @@ static int wgrad(hipStream_t s, GemmTile tile, const float* dZ, int64_t ld_dz, i
   g.ldc = N;
   if (sp.splits == 1) {
     g.C = out; g.c_split_stride = 0;
-    return launch_gemm(s, tile, KROW, KROW, EPI_STORE, g, 1);
+    return launch_gemm(s, tile, KROW, KROW, EPI_STORE, g, 1, dtype);
   }
   g.C = slabs; g.c_split_stride = (int64_t)M * N;
-  BLH_TRY(launch_gemm(s, tile, KROW, KROW, EPI_STORE, g, sp.splits));
+  BLH_TRY(launch_gemm(s, tile, KROW, KROW, EPI_STORE, g, sp.splits, dtype));
   return launch_sum_slabs(s, slabs, (int64_t)M * N, sp.splits, out);
 }
 
@@ -302,7 +305,7 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
   const int chunks = ew_num_row_chunks(batch);
 
   // decode: dW = dP^T A_last, db = colsum(dP), dA_last = dP W_d
-  BLH_TRY(wgrad(s, TILE_64x128, dpred, OF, OF, ws.A[nh - 1], W, W, batch,
+  BLH_TRY(wgrad(d->gemm_dtype, s, TILE_64x128, dpred, OF, OF, ws.A[nh - 1], W, W, batch,
                 ceil_div(OF, 64) * ceil_div(W, 128), ws.slabs, grads + L.dec_w));
   BLH_TRY(launch_colsum(s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
   if (on_ready) on_ready(user, L.dec_w, L.total - L.dec_w);
@@ -312,7 +315,7 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
     g.B = params + L.dec_w; g.ldb = W;
     g.C = ws.G0; g.ldc = W;
     g.M = (int)batch; g.N = W; g.K = OF; g.k_per_split = OF;
-    BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, 1));
+    BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, 1, d->gemm_dtype));
   }
 
   for (int i = nh - 1; i >= 0; --i) {
@@ -349,10 +352,10 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
       BLH_TRY(launch_colreduce(s, ws.dz_colsum_part + (int64_t)i * chunks * W, chunks, W, W,
                                grads + h.b));
     if (i == 0) {
-      BLH_TRY(wgrad(s, TILE_128x32, ws.dZ, W, W, x, d->in_features, d->in_features, batch,
+      BLH_TRY(wgrad(d->gemm_dtype, s, TILE_128x32, ws.dZ, W, W, x, d->in_features, d->in_features, batch,
                     ceil_div(W, 128) * ceil_div(d->in_features, 32), ws.slabs, grads + h.w));
     } else {
-      BLH_TRY(wgrad(s, TILE_128x128, ws.dZ, W, W, ws.A[i - 1], W, W, batch,
+      BLH_TRY(wgrad(d->gemm_dtype, s, TILE_128x128, ws.dZ, W, W, ws.A[i - 1], W, W, batch,
                     ceil_div(W, 128) * ceil_div(W, 128), ws.slabs, grads + h.w));
       GemmParams g{};
       g.A = ws.dZ; g.lda = W;
@@ -363,16 +366,16 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
       float* dst = first_of_block ? ws.G0 : ws.G1;
       if (ds2.splits > 1) {
         g.C = ws.slabs; g.c_split_stride = batch * (int64_t)W; g.k_per_split = ds2.k_per;
-        BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, ds2.splits));
+        BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, ds2.splits, d->gemm_dtype));
         BLH_TRY(launch_sum_slabs_add(s, ws.slabs, batch * (int64_t)W, ds2.splits,
                                      first_of_block ? ws.G0 : nullptr, dst));
       } else if (first_of_block) {
         // d(block input) = dZ W + d(block output)   (skip path), in place in G0
         g.C = ws.G0; g.addend = ws.G0; g.ldadd = W;
-        BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_ADD, g, 1));
+        BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_ADD, g, 1, d->gemm_dtype));
       } else {
         g.C = ws.G1;
-        BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, 1));
+        BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, 1, d->gemm_dtype));
       }
     }
     if (on_ready) {
@@ -641,10 +644,10 @@ int blh_train_step_captured(const blh_model_desc* d, void* stream, float* params
                               ws.sumsq_part, np, stats_out);
 }
 
-int blh_gemm_f32(void* stream, const float* A, int64_t lda, int32_t a_kmajor, const float* B,
-                 int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc, int64_t M, int64_t N,
-                 int64_t K, int32_t splits, const float* bias, const float* addend,
-                 int64_t ldadd) {
+static int gemm_entry(int dtype, void* stream, const float* A, int64_t lda, int32_t a_kmajor,
+                      const float* B, int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc,
+                      int64_t M, int64_t N, int64_t K, int32_t splits, const float* bias,
+                      const float* addend, int64_t ldadd) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || splits < 1) return BLH_ERR_INVALID_ARGUMENT;
   if (bias && addend) return BLH_ERR_INVALID_ARGUMENT;
   if (splits > 1 && (bias || addend)) return BLH_ERR_INVALID_ARGUMENT;
@@ -659,9 +662,25 @@ int blh_gemm_f32(void* stream, const float* A, int64_t lda, int32_t a_kmajor, co
   GemmTile tile = TILE_128x128;
   if (N <= 32) tile = TILE_128x32;
   else if (N <= 64) tile = TILE_128x64;
-  else if (M <= 64) tile = TILE_64x128;
+  else if (M <= 64 && (dtype == 0 || (a_kmajor && b_kmajor))) tile = TILE_64x128;
   return launch_gemm((hipStream_t)stream, tile, a_kmajor ? KROW : ROWK, b_kmajor ? KROW : ROWK,
-                     epi, g, splits);
+                     epi, g, splits, dtype);
+}
+
+int blh_gemm_f32(void* stream, const float* A, int64_t lda, int32_t a_kmajor, const float* B,
+                 int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc, int64_t M, int64_t N,
+                 int64_t K, int32_t splits, const float* bias, const float* addend,
+                 int64_t ldadd) {
+  return gemm_entry(0, stream, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, splits, bias,
+                    addend, ldadd);
+}
+
+int blh_gemm_bf16(void* stream, const float* A, int64_t lda, int32_t a_kmajor, const float* B,
+                  int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc, int64_t M, int64_t N,
+                  int64_t K, int32_t splits, const float* bias, const float* addend,
+                  int64_t ldadd) {
+  return gemm_entry(1, stream, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, splits, bias,
+                    addend, ldadd);
 }
 
 int blh_linear_fwd_stats(void* stream, const float* A, const float* W, const float* bias, float* Z,

@@ -62,8 +62,9 @@ enum GemmTile : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_1
 // number of BM-row tiles the EPI_BIAS_STATS epilogue produces partials for
 int gemm_stat_tile_rows(GemmTile tile);
 int gemm_grid_blocks(GemmTile tile, int M, int N);
+// dtype 0: exact fp32 MFMA; 1: operands rounded to bf16 on load, bf16 MFMA, fp32 accumulate
 int launch_gemm(hipStream_t s, GemmTile tile, int la, int lb, int epi, const GemmParams& p,
-                int splits);
+                int splits, int dtype = 0);
 
 // ---------------------------------------------------------- elementwise ----
 struct DropoutSrc {

@@ -1,6 +1,7 @@
 // Host-side dispatch of the fp32 MFMA GEMM (kernel templates: gemm_f32_kernel.h).
 #include <cstdlib>
 
+#include "gemm_bf16_kernel.h"
 #include "gemm_f32_kernel.h"
 
 namespace blh {
@@ -72,6 +73,54 @@ static int launch_128x32(hipStream_t s, int la, int lb, int epi, const GemmParam
 }
 #undef BLH_CASE
 
+// ---- bf16-MFMA instantiations (mixed mode: fp32 storage, bf16 MFMA inputs) ----------------
+template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI>
+static int launch_cfg_bf16(hipStream_t s, const GemmParams& p, int splits) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr size_t lds = gemm_bf16_lds_bytes<BM, BN>();
+  static bool attr_set = false;
+  auto kern = gemm_bf16_kernel<BM, BN, WM, WN, LA, LB, EPI>;
+  if (!attr_set) {
+    BLH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N, BN));
+  hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(NT), lds, s, p);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+#define BLH_CASE16(BM_, BN_, WM_, WN_, LA_, LB_, EPI_) \
+  if (la == LA_ && lb == LB_ && epi == EPI_)           \
+    return launch_cfg_bf16<BM_, BN_, WM_, WN_, LA_, LB_, EPI_>(s, p, splits);
+
+static int launch_bf16(hipStream_t s, GemmTile tile, int la, int lb, int epi, const GemmParams& p,
+                       int splits) {
+  switch (tile) {
+    case TILE_128x128:
+      BLH_CASE16(128, 128, 2, 2, ROWK, ROWK, EPI_BIAS_STATS)
+      BLH_CASE16(128, 128, 2, 2, ROWK, ROWK, EPI_BIAS)
+      BLH_CASE16(128, 128, 2, 2, ROWK, ROWK, EPI_STORE)
+      BLH_CASE16(128, 128, 2, 2, ROWK, KROW, EPI_STORE)
+      BLH_CASE16(128, 128, 2, 2, ROWK, KROW, EPI_ADD)
+      BLH_CASE16(128, 128, 2, 2, KROW, KROW, EPI_STORE)
+      break;
+    case TILE_128x64:
+      BLH_CASE16(128, 64, 2, 2, ROWK, ROWK, EPI_STORE)
+      BLH_CASE16(128, 64, 2, 2, ROWK, ROWK, EPI_BIAS)
+      break;
+    case TILE_64x128:
+      BLH_CASE16(64, 128, 2, 2, KROW, KROW, EPI_STORE)
+      break;
+    case TILE_128x32:
+      BLH_CASE16(128, 32, 4, 1, KROW, KROW, EPI_STORE)
+      break;
+  }
+  return BLH_ERR_INVALID_ARGUMENT;
+}
+#undef BLH_CASE16
+
 int gemm_stat_tile_rows(GemmTile tile) { return tile == TILE_64x128 ? 64 : 128; }
 
 int gemm_grid_blocks(GemmTile tile, int M, int N) {
@@ -85,12 +134,13 @@ int gemm_grid_blocks(GemmTile tile, int M, int N) {
 }
 
 int launch_gemm(hipStream_t s, GemmTile tile, int la, int lb, int epi, const GemmParams& p,
-                int splits) {
+                int splits, int dtype) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || splits < 1) return BLH_ERR_INVALID_ARGUMENT;
   if ((la == ROWK || lb == ROWK) && p.K % 4 != 0) return BLH_ERR_SHAPE;
   if (la == KROW && p.M % 4 != 0) return BLH_ERR_SHAPE;
   if (lb == KROW && p.N % 4 != 0) return BLH_ERR_SHAPE;
   if (splits > 1 && (p.k_per_split % BK != 0)) return BLH_ERR_SHAPE;
+  if (dtype == 1) return launch_bf16(s, tile, la, lb, epi, p, splits);
   switch (tile) {
     case TILE_128x128: return launch_128x128(s, la, lb, epi, p, splits);
     case TILE_128x64: return launch_128x64(s, la, lb, epi, p, splits);

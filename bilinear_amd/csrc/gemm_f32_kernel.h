@@ -29,10 +29,9 @@
 // the permutation of k inside a group is immaterial.
 #pragma once
 #include "common.h"
+#include "gemm_epilogue.h"
 
 namespace blh {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static constexpr int BK = 32;
 static constexpr int ROWK_PITCH = BK + 4;   // floats; 36*4 B rows -> ds_read_b128 conflict-free
@@ -566,116 +565,7 @@ __global__ __launch_bounds__(64 * WM * WN + (PIPE == 4 ? 64 : 0)) void gemm_f32_
     }
   }
   // ------------------------------------------------------------- epilogue --
-  const int h = lane >> 5, lc = lane & 31;
-  const int row_w = m0 + wm * (TM * 32) + 4 * h;   // + tm*32 + (r&3) + 8*(r>>2)
-  const int col_w = n0 + wn * (TN * 32) + lc;      // + tn*32
-
-  if (EPI == EPI_BIAS || EPI == EPI_BIAS_STATS || EPI == EPI_MSE) {
-#pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-      const int col = col_w + jn * 32;
-      const float bv = (col < p.N) ? p.bias[col] : 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][jn][r] += bv;
-    }
-  }
-
-  if (EPI == EPI_BIAS_STATS) {
-    // Per-tile column statistics in the shifted (Welford/Chan) form: tile mean and
-    // M2 = sum (z - tile_mean)^2, merged across tiles by bn_fwd_finalize.  Avoids the
-    // cancellation of sum(z^2) - sum(z)^2/n at large batch (SURVEY.md hazard H1).
-    float* red = smem;   // [WM][BN]; stage buffers are dead (barrier closed the main loop)
-    const int cnt = min(BM, p.M - m0);
-    float mean[TN];
-#pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2);
-          if (row < p.M) s += acc[i][jn][r];
-        }
-      s += __shfl_xor(s, 32);
-      if (h == 0 && is_cons) red[wm * BN + wn * (TN * 32) + jn * 32 + lc] = s;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) t += red[w * BN + wn * (TN * 32) + jn * 32 + lc];
-      mean[jn] = t / (float)cnt;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2);
-          const float dlt = acc[i][jn][r] - mean[jn];
-          if (row < p.M) s += dlt * dlt;
-        }
-      s += __shfl_xor(s, 32);
-      if (h == 0 && is_cons) red[wm * BN + wn * (TN * 32) + jn * 32 + lc] = s;
-    }
-    __syncthreads();
-    if (wm == 0 && h == 0 && is_cons) {
-#pragma unroll
-      for (int jn = 0; jn < TN; ++jn) {
-        const int col = col_w + jn * 32;
-        float m2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) m2 += red[w * BN + wn * (TN * 32) + jn * 32 + lc];
-        if (col < p.N) {
-          p.stat_part[((int64_t)tile_m * 2 + 0) * p.N + col] = mean[jn];
-          p.stat_part[((int64_t)tile_m * 2 + 1) * p.N + col] = m2;
-        }
-      }
-    }
-  }
-
-  float lsum = 0.f;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2);
-#pragma unroll
-      for (int jn = 0; jn < TN; ++jn) {
-        const int col = col_w + jn * 32;
-        if (row < p.M && col < p.N && is_cons) {
-          float v = acc[i][jn][r];
-          if (EPI == EPI_ADD) v += p.addend[(int64_t)row * p.ldadd + col];
-          C[(int64_t)row * p.ldc + col] = v;
-          if (EPI == EPI_MSE) {
-            const float d = v - p.target[(int64_t)row * p.ldt + col];
-            p.dpred[(int64_t)row * p.lddp + col] = d * p.mse_scale;
-            lsum += d * d;
-          }
-        }
-      }
-    }
-
-  if (EPI == EPI_MSE) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) lsum += __shfl_xor(lsum, o);
-    float* red = smem;
-    __syncthreads();
-    if (lane == 0 && is_cons) red[wave] = lsum;
-    __syncthreads();
-    if (tid == 0) {
-      float t = 0.f;
-      for (int w = 0; w < WM * WN; ++w) t += red[w];
-      p.loss_part[blockIdx.x] = t;
-    }
-  }
+  gemm_epilogue<BM, BN, WM, WN, EPI>(acc, p, C, smem, m0, n0, tile_m, is_cons);
   if (STAMP) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long r2 = __builtin_amdgcn_s_memrealtime();

@@ -32,9 +32,9 @@ def _require_hip(device):
 class ArenaLayout:
     """Names / offsets / shapes of the flat parameter arena, as the library lays it out."""
 
-    def __init__(self, num_blocks, width):
+    def __init__(self, num_blocks, width, gemm_dtype=0):
         lib = N.lib()
-        self.desc = N.ModelDesc(num_blocks, width, IN_FEATURES, OUT_FEATURES)
+        self.desc = N.ModelDesc(num_blocks, width, IN_FEATURES, OUT_FEATURES, int(gemm_dtype))
         total = lib.blh_param_arena_floats(ctypes.byref(self.desc))
         if total < 0:
             N.check(int(total), "blh_param_arena_floats(num_blocks=%d, width=%d)" % (num_blocks, width))
@@ -63,8 +63,8 @@ class ArenaLayout:
 class Engine:
     """Device arenas + calls into the native library for one BilinearUnit."""
 
-    def __init__(self, module, num_blocks, width):
-        self.layout = ArenaLayout(num_blocks, width)
+    def __init__(self, module, num_blocks, width, gemm_dtype=0):
+        self.layout = ArenaLayout(num_blocks, width, gemm_dtype)
         self.module = module
         self.width = width
         self.device = None

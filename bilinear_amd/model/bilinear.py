@@ -22,6 +22,8 @@ from ..optim import Adam
 
 __all__ = ["heavy_linear", "BilinearUnit", "Bilinear", "load"]
 
+GEMM_DTYPES = {"fp32": 0, "bf16": 1}
+
 
 class _HeavyLinear(nn.Sequential):
     """Linear -> BatchNorm1d -> ReLU -> Dropout(0.5) as ONE fused stage.
@@ -84,10 +86,15 @@ class _LifterFunction(torch.autograd.Function):
 class BilinearUnit(nn.Module):
     """/root/reference/model/bilinear.py:16-55."""
 
-    def __init__(self, num_blocks=2, width=1024):
+    def __init__(self, num_blocks=2, width=1024, gemm_dtype="fp32"):
         super().__init__()
         self.num_blocks = int(num_blocks)
         self.width = int(width)
+        if gemm_dtype not in GEMM_DTYPES:
+            raise ValueError("gemm_dtype must be one of %s" % sorted(GEMM_DTYPES))
+        # "fp32": exact fp32 MFMA, the reference's arithmetic.  "bf16": tensors stay fp32, GEMM
+        # operands are rounded to bf16 on load (bf16 MFMA, fp32 accumulate) — BASELINE configs 3-5
+        self.gemm_dtype = gemm_dtype
         self.encode = heavy_linear(in_features=IN_FEATURES, out_features=self.width)
         self.bilinear = nn.ModuleList([
             nn.Sequential(
@@ -103,7 +110,7 @@ class BilinearUnit(nn.Module):
     @property
     def engine(self):
         if self._engine is None:
-            eng = Engine(self, self.num_blocks, self.width)
+            eng = Engine(self, self.num_blocks, self.width, GEMM_DTYPES[self.gemm_dtype])
             object.__setattr__(self, "_engine", eng)
         return self._engine
 
@@ -149,12 +156,13 @@ class BilinearUnit(nn.Module):
 Bilinear = BilinearUnit   # BASELINE.json names the class `Bilinear`; the reference calls it BilinearUnit
 
 
-def load(device, parameter_dir=None, learning_rate=1.0e-3, num_blocks=2, width=1024):
+def load(device, parameter_dir=None, learning_rate=1.0e-3, num_blocks=2, width=1024,
+         gemm_dtype="fp32"):
     """/root/reference/model/bilinear.py:58-92 — build the module on ``device``,
     an Adam optimiser, and either restore the newest ``{epoch}.save`` checkpoint
     under ``parameter_dir`` or Kaiming-initialise every Linear weight.
     Returns (module, optimizer, step, epoch_to_load)."""
-    bilinear = BilinearUnit(num_blocks=num_blocks, width=width).to(device)
+    bilinear = BilinearUnit(num_blocks=num_blocks, width=width, gemm_dtype=gemm_dtype).to(device)
     optimizer = Adam(bilinear.parameters(), lr=learning_rate, module=bilinear)
     step = 1
 

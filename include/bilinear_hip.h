@@ -64,6 +64,10 @@ typedef struct {
   int32_t width;        /* hidden width W                                    */
   int32_t in_features;  /* 2*16 = 32                                         */
   int32_t out_features; /* 3*16 = 48                                         */
+  int32_t gemm_dtype;   /* 0: exact fp32 MFMA (the reference's arithmetic);
+                           1: "mixed" — every tensor stays fp32 in memory, GEMM operands are
+                              rounded to bf16 on load and multiplied on bf16 MFMA with fp32
+                              accumulation (BASELINE configs 3-5)                  */
 } blh_model_desc;
 
 /* Number of heavy_linear stages = 1 + 2*num_blocks (encode + hidden). */
@@ -241,6 +245,12 @@ int blh_gemm_f32(void* stream, const float* A, int64_t lda, int32_t a_kmajor, co
                  int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc, int64_t M, int64_t N,
                  int64_t K, int32_t splits, const float* bias, const float* addend,
                  int64_t ldadd);
+/* Same contraction with the operands rounded to bf16 on load (bf16 MFMA, fp32 accumulate):
+ * the GEMM of gemm_dtype = 1.  Only the operand layouts the network uses are built.        */
+int blh_gemm_bf16(void* stream, const float* A, int64_t lda, int32_t a_kmajor, const float* B,
+                  int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc, int64_t M, int64_t N,
+                  int64_t K, int32_t splits, const float* bias, const float* addend,
+                  int64_t ldadd);
 int blh_sum_slabs(void* stream, const float* slabs, int64_t count, int32_t splits, float* out);
 /* The forward kernel of one heavy_linear exactly as blh_forward_train launches it:
  * Z[M,N] = A[M,K] W[N,K]^T + bias, plus per-128-row-tile column statistics

@@ -128,6 +128,36 @@ def random_masks(seed, batch, num_blocks=2, width=1024):
 
 
 # --------------------------------------------------------------------------
+# GEMM operand rounding (gemm_dtype = "bf16" of the build: tensors stay fp32, the two
+# operands of every Linear contraction are rounded to bfloat16, products and sums are exact /
+# fp32).  Not part of the reference; restated here so that the bf16 mode of the HIP path can be
+# checked against the SAME arithmetic instead of only "close to fp32".
+# --------------------------------------------------------------------------
+_GEMM_ROUND = None
+
+
+def set_gemm_rounding(mode):
+    """mode None (fp32/fp64 exact operands) or "bf16" (round-to-nearest-even to bfloat16)."""
+    global _GEMM_ROUND
+    assert mode in (None, "bf16")
+    _GEMM_ROUND = mode
+
+
+def round_bf16(a):
+    a32 = np.ascontiguousarray(a, np.float32)
+    u = a32.view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return u.astype(np.uint32).view(np.float32).astype(a.dtype if hasattr(a, "dtype") else np.float32)
+
+
+def _mm(a, b):
+    """a @ b with the configured operand rounding."""
+    if _GEMM_ROUND == "bf16":
+        return round_bf16(a) @ round_bf16(b)
+    return a @ b
+
+
+# --------------------------------------------------------------------------
 # forward
 # --------------------------------------------------------------------------
 def _heavy_fwd(st, h, a_in, mask, training, dtype, update_running, momentum):
@@ -144,7 +174,7 @@ def _heavy_fwd(st, h, a_in, mask, training, dtype, update_running, momentum):
     b = st[h + ".0.bias"].astype(dtype)
     gamma = st[h + ".1.weight"].astype(dtype)
     beta = st[h + ".1.bias"].astype(dtype)
-    z = a_in @ W.T + b
+    z = _mm(a_in, W.T) + b
     n = z.shape[0]
     if training:
         mu = z.mean(axis=0, dtype=np.float64)
@@ -201,7 +231,7 @@ def forward(st, x, masks=None, training=True, dtype=np.float32,
         a = a + skip                                   # model/bilinear.py:38
     Wd = st["decode.weight"].astype(dtype)
     bd = st["decode.bias"].astype(dtype)
-    pred = a @ Wd.T + bd                               # model/bilinear.py:39
+    pred = _mm(a, Wd.T) + bd                           # model/bilinear.py:39
     return pred, dict(layers=caches, a_last=a, names=names, num_blocks=num_blocks)
 
 
@@ -237,12 +267,12 @@ def _heavy_bwd(st, h, c, d_a, dtype, need_dx=True):
                                   - c["zhat"] * (dgamma / n).astype(dtype))
     dZ = dZ.astype(dtype)
     g = {
-        h + ".0.weight": dZ.T @ c["a_in"],
+        h + ".0.weight": _mm(dZ.T, c["a_in"]),
         h + ".0.bias": dZ.sum(axis=0, dtype=np.float64).astype(dtype),
         h + ".1.weight": dgamma.astype(dtype),
         h + ".1.bias": dbeta.astype(dtype),
     }
-    d_in = (dZ @ W) if need_dx else None
+    d_in = _mm(dZ, W) if need_dx else None
     return d_in, g
 
 
@@ -253,9 +283,9 @@ def backward(st, cache, dpred, dtype=np.float32):
     names, nb = cache["names"], cache["num_blocks"]
     grads = {}
     Wd = st["decode.weight"].astype(dtype)
-    grads["decode.weight"] = dpred.T @ cache["a_last"]
+    grads["decode.weight"] = _mm(dpred.T, cache["a_last"])
     grads["decode.bias"] = dpred.sum(axis=0, dtype=np.float64).astype(dtype)
-    d_a = dpred @ Wd
+    d_a = _mm(dpred, Wd)
     li = len(names) - 1
     for _ in range(nb):
         d_skip = d_a                                    # a = block(a) + skip

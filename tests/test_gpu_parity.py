@@ -443,3 +443,109 @@ def test_mpjpe_matches_oracle():
         sel = ids == i
         assert abs(per_action[n] - ref[sel].sum() / (sel.sum() * 16)) <= 1e-5 * per_action[n]
     assert abs(avg - ref.sum() / (B * 16)) <= 1e-5 * avg
+
+
+# ----------------------------------------------------------------------------
+# gemm_dtype = "bf16" (BASELINE configs 3-5): fp32 tensors, GEMM operands rounded to bf16,
+# bf16 MFMA with fp32 accumulation.  Tolerances are bf16's (8-bit mantissa, eps = 2^-8):
+# a K-term dot product of rounded operands carries ~2^-9*sqrt(2) relative error per term,
+# i.e. ~4e-3 of the output RMS; the tests allow 2e-2 on outputs/gradients (north_star's 1e-3
+# is stated for fp32 only).
+# ----------------------------------------------------------------------------
+BF16_GEMM_CASES = [
+    (4096, 1024, 1024, 0, 0, 1),      # forward
+    (300, 1024, 64, 0, 0, 1),         # ragged M, one K tile
+    (4096, 48, 1024, 0, 0, 4),        # decode forward (split over W)
+    (200, 1024, 1024, 0, 1, 1),       # dgrad
+    (64, 1024, 48, 0, 1, 1),          # decode dgrad, ragged K
+    (1024, 1024, 4096, 1, 1, 4),      # wgrad
+    (1024, 32, 1000, 1, 1, 8),        # encode wgrad
+    (48, 1024, 777, 1, 1, 1),         # decode wgrad
+]
+
+
+def _to_bf16(a):
+    """Round-to-nearest-even fp32 -> bf16 -> fp32, as v_cvt_pk_bf16_f32 does."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return u.astype(np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize("M,N,K,ak,bk,splits", BF16_GEMM_CASES)
+def test_gemm_bf16_layouts(native, M, N, K, ak, bk, splits):
+    dev = _dev()
+    rng = np.random.RandomState(M + 3 * N + 7 * K)
+    A = rng.standard_normal((K, M) if ak else (M, K)).astype(np.float32)
+    B = rng.standard_normal((K, N) if bk else (N, K)).astype(np.float32)
+    Ar, Br = _to_bf16(A), _to_bf16(B)
+    # exact expectation: the product of the ROUNDED operands in high precision
+    ref = (Ar.T if ak else Ar).astype(np.float64) @ (Br if bk else Br.T).astype(np.float64)
+    a, b = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+    c = torch.full((splits, M, N), float("nan"), device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = native.blh_gemm_bf16(st, a.data_ptr(), A.shape[1], ak, b.data_ptr(), B.shape[1], bk,
+                              c.data_ptr(), N, M, N, K, splits, None, None, 0)
+    assert rc == 0, native.blh_status_string(rc)
+    out = c.sum(dim=0) if splits > 1 else c[0]
+    torch.cuda.synchronize()
+    _close(out.cpu().numpy(), ref, 2e-5, "bf16 gemm vs rounded-operand product")
+
+
+@pytest.mark.parametrize("nb,width,batch", [(2, 1024, 512), (4, 1024, 256), (1, 256, 4096)])
+def test_bf16_mode_against_oracle(nb, width, batch):
+    """The bf16 mode must reproduce the oracle run with the SAME operand rounding (fp64
+    accumulation) to fp32 accuracy; the distance to the un-rounded oracle is reported (ReLU /
+    dropout gates of pre-activations within bf16 rounding of zero flip, which alone puts
+    ~5 % relative L2 error on hidden-layer weight gradients — a property of bf16, not of the
+    kernels)."""
+    dev = _dev()
+    st = O.init_state(200 + nb, nb, width)
+    import bilinear_amd
+    net = bilinear_amd.BilinearUnit(nb, width, gemm_dtype="bf16")
+    sd = net.state_dict()
+    net.load_state_dict({k: torch.from_numpy(np.array(st[k])).reshape(sd[k].shape) for k in sd})
+    net = net.to(dev).train()
+    x, t = O.synthetic_batch(5, batch)
+    masks = O.random_masks(9, batch, nb, width)
+    net.engine.set_dropout_masks(masks)
+    xt, tt = torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev)
+    pred = net(xt)
+    loss = torch.nn.functional.mse_loss(pred, tt)
+    loss.backward()
+
+    def oracle(rounding):
+        O.set_gemm_rounding(rounding)
+        try:
+            s2 = {k: v.copy() for k, v in st.items()}
+            rp, cache = O.forward(s2, x, masks, training=True, dtype=np.float64)
+            rl, dp = O.mse_loss(rp, t.astype(np.float64))
+            return rp, rl, O.backward(s2, cache, dp, dtype=np.float64)
+        finally:
+            O.set_gemm_rounding(None)
+
+    rp, rl, rg = oracle("bf16")
+    got_pred = pred.detach().cpu().numpy()
+    # (the bf16 MFMA's internal fp32 accumulation is not an exact fmaf chain like the f32
+    #  MFMA's: ~1e-5 per GEMM, a few 1e-4 after five BatchNorm'ed stages)
+    assert np.linalg.norm(got_pred - rp) / np.linalg.norm(rp) <= 2e-3
+    assert abs(loss.item() - rl) <= 2e-3 * rl
+    worst = 0.0
+    for k, p in net.named_parameters():
+        if is_prebn_bias(k):
+            continue
+        got = p.grad.cpu().numpy().astype(np.float64)
+        rel = np.linalg.norm(got - rg[k]) / np.linalg.norm(rg[k])
+        # Not tight by nature: a 1e-5 accumulation-order difference moves ~0.25 % of the next
+        # stage's operands across a bf16 rounding boundary (2^-8 each) and flips a few ReLU
+        # gates, so two correct bf16 runs drift apart by 1e-4..1e-3 per stage and by per-cent on
+        # the gradients of the early stages.  The bit-level check of the kernels is
+        # test_gemm_bf16_layouts (exact product of the rounded operands, 2e-5).
+        assert rel <= 0.1, (k, rel)
+        worst = max(worst, rel)
+    fp, fl, fg = oracle(None)
+    far = max(np.linalg.norm(p.grad.cpu().numpy() - fg[k]) / np.linalg.norm(fg[k])
+              for k, p in net.named_parameters() if not is_prebn_bias(k))
+    print("bf16 mode: vs same-rounding oracle %.2e; vs exact oracle pred %.2e, grads %.2e" % (
+        worst, np.linalg.norm(got_pred - fp) / np.linalg.norm(fp), far))
+    assert np.linalg.norm(got_pred - fp) / np.linalg.norm(fp) <= 2e-2
+    assert far <= 0.3
