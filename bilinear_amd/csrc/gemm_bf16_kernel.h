@@ -5,8 +5,8 @@
 // Same contractions, operand layouts (ROWK / KROW) and epilogues as gemm_f32_kernel.h; with
 // fp32 operands in memory the kernel is bound by the L2 -> LDS traffic, not by the MFMA.
 //
-// LDS image: both operands as [row][k] bf16 with k contiguous (K tile = 64, row pitch 72 bf16
-// = 144 B so that the 16-B fragment reads of 16 consecutive rows hit 16 different slots).
+// LDS image: both operands as [row][k] bf16 with k contiguous (K tile = 128, row pitch 136 bf16
+// = 272 B so that the 16-B fragment reads of 16 consecutive rows hit 16 different slots).
 //   ROWK operand: a lane loads 4 consecutive k (float4), writes 4 bf16 (ds_write_b64).
 //   KROW operand: a lane loads a 8(k) x 4(rows) patch (8 x float4, 512 B contiguous per k row
 //   across 32 lanes), transposes it in registers and writes 4 x ds_write_b128 (8 k of one row).
@@ -22,7 +22,10 @@ namespace blh {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 
-static constexpr int BKH = 64;            // K tile in elements
+#ifndef BLH_BKH
+#define BLH_BKH 128
+#endif
+static constexpr int BKH = BLH_BKH;       // K tile in elements (tools may override)
 static constexpr int PITCHH = BKH + 8;    // bf16 per LDS row
 
 template <int R>
@@ -48,7 +51,8 @@ struct TileCvt {
     for (int p = 0; p < PER; ++p) {
       const int q = tid + p * NT;
       if (LAYOUT == ROWK) {
-        const int row = row0 + (q >> 4), k = k0 + ((q & 15) << 2);
+        constexpr int CPR = BKH / 4;
+        const int row = row0 + (q / CPR), k = k0 + ((q % CPR) << 2);
         const bool ok = (ITEMS % NT == 0 || q < ITEMS) && row < rows_limit && k < k_end;
         reg[p] = ok ? *reinterpret_cast<const float4*>(base + (int64_t)row * ld + k)
                     : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -74,7 +78,8 @@ struct TileCvt {
       if (LAYOUT == ROWK) {
         bf16x4_t v;
         v[0] = (__bf16)reg[p].x; v[1] = (__bf16)reg[p].y; v[2] = (__bf16)reg[p].z; v[3] = (__bf16)reg[p].w;
-        *reinterpret_cast<bf16x4_t*>(lds + (q >> 4) * PITCHH + ((q & 15) << 2)) = v;
+        constexpr int CPR = BKH / 4;
+        *reinterpret_cast<bf16x4_t*>(lds + (q / CPR) * PITCHH + ((q % CPR) << 2)) = v;
       } else {
         constexpr int MG = R / 4;
         const int r = (q % MG) << 2, kb = (q / MG) << 3;

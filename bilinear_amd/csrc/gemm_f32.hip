@@ -99,12 +99,12 @@ static int launch_bf16(hipStream_t s, GemmTile tile, int la, int lb, int epi, co
                        int splits) {
   switch (tile) {
     case TILE_128x128:
-      BLH_CASE16(128, 128, 2, 2, ROWK, ROWK, EPI_BIAS_STATS)
-      BLH_CASE16(128, 128, 2, 2, ROWK, ROWK, EPI_BIAS)
-      BLH_CASE16(128, 128, 2, 2, ROWK, ROWK, EPI_STORE)
-      BLH_CASE16(128, 128, 2, 2, ROWK, KROW, EPI_STORE)
-      BLH_CASE16(128, 128, 2, 2, ROWK, KROW, EPI_ADD)
-      BLH_CASE16(128, 128, 2, 2, KROW, KROW, EPI_STORE)
+      BLH_CASE16(128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS)
+      BLH_CASE16(128, 128, 4, 2, ROWK, ROWK, EPI_BIAS)
+      BLH_CASE16(128, 128, 4, 2, ROWK, ROWK, EPI_STORE)
+      BLH_CASE16(128, 128, 4, 2, ROWK, KROW, EPI_STORE)
+      BLH_CASE16(128, 128, 4, 2, ROWK, KROW, EPI_ADD)
+      BLH_CASE16(128, 128, 4, 2, KROW, KROW, EPI_STORE)
       break;
     case TILE_128x64:
       BLH_CASE16(128, 64, 2, 2, ROWK, ROWK, EPI_STORE)
