@@ -208,6 +208,18 @@ struct DmaPlan {
     }
   }
 
+  // one chunk (compile-time index) of the same tile: lets the caller spread the DMA issue
+  // between MFMAs instead of clumping it at the top of the K tile
+  template <int P>
+  __device__ inline void issue_chunk(uint32_t lds_tile, int k0, int k_end) {
+    if (P < CHUNKS) {
+      const float* g = src[P < CHUNKS ? P : 0];
+      if (ragged_k && !(k0 + koff[P < CHUNKS ? P : 0] < k_end)) g = reinterpret_cast<const float*>(&g_zero16);
+      lds_dma16_asm(g, lds_tile + wave_off + (uint32_t)(P * NT * 16));
+      src[P < CHUNKS ? P : 0] += step[P < CHUNKS ? P : 0];
+    }
+  }
+
   // DMA tile whose first k is k0 into the LDS tile at byte address lds_tile (wave-uniform)
   __device__ inline void issue(uint32_t lds_tile, int k0, int k_end) {
 #pragma unroll
@@ -438,7 +450,11 @@ __global__ __launch_bounds__(64 * WM * WN + (PIPE == 4 ? 64 : 0)) void gemm_f32_
       const float* sB = sA + BM * BK;
       const float* nA = smem + st_nxt * RING;
       const bool more = (kt + 1 < nkt), more2 = (kt + 2 < nkt);
-      if (more2) {
+      constexpr bool SPREAD = (PIPE == 3) && (ABLATE & 8) && DmaPlan<LA, BM, NT>::CHUNKS <= 2 &&
+                              DmaPlan<LB, BN, NT>::CHUNKS <= 2;
+      const int k2 = kz0 + (kt + 2) * BK;
+      const uint32_t ldsA2 = lds0 + st_nn * (RING * 4), ldsB2 = ldsA2 + BM * BK * 4;
+      if (more2 && !SPREAD) {
         const int k0 = kz0 + (kt + 2) * BK;
         if (PIPE == 3) {
           planA.issue(lds0 + st_nn * (RING * 4), k0, k_end);
@@ -459,13 +475,20 @@ __global__ __launch_bounds__(64 * WM * WN + (PIPE == 4 ? 64 : 0)) void gemm_f32_
           read_frags_dma<LB, BN, TN>(fb[nxt], nA + BM * BK, wn * (TN * 32), 0, lane);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn)
               acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][j], fb[cur][jn][j],
                                                                 acc[i][jn], 0, 0, 0);
+          if (SPREAD && more2) {   // one DMA behind every second MFMA pair of groups 0 and 1
+            if (s == 0 && j == 0) planA.template issue_chunk<0>(ldsA2, k2, k_end);
+            if (s == 0 && j == 2) planA.template issue_chunk<1>(ldsA2, k2, k_end);
+            if (s == 1 && j == 0) planB.template issue_chunk<0>(ldsB2, k2, k_end);
+            if (s == 1 && j == 2) planB.template issue_chunk<1>(ldsB2, k2, k_end);
+          }
+        }
         if (s == BK / 8 - 2 && more) {
           if (more2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
           else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

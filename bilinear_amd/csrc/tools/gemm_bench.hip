@@ -113,17 +113,21 @@ int main(int argc, char** argv) {
   ROW("256x128 w4x2 pipe2", 256, 128, 4, 2, 2)
   {  // ablations of the PIPE=1 main loop (timing only; results are wrong)
     auto abl = [&](const char* name, auto kern) {
-      constexpr size_t lds = gemm_lds_bytes<128, 128, ROWK, ROWK, 1>();
+      constexpr size_t lds = gemm_lds_bytes<128, 128, ROWK, ROWK, 3>();
       CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       const int tiles = (int)(ceil_div(M, 128) * ceil_div(W, 128));
       hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-      for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, 0, f);
+      for (int i = 0; i < 300; ++i) hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, 0, f);
       CK(hipEventRecord(a, 0));
-      for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, 0, f);
+      for (int i = 0; i < 500; ++i) hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, 0, f);
       CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
       float ms; CK(hipEventElapsedTime(&ms, a, b));
-      printf("  ablate %-34s %.1f us\n", name, ms / 50 * 1e3);
+      printf("  ablate %-34s %.1f us\n", name, ms / 500 * 1e3);
     };
+    abl("PIPE3 clumped DMA issue", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 3, 0, 0>);
+    abl("PIPE3 DMA spread between MFMAs", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 3, 0, 8>);
+    abl("PIPE3 clumped (again)", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 3, 0, 0>);
+    abl("PIPE3 spread (again)", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 3, 0, 8>);
     abl("none", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 1, 0, 0>);
     abl("no global loads", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 1, 0, 1>);
     abl("no ds_write (loads unused)", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 1, 0, 2>);
