@@ -549,3 +549,110 @@ def test_bf16_mode_against_oracle(nb, width, batch):
         worst, np.linalg.norm(got_pred - fp) / np.linalg.norm(fp), far))
     assert np.linalg.norm(got_pred - fp) / np.linalg.norm(fp) <= 2e-2
     assert far <= 0.3
+
+
+# ----------------------------------------------------------------------------
+# cold API rows of SURVEY.md §8(a): reset_statistics (a4), checkpoint restore (a5)
+# ----------------------------------------------------------------------------
+def test_reset_statistics_cumulative_average():
+    """model/bilinear.py:43-55: momentum=None makes BatchNorm keep the cumulative average
+    of the batch statistics (factor 1/num_batches_tracked)."""
+    dev = _dev()
+    nb, width, batch = 1, 256, 160
+    st = O.init_state(77, nb, width)
+    net, _ = _build(None, dev, nb, width, state={k: v.copy() for k, v in st.items()})
+    net.reset_statistics()
+    assert net.encode[1].momentum is None
+    for i in range(3):
+        x, _ = O.synthetic_batch(300 + i, batch)
+        masks = O.random_masks(400 + i, batch, nb, width)
+        net.engine.set_dropout_masks(masks)
+        with torch.no_grad():
+            net(torch.from_numpy(x).to(dev))
+        O.forward(st, x, masks, training=True, dtype=np.float64, momentum=None)
+    sd = net.state_dict()
+    for k in sd:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            _close(sd[k].cpu().numpy(), st[k], TIGHT, k)
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == 3
+
+
+def test_checkpoint_round_trip_and_reference_format(tmp_path):
+    """train_bilinear.py:92-104 / model/bilinear.py:63-83: a checkpoint written in the
+    reference's format resumes exactly; a checkpoint produced by plain PyTorch (the CPU port
+    with torch.optim.Adam) loads into the HIP module."""
+    import bilinear_amd
+    from oracle import torch_port as TP
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(64, 32, generator=g).to(dev) for _ in range(3)]
+    ts = [torch.randn(64, 48, generator=g).to(dev) for _ in range(3)]
+
+    torch.manual_seed(3)
+    net, opt, step, _ = bilinear_amd.load(dev)
+    net.train()
+    net.engine.seed = 5
+    for i in range(2):
+        net.train_step(opt, xs[i], ts[i])
+    d = tmp_path / "parameter"
+    d.mkdir()
+    torch.save({"epoch": 1, "step": 3, "state": net.state_dict(), "optimizer": opt.state_dict()},
+               str(d / "1.save"))
+    net.train_step(opt, xs[2], ts[2])
+    want = net.engine.params.clone()
+
+    net2, opt2, step2, epoch2 = bilinear_amd.load(dev, parameter_dir=str(d))
+    assert (step2, epoch2) == (3, 1)
+    net2.train()
+    net2.engine.seed = 5
+    net2.engine.rng_step = 2                 # the reference does not checkpoint its RNG either
+    net2.train_step(opt2, xs[2], ts[2])
+    assert torch.equal(net2.engine.params, want)
+    assert opt2.state_dict()["state"][0]["step"] == 3
+
+    # a checkpoint made entirely by PyTorch on the CPU
+    port = TP.LifterPort(2, 1024)
+    popt = torch.optim.Adam(port.parameters(), lr=1e-3)
+    port.train()
+    TP.train_step(port, popt, xs[0].cpu(), ts[0].cpu())
+    d2 = tmp_path / "ref"
+    d2.mkdir()
+    torch.save({"epoch": 7, "step": 2, "state": port.state_dict(), "optimizer": popt.state_dict()},
+               str(d2 / "7.save"))
+    net3, opt3, step3, epoch3 = bilinear_amd.load(dev, parameter_dir=str(d2))
+    assert (step3, epoch3) == (2, 7)
+    net3.eval(); port.eval()
+    with torch.no_grad():
+        a = net3(xs[1]).cpu().numpy()
+        b = port(xs[1].cpu()).numpy()
+    _close(a, b, TIGHT, "eval after loading a PyTorch checkpoint")
+    net3.train()
+    net3.train_step(opt3, xs[1], ts[1])      # Adam moments restored into the flat arenas
+    assert opt3._t == 2 and float(opt3._exp_avg_sq.abs().sum()) > 0
+
+
+def test_batchnorm_statistics_large_batch_with_offset():
+    """SURVEY.md hazard H1: column statistics over a large batch whose mean dwarfs its
+    spread (|mean|/std = 1000) — the tile-wise (mean, M2) + Chan merge must not cancel."""
+    from bilinear_amd import _native as N
+    dev = _dev()
+    native = N.lib()
+    M, K, Nn = 65536, 32, 128
+    rng = np.random.RandomState(1)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Wt = (rng.standard_normal((Nn, K)) * 0.01).astype(np.float32)
+    bias = np.full(Nn, 10.0, np.float32)           # z = 10 +- 0.06
+    a, w, b = (torch.from_numpy(v).to(dev) for v in (A, Wt, bias))
+    Z = torch.empty(M, Nn, device=dev)
+    part = torch.empty(M // 128, 2, Nn, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert native.blh_linear_fwd_stats(st, a.data_ptr(), w.data_ptr(), b.data_ptr(), Z.data_ptr(),
+                                       part.data_ptr(), M, Nn, K) == 0
+    torch.cuda.synchronize()
+    z = Z.cpu().numpy().astype(np.float64)
+    p = part.cpu().numpy().astype(np.float64)
+    mean = p[:, 0].mean(axis=0)
+    m2 = (p[:, 1] + 128 * (p[:, 0] - mean) ** 2).sum(axis=0)
+    assert np.abs(mean - z.mean(axis=0)).max() <= 1e-6 * 10
+    assert np.abs(m2 / M - z.var(axis=0)).max() <= 2e-3 * z.var(axis=0).max()
