@@ -2,6 +2,7 @@
 // DAG of the lifter's forward / backward / optimiser step.  Pure enqueue code: no
 // allocation, no synchronisation, so every entry point is hipGraph-capturable.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -92,6 +93,8 @@ struct Workspace {
   double* sumsq_part;             // [1024]
   float* colsum_part;             // [ceil(B/256)][out]
   double* sync_buf;               // [2][W] fp64 (SyncBN exchange; also used as float [2][W])
+  std::vector<float*> stage_slabs; // per stage (+ decode): split-K wgrad slabs kept until grads_finish
+  float* dec_bias_part;           // [blocks][out] partial sums of dpred (fused step)
   int64_t bytes;
 };
 
@@ -167,6 +170,15 @@ static Workspace carve(const blh_model_desc* d, int64_t batch, void* base) {
   ws.sumsq_part = (double*)take(SUMSQ_MAX_PARTS * sizeof(double));
   ws.colsum_part = (float*)take(ceil_div(batch, 256) * d->out_features * sizeof(float));
   ws.sync_buf = (double*)take(2 * W * sizeof(double));
+  for (int i = 0; i <= nh; ++i) {
+    int64_t M, N, tiles;
+    if (i == nh) { M = d->out_features; N = W; tiles = ceil_div(M, 64) * ceil_div(N, 128); }
+    else if (i == 0) { M = W; N = d->in_features; tiles = ceil_div(M, 128) * ceil_div(N, 32); }
+    else { M = W; N = W; tiles = ceil_div(M, 128) * ceil_div(N, 128); }
+    const Splits sp = pick_splits(batch, tiles);
+    ws.stage_slabs.push_back(sp.splits > 1 ? (float*)take(sp.splits * M * N * sizeof(float)) : nullptr);
+  }
+  ws.dec_bias_part = (float*)take(1026 * d->out_features * sizeof(float));
   ws.bytes = off;
   return ws;
 }
@@ -272,42 +284,64 @@ static int forward_impl(const blh_model_desc* d, hipStream_t s, const float* par
   g.M = (int)batch; g.N = OF; g.K = W; g.k_per_split = sp.k_per;
   BLH_TRY(launch_gemm(s, TILE_128x64, ROWK, ROWK, EPI_STORE, g, sp.splits, d->gemm_dtype));
   return launch_decode_finish(s, ws.slabs, sp.splits, batch, OF, params + L.dec_b, pred, target,
-                              mse_scale, target ? ws.dpred : nullptr, loss_part, loss_nparts);
+                              mse_scale, target ? ws.dpred : nullptr, loss_part, loss_nparts,
+                              target ? ws.dec_bias_part : nullptr);
 }
 
 // ------------------------------------------------------------ backward -----
+// dW = dZ^T act, the reduction over the batch split across workgroups.  With `defer` the
+// partial slabs stay in `slabs` (a per-stage buffer) and *region records them for the single
+// grads_finish launch at the end of backward; otherwise they are summed right away.
 static int wgrad(int dtype, hipStream_t s, GemmTile tile, const float* dZ, int64_t ld_dz, int M,
                  const float* act, int64_t ld_act, int N, int64_t batch, int64_t tiles,
-                 float* slabs, float* out) {
+                 float* slabs, float* out, GradRegion* region) {
   const Splits sp = pick_splits(batch, tiles);
   GemmParams g{};
   g.A = dZ; g.lda = ld_dz;
   g.B = act; g.ldb = ld_act;
   g.M = M; g.N = N; g.K = (int)batch; g.k_per_split = sp.k_per;
   g.ldc = N;
+  if (region) { region->slabs = nullptr; region->splits = 0; }
   if (sp.splits == 1) {
     g.C = out; g.c_split_stride = 0;
     return launch_gemm(s, tile, KROW, KROW, EPI_STORE, g, 1, dtype);
   }
   g.C = slabs; g.c_split_stride = (int64_t)M * N;
   BLH_TRY(launch_gemm(s, tile, KROW, KROW, EPI_STORE, g, sp.splits, dtype));
+  if (region) {
+    region->slabs = slabs; region->splits = sp.splits;
+    return BLH_OK;
+  }
   return launch_sum_slabs(s, slabs, (int64_t)M * N, sp.splits, out);
 }
+
+// fused: the caller is the whole-step path: the decode-bias partials come from decode_finish
+// (dec_bias_S rows) and the sum-of-squares partials of the arena are returned for clip+Adam.
+struct FusedBackward { int dec_bias_S; double* sumsq_part; int* sumsq_nparts; };
 
 static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* params,
                          const float* x, const blh_dropout* drop, const Workspace& ws,
                          const float* dpred, float* grads, int64_t batch,
-                         blh_grad_ready_fn on_ready, void* user) {
+                         blh_grad_ready_fn on_ready, void* user,
+                         const FusedBackward* fused = nullptr) {
   const ArenaLayout L = make_layout(d);
   const int nh = (int)L.heavy.size();
   const int W = d->width;
   const int OF = d->out_features;
   const int chunks = ew_num_row_chunks(batch);
 
+  // The split-K slabs of each stage are summed right after its wgrad, while they are still in
+  // L2 / Infinity Cache.  Deferring all of them to the single grads_finish launch at the end
+  // (BLH_DEFER_SLABS=1, kept for experiments) saves six launches but reads 68 MB of by then
+  // cold slabs: measured 1.268 vs 1.253 ms/step, so it is off.
+  static const bool defer_env = getenv("BLH_DEFER_SLABS") != nullptr;
+  const bool defer = (on_ready == nullptr) && defer_env;
+  std::vector<GradRegion> wreg(nh + 1);
   // decode: dW = dP^T A_last, db = colsum(dP), dA_last = dP W_d
   BLH_TRY(wgrad(d->gemm_dtype, s, TILE_64x128, dpred, OF, OF, ws.A[nh - 1], W, W, batch,
-                ceil_div(OF, 64) * ceil_div(W, 128), ws.slabs, grads + L.dec_w));
-  BLH_TRY(launch_colsum(s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
+                ceil_div(OF, 64) * ceil_div(W, 128), defer ? ws.stage_slabs[nh] : ws.slabs,
+                grads + L.dec_w, defer ? &wreg[nh] : nullptr));
+  if (!fused) BLH_TRY(launch_colsum(s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
   if (on_ready) on_ready(user, L.dec_w, L.total - L.dec_w);
   {
     GemmParams g{};
@@ -352,11 +386,13 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
       BLH_TRY(launch_colreduce(s, ws.dz_colsum_part + (int64_t)i * chunks * W, chunks, W, W,
                                grads + h.b));
     if (i == 0) {
-      BLH_TRY(wgrad(d->gemm_dtype, s, TILE_128x32, ws.dZ, W, W, x, d->in_features, d->in_features, batch,
-                    ceil_div(W, 128) * ceil_div(d->in_features, 32), ws.slabs, grads + h.w));
+      BLH_TRY(wgrad(d->gemm_dtype, s, TILE_128x32, ws.dZ, W, W, x, d->in_features,
+                    d->in_features, batch, ceil_div(W, 128) * ceil_div(d->in_features, 32),
+                    defer ? ws.stage_slabs[0] : ws.slabs, grads + h.w, defer ? &wreg[0] : nullptr));
     } else {
       BLH_TRY(wgrad(d->gemm_dtype, s, TILE_128x128, ws.dZ, W, W, ws.A[i - 1], W, W, batch,
-                    ceil_div(W, 128) * ceil_div(W, 128), ws.slabs, grads + h.w));
+                    ceil_div(W, 128) * ceil_div(W, 128), defer ? ws.stage_slabs[i] : ws.slabs,
+                    grads + h.w, defer ? &wreg[i] : nullptr));
       GemmParams g{};
       g.A = ws.dZ; g.lda = W;
       g.B = params + h.w; g.ldb = W;
@@ -383,12 +419,31 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
       on_ready(user, h.w, end - h.w);
     }
   }
-  if (!on_ready) {
+  if (!on_ready) {   // (covers the no_defer A/B mode too: its regions are all plain)
     int64_t offs[32];
     if (nh > 32) return BLH_ERR_SHAPE;
     for (int i = 0; i < nh; ++i) offs[i] = L.heavy[i].b;
     BLH_TRY(launch_bias_colreduce(s, ws.dz_colsum_part, (int64_t)chunks * W, chunks, W, nh, offs,
-                                  grads));
+                                  grads, fused ? ws.dec_bias_part : nullptr,
+                                  fused ? fused->dec_bias_S : 0, OF, L.dec_b));
+    // regions in arena order: [weight (slabs or plain)] [bias, gamma, beta (plain)] per stage,
+    // then decode weight and decode bias (+ tail padding)
+    GradRegions R{};
+    auto push = [&](int64_t off, int64_t end, const GradRegion* w) {
+      GradRegion& r = R.r[R.n++];
+      r.off4 = off / 4; r.cnt4 = (end - off) / 4;
+      r.slabs = w ? w->slabs : nullptr; r.splits = w ? w->splits : 0; r.first_block = 0;
+    };
+    for (int i = 0; i < nh; ++i) {
+      const HeavyOffsets& h = L.heavy[i];
+      const int64_t wend = h.w + (int64_t)W * h.fan_in;
+      push(h.w, wend, &wreg[i]);
+      push(wend, (i + 1 < nh) ? L.heavy[i + 1].w : L.dec_w, nullptr);
+    }
+    push(L.dec_w, L.dec_w + (int64_t)OF * W, &wreg[nh]);
+    push(L.dec_w + (int64_t)OF * W, L.total, nullptr);
+    BLH_TRY(launch_grads_finish(s, grads, R, L.total / 4, fused ? fused->sumsq_part : nullptr,
+                                fused ? fused->sumsq_nparts : nullptr));
   }
   return BLH_OK;
 }
@@ -557,13 +612,12 @@ int blh_train_step(const blh_model_desc* d, void* stream, float* params, float* 
   int nparts = 0;
   BLH_TRY(forward_impl(d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
                        target, (float)(2.0 / denom), ws.loss_part, &nparts));
-  BLH_TRY(launch_loss_finalize(s, ws.loss_part, nparts, denom, loss_out));
-  BLH_TRY(backward_impl(d, s, params, x, drop, ws, ws.dpred, grads, batch, nullptr, nullptr));
-  const int64_t count = make_layout(d).total;
   int np = 0;
-  BLH_TRY(launch_sumsq(s, grads, count, ws.sumsq_part, &np));
+  const FusedBackward fb{nparts, ws.sumsq_part, &np};
+  BLH_TRY(backward_impl(d, s, params, x, drop, ws, ws.dpred, grads, batch, nullptr, nullptr, &fb));
+  const int64_t count = make_layout(d).total;
   return launch_clip_adam(s, params, grads, exp_avg, exp_avg_sq, count, *hyper, ws.sumsq_part, np,
-                          stats_out);
+                          stats_out, LossFinish{ws.loss_part, nparts, denom, loss_out});
 }
 
 int blh_forward_train_sync(const blh_model_desc* d, void* stream, const float* params,
@@ -636,12 +690,12 @@ int blh_train_step_captured(const blh_model_desc* d, void* stream, float* params
   } guard(&dev_state->rng_step);
   BLH_TRY(forward_impl(d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
                        target, (float)(2.0 / denom), ws.loss_part, &nparts));
-  BLH_TRY(launch_loss_finalize(s, ws.loss_part, nparts, denom, loss_out));
-  BLH_TRY(backward_impl(d, s, params, x, drop, ws, ws.dpred, grads, batch, nullptr, nullptr));
+  const FusedBackward fb{nparts, ws.sumsq_part, &np};
+  BLH_TRY(backward_impl(d, s, params, x, drop, ws, ws.dpred, grads, batch, nullptr, nullptr, &fb));
   const int64_t count = make_layout(d).total;
-  BLH_TRY(launch_sumsq(s, grads, count, ws.sumsq_part, &np));
   return launch_clip_adam_dev(s, params, grads, exp_avg, exp_avg_sq, count, dev_state,
-                              ws.sumsq_part, np, stats_out);
+                              ws.sumsq_part, np, stats_out,
+                              LossFinish{ws.loss_part, nparts, denom, loss_out});
 }
 
 static int gemm_entry(int dtype, void* stream, const float* A, int64_t lda, int32_t a_kmajor,

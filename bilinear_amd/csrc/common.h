@@ -128,7 +128,9 @@ int launch_bn_fwd_finalize_sums(hipStream_t s, const double* sums, int64_t n_glo
 int launch_colreduce(hipStream_t s, const float* in, int S, int64_t ld, int ncols, float* out);
 // Linear-bias gradients of all stages in one launch (partials [stage][S][W])
 int launch_bias_colreduce(hipStream_t s, const float* part, int64_t stage_stride, int S, int W,
-                          int num_stages, const int64_t* out_offsets, float* grads);
+                          int num_stages, const int64_t* out_offsets, float* grads,
+                          const float* extra_part = nullptr, int extra_S = 0, int extra_cols = 0,
+                          int64_t extra_off = 0);
 // out[i] = sum_s in[s][i]   (slabs of `count` floats)
 int launch_sum_slabs(hipStream_t s, const float* slabs, int64_t count, int splits, float* out);
 int launch_sum_slabs_add(hipStream_t s, const float* slabs, int64_t count, int splits,
@@ -146,21 +148,31 @@ int launch_loss_finalize(hipStream_t s, const float* part, int n, double denom, 
 int launch_mse(hipStream_t s, const float* pred, const float* target, int64_t n, float scale,
                float* dpred, float* part, int* nparts);
 // optimiser
+// loss = sum(part[0..n)) / denom, finished by block 0 of the optimiser kernel (part == nullptr: off)
+struct LossFinish { const float* part; int n; double denom; float* out; };
 int launch_sumsq(hipStream_t s, const float* g, int64_t count, double* part, int* nparts);
 int launch_clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count,
                      const blh_adam_hyper& h, const double* sumsq_part, int nparts,
-                     float* stats_out);
+                     float* stats_out, LossFinish lf = LossFinish{nullptr, 0, 1.0, nullptr});
+// one launch at the end of backward: sum every stage's split-K weight-gradient slabs into the
+// arena and produce the sum-of-squares partials of the whole arena
+struct GradRegion { int64_t off4, cnt4; const float* slabs; int splits; int first_block; };
+static constexpr int MAX_GRAD_REGIONS = 72;
+struct GradRegions { int n; int64_t items_per_block; GradRegion r[MAX_GRAD_REGIONS]; };
+int launch_grads_finish(hipStream_t s, float* grads, GradRegions& R, int64_t total4,
+                        double* sumsq_part, int* nparts);
 // device-state variants (graph replay): hyper-parameters and step counters read on the device
 int launch_step_state_advance(hipStream_t s, blh_step_state* st);
 int launch_clip_adam_dev(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count,
                          const blh_step_state* st, const double* sumsq_part, int nparts,
-                         float* stats_out);
+                         float* stats_out, LossFinish lf = LossFinish{nullptr, 0, 1.0, nullptr});
 int launch_clip_scale(hipStream_t s, float* g, int64_t count, float max_norm,
                       const double* sumsq_part, int nparts, float* stats_out);
 // pred = sum(slabs) + bias (+ fused MSE when target != nullptr)
 int launch_decode_finish(hipStream_t s, const float* slabs, int splits, int64_t batch,
                          int out_features, const float* bias, float* pred, const float* target,
-                         float scale, float* dpred, float* loss_part, int* nparts);
+                         float scale, float* dpred, float* loss_part, int* nparts,
+                         float* dbias_part = nullptr);
 int launch_mpjpe(hipStream_t s, const float* pred, const float* target, const float* mean,
                  const float* stddev, int64_t batch, int joints, float* dist);
 int launch_segment_sum(hipStream_t s, const float* dist, const int32_t* ids, int64_t batch,

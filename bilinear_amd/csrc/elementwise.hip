@@ -332,36 +332,48 @@ int launch_colreduce(hipStream_t s, const float* in, int S, int64_t ld, int ncol
   return BLH_OK;
 }
 
-// all stages' Linear-bias gradients in one launch: out[stage][c] = sum_s part[stage][s][c]
-struct BiasOffsets { int64_t off[32]; };
+// all stages' Linear-bias gradients in one launch: out[stage][c] = sum_s part[stage][s][c];
+// an optional extra entry (the decode bias) has its own partial array, row count and width
+struct BiasOffsets {
+  int64_t off[32];
+  const float* extra_part; int extra_S; int extra_cols; int64_t extra_off;
+};
 __global__ __launch_bounds__(256) void bias_colreduce_kernel(const float* __restrict__ part,
                                                              int64_t stage_stride, int S, int W,
+                                                             int num_stages,
                                                              float* __restrict__ grads,
                                                              BiasOffsets offs) {
   __shared__ double red[8][32];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + cl;
-  const float* in = part + (int64_t)blockIdx.y * stage_stride;
+  const bool extra = (int)blockIdx.y == num_stages;
+  const float* in = extra ? offs.extra_part : part + (int64_t)blockIdx.y * stage_stride;
+  const int rows = extra ? offs.extra_S : S, cols = extra ? offs.extra_cols : W;
+  const int64_t out = extra ? offs.extra_off : offs.off[blockIdx.y];
   double acc = 0.0;
-  if (col < W)
-    for (int s = sl; s < S; s += 8) acc += (double)in[(int64_t)s * W + col];
+  if (col < cols)
+    for (int s = sl; s < rows; s += 8) acc += (double)in[(int64_t)s * cols + col];
   red[sl][cl] = acc;
   __syncthreads();
-  if (sl == 0 && col < W) {
+  if (sl == 0 && col < cols) {
     double t = 0.0;
 #pragma unroll
     for (int s = 0; s < 8; ++s) t += red[s][cl];
-    grads[offs.off[blockIdx.y] + col] = (float)t;
+    grads[out + col] = (float)t;
   }
 }
 
 int launch_bias_colreduce(hipStream_t s, const float* part, int64_t stage_stride, int S, int W,
-                          int num_stages, const int64_t* out_offsets, float* grads) {
+                          int num_stages, const int64_t* out_offsets, float* grads,
+                          const float* extra_part, int extra_S, int extra_cols,
+                          int64_t extra_off) {
   if (num_stages > 32) return BLH_ERR_SHAPE;
   BiasOffsets o{};
   for (int i = 0; i < num_stages; ++i) o.off[i] = out_offsets[i];
-  hipLaunchKernelGGL(bias_colreduce_kernel, dim3((unsigned)ceil_div(W, 32), num_stages), dim3(256),
-                     0, s, part, stage_stride, S, W, grads, o);
+  o.extra_part = extra_part; o.extra_S = extra_S; o.extra_cols = extra_cols; o.extra_off = extra_off;
+  hipLaunchKernelGGL(bias_colreduce_kernel,
+                     dim3((unsigned)ceil_div(W, 32), num_stages + (extra_part ? 1 : 0)), dim3(256),
+                     0, s, part, stage_stride, S, W, num_stages, grads, o);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
@@ -695,12 +707,29 @@ int launch_sumsq(hipStream_t s, const float* g, int64_t count, double* part, int
   return BLH_OK;
 }
 
+// block 0 of the optimiser kernel also finishes the MSE loss (sum of the partials / denom),
+// which saves a 1-block launch per step
+__device__ __forceinline__ void finish_loss(const LossFinish& lf, double* sh) {
+  if (lf.part == nullptr || blockIdx.x != 0) return;
+  double a = 0.0;
+  for (int i = threadIdx.x; i < lf.n; i += 256) a += (double)lf.part[i];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) lf.out[0] = (float)(sh[0] / lf.denom);
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void clip_adam_kernel(
     float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
     int64_t count, float one_minus_b1, float b2, float one_minus_b2, float step_size,
     float bc2_sqrt, float eps, float max_norm, const double* __restrict__ sumsq_part, int nparts,
-    float* stats_out) {
+    float* stats_out, LossFinish lf) {
   __shared__ double sh[256];
+  finish_loss(lf, sh);
   double a = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 256) a += sumsq_part[i];
   sh[threadIdx.x] = a;
@@ -736,7 +765,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(
 
 int launch_clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count,
                      const blh_adam_hyper& h, const double* sumsq_part, int nparts,
-                     float* stats_out) {
+                     float* stats_out, LossFinish lf) {
   if (count % 4 != 0) return BLH_ERR_SHAPE;
   if (h.step < 1) return BLH_ERR_INVALID_ARGUMENT;
   const double bc1 = 1.0 - pow((double)h.beta1, (double)h.step);
@@ -746,7 +775,7 @@ int launch_clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int6
   const int blocks = (int)std::min<int64_t>(ceil_div(count / 4, 256), 2048);
   hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, count,
                      (float)(1.0 - (double)h.beta1), h.beta2, (float)(1.0 - (double)h.beta2),
-                     step_size, bc2_sqrt, h.eps, h.max_norm, sumsq_part, nparts, stats_out);
+                     step_size, bc2_sqrt, h.eps, h.max_norm, sumsq_part, nparts, stats_out, lf);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
@@ -834,12 +863,17 @@ int launch_dropout_mask(hipStream_t s, uint8_t* out, int64_t batch, int W, const
 // ---------------------------------------------------------------------------
 namespace blh {
 
+// grid = multiple of 3 blocks of 256 threads, so that a thread's 4 columns never change
+// (256*4*3 = 3072 = 64*48): per-thread sums of dpred give the decode-bias gradient partials
 __global__ __launch_bounds__(256) void decode_finish_kernel(
     const float* __restrict__ slabs, int splits, int64_t n, int out_features,
     const float* __restrict__ bias, float* __restrict__ pred, const float* __restrict__ target,
-    float scale, float* __restrict__ dpred, float* __restrict__ loss_part) {
+    float scale, float* __restrict__ dpred, float* __restrict__ loss_part,
+    float* __restrict__ dbias_part) {
   __shared__ float sh[4];
+  __shared__ float4 shc[256];
   float acc = 0.f;
+  float4 dsum = make_float4(0.f, 0.f, 0.f, 0.f);
   const int64_t n4 = n >> 2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -857,23 +891,45 @@ __global__ __launch_bounds__(256) void decode_finish_kernel(
       d.x = v.x - t.x; d.y = v.y - t.y; d.z = v.z - t.z; d.w = v.w - t.w;
       acc += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
       d.x *= scale; d.y *= scale; d.z *= scale; d.w *= scale;
+      dsum.x += d.x; dsum.y += d.y; dsum.z += d.z; dsum.w += d.w;
       st4(dpred + i * 4, d);
     }
   }
   if (target) {
     const float t = block_sum_f32(acc, sh);
     if (threadIdx.x == 0) loss_part[blockIdx.x] = t;
+    if (dbias_part) {
+      // thread t of block b owns column group (b*256 + t) % (out_features/4); fixed-order sums
+      shc[threadIdx.x] = dsum;
+      __syncthreads();
+      const int cg = out_features >> 2;
+      if ((int)threadIdx.x < cg) {
+        const int first = (int)((threadIdx.x + cg - (blockIdx.x * 256) % cg) % cg);
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = first; k < 256; k += cg) {
+          const float4 u = shc[k];
+          a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        }
+        st4(dbias_part + (int64_t)blockIdx.x * out_features + threadIdx.x * 4, a);
+      }
+    }
   }
 }
 
 int launch_decode_finish(hipStream_t s, const float* slabs, int splits, int64_t batch,
                          int out_features, const float* bias, float* pred, const float* target,
-                         float scale, float* dpred, float* loss_part, int* nparts) {
+                         float scale, float* dpred, float* loss_part, int* nparts,
+                         float* dbias_part) {
   const int64_t n = batch * out_features;
   if (out_features % 4 != 0) return BLH_ERR_SHAPE;
-  const int blocks = (int)std::min<int64_t>(ceil_div(n / 4, 256), 1024);
+  int blocks = (int)std::min<int64_t>(ceil_div(n / 4, 256), 1023);
+  if (dbias_part) {
+    // the fixed thread -> column mapping needs (gridDim*256) % (out_features/4) == 0
+    if ((256 * 3) % (out_features / 4) != 0) return BLH_ERR_SHAPE;
+    blocks = (int)round_up(blocks, 3);
+  }
   hipLaunchKernelGGL(decode_finish_kernel, dim3(blocks), dim3(256), 0, s, slabs, splits, n,
-                     out_features, bias, pred, target, scale, dpred, loss_part);
+                     out_features, bias, pred, target, scale, dpred, loss_part, dbias_part);
   BLH_HIP_TRY(hipGetLastError());
   if (nparts) *nparts = blocks;
   return BLH_OK;
@@ -907,8 +963,9 @@ int launch_step_state_advance(hipStream_t s, blh_step_state* st) {
 __global__ __launch_bounds__(256) void clip_adam_dev_kernel(
     float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
     int64_t count, const blh_step_state* __restrict__ st, const double* __restrict__ sumsq_part,
-    int nparts, float* stats_out) {
+    int nparts, float* stats_out, LossFinish lf) {
   __shared__ double sh[256];
+  finish_loss(lf, sh);
   double a = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 256) a += sumsq_part[i];
   sh[threadIdx.x] = a;
@@ -948,11 +1005,11 @@ __global__ __launch_bounds__(256) void clip_adam_dev_kernel(
 
 int launch_clip_adam_dev(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count,
                          const blh_step_state* st, const double* sumsq_part, int nparts,
-                         float* stats_out) {
+                         float* stats_out, LossFinish lf) {
   if (count % 4 != 0) return BLH_ERR_SHAPE;
   const int blocks = (int)std::min<int64_t>(ceil_div(count / 4, 256), 2048);
   hipLaunchKernelGGL(clip_adam_dev_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, count, st,
-                     sumsq_part, nparts, stats_out);
+                     sumsq_part, nparts, stats_out, lf);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
@@ -1104,6 +1161,80 @@ int launch_bn_fwd_finalize_sums(hipStream_t s, const double* sums, int64_t n_glo
                      sums, n_global, W, gamma, beta, running_mean, running_var, nbt, momentum,
                      saved_mean, saved_invstd, scale, shift);
   BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+}  // namespace blh
+
+// ---------------------------------------------------------------------------
+// end of backward on the fused path: every weight gradient whose wgrad was split over the
+// batch is still a set of partial slabs; this ONE launch sums the slabs of all stages into
+// the gradient arena and, in the same pass, produces the partial sums of squares of the
+// WHOLE arena for clip_grad_norm_ (replaces one sum_slabs launch per stage + the sumsq
+// launch).  Regions tile the arena; a region without slabs is read as is.
+// ---------------------------------------------------------------------------
+namespace blh {
+
+__global__ __launch_bounds__(256) void grads_finish_kernel(float* __restrict__ grads, GradRegions R,
+                                                           double* __restrict__ sumsq_part) {
+  __shared__ double sh[256];
+  // select this block's region with compile-time indices only: a runtime index into the
+  // by-value argument struct would make the compiler copy it to scratch memory
+  GradRegion reg = R.r[0];
+#pragma unroll
+  for (int k = 1; k < MAX_GRAD_REGIONS; ++k)
+    if (k < R.n && (int)blockIdx.x >= R.r[k].first_block) reg = R.r[k];
+  const int64_t base = (int64_t)(blockIdx.x - reg.first_block) * R.items_per_block;
+  double acc = 0.0;
+  const int64_t end = min(reg.cnt4, base + R.items_per_block);
+  float facc = 0.f;
+  for (int64_t i = base + threadIdx.x; i < end; i += 256) {
+    float4 v;
+    if (reg.splits > 0) {
+      v = ld4(reg.slabs + i * 4);
+      int s = 1;
+      for (; s + 3 <= reg.splits; s += 3) {
+        const float4 u0 = ld4(reg.slabs + ((int64_t)(s + 0) * reg.cnt4 + i) * 4);
+        const float4 u1 = ld4(reg.slabs + ((int64_t)(s + 1) * reg.cnt4 + i) * 4);
+        const float4 u2 = ld4(reg.slabs + ((int64_t)(s + 2) * reg.cnt4 + i) * 4);
+        v.x += u0.x; v.y += u0.y; v.z += u0.z; v.w += u0.w;
+        v.x += u1.x; v.y += u1.y; v.z += u1.z; v.w += u1.w;
+        v.x += u2.x; v.y += u2.y; v.z += u2.z; v.w += u2.w;
+      }
+      for (; s < reg.splits; ++s) {
+        const float4 u = ld4(reg.slabs + ((int64_t)s * reg.cnt4 + i) * 4);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      st4(grads + (reg.off4 + i) * 4, v);
+    } else {
+      v = ld4(grads + (reg.off4 + i) * 4);
+    }
+    facc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  acc = (double)facc;   // <= 8 float4 per thread: fp32 partial, fp64 from here on
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && sumsq_part) sumsq_part[blockIdx.x] = sh[0];
+}
+
+// regions: n entries with off4/cnt4/slabs/splits filled in ascending arena order, covering
+// [0, total4); first_block / items_per_block are computed here.  Returns the block count.
+int launch_grads_finish(hipStream_t s, float* grads, GradRegions& R, int64_t total4,
+                        double* sumsq_part, int* nparts) {
+  R.items_per_block = std::max<int64_t>(2048, round_up(ceil_div(total4, 900), 256));
+  int blocks = 0;
+  for (int i = 0; i < R.n; ++i) {
+    R.r[i].first_block = blocks;
+    blocks += (int)ceil_div(R.r[i].cnt4, R.items_per_block);
+  }
+  if (blocks > SUMSQ_MAX_PARTS || blocks == 0) return BLH_ERR_SHAPE;
+  hipLaunchKernelGGL(grads_finish_kernel, dim3(blocks), dim3(256), 0, s, grads, R, sumsq_part);
+  BLH_HIP_TRY(hipGetLastError());
+  if (nparts) *nparts = blocks;
   return BLH_OK;
 }
 
