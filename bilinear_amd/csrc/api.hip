@@ -84,7 +84,7 @@ struct Workspace {
   std::vector<float*> Z, A;       // per heavy: pre-BN output, activation (skip added)
   std::vector<float*> bn_saved;   // per heavy: [4][W] mean, invstd, scale, shift
   float* stat_part;               // [tiles_m][2][W]
-  float* G0; float* G1; float* dZ;
+  float* G0; float* G1; float* dZ; float* dZ2;
   float* bn_part;                 // [chunks][2][W]
   float* dz_colsum_part;          // [stage][chunks][W]
   float* slabs;                   // split-K partial products
@@ -161,6 +161,7 @@ static Workspace carve(const blh_model_desc* d, int64_t batch, void* base) {
   ws.G0 = (float*)take(act);
   ws.G1 = (float*)take(act);
   ws.dZ = (float*)take(act);
+  ws.dZ2 = (float*)take(act);
   const int64_t chunks = ew_num_row_chunks(batch);
   ws.bn_part = (float*)take(chunks * 2 * W * sizeof(float));
   ws.dz_colsum_part = (float*)take((int64_t)nh * chunks * W * sizeof(float));
@@ -315,6 +316,28 @@ static int wgrad(int dtype, hipStream_t s, GemmTile tile, const float* dZ, int64
   return launch_sum_slabs(s, slabs, (int64_t)M * N, sp.splits, out);
 }
 
+// Side stream for the weight-gradient GEMMs of the fused single-GPU step: nothing in the rest
+// of backward depends on dW, so wgrad(l) (+ its slab sum) runs on a second stream concurrently
+// with dgrad(l) and the HBM-bound BatchNorm-backward kernels of stage l-1, which leave the
+// MFMA pipes idle.  Fork / join by events (capturable into a hipGraph); dZ is double-buffered
+// so that stage l-2 does not overwrite what wgrad(l) is still reading.
+struct SideStream {
+  hipStream_t s2 = nullptr;
+  hipEvent_t ev_dz[34], ev_w[34];
+  bool ready = false;
+  int init() {
+    if (ready) return BLH_OK;
+    BLH_HIP_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    for (int i = 0; i < 34; ++i) {
+      BLH_HIP_TRY(hipEventCreateWithFlags(&ev_dz[i], hipEventDisableTiming));
+      BLH_HIP_TRY(hipEventCreateWithFlags(&ev_w[i], hipEventDisableTiming));
+    }
+    ready = true;
+    return BLH_OK;
+  }
+};
+static SideStream g_side;
+
 // fused: the caller is the whole-step path: the decode-bias partials come from decode_finish
 // (dec_bias_S rows) and the sum-of-squares partials of the arena are returned for clip+Adam.
 struct FusedBackward { int dec_bias_S; double* sumsq_part; int* sumsq_nparts; };
@@ -337,10 +360,32 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
   static const bool defer_env = getenv("BLH_DEFER_SLABS") != nullptr;
   const bool defer = (on_ready == nullptr) && defer_env;
   std::vector<GradRegion> wreg(nh + 1);
+  static const bool two_env = getenv("BLH_ONE_STREAM") == nullptr;   // on by default (-3 % step)
+  const bool two = two_env && !on_ready && !g_sync.fn && !defer &&
+                   small_m_splits(batch, W, W).splits == 1;
+  hipStream_t s2 = s;
+  if (two) {
+    BLH_TRY(g_side.init());
+    s2 = g_side.s2;
+  }
+  // fork: s2 continues after everything enqueued on s so far; wdone: marks wgrad(idx) complete
+  auto fork = [&](int idx) -> int {
+    if (!two) return BLH_OK;
+    BLH_HIP_TRY(hipEventRecord(g_side.ev_dz[idx], s));
+    BLH_HIP_TRY(hipStreamWaitEvent(s2, g_side.ev_dz[idx], 0));
+    return BLH_OK;
+  };
+  auto wdone = [&](int idx) -> int {
+    if (!two) return BLH_OK;
+    BLH_HIP_TRY(hipEventRecord(g_side.ev_w[idx], s2));
+    return BLH_OK;
+  };
   // decode: dW = dP^T A_last, db = colsum(dP), dA_last = dP W_d
-  BLH_TRY(wgrad(d->gemm_dtype, s, TILE_64x128, dpred, OF, OF, ws.A[nh - 1], W, W, batch,
+  BLH_TRY(fork(nh));
+  BLH_TRY(wgrad(d->gemm_dtype, s2, TILE_64x128, dpred, OF, OF, ws.A[nh - 1], W, W, batch,
                 ceil_div(OF, 64) * ceil_div(W, 128), defer ? ws.stage_slabs[nh] : ws.slabs,
                 grads + L.dec_w, defer ? &wreg[nh] : nullptr));
+  BLH_TRY(wdone(nh));
   if (!fused) BLH_TRY(launch_colsum(s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
   if (on_ready) on_ready(user, L.dec_w, L.total - L.dec_w);
   {
@@ -375,10 +420,14 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
       g_sync.fn(g_sync.user, sb, 2 * (int64_t)W, 0);
       dg = sb; db = sb + W; norm_batch = g_sync.global_batch;
     }
+    float* dzbuf = (two && (i & 1)) ? ws.dZ2 : ws.dZ;
+    if (two && i + 2 <= nh - 1)   // wgrad(i+2) read this dZ buffer
+      BLH_HIP_TRY(hipStreamWaitEvent(s, g_side.ev_w[i + 2], 0));
     BLH_TRY(launch_bn_bwd_apply(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W,
-                                params + h.gamma, dg, db, ws.dZ,
+                                params + h.gamma, dg, db, dzbuf,
                                 ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W, ds,
                                 norm_batch));
+    BLH_TRY(fork(i));
     // Linear: db = colsum(dZ); dW = dZ^T a_in; d a_in = dZ W
     // (data parallel: the bucket hook needs this stage's bias gradient now; otherwise all
     //  stages are reduced by one launch after the loop)
@@ -386,15 +435,17 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
       BLH_TRY(launch_colreduce(s, ws.dz_colsum_part + (int64_t)i * chunks * W, chunks, W, W,
                                grads + h.b));
     if (i == 0) {
-      BLH_TRY(wgrad(d->gemm_dtype, s, TILE_128x32, ws.dZ, W, W, x, d->in_features,
+      BLH_TRY(wgrad(d->gemm_dtype, s2, TILE_128x32, dzbuf, W, W, x, d->in_features,
                     d->in_features, batch, ceil_div(W, 128) * ceil_div(d->in_features, 32),
                     defer ? ws.stage_slabs[0] : ws.slabs, grads + h.w, defer ? &wreg[0] : nullptr));
+      BLH_TRY(wdone(0));
     } else {
-      BLH_TRY(wgrad(d->gemm_dtype, s, TILE_128x128, ws.dZ, W, W, ws.A[i - 1], W, W, batch,
+      BLH_TRY(wgrad(d->gemm_dtype, s2, TILE_128x128, dzbuf, W, W, ws.A[i - 1], W, W, batch,
                     ceil_div(W, 128) * ceil_div(W, 128), defer ? ws.stage_slabs[i] : ws.slabs,
                     grads + h.w, defer ? &wreg[i] : nullptr));
+      BLH_TRY(wdone(i));
       GemmParams g{};
-      g.A = ws.dZ; g.lda = W;
+      g.A = dzbuf; g.lda = W;
       g.B = params + h.w; g.ldb = W;
       g.M = (int)batch; g.N = W; g.K = W; g.k_per_split = W;
       g.ldc = W;
@@ -419,6 +470,7 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
       on_ready(user, h.w, end - h.w);
     }
   }
+  if (two) BLH_HIP_TRY(hipStreamWaitEvent(s, g_side.ev_w[0], 0));   // join: s2 is in order
   if (!on_ready) {   // (covers the no_defer A/B mode too: its regions are all plain)
     int64_t offs[32];
     if (nh > 32) return BLH_ERR_SHAPE;

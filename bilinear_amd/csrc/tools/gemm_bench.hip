@@ -111,6 +111,32 @@ int main(int argc, char** argv) {
   ROW("128x128 w2x2 pipe2", 128, 128, 2, 2, 2)
   ROW("128x64  w4x2 pipe2", 128, 64, 4, 2, 2)
   ROW("256x128 w4x2 pipe2", 256, 128, 4, 2, 2)
+  if (getenv("BENCH_COLD")) {  // cold-cache timing: evict L2 + Infinity Cache before every launch
+    char* big; const size_t bigsz = (size_t)768 << 20; CK(hipMalloc(&big, bigsz));
+    auto cold = [&](const char* name, auto kern, const GemmParams& pp, int splits, size_t lds, int nt) {
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const int tiles = (int)(ceil_div(pp.M, 128) * ceil_div(pp.N, 128));
+      hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+      double tot_cold = 0, tot_warm = 0; const int n = 40;
+      for (int i = 0; i < n; ++i) {
+        CK(hipMemsetAsync(big, i, bigsz, 0));
+        CK(hipEventRecord(a, 0));
+        hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(nt), lds, 0, pp);
+        CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); tot_cold += ms;
+        CK(hipEventRecord(a, 0));
+        hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(nt), lds, 0, pp);
+        CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+        CK(hipEventElapsedTime(&ms, a, b)); tot_warm += ms;
+      }
+      printf("  %-12s cold %.1f us   warm (2nd launch) %.1f us\n", name, tot_cold / n * 1e3, tot_warm / n * 1e3);
+    };
+    w.k_per_split = (int)round_up(ceil_div(M, 4), 32); w.c_split_stride = (int64_t)W * W;
+    cold("fwd", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 3>, f, 1, gemm_lds_bytes<128, 128, ROWK, ROWK, 3>(), 512);
+    cold("dgrad", gemm_f32_kernel<128, 128, 4, 2, ROWK, KROW, EPI_STORE, 3>, d, 1, gemm_lds_bytes<128, 128, ROWK, KROW, 3>(), 512);
+    cold("wgrad", gemm_f32_kernel<128, 128, 4, 2, KROW, KROW, EPI_STORE, 3>, w, 4, gemm_lds_bytes<128, 128, KROW, KROW, 3>(), 512);
+    return 0;
+  }
   {  // ablations of the PIPE=1 main loop (timing only; results are wrong)
     auto abl = [&](const char* name, auto kern) {
       constexpr size_t lds = gemm_lds_bytes<128, 128, ROWK, ROWK, 3>();
