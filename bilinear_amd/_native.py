@@ -79,6 +79,13 @@ _SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                POINTER(Dropout), c_float, POINTER(AdamHyper), c_void_p, c_int64,
                                c_void_p, c_void_p, c_void_p, c_int64]),
+    "blh_heavy_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32]),
+    "blh_heavy_forward": (c_int, [c_void_p] * 9 + [POINTER(Dropout), c_float, c_int32, c_int32,
+                                                   c_void_p, c_int64, c_void_p, c_int64, c_int32,
+                                                   c_int32]),
+    "blh_heavy_backward": (c_int, [c_void_p] * 5 + [POINTER(Dropout), c_int32, c_void_p, c_int64,
+                                                    c_void_p, c_void_p, c_void_p, c_void_p,
+                                                    c_void_p, c_int64, c_int32, c_int32]),
     "blh_mpjpe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                           c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "blh_step_state_advance": (c_int, [c_void_p, c_void_p]),

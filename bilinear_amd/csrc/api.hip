@@ -699,6 +699,109 @@ int blh_backward_sync(const blh_model_desc* d, void* stream, const float* params
                       on_ready, user);
 }
 
+// ---------------------------------------------------------------- single stage ----
+// heavy_linear (model/bilinear.py:7-13) on its own: Linear -> BatchNorm1d -> ReLU -> Dropout.
+struct HeavyWs {
+  float* Z; float* dZ; float* saved; float* stat_part; float* bn_part; float* dz_part; float* slabs;
+  int64_t bytes;
+};
+static HeavyWs carve_heavy(int64_t batch, int in_f, int out_f, void* base) {
+  HeavyWs w;
+  char* p = (char*)base;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) {
+    char* r = p ? p + off : nullptr;
+    off += round_up(bytes, WS_ALIGN);
+    return r;
+  };
+  const int64_t chunks = ew_num_row_chunks(batch);
+  w.Z = (float*)take(batch * out_f * sizeof(float));
+  w.dZ = (float*)take(batch * out_f * sizeof(float));
+  w.saved = (float*)take(4 * (int64_t)out_f * sizeof(float));
+  w.stat_part = (float*)take(ceil_div(batch, 64) * 2 * out_f * sizeof(float));
+  w.bn_part = (float*)take(chunks * 2 * out_f * sizeof(float));
+  w.dz_part = (float*)take(chunks * out_f * sizeof(float));
+  const Splits sp = pick_splits(batch, ceil_div(out_f, 128) * ceil_div(in_f, 128));
+  w.slabs = (float*)take((int64_t)sp.splits * out_f * in_f * sizeof(float));
+  w.bytes = off;
+  return w;
+}
+
+int64_t blh_heavy_workspace_bytes(int64_t batch, int32_t in_features, int32_t out_features) {
+  if (batch <= 0 || in_features <= 0 || out_features <= 0) return BLH_ERR_INVALID_ARGUMENT;
+  if (in_features % 4 != 0 || out_features % 4 != 0) return BLH_ERR_SHAPE;
+  return carve_heavy(batch, in_features, out_features, nullptr).bytes;
+}
+
+int blh_heavy_forward(void* stream, const float* a_in, const float* weight, const float* bias,
+                      const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, int64_t* num_batches_tracked, const blh_dropout* drop,
+                      float momentum, int32_t training, int32_t gemm_dtype, void* workspace,
+                      int64_t workspace_bytes, float* a_out, int64_t batch, int32_t in_features,
+                      int32_t out_features) {
+  if (!a_in || !weight || !bias || !gamma || !beta || !running_mean || !running_var || !a_out ||
+      !workspace || batch <= 0)
+    return BLH_ERR_INVALID_ARGUMENT;
+  if (in_features % 4 != 0 || out_features % 4 != 0) return BLH_ERR_SHAPE;
+  if (training && (batch < 2 || !drop || !num_batches_tracked)) return BLH_ERR_INVALID_ARGUMENT;
+  if (training) BLH_TRY(check_drop(drop));
+  if (((uintptr_t)workspace % WS_ALIGN) != 0) return BLH_ERR_INVALID_ARGUMENT;
+  const HeavyWs w = carve_heavy(batch, in_features, out_features, workspace);
+  if (workspace_bytes < w.bytes) return BLH_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int W = out_features;
+  GemmParams g{};
+  g.A = a_in; g.lda = in_features; g.B = weight; g.ldb = in_features; g.C = w.Z; g.ldc = W;
+  g.M = (int)batch; g.N = W; g.K = in_features; g.k_per_split = in_features;
+  g.bias = bias; g.stat_part = w.stat_part;
+  BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, training ? EPI_BIAS_STATS : EPI_BIAS, g, 1,
+                      gemm_dtype));
+  if (!training)
+    return launch_bn_apply_eval(s, w.Z, gamma, beta, running_mean, running_var, nullptr, a_out,
+                                batch, W);
+  float* sv = w.saved;
+  BLH_TRY(launch_bn_fwd_finalize(s, w.stat_part, (int)ceil_div(batch, 128), 128, batch, W, gamma,
+                                 beta, running_mean, running_var, num_batches_tracked, momentum, sv,
+                                 sv + W, sv + 2 * W, sv + 3 * W));
+  DropoutSrc ds{drop->keep_mask, drop->seed, drop->step, drop->row_offset, 0, nullptr};
+  return launch_bn_apply_train(s, w.Z, sv + 2 * W, sv + 3 * W, nullptr, a_out, batch, W, ds,
+                               num_batches_tracked);
+}
+
+int blh_heavy_backward(void* stream, const float* d_out, const float* a_in, const float* weight,
+                       const float* gamma, const blh_dropout* drop, int32_t gemm_dtype,
+                       void* workspace, int64_t workspace_bytes, float* d_weight, float* d_bias,
+                       float* d_gamma, float* d_beta, float* d_in, int64_t batch,
+                       int32_t in_features, int32_t out_features) {
+  if (!d_out || !a_in || !weight || !gamma || !drop || !workspace || !d_weight || !d_bias ||
+      !d_gamma || !d_beta || batch < 2)
+    return BLH_ERR_INVALID_ARGUMENT;
+  if (in_features % 4 != 0 || out_features % 4 != 0) return BLH_ERR_SHAPE;
+  BLH_TRY(check_drop(drop));
+  const HeavyWs w = carve_heavy(batch, in_features, out_features, workspace);
+  if (workspace_bytes < w.bytes) return BLH_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int W = out_features;
+  const int chunks = ew_num_row_chunks(batch);
+  const float* sv = w.saved;
+  DropoutSrc ds{drop->keep_mask, drop->seed, drop->step, drop->row_offset, 0, nullptr};
+  BLH_TRY(launch_bn_bwd_reduce(s, d_out, w.Z, sv + 2 * W, sv + 3 * W, sv, sv + W, w.bn_part, batch,
+                               W, ds));
+  BLH_TRY(launch_bn_bwd_finalize(s, w.bn_part, chunks, W, d_gamma, d_beta));
+  BLH_TRY(launch_bn_bwd_apply(s, d_out, w.Z, sv + 2 * W, sv + 3 * W, sv, sv + W, gamma, d_gamma,
+                              d_beta, w.dZ, w.dz_part, batch, W, ds, batch));
+  BLH_TRY(launch_colreduce(s, w.dz_part, chunks, W, W, d_bias));
+  BLH_TRY(wgrad(gemm_dtype, s, TILE_128x128, w.dZ, W, W, a_in, in_features, in_features, batch,
+                ceil_div(W, 128) * ceil_div(in_features, 128), w.slabs, d_weight, nullptr));
+  if (d_in) {
+    GemmParams g{};
+    g.A = w.dZ; g.lda = W; g.B = weight; g.ldb = in_features; g.C = d_in; g.ldc = in_features;
+    g.M = (int)batch; g.N = in_features; g.K = W; g.k_per_split = W;
+    BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, 1, gemm_dtype));
+  }
+  return BLH_OK;
+}
+
 int blh_mpjpe(void* stream, const float* pred, const float* target, const float* mean,
               const float* stddev, int64_t batch, int32_t joints, float* dist_out,
               const int32_t* action_ids, int32_t num_actions, double* action_sum,

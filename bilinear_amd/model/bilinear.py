@@ -25,18 +25,86 @@ __all__ = ["heavy_linear", "BilinearUnit", "Bilinear", "load"]
 GEMM_DTYPES = {"fp32": 0, "bf16": 1}
 
 
+class _HeavyStageFunction(torch.autograd.Function):
+    """Autograd bridge of one stand-alone stage (blh_heavy_forward / blh_heavy_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, stage, weight, bias, gamma, beta):
+        import ctypes
+
+        from .. import _native as N
+        lin, bn = stage[0], stage[1]
+        batch = x.shape[0]
+        in_f, out_f = lin.in_features, lin.out_features
+        need = N.lib().blh_heavy_workspace_bytes(batch, in_f, out_f)
+        if need < 0:
+            N.check(int(need), "blh_heavy_workspace_bytes")
+        ws = torch.empty(int(need), dtype=torch.uint8, device=x.device)
+        out = torch.empty(batch, out_f, dtype=torch.float32, device=x.device)
+        training = bool(stage.training)
+        drop = N.Dropout(None, stage._seed, stage._rng_step, 0)
+        momentum = -1.0 if bn.momentum is None else float(bn.momentum)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        N.check(N.lib().blh_heavy_forward(
+            st, N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(gamma), N.ptr(beta),
+            N.ptr(bn.running_mean), N.ptr(bn.running_var), N.ptr(bn.num_batches_tracked),
+            ctypes.byref(drop), momentum, int(training), 0, N.ptr(ws), ws.numel(), N.ptr(out),
+            batch, in_f, out_f), "blh_heavy_forward")
+        if training:
+            stage._rng_step += 1
+        ctx.saved = (x, weight, gamma, ws, drop, in_f, out_f, training)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        import ctypes
+
+        from .. import _native as N
+        x, weight, gamma, ws, drop, in_f, out_f, training = ctx.saved
+        if not training:
+            raise RuntimeError("backward through an eval-mode heavy_linear stage is not supported")
+        batch = x.shape[0]
+        d_out = d_out.contiguous()
+        dw = torch.empty_like(weight)
+        db = torch.empty(out_f, dtype=torch.float32, device=x.device)
+        dg = torch.empty_like(db)
+        dbeta = torch.empty_like(db)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        N.check(N.lib().blh_heavy_backward(
+            st, N.ptr(d_out), N.ptr(x), N.ptr(weight), N.ptr(gamma), ctypes.byref(drop), 0,
+            N.ptr(ws), ws.numel(), N.ptr(dw), N.ptr(db), N.ptr(dg), N.ptr(dbeta), N.ptr(dx), batch,
+            in_f, out_f), "blh_heavy_backward")
+        return dx, None, dw, db, dg, dbeta
+
+
 class _HeavyLinear(nn.Sequential):
     """Linear -> BatchNorm1d -> ReLU -> Dropout(0.5) as ONE fused stage.
 
-    Inside ``BilinearUnit`` the children only hold parameters and buffers (the
-    unit drives all stages natively, fused across stage boundaries).  The C ABI
-    has no single-stage entry point, so calling a stage on its own is rejected
-    loudly instead of silently running ATen ops."""
+    Inside ``BilinearUnit`` the children only hold parameters and buffers (the unit drives all
+    stages natively, fused across stage boundaries).  Called on its own, the stage runs the
+    same kernels through blh_heavy_forward / blh_heavy_backward (HIP device only)."""
 
     def forward(self, in_tensor):   # noqa: D401
-        raise RuntimeError(
-            "bilinear_amd.heavy_linear stages are executed by BilinearUnit's native engine; "
-            "a stand-alone stage has no HIP entry point (and there is no ATen fallback).")
+        if in_tensor.device.type != "cuda":
+            raise RuntimeError(
+                "bilinear_amd.heavy_linear runs only on a HIP device (MI355X); input is on '%s' "
+                "and there is no CPU/ATen fallback." % in_tensor.device)
+        lin, bn = self[0], self[1]
+        if in_tensor.dim() != 2 or in_tensor.shape[1] != lin.in_features or in_tensor.dtype != torch.float32:
+            raise RuntimeError("expected a float32 input of shape [B, %d]" % lin.in_features)
+        if self.training and in_tensor.shape[0] < 2:
+            raise ValueError("Expected more than 1 value per channel when training")
+        if not hasattr(self, "_rng_step"):
+            object.__setattr__(self, "_rng_step", 0)
+            object.__setattr__(self, "_seed", int(torch.initial_seed()) & ((1 << 63) - 1))
+        x = in_tensor.contiguous()
+        args = (x, self, lin.weight.contiguous(), lin.bias.contiguous(), bn.weight.contiguous(),
+                bn.bias.contiguous())
+        if torch.is_grad_enabled() and self.training:
+            return _HeavyStageFunction.apply(*args)
+        with torch.no_grad():
+            return _HeavyStageFunction.apply(*args)
 
 
 def heavy_linear(in_features, out_features, bias=True):

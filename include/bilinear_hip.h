@@ -224,6 +224,25 @@ int blh_train_step_captured(const blh_model_desc* d, void* stream, float* params
                             void* workspace, int64_t workspace_bytes, float* pred,
                             float* loss_out, float* stats_out, int64_t batch);
 
+/* ---- one heavy_linear stage on its own --------------------------------------------------
+ * model/bilinear.py:7-13 as a stand-alone module: a_out = Dropout(ReLU(BN(a_in W^T + b))).
+ * in/out features must be multiples of 4.  `workspace` (blh_heavy_workspace_bytes) keeps the
+ * pre-BN output and the batch statistics between forward and backward.  training = 0: running
+ * statistics, no dropout, nothing saved.  backward writes dW, db, dgamma, dbeta and, if d_in is
+ * not NULL, the input gradient [B, in].  drop->keep_mask, if given, is [B, out].            */
+int64_t blh_heavy_workspace_bytes(int64_t batch, int32_t in_features, int32_t out_features);
+int blh_heavy_forward(void* stream, const float* a_in, const float* weight, const float* bias,
+                      const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, int64_t* num_batches_tracked, const blh_dropout* drop,
+                      float momentum, int32_t training, int32_t gemm_dtype, void* workspace,
+                      int64_t workspace_bytes, float* a_out, int64_t batch, int32_t in_features,
+                      int32_t out_features);
+int blh_heavy_backward(void* stream, const float* d_out, const float* a_in, const float* weight,
+                       const float* gamma, const blh_dropout* drop, int32_t gemm_dtype,
+                       void* workspace, int64_t workspace_bytes, float* d_weight, float* d_bias,
+                       float* d_gamma, float* d_beta, float* d_in, int64_t batch,
+                       int32_t in_features, int32_t out_features);
+
 /* ---- validation metric ----------------------------------------------------------------
  * valid_bilinear.py:53-70: pred/target [B, joints*3] are de-normalised with the train-set
  * mean/stddev [joints*3]; dist_out[b] = sum over joints of the Euclidean distance (mm).

@@ -95,7 +95,7 @@ def test_no_cpu_fallback():
     net.eval()
     with pytest.raises(RuntimeError, match="HIP device"):
         net(torch.zeros(8, 32))
-    with pytest.raises(RuntimeError):
+    with pytest.raises(RuntimeError, match="HIP device"):
         bilinear_amd.heavy_linear(32, 64)(torch.zeros(8, 32))
 
 

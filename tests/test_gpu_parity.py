@@ -656,3 +656,39 @@ def test_batchnorm_statistics_large_batch_with_offset():
     m2 = (p[:, 1] + 128 * (p[:, 0] - mean) ** 2).sum(axis=0)
     assert np.abs(mean - z.mean(axis=0)).max() <= 1e-6 * 10
     assert np.abs(m2 / M - z.var(axis=0)).max() <= 2e-3 * z.var(axis=0).max()
+
+
+def test_standalone_heavy_linear_stage():
+    """heavy_linear (model/bilinear.py:7-13) called on its own: forward/backward of one stage
+    against plain PyTorch on the CPU with the same dropout mask (recovered from the output)."""
+    import bilinear_amd
+    dev = _dev()
+    torch.manual_seed(21)
+    stage = bilinear_amd.heavy_linear(64, 192).to(dev).train()
+    ref = torch.nn.Sequential(torch.nn.Linear(64, 192), torch.nn.BatchNorm1d(192), torch.nn.ReLU())
+    ref[0].load_state_dict({k: v.cpu() for k, v in stage[0].state_dict().items()})
+    with torch.no_grad():
+        stage[1].weight.uniform_(0.5, 1.5); stage[1].bias.normal_(0, 0.2)
+    ref[1].load_state_dict({k: v.cpu() for k, v in stage[1].state_dict().items()})
+    ref.train()
+    x = torch.randn(300, 64)
+    xg = x.to(dev).requires_grad_(True)
+    out = stage(xg)
+    xr = x.clone().requires_grad_(True)
+    y = ref(xr)
+    keep = (out.detach().cpu() != 0) | (y.detach() <= 0)       # mask irrelevant where relu is 0
+    assert abs(keep[y.detach() > 0].float().mean().item() - 0.5) < 0.03
+    yr = y * keep.float() * 2.0
+    _close(out.detach().cpu().numpy(), yr.detach().numpy(), TIGHT, "stage output")
+    g = torch.randn(300, 192)
+    out.backward(g.to(dev))
+    yr.backward(g)
+    _close(xg.grad.cpu().numpy(), xr.grad.numpy(), TIGHT * 3, "d input")
+    _close(stage[0].weight.grad.cpu().numpy(), ref[0].weight.grad.numpy(), TIGHT * 3, "d weight")
+    _close(stage[1].weight.grad.cpu().numpy(), ref[1].weight.grad.numpy(), TIGHT * 3, "d gamma")
+    _close(stage[1].bias.grad.cpu().numpy(), ref[1].bias.grad.numpy(), TIGHT * 3, "d beta")
+    _close(stage[1].running_var.cpu().numpy(), ref[1].running_var.numpy(), TIGHT, "running_var")
+    assert int(stage[1].num_batches_tracked) == 1
+    stage.eval(); ref.eval()
+    with torch.no_grad():
+        _close(stage(x.to(dev)).cpu().numpy(), ref(x).numpy(), TIGHT, "eval stage")
