@@ -13,14 +13,16 @@
 // ROWK = the reduction index is the contiguous one in memory; KROW = the
 // output index is contiguous.
 //
-// Data movement per workgroup (256 threads = 4 waves of 64):
-//   HBM/L2 --global_load_dwordx4 (16 B/lane, coalesced along the contiguous
-//   axis)--> VGPR --ds_write_b128--> LDS tile (double buffered, one barrier per
-//   32-deep K tile) --ds_read_b128 (ROWK, 36-float padded rows: conflict-free)
-//   or ds_read_b32 (KROW, 32 consecutive lanes = 32 consecutive banks)--> MFMA.
-//   The next K tile's global loads are issued before the current tile's MFMAs
-//   and written to the other LDS stage after them, so HBM/L2 latency hides
-//   under 64 MFMAs (4096 cycles) per wave.
+// Data movement per workgroup (512 threads = 8 waves of 64, tile 128x128, K tile 32), PIPE 3:
+//   HBM/L2 --global_load_lds_dwordx4 (LDS-DMA: 16 B/lane, coalesced along the contiguous axis,
+//   no VGPR staging, no ds_write)--> 3-stage ring of unpadded LDS tiles, tile kt+2 in flight
+//   while tile kt is multiplied; counted s_waitcnt vmcnt + one raw s_barrier per K tile
+//   --ds_read_b128 (ROWK; XOR swizzle on the DMA source address and on the read) or
+//   ds_read_b32 (KROW; 32 consecutive lanes = 32 consecutive banks)--> MFMA, with the
+//   fragments of k-group s+1 read while the MFMAs of group s issue.
+//   PIPE 1 is the register-staged double buffer (global_load_dwordx4 -> VGPR -> ds_write_b128
+//   into 36-float padded rows), kept as the A/B baseline of tools/gemm_bench.hip together
+//   with the STAMP (in-kernel clock stamps) and ABLATE (timing-only) diagnostic switches.
 // Each wave owns a (BM/WM) x (BN/WN) sub-tile as TM x TN accumulators of 32x32.
 //
 // Fragment/k ordering: a lane of half h = lane>>5 reads 4 consecutive k
@@ -108,7 +110,7 @@ __device__ inline void read_frags(float (&frag)[T][4], const float* lds, int row
   }
 }
 
-// ---- global -> LDS by LDS-DMA (global_load_lds_dwordx4), PIPE == 2 ---------------------
+// ---- global -> LDS by LDS-DMA (global_load_lds_dwordx4), PIPE == 3 ---------------------
 // The DMA writes LDS linearly (wave-uniform base + lane*16 B), so tiles are unpadded and the
 // bank-conflict fix for the ROWK fragment reads is an XOR swizzle applied to the per-lane
 // SOURCE address (chunk c of row r lands in slot c ^ (r & 7)) and again on the read.
@@ -130,42 +132,6 @@ __device__ __forceinline__ void lds_dma16_asm(const float* gsrc, uint32_t lds_by
       : "v"(gsrc), "s"(lds_byte_addr_uniform)
       : "memory", "m0");
 }
-
-template <int LAYOUT, int R, int NT, bool ASM = false>
-struct TileDMA {
-  static constexpr int CHUNKS = (R * BK / 4) / NT;
-  static constexpr int FLOATS = R * BK;
-  static_assert((R * BK / 4) % NT == 0, "tile not divisible among threads");
-
-  __device__ static inline void issue(float* lds_tile, const float* __restrict__ base, int64_t ld,
-                                      int row0, int rows_limit, int k0, int k_end, int tid) {
-#pragma unroll
-    for (int p = 0; p < CHUNKS; ++p) {
-      const int q = tid + p * NT;
-      int row, k;
-      if (LAYOUT == ROWK) {
-        const int r = q >> 3;
-        row = row0 + r;
-        k = k0 + ((((q & 7) ^ (r & 7))) << 2);
-      } else {
-        constexpr int CPR = R / 4;
-        row = row0 + ((q % CPR) << 2);
-        k = k0 + (q / CPR);
-      }
-      const bool ok = (row < rows_limit) && (k < k_end);
-      const int64_t off = (LAYOUT == ROWK) ? ((int64_t)row * ld + k) : ((int64_t)k * ld + row);
-      const float* src = ok ? (base + off) : reinterpret_cast<const float*>(&g_zero16);
-      float* dst = lds_tile + (p * NT + (tid & ~63)) * 4;   // wave-uniform; HW adds lane*16
-      if (ASM) {
-        const uint32_t a = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) float*)dst);
-        lds_dma16_asm(src, __builtin_amdgcn_readfirstlane(a));
-      } else {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-      }
-    }
-  }
-};
 
 // Loop-invariant part of a thread's DMA work hoisted out of the K loop: source pointers at
 // the first tile (advanced by a constant stride per tile), row validity, and the wave-uniform
@@ -208,18 +174,6 @@ struct DmaPlan {
     }
   }
 
-  // one chunk (compile-time index) of the same tile: lets the caller spread the DMA issue
-  // between MFMAs instead of clumping it at the top of the K tile
-  template <int P>
-  __device__ inline void issue_chunk(uint32_t lds_tile, int k0, int k_end) {
-    if (P < CHUNKS) {
-      const float* g = src[P < CHUNKS ? P : 0];
-      if (ragged_k && !(k0 + koff[P < CHUNKS ? P : 0] < k_end)) g = reinterpret_cast<const float*>(&g_zero16);
-      lds_dma16_asm(g, lds_tile + wave_off + (uint32_t)(P * NT * 16));
-      src[P < CHUNKS ? P : 0] += step[P < CHUNKS ? P : 0];
-    }
-  }
-
   // DMA tile whose first k is k0 into the LDS tile at byte address lds_tile (wave-uniform)
   __device__ inline void issue(uint32_t lds_tile, int k0, int k_end) {
 #pragma unroll
@@ -253,7 +207,7 @@ __device__ inline void read_frags_dma(float (&frag)[T][4], const float* lds, int
 
 template <int BM, int BN, int LA, int LB, int PIPE>
 constexpr size_t gemm_lds_bytes() {
-  return PIPE >= 2 ? 3 * (size_t)(BM + BN) * BK * sizeof(float)
+  return PIPE == 3 ? 3 * (size_t)(BM + BN) * BK * sizeof(float)
                    : 2 * (size_t)(TileGeom<LA, BM>::LDS_FLOATS + TileGeom<LB, BN>::LDS_FLOATS) * sizeof(float);
 }
 
@@ -267,8 +221,8 @@ __device__ inline int xcd_remap(int bid, int nwg) {
 }
 
 template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int PIPE = 1, int STAMP = 0, int ABLATE = 0>
-__global__ __launch_bounds__(64 * WM * WN + (PIPE == 4 ? 64 : 0)) void gemm_f32_kernel(GemmParams p) {
-  constexpr int NT = 64 * WM * WN;   // MFMA (consumer) threads; PIPE 4 adds one DMA (producer) wave
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmParams p) {
+  constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile must be at least 32x32");
   constexpr int A_FLOATS = TileGeom<LA, BM>::LDS_FLOATS;
@@ -280,7 +234,6 @@ __global__ __launch_bounds__(64 * WM * WN + (PIPE == 4 ? 64 : 0)) void gemm_f32_
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const bool is_cons = wave < WM * WN;   // false only for the PIPE 4 producer wave
   const int tiles_n = (p.N + BN - 1) / BN;
   const int nwg = gridDim.x;
   const int tile = xcd_remap(blockIdx.x, nwg);
@@ -306,7 +259,7 @@ __global__ __launch_bounds__(64 * WM * WN + (PIPE == 4 ? 64 : 0)) void gemm_f32_
   // STAMP: diagnostic builds only (tools/gemm_bench): shader clock vs 100 MHz real-time clock
   unsigned long long stamp_c0 = 0, stamp_r0 = 0;
   if (STAMP) { stamp_c0 = __builtin_amdgcn_s_memtime(); stamp_r0 = __builtin_amdgcn_s_memrealtime(); }
-  if (PIPE < 2) {
+  if (PIPE != 3) {
     if (nkt > 0) {
       IOA::load(ra, p.A, p.lda, m0, p.M, kz0, k_end, tid);
       IOB::load(rb, p.B, p.ldb, n0, p.N, kz0, k_end, tid);
@@ -316,123 +269,26 @@ __global__ __launch_bounds__(64 * WM * WN + (PIPE == 4 ? 64 : 0)) void gemm_f32_
     __syncthreads();
   }
 
-  if (PIPE == 4) {
-    // Wave-specialised LDS-DMA pipeline: wave WM*WN (the producer) issues every global->LDS
-    // DMA of the 3-stage ring (tile kt+2 while tile kt is multiplied) and does the counted
-    // vmcnt wait; the WM*WN consumer waves run nothing but ds_read + MFMA.  One s_barrier per
-    // K tile, executed by all waves: the producer arrives once tile kt+1 has landed, the
-    // consumers once their reads of tile kt are complete (lgkmcnt(0)), so after it tile kt+1
-    // may be read and the stage of tile kt may be overwritten (by the DMA of tile kt+3).
-    using DA = TileDMA<LA, BM, 64, true>;
-    using DB = TileDMA<LB, BN, 64, true>;
-    constexpr int RING = (BM + BN) * BK;
-    constexpr int G = DA::CHUNKS + DB::CHUNKS;
-    static_assert(G <= 60, "vmcnt is a 6-bit counter");
-    if (!is_cons) {
-      if (nkt > 0) {
-        DA::issue(smem, p.A, p.lda, m0, p.M, kz0, k_end, lane);
-        DB::issue(smem + BM * BK, p.B, p.ldb, n0, p.N, kz0, k_end, lane);
-        if (nkt > 1) {
-          DA::issue(smem + RING, p.A, p.lda, m0, p.M, kz0 + BK, k_end, lane);
-          DB::issue(smem + RING + BM * BK, p.B, p.ldb, n0, p.N, kz0 + BK, k_end, lane);
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-      }
-      int st_nn = 2;                                 // (kt + 2) % 3
-      for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = (kt + 1 < nkt), more2 = (kt + 2 < nkt);
-        if (more2) {
-          const int k0 = kz0 + (kt + 2) * BK;
-          DA::issue(smem + st_nn * RING, p.A, p.lda, m0, p.M, k0, k_end, lane);
-          DB::issue(smem + st_nn * RING + BM * BK, p.B, p.ldb, n0, p.N, k0, k_end, lane);
-        }
-        if (more) {
-          if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-        }
-        st_nn = (st_nn == 2) ? 0 : st_nn + 1;
-      }
-    } else {
-      float fa[2][TM][4], fb[2][TN][4];
-      if (nkt > 0) {
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        read_frags_dma<LA, BM, TM>(fa[0], smem, wm * (TM * 32), 0, lane);
-        read_frags_dma<LB, BN, TN>(fb[0], smem + BM * BK, wn * (TN * 32), 0, lane);
-      }
-      int st_cur = 0;
-      for (int kt = 0; kt < nkt; ++kt) {
-        const int st_nxt = (st_cur == 2) ? 0 : st_cur + 1;
-        const float* sA = smem + st_cur * RING;
-        const float* sB = sA + BM * BK;
-        const float* nA = smem + st_nxt * RING;
-        const bool more = (kt + 1 < nkt);
-#pragma unroll
-        for (int s = 0; s < BK / 8; ++s) {
-          const int cur = s & 1, nxt = cur ^ 1;
-          if (s < BK / 8 - 1) {
-            read_frags_dma<LA, BM, TM>(fa[nxt], sA, wm * (TM * 32), s + 1, lane);
-            read_frags_dma<LB, BN, TN>(fb[nxt], sB, wn * (TN * 32), s + 1, lane);
-          } else if (more) {
-            read_frags_dma<LA, BM, TM>(fa[nxt], nA, wm * (TM * 32), 0, lane);
-            read_frags_dma<LB, BN, TN>(fb[nxt], nA + BM * BK, wn * (TN * 32), 0, lane);
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int jn = 0; jn < TN; ++jn)
-                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][j], fb[cur][jn][j],
-                                                                  acc[i][jn], 0, 0, 0);
-          if (s == BK / 8 - 2 && more) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-          }
-        }
-        st_cur = st_nxt;
-      }
-    }
-    __syncthreads();
-  } else if (PIPE >= 2) {
-    // LDS-DMA pipeline (PIPE 2: builtin DMA; PIPE 3: DMA issued from inline asm): a 3-stage ring of unpadded tiles filled by global_load_lds (no VGPR
+  if (PIPE == 3) {
+    // LDS-DMA pipeline: a 3-stage ring of unpadded tiles filled by global_load_lds (no VGPR
     // staging, no ds_write); tile kt+2 is in flight while tile kt is multiplied.  One raw
     // s_barrier per K tile, behind a COUNTED vmcnt that retires only tile kt+1's DMAs (a
     // __syncthreads() would drain the ring) and lgkmcnt(0) (this wave's reads of the stage
     // that the next iteration's DMA overwrites are complete).
-    using DA = TileDMA<LA, BM, NT, false>;
-    using DB = TileDMA<LB, BN, NT, false>;
     DmaPlan<LA, BM, NT> planA;
     DmaPlan<LB, BN, NT> planB;
     const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) float*)smem);
-    if (PIPE == 3) {
-      planA.init(p.A, p.lda, m0, p.M, kz0, k_end, tid);
-      planB.init(p.B, p.ldb, n0, p.N, kz0, k_end, tid);
-    }
+    planA.init(p.A, p.lda, m0, p.M, kz0, k_end, tid);
+    planB.init(p.B, p.ldb, n0, p.N, kz0, k_end, tid);
     constexpr int RING = (BM + BN) * BK;          // floats per stage
-    constexpr int G = DA::CHUNKS + DB::CHUNKS;    // DMA instructions per thread per tile
+    constexpr int G = DmaPlan<LA, BM, NT>::CHUNKS + DmaPlan<LB, BN, NT>::CHUNKS;   // DMAs per thread per tile
     float fa[2][TM][4], fb[2][TN][4];
     if (nkt > 0) {
-      if (PIPE == 3) {
-        planA.issue(lds0, kz0, k_end);
-        planB.issue(lds0 + BM * BK * 4, kz0, k_end);
-      } else {
-        DA::issue(smem, p.A, p.lda, m0, p.M, kz0, k_end, tid);
-        DB::issue(smem + BM * BK, p.B, p.ldb, n0, p.N, kz0, k_end, tid);
-      }
+      planA.issue(lds0, kz0, k_end);
+      planB.issue(lds0 + BM * BK * 4, kz0, k_end);
       if (nkt > 1) {
-        if (PIPE == 3) {
-          planA.issue(lds0 + RING * 4, kz0 + BK, k_end);
-          planB.issue(lds0 + (RING + BM * BK) * 4, kz0 + BK, k_end);
-        } else {
-          DA::issue(smem + RING, p.A, p.lda, m0, p.M, kz0 + BK, k_end, tid);
-          DB::issue(smem + RING + BM * BK, p.B, p.ldb, n0, p.N, kz0 + BK, k_end, tid);
-        }
+        planA.issue(lds0 + RING * 4, kz0 + BK, k_end);
+        planB.issue(lds0 + (RING + BM * BK) * 4, kz0 + BK, k_end);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -450,19 +306,12 @@ __global__ __launch_bounds__(64 * WM * WN + (PIPE == 4 ? 64 : 0)) void gemm_f32_
       const float* sB = sA + BM * BK;
       const float* nA = smem + st_nxt * RING;
       const bool more = (kt + 1 < nkt), more2 = (kt + 2 < nkt);
-      constexpr bool SPREAD = (PIPE == 3) && (ABLATE & 8) && DmaPlan<LA, BM, NT>::CHUNKS <= 2 &&
-                              DmaPlan<LB, BN, NT>::CHUNKS <= 2;
-      const int k2 = kz0 + (kt + 2) * BK;
-      const uint32_t ldsA2 = lds0 + st_nn * (RING * 4), ldsB2 = ldsA2 + BM * BK * 4;
-      if (more2 && !SPREAD) {
+      if (more2) {
+        // (spreading these DMAs between the MFMAs of groups 0/1 instead of issuing them here
+        //  was measured and changes nothing: 72.1 vs 72.3 us)
         const int k0 = kz0 + (kt + 2) * BK;
-        if (PIPE == 3) {
-          planA.issue(lds0 + st_nn * (RING * 4), k0, k_end);
-          planB.issue(lds0 + st_nn * (RING * 4) + BM * BK * 4, k0, k_end);
-        } else {
-          DA::issue(smem + st_nn * RING, p.A, p.lda, m0, p.M, k0, k_end, tid);
-          DB::issue(smem + st_nn * RING + BM * BK, p.B, p.ldb, n0, p.N, k0, k_end, tid);
-        }
+        planA.issue(lds0 + st_nn * (RING * 4), k0, k_end);
+        planB.issue(lds0 + st_nn * (RING * 4) + BM * BK * 4, k0, k_end);
       }
 #pragma unroll
       for (int s = 0; s < BK / 8; ++s) {
@@ -475,20 +324,13 @@ __global__ __launch_bounds__(64 * WM * WN + (PIPE == 4 ? 64 : 0)) void gemm_f32_
           read_frags_dma<LB, BN, TN>(fb[nxt], nA + BM * BK, wn * (TN * 32), 0, lane);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn)
               acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][j], fb[cur][jn][j],
                                                                 acc[i][jn], 0, 0, 0);
-          if (SPREAD && more2) {   // one DMA behind every second MFMA pair of groups 0 and 1
-            if (s == 0 && j == 0) planA.template issue_chunk<0>(ldsA2, k2, k_end);
-            if (s == 0 && j == 2) planA.template issue_chunk<1>(ldsA2, k2, k_end);
-            if (s == 1 && j == 0) planB.template issue_chunk<0>(ldsB2, k2, k_end);
-            if (s == 1 && j == 2) planB.template issue_chunk<1>(ldsB2, k2, k_end);
-          }
-        }
         if (s == BK / 8 - 2 && more) {
           if (more2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
           else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -499,38 +341,6 @@ __global__ __launch_bounds__(64 * WM * WN + (PIPE == 4 ? 64 : 0)) void gemm_f32_
       st_cur = st_nxt;
     }
     __syncthreads();
-  } else if (PIPE == 0) {
-    // reference structure (kept for A/B timing in tools/gemm_bench): fragments are read
-    // group by group in front of their MFMAs, one barrier at the end of the K tile
-    for (int kt = 0; kt < nkt; ++kt) {
-      const float* sA = smem + (kt & 1) * STAGE;
-      const float* sB = sA + A_FLOATS;
-      const bool more = (kt + 1 < nkt);
-      if (more) {
-        const int k0 = kz0 + (kt + 1) * BK;
-        IOA::load(ra, p.A, p.lda, m0, p.M, k0, k_end, tid);
-        IOB::load(rb, p.B, p.ldb, n0, p.N, k0, k_end, tid);
-      }
-#pragma unroll
-      for (int s = 0; s < BK / 8; ++s) {
-        float fa[TM][4], fb[TN][4];
-        read_frags<LA, BM, TM>(fa, sA, wm * (TM * 32), s, lane);
-        read_frags<LB, BN, TN>(fb, sB, wn * (TN * 32), s, lane);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn)
-              acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[jn][j], acc[i][jn], 0, 0, 0);
-        if (s == 1 && more) {
-          float* dA = smem + ((kt + 1) & 1) * STAGE;
-          IOA::store(ra, dA, tid);
-          IOB::store(rb, dA + A_FLOATS, tid);
-        }
-      }
-      __syncthreads();
-    }
   } else {
     // Software-pipelined main loop.  The fragments of k-group s+1 are read from LDS while the
     // MFMAs of group s execute (two register sets, static indices), so a wave never waits on
@@ -588,7 +398,7 @@ __global__ __launch_bounds__(64 * WM * WN + (PIPE == 4 ? 64 : 0)) void gemm_f32_
     }
   }
   // ------------------------------------------------------------- epilogue --
-  gemm_epilogue<BM, BN, WM, WN, EPI>(acc, p, C, smem, m0, n0, tile_m, is_cons);
+  gemm_epilogue<BM, BN, WM, WN, EPI>(acc, p, C, smem, m0, n0, tile_m, true);
   if (STAMP) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long r2 = __builtin_amdgcn_s_memrealtime();
