@@ -33,8 +33,7 @@ enum Epilogue : int {
   EPI_STORE = 0,       // C = acc                         (split-K slabs, plain)
   EPI_BIAS = 1,        // C = acc + bias[n]
   EPI_BIAS_STATS = 2,  // C = acc + bias[n]; per-tile column (mean, M2) partials
-  EPI_ADD = 3,         // C = acc + addend[m][n]
-  EPI_MSE = 4          // C = acc + bias; dpred = scale*(C - target); loss partial
+  EPI_ADD = 3          // C = acc + addend[m][n]
 };
 
 struct GemmParams {
@@ -49,12 +48,7 @@ struct GemmParams {
   const float* addend;      // [M][ldadd]
   int64_t ldadd;
   float* stat_part;         // [tiles_m][2][N]  (mean, M2) of each BM-row tile
-  const float* target;      // [M][ldt]
-  int64_t ldt;
-  float* dpred;             // [M][lddp]
-  int64_t lddp;
-  float mse_scale;
-  float* loss_part;         // [gridDim.x] partial sums of squared error
+  float* loss_part;         // diagnostic builds only: STAMP output (tools/gemm_bench)
 };
 
 enum GemmTile : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_128x32 = 3 };

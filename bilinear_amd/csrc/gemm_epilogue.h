@@ -1,7 +1,7 @@
 // Shared epilogue of the MFMA GEMM kernels (fp32 accumulators of 32x32 MFMA tiles; the C/D
 // register layout is the same for the f32 and bf16 MFMA shapes on gfx950):
-//   EPI_STORE / EPI_BIAS / EPI_ADD, EPI_BIAS_STATS (per-128-row-tile BatchNorm partials),
-//   EPI_MSE (fused decode + loss).  See gemm_f32_kernel.h for the contractions it serves.
+//   EPI_STORE / EPI_BIAS / EPI_ADD, EPI_BIAS_STATS (per-128-row-tile BatchNorm partials).
+//   See gemm_f32_kernel.h for the contractions it serves.
 #pragma once
 #include "common.h"
 
@@ -20,7 +20,7 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], 
   const int row_w = m0 + wm * (TM * 32) + 4 * h;   // + tm*32 + (r&3) + 8*(r>>2)
   const int col_w = n0 + wn * (TN * 32) + lc;      // + tn*32
 
-  if (EPI == EPI_BIAS || EPI == EPI_BIAS_STATS || EPI == EPI_MSE) {
+  if (EPI == EPI_BIAS || EPI == EPI_BIAS_STATS) {
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
       const int col = col_w + jn * 32;
@@ -91,7 +91,6 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], 
     }
   }
 
-  float lsum = 0.f;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -104,28 +103,9 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], 
           float v = acc[i][jn][r];
           if (EPI == EPI_ADD) v += p.addend[(int64_t)row * p.ldadd + col];
           C[(int64_t)row * p.ldc + col] = v;
-          if (EPI == EPI_MSE) {
-            const float d = v - p.target[(int64_t)row * p.ldt + col];
-            p.dpred[(int64_t)row * p.lddp + col] = d * p.mse_scale;
-            lsum += d * d;
-          }
         }
       }
     }
-
-  if (EPI == EPI_MSE) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) lsum += __shfl_xor(lsum, o);
-    float* red = smem;
-    __syncthreads();
-    if (lane == 0 && is_cons) red[wave] = lsum;
-    __syncthreads();
-    if (tid == 0) {
-      float t = 0.f;
-      for (int w = 0; w < WM * WN; ++w) t += red[w];
-      p.loss_part[blockIdx.x] = t;
-    }
-  }
 }
 
 }  // namespace blh

@@ -50,7 +50,6 @@ static int launch_128x128(hipStream_t s, int la, int lb, int epi, const GemmPara
   return BLH_ERR_INVALID_ARGUMENT;
 }
 static int launch_128x64(hipStream_t s, int la, int lb, int epi, const GemmParams& p, int splits) {
-  BLH_CASE(128, 64, 2, 2, ROWK, ROWK, EPI_MSE)           // decode forward + MSE
   BLH_CASE(128, 64, 2, 2, ROWK, ROWK, EPI_BIAS)          // decode forward
   BLH_CASE(128, 64, 2, 2, ROWK, ROWK, EPI_STORE)
   BLH_CASE(128, 64, 2, 2, ROWK, KROW, EPI_STORE)

@@ -2,7 +2,7 @@
 """Summarise a rocprofv3 --kernel-trace --stats CSV (per-kernel calls / avg / share)."""
 import csv, glob, sys
 d = sys.argv[1]
-f = glob.glob(d + '/*/*_kernel_stats.csv')[0]
+f = (glob.glob(d + '/*/*_kernel_stats.csv') + glob.glob(d + '/*_kernel_stats.csv'))[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 print("total GPU time %.1f ms" % (tot / 1e6))
