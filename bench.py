@@ -60,7 +60,7 @@ def gemm_rooflines(batch, width, reps, dtype="fp32"):
     """Live timings of the three Linear contractions at the hidden-layer shape."""
     from bilinear_amd import _native as N
     lib = N.lib()
-    gemm = lib.blh_gemm_bf16 if dtype == "bf16" else lib.blh_gemm_f32
+    gemm = {"bf16": lib.blh_gemm_bf16, "bf16x3": lib.blh_gemm_bf16x3}.get(dtype, lib.blh_gemm_f32)
     dev = torch.device("cuda", torch.cuda.current_device())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     A = torch.randn(batch, width, device=dev)
@@ -74,7 +74,7 @@ def gemm_rooflines(batch, width, reps, dtype="fp32"):
     out = {}
 
     def fwd():
-        if dtype == "bf16":
+        if dtype != "fp32":
             N.check(gemm(st, A.data_ptr(), width, 0, Wt.data_ptr(), width, 0, Z.data_ptr(), width,
                          batch, width, width, 1, bias.data_ptr(), None, 0), "fwd")
         else:
@@ -123,6 +123,18 @@ def roofline_block(args, dom):
             "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json)",
             "avg_launch_ms": dom["ms"], "flop_per_launch": flop,
         }
+    if args.dtype == "bf16x3":
+        # fp32 product from six bf16 MFMAs: priced against the bf16 MFMA peak / 6
+        peak = BF16_MFMA_PEAK_TFLOPS / 6.0
+        return {
+            "kernel": "gemm_split_kernel<128,128,2,2,ROWK,ROWK,BIAS> (Linear %dx%d forward, M=%d; "
+                      "operands split into 3 bf16 pieces, 6 bf16 MFMAs per product)" % (
+                          args.width, args.width, args.batch),
+            "bound": "mfma", "achieved": dom["tflops"], "peak": peak,
+            "unit": "TFLOP/s (fp32-equivalent = bf16 MFMA TFLOP/s / 6)", "frac": dom["tflops"] / peak,
+            "traffic": None, "avg_launch_ms": dom["ms"], "flop_per_launch": flop,
+            "bf16_mfma_tflops_executed": 6.0 * dom["tflops"],
+        }
     # mixed mode keeps fp32 tensors in memory: the bf16 MFMA (2.5 PF) is fed at most at the
     # memory rate, so the kernel is priced against HBM with its algorithmic bytes A + W + Z
     alg = 4.0 * (args.batch * args.width * 2 + args.width * args.width)
@@ -168,7 +180,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=2)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
+    ap.add_argument("--dtype", choices=["fp32", "bf16", "bf16x3"], default="fp32",
                     help="GEMM arithmetic: fp32 MFMA (BASELINE configs[1], default) or bf16 MFMA "
                          "inputs with fp32 accumulation and fp32 storage (configs 3-5)")
     ap.add_argument("--sync-bn", action="store_true",
@@ -266,7 +278,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "fp32" else "bf16 (MFMA inputs; fp32 accumulate and storage)",
+            "dtype": {"fp32": "f32", "bf16x3": "f32 (operands split into 3 bf16 pieces, bf16 MFMA, fp32 accumulate)",
+                      "bf16": "bf16 (MFMA inputs; fp32 accumulate and storage)"}[args.dtype],
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[1]: %d-block width %d, batch %d per GPU, fp32, "

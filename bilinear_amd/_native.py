@@ -99,6 +99,9 @@ _SIGNATURES = {
     "blh_gemm_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
                               c_void_p, c_int64, c_int64, c_int64, c_int64, c_int32, c_void_p,
                               c_void_p, c_int64]),
+    "blh_gemm_bf16x3": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
+                                c_void_p, c_int64, c_int64, c_int64, c_int64, c_int32, c_void_p,
+                                c_void_p, c_int64]),
     "blh_sum_slabs": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "blh_linear_fwd_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int64, c_int64, c_int64]),

@@ -40,7 +40,7 @@ static int check_desc(const blh_model_desc* d) {
     return BLH_ERR_SHAPE;
   if (d->out_features > 64) return BLH_ERR_SHAPE;   // decode uses one 64-wide column tile
   if (1 + 2 * d->num_blocks > 32) return BLH_ERR_SHAPE;
-  if (d->gemm_dtype != 0 && d->gemm_dtype != 1) return BLH_ERR_INVALID_ARGUMENT;
+  if (d->gemm_dtype < 0 || d->gemm_dtype > 2) return BLH_ERR_INVALID_ARGUMENT;
   return BLH_OK;
 }
 
@@ -871,7 +871,7 @@ static int gemm_entry(int dtype, void* stream, const float* A, int64_t lda, int3
   GemmTile tile = TILE_128x128;
   if (N <= 32) tile = TILE_128x32;
   else if (N <= 64) tile = TILE_128x64;
-  else if (M <= 64 && (dtype == 0 || (a_kmajor && b_kmajor))) tile = TILE_64x128;
+  else if (M <= 64 && (dtype != 1 || (a_kmajor && b_kmajor))) tile = TILE_64x128;
   return launch_gemm((hipStream_t)stream, tile, a_kmajor ? KROW : ROWK, b_kmajor ? KROW : ROWK,
                      epi, g, splits, dtype);
 }
@@ -889,6 +889,14 @@ int blh_gemm_bf16(void* stream, const float* A, int64_t lda, int32_t a_kmajor, c
                   int64_t K, int32_t splits, const float* bias, const float* addend,
                   int64_t ldadd) {
   return gemm_entry(1, stream, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, splits, bias,
+                    addend, ldadd);
+}
+
+int blh_gemm_bf16x3(void* stream, const float* A, int64_t lda, int32_t a_kmajor, const float* B,
+                    int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc, int64_t M, int64_t N,
+                    int64_t K, int32_t splits, const float* bias, const float* addend,
+                    int64_t ldadd) {
+  return gemm_entry(2, stream, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, splits, bias,
                     addend, ldadd);
 }
 

@@ -3,6 +3,7 @@
 
 #include "gemm_bf16_kernel.h"
 #include "gemm_f32_kernel.h"
+#include "gemm_split_kernel.h"
 
 namespace blh {
 
@@ -120,6 +121,40 @@ static int launch_bf16(hipStream_t s, GemmTile tile, int la, int lb, int epi, co
 }
 #undef BLH_CASE16
 
+// ---- bf16x3 split instantiations (gemm_dtype = 2: fp32 accuracy on the bf16 matrix cores) ---
+template <int LA, int LB, int EPI>
+static int launch_cfg_split(hipStream_t s, const GemmParams& p, int splits) {
+  constexpr size_t lds = gemm_split_lds_bytes<128, 128>();
+  static bool attr_set = false;
+  auto kern = gemm_split_kernel<128, 128, 2, 2, LA, LB, EPI>;
+  if (!attr_set) {
+    BLH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int tiles = (int)(ceil_div(p.M, 128) * ceil_div(p.N, 128));
+  hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(256), lds, s, p);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+#define BLH_CASE3(LA_, LB_, EPI_) \
+  if (la == LA_ && lb == LB_ && epi == EPI_) return launch_cfg_split<LA_, LB_, EPI_>(s, p, splits);
+
+// Only the 128x128 tile exists in split form (the 1024-wide Linears, 98 % of the FLOPs); the
+// skinny encode / decode contractions of this mode run on the exact-fp32 MFMA kernels.
+static int launch_split_128x128(hipStream_t s, int la, int lb, int epi, const GemmParams& p,
+                                int splits) {
+  BLH_CASE3(ROWK, ROWK, EPI_BIAS_STATS)
+  BLH_CASE3(ROWK, ROWK, EPI_BIAS)
+  BLH_CASE3(ROWK, ROWK, EPI_STORE)
+  BLH_CASE3(ROWK, KROW, EPI_STORE)
+  BLH_CASE3(ROWK, KROW, EPI_ADD)
+  BLH_CASE3(KROW, KROW, EPI_STORE)
+  return BLH_ERR_INVALID_ARGUMENT;
+}
+#undef BLH_CASE3
+
 int gemm_stat_tile_rows(GemmTile tile) { return tile == TILE_64x128 ? 64 : 128; }
 
 int gemm_grid_blocks(GemmTile tile, int M, int N) {
@@ -140,6 +175,10 @@ int launch_gemm(hipStream_t s, GemmTile tile, int la, int lb, int epi, const Gem
   if (lb == KROW && p.N % 4 != 0) return BLH_ERR_SHAPE;
   if (splits > 1 && (p.k_per_split % BK != 0)) return BLH_ERR_SHAPE;
   if (dtype == 1) return launch_bf16(s, tile, la, lb, epi, p, splits);
+  if (dtype == 2 && tile == TILE_128x128) {   // combinations not built in split form: exact fp32
+    const int rc = launch_split_128x128(s, la, lb, epi, p, splits);
+    if (rc != BLH_ERR_INVALID_ARGUMENT) return rc;
+  }
   switch (tile) {
     case TILE_128x128: return launch_128x128(s, la, lb, epi, p, splits);
     case TILE_128x64: return launch_128x64(s, la, lb, epi, p, splits);

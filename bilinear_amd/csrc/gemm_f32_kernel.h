@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmParams p) {
       const float* sB = sA + BM * BK;
       const float* nA = smem + st_nxt * RING;
       const bool more = (kt + 1 < nkt), more2 = (kt + 2 < nkt);
-      if (more2) {
+      if (more2 && !(ABLATE & 8)) {   // ABLATE: timing-only diagnostic builds (wrong results)
         // (spreading these DMAs between the MFMAs of groups 0/1 instead of issuing them here
         //  was measured and changes nothing: 72.1 vs 72.3 us)
         const int k0 = kz0 + (kt + 2) * BK;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmParams p) {
             for (int jn = 0; jn < TN; ++jn)
               acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][j], fb[cur][jn][j],
                                                                 acc[i][jn], 0, 0, 0);
-        if (s == BK / 8 - 2 && more) {
+        if (s == BK / 8 - 2 && more && !(ABLATE & 16)) {
           if (more2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
           else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();

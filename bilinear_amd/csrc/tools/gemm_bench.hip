@@ -143,6 +143,9 @@ int main(int argc, char** argv) {
       printf("  ablate %-34s %.1f us\n", name, ms / 500 * 1e3);
     };
     abl("PIPE 3 (shipped)", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 3, 0, 0>);
+    abl("PIPE 3 no in-loop DMA", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 3, 0, 8>);
+    abl("PIPE 3 no wait/barrier", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 3, 0, 16>);
+    abl("PIPE 3 no DMA, no wait/barrier", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 3, 0, 24>);
     abl("none", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 1, 0, 0>);
     abl("no global loads", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 1, 0, 1>);
     abl("no ds_write (loads unused)", gemm_f32_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 1, 0, 2>);

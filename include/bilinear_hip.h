@@ -67,7 +67,13 @@ typedef struct {
   int32_t gemm_dtype;   /* 0: exact fp32 MFMA (the reference's arithmetic);
                            1: "mixed" — every tensor stays fp32 in memory, GEMM operands are
                               rounded to bf16 on load and multiplied on bf16 MFMA with fp32
-                              accumulation (BASELINE configs 3-5)                  */
+                              accumulation (BASELINE configs 3-5);
+                           2: "bf16x3" — fp32 accuracy on the bf16 matrix cores: every operand
+                              value is split exactly into three bf16 pieces on load and the
+                              product is accumulated in fp32 from six bf16 MFMAs (the dropped
+                              terms are below 2^-25 |a b|, under the rounding of an fp32
+                              multiply); the 1024-wide Linears only, the skinny contractions
+                              stay on the exact fp32 MFMA                              */
 } blh_model_desc;
 
 /* Number of heavy_linear stages = 1 + 2*num_blocks (encode + hidden). */
@@ -270,6 +276,13 @@ int blh_gemm_bf16(void* stream, const float* A, int64_t lda, int32_t a_kmajor, c
                   int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc, int64_t M, int64_t N,
                   int64_t K, int32_t splits, const float* bias, const float* addend,
                   int64_t ldadd);
+/* Same contraction in gemm_dtype = 2 arithmetic (three-way bf16 split of both operands, six bf16
+ * MFMAs per product, fp32 accumulate).  Shapes the 128x128 split kernel does not cover (N <= 64,
+ * or M <= 64) run on the exact fp32 kernel.                                                    */
+int blh_gemm_bf16x3(void* stream, const float* A, int64_t lda, int32_t a_kmajor, const float* B,
+                    int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc, int64_t M, int64_t N,
+                    int64_t K, int32_t splits, const float* bias, const float* addend,
+                    int64_t ldadd);
 int blh_sum_slabs(void* stream, const float* slabs, int64_t count, int32_t splits, float* out);
 /* The forward kernel of one heavy_linear exactly as blh_forward_train launches it:
  * Z[M,N] = A[M,K] W[N,K]^T + bias, plus per-128-row-tile column statistics

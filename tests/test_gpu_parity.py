@@ -58,8 +58,11 @@ GEMM_CASES = [
 ]
 
 
+@pytest.mark.parametrize("entry", ["blh_gemm_f32", "blh_gemm_bf16x3"])
 @pytest.mark.parametrize("M,N,K,ak,bk,splits", GEMM_CASES)
-def test_gemm_f32_layouts(native, M, N, K, ak, bk, splits):
+def test_gemm_f32_layouts(native, M, N, K, ak, bk, splits, entry):
+    """Both fp32-accurate GEMMs (exact fp32 MFMA; three-way bf16 split on the bf16 MFMA) against
+    the fp64 product, same tolerance."""
     dev = _dev()
     rng = np.random.RandomState(M + 3 * N + 7 * K)
     # asymmetric, non-trivial operands (a transposed output or a swapped fragment map shows)
@@ -70,8 +73,8 @@ def test_gemm_f32_layouts(native, M, N, K, ak, bk, splits):
     a, b = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
     c = torch.full((splits, M, N), float("nan"), device=dev)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    rc = native.blh_gemm_f32(st, a.data_ptr(), A.shape[1], ak, b.data_ptr(), B.shape[1], bk,
-                             c.data_ptr(), N, M, N, K, splits, None, None, 0)
+    rc = getattr(native, entry)(st, a.data_ptr(), A.shape[1], ak, b.data_ptr(), B.shape[1], bk,
+                                c.data_ptr(), N, M, N, K, splits, None, None, 0)
     assert rc == 0, native.blh_status_string(rc)
     if splits > 1:
         out = torch.empty(M, N, device=dev)
@@ -83,7 +86,40 @@ def test_gemm_f32_layouts(native, M, N, K, ak, bk, splits):
     _close(out.cpu().numpy(), ref, 2e-5, "gemm")
 
 
-def test_gemm_bias_and_addend(native):
+@pytest.mark.parametrize("M,N,K,ak,bk,splits", [(512, 1024, 1024, 0, 0, 1), (384, 1024, 1024, 0, 1, 1),
+                                                (1024, 1024, 4096, 1, 1, 4)])
+def test_bf16x3_gemm_error_is_fp32_level(native, M, N, K, ak, bk, splits):
+    """gemm_dtype = 2 claims fp32 accuracy: its error against the fp64 product, measured on the
+    scale sum_k |a b| that bounds an fp32 dot product, must not exceed the exact-fp32 MFMA
+    kernel's on operands with a wide dynamic range (1.5x slack for sampling noise)."""
+    dev = _dev()
+    rng = np.random.RandomState(K + M)
+    shape_a, shape_b = ((K, M) if ak else (M, K)), ((K, N) if bk else (N, K))
+    A = (rng.standard_normal(shape_a) * np.exp(2.0 * rng.standard_normal(shape_a))).astype(np.float32)
+    B = (rng.standard_normal(shape_b) * 0.05).astype(np.float32)
+    A64, B64 = (A.T if ak else A).astype(np.float64), (B if bk else B.T).astype(np.float64)
+    ref, mag = A64 @ B64, np.abs(A64) @ np.abs(B64)
+    a, b = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    errs = {}
+    for entry in ("blh_gemm_f32", "blh_gemm_bf16x3"):
+        c = torch.full((splits, M, N), float("nan"), device=dev)
+        rc = getattr(native, entry)(st, a.data_ptr(), A.shape[1], ak, b.data_ptr(), B.shape[1], bk,
+                                    c.data_ptr(), N, M, N, K, splits, None, None, 0)
+        assert rc == 0, native.blh_status_string(rc)
+        torch.cuda.synchronize()
+        out = c.cpu().numpy().astype(np.float64).sum(axis=0)
+        rel = np.abs(out - ref) / mag
+        errs[entry] = (rel.max(), np.sqrt((rel ** 2).mean()))
+    print("err / sum|ab|  fp32 MFMA: max %.2e rms %.2e | bf16x3: max %.2e rms %.2e" % (
+        errs["blh_gemm_f32"] + errs["blh_gemm_bf16x3"]))
+    assert errs["blh_gemm_bf16x3"][1] <= 1.5 * errs["blh_gemm_f32"][1]
+    assert errs["blh_gemm_bf16x3"][0] <= 1.5 * errs["blh_gemm_f32"][0] + 1e-7
+    assert errs["blh_gemm_bf16x3"][0] < 2e-6          # a dropped middle product would show as ~1e-5
+
+
+@pytest.mark.parametrize("entry", ["blh_gemm_f32", "blh_gemm_bf16x3"])
+def test_gemm_bias_and_addend(native, entry):
     dev = _dev()
     rng = np.random.RandomState(5)
     M, N, K = 260, 384, 96
@@ -95,14 +131,14 @@ def test_gemm_bias_and_addend(native):
     bt, at = torch.from_numpy(bias).to(dev), torch.from_numpy(add).to(dev)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     c = torch.empty(M, N, device=dev)
-    assert native.blh_gemm_f32(st, a.data_ptr(), K, 0, w.data_ptr(), K, 0, c.data_ptr(), N, M, N, K,
+    assert getattr(native, entry)(st, a.data_ptr(), K, 0, w.data_ptr(), K, 0, c.data_ptr(), N, M, N, K,
                                1, bt.data_ptr(), None, 0) == 0
     torch.cuda.synchronize()
     _close(c.cpu().numpy(), A.astype(np.float64) @ Wt.T.astype(np.float64) + bias, 2e-5, "bias")
     # dgrad-with-residual form: C = A * B[K,N] + addend, in place on the addend buffer
     Bk = rng.standard_normal((K, N)).astype(np.float32)
     bk = torch.from_numpy(Bk).to(dev)
-    assert native.blh_gemm_f32(st, a.data_ptr(), K, 0, bk.data_ptr(), N, 1, at.data_ptr(), N, M, N, K,
+    assert getattr(native, entry)(st, a.data_ptr(), K, 0, bk.data_ptr(), N, 1, at.data_ptr(), N, M, N, K,
                                1, None, at.data_ptr(), N) == 0
     torch.cuda.synchronize()
     _close(at.cpu().numpy(), A.astype(np.float64) @ Bk.astype(np.float64) + add, 2e-5, "addend")
@@ -111,9 +147,12 @@ def test_gemm_bias_and_addend(native):
 # ----------------------------------------------------------------------------
 # module level against the reference's golden vectors
 # ----------------------------------------------------------------------------
-def _build(g, dev, num_blocks=2, width=1024, state=None):
+FP32_MODES = ["fp32", "bf16x3"]     # the two fp32-accurate GEMM paths: same tests, same tolerances
+
+
+def _build(g, dev, num_blocks=2, width=1024, state=None, gemm_dtype="fp32"):
     import bilinear_amd
-    net = bilinear_amd.BilinearUnit(num_blocks=num_blocks, width=width)
+    net = bilinear_amd.BilinearUnit(num_blocks=num_blocks, width=width, gemm_dtype=gemm_dtype)
     st = state if state is not None else g.init_state()
     sd = net.state_dict()
     assert list(sd.keys()) == list(st.keys())
@@ -152,14 +191,15 @@ def _compare_step(g, s, net, opt, raw, clipped, pred, loss, total_norm, rtol):
     return worst
 
 
+@pytest.mark.parametrize("mode", FP32_MODES)
 @pytest.mark.parametrize("fname", FIXTURES)
-def test_dropin_steps_match_reference(fname):
+def test_dropin_steps_match_reference(fname, mode):
     """The reference's own step body (train_bilinear.py:66-83) on the drop-in surface:
     zero_grad, forward, nn.MSELoss, backward, clip_grad_norm_, Adam.step."""
     import bilinear_amd
     dev = _dev()
     g = Golden(fname)
-    net, opt = _build(g, dev)
+    net, opt = _build(g, dev, gemm_dtype=mode)
     criterion = torch.nn.MSELoss()
     step = 1
     for s in range(g.steps):
@@ -188,12 +228,13 @@ def test_dropin_steps_match_reference(fname):
     assert np.abs(pe.cpu().numpy() - ref).max() <= 5e-3 * np.sqrt((ref ** 2).mean()) + 5e-3
 
 
+@pytest.mark.parametrize("mode", FP32_MODES)
 @pytest.mark.parametrize("fname", FIXTURES)
-def test_fused_train_step_matches_reference(fname):
+def test_fused_train_step_matches_reference(fname, mode):
     """The same steps through the one-enqueue fast path (blh_train_step)."""
     dev = _dev()
     g = Golden(fname)
-    net, opt = _build(g, dev)
+    net, opt = _build(g, dev, gemm_dtype=mode)
     step = 1
     for s in range(g.steps):
         x, t = g.batch_xy(s)
@@ -232,8 +273,10 @@ def test_eval_forward_matches_oracle():
 # ----------------------------------------------------------------------------
 # other shapes against the oracle (the reference cannot express them)
 # ----------------------------------------------------------------------------
-@pytest.mark.parametrize("nb,width,batch", [(1, 256, 100), (3, 512, 257), (2, 1024, 30), (0, 128, 64)])
-def test_general_shapes_against_oracle(nb, width, batch):
+@pytest.mark.parametrize("mode", FP32_MODES)
+@pytest.mark.parametrize("nb,width,batch", [(1, 256, 100), (3, 512, 257), (2, 1024, 30), (0, 128, 64),
+                                            (2, 1024, 640)])
+def test_general_shapes_against_oracle(nb, width, batch, mode):
     dev = _dev()
     st = O.init_state(100 + nb, nb, width)
     rng = np.random.RandomState(nb * 7 + 1)
@@ -242,7 +285,7 @@ def test_general_shapes_against_oracle(nb, width, batch):
             st[k] = (1.0 + 0.2 * rng.standard_normal(st[k].shape)).astype(np.float32)
         if k.endswith(".1.bias"):
             st[k] = (0.1 * rng.standard_normal(st[k].shape)).astype(np.float32)
-    net, opt = _build(None, dev, nb, width, state={k: v.copy() for k, v in st.items()})
+    net, opt = _build(None, dev, nb, width, state={k: v.copy() for k, v in st.items()}, gemm_dtype=mode)
     x, t = O.synthetic_batch(5, batch)
     masks = O.random_masks(9, batch, nb, width)
     net.engine.set_dropout_masks(masks)
