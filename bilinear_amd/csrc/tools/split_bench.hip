@@ -3,10 +3,12 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "../gemm_split_kernel.h"
 #include "../gemm_splitr_kernel.h"
 #include "../gemm_split8_kernel.h"
+#include "../gemm_splitw_kernel.h"
 using namespace blh;
 thread_local int blh::g_last_hip_error = 0;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
@@ -127,6 +129,29 @@ int main(int argc, char** argv) {
     printf("K loop: %.0f shader cycles, %.2f us -> clock %.3f GHz; per MFMA slot %.1f cycles (ideal 32)\n", cyc, rt / 100.0, cyc / (rt * 10.0), cyc / (M ? (W / 16.0 * 24.0) : 1));
   }
 #endif
+  {  // pre-split weight planes (host-side split), forward + transposed, and the planes kernel
+    auto bf = [](float x) { uint32_t u; memcpy(&u, &x, 4); uint32_t r = u + 0x7fff + ((u >> 16) & 1); return (uint16_t)(r >> 16); };
+    auto fl = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+    std::vector<uint16_t> pl((size_t)6 * W * W);
+    for (size_t i = 0; i < (size_t)W * W; ++i) {
+      float x = hb[i]; uint16_t h = bf(x); float r = x - fl(h); uint16_t m = bf(r); float q = r - fl(m); uint16_t l = bf(q);
+      const size_t n = i / W, k = i % W;
+      pl[i] = h; pl[(size_t)W * W + i] = m; pl[(size_t)2 * W * W + i] = l;
+      pl[(size_t)3 * W * W + k * W + n] = h; pl[(size_t)4 * W * W + k * W + n] = m; pl[(size_t)5 * W * W + k * W + n] = l;
+    }
+    uint16_t* dpl; CK(hipMalloc(&dpl, pl.size() * 2)); CK(hipMemcpy(dpl, pl.data(), pl.size() * 2, hipMemcpyHostToDevice));
+    GemmParams fw = f; fw.B = reinterpret_cast<const float*>(dpl); fw.ldb = W; fw.b_plane_stride = (int64_t)W * W; fw.C = C2;
+    auto kern = gemm_splitw_kernel<EPI_BIAS>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS_BYTES));
+    const int tiles = (int)(ceil_div(M, 128) * ceil_div(W, 128));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 100; ++i) hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), SW_LDS_BYTES, 0, fw);
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), SW_LDS_BYTES, 0, fw);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("planes kernel (ablate %d)  fwd %6.1f us %6.0f TF(fp32-equiv)\n", BLH_SW_ABLATE, ms / reps * 1e3, flop / (ms / reps * 1e3) / 1e6);
+  }
   // ---- accuracy: sampled entries against an fp64 product ---------------------------------
   auto check = [&](const char* name, const GemmParams& gp, int la, int lb, int nsplit, bool split_kernel) {
     std::vector<float> hc((size_t)gp.M * gp.N * nsplit);
