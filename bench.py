@@ -73,16 +73,8 @@ def gemm_rooflines(batch, width, reps, dtype="fp32"):
     flop = 2.0 * batch * width * width
     out = {}
 
-    planes = None
-    if dtype == "bf16x3":      # the network's forward / dgrad take the weight as pre-split bf16 planes
-        planes = torch.empty(lib.blh_weight_planes_bytes(width, width), dtype=torch.uint8, device=dev)
-        N.check(lib.blh_weight_planes(st, Wt.data_ptr(), width, width, planes.data_ptr()), "planes")
-
     def fwd():
-        if planes is not None:
-            N.check(lib.blh_gemm_bf16x3_planes(st, A.data_ptr(), width, planes.data_ptr(), width, width,
-                                               Z.data_ptr(), width, batch, bias.data_ptr(), None, 0), "fwd")
-        elif dtype != "fp32":
+        if dtype != "fp32":
             N.check(gemm(st, A.data_ptr(), width, 0, Wt.data_ptr(), width, 0, Z.data_ptr(), width,
                          batch, width, width, 1, bias.data_ptr(), None, 0), "fwd")
         else:
@@ -90,10 +82,6 @@ def gemm_rooflines(batch, width, reps, dtype="fp32"):
                                              Z.data_ptr(), stat.data_ptr(), batch, width, width), "fwd")
 
     def dgrad():
-        if planes is not None:
-            N.check(lib.blh_gemm_bf16x3_planes(st, A.data_ptr(), width, planes.data_ptr() + 6 * width * width,
-                                               width, width, Z.data_ptr(), width, batch, None, None, 0), "dgrad")
-            return
         N.check(gemm(st, A.data_ptr(), width, 0, Wt.data_ptr(), width, 1, Z.data_ptr(),
                                  width, batch, width, width, 1, None, None, 0), "dgrad")
 
@@ -102,6 +90,7 @@ def gemm_rooflines(batch, width, reps, dtype="fp32"):
                                  slabs.data_ptr(), width, width, width, batch, splits, None, None,
                                  0), "wgrad")
 
+    time_kernel(fwd, 3 * reps)     # clock ramp: the first ~50 ms after idle run 10-15 % slow
     for name, fn in (("linear_fwd", fwd), ("linear_dgrad", dgrad), ("linear_wgrad", wgrad)):
         ms = time_kernel(fn, reps)
         out[name] = {"ms": ms, "tflops": flop / ms / 1e9}
@@ -139,8 +128,8 @@ def roofline_block(args, dom):
         # fp32 product from six bf16 MFMAs: priced against the bf16 MFMA peak / 6
         peak = BF16_MFMA_PEAK_TFLOPS / 6.0
         return {
-            "kernel": "gemm_splitw_kernel<BIAS> (Linear %dx%d forward, M=%d; A split in-kernel, W pre-split "
-                      "into 3 bf16 planes, 6 bf16 MFMAs per product)" % (
+            "kernel": "gemm_split_kernel<128,128,2,2,ROWK,ROWK,BIAS> (Linear %dx%d forward, M=%d; "
+                      "operands split into 3 bf16 pieces, 6 bf16 MFMAs per product)" % (
                           args.width, args.width, args.batch),
             "bound": "mfma", "achieved": dom["tflops"], "peak": peak,
             "unit": "TFLOP/s (fp32-equivalent = bf16 MFMA TFLOP/s / 6)", "frac": dom["tflops"] / peak,

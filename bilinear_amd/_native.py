@@ -102,10 +102,6 @@ _SIGNATURES = {
     "blh_gemm_bf16x3": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
                                 c_void_p, c_int64, c_int64, c_int64, c_int64, c_int32, c_void_p,
                                 c_void_p, c_int64]),
-    "blh_weight_planes_bytes": (c_int64, [c_int64, c_int64]),
-    "blh_weight_planes": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
-    "blh_gemm_bf16x3_planes": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
-                                       c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64]),
     "blh_sum_slabs": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "blh_linear_fwd_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int64, c_int64, c_int64]),

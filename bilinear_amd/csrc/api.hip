@@ -95,9 +95,6 @@ struct Workspace {
   double* sync_buf;               // [2][W] fp64 (SyncBN exchange; also used as float [2][W])
   std::vector<float*> stage_slabs; // per stage (+ decode): split-K wgrad slabs kept until grads_finish
   float* dec_bias_part;           // [blocks][out] partial sums of dpred (fused step)
-  // gemm_dtype 2: bf16 planes of the hidden Linear weights, [layer][3][W][W] each (layer 0 =
-  // heavy stage 1); rewritten by every forward pass
-  char* wplanes; char* wplanesT;
   int64_t bytes;
 };
 
@@ -183,12 +180,6 @@ static Workspace carve(const blh_model_desc* d, int64_t batch, void* base) {
     ws.stage_slabs.push_back(sp.splits > 1 ? (float*)take(sp.splits * M * N * sizeof(float)) : nullptr);
   }
   ws.dec_bias_part = (float*)take(1026 * d->out_features * sizeof(float));
-  ws.wplanes = ws.wplanesT = nullptr;
-  if (d->gemm_dtype == 2 && nh > 1) {
-    const int64_t pb = (int64_t)(nh - 1) * 3 * W * W * 2;
-    ws.wplanes = take(pb);
-    ws.wplanesT = take(pb);
-  }
   ws.bytes = off;
   return ws;
 }
@@ -222,26 +213,6 @@ static DropoutSrc layer_drop(const blh_dropout* drop, int layer, int64_t batch, 
   return d;
 }
 
-// gemm_dtype 2: the hidden Linear weights as bf16 planes (both orientations), from the current
-// parameters.  Hidden stages sit at a regular stride in the arena ({W, b, gamma, beta} each), so
-// one launch covers them all.
-static bool wplanes_usable(const blh_model_desc* d, const ArenaLayout& L, const Workspace& ws) {
-  if (d->gemm_dtype != 2 || !ws.wplanes || d->width % 32 != 0) return false;
-  const int nh = (int)L.heavy.size();
-  for (int i = 3; i < nh; ++i)
-    if (L.heavy[i].w - L.heavy[i - 1].w != L.heavy[2].w - L.heavy[1].w) return false;
-  return nh > 1;
-}
-static int make_wplanes(const blh_model_desc* d, const ArenaLayout& L, hipStream_t s,
-                        const float* params, const Workspace& ws) {
-  const int nh = (int)L.heavy.size(), W = d->width;
-  const int64_t stride = nh > 2 ? L.heavy[2].w - L.heavy[1].w : 0;
-  return launch_wplanes(s, params + L.heavy[1].w, stride, nh - 1, W, W, ws.wplanes, ws.wplanesT);
-}
-static const float* wplane_of(const char* base, int stage, int W) {
-  return reinterpret_cast<const float*>(base + (int64_t)(stage - 1) * 3 * W * W * 2);
-}
-
 // ------------------------------------------------------------- forward -----
 static int forward_impl(const blh_model_desc* d, hipStream_t s, const float* params,
                         float* bn_running, int64_t* nbt, const float* x, const blh_dropout* drop,
@@ -252,8 +223,6 @@ static int forward_impl(const blh_model_desc* d, hipStream_t s, const float* par
   const int nh = (int)L.heavy.size();
   const int W = d->width;
   const int tiles_m = (int)ceil_div(batch, 128);
-  const bool planes = wplanes_usable(d, L, ws);
-  if (planes) BLH_TRY(make_wplanes(d, L, s, params, ws));
   for (int i = 0; i < nh; ++i) {
     const HeavyOffsets& h = L.heavy[i];
     const float* in = (i == 0) ? x : ws.A[i - 1];
@@ -274,16 +243,8 @@ static int forward_impl(const blh_model_desc* d, hipStream_t s, const float* par
       BLH_TRY(launch_fwd_finish(s, ws.slabs, fs.splits, batch, W, params + h.b, ws.Z[i],
                                 train ? ws.stat_part : nullptr));
     } else {
-      int rc = BLH_ERR_SHAPE;
-      if (planes && i >= 1) {   // B from the pre-split planes [3][W][W] (rows n, k contiguous)
-        GemmParams gp = g;
-        gp.B = wplane_of(ws.wplanes, i, W); gp.ldb = W; gp.b_plane_stride = (int64_t)W * W;
-        rc = launch_gemm_wplanes(s, train ? EPI_BIAS_STATS : EPI_BIAS, gp);
-        if (rc != BLH_OK && rc != BLH_ERR_SHAPE) return rc;
-      }
-      if (rc == BLH_ERR_SHAPE)
-        BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, train ? EPI_BIAS_STATS : EPI_BIAS, g, 1,
-                            d->gemm_dtype));
+      BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, train ? EPI_BIAS_STATS : EPI_BIAS, g, 1,
+                          d->gemm_dtype));
     }
     // second stage of a block adds the block input (model/bilinear.py:36-38)
     const float* skip = (i >= 2 && (i % 2) == 0) ? ws.A[i - 2] : nullptr;
@@ -495,20 +456,13 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
         BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, ds2.splits, d->gemm_dtype));
         BLH_TRY(launch_sum_slabs_add(s, ws.slabs, batch * (int64_t)W, ds2.splits,
                                      first_of_block ? ws.G0 : nullptr, dst));
+      } else if (first_of_block) {
+        // d(block input) = dZ W + d(block output)   (skip path), in place in G0
+        g.C = ws.G0; g.addend = ws.G0; g.ldadd = W;
+        BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_ADD, g, 1, d->gemm_dtype));
       } else {
-        // first_of_block: d(block input) = dZ W + d(block output)   (skip path), in place in G0
-        const int epi = first_of_block ? EPI_ADD : EPI_STORE;
-        if (first_of_block) { g.C = ws.G0; g.addend = ws.G0; g.ldadd = W; }
-        else g.C = ws.G1;
-        int rc = BLH_ERR_SHAPE;
-        if (wplanes_usable(d, L, ws)) {   // B from the transposed planes written by this step's forward
-          GemmParams gp = g;
-          gp.B = wplane_of(ws.wplanesT, i, W); gp.ldb = W; gp.b_plane_stride = (int64_t)W * W;
-          rc = launch_gemm_wplanes(s, epi, gp);
-          if (rc != BLH_OK && rc != BLH_ERR_SHAPE) return rc;
-        }
-        if (rc == BLH_ERR_SHAPE)
-          BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, epi, g, 1, d->gemm_dtype));
+        g.C = ws.G1;
+        BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, 1, d->gemm_dtype));
       }
     }
     if (on_ready) {
@@ -944,30 +898,6 @@ int blh_gemm_bf16x3(void* stream, const float* A, int64_t lda, int32_t a_kmajor,
                     int64_t ldadd) {
   return gemm_entry(2, stream, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, splits, bias,
                     addend, ldadd);
-}
-
-int64_t blh_weight_planes_bytes(int64_t N, int64_t K) {
-  if (N <= 0 || K <= 0) return BLH_ERR_INVALID_ARGUMENT;
-  return 2 * 3 * N * K * 2;
-}
-
-int blh_weight_planes(void* stream, const float* W, int64_t N, int64_t K, void* planes) {
-  if (!W || !planes || N <= 0 || K <= 0) return BLH_ERR_INVALID_ARGUMENT;
-  return launch_wplanes((hipStream_t)stream, W, 0, 1, (int)N, (int)K, planes,
-                        (char*)planes + 3 * N * K * 2);
-}
-
-int blh_gemm_bf16x3_planes(void* stream, const float* A, int64_t lda, const void* planes, int64_t N,
-                           int64_t K, float* C, int64_t ldc, int64_t M, const float* bias,
-                           const float* addend, int64_t ldadd) {
-  if (!A || !planes || !C || M <= 0 || N <= 0 || K <= 0 || (bias && addend))
-    return BLH_ERR_INVALID_ARGUMENT;
-  GemmParams g{};
-  g.A = A; g.lda = lda; g.B = reinterpret_cast<const float*>(planes); g.ldb = K;
-  g.b_plane_stride = N * K;
-  g.C = C; g.ldc = ldc; g.M = (int)M; g.N = (int)N; g.K = (int)K; g.k_per_split = (int)K;
-  g.bias = bias; g.addend = addend; g.ldadd = ldadd;
-  return launch_gemm_wplanes((hipStream_t)stream, bias ? EPI_BIAS : (addend ? EPI_ADD : EPI_STORE), g);
 }
 
 int blh_linear_fwd_stats(void* stream, const float* A, const float* W, const float* bias, float* Z,

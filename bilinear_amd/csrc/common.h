@@ -49,7 +49,6 @@ struct GemmParams {
   int64_t ldadd;
   float* stat_part;         // [tiles_m][2][N]  (mean, M2) of each BM-row tile
   float* loss_part;         // diagnostic builds only: STAMP output (tools/gemm_bench)
-  int64_t b_plane_stride;   // launch_gemm_wplanes only: B = bf16 planes [3][N][ldb], elements per plane
 };
 
 enum GemmTile : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_128x32 = 3 };
@@ -60,15 +59,6 @@ int gemm_grid_blocks(GemmTile tile, int M, int N);
 // dtype 0: exact fp32 MFMA; 1: operands rounded to bf16 on load, bf16 MFMA, fp32 accumulate
 int launch_gemm(hipStream_t s, GemmTile tile, int la, int lb, int epi, const GemmParams& p,
                 int splits, int dtype = 0);
-
-// gemm_dtype 2, forward / dgrad of a W x W Linear with the weight pre-split into bf16 planes
-// (p.B = planes [3][N][K] bf16 as written by launch_wplanes, p.ldb = K, p.b_plane_stride = N * K).
-// Returns BLH_ERR_SHAPE when the shape does not qualify (caller falls back to launch_gemm).
-int launch_gemm_wplanes(hipStream_t s, int epi, const GemmParams& p);
-// W [layers][N][K] fp32 (layer stride w_stride floats) -> planes [layer][3][N][K] and the
-// transposed planesT [layer][3][K][N], bf16 pieces h | m | l of the exact three-way split.
-int launch_wplanes(hipStream_t s, const float* W, int64_t w_stride, int layers, int N, int K,
-                   void* planes, void* planesT);
 
 // ---------------------------------------------------------- elementwise ----
 struct DropoutSrc {

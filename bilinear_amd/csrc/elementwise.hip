@@ -1239,82 +1239,3 @@ int launch_grads_finish(hipStream_t s, float* grads, GradRegions& R, int64_t tot
 }
 
 }  // namespace blh
-
-// ---------------------------------------------------------------------------
-// gemm_dtype = 2: the weights of the W x W Linears as three bf16 planes (exact split
-// w = h + m + l, gemm_split_kernel.h), in both orientations, once per step:
-//   planes  [layer][3][N][K]   B operand of the forward GEMM  (rows n, k contiguous)
-//   planesT [layer][3][K][N]   B operand of the dgrad GEMM    (rows k, n contiguous)
-// One block = one 64 x 64 tile of one layer; the transpose goes through LDS.
-// ---------------------------------------------------------------------------
-namespace blh {
-
-__device__ __forceinline__ void split3_scalar(float x, uint16_t& h, uint16_t& m, uint16_t& l) {
-  const __bf16 hb = (__bf16)x;
-  const float r = x - (float)hb;
-  const __bf16 mb = (__bf16)r;
-  const float q = r - (float)mb;
-  const __bf16 lb = (__bf16)q;
-  h = __builtin_bit_cast(uint16_t, hb);
-  m = __builtin_bit_cast(uint16_t, mb);
-  l = __builtin_bit_cast(uint16_t, lb);
-}
-
-__global__ __launch_bounds__(256) void wplanes_kernel(const float* __restrict__ W, int64_t w_stride,
-                                                      int N, int K, uint16_t* __restrict__ planes,
-                                                      uint16_t* __restrict__ planesT) {
-  __shared__ uint16_t tile[3][64][66];
-  const int layer = blockIdx.z;
-  const int n0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
-  const float* __restrict__ Wl = W + (int64_t)layer * w_stride;
-  const int64_t plane = (int64_t)N * K;
-  uint16_t* __restrict__ P = planes + (int64_t)layer * 3 * plane;
-  uint16_t* __restrict__ PT = planesT + (int64_t)layer * 3 * plane;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int idx = threadIdx.x + 256 * p, row = idx >> 4, c = (idx & 15) << 2;
-    const int n = n0 + row, k = k0 + c;
-    uint16_t h[4] = {0, 0, 0, 0}, m[4] = {0, 0, 0, 0}, l[4] = {0, 0, 0, 0};
-    if (n < N && k < K) {   // K % 4 == 0
-      const float4 v = *reinterpret_cast<const float4*>(Wl + (int64_t)n * K + k);
-      split3_scalar(v.x, h[0], m[0], l[0]);
-      split3_scalar(v.y, h[1], m[1], l[1]);
-      split3_scalar(v.z, h[2], m[2], l[2]);
-      split3_scalar(v.w, h[3], m[3], l[3]);
-      const int64_t o = (int64_t)n * K + k;
-      *reinterpret_cast<uint2*>(P + o) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
-      *reinterpret_cast<uint2*>(P + plane + o) = make_uint2(m[0] | ((uint32_t)m[1] << 16), m[2] | ((uint32_t)m[3] << 16));
-      *reinterpret_cast<uint2*>(P + 2 * plane + o) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { tile[0][row][c + j] = h[j]; tile[1][row][c + j] = m[j]; tile[2][row][c + j] = l[j]; }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int idx = threadIdx.x + 256 * p, kk = idx >> 4, c = (idx & 15) << 2;
-    const int k = k0 + kk, n = n0 + c;
-    if (k < K && n < N) {   // N % 4 == 0
-      const int64_t o = (int64_t)k * N + n;
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        const uint32_t a = tile[pl][c][kk] | ((uint32_t)tile[pl][c + 1][kk] << 16);
-        const uint32_t b = tile[pl][c + 2][kk] | ((uint32_t)tile[pl][c + 3][kk] << 16);
-        *reinterpret_cast<uint2*>(PT + pl * plane + o) = make_uint2(a, b);
-      }
-    }
-  }
-}
-
-int launch_wplanes(hipStream_t s, const float* W, int64_t w_stride, int layers, int N, int K,
-                   void* planes, void* planesT) {
-  if (layers <= 0) return BLH_OK;
-  if (N % 4 != 0 || K % 4 != 0) return BLH_ERR_SHAPE;
-  dim3 grid((unsigned)ceil_div(K, 64), (unsigned)ceil_div(N, 64), (unsigned)layers);
-  hipLaunchKernelGGL(wplanes_kernel, grid, dim3(256), 0, s, W, w_stride, N, K,
-                     reinterpret_cast<uint16_t*>(planes), reinterpret_cast<uint16_t*>(planesT));
-  BLH_HIP_TRY(hipGetLastError());
-  return BLH_OK;
-}
-
-}  // namespace blh

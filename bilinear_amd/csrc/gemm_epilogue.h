@@ -9,6 +9,14 @@ namespace blh {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Workgroup barrier that orders LDS traffic only (a __syncthreads() would also wait for the
+// output stores that are still draining).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 template <int BM, int BN, int WM, int WN, int EPI>
 __device__ inline void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const GemmParams& p,
                                      float* __restrict__ C, float* smem, int m0, int n0, int tile_m,
@@ -32,6 +40,23 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], 
     }
   }
 
+  // the output stores go first: they drain while the statistics below are reduced
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) {
+        const int col = col_w + jn * 32;
+        if (row < p.M && col < p.N && is_cons) {
+          float v = acc[i][jn][r];
+          if (EPI == EPI_ADD) v += p.addend[(int64_t)row * p.ldadd + col];
+          C[(int64_t)row * p.ldc + col] = v;
+        }
+      }
+    }
+
   if (EPI == EPI_BIAS_STATS) {
     // Per-tile column statistics in the shifted (Welford/Chan) form: tile mean and
     // M2 = sum (z - tile_mean)^2, merged across tiles by bn_fwd_finalize.  Avoids the
@@ -52,7 +77,7 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], 
       s += __shfl_xor(s, 32);
       if (h == 0 && is_cons) red[wm * BN + wn * (TN * 32) + jn * 32 + lc] = s;
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
       float t = 0.f;
@@ -60,7 +85,7 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], 
       for (int w = 0; w < WM; ++w) t += red[w * BN + wn * (TN * 32) + jn * 32 + lc];
       mean[jn] = t / (float)cnt;
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
       float s = 0.f;
@@ -75,7 +100,7 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], 
       s += __shfl_xor(s, 32);
       if (h == 0 && is_cons) red[wm * BN + wn * (TN * 32) + jn * 32 + lc] = s;
     }
-    __syncthreads();
+    lds_barrier();
     if (wm == 0 && h == 0 && is_cons) {
 #pragma unroll
       for (int jn = 0; jn < TN; ++jn) {
@@ -90,22 +115,6 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], 
       }
     }
   }
-
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2);
-#pragma unroll
-      for (int jn = 0; jn < TN; ++jn) {
-        const int col = col_w + jn * 32;
-        if (row < p.M && col < p.N && is_cons) {
-          float v = acc[i][jn][r];
-          if (EPI == EPI_ADD) v += p.addend[(int64_t)row * p.ldadd + col];
-          C[(int64_t)row * p.ldc + col] = v;
-        }
-      }
-    }
 }
 
 }  // namespace blh

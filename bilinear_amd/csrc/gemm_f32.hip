@@ -4,7 +4,6 @@
 #include "gemm_bf16_kernel.h"
 #include "gemm_f32_kernel.h"
 #include "gemm_split_kernel.h"
-#include "gemm_splitw_kernel.h"
 
 namespace blh {
 
@@ -155,35 +154,6 @@ static int launch_split_128x128(hipStream_t s, int la, int lb, int epi, const Ge
   return BLH_ERR_INVALID_ARGUMENT;
 }
 #undef BLH_CASE3
-
-template <int EPI>
-static int launch_cfg_splitw(hipStream_t s, const GemmParams& p) {
-  static bool attr_set = false;
-  auto kern = gemm_splitw_kernel<EPI>;
-  if (!attr_set) {
-    BLH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS_BYTES));
-    attr_set = true;
-  }
-  const int tiles = (int)(ceil_div(p.M, 128) * ceil_div(p.N, 128));
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), SW_LDS_BYTES, s, p);
-  BLH_HIP_TRY(hipGetLastError());
-  return BLH_OK;
-}
-
-int launch_gemm_wplanes(hipStream_t s, int epi, const GemmParams& p) {
-  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return BLH_ERR_INVALID_ARGUMENT;
-  if (p.K % 32 != 0 || p.lda % 4 != 0 || p.ldb % 8 != 0 || p.b_plane_stride % 8 != 0 ||
-      (reinterpret_cast<uintptr_t>(p.B) & 15) != 0)
-    return BLH_ERR_SHAPE;
-  switch (epi) {
-    case EPI_BIAS_STATS: return launch_cfg_splitw<EPI_BIAS_STATS>(s, p);
-    case EPI_BIAS: return launch_cfg_splitw<EPI_BIAS>(s, p);
-    case EPI_STORE: return launch_cfg_splitw<EPI_STORE>(s, p);
-    case EPI_ADD: return launch_cfg_splitw<EPI_ADD>(s, p);
-  }
-  return BLH_ERR_INVALID_ARGUMENT;
-}
 
 int gemm_stat_tile_rows(GemmTile tile) { return tile == TILE_64x128 ? 64 : 128; }
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Developer tool: launch the three forward-GEMM variants of the W x W Linear a few times so that
-`rocprofv3 --pmc ... -- python3 tools/pmc_gemm.py` can attribute counters to them; with `--sum DIR`
+"""Developer tool: launch the forward GEMM of the W x W Linear in its two fp32-accurate forms of the W x W Linear a few times so that
+`PYTHONPATH=. rocprofv3 --pmc ... -- python3 bilinear_amd/csrc/tools/pmc_gemm.py` can attribute counters to them; with `--sum DIR`
 summarise a counter_collection.csv directory per kernel."""
 import csv, ctypes, glob, sys, collections
 
@@ -32,11 +32,7 @@ def main():
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     A = torch.randn(B, W, device=dev); Wt = torch.randn(W, W, device=dev) * 0.03
     bias = torch.randn(W, device=dev); Z = torch.empty(B, W, device=dev)
-    planes = torch.empty(lib.blh_weight_planes_bytes(W, W), dtype=torch.uint8, device=dev)
-    N.check(lib.blh_weight_planes(st, Wt.data_ptr(), W, W, planes.data_ptr()), "planes")
     for _ in range(12):
-        N.check(lib.blh_gemm_bf16x3_planes(st, A.data_ptr(), W, planes.data_ptr(), W, W, Z.data_ptr(), W, B,
-                                           bias.data_ptr(), None, 0), "planes gemm")
         N.check(lib.blh_gemm_bf16x3(st, A.data_ptr(), W, 0, Wt.data_ptr(), W, 0, Z.data_ptr(), W, B, W, W, 1,
                                     bias.data_ptr(), None, 0), "split gemm")
         N.check(lib.blh_gemm_f32(st, A.data_ptr(), W, 0, Wt.data_ptr(), W, 0, Z.data_ptr(), W, B, W, W, 1,

@@ -3,12 +3,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
-#include <cstring>
 #include <vector>
 #include "../gemm_split_kernel.h"
-#include "../gemm_splitr_kernel.h"
-#include "../gemm_split8_kernel.h"
-#include "../gemm_splitw_kernel.h"
 using namespace blh;
 thread_local int blh::g_last_hip_error = 0;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
@@ -24,36 +20,6 @@ float run_split(const GemmParams& p, int splits, int reps) {
   for (int i = 0; i < (reps > 1 ? 100 : 0); ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(NT), lds, 0, p);
   CK(hipEventRecord(e0, 0));
   for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(NT), lds, 0, p);
-  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
-  float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
-  return ms / reps * 1e3f;
-}
-
-template <int LA, int LB, int EPI>
-float run_splitr(const GemmParams& p, int splits, int reps) {
-  constexpr size_t lds = gemm_splitr_lds_bytes<128, 128>();
-  auto kern = gemm_splitr_kernel<128, 128, LA, LB, EPI>;
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int tiles = (int)(ceil_div(p.M, 128) * ceil_div(p.N, 128));
-  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < (reps > 1 ? 100 : 0); ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(256), lds, 0, p);
-  CK(hipEventRecord(e0, 0));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(256), lds, 0, p);
-  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
-  float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
-  return ms / reps * 1e3f;
-}
-
-template <int LA, int LB, int EPI>
-float run_split8(const GemmParams& p, int splits, int reps) {
-  constexpr size_t lds = gemm_split_lds_bytes<128, 128>();
-  auto kern = gemm_split8_kernel<128, 128, LA, LB, EPI>;
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int tiles = (int)(ceil_div(p.M, 128) * ceil_div(p.N, 128));
-  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < (reps > 1 ? 100 : 0); ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(512), lds, 0, p);
-  CK(hipEventRecord(e0, 0));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(512), lds, 0, p);
   CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
   float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
   return ms / reps * 1e3f;
@@ -94,6 +60,8 @@ int main(int argc, char** argv) {
 
 #define ROW(name, WM, WN)                                                                     \
   {                                                                                            \
+    float t0 = run_split<128, 128, WM, WN, ROWK, ROWK, EPI_BIAS_STATS>(f, 1, 3 * reps);        \
+    (void)t0; /* clock ramp: the first ~50 ms after idle run 10-15 % slow */                  \
     float t1 = run_split<128, 128, WM, WN, ROWK, ROWK, EPI_BIAS_STATS>(f, 1, reps);            \
     float t2 = run_split<128, 128, WM, WN, ROWK, KROW, EPI_STORE>(f, 1, reps);                 \
     float t3 = run_split<128, 128, WM, WN, KROW, KROW, EPI_STORE>(w, splits, reps);            \
@@ -101,20 +69,6 @@ int main(int argc, char** argv) {
            name, t1, flop / t1 / 1e6, t2, flop / t2 / 1e6, splits, t3, flop / t3 / 1e6);       \
   }
   ROW("128x128 w2x2", 2, 2)
-  {
-    float t1 = run_split8<ROWK, ROWK, EPI_BIAS_STATS>(f, 1, reps);
-    float t2 = run_split8<ROWK, KROW, EPI_STORE>(f, 1, reps);
-    float t3 = run_split8<KROW, KROW, EPI_STORE>(w, splits, reps);
-    printf("split 8 waves        fwd %6.1f us %6.0f TF(fp32-equiv) | dgrad %6.1f us %6.0f TF | wgrad(x%d) %6.1f us %6.0f TF\n",
-           t1, flop / t1 / 1e6, t2, flop / t2 / 1e6, splits, t3, flop / t3 / 1e6);
-  }
-  {
-    float t1 = run_splitr<ROWK, ROWK, EPI_BIAS_STATS>(f, 1, reps);
-    float t2 = run_splitr<ROWK, KROW, EPI_STORE>(f, 1, reps);
-    float t3 = run_splitr<KROW, KROW, EPI_STORE>(w, splits, reps);
-    printf("split-on-read        fwd %6.1f us %6.0f TF(fp32-equiv) | dgrad %6.1f us %6.0f TF | wgrad(x%d) %6.1f us %6.0f TF\n",
-           t1, flop / t1 / 1e6, t2, flop / t2 / 1e6, splits, t3, flop / t3 / 1e6);
-  }
 
 #ifdef BLH_SPLIT_STAMP
   {
@@ -129,29 +83,6 @@ int main(int argc, char** argv) {
     printf("K loop: %.0f shader cycles, %.2f us -> clock %.3f GHz; per MFMA slot %.1f cycles (ideal 32)\n", cyc, rt / 100.0, cyc / (rt * 10.0), cyc / (M ? (W / 16.0 * 24.0) : 1));
   }
 #endif
-  {  // pre-split weight planes (host-side split), forward + transposed, and the planes kernel
-    auto bf = [](float x) { uint32_t u; memcpy(&u, &x, 4); uint32_t r = u + 0x7fff + ((u >> 16) & 1); return (uint16_t)(r >> 16); };
-    auto fl = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
-    std::vector<uint16_t> pl((size_t)6 * W * W);
-    for (size_t i = 0; i < (size_t)W * W; ++i) {
-      float x = hb[i]; uint16_t h = bf(x); float r = x - fl(h); uint16_t m = bf(r); float q = r - fl(m); uint16_t l = bf(q);
-      const size_t n = i / W, k = i % W;
-      pl[i] = h; pl[(size_t)W * W + i] = m; pl[(size_t)2 * W * W + i] = l;
-      pl[(size_t)3 * W * W + k * W + n] = h; pl[(size_t)4 * W * W + k * W + n] = m; pl[(size_t)5 * W * W + k * W + n] = l;
-    }
-    uint16_t* dpl; CK(hipMalloc(&dpl, pl.size() * 2)); CK(hipMemcpy(dpl, pl.data(), pl.size() * 2, hipMemcpyHostToDevice));
-    GemmParams fw = f; fw.B = reinterpret_cast<const float*>(dpl); fw.ldb = W; fw.b_plane_stride = (int64_t)W * W; fw.C = C2;
-    auto kern = gemm_splitw_kernel<EPI_BIAS>;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS_BYTES));
-    const int tiles = (int)(ceil_div(M, 128) * ceil_div(W, 128));
-    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 100; ++i) hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), SW_LDS_BYTES, 0, fw);
-    CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), SW_LDS_BYTES, 0, fw);
-    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
-    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("planes kernel (ablate %d)  fwd %6.1f us %6.0f TF(fp32-equiv)\n", BLH_SW_ABLATE, ms / reps * 1e3, flop / (ms / reps * 1e3) / 1e6);
-  }
   // ---- accuracy: sampled entries against an fp64 product ---------------------------------
   auto check = [&](const char* name, const GemmParams& gp, int la, int lb, int nsplit, bool split_kernel) {
     std::vector<float> hc((size_t)gp.M * gp.N * nsplit);
@@ -174,18 +105,6 @@ int main(int argc, char** argv) {
     printf("  %-6s %-22s max |err| / sum|ab| = %.3e   rms = %.3e\n", name, split_kernel ? "bf16x3 split" : "fp32 MFMA (exact)", max_rel, sqrt(sum_rel2 / n));
   };
   GemmParams g = f; g.C = C2;
-  run_split8<ROWK, ROWK, EPI_BIAS_STATS>(g, 1, 1); CK(hipDeviceSynchronize());
-  check("fwd-8", g, ROWK, ROWK, 1, true);
-  run_split8<ROWK, KROW, EPI_STORE>(g, 1, 1); CK(hipDeviceSynchronize());
-  check("dgrd-8", g, ROWK, KROW, 1, true);
-  { GemmParams gw2 = w; gw2.C = C2; run_split8<KROW, KROW, EPI_STORE>(gw2, splits, 1); CK(hipDeviceSynchronize());
-    check("wgrd-8", gw2, KROW, KROW, splits, true); }
-  run_splitr<ROWK, ROWK, EPI_BIAS_STATS>(g, 1, 1); CK(hipDeviceSynchronize());
-  check("fwd-r", g, ROWK, ROWK, 1, true);
-  run_splitr<ROWK, KROW, EPI_STORE>(g, 1, 1); CK(hipDeviceSynchronize());
-  check("dgrd-r", g, ROWK, KROW, 1, true);
-  { GemmParams gw2 = w; gw2.C = C2; run_splitr<KROW, KROW, EPI_STORE>(gw2, splits, 1); CK(hipDeviceSynchronize());
-    check("wgrd-r", gw2, KROW, KROW, splits, true); }
   run_split<128, 128, 2, 2, ROWK, ROWK, EPI_BIAS_STATS>(g, 1, 1); CK(hipDeviceSynchronize());
   check("fwd", g, ROWK, ROWK, 1, true);
   run_f32<ROWK, ROWK, EPI_BIAS_STATS>(g, 1);

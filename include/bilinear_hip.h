@@ -283,17 +283,6 @@ int blh_gemm_bf16x3(void* stream, const float* A, int64_t lda, int32_t a_kmajor,
                     int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc, int64_t M, int64_t N,
                     int64_t K, int32_t splits, const float* bias, const float* addend,
                     int64_t ldadd);
-/* gemm_dtype = 2 with a PRE-SPLIT weight (what blh_forward_train / blh_backward use for the
- * W x W Linears): blh_weight_planes writes the exact three-way bf16 split of W[N,K] as
- * planes[3][N][K] followed by the transposed planesT[3][K][N] (blh_weight_planes_bytes(N, K)
- * bytes, 16-byte aligned); blh_gemm_bf16x3_planes computes C[M,N] = A[M,K] * Wsplit^T from
- * planes[3][N][K] (+ bias[N] | + addend) — pass planesT with (N, K) swapped for A * W.
- * Needs K % 32 == 0, otherwise BLH shape error (use blh_gemm_bf16x3).                          */
-int64_t blh_weight_planes_bytes(int64_t N, int64_t K);
-int blh_weight_planes(void* stream, const float* W, int64_t N, int64_t K, void* planes);
-int blh_gemm_bf16x3_planes(void* stream, const float* A, int64_t lda, const void* planes, int64_t N,
-                           int64_t K, float* C, int64_t ldc, int64_t M, const float* bias,
-                           const float* addend, int64_t ldadd);
 int blh_sum_slabs(void* stream, const float* slabs, int64_t count, int32_t splits, float* out);
 /* The forward kernel of one heavy_linear exactly as blh_forward_train launches it:
  * Z[M,N] = A[M,K] W[N,K]^T + bias, plus per-128-row-tile column statistics

@@ -118,53 +118,6 @@ def test_bf16x3_gemm_error_is_fp32_level(native, M, N, K, ak, bk, splits):
     assert errs["blh_gemm_bf16x3"][0] < 2e-6          # a dropped middle product would show as ~1e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (4096, 1024, 1024), (128, 384, 64), (77, 128, 32),
-                                   (1000, 200, 96), (64, 128, 40)])
-def test_bf16x3_preplit_weight_gemm(native, M, N, K):
-    """The forward / dgrad GEMM of gemm_dtype = 2 with the weight pre-split into bf16 planes
-    (blh_weight_planes + blh_gemm_bf16x3_planes): both plane orientations, bias and in-place
-    addend epilogues, ragged M and N, against the fp64 product at the fp32 tolerance."""
-    dev = _dev()
-    rng = np.random.RandomState(M + N + K)
-    A = (rng.standard_normal((M, K)) * np.exp(rng.standard_normal((M, K)))).astype(np.float32)
-    Wt = (rng.standard_normal((N, K)) * 0.1).astype(np.float32)
-    dZ = rng.standard_normal((M, N)).astype(np.float32)
-    bias = rng.standard_normal(N).astype(np.float32)
-    add = rng.standard_normal((M, K)).astype(np.float32)
-    a, w, dz = (torch.from_numpy(v).to(dev) for v in (A, Wt, dZ))
-    bt, at = torch.from_numpy(bias).to(dev), torch.from_numpy(add).to(dev)
-    nbytes = native.blh_weight_planes_bytes(N, K)
-    assert nbytes == 12 * N * K
-    planes = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    assert native.blh_weight_planes(st, w.data_ptr(), N, K, planes.data_ptr()) == 0
-    torch.cuda.synchronize()
-    # the planes are the exact split: h + m + l == w bit for bit
-    pl = planes.cpu().numpy().view(np.uint16).reshape(2, 3 * N * K)
-    f = (pl[0].astype(np.uint32) << 16).view(np.float32).reshape(3, N, K).astype(np.float64)
-    assert np.array_equal((f[0] + f[1] + f[2]).astype(np.float32), Wt)
-    ft = (pl[1].astype(np.uint32) << 16).view(np.float32).reshape(3, K, N)
-    assert np.array_equal(ft, np.transpose(f.astype(np.float32), (0, 2, 1)))
-    # forward form: C = A W^T + bias
-    c = torch.full((M, N), float("nan"), device=dev)
-    rc = native.blh_gemm_bf16x3_planes(st, a.data_ptr(), K, planes.data_ptr(), N, K, c.data_ptr(), N, M,
-                                       bt.data_ptr(), None, 0)
-    if K % 32 != 0:
-        assert rc == -2, "shapes the planes kernel does not cover must be refused (BLH_ERR_SHAPE)"
-        return
-    assert rc == 0, native.blh_status_string(rc)
-    torch.cuda.synchronize()
-    _close(c.cpu().numpy(), A.astype(np.float64) @ Wt.T.astype(np.float64) + bias, 2e-5, "planes fwd")
-    # dgrad form: dA = dZ W (+ addend, in place), B = transposed planes with (N, K) swapped
-    if N % 32 == 0:
-        pt = planes.data_ptr() + 6 * N * K
-        rc = native.blh_gemm_bf16x3_planes(st, dz.data_ptr(), N, pt, K, N, at.data_ptr(), K, M, None,
-                                           at.data_ptr(), K)
-        assert rc == 0, native.blh_status_string(rc)
-        torch.cuda.synchronize()
-        _close(at.cpu().numpy(), dZ.astype(np.float64) @ Wt.astype(np.float64) + add, 2e-5, "planes dgrad")
-
-
 @pytest.mark.parametrize("entry", ["blh_gemm_f32", "blh_gemm_bf16x3"])
 def test_gemm_bias_and_addend(native, entry):
     dev = _dev()
