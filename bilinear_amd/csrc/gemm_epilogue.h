@@ -41,6 +41,28 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], 
   }
 
   // the output stores go first: they drain while the statistics below are reduced
+  if (EPI == EPI_ADD) {
+    // all addend loads are issued before the first add: one memory latency for the tile instead
+    // of one per element (the add + store chain otherwise serialises on every load)
+    float add[TM][TN][16];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+          const int col = col_w + jn * 32;
+          add[i][jn][r] = (row < p.M && col < p.N) ? p.addend[(int64_t)row * p.ldadd + col] : 0.f;
+        }
+      }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][jn][r] += add[i][jn][r];
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -49,11 +71,7 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], 
 #pragma unroll
       for (int jn = 0; jn < TN; ++jn) {
         const int col = col_w + jn * 32;
-        if (row < p.M && col < p.N && is_cons) {
-          float v = acc[i][jn][r];
-          if (EPI == EPI_ADD) v += p.addend[(int64_t)row * p.ldadd + col];
-          C[(int64_t)row * p.ldc + col] = v;
-        }
+        if (row < p.M && col < p.N && is_cons) C[(int64_t)row * p.ldc + col] = acc[i][jn][r];
       }
     }
 
