@@ -102,6 +102,7 @@ _SIGNATURES = {
     "blh_gemm_bf16x3": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
                                 c_void_p, c_int64, c_int64, c_int64, c_int64, c_int32, c_void_p,
                                 c_void_p, c_int64]),
+    "blh_backward_side_stream": (c_void_p, []),
     "blh_sum_slabs": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "blh_linear_fwd_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int64, c_int64, c_int64]),

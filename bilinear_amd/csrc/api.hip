@@ -323,7 +323,7 @@ static int wgrad(int dtype, hipStream_t s, GemmTile tile, const float* dZ, int64
 // so that stage l-2 does not overwrite what wgrad(l) is still reading.
 struct SideStream {
   hipStream_t s2 = nullptr;
-  hipEvent_t ev_dz[34], ev_w[34];
+  hipEvent_t ev_dz[34], ev_w[34], ev_r[34];
   bool ready = false;
   int init() {
     if (ready) return BLH_OK;
@@ -331,6 +331,7 @@ struct SideStream {
     for (int i = 0; i < 34; ++i) {
       BLH_HIP_TRY(hipEventCreateWithFlags(&ev_dz[i], hipEventDisableTiming));
       BLH_HIP_TRY(hipEventCreateWithFlags(&ev_w[i], hipEventDisableTiming));
+      BLH_HIP_TRY(hipEventCreateWithFlags(&ev_r[i], hipEventDisableTiming));
     }
     ready = true;
     return BLH_OK;
@@ -361,8 +362,7 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
   const bool defer = (on_ready == nullptr) && defer_env;
   std::vector<GradRegion> wreg(nh + 1);
   static const bool two_env = getenv("BLH_ONE_STREAM") == nullptr;   // on by default (-3 % step)
-  const bool two = two_env && !on_ready && !g_sync.fn && !defer &&
-                   small_m_splits(batch, W, W).splits == 1;
+  const bool two = two_env && !g_sync.fn && !defer && small_m_splits(batch, W, W).splits == 1;
   hipStream_t s2 = s;
   if (two) {
     BLH_TRY(g_side.init());
@@ -380,6 +380,22 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
     BLH_HIP_TRY(hipEventRecord(g_side.ev_w[idx], s2));
     return BLH_OK;
   };
+  // Data-parallel hook.  A range's weight gradient is produced on the side stream, its bias /
+  // gamma / beta gradients on the main stream: the side stream is made to wait for the main one
+  // (everything enqueued so far), so that the range is complete ON THE SIDE STREAM when the
+  // host callback runs — blh_backward_side_stream() tells the caller which stream that is.
+  auto ready = [&](int idx, int64_t off, int64_t cnt) -> int {
+    if (!on_ready) return BLH_OK;
+    if (two) {
+      BLH_HIP_TRY(hipEventRecord(g_side.ev_r[idx], s));
+      BLH_HIP_TRY(hipStreamWaitEvent(s2, g_side.ev_r[idx], 0));
+    } else if (g_side.ready) {   // one-stream call while a side stream exists: keep the contract
+      BLH_HIP_TRY(hipEventRecord(g_side.ev_r[idx], s));
+      BLH_HIP_TRY(hipStreamWaitEvent(g_side.s2, g_side.ev_r[idx], 0));
+    }
+    on_ready(user, off, cnt);
+    return BLH_OK;
+  };
   // decode: dW = dP^T A_last, db = colsum(dP), dA_last = dP W_d
   BLH_TRY(fork(nh));
   BLH_TRY(wgrad(d->gemm_dtype, s2, TILE_64x128, dpred, OF, OF, ws.A[nh - 1], W, W, batch,
@@ -387,7 +403,7 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
                 grads + L.dec_w, defer ? &wreg[nh] : nullptr));
   BLH_TRY(wdone(nh));
   if (!fused) BLH_TRY(launch_colsum(s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
-  if (on_ready) on_ready(user, L.dec_w, L.total - L.dec_w);
+  BLH_TRY(ready(nh, L.dec_w, L.total - L.dec_w));
   {
     GemmParams g{};
     g.A = dpred; g.lda = OF;
@@ -467,7 +483,7 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
     }
     if (on_ready) {
       const int64_t end = (i + 1 < nh) ? L.heavy[i + 1].w : L.dec_w;
-      on_ready(user, h.w, end - h.w);
+      BLH_TRY(ready(i, h.w, end - h.w));
     }
   }
   if (two) BLH_HIP_TRY(hipStreamWaitEvent(s, g_side.ev_w[0], 0));   // join: s2 is in order
@@ -898,6 +914,13 @@ int blh_gemm_bf16x3(void* stream, const float* A, int64_t lda, int32_t a_kmajor,
                     int64_t ldadd) {
   return gemm_entry(2, stream, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, splits, bias,
                     addend, ldadd);
+}
+
+void* blh_backward_side_stream(void) {
+  static const bool one = getenv("BLH_ONE_STREAM") != nullptr;
+  if (one) return nullptr;
+  if (g_side.init() != BLH_OK) return nullptr;
+  return g_side.s2;
 }
 
 int blh_linear_fwd_stats(void* stream, const float* A, const float* W, const float* bias, float* Z,

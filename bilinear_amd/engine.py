@@ -280,12 +280,22 @@ class Engine:
         ws = self.workspace(batch)
         errors = []
         if on_ready is not None:
+            # a reported range is complete on the library's side stream (weight-gradient GEMMs):
+            # the hook runs with that stream current, so a collective launched from it is
+            # ordered behind the range without stalling the main stream
+            side = N.lib().blh_backward_side_stream()
+            side_stream = torch.cuda.ExternalStream(side, device=x.device) if side else None
+
             def _hook(user, off, cnt):
                 # an exception must not unwind through the C frames of blh_backward:
                 # remember it and re-raise once the call has returned
                 if not errors:
                     try:
-                        on_ready(int(off), int(cnt))
+                        if side_stream is not None:
+                            with torch.cuda.stream(side_stream):
+                                on_ready(int(off), int(cnt))
+                        else:
+                            on_ready(int(off), int(cnt))
                     except BaseException as exc:   # noqa: BLE001
                         errors.append(exc)
             cb = N.GradReadyFn(_hook)

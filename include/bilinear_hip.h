@@ -162,8 +162,15 @@ int blh_mse_loss_grad(void* stream, const float* pred, const float* target, int6
  * NULL, is called on the host right after the kernels that complete a
  * contiguous arena range [offset, offset+count) have been enqueued, in
  * decode -> encode order: the data-parallel host code launches the RCCL
- * all-reduce of that bucket from it, overlapping the rest of backward.      */
+ * all-reduce of that bucket from it, overlapping the rest of backward.
+ * The weight-gradient GEMMs run on a side stream owned by the library (next to the
+ * data-gradient GEMM and the BatchNorm-backward kernels of the following stage); a reported
+ * range is complete on THAT stream: blh_backward_side_stream() returns it (NULL when the
+ * library runs single-stream, BLH_ONE_STREAM=1, and the range is complete on `stream`), and
+ * the collective must be ordered behind it (e.g. make it the current stream while launching
+ * the all-reduce).  blh_backward itself returns with `stream` waiting for the side stream. */
 typedef void (*blh_grad_ready_fn)(void* user, int64_t offset_floats, int64_t count_floats);
+void* blh_backward_side_stream(void);
 int blh_backward(const blh_model_desc* d, void* stream, const float* params, const float* x,
                  const blh_dropout* drop, void* workspace, int64_t workspace_bytes,
                  const float* dpred, float* grads, int64_t batch, blh_grad_ready_fn on_ready,
