@@ -381,3 +381,40 @@ def mpjpe_sum(pred, target, mean, stddev):
     p = (stddev * pred + mean).reshape(-1, NUM_JOINT, 3)
     g = (stddev * target + mean).reshape(-1, NUM_JOINT, 3)
     return np.sqrt(((p - g) ** 2).sum(axis=2)).sum(axis=1)
+
+
+# ----------------------------------------------------------------------------
+# Input pipeline: the preprocessing the reference's H36M.Dataset does in
+# its constructor and in __getitem__, restated on whole arrays.
+# ----------------------------------------------------------------------------
+def h36m_decode_action(image_name):
+    """Action of one sample from its image name, /root/reference/H36M/util.py:13-22
+    ('S1_Directions_1.54138969_000001.jpg' -> 'Directions_1'), then the validator's merge of the
+    two sub-actions, /root/reference/valid_bilinear.py:64 ('Directions_1' -> 'Directions')."""
+    subject_action = image_name.split('.')[0]
+    parts = subject_action.split('_')
+    action = parts[1]
+    if len(parts) >= 3:
+        action = action + '_' + parts[2]
+    return action.split('_')[0]
+
+
+def h36m_flatten(part, S):
+    """Raw annotations -> flat features, /root/reference/H36M/data.py:36-59:
+    part [n,17,2] loses joint 9 (nose) -> [n,32]; S [n,17,3] is root-centred (joint 0) and loses
+    the pelvis -> [n,48].  float32 like the reference."""
+    part = np.asarray(part, dtype=np.float32)
+    S = np.asarray(S, dtype=np.float32)
+    p = np.delete(part, 9, axis=1)
+    s = (S - S[:, 0:1, :])[:, 1:, :]
+    return p.reshape(-1, 32), s.reshape(-1, 48)
+
+
+def h36m_stats(flat):
+    """Per-feature mean and (population) standard deviation, H36M/data.py:58-59 (np.mean / np.std)."""
+    return np.mean(flat, axis=0), np.std(flat, axis=0)
+
+
+def h36m_normalise(flat, mean, stddev):
+    """__getitem__ z-scoring with the TRAIN statistics, H36M/data.py:108-110."""
+    return (flat - mean) / stddev

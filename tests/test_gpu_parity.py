@@ -735,3 +735,55 @@ def test_standalone_heavy_linear_stage():
     stage.eval(); ref.eval()
     with torch.no_grad():
         _close(stage(x.to(dev)).cpu().numpy(), ref(x).numpy(), TIGHT, "eval stage")
+
+
+# ----------------------------------------------------------------------------
+# input pipeline on the device
+# ----------------------------------------------------------------------------
+def test_device_dataset_feeds_training_and_metric():
+    """The device-resident split (bilinear_amd.data.DevicePoseDataset) against the oracle's
+    restatement of H36M/data.py, then end to end: a few fused steps on shuffled batches reduce
+    the loss, and the MPJPE of the validation split equals the oracle's per-action loop."""
+    import bilinear_amd
+    from bilinear_amd.data import DevicePoseDataset, synthetic_raw
+    from bilinear_amd.metrics import MPJPE
+    dev = _dev()
+    raw_tr, raw_va = synthetic_raw(8192, seed=11), synthetic_raw(1000, seed=12)
+    train = DevicePoseDataset(raw_tr, dev, seed=3)
+    valid = DevicePoseDataset(raw_va, dev, stats_from=train)
+    ptr, str_ = O.h36m_flatten(raw_tr["part"], raw_tr["S"])
+    pva, sva = O.h36m_flatten(raw_va["part"], raw_va["S"])
+    mx, sx = O.h36m_stats(ptr)
+    mt, st = O.h36m_stats(str_)
+    _close(valid.x.cpu().numpy(), O.h36m_normalise(pva, mx, sx), 2e-5, "valid x")
+    _close(valid.t.cpu().numpy(), O.h36m_normalise(sva, mt, st), 2e-5, "valid t")
+    torch.manual_seed(0)
+    net, opt, _, _ = bilinear_amd.load(dev, num_blocks=1, width=256)
+    net.train()
+    losses = []
+    for epoch in range(3):
+        for x, t in train.epoch(epoch, 1024, shuffle=True):
+            _, loss = net.train_step(opt, x, t, max_norm=1.0)
+            losses.append(float(loss.item()))
+    assert losses[-1] < 0.7 * losses[0], losses
+    net.eval()
+    metric = MPJPE(valid.action_names, valid.norm_mean, valid.norm_stddev, dev)
+    preds = []
+    with torch.no_grad():
+        for x, t, a in valid.epoch(0, 256, with_actions=True):
+            p = net(x)
+            metric.update(p, t, a)
+            preds.append(p)
+    per_action, avg = metric.result()
+    pred = torch.cat(preds).cpu().numpy().astype(np.float64)
+    gt = O.h36m_normalise(sva, mt, st).astype(np.float64)
+    dist = O.mpjpe_sum(pred, gt, mt.astype(np.float64), st.astype(np.float64))
+    ref_sum, ref_cnt = {}, {}
+    for d, n in zip(dist, raw_va["image"]):          # the per-sample loop of valid_bilinear.py:61-70
+        k = O.h36m_decode_action(n)
+        ref_sum[k] = ref_sum.get(k, 0.0) + float(d)
+        ref_cnt[k] = ref_cnt.get(k, 0) + 1
+    for k in ref_sum:
+        assert abs(per_action[k] - ref_sum[k] / (ref_cnt[k] * 16)) <= 1e-4 * per_action[k] + 1e-3
+    tot = sum(ref_sum.values()) / (sum(ref_cnt.values()) * 16)
+    assert abs(avg - tot) <= 1e-4 * tot + 1e-3

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 import bilinear_amd
-from bilinear_amd.data import SyntheticPoses
+from bilinear_amd.data import DevicePoseDataset, SyntheticPoses, synthetic_raw
 
 # util/config.py:13-25
 COMMENT = "Bilinear GT"
@@ -45,6 +45,11 @@ def main():
     ap.add_argument("--steps-per-epoch", type=int, default=200)
     ap.add_argument("--batch-size", type=int, default=BATCH_SIZE)
     ap.add_argument("--save-root", default="save")
+    ap.add_argument("--data-dir", default=None,
+                    help="Human3.6M directory holding the reference's train_GT.bin / valid_GT.bin; "
+                         "the split is preprocessed once and kept on the device")
+    ap.add_argument("--synthetic-poses", type=int, default=0,
+                    help="no dataset: N synthetic raw annotations through the same device pipeline")
     args = ap.parse_args()
 
     logging.basicConfig(level=logging.INFO, format="[%(levelname)s|%(filename)s:%(lineno)s] %(asctime)s > %(message)s")
@@ -55,6 +60,12 @@ def main():
     log_dir = os.path.join(args.save_root, COMMENT)
     parameter_dir = os.path.join(log_dir, "parameter")
 
+    # H36M.Dataset + DataLoader(shuffle=True) (train_bilinear.py:33-43) as one device-resident split
+    dataset = None
+    if args.data_dir:
+        dataset, _ = DevicePoseDataset.from_pickles(args.data_dir, device)
+    elif args.synthetic_poses:
+        dataset = DevicePoseDataset(synthetic_raw(args.synthetic_poses, seed=0), device)
     data = SyntheticPoses(args.steps_per_epoch, args.batch_size, device)
     bilinear, optimizer, step, train_epoch = bilinear_amd.load(
         device=device, parameter_dir=parameter_dir if os.path.exists(parameter_dir) else None)
@@ -63,7 +74,9 @@ def main():
 
     for epoch in range(train_epoch + 1, train_epoch + args.epochs + 1):
         loss = None
-        for in_image_space, in_camera_space in data.epoch(epoch):
+        batches = (dataset.epoch(epoch, args.batch_size, shuffle=True) if dataset is not None
+                   else data.epoch(epoch))
+        for in_image_space, in_camera_space in batches:
             if LR_DECAY_ACTIVATE and lr_decay_condition(step):
                 lr = lr_decay_function(step)
                 logger.info("Learning rate decay to %s (step: %d)", lr, step)

@@ -10,7 +10,7 @@ import os
 import torch
 
 import bilinear_amd
-from bilinear_amd.data import ACTIONS, SyntheticPoses
+from bilinear_amd.data import ACTIONS, DevicePoseDataset, SyntheticPoses, synthetic_raw
 from bilinear_amd.metrics import MPJPE
 
 COMMENT = "Bilinear GT"
@@ -21,6 +21,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--batch-size", type=int, default=64)
     ap.add_argument("--save-root", default="save")
+    ap.add_argument("--data-dir", default=None, help="Human3.6M directory with train_GT.bin / valid_GT.bin")
+    ap.add_argument("--synthetic-poses", type=int, default=0,
+                    help="no dataset: N synthetic raw annotations through the same device pipeline "
+                         "(use the value train_bilinear.py was run with)")
     args = ap.parse_args()
     logging.basicConfig(level=logging.INFO)
     logger = logging.getLogger("valid_bilinear")
@@ -30,6 +34,24 @@ def main():
     parameter_dir = os.path.join(args.save_root, COMMENT, "parameter")
     bilinear, optimizer, step, train_epoch = bilinear_amd.load(device=device, parameter_dir=parameter_dir)
     bilinear.eval()
+
+    valid = None
+    if args.data_dir:
+        _, valid = DevicePoseDataset.from_pickles(args.data_dir, device)
+    elif args.synthetic_poses:
+        train = DevicePoseDataset(synthetic_raw(args.synthetic_poses, seed=0), device)
+        valid = DevicePoseDataset(synthetic_raw(max(1, args.synthetic_poses // 4), seed=1), device, stats_from=train)
+    if valid is not None:
+        # the whole split, its train-set statistics and the action ids are device tensors
+        metric = MPJPE(valid.action_names, valid.norm_mean, valid.norm_stddev, device)
+        with torch.set_grad_enabled(False):
+            for in_image_space, in_camera_space, ids in valid.epoch(0, args.batch_size, with_actions=True):
+                metric.update(bilinear(in_image_space), in_camera_space, ids)
+        per_action, average = metric.result()
+        for key, value in per_action.items():
+            logger.info("%s: %f", key, value)
+        logger.info("avg: %f", average)
+        return
 
     data = SyntheticPoses(args.steps, args.batch_size, device, seed=999)
     metric = MPJPE(ACTIONS, data.mean, data.stddev, device)   # per-action sums stay on the device
