@@ -230,6 +230,9 @@ def main():
                          "(1.25 vs 1.19 ms: the two-stream fork/join replays worse than it runs "
                          "eagerly) and equal at B=64, so eager is the default")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --batch is the GLOBAL batch, split evenly over the GPUs "
+                         "(SURVEY.md 8(d)); default is weak scaling, --batch per GPU")
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the extra timing of the bf16x3 GEMM mode (reported beside the headline)")
@@ -240,6 +243,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if args.strong:
+        if args.batch % (32 * world) != 0:
+            raise SystemExit("--strong needs a global batch divisible by 32 * n_gpus")
+        args.batch //= world          # per-GPU rows from here on
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -317,7 +324,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x3": "f32 (operands split into 3 bf16 pieces, bf16 MFMA, fp32 accumulate)",
                       "bf16": "bf16 (MFMA inputs; fp32 accumulate and storage)"}[args.dtype],
