@@ -247,11 +247,19 @@ def main():
         if args.batch % (32 * world) != 0:
             raise SystemExit("--strong needs a global batch divisible by 32 * n_gpus")
         args.batch //= world          # per-GPU rows from here on
+    # rehearsal on a one-GPU box (developer use): BLH_BENCH_REHEARSE=1 puts every rank on GPU 0
+    # and exchanges over gloo, to exercise this file's multi-rank control flow without RCCL
+    rehearse = os.environ.get("BLH_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import bilinear_amd
     from bilinear_amd.dp import DataParallel
