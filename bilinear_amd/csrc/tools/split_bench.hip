@@ -70,6 +70,14 @@ int main(int argc, char** argv) {
   }
   ROW("128x128 w2x2", 2, 2)
 
+  {  // fixed part: the same launches with K = 64 (one loop round)
+    GemmParams f1 = f; f1.K = 64; f1.k_per_split = 64;
+    float a = run_split<128, 128, 2, 2, ROWK, ROWK, EPI_BIAS_STATS>(f1, 1, reps);
+    float b = run_split<128, 128, 2, 2, ROWK, KROW, EPI_STORE>(f1, 1, reps);
+    GemmParams f2 = f1; f2.M = 128;
+    float c = run_split<128, 128, 2, 2, ROWK, KROW, EPI_STORE>(f2, 1, reps);
+    printf("K=64: fwd(stats) %.1f us | dgrad(store) %.1f us | dgrad, 8 tiles only %.1f us\n", a, b, c);
+  }
 #ifdef BLH_SPLIT_STAMP
   {
     unsigned long long* st; CK(hipMalloc(&st, 4096 * 16)); CK(hipMemset(st, 0, 4096 * 16));
