@@ -307,8 +307,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmParams p) {
       const float* nA = smem + st_nxt * RING;
       const bool more = (kt + 1 < nkt), more2 = (kt + 2 < nkt);
       if (more2 && !(ABLATE & 8)) {   // ABLATE: timing-only diagnostic builds (wrong results)
-        // (spreading these DMAs between the MFMAs of groups 0/1 instead of issuing them here
-        //  was measured and changes nothing: 72.1 vs 72.3 us)
+        // (measured and not kept: spreading these DMAs between the MFMA groups, 72.1 vs 72.3 us;
+        //  a hand-interleaved group with one asm statement per MFMA and the next group's LDS
+        //  reads in between, 74.4 / 74.7 / 74.6 vs 72.2 / 74.1 / 71.3 us)
         const int k0 = kz0 + (kt + 2) * BK;
         planA.issue(lds0 + st_nn * (RING * 4), k0, k_end);
         planB.issue(lds0 + st_nn * (RING * 4) + BM * BK * 4, k0, k_end);
