@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <vector>
 #include "../gemm_split_kernel.h"
+#include "split_f16_proto.h"
 using namespace blh;
 thread_local int blh::g_last_hip_error = 0;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
@@ -20,6 +21,21 @@ float run_split(const GemmParams& p, int splits, int reps) {
   for (int i = 0; i < (reps > 1 ? 100 : 0); ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(NT), lds, 0, p);
   CK(hipEventRecord(e0, 0));
   for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(NT), lds, 0, p);
+  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+  float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / reps * 1e3f;
+}
+
+template <int LA, int LB, int EPI>
+float run_f16x2(const GemmParams& p, int splits, int reps) {
+  constexpr size_t lds = gemm_f16x2_lds_bytes<128, 128>();
+  auto kern = gemm_f16x2_kernel<LA, LB, EPI>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int tiles = (int)(ceil_div(p.M, 128) * ceil_div(p.N, 128));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < (reps > 1 ? 100 : 0); ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(256), lds, 0, p);
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(256), lds, 0, p);
   CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
   float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
   return ms / reps * 1e3f;
@@ -69,6 +85,13 @@ int main(int argc, char** argv) {
            name, t1, flop / t1 / 1e6, t2, flop / t2 / 1e6, splits, t3, flop / t3 / 1e6);       \
   }
   ROW("128x128 w2x2", 2, 2)
+  {
+    float t1 = run_f16x2<ROWK, ROWK, EPI_BIAS_STATS>(f, 1, reps);
+    float t2 = run_f16x2<ROWK, KROW, EPI_STORE>(f, 1, reps);
+    float t3 = run_f16x2<KROW, KROW, EPI_STORE>(w, splits, reps);
+    printf("fp16x2 prototype     fwd %6.1f us %6.0f TF(fp32-equiv) | dgrad %6.1f us %6.0f TF | wgrad(x%d) %6.1f us %6.0f TF\n",
+           t1, flop / t1 / 1e6, t2, flop / t2 / 1e6, splits, t3, flop / t3 / 1e6);
+  }
 
   {  // fixed part: the same launches with K = 64 (one loop round)
     GemmParams f1 = f; f1.K = 64; f1.k_per_split = 64;
@@ -113,6 +136,14 @@ int main(int argc, char** argv) {
     printf("  %-6s %-22s max |err| / sum|ab| = %.3e   rms = %.3e\n", name, split_kernel ? "bf16x3 split" : "fp32 MFMA (exact)", max_rel, sqrt(sum_rel2 / n));
   };
   GemmParams g = f; g.C = C2;
+  run_f16x2<ROWK, ROWK, EPI_BIAS_STATS>(g, 1, 1); CK(hipDeviceSynchronize());
+  check("fwd", g, ROWK, ROWK, 1, true);
+  printf("      ^ fp16x2 prototype\n");
+  run_f16x2<ROWK, KROW, EPI_STORE>(g, 1, 1); CK(hipDeviceSynchronize());
+  check("dgrad", g, ROWK, KROW, 1, true);
+  printf("      ^ fp16x2 prototype\n");
+  { GemmParams gw2 = w; gw2.C = C2; run_f16x2<KROW, KROW, EPI_STORE>(gw2, splits, 1); CK(hipDeviceSynchronize());
+    check("wgrad", gw2, KROW, KROW, splits, true); printf("      ^ fp16x2 prototype\n"); }
   run_split<128, 128, 2, 2, ROWK, ROWK, EPI_BIAS_STATS>(g, 1, 1); CK(hipDeviceSynchronize());
   check("fwd", g, ROWK, ROWK, 1, true);
   run_f32<ROWK, ROWK, EPI_BIAS_STATS>(g, 1);
