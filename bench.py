@@ -63,6 +63,16 @@ def gemm_rooflines(batch, width, reps, dtype="fp32"):
     gemm = {"bf16": lib.blh_gemm_bf16, "bf16x3": lib.blh_gemm_bf16x3}.get(dtype, lib.blh_gemm_f32)
     dev = torch.device("cuda", torch.cuda.current_device())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if dtype == "fp16x2":      # operand maxima once (inside the network the producers supply them)
+        ws16 = [torch.empty(lib.blh_gemm_fp16x2_workspace_bytes(), dtype=torch.uint8, device=dev) for _ in range(3)]
+        ready = [0, 0, 0]
+
+        def gemm16(slot):
+            def call(*a):
+                rc = lib.blh_gemm_fp16x2(*a, ws16[slot].data_ptr(), ready[slot])
+                ready[slot] = 1
+                return rc
+            return call
     A = torch.randn(batch, width, device=dev)
     Wt = torch.randn(width, width, device=dev) * 0.03
     bias = torch.randn(width, device=dev)
@@ -74,7 +84,10 @@ def gemm_rooflines(batch, width, reps, dtype="fp32"):
     out = {}
 
     def fwd():
-        if dtype != "fp32":
+        if dtype == "fp16x2":
+            N.check(gemm16(0)(st, A.data_ptr(), width, 0, Wt.data_ptr(), width, 0, Z.data_ptr(), width,
+                              batch, width, width, 1, bias.data_ptr(), None, 0), "fwd")
+        elif dtype != "fp32":
             N.check(gemm(st, A.data_ptr(), width, 0, Wt.data_ptr(), width, 0, Z.data_ptr(), width,
                          batch, width, width, 1, bias.data_ptr(), None, 0), "fwd")
         else:
@@ -82,10 +95,18 @@ def gemm_rooflines(batch, width, reps, dtype="fp32"):
                                              Z.data_ptr(), stat.data_ptr(), batch, width, width), "fwd")
 
     def dgrad():
+        if dtype == "fp16x2":
+            N.check(gemm16(1)(st, A.data_ptr(), width, 0, Wt.data_ptr(), width, 1, Z.data_ptr(), width,
+                              batch, width, width, 1, None, None, 0), "dgrad")
+            return
         N.check(gemm(st, A.data_ptr(), width, 0, Wt.data_ptr(), width, 1, Z.data_ptr(),
                                  width, batch, width, width, 1, None, None, 0), "dgrad")
 
     def wgrad():
+        if dtype == "fp16x2":
+            N.check(gemm16(2)(st, A.data_ptr(), width, 1, Z.data_ptr(), width, 1, slabs.data_ptr(), width,
+                              width, width, batch, splits, None, None, 0), "wgrad")
+            return
         N.check(gemm(st, A.data_ptr(), width, 1, Z.data_ptr(), width, 1,
                                  slabs.data_ptr(), width, width, width, batch, splits, None, None,
                                  0), "wgrad")
@@ -124,6 +145,16 @@ def roofline_block(args, dom):
             "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json)",
             "avg_launch_ms": dom["ms"], "flop_per_launch": flop,
         }
+    if args.dtype == "fp16x2":
+        peak = BF16_MFMA_PEAK_TFLOPS / 3.0   # f16 MFMA peak = bf16 MFMA peak; three MFMAs per product
+        return {
+            "kernel": "gemm_f16x2_kernel<ROWK,ROWK,BIAS> (Linear %dx%d forward, M=%d; operands split into "
+                      "2 scaled fp16 pieces, 3 f16 MFMAs per product)" % (args.width, args.width, args.batch),
+            "bound": "mfma", "achieved": dom["tflops"], "peak": peak,
+            "unit": "TFLOP/s (fp32-equivalent = f16 MFMA TFLOP/s / 3)", "frac": dom["tflops"] / peak,
+            "traffic": None, "avg_launch_ms": dom["ms"], "flop_per_launch": flop,
+            "f16_mfma_tflops_executed": 3.0 * dom["tflops"],
+        }
     if args.dtype == "bf16x3":
         # fp32 product from six bf16 MFMAs: priced against the bf16 MFMA peak / 6
         peak = BF16_MFMA_PEAK_TFLOPS / 6.0
@@ -150,25 +181,26 @@ def roofline_block(args, dom):
     }
 
 
-def alt_mode_block(args, dev, x, t, pred_ref):
-    """The same workload with gemm_dtype = "bf16x3": the 1024-wide Linear contractions computed to
-    fp32 accuracy on the bf16 matrix cores (three-way exact split of both operands, six MFMAs per
-    product).  Reported beside the headline, which stays on the exact-fp32 MFMA path."""
+def alt_mode_block(args, dev, x, t, alt):
+    """The same workload with the 1024-wide Linear contractions computed to fp32 accuracy on the
+    16-bit matrix cores: "bf16x3" (three-way exact bf16 split, six MFMAs per product) or "fp16x2"
+    (two fp16 pieces with per-tensor power-of-two scales, three MFMAs).  Reported beside the
+    headline, which stays on the exact-fp32 MFMA path."""
     import bilinear_amd
     out = {}
     preds = {}
-    for mode in ("fp32", "bf16x3"):          # first-step agreement from identical state and dropout
+    for mode in ("fp32", alt):               # first-step agreement from identical state and dropout
         torch.manual_seed(1)
         n, o, _, _ = bilinear_amd.load(dev, num_blocks=args.blocks, width=args.width, gemm_dtype=mode)
         n.train()
         p, l = n.train_step(o, x, t, max_norm=1.0)
         preds[mode] = (p.detach().double(), float(l.item()))
-    d = (preds["bf16x3"][0] - preds["fp32"][0]).abs().max().item()
+    d = (preds[alt][0] - preds["fp32"][0]).abs().max().item()
     out["first_step_max_abs_pred_diff_vs_exact_fp32"] = d
     out["first_step_pred_rms"] = preds["fp32"][0].pow(2).mean().sqrt().item()
-    out["first_step_loss"] = {"fp32": preds["fp32"][1], "bf16x3": preds["bf16x3"][1]}
+    out["first_step_loss"] = {"fp32": preds["fp32"][1], alt: preds[alt][1]}
     torch.manual_seed(1)
-    net, opt, _, _ = bilinear_amd.load(dev, num_blocks=args.blocks, width=args.width, gemm_dtype="bf16x3")
+    net, opt, _, _ = bilinear_amd.load(dev, num_blocks=args.blocks, width=args.width, gemm_dtype=alt)
     net.train()
     for _ in range(args.warmup):
         net.train_step(opt, x, t, max_norm=1.0)
@@ -181,10 +213,14 @@ def alt_mode_block(args, dev, x, t, pred_ref):
     out["ms_per_step"] = 1e3 * el / args.steps
     out["poses_per_s"] = args.batch * args.steps / el
     out["final_loss"] = float(loss.item())
-    kern = gemm_rooflines(args.batch, args.width, reps=500, dtype="bf16x3")
+    kern = gemm_rooflines(args.batch, args.width, reps=500, dtype=alt)
     out["kernels"] = kern
-    out["arithmetic"] = ("x = h + m + l exactly (3 bf16 pieces); a*b from 6 bf16 MFMAs, fp32 accumulate; "
-                         "dropped terms < 2^-25 |ab|; same parity tests and tolerances as the exact path")
+    out["arithmetic"] = {
+        "bf16x3": "x = h + m + l exactly (3 bf16 pieces); a*b from 6 bf16 MFMAs, fp32 accumulate; "
+                  "dropped terms < 2^-25 |ab|; same parity tests and tolerances as the exact path",
+        "fp16x2": "x*2^e = hi + lo (2 fp16 pieces, e from the tensor's largest magnitude); a*b from 3 f16 "
+                  "MFMAs, fp32 accumulate, exact unscale; same parity tests and tolerances as the exact path",
+    }[alt]
     return out
 
 
@@ -219,7 +255,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=2)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", choices=["fp32", "bf16", "bf16x3"], default="fp32",
+    ap.add_argument("--dtype", choices=["fp32", "bf16", "bf16x3", "fp16x2"], default="fp32",
                     help="GEMM arithmetic: fp32 MFMA (BASELINE configs[1], default) or bf16 MFMA "
                          "inputs with fp32 accumulation and fp32 storage (configs 3-5)")
     ap.add_argument("--sync-bn", action="store_true",
@@ -335,6 +371,7 @@ def main():
             "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x3": "f32 (operands split into 3 bf16 pieces, bf16 MFMA, fp32 accumulate)",
+                      "fp16x2": "f32 (operands split into 2 scaled fp16 pieces, f16 MFMA, fp32 accumulate)",
                       "bf16": "bf16 (MFMA inputs; fp32 accumulate and storage)"}[args.dtype],
             "data": "synthetic",
             "config": {
@@ -358,7 +395,7 @@ def main():
             "kernels": kern,
         }
         if world == 1 and args.dtype == "fp32" and not args.no_alt:
-            result["bf16x3_mode"] = alt_mode_block(args, dev, x, t, pred_ref=None)
+            result["fp32_on_16bit_mfma"] = {m: alt_mode_block(args, dev, x, t, m) for m in ("bf16x3", "fp16x2")}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import torch_port as TP
             cores = host_cores()

@@ -103,6 +103,10 @@ _SIGNATURES = {
                                 c_void_p, c_int64, c_int64, c_int64, c_int64, c_int32, c_void_p,
                                 c_void_p, c_int64]),
     "blh_backward_side_stream": (c_void_p, []),
+    "blh_gemm_fp16x2_workspace_bytes": (c_int64, []),
+    "blh_gemm_fp16x2": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
+                                c_void_p, c_int64, c_int64, c_int64, c_int64, c_int32, c_void_p,
+                                c_void_p, c_int64, c_void_p, c_int32]),
     "blh_sum_slabs": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "blh_linear_fwd_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int64, c_int64, c_int64]),

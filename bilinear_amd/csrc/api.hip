@@ -40,7 +40,7 @@ static int check_desc(const blh_model_desc* d) {
     return BLH_ERR_SHAPE;
   if (d->out_features > 64) return BLH_ERR_SHAPE;   // decode uses one 64-wide column tile
   if (1 + 2 * d->num_blocks > 32) return BLH_ERR_SHAPE;
-  if (d->gemm_dtype < 0 || d->gemm_dtype > 2) return BLH_ERR_INVALID_ARGUMENT;
+  if (d->gemm_dtype < 0 || d->gemm_dtype > 3) return BLH_ERR_INVALID_ARGUMENT;
   return BLH_OK;
 }
 
@@ -95,6 +95,11 @@ struct Workspace {
   double* sync_buf;               // [2][W] fp64 (SyncBN exchange; also used as float [2][W])
   std::vector<float*> stage_slabs; // per stage (+ decode): split-K wgrad slabs kept until grads_finish
   float* dec_bias_part;           // [blocks][out] partial sums of dpred (fused step)
+  // gemm_dtype 3: max |value| partials of the GEMM operand tensors (see gemm_f16x2_kernel.h)
+  std::vector<float*> amax_A;     // per heavy stage: activation A_l (written by bn_apply)
+  float* amax_dZ[2];              // dZ / dZ2 (written by bn_bwd_apply)
+  float* amax_W;                  // [nh][WAMAX_PARTS], hidden weights (stage 0 unused)
+  int amax_parts;
   int64_t bytes;
 };
 
@@ -180,6 +185,17 @@ static Workspace carve(const blh_model_desc* d, int64_t batch, void* base) {
     ws.stage_slabs.push_back(sp.splits > 1 ? (float*)take(sp.splits * M * N * sizeof(float)) : nullptr);
   }
   ws.dec_bias_part = (float*)take(1026 * d->out_features * sizeof(float));
+  ws.amax_parts = 0;
+  ws.amax_dZ[0] = ws.amax_dZ[1] = ws.amax_W = nullptr;
+  if (d->gemm_dtype == 3) {
+    ws.amax_parts = ew_num_amax_parts(batch, (int)W);
+    for (int i = 0; i < nh; ++i) ws.amax_A.push_back((float*)take(ws.amax_parts * sizeof(float)));
+    ws.amax_dZ[0] = (float*)take(ws.amax_parts * sizeof(float));
+    ws.amax_dZ[1] = (float*)take(ws.amax_parts * sizeof(float));
+    ws.amax_W = (float*)take((int64_t)nh * WAMAX_PARTS * sizeof(float));
+  } else {
+    for (int i = 0; i < nh; ++i) ws.amax_A.push_back(nullptr);
+  }
   ws.bytes = off;
   return ws;
 }
@@ -223,12 +239,19 @@ static int forward_impl(const blh_model_desc* d, hipStream_t s, const float* par
   const int nh = (int)L.heavy.size();
   const int W = d->width;
   const int tiles_m = (int)ceil_div(batch, 128);
+  if (ws.amax_W)   // gemm_dtype 3: max |w| of every hidden Linear weight, once per forward
+    for (int i = 1; i < nh; ++i)
+      BLH_TRY(launch_wamax(s, params + L.heavy[i].w, 0, 1, (int64_t)W * W, ws.amax_W + (int64_t)i * WAMAX_PARTS));
   for (int i = 0; i < nh; ++i) {
     const HeavyOffsets& h = L.heavy[i];
     const float* in = (i == 0) ? x : ws.A[i - 1];
     GemmParams g{};
     g.A = in; g.lda = h.fan_in;
     g.B = params + h.w; g.ldb = h.fan_in;
+    if (ws.amax_W && i >= 1) {
+      g.a_amax = ws.amax_A[i - 1]; g.a_namax = ws.amax_parts;
+      g.b_amax = ws.amax_W + (int64_t)i * WAMAX_PARTS; g.b_namax = WAMAX_PARTS;
+    }
     g.C = ws.Z[i]; g.ldc = W;
     g.M = (int)batch; g.N = W; g.K = h.fan_in; g.k_per_split = h.fan_in;
     g.bias = params + h.b;
@@ -267,10 +290,10 @@ static int forward_impl(const blh_model_desc* d, hipStream_t s, const float* par
                                        momentum, sv, sv + W, sv + 2 * W, sv + 3 * W));
       }
       BLH_TRY(launch_bn_apply_train(s, ws.Z[i], sv + 2 * W, sv + 3 * W, skip, ws.A[i], batch, W,
-                                    layer_drop(drop, i, batch, W), nbt + i));
+                                    layer_drop(drop, i, batch, W), nbt + i, ws.amax_A[i]));
     } else {
       BLH_TRY(launch_bn_apply_eval(s, ws.Z[i], params + h.gamma, params + h.beta, rm, rv, skip,
-                                   ws.A[i], batch, W));
+                                   ws.A[i], batch, W, ws.amax_A[i]));
     }
   }
   // decode (model/bilinear.py:39): N = 48 gives only B/128 output tiles, so the reduction
@@ -295,11 +318,16 @@ static int forward_impl(const blh_model_desc* d, hipStream_t s, const float* par
 // grads_finish launch at the end of backward; otherwise they are summed right away.
 static int wgrad(int dtype, hipStream_t s, GemmTile tile, const float* dZ, int64_t ld_dz, int M,
                  const float* act, int64_t ld_act, int N, int64_t batch, int64_t tiles,
-                 float* slabs, float* out, GradRegion* region) {
+                 float* slabs, float* out, GradRegion* region, const float* amax_dz = nullptr,
+                 const float* amax_act = nullptr, int amax_parts = 0) {
   const Splits sp = pick_splits(batch, tiles);
   GemmParams g{};
   g.A = dZ; g.lda = ld_dz;
   g.B = act; g.ldb = ld_act;
+  if (amax_dz && amax_act) {   // gemm_dtype 3
+    g.a_amax = amax_dz; g.a_namax = amax_parts;
+    g.b_amax = amax_act; g.b_namax = amax_parts;
+  }
   g.M = M; g.N = N; g.K = (int)batch; g.k_per_split = sp.k_per;
   g.ldc = N;
   if (region) { region->slabs = nullptr; region->splits = 0; }
@@ -439,10 +467,11 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
     float* dzbuf = (two && (i & 1)) ? ws.dZ2 : ws.dZ;
     if (two && i + 2 <= nh - 1)   // wgrad(i+2) read this dZ buffer
       BLH_HIP_TRY(hipStreamWaitEvent(s, g_side.ev_w[i + 2], 0));
+    float* dz_amax = ws.amax_dZ[(two && (i & 1)) ? 1 : 0];
     BLH_TRY(launch_bn_bwd_apply(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W,
                                 params + h.gamma, dg, db, dzbuf,
                                 ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W, ds,
-                                norm_batch));
+                                norm_batch, dz_amax));
     BLH_TRY(fork(i));
     // Linear: db = colsum(dZ); dW = dZ^T a_in; d a_in = dZ W
     // (data parallel: the bucket hook needs this stage's bias gradient now; otherwise all
@@ -458,13 +487,18 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
     } else {
       BLH_TRY(wgrad(d->gemm_dtype, s2, TILE_128x128, dzbuf, W, W, ws.A[i - 1], W, W, batch,
                     ceil_div(W, 128) * ceil_div(W, 128), defer ? ws.stage_slabs[i] : ws.slabs,
-                    grads + h.w, defer ? &wreg[i] : nullptr));
+                    grads + h.w, defer ? &wreg[i] : nullptr, dz_amax, ws.amax_A[i - 1],
+                    ws.amax_parts));
       BLH_TRY(wdone(i));
       GemmParams g{};
       g.A = dzbuf; g.lda = W;
       g.B = params + h.w; g.ldb = W;
       g.M = (int)batch; g.N = W; g.K = W; g.k_per_split = W;
       g.ldc = W;
+      if (dz_amax && ws.amax_W) {   // gemm_dtype 3
+        g.a_amax = dz_amax; g.a_namax = ws.amax_parts;
+        g.b_amax = ws.amax_W + (int64_t)i * WAMAX_PARTS; g.b_namax = WAMAX_PARTS;
+      }
       const Splits ds2 = small_m_splits(batch, W, W);
       float* dst = first_of_block ? ws.G0 : ws.G1;
       if (ds2.splits > 1) {
@@ -914,6 +948,42 @@ int blh_gemm_bf16x3(void* stream, const float* A, int64_t lda, int32_t a_kmajor,
                     int64_t ldadd) {
   return gemm_entry(2, stream, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, splits, bias,
                     addend, ldadd);
+}
+
+int64_t blh_gemm_fp16x2_workspace_bytes(void) { return 2 * WAMAX_PARTS * (int64_t)sizeof(float); }
+
+int blh_gemm_fp16x2(void* stream, const float* A, int64_t lda, int32_t a_kmajor, const float* B,
+                    int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc, int64_t M, int64_t N,
+                    int64_t K, int32_t splits, const float* bias, const float* addend,
+                    int64_t ldadd, void* workspace, int32_t maxima_ready) {
+  if (!A || !B || !C || !workspace || M <= 0 || N <= 0 || K <= 0 || splits < 1)
+    return BLH_ERR_INVALID_ARGUMENT;
+  if (bias && addend) return BLH_ERR_INVALID_ARGUMENT;
+  if (splits > 1 && (bias || addend)) return BLH_ERR_INVALID_ARGUMENT;
+  // dense operands only (the maxima are taken over M*K and N*K contiguous floats)
+  if (lda != (a_kmajor ? M : K) || ldb != (b_kmajor ? N : K)) return BLH_ERR_SHAPE;
+  if ((M * K) % 4 != 0 || (N * K) % 4 != 0) return BLH_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  if (!maxima_ready) {
+    BLH_TRY(launch_wamax(s, A, 0, 1, M * K, part));
+    BLH_TRY(launch_wamax(s, B, 0, 1, N * K, part + WAMAX_PARTS));
+  }
+  GemmParams g{};
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.M = (int)M; g.N = (int)N; g.K = (int)K;
+  g.k_per_split = (splits > 1) ? (int)round_up(ceil_div(K, splits), 32) : (int)K;
+  if (splits > 1 && (int64_t)g.k_per_split * (splits - 1) >= K) return BLH_ERR_SHAPE;
+  g.c_split_stride = M * ldc;
+  g.bias = bias; g.addend = addend; g.ldadd = ldadd;
+  g.a_amax = part; g.a_namax = WAMAX_PARTS;
+  g.b_amax = part + WAMAX_PARTS; g.b_namax = WAMAX_PARTS;
+  const int epi = bias ? EPI_BIAS : (addend ? EPI_ADD : EPI_STORE);
+  GemmTile tile = TILE_128x128;
+  if (N <= 32) tile = TILE_128x32;
+  else if (N <= 64) tile = TILE_128x64;
+  else if (M <= 64) tile = TILE_64x128;
+  return launch_gemm(s, tile, a_kmajor ? KROW : ROWK, b_kmajor ? KROW : ROWK, epi, g, splits, 3);
 }
 
 void* blh_backward_side_stream(void) {

@@ -49,6 +49,9 @@ struct GemmParams {
   int64_t ldadd;
   float* stat_part;         // [tiles_m][2][N]  (mean, M2) of each BM-row tile
   float* loss_part;         // diagnostic builds only: STAMP output (tools/gemm_bench)
+  // gemm_dtype 3 (fp16 two-piece split): max |value| partials of each operand tensor
+  const float* a_amax; int a_namax;
+  const float* b_amax; int b_namax;
 };
 
 enum GemmTile : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_128x32 = 3 };
@@ -56,7 +59,8 @@ enum GemmTile : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_1
 // number of BM-row tiles the EPI_BIAS_STATS epilogue produces partials for
 int gemm_stat_tile_rows(GemmTile tile);
 int gemm_grid_blocks(GemmTile tile, int M, int N);
-// dtype 0: exact fp32 MFMA; 1: operands rounded to bf16 on load, bf16 MFMA, fp32 accumulate
+// dtype 0: exact fp32 MFMA; 1: operands rounded to bf16 on load, bf16 MFMA, fp32 accumulate;
+// 2: bf16x3 split; 3: fp16x2 split (needs p.a_amax / p.b_amax, else falls back to dtype 2)
 int launch_gemm(hipStream_t s, GemmTile tile, int la, int lb, int epi, const GemmParams& p,
                 int splits, int dtype = 0);
 
@@ -90,13 +94,20 @@ int launch_bn_fwd_finalize(hipStream_t s, const float* stat_part, int tiles, int
                            float* scale, float* shift);
 // A = dropout(relu(Z*scale+shift)) (+ skip)
 // (nbt, if not null, is incremented once: num_batches_tracked of this BN layer)
+// gemm_dtype 3: the streaming BatchNorm kernels can emit max |value| partials of what they write
+// (one per wave: ew_num_amax_parts() floats), from which the fp16-split GEMM picks its scale
+int ew_num_amax_parts(int64_t batch, int W);
+static constexpr int WAMAX_PARTS = 64;
+int launch_wamax(hipStream_t s, const float* W, int64_t w_stride, int layers, int64_t count,
+                 float* part);
 int launch_bn_apply_train(hipStream_t s, const float* Z, const float* scale, const float* shift,
                           const float* skip, float* A, int64_t batch, int W,
-                          const DropoutSrc& drop, int64_t* nbt);
+                          const DropoutSrc& drop, int64_t* nbt, float* amax_part = nullptr);
 // eval: scale/shift from running stats, no dropout
 int launch_bn_apply_eval(hipStream_t s, const float* Z, const float* gamma, const float* beta,
                          const float* running_mean, const float* running_var,
-                         const float* skip, float* A, int64_t batch, int W);
+                         const float* skip, float* A, int64_t batch, int W,
+                         float* amax_part = nullptr);
 // backward pass 1: partial column sums of dY and dY*zhat
 int launch_bn_bwd_reduce(hipStream_t s, const float* dA, const float* Z, const float* scale,
                          const float* shift, const float* mean, const float* invstd,
@@ -109,7 +120,7 @@ int launch_bn_bwd_apply(hipStream_t s, const float* dA, const float* Z, const fl
                         const float* shift, const float* mean, const float* invstd,
                         const float* gamma, const float* dgamma, const float* dbeta, float* dZ,
                         float* dz_colsum_part, int64_t batch, int W, const DropoutSrc& drop,
-                        int64_t norm_batch);
+                        int64_t norm_batch, float* amax_part = nullptr);
 // SyncBN: local fp64 column sums [sum z | sum z^2] -> (host all-reduce) -> finalize
 int launch_bn_fwd_local_sums(hipStream_t s, const float* stat_part, int tiles, int tile_rows,
                              int64_t batch, int W, double* sums);

@@ -23,6 +23,18 @@ int ew_num_row_chunks(int64_t batch) { return (int)ceil_div(batch, ew_row_chunk(
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// max |v| of a float4, folded into m
+__device__ __forceinline__ float amax4(float m, float4 v) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+// one partial per wave (all 64 lanes must be active): part[wave_global]
+__device__ __forceinline__ void wave_amax_store(float m, float* __restrict__ part) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0)
+    part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (EW_THREADS / 64) + (threadIdx.x >> 6)] = m;
+}
+
 struct DropState {
   Philox128 patch;
 };
@@ -172,18 +184,20 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ running_mean, const float* __restrict__ running_var,
     const float* __restrict__ skip, float* __restrict__ A, int64_t batch, int W, int row_chunk,
-    DropoutSrc drop, int64_t* nbt) {
+    DropoutSrc drop, int64_t* nbt, float* __restrict__ amax_part) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col = blockIdx.x * EW_COLS_PER_BLOCK + lane * 4;
   if (TRAIN && nbt && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) nbt[0] += 1;
-  if (col >= W) return;
+  float am = 0.f;
+  const bool okc = col < W;        // (no early return: the amax reduction needs whole waves)
+  const int cc = okc ? col : 0;
   float4 sc, sh;
   if (TRAIN) {
-    sc = ld4(scale + col);
-    sh = ld4(shift + col);
+    sc = ld4(scale + cc);
+    sh = ld4(shift + cc);
   } else {
-    const float4 g = ld4(gamma + col), b = ld4(beta + col), rm = ld4(running_mean + col),
-                 rv = ld4(running_var + col);
+    const float4 g = ld4(gamma + cc), b = ld4(beta + cc), rm = ld4(running_mean + cc),
+                 rv = ld4(running_var + cc);
     sc.x = g.x * (1.0f / sqrtf(rv.x + BN_EPS)); sc.y = g.y * (1.0f / sqrtf(rv.y + BN_EPS));
     sc.z = g.z * (1.0f / sqrtf(rv.z + BN_EPS)); sc.w = g.w * (1.0f / sqrtf(rv.w + BN_EPS));
     sh.x = b.x - rm.x * sc.x; sh.y = b.y - rm.y * sc.y;
@@ -191,7 +205,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(
   }
   const int64_t r0 = (int64_t)blockIdx.y * row_chunk;
   const int64_t r1 = min(batch, r0 + row_chunk);
-  for (int64_t base = r0; base < r1; base += PATCH_ROWS) {
+  for (int64_t base = r0; okc && base < r1; base += PATCH_ROWS) {
     float4 z[ROWS_PER_LANE], k[ROWS_PER_LANE];
 #pragma unroll
     for (int i = 0; i < ROWS_PER_LANE; ++i) {
@@ -211,32 +225,40 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(
         a.z = (nib & 4u) ? a.z * 2.f : 0.f; a.w = (nib & 8u) ? a.w * 2.f : 0.f;
       }
       a.x += k[i].x; a.y += k[i].y; a.z += k[i].z; a.w += k[i].w;
-      if (r < batch) st4(A + r * W + col, a);
+      if (r < batch) {
+        st4(A + r * W + col, a);
+        am = amax4(am, a);
+      }
     }
   }
+  if (amax_part) wave_amax_store(am, amax_part);
 }
 
 static dim3 ew_grid(int64_t batch, int W) {
   return dim3((unsigned)ceil_div(W, EW_COLS_PER_BLOCK), (unsigned)ew_num_row_chunks(batch));
 }
 
+int ew_num_amax_parts(int64_t batch, int W) {
+  return (int)(ceil_div(W, EW_COLS_PER_BLOCK) * ew_num_row_chunks(batch) * (EW_THREADS / 64));
+}
+
 int launch_bn_apply_train(hipStream_t s, const float* Z, const float* scale, const float* shift,
                           const float* skip, float* A, int64_t batch, int W,
-                          const DropoutSrc& drop, int64_t* nbt) {
+                          const DropoutSrc& drop, int64_t* nbt, float* amax_part) {
   hipLaunchKernelGGL(bn_apply_kernel<true>, ew_grid(batch, W), dim3(EW_THREADS), 0, s, Z, scale,
                      shift, nullptr, nullptr, nullptr, nullptr, skip, A, batch, W,
-                     ew_row_chunk(batch), drop, nbt);
+                     ew_row_chunk(batch), drop, nbt, amax_part);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
 
 int launch_bn_apply_eval(hipStream_t s, const float* Z, const float* gamma, const float* beta,
                          const float* running_mean, const float* running_var, const float* skip,
-                         float* A, int64_t batch, int W) {
+                         float* A, int64_t batch, int W, float* amax_part) {
   DropoutSrc none{nullptr, 0, 0, 0, 0, nullptr};
   hipLaunchKernelGGL(bn_apply_kernel<false>, ew_grid(batch, W), dim3(EW_THREADS), 0, s, Z,
                      nullptr, nullptr, gamma, beta, running_mean, running_var, skip, A, batch, W,
-                     ew_row_chunk(batch), none, nullptr);
+                     ew_row_chunk(batch), none, nullptr, amax_part);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
@@ -395,7 +417,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
     const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ dgamma,
     const float* __restrict__ dbeta, float* __restrict__ dZ, float* __restrict__ colsum_part,
-    int64_t batch, int W, int row_chunk, DropoutSrc drop, int64_t norm_batch) {
+    int64_t batch, int W, int row_chunk, DropoutSrc drop, int64_t norm_batch,
+    float* __restrict__ amax_part) {
   __shared__ __attribute__((aligned(16))) float red[4 * 256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col0 = blockIdx.x * EW_COLS_PER_BLOCK;
@@ -411,6 +434,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
   const int64_t r0 = (int64_t)blockIdx.y * row_chunk;
   const int64_t r1 = min(batch, r0 + row_chunk);
   float4 cs = make_float4(0, 0, 0, 0);
+  float am = 0.f;
   if (ok)
     for (int64_t base = r0; base < r1; base += PATCH_ROWS) {
       float4 z[ROWS_PER_LANE], g[ROWS_PER_LANE];
@@ -433,21 +457,23 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
         if (r < batch) {
           cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
           st4(dZ + r * W + col, o);
+          am = amax4(am, o);
         }
       }
     }
   block_colsum_store(cs, red, colsum_part + (int64_t)blockIdx.y * W, col0, W);
+  if (amax_part) wave_amax_store(am, amax_part);
 }
 
 int launch_bn_bwd_apply(hipStream_t s, const float* dA, const float* Z, const float* scale,
                         const float* shift, const float* mean, const float* invstd,
                         const float* gamma, const float* dgamma, const float* dbeta, float* dZ,
                         float* dz_colsum_part, int64_t batch, int W, const DropoutSrc& drop,
-                        int64_t norm_batch) {
+                        int64_t norm_batch, float* amax_part) {
   (void)gamma;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, ew_grid(batch, W), dim3(EW_THREADS), 0, s, dA, Z, scale,
                      shift, mean, invstd, dgamma, dbeta, dZ, dz_colsum_part, batch, W,
-                     ew_row_chunk(batch), drop, norm_batch);
+                     ew_row_chunk(batch), drop, norm_batch, amax_part);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
@@ -1235,6 +1261,39 @@ int launch_grads_finish(hipStream_t s, float* grads, GradRegions& R, int64_t tot
   hipLaunchKernelGGL(grads_finish_kernel, dim3(blocks), dim3(256), 0, s, grads, R, sumsq_part);
   BLH_HIP_TRY(hipGetLastError());
   if (nparts) *nparts = blocks;
+  return BLH_OK;
+}
+
+}  // namespace blh
+
+// ---------------------------------------------------------------------------
+// gemm_dtype = 3 (fp16 two-piece split): max |w| of each hidden Linear weight, as 64 partials
+// per layer that the GEMM reduces in its prologue.  W [layers][count] with layer stride w_stride.
+// ---------------------------------------------------------------------------
+namespace blh {
+
+__global__ __launch_bounds__(256) void wamax_kernel(const float* __restrict__ W, int64_t w_stride,
+                                                    int64_t count, float* __restrict__ part) {
+  __shared__ float red[4];
+  const float* __restrict__ Wl = W + (int64_t)blockIdx.y * w_stride;
+  float m = 0.f;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < count; i += (int64_t)gridDim.x * 1024)
+    m = amax4(m, *reinterpret_cast<const float4*>(Wl + i));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+int launch_wamax(hipStream_t s, const float* W, int64_t w_stride, int layers, int64_t count,
+                 float* part) {
+  if (layers <= 0) return BLH_OK;
+  if (count % 4 != 0) return BLH_ERR_SHAPE;
+  hipLaunchKernelGGL(wamax_kernel, dim3(WAMAX_PARTS, (unsigned)layers), dim3(256), 0, s, W, w_stride,
+                     count, part);
+  BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
 

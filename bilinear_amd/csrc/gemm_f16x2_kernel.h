@@ -1,12 +1,25 @@
-// PROTOTYPE (tools only, not part of the library): fp32 GEMM from a TWO-piece fp16 split,
-// x = hi + lo with hi = RNE_f16(x), lo = RNE_f16(x - hi)  (|x - hi - lo| <= 2^-24 |x| inside
-// fp16's exponent range), three v_mfma_f32_32x32x16_f16 per product (lo*hi + hi*lo + hi*hi)
-// instead of the six bf16 MFMAs of gemm_split_kernel.h, and 4 B of LDS per value instead of 6.
-// No range management: operands must sit in fp16's comfortable range (|x| roughly 2^-6 .. 2^12),
-// which a shipped version would have to arrange with per-tensor power-of-two scales.
-// Same tile / wave / phase structure as gemm_split_kernel.h (whose TileSplit loader it reuses).
+// fp32 GEMM from a TWO-piece fp16 split (gemm_dtype = 3, "fp16x2"): fp32 accuracy on the f16
+// matrix cores of gfx950 at half the MFMA work of the bf16 split.
+//
+//   Every operand value is scaled by a per-tensor power of two and written as  x s = hi + lo,
+//   hi = RNE_f16(x s), lo = RNE_f16(x s - hi)  (the residual is exact in fp32; hi + lo reproduce
+//   x s to 2^-24 relative while lo stays a normal fp16 number, and to 2^-25 of the tensor's scaled
+//   maximum below that), and a product is accumulated in fp32 from THREE v_mfma_f32_32x32x16_f16:
+//   lo*hi + hi*lo + hi*hi  (the dropped lo*lo is below 2^-24 |a b|).  Against the bf16 split
+//   (gemm_split_kernel.h): 3 MFMAs instead of 6, 7 VALU per value pair instead of 11, 4 B of LDS
+//   per value instead of 6.
+//
+//   Range: fp16 has 5 exponent bits, so each operand tensor gets a scale 2^e that puts its largest
+//   magnitude in [2^12, 2^13).  The maxima come as partials from the kernels that produce the
+//   tensors (bn_apply / bn_bwd_apply: one per wave; wamax_kernel for the weights) and every
+//   workgroup reduces them in its prologue — same input, same scale, deterministic.  The scale is
+//   applied for free inside the split (v_fma_mix: f16(x*s), then x*s - hi by v_fma_f32) and
+//   removed exactly in the epilogue (acc * 2^-(ea+eb)).  A tensor of zeros gets scale 1.
+//
+// Tile / wave / phase structure, loader (TileSplit) and LDS image (two planes per operand):
+// gemm_split_kernel.h.
 #pragma once
-#include "../gemm_split_kernel.h"
+#include "gemm_split_kernel.h"
 
 namespace blh {
 
@@ -52,12 +65,39 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // ---- per-tensor scales from the amax partials (identical in every workgroup) -------------
+  float red_a = 0.f, red_b = 0.f;
+  for (int i = tid; i < p.a_namax; i += NT) red_a = fmaxf(red_a, p.a_amax[i]);
+  for (int i = tid; i < p.b_namax; i += NT) red_b = fmaxf(red_b, p.b_amax[i]);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    red_a = fmaxf(red_a, __shfl_xor(red_a, o));
+    red_b = fmaxf(red_b, __shfl_xor(red_b, o));
+  }
+  if (lane == 0) { smem[wave] = red_a; smem[4 + wave] = red_b; }
+  __syncthreads();
+  red_a = fmaxf(fmaxf(smem[0], smem[1]), fmaxf(smem[2], smem[3]));
+  red_b = fmaxf(fmaxf(smem[4], smem[5]), fmaxf(smem[6], smem[7]));
+  __syncthreads();
+  // e = 12 - floor(log2(amax)), clamped; amax == 0 (or denormal) -> e = 0
+  auto scale_exp = [](float amax) {
+    const int ex = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+    return ex == 0 ? 0 : max(-100, min(100, 12 - (ex - 127)));
+  };
+  const int ea = __builtin_amdgcn_readfirstlane(scale_exp(red_a));
+  const int eb = __builtin_amdgcn_readfirstlane(scale_exp(red_b));
+  const float sa = __uint_as_float((uint32_t)(ea + 127) << 23);
+  const float sb = __uint_as_float((uint32_t)(eb + 127) << 23);
+  // (ea + eb can exceed the exponent range of one float: unscale in two exact steps)
+  const float un_a = __uint_as_float((uint32_t)(127 - ea) << 23);
+  const float un_b = __uint_as_float((uint32_t)(127 - eb) << 23);
+
   IOA ioa;
   IOB iob;
   ioa.init(p.A, p.lda, m0, p.M, kz0, k_end, tid);
   iob.init(p.B, p.ldb, n0, p.N, kz0, k_end, tid);
 
-  auto store_all = [&](auto io, const f32x4_t (&regs)[4], __bf16* dst) {
+  auto store_all = [&](auto io, const f32x4_t (&regs)[4], __bf16* dst, float sc) {
     using IO = decltype(io);
 #pragma unroll
     for (int put = 0; put < 4; ++put) {
@@ -65,8 +105,8 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(GemmParams p) {
       IO::pair(regs, 2 * put, a, b);
       IO::pair(regs, 2 * put + 1, c, d);
       uint32_t h0, l0, h1, l1;
-      split2_f16(a, b, h0, l0);
-      split2_f16(c, d, h1, l1);
+      split2_f16(a * sc, b * sc, h0, l0);
+      split2_f16(c * sc, d * sc, h1, l1);
       __bf16* at = IO::row_ptr(dst, put, tid);
       *reinterpret_cast<uint2*>(at) = make_uint2(h0, h1);
       *reinterpret_cast<uint2*>(at + IO::PLANE) = make_uint2(l0, l1);
@@ -77,11 +117,11 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(GemmParams p) {
   iob.load(rb[0], kz0, k_end);
   ioa.load(ra[1], kz0 + SBK, k_end);
   iob.load(rb[1], kz0 + SBK, k_end);
-  store_all(ioa, ra[0], lds);
-  store_all(iob, rb[0], lds + A_EL);
+  store_all(ioa, ra[0], lds, sa);
+  store_all(iob, rb[0], lds + A_EL, sb);
   ioa.load(ra[0], kz0 + 2 * SBK, k_end);
   iob.load(rb[0], kz0 + 2 * SBK, k_end);
-  store_all(ioa, ra[1], lds + STAGE);
+  store_all(ioa, ra[1], lds + STAGE, sa);
   __syncthreads();
 
   const int h = lane >> 5, lr = lane & 31;
@@ -109,7 +149,7 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(GemmParams p) {
   // of the next k-step, the split of 8 value pairs: slot s < 8 carries stage 0 of pair s (5 VALU)
   // and stage 1 of pair s - 1 (1 VALU)
   auto phase = [&](const Frags& fc, Frags& fn, const __bf16* rA, int kkn, auto io,
-                   const f32x4_t (&regs)[4], __bf16* dst) {
+                   const f32x4_t (&regs)[4], __bf16* dst, float sc) {
     using IO = decltype(io);
     constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
     uint32_t hh[2], ll[2];
@@ -135,13 +175,14 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(GemmParams p) {
       }
       if (s < 8) {   // stage 0 of pair s: hi piece and the exact residuals
         IO::pair(regs, s, xs[s & 1], ys[s & 1]);
-        asm volatile(
-            "v_cvt_pk_f16_f32 %0, %1, %2\n\t"
+        asm volatile(   // hi = f16(x s) (RNE), residual x s - hi (exact)
+            "v_fma_mixlo_f16 %0, %1, %5, 0\n\t"
+            "v_fma_mixhi_f16 %0, %2, %5, 0\n\t"
             "v_cvt_f32_f16 %3, %0\n\t"
             "v_cvt_f32_f16_sdwa %4, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-            "v_sub_f32 %1, %1, %3\n\t"
-            "v_sub_f32 %2, %2, %4"
-            : "=&v"(hh[s & 1]), "+v"(xs[s & 1]), "+v"(ys[s & 1]), "=&v"(t0), "=&v"(t1) : : "memory");
+            "v_fma_f32 %1, %1, %5, -%3\n\t"
+            "v_fma_f32 %2, %2, %5, -%4"
+            : "=&v"(hh[s & 1]), "+v"(xs[s & 1]), "+v"(ys[s & 1]), "=&v"(t0), "=&v"(t1) : "s"(sc) : "memory");
         read_frag(fn, rA, kkn, s);
       }
     }
@@ -161,14 +202,14 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(GemmParams p) {
 #pragma unroll
     for (int r = 0; r < IOB::REGS; ++r) asm volatile("" : "+v"(rb[P ^ 1][r]));
     fence();
-    phase(f0, f1, sA, 1, iob, rb[P ^ 1], nA + A_EL);
+    phase(f0, f1, sA, 1, iob, rb[P ^ 1], nA + A_EL, sb);
     __syncthreads();
     fence();
     iob.load(rb[P ^ 1], k3, k_end);
 #pragma unroll
     for (int r = 0; r < IOA::REGS; ++r) asm volatile("" : "+v"(ra[P][r]));
     fence();
-    phase(f1, f0, nA, 0, ioa, ra[P], sA);
+    phase(f1, f0, nA, 0, ioa, ra[P], sA, sa);
   };
   for (int kt = 0; kt < nkt; kt += 2) {
     iter(IntC<0>{}, kt);
@@ -176,6 +217,12 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(GemmParams p) {
   }
   __syncthreads();
 
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] * un_a) * un_b;
   gemm_epilogue<BM, BN, 2, 2, EPI>(acc, p, C, smem, m0, n0, tile_m, true);
 }
 

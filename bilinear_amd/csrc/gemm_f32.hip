@@ -4,6 +4,7 @@
 #include "gemm_bf16_kernel.h"
 #include "gemm_f32_kernel.h"
 #include "gemm_split_kernel.h"
+#include "gemm_f16x2_kernel.h"
 
 namespace blh {
 
@@ -155,6 +156,38 @@ static int launch_split_128x128(hipStream_t s, int la, int lb, int epi, const Ge
 }
 #undef BLH_CASE3
 
+// ---- fp16x2 split instantiations (gemm_dtype = 3) ------------------------------------------
+template <int LA, int LB, int EPI>
+static int launch_cfg_f16x2(hipStream_t s, const GemmParams& p, int splits) {
+  constexpr size_t lds = gemm_f16x2_lds_bytes<128, 128>();
+  static bool attr_set = false;
+  auto kern = gemm_f16x2_kernel<LA, LB, EPI>;
+  if (!attr_set) {
+    BLH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int tiles = (int)(ceil_div(p.M, 128) * ceil_div(p.N, 128));
+  hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(256), lds, s, p);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+#define BLH_CASE4(LA_, LB_, EPI_) \
+  if (la == LA_ && lb == LB_ && epi == EPI_) return launch_cfg_f16x2<LA_, LB_, EPI_>(s, p, splits);
+
+static int launch_f16x2_128x128(hipStream_t s, int la, int lb, int epi, const GemmParams& p,
+                                int splits) {
+  BLH_CASE4(ROWK, ROWK, EPI_BIAS_STATS)
+  BLH_CASE4(ROWK, ROWK, EPI_BIAS)
+  BLH_CASE4(ROWK, ROWK, EPI_STORE)
+  BLH_CASE4(ROWK, KROW, EPI_STORE)
+  BLH_CASE4(ROWK, KROW, EPI_ADD)
+  BLH_CASE4(KROW, KROW, EPI_STORE)
+  return BLH_ERR_INVALID_ARGUMENT;
+}
+#undef BLH_CASE4
+
 int gemm_stat_tile_rows(GemmTile tile) { return tile == TILE_64x128 ? 64 : 128; }
 
 int gemm_grid_blocks(GemmTile tile, int M, int N) {
@@ -175,7 +208,13 @@ int launch_gemm(hipStream_t s, GemmTile tile, int la, int lb, int epi, const Gem
   if (lb == KROW && p.N % 4 != 0) return BLH_ERR_SHAPE;
   if (splits > 1 && (p.k_per_split % BK != 0)) return BLH_ERR_SHAPE;
   if (dtype == 1) return launch_bf16(s, tile, la, lb, epi, p, splits);
-  if (dtype == 2 && tile == TILE_128x128) {   // combinations not built in split form: exact fp32
+  if (dtype == 3 && tile == TILE_128x128 && p.a_amax && p.b_amax && p.a_namax > 0 && p.b_namax > 0) {
+    const int rc = launch_f16x2_128x128(s, la, lb, epi, p, splits);
+    if (rc != BLH_ERR_INVALID_ARGUMENT) return rc;
+  }
+  // (fp16x2 without operand maxima — stand-alone stages, the encode / decode contractions — runs
+  //  on the range-safe bf16 split)
+  if (dtype >= 2 && tile == TILE_128x128) {   // combinations not built in split form: exact fp32
     const int rc = launch_split_128x128(s, la, lb, epi, p, splits);
     if (rc != BLH_ERR_INVALID_ARGUMENT) return rc;
   }

@@ -22,7 +22,7 @@ from ..optim import Adam
 
 __all__ = ["heavy_linear", "BilinearUnit", "Bilinear", "load"]
 
-GEMM_DTYPES = {"fp32": 0, "bf16": 1, "bf16x3": 2}
+GEMM_DTYPES = {"fp32": 0, "bf16": 1, "bf16x3": 2, "fp16x2": 3}
 
 
 class _HeavyStageFunction(torch.autograd.Function):

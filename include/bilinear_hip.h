@@ -73,7 +73,13 @@ typedef struct {
                               product is accumulated in fp32 from six bf16 MFMAs (the dropped
                               terms are below 2^-25 |a b|, under the rounding of an fp32
                               multiply); the 1024-wide Linears only, the skinny contractions
-                              stay on the exact fp32 MFMA                              */
+                              stay on the exact fp32 MFMA;
+                           3: "fp16x2" — the same idea with TWO fp16 pieces and three f16 MFMAs
+                              per product; every operand tensor is scaled by a power of two taken
+                              from its largest magnitude (gathered by the kernels that produce
+                              it), so fp16's exponent range is never left; contractions whose
+                              operands carry no such maximum (encode, decode, stand-alone
+                              stages) run as in mode 2                                   */
 } blh_model_desc;
 
 /* Number of heavy_linear stages = 1 + 2*num_blocks (encode + hidden). */
@@ -290,6 +296,18 @@ int blh_gemm_bf16x3(void* stream, const float* A, int64_t lda, int32_t a_kmajor,
                     int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc, int64_t M, int64_t N,
                     int64_t K, int32_t splits, const float* bias, const float* addend,
                     int64_t ldadd);
+/* Same contraction in gemm_dtype = 3 arithmetic (two-piece fp16 split with per-operand power-of-two
+ * scales, three f16 MFMAs per product, fp32 accumulate).  The entry point takes the maxima of the
+ * two (dense: lda / ldb = the contiguous extent) operands itself, into `workspace`
+ * (blh_gemm_fp16x2_workspace_bytes() bytes); inside the network they come for free from the
+ * kernels that produce the operands (maxima_ready != 0: `workspace` already holds them from an
+ * earlier call on the same operands).  Shapes outside the 128x128 split kernel run as in
+ * blh_gemm_bf16x3.                                                                             */
+int64_t blh_gemm_fp16x2_workspace_bytes(void);
+int blh_gemm_fp16x2(void* stream, const float* A, int64_t lda, int32_t a_kmajor, const float* B,
+                    int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc, int64_t M, int64_t N,
+                    int64_t K, int32_t splits, const float* bias, const float* addend,
+                    int64_t ldadd, void* workspace, int32_t maxima_ready);
 int blh_sum_slabs(void* stream, const float* slabs, int64_t count, int32_t splits, float* out);
 /* The forward kernel of one heavy_linear exactly as blh_forward_train launches it:
  * Z[M,N] = A[M,K] W[N,K]^T + bias, plus per-128-row-tile column statistics

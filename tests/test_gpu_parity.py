@@ -118,6 +118,78 @@ def test_bf16x3_gemm_error_is_fp32_level(native, M, N, K, ak, bk, splits):
     assert errs["blh_gemm_bf16x3"][0] < 2e-6          # a dropped middle product would show as ~1e-5
 
 
+def _gemm_fp16x2(native, st, a, A_ld, ak, b, B_ld, bk, c, N, M, K, splits, bias=None, addend=None, ldadd=0):
+    dev = a.device
+    ws = torch.empty(native.blh_gemm_fp16x2_workspace_bytes(), dtype=torch.uint8, device=dev)
+    return native.blh_gemm_fp16x2(st, a.data_ptr(), A_ld, ak, b.data_ptr(), B_ld, bk, c.data_ptr(), N, M, N, K,
+                                  splits, bias, addend, ldadd, ws.data_ptr(), 0)
+
+
+@pytest.mark.parametrize("scale_a,scale_b", [(1.0, 1.0), (3e-7, 0.04), (2.0e4, 1e-3), (1e-12, 1e9),
+                                             (7e4, 7e4)])
+@pytest.mark.parametrize("M,N,K,ak,bk,splits", [(512, 1024, 1024, 0, 0, 1), (384, 1024, 1024, 0, 1, 1),
+                                                (1024, 1024, 4096, 1, 1, 4), (300, 256, 96, 0, 0, 1)])
+def test_fp16x2_gemm_error_is_fp32_level_at_any_scale(native, M, N, K, ak, bk, splits, scale_a, scale_b):
+    """gemm_dtype = 3: two fp16 pieces per value and a per-operand power-of-two scale taken from
+    the operand's largest magnitude.  Gradient-sized (1e-7), activation-sized and huge operands,
+    each with four decades of spread inside the tensor, must come out with the error of the
+    exact-fp32 MFMA kernel (measured on sum_k |a b|)."""
+    dev = _dev()
+    rng = np.random.RandomState(K + M + int(np.log10(scale_a) * 7))
+    shape_a, shape_b = ((K, M) if ak else (M, K)), ((K, N) if bk else (N, K))
+    A = (scale_a * rng.standard_normal(shape_a) * np.exp(2.0 * rng.standard_normal(shape_a))).astype(np.float32)
+    B = (scale_b * rng.standard_normal(shape_b) * np.exp(1.0 * rng.standard_normal(shape_b))).astype(np.float32)
+    A64, B64 = (A.T if ak else A).astype(np.float64), (B if bk else B.T).astype(np.float64)
+    ref, mag = A64 @ B64, np.abs(A64) @ np.abs(B64)
+    a, b = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    errs = {}
+    for entry in ("blh_gemm_f32", "fp16x2"):
+        c = torch.full((splits, M, N), float("nan"), device=dev)
+        if entry == "fp16x2":
+            rc = _gemm_fp16x2(native, st, a, A.shape[1], ak, b, B.shape[1], bk, c, N, M, K, splits)
+        else:
+            rc = native.blh_gemm_f32(st, a.data_ptr(), A.shape[1], ak, b.data_ptr(), B.shape[1], bk,
+                                     c.data_ptr(), N, M, N, K, splits, None, None, 0)
+        assert rc == 0, native.blh_status_string(rc)
+        torch.cuda.synchronize()
+        out = c.cpu().numpy().astype(np.float64).sum(axis=0)
+        assert np.isfinite(out).all(), entry
+        rel = np.abs(out - ref) / mag
+        errs[entry] = (rel.max(), np.sqrt((rel ** 2).mean()))
+    print("err / sum|ab|  fp32 MFMA: max %.2e rms %.2e | fp16x2: max %.2e rms %.2e" % (
+        errs["blh_gemm_f32"] + errs["fp16x2"]))
+    assert errs["fp16x2"][1] <= 1.5 * errs["blh_gemm_f32"][1]
+    assert errs["fp16x2"][0] <= 1.5 * errs["blh_gemm_f32"][0] + 1e-7
+    assert errs["fp16x2"][0] < 2e-6
+
+
+def test_fp16x2_gemm_zero_operand_and_epilogues(native):
+    dev = _dev()
+    rng = np.random.RandomState(11)
+    M, N, K = 260, 384, 96
+    A = (1e-5 * rng.standard_normal((M, K))).astype(np.float32)
+    Wt = rng.standard_normal((N, K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    add = rng.standard_normal((M, N)).astype(np.float32)
+    a, w = torch.from_numpy(A).to(dev), torch.from_numpy(Wt).to(dev)
+    bt, at = torch.from_numpy(bias).to(dev), torch.from_numpy(add).to(dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    c = torch.empty(M, N, device=dev)
+    assert _gemm_fp16x2(native, st, a, K, 0, w, K, 0, c, N, M, K, 1, bias=bt.data_ptr()) == 0
+    torch.cuda.synchronize()
+    _close(c.cpu().numpy(), A.astype(np.float64) @ Wt.T.astype(np.float64) + bias, 2e-5, "bias")
+    Bk = rng.standard_normal((K, N)).astype(np.float32)
+    bk = torch.from_numpy(Bk).to(dev)
+    assert _gemm_fp16x2(native, st, a, K, 0, bk, N, 1, at, N, M, K, 1, addend=at.data_ptr(), ldadd=N) == 0
+    torch.cuda.synchronize()
+    _close(at.cpu().numpy(), A.astype(np.float64) @ Bk.astype(np.float64) + add, 2e-5, "addend")
+    z = torch.zeros(M, K, device=dev)          # an all-zero operand: scale 1, exact zeros out
+    assert _gemm_fp16x2(native, st, z, K, 0, w, K, 0, c, N, M, K, 1) == 0
+    torch.cuda.synchronize()
+    assert float(c.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("entry", ["blh_gemm_f32", "blh_gemm_bf16x3"])
 def test_gemm_bias_and_addend(native, entry):
     dev = _dev()
@@ -147,7 +219,7 @@ def test_gemm_bias_and_addend(native, entry):
 # ----------------------------------------------------------------------------
 # module level against the reference's golden vectors
 # ----------------------------------------------------------------------------
-FP32_MODES = ["fp32", "bf16x3"]     # the two fp32-accurate GEMM paths: same tests, same tolerances
+FP32_MODES = ["fp32", "bf16x3", "fp16x2"]     # the fp32-accurate GEMM paths: same tests, same tolerances
 
 
 def _build(g, dev, num_blocks=2, width=1024, state=None, gemm_dtype="fp32"):
@@ -787,3 +859,37 @@ def test_device_dataset_feeds_training_and_metric():
         assert abs(per_action[k] - ref_sum[k] / (ref_cnt[k] * 16)) <= 1e-4 * per_action[k] + 1e-3
     tot = sum(ref_sum.values()) / (sum(ref_cnt.values()) * 16)
     assert abs(avg - tot) <= 1e-4 * tot + 1e-3
+
+
+@pytest.mark.parametrize("loss_scale,gamma_scale", [(1e-7, 1.0), (1e4, 1.0), (1.0, 300.0), (1e-5, 0.01)])
+def test_fp16x2_mode_keeps_fp32_accuracy_when_magnitudes_move(loss_scale, gamma_scale):
+    """Network level: tiny / huge gradients (loss scaled) and huge / tiny activations (BatchNorm
+    gamma, beta scaled) through gemm_dtype = "fp16x2" against the fp64 oracle, with the tolerance
+    of the exact path: the per-tensor scales must follow the magnitudes."""
+    dev = _dev()
+    nb, width, batch = 2, 1024, 640
+    st = O.init_state(321, nb, width)
+    rng = np.random.RandomState(5)
+    for k in st:
+        if k.endswith(".1.weight"):
+            st[k] = (gamma_scale * (1.0 + 0.2 * rng.standard_normal(st[k].shape))).astype(np.float32)
+        if k.endswith(".1.bias"):
+            st[k] = (gamma_scale * 0.1 * rng.standard_normal(st[k].shape)).astype(np.float32)
+    net, opt = _build(None, dev, nb, width, state={k: v.copy() for k, v in st.items()}, gemm_dtype="fp16x2")
+    x, t = O.synthetic_batch(5, batch)
+    masks = O.random_masks(9, batch, nb, width)
+    net.engine.set_dropout_masks(masks)
+    xt, tt = torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev)
+    pred = net(xt)
+    loss = torch.nn.functional.mse_loss(pred, tt) * loss_scale
+    loss.backward()
+    ref_pred, cache = O.forward(st, x, masks, training=True, dtype=np.float64)
+    ref_loss, dpred = O.mse_loss(ref_pred, t.astype(np.float64))
+    ref_grads = O.backward(st, cache, dpred * loss_scale, dtype=np.float64)
+    _close(pred.detach().cpu().numpy(), ref_pred, TIGHT, "pred")
+    for k, p in net.named_parameters():
+        if is_prebn_bias(k):
+            continue
+        g = p.grad.cpu().numpy()
+        assert np.isfinite(g).all(), k
+        _close(g, ref_grads[k], TIGHT * 3, "grad " + k)
