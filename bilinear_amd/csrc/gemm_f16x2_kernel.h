@@ -65,6 +65,33 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  IOA ioa;
+  IOB iob;
+  ioa.init(p.A, p.lda, m0, p.M, kz0, k_end, tid);
+  iob.init(p.B, p.ldb, n0, p.N, kz0, k_end, tid);
+
+  auto store_all = [&](auto io, const f32x4_t (&regs)[4], __bf16* dst, float sc) {
+    using IO = decltype(io);
+#pragma unroll
+    for (int put = 0; put < 4; ++put) {
+      float a, b, c, d;
+      IO::pair(regs, 2 * put, a, b);
+      IO::pair(regs, 2 * put + 1, c, d);
+      uint32_t h0, l0, h1, l1;
+      split2_f16(a * sc, b * sc, h0, l0);
+      split2_f16(c * sc, d * sc, h1, l1);
+      __bf16* at = IO::row_ptr(dst, put, tid);
+      *reinterpret_cast<uint2*>(at) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(at + IO::PLANE) = make_uint2(l0, l1);
+    }
+  };
+
+  ioa.load(ra[0], kz0, k_end);
+  iob.load(rb[0], kz0, k_end);
+  ioa.load(ra[1], kz0 + SBK, k_end);
+  iob.load(rb[1], kz0 + SBK, k_end);
+
+  // (the first two K tiles are already requested: the reduction below runs in their shadow)
   // ---- per-tensor scales from the amax partials (identical in every workgroup) -------------
   float red_a = 0.f, red_b = 0.f;
   for (int i = tid; i < p.a_namax; i += NT) red_a = fmaxf(red_a, p.a_amax[i]);
@@ -92,31 +119,6 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(GemmParams p) {
   const float un_a = __uint_as_float((uint32_t)(127 - ea) << 23);
   const float un_b = __uint_as_float((uint32_t)(127 - eb) << 23);
 
-  IOA ioa;
-  IOB iob;
-  ioa.init(p.A, p.lda, m0, p.M, kz0, k_end, tid);
-  iob.init(p.B, p.ldb, n0, p.N, kz0, k_end, tid);
-
-  auto store_all = [&](auto io, const f32x4_t (&regs)[4], __bf16* dst, float sc) {
-    using IO = decltype(io);
-#pragma unroll
-    for (int put = 0; put < 4; ++put) {
-      float a, b, c, d;
-      IO::pair(regs, 2 * put, a, b);
-      IO::pair(regs, 2 * put + 1, c, d);
-      uint32_t h0, l0, h1, l1;
-      split2_f16(a * sc, b * sc, h0, l0);
-      split2_f16(c * sc, d * sc, h1, l1);
-      __bf16* at = IO::row_ptr(dst, put, tid);
-      *reinterpret_cast<uint2*>(at) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(at + IO::PLANE) = make_uint2(l0, l1);
-    }
-  };
-
-  ioa.load(ra[0], kz0, k_end);
-  iob.load(rb[0], kz0, k_end);
-  ioa.load(ra[1], kz0 + SBK, k_end);
-  iob.load(rb[1], kz0 + SBK, k_end);
   store_all(ioa, ra[0], lds, sa);
   store_all(iob, rb[0], lds + A_EL, sb);
   ioa.load(ra[0], kz0 + 2 * SBK, k_end);
