@@ -26,33 +26,39 @@ def _free_port():
     return p
 
 
-def _make(dev):
+# (num_blocks, width, rows per rank, gemm_dtype).  The second configuration is large enough for
+# the ordinary (not split-K) GEMM path, i.e. the side-stream weight gradients + the grad-ready
+# hook that runs with the side stream current; the third runs it in the fp16x2 arithmetic.
+CONFIGS = [(NB, WIDTH, LOCAL_B, "fp32"), (1, 1024, 2048, "fp32"), (1, 1024, 2048, "fp16x2")]
+
+
+def _make(dev, cfg=CONFIGS[0]):
     import bilinear_amd
     torch.manual_seed(123)
-    net, opt, _, _ = bilinear_amd.load(dev, num_blocks=NB, width=WIDTH)
+    net, opt, _, _ = bilinear_amd.load(dev, num_blocks=cfg[0], width=cfg[1], gemm_dtype=cfg[3])
     net.train()
     net.engine.seed = 4242
     return net, opt
 
 
-def _data(dev):
+def _data(dev, cfg=CONFIGS[0]):
     g = torch.Generator().manual_seed(7)
-    x = torch.randn(2 * LOCAL_B, 32, generator=g).to(dev)
-    t = torch.randn(2 * LOCAL_B, 48, generator=g).to(dev)
+    x = torch.randn(2 * cfg[2], 32, generator=g).to(dev)
+    t = torch.randn(2 * cfg[2], 48, generator=g).to(dev)
     return x, t
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, cfg=CONFIGS[0]):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from bilinear_amd.dp import DataParallel
         dev = torch.device("cuda:0")
-        net, opt = _make(dev)
-        x, t = _data(dev)
+        net, opt = _make(dev, cfg)
+        x, t = _data(dev, cfg)
         dp = DataParallel(net, opt, bucket_floats=50000)
-        sl = slice(rank * LOCAL_B, (rank + 1) * LOCAL_B)
+        sl = slice(rank * cfg[2], (rank + 1) * cfg[2])
         for _ in range(2):
             pred, loss = dp.train_step(x[sl], t[sl])
         torch.cuda.synchronize()
@@ -63,9 +69,11 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_data_parallel_two_ranks_match_manual_average(tmp_path):
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: "%dx%d_b%d_%s" % c)
+def test_data_parallel_two_ranks_match_manual_average(tmp_path, cfg):
+    LOCAL_B = cfg[2]
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), cfg), nprocs=2, join=True)
     p0, p1 = np.load(tmp_path / "params0.npy"), np.load(tmp_path / "params1.npy")
     g0, g1 = np.load(tmp_path / "grads0.npy"), np.load(tmp_path / "grads1.npy")
     assert np.array_equal(p0, p1), "replicas diverged"
@@ -74,8 +82,8 @@ def test_data_parallel_two_ranks_match_manual_average(tmp_path):
     # single process: same two steps, gradients of the two shards computed one after the
     # other (per-shard BN statistics, global-row dropout offsets) and averaged by hand
     dev = torch.device("cuda:0")
-    net, opt = _make(dev)
-    x, t = _data(dev)
+    net, opt = _make(dev, cfg)
+    x, t = _data(dev, cfg)
     eng = net.engine
     eng.ensure(dev)
     opt._ensure_moments(eng)

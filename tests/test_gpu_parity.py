@@ -497,14 +497,14 @@ def test_cpu_input_is_rejected():
 # ----------------------------------------------------------------------------
 # hipGraph-captured step == eager fused step
 # ----------------------------------------------------------------------------
-@pytest.mark.parametrize("batch", [64, 512])
-def test_captured_step_matches_eager(batch):
+@pytest.mark.parametrize("batch,mode", [(64, "fp32"), (512, "fp32"), (256, "fp16x2"), (256, "bf16x3")])
+def test_captured_step_matches_eager(batch, mode):
     import bilinear_amd
     dev = _dev()
 
     def make():
         torch.manual_seed(5)
-        net, opt, _, _ = bilinear_amd.load(dev)
+        net, opt, _, _ = bilinear_amd.load(dev, gemm_dtype=mode)
         net.train()
         net.engine.seed = 99
         return net, opt
