@@ -265,6 +265,18 @@ static int forward_impl(const blh_model_desc* d, hipStream_t s, const float* par
       BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, EPI_STORE, g, fs.splits, d->gemm_dtype));
       BLH_TRY(launch_fwd_finish(s, ws.slabs, fs.splits, batch, W, params + h.b, ws.Z[i],
                                 train ? ws.stat_part : nullptr));
+    } else if (!train && d->gemm_dtype != 3) {
+      // eval: the whole heavy_linear in one kernel — bias, BatchNorm with the running statistics,
+      // ReLU and the block skip sit in the GEMM epilogue (the BN "folded into the Linear" of
+      // SURVEY.md 8(f) rank 1); Z is not materialised.  (fp16x2 keeps the two-kernel form: its
+      // next GEMM wants the maximum of A that bn_apply gathers.)
+      g.C = ws.A[i];
+      g.bn_gamma = params + h.gamma; g.bn_beta = params + h.beta;
+      g.bn_mean = bn_running + ((int64_t)i * 2 + 0) * W;
+      g.bn_var = bn_running + ((int64_t)i * 2 + 1) * W;
+      g.addend = (i >= 2 && (i % 2) == 0) ? ws.A[i - 2] : nullptr; g.ldadd = W;
+      BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, EPI_BN_RELU, g, 1, d->gemm_dtype));
+      continue;
     } else {
       BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, train ? EPI_BIAS_STATS : EPI_BIAS, g, 1,
                           d->gemm_dtype));

@@ -33,7 +33,8 @@ enum Epilogue : int {
   EPI_STORE = 0,       // C = acc                         (split-K slabs, plain)
   EPI_BIAS = 1,        // C = acc + bias[n]
   EPI_BIAS_STATS = 2,  // C = acc + bias[n]; per-tile column (mean, M2) partials
-  EPI_ADD = 3          // C = acc + addend[m][n]
+  EPI_ADD = 3,         // C = acc + addend[m][n]
+  EPI_BN_RELU = 4      // eval forward: C = relu(bn_eval(acc + bias[n])) (+ addend[m][n], the block skip)
 };
 
 struct GemmParams {
@@ -49,6 +50,8 @@ struct GemmParams {
   int64_t ldadd;
   float* stat_part;         // [tiles_m][2][N]  (mean, M2) of each BM-row tile
   float* loss_part;         // diagnostic builds only: STAMP output (tools/gemm_bench)
+  // EPI_BN_RELU: BatchNorm1d in eval mode (running statistics), [N] each
+  const float* bn_gamma; const float* bn_beta; const float* bn_mean; const float* bn_var;
   // gemm_dtype 3 (fp16 two-piece split): max |value| partials of each operand tensor
   const float* a_amax; int a_namax;
   const float* b_amax; int b_namax;

@@ -1,6 +1,8 @@
 // Shared epilogue of the MFMA GEMM kernels (fp32 accumulators of 32x32 MFMA tiles; the C/D
 // register layout is the same for the f32 and bf16 MFMA shapes on gfx950):
-//   EPI_STORE / EPI_BIAS / EPI_ADD, EPI_BIAS_STATS (per-128-row-tile BatchNorm partials).
+//   EPI_STORE / EPI_BIAS / EPI_ADD, EPI_BIAS_STATS (per-128-row-tile BatchNorm partials),
+//   EPI_BN_RELU (eval-mode heavy_linear in one kernel: bias, BatchNorm with running statistics,
+//   ReLU, optional block skip).
 //   See gemm_f32_kernel.h for the contractions it serves.
 #pragma once
 #include "common.h"
@@ -28,6 +30,22 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], 
   const int row_w = m0 + wm * (TM * 32) + 4 * h;   // + tm*32 + (r&3) + 8*(r>>2)
   const int col_w = n0 + wn * (TN * 32) + lc;      // + tn*32
 
+  if (EPI == EPI_BN_RELU) {
+    // same operations, in the same order, as bn_apply_kernel<false> on Z = acc + bias:
+    // sc = gamma / sqrt(var + eps); sh = beta - mean * sc; a = max(fma(z, sc, sh), 0) (+ skip)
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+      const int col = col_w + jn * 32;
+      const bool okc = col < p.N;
+      const float bv = okc ? p.bias[col] : 0.f;
+      const float sc = okc ? p.bn_gamma[col] * (1.0f / sqrtf(p.bn_var[col] + 1e-5f)) : 0.f;
+      const float sh = okc ? p.bn_beta[col] - p.bn_mean[col] * sc : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][jn][r] = fmaxf(fmaf(acc[i][jn][r] + bv, sc, sh), 0.f);
+    }
+  }
   if (EPI == EPI_BIAS || EPI == EPI_BIAS_STATS) {
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
@@ -41,7 +59,7 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], 
   }
 
   // the output stores go first: they drain while the statistics below are reduced
-  if (EPI == EPI_ADD) {
+  if (EPI == EPI_ADD || EPI == EPI_BN_RELU) {
     // all addend loads are issued before the first add: one memory latency for the tile instead
     // of one per element (the add + store chain otherwise serialises on every load)
     float add[TM][TN][16];
@@ -53,7 +71,7 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], 
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) {
           const int col = col_w + jn * 32;
-          add[i][jn][r] = (row < p.M && col < p.N) ? p.addend[(int64_t)row * p.ldadd + col] : 0.f;
+          add[i][jn][r] = (p.addend && row < p.M && col < p.N) ? p.addend[(int64_t)row * p.ldadd + col] : 0.f;
         }
       }
 #pragma unroll

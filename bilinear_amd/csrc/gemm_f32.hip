@@ -43,7 +43,8 @@ static int gemm_pipe() {   // developer knob for on-box A/B runs: BLH_GEMM_PIPE=
 // instantiated (each is a separate gfx950 kernel).
 static int launch_128x128(hipStream_t s, int la, int lb, int epi, const GemmParams& p, int splits) {
   BLH_CASE(128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS)   // hidden / encode forward (train)
-  BLH_CASE(128, 128, 4, 2, ROWK, ROWK, EPI_BIAS)         // forward (eval)
+  BLH_CASE(128, 128, 4, 2, ROWK, ROWK, EPI_BIAS)         // forward (eval, small batch)
+  BLH_CASE(128, 128, 4, 2, ROWK, ROWK, EPI_BN_RELU)      // forward (eval): Linear + BN + ReLU (+ skip)
   BLH_CASE(128, 128, 4, 2, ROWK, ROWK, EPI_STORE)
   BLH_CASE(128, 128, 4, 2, ROWK, KROW, EPI_STORE)        // dgrad
   BLH_CASE(128, 128, 4, 2, ROWK, KROW, EPI_ADD)          // dgrad + residual gradient
@@ -102,6 +103,7 @@ static int launch_bf16(hipStream_t s, GemmTile tile, int la, int lb, int epi, co
     case TILE_128x128:
       BLH_CASE16(128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS)
       BLH_CASE16(128, 128, 4, 2, ROWK, ROWK, EPI_BIAS)
+      BLH_CASE16(128, 128, 4, 2, ROWK, ROWK, EPI_BN_RELU)
       BLH_CASE16(128, 128, 4, 2, ROWK, ROWK, EPI_STORE)
       BLH_CASE16(128, 128, 4, 2, ROWK, KROW, EPI_STORE)
       BLH_CASE16(128, 128, 4, 2, ROWK, KROW, EPI_ADD)
@@ -148,6 +150,7 @@ static int launch_split_128x128(hipStream_t s, int la, int lb, int epi, const Ge
                                 int splits) {
   BLH_CASE3(ROWK, ROWK, EPI_BIAS_STATS)
   BLH_CASE3(ROWK, ROWK, EPI_BIAS)
+  BLH_CASE3(ROWK, ROWK, EPI_BN_RELU)
   BLH_CASE3(ROWK, ROWK, EPI_STORE)
   BLH_CASE3(ROWK, KROW, EPI_STORE)
   BLH_CASE3(ROWK, KROW, EPI_ADD)

@@ -322,8 +322,11 @@ def test_fused_train_step_matches_reference(fname, mode):
         _compare_step(g, s, net, opt, None, clipped, pred, loss.item(), stats[0], RTOL if s else TIGHT)
 
 
-def test_eval_forward_matches_oracle():
-    """valid_bilinear.py:31,52 — eval mode uses running statistics, no dropout."""
+@pytest.mark.parametrize("mode", FP32_MODES)
+@pytest.mark.parametrize("batch", [333, 2048])
+def test_eval_forward_matches_oracle(mode, batch):
+    """valid_bilinear.py:31,52 — eval mode uses running statistics, no dropout.  (At the larger
+    batch every heavy_linear is ONE kernel: bias + BatchNorm + ReLU + skip in the GEMM epilogue.)"""
     dev = _dev()
     g = Golden(FIXTURES[0])
     st = g.init_state()
@@ -333,9 +336,9 @@ def test_eval_forward_matches_oracle():
             st[k] = rng.standard_normal(st[k].shape).astype(np.float32) * 0.3
         if k.endswith("running_var"):
             st[k] = (0.5 + rng.random_sample(st[k].shape)).astype(np.float32)
-    net, _ = _build(g, dev, state=st)
+    net, _ = _build(g, dev, state=st, gemm_dtype=mode)
     net.eval()
-    x, _ = O.synthetic_batch(77, 333)
+    x, _ = O.synthetic_batch(77, batch)
     with torch.no_grad():
         pred = net(torch.from_numpy(x).to(dev))
     ref, _ = O.forward(st, x, None, training=False, dtype=np.float64)
