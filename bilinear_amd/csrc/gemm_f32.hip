@@ -27,17 +27,11 @@ static int launch_cfg(hipStream_t s, const GemmParams& p, int splits) {
   return BLH_OK;
 }
 
-// Main-loop structure used by the library: 3 = three-stage LDS ring filled by LDS-DMA issued
-// from inline asm (see gemm_f32_kernel.h); 1 = register-staged double buffer.
-static int gemm_pipe() {   // developer knob for on-box A/B runs: BLH_GEMM_PIPE=1|3
-  static const int v = [] { const char* e = getenv("BLH_GEMM_PIPE"); return (e && e[0] == '1') ? 1 : 3; }();
-  return v;
-}
-
+// The library ships the LDS-DMA ring (PIPE 3, gemm_f32_kernel.h); the register-staged PIPE 1 is
+// built by tools/gemm_bench only.
 #define BLH_CASE(BM_, BN_, WM_, WN_, LA_, LB_, EPI_) \
   if (la == LA_ && lb == LB_ && epi == EPI_)         \
-    return gemm_pipe() == 1 ? launch_cfg<BM_, BN_, WM_, WN_, LA_, LB_, EPI_, 1>(s, p, splits) \
-                            : launch_cfg<BM_, BN_, WM_, WN_, LA_, LB_, EPI_, 3>(s, p, splits);
+    return launch_cfg<BM_, BN_, WM_, WN_, LA_, LB_, EPI_, 3>(s, p, splits);
 
 // Only the (tile, layout, epilogue) combinations the network and the unit tests use are
 // instantiated (each is a separate gfx950 kernel).
