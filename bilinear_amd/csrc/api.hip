@@ -488,8 +488,8 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
     // Linear: db = colsum(dZ); dW = dZ^T a_in; d a_in = dZ W
     // (data parallel: the bucket hook needs this stage's bias gradient now; otherwise all
     //  stages are reduced by one launch after the loop)
-    if (on_ready)
-      BLH_TRY(launch_colreduce(s, ws.dz_colsum_part + (int64_t)i * chunks * W, chunks, W, W,
+    if (on_ready)   // on the side stream (after the fork): nothing on the main stream waits for it
+      BLH_TRY(launch_colreduce(s2, ws.dz_colsum_part + (int64_t)i * chunks * W, chunks, W, W,
                                grads + h.b));
     if (i == 0) {
       BLH_TRY(wgrad(d->gemm_dtype, s2, TILE_128x32, dzbuf, W, W, x, d->in_features,
