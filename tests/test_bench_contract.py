@@ -1,0 +1,46 @@
+"""bench.py pieces that run without a GPU: the FLOP model of SURVEY.md 8(d), the roofline blocks
+(fields the driver's contract names) and the CPU-baseline port used for `cpu_baseline`."""
+import argparse
+import importlib.util
+import os
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(REPO, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_flop_model_matches_survey():
+    b = _bench()
+    assert sum(b.flops_per_pose(2, 1024)) == 25591808          # SURVEY.md 8(d), BASELINE configs[1]
+    assert b.flops_per_pose(2, 1024) == (8552448, 17039360)
+    assert sum(b.flops_per_pose(4, 1024)) == 50757632
+    assert sum(b.flops_per_pose(8, 2048)) == 403505152
+
+
+@pytest.mark.parametrize("dtype,bound,peak", [("fp32", "mfma", 157.3), ("bf16x3", "mfma", 2500.0 / 6),
+                                              ("fp16x2", "mfma", 2500.0 / 3), ("bf16", "hbm", 8000.0)])
+def test_roofline_block_fields(dtype, bound, peak):
+    b = _bench()
+    args = argparse.Namespace(batch=4096, width=1024, dtype=dtype)
+    dom = {"ms": 0.072, "tflops": 2.0 * 4096 * 1024 * 1024 / 0.072 / 1e9}
+    r = b.roofline_block(args, dom)
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r
+    assert r["bound"] == bound and abs(r["peak"] - peak) < 1e-6 * peak
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    if dtype == "fp32":          # PMC traffic of the dominant kernel, recorded under profiles/
+        assert r["traffic"] == 67549184 and abs(r["achieved"] - 119.3) < 0.1
+
+
+def test_cpu_baseline_port_runs_the_whole_step():
+    from oracle import torch_port as TP
+    out = TP.time_cpu_steps(1, 64, 32, steps=2, warmup=1, threads=2)
+    assert out["steps"] == 2 and out["threads"] == 2
+    assert out["poses_per_s"] > 0 and abs(out["ms_per_step"] * out["poses_per_s"] / 1e3 - 32) < 1e-6 * 32
