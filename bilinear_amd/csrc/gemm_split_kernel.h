@@ -65,6 +65,15 @@ struct TileSplit {
   static constexpr int REGS = (LAYOUT == ROWK) ? PER : PER * 4;
   static constexpr int PLANE = R * SPITCH;   // bf16 elements per plane
 
+  // ROWK: chunk q -> tile row.  Rows are visited in the order 0,4,1,5,2,6,3,7 inside each block of 8,
+  // so that the two rows a 16-lane ds_write_b64 group covers are 4 apart: with the 80-byte pitch
+  // their 16-dword spans then fall on disjoint halves of the 32 write banks (adjacent rows overlap
+  // on 12 banks).  The global side is unaffected (8 lanes still read one 128-byte row segment).
+  __device__ static inline int rowk_row(int q) {
+    const int g = q >> 3;
+    return (g & ~7) + ((g >> 1) & 3) + ((g & 1) << 2);
+  }
+
   // Branch-free loads: per-thread source pointers are set up once (rows outside the operand
   // point at a 16-byte zero page and never advance), every tile request is PER (x4) unconditional
   // global_load_dwordx4 plus a pointer add; chunks at or beyond k_end (ragged last K tile, or a
@@ -79,7 +88,7 @@ struct TileSplit {
 #pragma unroll
     for (int p = 0; p < PER; ++p) {
       const int q = tid + p * NT;
-      const int row = row0 + ((LAYOUT == ROWK) ? (q >> 3) : ((q >> 3) << 2));
+      const int row = row0 + ((LAYOUT == ROWK) ? rowk_row(q) : ((q >> 3) << 2));
       const int kk = (q & 7) << 2;
       const bool ok = row < rows_limit;
       koff[p] = kk;
@@ -139,7 +148,7 @@ struct TileSplit {
   __device__ static inline __bf16* row_ptr(__bf16* lds, int put, int tid) {
     if (LAYOUT == ROWK) {
       const int q = tid + put * NT;
-      return lds + (q >> 3) * SPITCH + ((q & 7) << 2);
+      return lds + rowk_row(q) * SPITCH + ((q & 7) << 2);
     }
     return lds + (((tid >> 3) << 2) + put) * SPITCH + ((tid & 7) << 2);
   }
@@ -149,7 +158,7 @@ struct TileSplit {
     for (int p = 0; p < PER; ++p) {
       const int q = tid + p * NT;
       if (LAYOUT == ROWK) {
-        put(lds + (q >> 3) * SPITCH + ((q & 7) << 2), reg[p].x, reg[p].y, reg[p].z, reg[p].w);
+        put(lds + rowk_row(q) * SPITCH + ((q & 7) << 2), reg[p].x, reg[p].y, reg[p].z, reg[p].w);
       } else {
         __bf16* at = lds + ((q >> 3) << 2) * SPITCH + ((q & 7) << 2);
         const f32x4_t &k0 = reg[p * 4], &k1 = reg[p * 4 + 1], &k2 = reg[p * 4 + 2], &k3 = reg[p * 4 + 3];
