@@ -67,8 +67,8 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(GemmParams p) {
 
   IOA ioa;
   IOB iob;
-  ioa.init(p.A, p.lda, m0, p.M, kz0, k_end, tid);
-  iob.init(p.B, p.ldb, n0, p.N, kz0, k_end, tid);
+  ioa.init(p.A, p.lda, m0, p.M, p.K, tid);
+  iob.init(p.B, p.ldb, n0, p.N, p.K, tid);
 
   auto store_all = [&](auto io, const f32x4_t (&regs)[4], __bf16* dst, float sc) {
     using IO = decltype(io);

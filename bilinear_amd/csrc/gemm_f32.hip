@@ -205,13 +205,18 @@ int launch_gemm(hipStream_t s, GemmTile tile, int la, int lb, int epi, const Gem
   if (lb == KROW && p.N % 4 != 0) return BLH_ERR_SHAPE;
   if (splits > 1 && (p.k_per_split % BK != 0)) return BLH_ERR_SHAPE;
   if (dtype == 1) return launch_bf16(s, tile, la, lb, epi, p, splits);
-  if (dtype == 3 && tile == TILE_128x128 && p.a_amax && p.b_amax && p.a_namax > 0 && p.b_namax > 0) {
+  // the split kernels take reductions in whole K tiles of 32 (every slab); other shapes (the
+  // K = 48 decode dgrad) run on the exact kernel
+  const bool whole_tiles = (p.K % 32 == 0) && (p.k_per_split % 32 == 0) &&
+                           (int64_t)std::max(p.M, p.K) * p.lda < (1ll << 28) &&
+                           (int64_t)std::max(p.N, p.K) * p.ldb < (1ll << 28);   // operands < 1 GiB (32-bit offsets)
+  if (dtype == 3 && whole_tiles && tile == TILE_128x128 && p.a_amax && p.b_amax && p.a_namax > 0 && p.b_namax > 0) {
     const int rc = launch_f16x2_128x128(s, la, lb, epi, p, splits);
     if (rc != BLH_ERR_INVALID_ARGUMENT) return rc;
   }
   // (fp16x2 without operand maxima — stand-alone stages, the encode / decode contractions — runs
   //  on the range-safe bf16 split)
-  if (dtype >= 2 && tile == TILE_128x128) {   // combinations not built in split form: exact fp32
+  if (dtype >= 2 && whole_tiles && tile == TILE_128x128) {   // combinations not built in split form: exact fp32
     const int rc = launch_split_128x128(s, la, lb, epi, p, splits);
     if (rc != BLH_ERR_INVALID_ARGUMENT) return rc;
   }

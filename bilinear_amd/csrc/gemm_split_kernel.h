@@ -74,50 +74,53 @@ struct TileSplit {
     return (g & ~7) + ((g >> 1) & 3) + ((g & 1) << 2);
   }
 
-  // Branch-free loads: per-thread source pointers are set up once (rows outside the operand
-  // point at a 16-byte zero page and never advance), every tile request is PER (x4) unconditional
-  // global_load_dwordx4 plus a pointer add; chunks at or beyond k_end (ragged last K tile, or a
-  // request past the last tile) read the zero page, so the K loop needs no branch.
-  const float* src[PER];
-  int64_t step[PER];      // floats per K tile
-  int64_t kstride[PER];   // KROW: floats between consecutive k of the patch
-  int koff[PER];
+  // Loads go through a buffer descriptor over the whole operand: the address of a request is
+  // descriptor base + a per-thread 32-bit byte offset (set up once) + a wave-uniform byte offset
+  // of the K tile (one SALU add per request; no 64-bit pointer arithmetic in the loop), and the
+  // hardware range check returns zeros for everything outside the operand — rows past its end
+  // (their per-thread offset is set beyond the descriptor's size) and whole tiles past the last
+  // one (the tile offset is) — so the K loop needs neither a branch nor a select.  The reduction
+  // range of a launch must be a multiple of the K tile (the dispatcher sends other shapes to the
+  // exact kernel).
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t voff[REGS];     // bytes: ROWK one per chunk, KROW one per k of the 4 x 4 patch
+  uint32_t tile_bytes;     // bytes from one K tile to the next
+  uint32_t nbytes;         // size of the operand = the offset that is out of range for sure
 
   __device__ inline void init(const float* __restrict__ base, int64_t ld, int row0, int rows_limit,
-                              int k_first, int k_end, int tid) {
+                              int k_total, int tid) {
+    // operand extent: ROWK [rows_limit][ld], KROW [k_total][ld]
+    const uint32_t bytes = (uint32_t)(((LAYOUT == ROWK) ? (int64_t)rows_limit : (int64_t)k_total) * ld * 4);
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+    nbytes = bytes;
+    tile_bytes = (LAYOUT == ROWK) ? (uint32_t)(SBK * 4) : (uint32_t)(SBK * ld * 4);
 #pragma unroll
     for (int p = 0; p < PER; ++p) {
       const int q = tid + p * NT;
       const int row = row0 + ((LAYOUT == ROWK) ? rowk_row(q) : ((q >> 3) << 2));
       const int kk = (q & 7) << 2;
       const bool ok = row < rows_limit;
-      koff[p] = kk;
-      const int64_t off = (LAYOUT == ROWK) ? ((int64_t)row * ld + k_first + kk)
-                                           : ((int64_t)(k_first + kk) * ld + row);
-      src[p] = ok ? base + off : reinterpret_cast<const float*>(&g_zero16);
-      step[p] = ok ? ((LAYOUT == ROWK) ? (int64_t)SBK : (int64_t)SBK * ld) : 0;
-      kstride[p] = (ok && LAYOUT == KROW) ? ld : 0;
+      if (LAYOUT == ROWK) {
+        voff[p] = ok ? (uint32_t)(((int64_t)row * ld + kk) * 4) : nbytes;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          voff[p * 4 + j] = ok ? (uint32_t)(((int64_t)(kk + j) * ld + row) * 4) : nbytes;
+      }
     }
   }
 
-  // request the next K tile (tiles are requested in order); k0 = its first k
+  // request the K tile whose first k is k0 (any order); k0 >= k_end returns zeros
   __device__ inline void load(f32x4_t (&reg)[REGS], int k0, int k_end) {
-    const float* zp = reinterpret_cast<const float*>(&g_zero16);
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    // (written without a conditional: a branch here would split the K loop into blocks and make
+    //  the compiler shuttle the accumulators between AGPRs and VGPRs at every block boundary)
+    const uint32_t in_range = 0u - (uint32_t)(k0 < k_end);
+    const uint32_t soff = (((uint32_t)(k0 / SBK) * tile_bytes) & in_range) | (nbytes & ~in_range);
 #pragma unroll
-    for (int p = 0; p < PER; ++p) {
-      if (LAYOUT == ROWK) {
-        const float* g = src[p];
-        if (!(k0 + koff[p] < k_end)) g = zp;
-        reg[p] = *reinterpret_cast<const f32x4_t*>(g);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float* g = src[p] + j * kstride[p];
-          if (!(k0 + koff[p] + j < k_end)) g = zp;
-          reg[p * 4 + j] = *reinterpret_cast<const f32x4_t*>(g);
-        }
-      }
-      src[p] += step[p];
+    for (int r = 0; r < REGS; ++r) {
+      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff[r], (int)soff, 0);
+      reg[r] = __builtin_bit_cast(f32x4_t, v);
     }
   }
 
@@ -207,8 +210,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmParams p) 
   const int nkt = (k_end - kz0 + SBK - 1) / SBK;
   IOA ioa;
   IOB iob;
-  ioa.init(p.A, p.lda, m0, p.M, kz0, k_end, tid);
-  iob.init(p.B, p.ldb, n0, p.N, kz0, k_end, tid);
+  ioa.init(p.A, p.lda, m0, p.M, p.K, tid);
+  iob.init(p.B, p.ldb, n0, p.N, p.K, tid);
   // prologue: tile 0 complete in stage 0, the A half of tile 1 in stage 1, B of tile 1 and all
   // of tile 2 requested
   ioa.load(ra[0], kz0, k_end);
