@@ -200,14 +200,14 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(GemmParams p) {
     __bf16* sA = lds + P * STAGE;
     __bf16* nA = lds + (P ^ 1) * STAGE;
     const int k3 = kz0 + (kt + 3) * SBK;
-    ioa.load(ra[P ^ 1], k3, k_end);
+    if (!(BLH_SPLIT_ABLATE & 1)) ioa.load(ra[P ^ 1], k3, k_end);
 #pragma unroll
     for (int r = 0; r < IOB::REGS; ++r) asm volatile("" : "+v"(rb[P ^ 1][r]));
     fence();
     phase(f0, f1, sA, 1, iob, rb[P ^ 1], nA + A_EL, sb);
-    __syncthreads();
+    if (!(BLH_SPLIT_ABLATE & 4)) __syncthreads();
     fence();
-    iob.load(rb[P ^ 1], k3, k_end);
+    if (!(BLH_SPLIT_ABLATE & 1)) iob.load(rb[P ^ 1], k3, k_end);
 #pragma unroll
     for (int r = 0; r < IOA::REGS; ++r) asm volatile("" : "+v"(ra[P][r]));
     fence();
