@@ -26,7 +26,7 @@ class ModelDesc(Structure):
 
 class Dropout(Structure):
     _fields_ = [("keep_mask", c_void_p), ("seed", c_uint64), ("step", c_uint64),
-                ("row_offset", c_int64)]
+                ("row_offset", c_int64), ("layer_base", c_int32), ("reserved", c_int32)]
 
 
 class AdamHyper(Structure):
@@ -48,6 +48,11 @@ _SIGNATURES = {
     "blh_status_string": (c_char_p, [c_int]),
     "blh_last_hip_error": (c_int, []),
     "blh_abi_version": (c_int, []),
+    "blh_context_create": (c_int, [POINTER(c_void_p)]),
+    "blh_context_destroy": (c_int, [c_void_p]),
+    "blh_context_set_option": (c_int, [c_void_p, c_int32, c_int32]),
+    "blh_context_get_option": (c_int, [c_void_p, c_int32]),
+    "blh_context_side_stream": (c_void_p, [c_void_p]),
     "blh_num_heavy": (c_int32, [POINTER(ModelDesc)]),
     "blh_param_arena_floats": (c_int64, [POINTER(ModelDesc)]),
     "blh_num_param_tensors": (c_int32, [POINTER(ModelDesc)]),
@@ -55,41 +60,41 @@ _SIGNATURES = {
                                       POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     "blh_bn_running_floats": (c_int64, [POINTER(ModelDesc)]),
     "blh_workspace_bytes": (c_int64, [POINTER(ModelDesc), c_int64]),
-    "blh_forward_train": (c_int, [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
+    "blh_forward_train": (c_int, [c_void_p, POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, POINTER(Dropout), c_float, c_void_p, c_int64,
                                   c_void_p, c_int64]),
-    "blh_forward_eval": (c_int, [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
+    "blh_forward_eval": (c_int, [c_void_p, POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int64, c_void_p, c_int64]),
     "blh_mse_loss_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double,
                                   c_float, c_void_p, c_void_p, c_void_p, c_int64]),
-    "blh_backward": (c_int, [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, POINTER(Dropout),
+    "blh_backward": (c_int, [c_void_p, POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, POINTER(Dropout),
                              c_void_p, c_int64, c_void_p, c_void_p, c_int64, GradReadyFn,
                              c_void_p]),
-    "blh_forward_train_sync": (c_int, [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
+    "blh_forward_train_sync": (c_int, [c_void_p, POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, POINTER(Dropout), c_float, c_void_p, c_int64,
                                        c_void_p, c_int64, c_int64, SyncFn, c_void_p]),
-    "blh_backward_sync": (c_int, [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p,
+    "blh_backward_sync": (c_int, [c_void_p, POINTER(ModelDesc), c_void_p, c_void_p, c_void_p,
                                   POINTER(Dropout), c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                   GradReadyFn, c_void_p, c_int64, SyncFn, c_void_p]),
     "blh_clip_grad_norm": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_int64,
                                    c_void_p]),
     "blh_clip_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                    POINTER(AdamHyper), c_void_p, c_int64, c_void_p]),
-    "blh_train_step": (c_int, [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
+    "blh_train_step": (c_int, [c_void_p, POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                POINTER(Dropout), c_float, POINTER(AdamHyper), c_void_p, c_int64,
                                c_void_p, c_void_p, c_void_p, c_int64]),
     "blh_heavy_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32]),
-    "blh_heavy_forward": (c_int, [c_void_p] * 9 + [POINTER(Dropout), c_float, c_int32, c_int32,
+    "blh_heavy_forward": (c_int, [c_void_p] * 10 + [POINTER(Dropout), c_float, c_int32, c_int32,
                                                    c_void_p, c_int64, c_void_p, c_int64, c_int32,
                                                    c_int32]),
-    "blh_heavy_backward": (c_int, [c_void_p] * 5 + [POINTER(Dropout), c_int32, c_void_p, c_int64,
+    "blh_heavy_backward": (c_int, [c_void_p] * 6 + [POINTER(Dropout), c_int32, c_void_p, c_int64,
                                                     c_void_p, c_void_p, c_void_p, c_void_p,
                                                     c_void_p, c_int64, c_int32, c_int32]),
     "blh_mpjpe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                           c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "blh_step_state_advance": (c_int, [c_void_p, c_void_p]),
-    "blh_train_step_captured": (c_int, [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
+    "blh_train_step_captured": (c_int, [c_void_p, POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         POINTER(Dropout), c_float, c_void_p, c_void_p, c_int64,
                                         c_void_p, c_void_p, c_void_p, c_int64]),
@@ -102,7 +107,6 @@ _SIGNATURES = {
     "blh_gemm_bf16x3": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
                                 c_void_p, c_int64, c_int64, c_int64, c_int64, c_int32, c_void_p,
                                 c_void_p, c_int64]),
-    "blh_backward_side_stream": (c_void_p, []),
     "blh_gemm_fp16x2_workspace_bytes": (c_int64, []),
     "blh_gemm_fp16x2": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
                                 c_void_p, c_int64, c_int64, c_int64, c_int64, c_int32, c_void_p,
@@ -142,6 +146,53 @@ def lib():
         fn.argtypes = argtypes
     _lib = handle
     return _lib
+
+
+OPT_TWO_STREAM = 0
+OPT_DEFER_SLABS = 1
+
+
+class Context:
+    """Owner of one ``blh_context`` (include/bilinear_hip.h): the library's side stream, events
+    and option flags on ONE device.  Created with that device current; destroyed with the object."""
+
+    def __init__(self, device):
+        import torch
+        self.device = torch.device(device)
+        handle = c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().blh_context_create(ctypes.byref(handle)), "blh_context_create")
+        self.handle = handle
+
+    def set_option(self, option, value):
+        check(lib().blh_context_set_option(self.handle, int(option), int(value)), "blh_context_set_option")
+
+    def get_option(self, option):
+        return int(lib().blh_context_get_option(self.handle, int(option)))
+
+    def side_stream(self):
+        return lib().blh_context_side_stream(self.handle)
+
+    def __del__(self):
+        try:
+            if self.handle and _lib is not None:
+                _lib.blh_context_destroy(self.handle)
+                self.handle = None
+        except Exception:   # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+_contexts = {}
+
+
+def default_context(device):
+    """One shared context per device for callers that own no engine (stand-alone stages)."""
+    import torch
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _contexts:
+        _contexts[key] = Context(torch.device("cuda", key[1]))
+    return _contexts[key]
 
 
 def exported_names():

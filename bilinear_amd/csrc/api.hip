@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "common.h"
@@ -213,24 +214,49 @@ static Scratch carve_scratch(void* base) {
   return s;
 }
 
-// SyncBN context of the current call (data parallel): statistics over `global_batch` rows,
+// SyncBN plumbing of the current call (data parallel): statistics over `global_batch` rows,
 // exchanged by the host callback
 struct SyncCtx { blh_sync_fn fn; void* user; int64_t global_batch; };
-static thread_local SyncCtx g_sync = {nullptr, nullptr, 0};
 
-// device address of blh_step_state.rng_step for the current call (graph-captured step), else null
-static thread_local const uint64_t* g_step_dev = nullptr;
+}  // namespace blh
 
-static DropoutSrc layer_drop(const blh_dropout* drop, int layer, int64_t batch, int W) {
+// Caller-owned context (include/bilinear_hip.h): the side stream of the two-stream backward with
+// its fork / join events, the option flags, and the per-call plumbing (SyncBN callback, device
+// address of the captured step's dropout counter).  Bound to one device; one call at a time.
+static constexpr int BLH_CTX_EVENTS = 34;      // 1 + 2*num_blocks <= 32 stages, + decode, + spare
+struct blh_context {
+  int device = -1;
+  hipStream_t s2 = nullptr;
+  hipEvent_t ev_dz[BLH_CTX_EVENTS], ev_w[BLH_CTX_EVENTS], ev_r[BLH_CTX_EVENTS];
+  bool two_stream = true;
+  bool defer_slabs = false;
+  // per-call state (set by the entry point for the duration of the call)
+  blh::SyncCtx sync = {nullptr, nullptr, 0};
+  const uint64_t* step_dev = nullptr;
+};
+
+namespace blh {
+
+static DropoutSrc layer_drop(const blh_context* ctx, const blh_dropout* drop, int layer,
+                             int64_t batch, int W) {
   DropoutSrc d;
-  d.step_dev = g_step_dev;
+  d.step_dev = ctx->step_dev;
   d.keep = drop->keep_mask ? drop->keep_mask + (int64_t)layer * batch * W : nullptr;
-  d.seed = drop->seed; d.step = drop->step; d.row_offset = drop->row_offset; d.layer = layer;
+  d.seed = drop->seed; d.step = drop->step; d.row_offset = drop->row_offset;
+  d.layer = drop->layer_base + layer;
   return d;
 }
 
+// every network-level entry point: the context must belong to the device that is current
+static int check_ctx(const blh_context* ctx) {
+  if (!ctx) return BLH_ERR_INVALID_ARGUMENT;
+  int dev = -1;
+  BLH_HIP_TRY(hipGetDevice(&dev));
+  return dev == ctx->device ? BLH_OK : BLH_ERR_INVALID_ARGUMENT;
+}
+
 // ------------------------------------------------------------- forward -----
-static int forward_impl(const blh_model_desc* d, hipStream_t s, const float* params,
+static int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
                         float* bn_running, int64_t* nbt, const float* x, const blh_dropout* drop,
                         float momentum, const Workspace& ws, float* pred, int64_t batch,
                         bool train, const float* target, float mse_scale, float* loss_part,
@@ -290,10 +316,10 @@ static int forward_impl(const blh_model_desc* d, hipStream_t s, const float* par
       // (the small-batch path produced one statistics tile covering all rows)
       const int st_tiles = fs.splits > 1 ? 1 : tiles_m;
       const int st_rows = fs.splits > 1 ? (int)batch : 128;
-      if (g_sync.fn) {
+      if (ctx->sync.fn) {
         BLH_TRY(launch_bn_fwd_local_sums(s, ws.stat_part, st_tiles, st_rows, batch, W, ws.sync_buf));
-        g_sync.fn(g_sync.user, ws.sync_buf, 2 * (int64_t)W, 1);
-        BLH_TRY(launch_bn_fwd_finalize_sums(s, ws.sync_buf, g_sync.global_batch, W,
+        ctx->sync.fn(ctx->sync.user, ws.sync_buf, 2 * (int64_t)W, 1);
+        BLH_TRY(launch_bn_fwd_finalize_sums(s, ws.sync_buf, ctx->sync.global_batch, W,
                                             params + h.gamma, params + h.beta, rm, rv, nbt + i,
                                             momentum, sv, sv + W, sv + 2 * W, sv + 3 * W));
       } else {
@@ -302,7 +328,7 @@ static int forward_impl(const blh_model_desc* d, hipStream_t s, const float* par
                                        momentum, sv, sv + W, sv + 2 * W, sv + 3 * W));
       }
       BLH_TRY(launch_bn_apply_train(s, ws.Z[i], sv + 2 * W, sv + 3 * W, skip, ws.A[i], batch, W,
-                                    layer_drop(drop, i, batch, W), nbt + i, ws.amax_A[i]));
+                                    layer_drop(ctx, drop, i, batch, W), nbt + i, ws.amax_A[i]));
     } else {
       BLH_TRY(launch_bn_apply_eval(s, ws.Z[i], params + h.gamma, params + h.beta, rm, rv, skip,
                                    ws.A[i], batch, W, ws.amax_A[i]));
@@ -356,34 +382,16 @@ static int wgrad(int dtype, hipStream_t s, GemmTile tile, const float* dZ, int64
   return launch_sum_slabs(s, slabs, (int64_t)M * N, sp.splits, out);
 }
 
-// Side stream for the weight-gradient GEMMs of the fused single-GPU step: nothing in the rest
-// of backward depends on dW, so wgrad(l) (+ its slab sum) runs on a second stream concurrently
+// Side stream for the weight-gradient GEMMs (owned by the context): nothing in the rest of
+// backward depends on dW, so wgrad(l) (+ its slab sum) runs on a second stream concurrently
 // with dgrad(l) and the HBM-bound BatchNorm-backward kernels of stage l-1, which leave the
 // MFMA pipes idle.  Fork / join by events (capturable into a hipGraph); dZ is double-buffered
 // so that stage l-2 does not overwrite what wgrad(l) is still reading.
-struct SideStream {
-  hipStream_t s2 = nullptr;
-  hipEvent_t ev_dz[34], ev_w[34], ev_r[34];
-  bool ready = false;
-  int init() {
-    if (ready) return BLH_OK;
-    BLH_HIP_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-    for (int i = 0; i < 34; ++i) {
-      BLH_HIP_TRY(hipEventCreateWithFlags(&ev_dz[i], hipEventDisableTiming));
-      BLH_HIP_TRY(hipEventCreateWithFlags(&ev_w[i], hipEventDisableTiming));
-      BLH_HIP_TRY(hipEventCreateWithFlags(&ev_r[i], hipEventDisableTiming));
-    }
-    ready = true;
-    return BLH_OK;
-  }
-};
-static SideStream g_side;
-
 // fused: the caller is the whole-step path: the decode-bias partials come from decode_finish
 // (dec_bias_S rows) and the sum-of-squares partials of the arena are returned for clip+Adam.
 struct FusedBackward { int dec_bias_S; double* sumsq_part; int* sumsq_nparts; };
 
-static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* params,
+static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
                          const float* x, const blh_dropout* drop, const Workspace& ws,
                          const float* dpred, float* grads, int64_t batch,
                          blh_grad_ready_fn on_ready, void* user,
@@ -398,16 +406,13 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
   // L2 / Infinity Cache.  Deferring all of them to the single grads_finish launch at the end
   // (BLH_DEFER_SLABS=1, kept for experiments) saves six launches but reads 68 MB of by then
   // cold slabs: measured 1.268 vs 1.253 ms/step, so it is off.
-  static const bool defer_env = getenv("BLH_DEFER_SLABS") != nullptr;
-  const bool defer = (on_ready == nullptr) && defer_env;
+  const bool defer = (on_ready == nullptr) && ctx->defer_slabs;
   std::vector<GradRegion> wreg(nh + 1);
-  static const bool two_env = getenv("BLH_ONE_STREAM") == nullptr;   // on by default (-3 % step)
-  const bool two = two_env && !g_sync.fn && !defer && small_m_splits(batch, W, W).splits == 1;
-  hipStream_t s2 = s;
-  if (two) {
-    BLH_TRY(g_side.init());
-    s2 = g_side.s2;
-  }
+  // two streams: on by default (-3 % step)
+  const bool two = ctx->two_stream && !ctx->sync.fn && !defer && small_m_splits(batch, W, W).splits == 1;
+  hipStream_t s2 = two ? ctx->s2 : s;
+  SyncCtx& g_sync = ctx->sync;
+  blh_context& g_side = *ctx;
   // fork: s2 continues after everything enqueued on s so far; wdone: marks wgrad(idx) complete
   auto fork = [&](int idx) -> int {
     if (!two) return BLH_OK;
@@ -429,7 +434,8 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
     if (two) {
       BLH_HIP_TRY(hipEventRecord(g_side.ev_r[idx], s));
       BLH_HIP_TRY(hipStreamWaitEvent(s2, g_side.ev_r[idx], 0));
-    } else if (g_side.ready) {   // one-stream call while a side stream exists: keep the contract
+    } else if (ctx->two_stream) {   // small-batch / SyncBN call of a two-stream context: the
+      // range is complete on `s`; keep the contract "complete on the side stream"
       BLH_HIP_TRY(hipEventRecord(g_side.ev_r[idx], s));
       BLH_HIP_TRY(hipStreamWaitEvent(g_side.s2, g_side.ev_r[idx], 0));
     }
@@ -460,7 +466,7 @@ static int backward_impl(const blh_model_desc* d, hipStream_t s, const float* pa
     const bool first_of_block = (i >= 1) && (i % 2 == 1);
     const float* dA = first_of_block ? ws.G1 : ws.G0;
     const float* sv = ws.bn_saved[i];
-    const DropoutSrc ds = layer_drop(drop, i, batch, W);
+    const DropoutSrc ds = layer_drop(ctx, drop, i, batch, W);
     BLH_TRY(launch_bn_bwd_reduce(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W, ws.bn_part,
                                  batch, W, ds));
     BLH_TRY(launch_bn_bwd_finalize(s, ws.bn_part, chunks, W, grads + h.gamma, grads + h.beta));
@@ -583,6 +589,66 @@ const char* blh_status_string(int status) {
 int blh_last_hip_error(void) { return g_last_hip_error; }
 int blh_abi_version(void) { return BLH_ABI_VERSION; }
 
+int blh_context_create(blh_context** out) {
+  if (!out) return BLH_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  blh_context* c = new (std::nothrow) blh_context();
+  if (!c) return BLH_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < BLH_CTX_EVENTS; ++i) c->ev_dz[i] = c->ev_w[i] = c->ev_r[i] = nullptr;
+  auto fail = [&](hipError_t e) {
+    g_last_hip_error = (int)e;
+    blh_context_destroy(c);
+    return BLH_ERR_HIP;
+  };
+  hipError_t e = hipGetDevice(&c->device);
+  if (e != hipSuccess) return fail(e);
+  if ((e = hipStreamCreateWithFlags(&c->s2, hipStreamNonBlocking)) != hipSuccess) return fail(e);
+  for (int i = 0; i < BLH_CTX_EVENTS; ++i) {
+    if ((e = hipEventCreateWithFlags(&c->ev_dz[i], hipEventDisableTiming)) != hipSuccess) return fail(e);
+    if ((e = hipEventCreateWithFlags(&c->ev_w[i], hipEventDisableTiming)) != hipSuccess) return fail(e);
+    if ((e = hipEventCreateWithFlags(&c->ev_r[i], hipEventDisableTiming)) != hipSuccess) return fail(e);
+  }
+  // A/B switches for experiments (the documented way is blh_context_set_option)
+  c->two_stream = getenv("BLH_ONE_STREAM") == nullptr;
+  c->defer_slabs = getenv("BLH_DEFER_SLABS") != nullptr;
+  *out = c;
+  return BLH_OK;
+}
+
+int blh_context_destroy(blh_context* c) {
+  if (!c) return BLH_OK;
+  for (int i = 0; i < BLH_CTX_EVENTS; ++i) {
+    if (c->ev_dz[i]) (void)hipEventDestroy(c->ev_dz[i]);
+    if (c->ev_w[i]) (void)hipEventDestroy(c->ev_w[i]);
+    if (c->ev_r[i]) (void)hipEventDestroy(c->ev_r[i]);
+  }
+  if (c->s2) (void)hipStreamDestroy(c->s2);
+  delete c;
+  return BLH_OK;
+}
+
+int blh_context_set_option(blh_context* c, int32_t option, int32_t value) {
+  if (!c) return BLH_ERR_INVALID_ARGUMENT;
+  switch (option) {
+    case BLH_OPT_TWO_STREAM: c->two_stream = value != 0; return BLH_OK;
+    case BLH_OPT_DEFER_SLABS: c->defer_slabs = value != 0; return BLH_OK;
+  }
+  return BLH_ERR_INVALID_ARGUMENT;
+}
+
+int blh_context_get_option(const blh_context* c, int32_t option) {
+  if (!c) return BLH_ERR_INVALID_ARGUMENT;
+  switch (option) {
+    case BLH_OPT_TWO_STREAM: return c->two_stream ? 1 : 0;
+    case BLH_OPT_DEFER_SLABS: return c->defer_slabs ? 1 : 0;
+  }
+  return BLH_ERR_INVALID_ARGUMENT;
+}
+
+void* blh_context_side_stream(blh_context* c) {
+  return (c && c->two_stream) ? (void*)c->s2 : nullptr;
+}
+
 int32_t blh_num_heavy(const blh_model_desc* d) { return d ? 1 + 2 * d->num_blocks : 0; }
 
 int64_t blh_param_arena_floats(const blh_model_desc* d) {
@@ -620,7 +686,9 @@ int64_t blh_workspace_bytes(const blh_model_desc* d, int64_t batch) {
   return carve(d, batch, nullptr).bytes;
 }
 
-static int check_common(const blh_model_desc* d, const void* ws, int64_t ws_bytes, int64_t batch) {
+static int check_common(const blh_context* ctx, const blh_model_desc* d, const void* ws,
+                        int64_t ws_bytes, int64_t batch) {
+  BLH_TRY(check_ctx(ctx));
   BLH_TRY(check_desc(d));
   if (batch <= 0 || batch > (1 << 30)) return BLH_ERR_INVALID_ARGUMENT;
   if (!ws || ((uintptr_t)ws % WS_ALIGN) != 0) return BLH_ERR_INVALID_ARGUMENT;
@@ -634,27 +702,27 @@ static int check_drop(const blh_dropout* drop) {
   return BLH_OK;
 }
 
-int blh_forward_train(const blh_model_desc* d, void* stream, const float* params,
+int blh_forward_train(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params,
                       float* bn_running, int64_t* bn_nbt, const float* x,
                       const blh_dropout* drop, float momentum, void* workspace,
                       int64_t workspace_bytes, float* pred, int64_t batch) {
-  BLH_TRY(check_common(d, workspace, workspace_bytes, batch));
+  BLH_TRY(check_common(ctx, d, workspace, workspace_bytes, batch));
   BLH_TRY(check_drop(drop));
   if (!params || !bn_running || !bn_nbt || !x || !pred) return BLH_ERR_INVALID_ARGUMENT;
   if (batch < 2) return BLH_ERR_SHAPE;   // BatchNorm1d needs > 1 value per channel in training
   const Workspace ws = carve(d, batch, workspace);
-  return forward_impl(d, (hipStream_t)stream, params, bn_running, bn_nbt, x, drop, momentum, ws,
+  return forward_impl(ctx, d, (hipStream_t)stream, params, bn_running, bn_nbt, x, drop, momentum, ws,
                       pred, batch, true, nullptr, 0.f, nullptr, nullptr);
 }
 
-int blh_forward_eval(const blh_model_desc* d, void* stream, const float* params,
+int blh_forward_eval(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params,
                      const float* bn_running, const float* x, void* workspace,
                      int64_t workspace_bytes, float* pred, int64_t batch) {
-  BLH_TRY(check_common(d, workspace, workspace_bytes, batch));
+  BLH_TRY(check_common(ctx, d, workspace, workspace_bytes, batch));
   if (!params || !bn_running || !x || !pred) return BLH_ERR_INVALID_ARGUMENT;
   const Workspace ws = carve(d, batch, workspace);
-  blh_dropout none{nullptr, 0, 0, 0};
-  return forward_impl(d, (hipStream_t)stream, params, const_cast<float*>(bn_running), nullptr, x,
+  blh_dropout none{nullptr, 0, 0, 0, 0, 0};
+  return forward_impl(ctx, d, (hipStream_t)stream, params, const_cast<float*>(bn_running), nullptr, x,
                       &none, 0.f, ws, pred, batch, false, nullptr, 0.f, nullptr, nullptr);
 }
 
@@ -673,15 +741,15 @@ int blh_mse_loss_grad(void* stream, const float* pred, const float* target, int6
                               loss_out);
 }
 
-int blh_backward(const blh_model_desc* d, void* stream, const float* params, const float* x,
+int blh_backward(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params, const float* x,
                  const blh_dropout* drop, void* workspace, int64_t workspace_bytes,
                  const float* dpred, float* grads, int64_t batch, blh_grad_ready_fn on_ready,
                  void* user) {
-  BLH_TRY(check_common(d, workspace, workspace_bytes, batch));
+  BLH_TRY(check_common(ctx, d, workspace, workspace_bytes, batch));
   BLH_TRY(check_drop(drop));
   if (!params || !x || !dpred || !grads) return BLH_ERR_INVALID_ARGUMENT;
   const Workspace ws = carve(d, batch, workspace);
-  return backward_impl(d, (hipStream_t)stream, params, x, drop, ws, dpred, grads, batch,
+  return backward_impl(ctx, d, (hipStream_t)stream, params, x, drop, ws, dpred, grads, batch,
                        on_ready, user);
 }
 
@@ -709,12 +777,12 @@ int blh_clip_grad_norm(void* stream, float* grads, int64_t count, float max_norm
                            stats_out);
 }
 
-int blh_train_step(const blh_model_desc* d, void* stream, float* params, float* grads,
+int blh_train_step(blh_context* ctx, const blh_model_desc* d, void* stream, float* params, float* grads,
                    float* exp_avg, float* exp_avg_sq, float* bn_running, int64_t* bn_nbt,
                    const float* x, const float* target, const blh_dropout* drop, float momentum,
                    const blh_adam_hyper* hyper, void* workspace, int64_t workspace_bytes,
                    float* pred, float* loss_out, float* stats_out, int64_t batch) {
-  BLH_TRY(check_common(d, workspace, workspace_bytes, batch));
+  BLH_TRY(check_common(ctx, d, workspace, workspace_bytes, batch));
   BLH_TRY(check_drop(drop));
   if (!params || !grads || !exp_avg || !exp_avg_sq || !bn_running || !bn_nbt || !x || !target ||
       !hyper || !pred || !loss_out)
@@ -724,40 +792,42 @@ int blh_train_step(const blh_model_desc* d, void* stream, float* params, float* 
   const Workspace ws = carve(d, batch, workspace);
   const double denom = (double)batch * d->out_features;
   int nparts = 0;
-  BLH_TRY(forward_impl(d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
+  BLH_TRY(forward_impl(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
                        target, (float)(2.0 / denom), ws.loss_part, &nparts));
   int np = 0;
   const FusedBackward fb{nparts, ws.sumsq_part, &np};
-  BLH_TRY(backward_impl(d, s, params, x, drop, ws, ws.dpred, grads, batch, nullptr, nullptr, &fb));
+  BLH_TRY(backward_impl(ctx, d, s, params, x, drop, ws, ws.dpred, grads, batch, nullptr, nullptr, &fb));
   const int64_t count = make_layout(d).total;
   return launch_clip_adam(s, params, grads, exp_avg, exp_avg_sq, count, *hyper, ws.sumsq_part, np,
                           stats_out, LossFinish{ws.loss_part, nparts, denom, loss_out});
 }
 
-int blh_forward_train_sync(const blh_model_desc* d, void* stream, const float* params,
+int blh_forward_train_sync(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params,
                            float* bn_running, int64_t* bn_nbt, const float* x,
                            const blh_dropout* drop, float momentum, void* workspace,
                            int64_t workspace_bytes, float* pred, int64_t batch,
                            int64_t global_batch, blh_sync_fn sync, void* user) {
-  if (!sync || global_batch < batch) return BLH_ERR_INVALID_ARGUMENT;
+  if (!ctx || !sync || global_batch < batch) return BLH_ERR_INVALID_ARGUMENT;
   struct Guard {
-    Guard(blh_sync_fn f, void* u, int64_t g) { g_sync = SyncCtx{f, u, g}; }
-    ~Guard() { g_sync = SyncCtx{nullptr, nullptr, 0}; }
-  } guard(sync, user, global_batch);
-  return blh_forward_train(d, stream, params, bn_running, bn_nbt, x, drop, momentum, workspace,
+    blh_context* c;
+    Guard(blh_context* c_, blh_sync_fn f, void* u, int64_t g) : c(c_) { c->sync = SyncCtx{f, u, g}; }
+    ~Guard() { c->sync = SyncCtx{nullptr, nullptr, 0}; }
+  } guard(ctx, sync, user, global_batch);
+  return blh_forward_train(ctx, d, stream, params, bn_running, bn_nbt, x, drop, momentum, workspace,
                            workspace_bytes, pred, batch);
 }
 
-int blh_backward_sync(const blh_model_desc* d, void* stream, const float* params, const float* x,
+int blh_backward_sync(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params, const float* x,
                       const blh_dropout* drop, void* workspace, int64_t workspace_bytes,
                       const float* dpred, float* grads, int64_t batch, blh_grad_ready_fn on_ready,
                       void* user, int64_t global_batch, blh_sync_fn sync, void* sync_user) {
-  if (!sync || global_batch < batch) return BLH_ERR_INVALID_ARGUMENT;
+  if (!ctx || !sync || global_batch < batch) return BLH_ERR_INVALID_ARGUMENT;
   struct Guard {
-    Guard(blh_sync_fn f, void* u, int64_t g) { g_sync = SyncCtx{f, u, g}; }
-    ~Guard() { g_sync = SyncCtx{nullptr, nullptr, 0}; }
-  } guard(sync, sync_user, global_batch);
-  return blh_backward(d, stream, params, x, drop, workspace, workspace_bytes, dpred, grads, batch,
+    blh_context* c;
+    Guard(blh_context* c_, blh_sync_fn f, void* u, int64_t g) : c(c_) { c->sync = SyncCtx{f, u, g}; }
+    ~Guard() { c->sync = SyncCtx{nullptr, nullptr, 0}; }
+  } guard(ctx, sync, sync_user, global_batch);
+  return blh_backward(ctx, d, stream, params, x, drop, workspace, workspace_bytes, dpred, grads, batch,
                       on_ready, user);
 }
 
@@ -795,7 +865,7 @@ int64_t blh_heavy_workspace_bytes(int64_t batch, int32_t in_features, int32_t ou
   return carve_heavy(batch, in_features, out_features, nullptr).bytes;
 }
 
-int blh_heavy_forward(void* stream, const float* a_in, const float* weight, const float* bias,
+int blh_heavy_forward(blh_context* ctx, void* stream, const float* a_in, const float* weight, const float* bias,
                       const float* gamma, const float* beta, float* running_mean,
                       float* running_var, int64_t* num_batches_tracked, const blh_dropout* drop,
                       float momentum, int32_t training, int32_t gemm_dtype, void* workspace,
@@ -806,6 +876,7 @@ int blh_heavy_forward(void* stream, const float* a_in, const float* weight, cons
     return BLH_ERR_INVALID_ARGUMENT;
   if (in_features % 4 != 0 || out_features % 4 != 0) return BLH_ERR_SHAPE;
   if (training && (batch < 2 || !drop || !num_batches_tracked)) return BLH_ERR_INVALID_ARGUMENT;
+  BLH_TRY(check_ctx(ctx));
   if (training) BLH_TRY(check_drop(drop));
   if (((uintptr_t)workspace % WS_ALIGN) != 0) return BLH_ERR_INVALID_ARGUMENT;
   const HeavyWs w = carve_heavy(batch, in_features, out_features, workspace);
@@ -825,12 +896,12 @@ int blh_heavy_forward(void* stream, const float* a_in, const float* weight, cons
   BLH_TRY(launch_bn_fwd_finalize(s, w.stat_part, (int)ceil_div(batch, 128), 128, batch, W, gamma,
                                  beta, running_mean, running_var, num_batches_tracked, momentum, sv,
                                  sv + W, sv + 2 * W, sv + 3 * W));
-  DropoutSrc ds{drop->keep_mask, drop->seed, drop->step, drop->row_offset, 0, nullptr};
+  DropoutSrc ds{drop->keep_mask, drop->seed, drop->step, drop->row_offset, drop->layer_base, nullptr};
   return launch_bn_apply_train(s, w.Z, sv + 2 * W, sv + 3 * W, nullptr, a_out, batch, W, ds,
                                num_batches_tracked);
 }
 
-int blh_heavy_backward(void* stream, const float* d_out, const float* a_in, const float* weight,
+int blh_heavy_backward(blh_context* ctx, void* stream, const float* d_out, const float* a_in, const float* weight,
                        const float* gamma, const blh_dropout* drop, int32_t gemm_dtype,
                        void* workspace, int64_t workspace_bytes, float* d_weight, float* d_bias,
                        float* d_gamma, float* d_beta, float* d_in, int64_t batch,
@@ -839,6 +910,7 @@ int blh_heavy_backward(void* stream, const float* d_out, const float* a_in, cons
       !d_gamma || !d_beta || batch < 2)
     return BLH_ERR_INVALID_ARGUMENT;
   if (in_features % 4 != 0 || out_features % 4 != 0) return BLH_ERR_SHAPE;
+  BLH_TRY(check_ctx(ctx));
   BLH_TRY(check_drop(drop));
   const HeavyWs w = carve_heavy(batch, in_features, out_features, workspace);
   if (workspace_bytes < w.bytes) return BLH_ERR_WORKSPACE;
@@ -846,7 +918,7 @@ int blh_heavy_backward(void* stream, const float* d_out, const float* a_in, cons
   const int W = out_features;
   const int chunks = ew_num_row_chunks(batch);
   const float* sv = w.saved;
-  DropoutSrc ds{drop->keep_mask, drop->seed, drop->step, drop->row_offset, 0, nullptr};
+  DropoutSrc ds{drop->keep_mask, drop->seed, drop->step, drop->row_offset, drop->layer_base, nullptr};
   BLH_TRY(launch_bn_bwd_reduce(s, d_out, w.Z, sv + 2 * W, sv + 3 * W, sv, sv + W, w.bn_part, batch,
                                W, ds));
   BLH_TRY(launch_bn_bwd_finalize(s, w.bn_part, chunks, W, d_gamma, d_beta));
@@ -884,13 +956,13 @@ int blh_step_state_advance(void* stream, blh_step_state* dev_state) {
   return launch_step_state_advance((hipStream_t)stream, dev_state);
 }
 
-int blh_train_step_captured(const blh_model_desc* d, void* stream, float* params, float* grads,
+int blh_train_step_captured(blh_context* ctx, const blh_model_desc* d, void* stream, float* params, float* grads,
                             float* exp_avg, float* exp_avg_sq, float* bn_running,
                             int64_t* bn_nbt, const float* x, const float* target,
                             const blh_dropout* drop, float momentum, blh_step_state* dev_state,
                             void* workspace, int64_t workspace_bytes, float* pred,
                             float* loss_out, float* stats_out, int64_t batch) {
-  BLH_TRY(check_common(d, workspace, workspace_bytes, batch));
+  BLH_TRY(check_common(ctx, d, workspace, workspace_bytes, batch));
   BLH_TRY(check_drop(drop));
   if (!params || !grads || !exp_avg || !exp_avg_sq || !bn_running || !bn_nbt || !x || !target ||
       !dev_state || !pred || !loss_out)
@@ -902,13 +974,14 @@ int blh_train_step_captured(const blh_model_desc* d, void* stream, float* params
   int nparts = 0, np = 0;
   BLH_TRY(launch_step_state_advance(s, dev_state));
   struct StepDevGuard {   // kernels of this call add dev_state->rng_step to the dropout step
-    StepDevGuard(const uint64_t* p) { g_step_dev = p; }
-    ~StepDevGuard() { g_step_dev = nullptr; }
-  } guard(&dev_state->rng_step);
-  BLH_TRY(forward_impl(d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
+    blh_context* c;
+    StepDevGuard(blh_context* c_, const uint64_t* p) : c(c_) { c->step_dev = p; }
+    ~StepDevGuard() { c->step_dev = nullptr; }
+  } guard(ctx, &dev_state->rng_step);
+  BLH_TRY(forward_impl(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
                        target, (float)(2.0 / denom), ws.loss_part, &nparts));
   const FusedBackward fb{nparts, ws.sumsq_part, &np};
-  BLH_TRY(backward_impl(d, s, params, x, drop, ws, ws.dpred, grads, batch, nullptr, nullptr, &fb));
+  BLH_TRY(backward_impl(ctx, d, s, params, x, drop, ws, ws.dpred, grads, batch, nullptr, nullptr, &fb));
   const int64_t count = make_layout(d).total;
   return launch_clip_adam_dev(s, params, grads, exp_avg, exp_avg_sq, count, dev_state,
                               ws.sumsq_part, np, stats_out,
@@ -998,13 +1071,6 @@ int blh_gemm_fp16x2(void* stream, const float* A, int64_t lda, int32_t a_kmajor,
   return launch_gemm(s, tile, a_kmajor ? KROW : ROWK, b_kmajor ? KROW : ROWK, epi, g, splits, 3);
 }
 
-void* blh_backward_side_stream(void) {
-  static const bool one = getenv("BLH_ONE_STREAM") != nullptr;
-  if (one) return nullptr;
-  if (g_side.init() != BLH_OK) return nullptr;
-  return g_side.s2;
-}
-
 int blh_linear_fwd_stats(void* stream, const float* A, const float* W, const float* bias, float* Z,
                          float* stat_part, int64_t M, int64_t N, int64_t K) {
   if (!A || !W || !bias || !Z || !stat_part || M <= 0 || N <= 0 || K <= 0)
@@ -1021,7 +1087,7 @@ int blh_dropout_mask(void* stream, const blh_dropout* drop, int32_t layer, int64
   if (!drop || !keep_out || batch <= 0 || width <= 0 || width % 4 != 0 || drop->keep_mask)
     return BLH_ERR_INVALID_ARGUMENT;
   BLH_TRY(check_drop(drop));
-  DropoutSrc d{nullptr, drop->seed, drop->step, drop->row_offset, layer, nullptr};
+  DropoutSrc d{nullptr, drop->seed, drop->step, drop->row_offset, drop->layer_base + layer, nullptr};
   return launch_dropout_mask((hipStream_t)stream, keep_out, batch, width, d);
 }
 

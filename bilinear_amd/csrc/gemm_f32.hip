@@ -1,4 +1,5 @@
 // Host-side dispatch of the fp32 MFMA GEMM (kernel templates: gemm_f32_kernel.h).
+#include <atomic>
 #include <cstdlib>
 
 #include "gemm_bf16_kernel.h"
@@ -9,17 +10,27 @@
 namespace blh {
 
 // ------------------------------------------------------------------ host ----
+// The dynamic-LDS attribute of a kernel is per device: one bit per device id and kernel, set
+// with an atomic OR after the attribute call succeeded (two host threads racing here both call
+// hipFuncSetAttribute, which is idempotent).
+static int ensure_lds_attr(std::atomic<uint64_t>& done, const void* kern, size_t lds) {
+  int dev = 0;
+  BLH_HIP_TRY(hipGetDevice(&dev));
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    BLH_HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    done.fetch_or(bit, std::memory_order_release);
+  }
+  return BLH_OK;
+}
+
 template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int PIPE>
 static int launch_cfg(hipStream_t s, const GemmParams& p, int splits) {
   constexpr int NT = 64 * WM * WN;
   constexpr size_t lds = gemm_lds_bytes<BM, BN, LA, LB, PIPE>();
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_done{0};
   auto kern = gemm_f32_kernel<BM, BN, WM, WN, LA, LB, EPI, PIPE>;
-  if (!attr_set) {
-    BLH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  BLH_TRY(ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), lds));
   const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N, BN));
   dim3 grid(tiles, 1, splits);
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);
@@ -74,13 +85,9 @@ template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI>
 static int launch_cfg_bf16(hipStream_t s, const GemmParams& p, int splits) {
   constexpr int NT = 64 * WM * WN;
   constexpr size_t lds = gemm_bf16_lds_bytes<BM, BN>();
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_done{0};
   auto kern = gemm_bf16_kernel<BM, BN, WM, WN, LA, LB, EPI>;
-  if (!attr_set) {
-    BLH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  BLH_TRY(ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), lds));
   const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N, BN));
   hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(NT), lds, s, p);
   BLH_HIP_TRY(hipGetLastError());
@@ -122,13 +129,9 @@ static int launch_bf16(hipStream_t s, GemmTile tile, int la, int lb, int epi, co
 template <int LA, int LB, int EPI>
 static int launch_cfg_split(hipStream_t s, const GemmParams& p, int splits) {
   constexpr size_t lds = gemm_split_lds_bytes<128, 128>();
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_done{0};
   auto kern = gemm_split_kernel<128, 128, 2, 2, LA, LB, EPI>;
-  if (!attr_set) {
-    BLH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  BLH_TRY(ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), lds));
   const int tiles = (int)(ceil_div(p.M, 128) * ceil_div(p.N, 128));
   hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(256), lds, s, p);
   BLH_HIP_TRY(hipGetLastError());
@@ -157,13 +160,9 @@ static int launch_split_128x128(hipStream_t s, int la, int lb, int epi, const Ge
 template <int LA, int LB, int EPI>
 static int launch_cfg_f16x2(hipStream_t s, const GemmParams& p, int splits) {
   constexpr size_t lds = gemm_f16x2_lds_bytes<128, 128>();
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_done{0};
   auto kern = gemm_f16x2_kernel<LA, LB, EPI>;
-  if (!attr_set) {
-    BLH_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  BLH_TRY(ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), lds));
   const int tiles = (int)(ceil_div(p.M, 128) * ceil_div(p.N, 128));
   hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(256), lds, s, p);
   BLH_HIP_TRY(hipGetLastError());

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../gemm_f32_kernel.h"
+#include "../gemm_f32_ring.h"
 
 using namespace blh;
 thread_local int blh::g_last_hip_error = 0;
@@ -17,6 +18,27 @@ float run(const GemmParams& p, int splits, int reps) {
   constexpr int NT = 64 * WM * WN;
   constexpr size_t lds = gemm_lds_bytes<BM, BN, LA, LB, PIPE>();
   auto kern = gemm_f32_kernel<BM, BN, WM, WN, LA, LB, EPI, PIPE>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N, BN));
+  dim3 grid(tiles, 1, splits);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, dim3(NT), lds, 0, p);
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, grid, dim3(NT), lds, 0, p);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  CK(hipGetLastError());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / reps;
+}
+
+template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int BKT, int STAGES>
+float run_ring(const GemmParams& p, int splits, int reps) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr size_t lds = gemm_ring_lds_bytes<BM, BN, BKT, STAGES>();
+  auto kern = gemm_f32_ring_kernel<BM, BN, WM, WN, LA, LB, EPI, BKT, STAGES>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N, BN));
   dim3 grid(tiles, 1, splits);
@@ -99,6 +121,31 @@ int main(int argc, char** argv) {
            t1 * 1e3, flop / t1 / 1e9, t2 * 1e3, flop / t2 / 1e9, splits, t3 * 1e3, flop / t3 / 1e9); \
   }
 
+#define RROW(name, BM, BN, WM, WN, BKT, ST) if (!filter || strstr(name, filter))                                                              \
+  {                                                                                            \
+    float t1 = run_ring<BM, BN, WM, WN, ROWK, ROWK, EPI_BIAS_STATS, BKT, ST>(f, 1, reps);                    \
+    verify("fwd", h, h, h, C, M, W, W, W, 0, 1);                                               \
+    float t2 = run_ring<BM, BN, WM, WN, ROWK, KROW, EPI_STORE, BKT, ST>(d, 1, reps);                         \
+    verify("dgrad", h, h, h, C, M, W, W, W, 1, 1);                                             \
+    int tiles = (int)(ceil_div(W, BM) * ceil_div(W, BN));                                      \
+    int splits = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(256, tiles), 16));      \
+    w.k_per_split = (int)round_up(ceil_div(M, splits), 64); w.c_split_stride = (int64_t)W * W; \
+    float t3 = run_ring<BM, BN, WM, WN, KROW, KROW, EPI_STORE, BKT, ST>(w, splits, reps);                    \
+    verify("wgrad", h, h, h, C, W, W, M, W, 2, splits);                                        \
+    printf("%-22s fwd %7.1f us %6.1f TF | dgrad %7.1f us %6.1f TF | wgrad(x%d) %7.1f us %6.1f TF\n", name, \
+           t1 * 1e3, flop / t1 / 1e9, t2 * 1e3, flop / t2 / 1e9, splits, t3 * 1e3, flop / t3 / 1e9); \
+  }
+  // interleaved rounds in one process (guide rule 24): shipped r01 kernel vs the ring variants
+  for (int round = 0; round < (getenv("BENCH_ROUNDS") ? atoi(getenv("BENCH_ROUNDS")) : 1); ++round) {
+  ROW("128x128 w4x2 pipe3", 128, 128, 4, 2, 3)
+  RROW("ring 4x2 bk32 st3", 128, 128, 4, 2, 32, 3)
+  RROW("ring 4x2 bk32 st4", 128, 128, 4, 2, 32, 4)
+  RROW("ring 4x2 bk64 st2", 128, 128, 4, 2, 64, 2)
+  RROW("ring 2x4 bk32 st4", 128, 128, 2, 4, 32, 4)
+  RROW("ring 2x2 bk32 st4", 128, 128, 2, 2, 32, 4)
+  RROW("ring 2x2 bk64 st2", 128, 128, 2, 2, 64, 2)
+  }
+  if (getenv("BENCH_RING_ONLY")) { printf("max spot-check error %g\n", g_maxerr); return 0; }
   ROW("128x128 w4x2 pipe1", 128, 128, 4, 2, 1)
   ROW("128x128 w4x2 pipe3", 128, 128, 4, 2, 3)
   ROW("128x128 w2x4 pipe3", 128, 128, 2, 4, 3)

@@ -82,6 +82,8 @@ class Engine:
         self._saved_drop = None
         self._grad_ready_cb = None
         self.grad_ready_hook = None    # callable(offset, count): data-parallel bucket hook
+        self.ctx = None                # N.Context on self.device (side stream, events, options)
+        self.generation = 0            # counts train-mode forwards (guards backward, see _LifterFunction)
 
     # ---------------------------------------------------------------- arenas --
     def _named_params(self):
@@ -138,6 +140,12 @@ class Engine:
             bn._buffers["running_var"] = running[i, 1]
             bn._buffers["num_batches_tracked"] = nbt[i]
         self.params, self.grads, self.bn_running, self.bn_nbt = params, grads, running, nbt
+        if self.ctx is None or self.ctx.device != device:
+            old = self.ctx
+            self.ctx = N.Context(device)
+            if old is not None:    # keep the options across a device move
+                for opt in (N.OPT_TWO_STREAM, N.OPT_DEFER_SLABS):
+                    self.ctx.set_option(opt, old.get_option(opt))
         self.device = device
         self._workspace = None
         self._saved_batch = None
@@ -193,8 +201,8 @@ class Engine:
             if tuple(self.masks.shape) != (self.layout.num_heavy, batch, self.width):
                 raise RuntimeError("dropout masks have shape %s, expected %s" % (
                     tuple(self.masks.shape), (self.layout.num_heavy, batch, self.width)))
-            return N.Dropout(self.masks.data_ptr(), 0, 0, 0)
-        return N.Dropout(None, self.seed, self.rng_step, self.row_offset)
+            return N.Dropout(self.masks.data_ptr(), 0, 0, 0, 0, 0)
+        return N.Dropout(None, self.seed, self.rng_step, self.row_offset, 0, 0)
 
     # ---------------------------------------------------------------- compute --
     def _check_input(self, x):
@@ -236,14 +244,14 @@ class Engine:
         drop = self._drop_struct(batch)
         if sync is None:
             N.check(N.lib().blh_forward_train(
-                ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params),
+                self.ctx.handle, ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params),
                 N.ptr(self.bn_running), N.ptr(self.bn_nbt), N.ptr(x), ctypes.byref(drop),
                 self._momentum(), N.ptr(ws), ws.numel(), N.ptr(pred), batch), "blh_forward_train")
         else:
             errors = []
             cb = self._sync_callback(ws, sync, errors)
             N.check(N.lib().blh_forward_train_sync(
-                ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params),
+                self.ctx.handle, ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params),
                 N.ptr(self.bn_running), N.ptr(self.bn_nbt), N.ptr(x), ctypes.byref(drop),
                 self._momentum(), N.ptr(ws), ws.numel(), N.ptr(pred), batch, int(global_batch),
                 cb, None), "blh_forward_train_sync")
@@ -251,6 +259,7 @@ class Engine:
                 raise errors[0]
         self._saved_batch = batch
         self._saved_drop = drop
+        self.generation += 1
         if self.masks is None:
             self.rng_step += 1
         return pred
@@ -263,14 +272,28 @@ class Engine:
         self._saved_batch = None       # eval overwrites the saved activations
         pred = torch.empty(batch, OUT_FEATURES, dtype=torch.float32, device=x.device)
         N.check(N.lib().blh_forward_eval(
-            ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params),
+            self.ctx.handle, ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params),
             N.ptr(self.bn_running), N.ptr(x), N.ptr(ws), ws.numel(), N.ptr(pred), batch),
             "blh_forward_eval")
         return pred
 
-    def backward(self, x, dpred, on_ready=None, sync=None, global_batch=None):
-        """Gradients of every parameter into the grad arena (overwritten)."""
+    def set_two_stream(self, enabled):
+        """A/B switch of the two-stream backward (bit-identical results either way)."""
+        if self.ctx is None:
+            raise RuntimeError("the engine is not on a device yet")
+        self.ctx.set_option(N.OPT_TWO_STREAM, 1 if enabled else 0)
+
+    def backward(self, x, dpred, on_ready=None, sync=None, global_batch=None, generation=None):
+        """Gradients of every parameter into the grad arena (overwritten).  ``generation`` (the
+        value of ``self.generation`` right after the forward this backward belongs to) guards
+        the single workspace: activations, batch statistics and the dropout step saved there
+        are those of the LAST train-mode forward only."""
         batch = x.shape[0]
+        if generation is not None and generation != self.generation:
+            raise RuntimeError(
+                "backward of a forward whose saved activations were overwritten: BilinearUnit keeps "
+                "the state of the most recent train-mode forward only (forward %d, latest %d); run "
+                "backward before the next forward" % (generation, self.generation))
         if self._saved_batch != batch:
             raise RuntimeError("backward called without a matching train-mode forward "
                                "(the workspace holds the activations of the last forward only)")
@@ -283,7 +306,7 @@ class Engine:
             # a reported range is complete on the library's side stream (weight-gradient GEMMs):
             # the hook runs with that stream current, so a collective launched from it is
             # ordered behind the range without stalling the main stream
-            side = N.lib().blh_backward_side_stream()
+            side = self.ctx.side_stream()
             side_stream = torch.cuda.ExternalStream(side, device=x.device) if side else None
 
             def _hook(user, off, cnt):
@@ -304,13 +327,13 @@ class Engine:
         self._grad_ready_cb = cb       # keep alive during the call
         if sync is None:
             N.check(N.lib().blh_backward(
-                ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params), N.ptr(x),
+                self.ctx.handle, ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params), N.ptr(x),
                 ctypes.byref(self._saved_drop), N.ptr(ws), ws.numel(), N.ptr(dpred),
                 N.ptr(self.grads), batch, cb, None), "blh_backward")
         else:
             scb = self._sync_callback(ws, sync, errors)
             N.check(N.lib().blh_backward_sync(
-                ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params), N.ptr(x),
+                self.ctx.handle, ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params), N.ptr(x),
                 ctypes.byref(self._saved_drop), N.ptr(ws), ws.numel(), N.ptr(dpred),
                 N.ptr(self.grads), batch, cb, None, int(global_batch), scb, None),
                 "blh_backward_sync")
@@ -356,7 +379,7 @@ class Engine:
         drop = self._drop_struct(batch)
         hyper = N.AdamHyper(lr, betas[0], betas[1], eps, 0.0 if max_norm is None else max_norm, step)
         N.check(N.lib().blh_train_step(
-            ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params), N.ptr(self.grads),
+            self.ctx.handle, ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params), N.ptr(self.grads),
             N.ptr(exp_avg), N.ptr(exp_avg_sq), N.ptr(self.bn_running), N.ptr(self.bn_nbt),
             N.ptr(x), N.ptr(target), ctypes.byref(drop), self._momentum(), ctypes.byref(hyper),
             N.ptr(ws), ws.numel(), N.ptr(pred), N.ptr(loss), N.ptr(stats), batch),

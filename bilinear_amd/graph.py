@@ -43,10 +43,15 @@ class CapturedTrainStep:
         self.loss = torch.empty((), dtype=torch.float32, device=dev)
         self.ws = eng.workspace(batch)
         self.state = torch.zeros(ctypes.sizeof(N.StepState), dtype=torch.uint8, device=dev)
-        self._host_state = torch.zeros(ctypes.sizeof(N.StepState), dtype=torch.uint8).pin_memory()
-        self._lr = None
+        # two pinned staging buffers used alternately, each guarded by the event of its last
+        # H2D copy: rewriting the state on consecutive steps never races an in-flight copy
+        self._host_state = [torch.zeros(ctypes.sizeof(N.StepState), dtype=torch.uint8).pin_memory()
+                            for _ in range(2)]
+        self._host_event = [None, None]
+        self._host_slot = 0
+        self._mirror = None            # (lr, opt._t, eng.rng_step) the device state was written for
         self._write_state()
-        self._drop = N.Dropout(None, eng.seed, 0, eng.row_offset)
+        self._drop = N.Dropout(None, eng.seed, 0, eng.row_offset, 0, 0)
         # Warm-up on a side stream (sets kernel attributes, touches every buffer) on a snapshot
         # of the training state, which is restored afterwards: building the graph must not
         # move the model.  Capture itself executes nothing.
@@ -74,14 +79,21 @@ class CapturedTrainStep:
                          0.0, 0.0)
         # rng_step holds (next dropout step - 1): blh_step_state_advance adds 1 before use
         raw = bytes(st)
-        self._host_state.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
-        self.state.copy_(self._host_state, non_blocking=True)
-        self._lr = float(g["lr"])
+        slot = self._host_slot
+        self._host_slot ^= 1
+        if self._host_event[slot] is not None:
+            self._host_event[slot].synchronize()
+        self._host_state[slot].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+        self.state.copy_(self._host_state[slot], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._host_event[slot] = ev
+        self._mirror = (float(g["lr"]), int(self.opt._t), int(self.eng.rng_step))
 
     def _enqueue(self):
         eng, opt = self.eng, self.opt
         N.check(N.lib().blh_train_step_captured(
-            ctypes.byref(eng.layout.desc), eng._stream(), N.ptr(eng.params), N.ptr(eng.grads),
+            eng.ctx.handle, ctypes.byref(eng.layout.desc), eng._stream(), N.ptr(eng.params), N.ptr(eng.grads),
             N.ptr(opt._exp_avg), N.ptr(opt._exp_avg_sq), N.ptr(eng.bn_running), N.ptr(eng.bn_nbt),
             N.ptr(self.x), N.ptr(self.t), ctypes.byref(self._drop), eng._momentum(),
             N.ptr(self.state), N.ptr(self.ws), self.ws.numel(), N.ptr(self.pred),
@@ -92,6 +104,9 @@ class CapturedTrainStep:
         self.opt._sync_step_state(self.eng)
         self.eng.rng_step += 1
         self.eng._saved_batch = None
+        self.eng.generation += 1
+        # the graph's first node advanced the device counters exactly like this
+        self._mirror = (self._mirror[0], int(self.opt._t), int(self.eng.rng_step))
 
     @torch.no_grad()
     def __call__(self, x, target):
@@ -99,8 +114,10 @@ class CapturedTrainStep:
             raise RuntimeError("captured for batch %d, got %d" % (self.batch, x.shape[0]))
         if not self.eng.is_packed(self.x.device) or self.eng.workspace(self.batch) is not self.ws:
             raise RuntimeError("the module's device arenas changed after capture; re-capture")
-        lr = float(self.opt.param_groups[0]["lr"])
-        if lr != self._lr:
+        # the device-resident (lr, Adam step, dropout step) must be what the host expects: an
+        # eager step, optimizer.step() or another captured step in between moves the host side
+        want = (float(self.opt.param_groups[0]["lr"]), int(self.opt._t), int(self.eng.rng_step))
+        if want != self._mirror:
             self._write_state()
         self.x.copy_(x, non_blocking=True)
         self.t.copy_(target, non_blocking=True)

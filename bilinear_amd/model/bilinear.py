@@ -42,11 +42,13 @@ class _HeavyStageFunction(torch.autograd.Function):
         ws = torch.empty(int(need), dtype=torch.uint8, device=x.device)
         out = torch.empty(batch, out_f, dtype=torch.float32, device=x.device)
         training = bool(stage.training)
-        drop = N.Dropout(None, stage._seed, stage._rng_step, 0)
+        # every stand-alone stage draws its own Philox stream (layer_base = its process-unique id)
+        drop = N.Dropout(None, stage._seed, stage._rng_step, 0, stage._stage_id, 0)
         momentum = -1.0 if bn.momentum is None else float(bn.momentum)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        hctx = N.default_context(x.device)
         N.check(N.lib().blh_heavy_forward(
-            st, N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(gamma), N.ptr(beta),
+            hctx.handle, st, N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(gamma), N.ptr(beta),
             N.ptr(bn.running_mean), N.ptr(bn.running_var), N.ptr(bn.num_batches_tracked),
             ctypes.byref(drop), momentum, int(training), 0, N.ptr(ws), ws.numel(), N.ptr(out),
             batch, in_f, out_f), "blh_heavy_forward")
@@ -72,7 +74,7 @@ class _HeavyStageFunction(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         N.check(N.lib().blh_heavy_backward(
-            st, N.ptr(d_out), N.ptr(x), N.ptr(weight), N.ptr(gamma), ctypes.byref(drop), 0,
+            N.default_context(x.device).handle, st, N.ptr(d_out), N.ptr(x), N.ptr(weight), N.ptr(gamma), ctypes.byref(drop), 0,
             N.ptr(ws), ws.numel(), N.ptr(dw), N.ptr(db), N.ptr(dg), N.ptr(dbeta), N.ptr(dx), batch,
             in_f, out_f), "blh_heavy_backward")
         return dx, None, dw, db, dg, dbeta
@@ -84,6 +86,15 @@ class _HeavyLinear(nn.Sequential):
     Inside ``BilinearUnit`` the children only hold parameters and buffers (the unit drives all
     stages natively, fused across stage boundaries).  Called on its own, the stage runs the
     same kernels through blh_heavy_forward / blh_heavy_backward (HIP device only)."""
+
+    # Philox stream ids of stand-alone stages start above any BilinearUnit's stage indices
+    # (<= 32), one per constructed stage: stacked stages of equal shape never share a mask
+    _next_stage_id = [1000]
+
+    def __init__(self, *mods):
+        super().__init__(*mods)
+        object.__setattr__(self, "_stage_id", _HeavyLinear._next_stage_id[0])
+        _HeavyLinear._next_stage_id[0] += 1
 
     def forward(self, in_tensor):   # noqa: D401
         if in_tensor.device.type != "cuda":
@@ -129,6 +140,7 @@ class _LifterFunction(torch.autograd.Function):
     def forward(ctx, x, engine, *params):
         pred = engine.forward_train(x)
         ctx.engine = engine
+        ctx.generation = engine.generation
         ctx.x = x
         ctx.params = params
         return pred
@@ -139,7 +151,7 @@ class _LifterFunction(torch.autograd.Function):
         accumulate = any(p.grad is not None for p in ctx.params)
         old = engine.grads.clone() if accumulate else None
         hook = engine.grad_ready_hook
-        engine.backward(ctx.x, dpred, on_ready=hook)
+        engine.backward(ctx.x, dpred, on_ready=hook, generation=ctx.generation)
         for (_, p, off, shape) in engine._named_params():
             view = engine.grad_view(off, shape)
             if p.grad is None:

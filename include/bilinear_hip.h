@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define BLH_ABI_VERSION 1
+#define BLH_ABI_VERSION 2
 
 typedef enum {
   BLH_OK = 0,
@@ -53,6 +53,33 @@ typedef enum {
 const char* blh_status_string(int status);
 int blh_last_hip_error(void);
 int blh_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * Context.  Everything the library owns on a device lives in a caller-owned blh_context:
+ * the side stream + fork/join events of the two-stream backward, the per-call SyncBN /
+ * captured-step plumbing and the option flags.  There is no process-global device state.
+ *   - blh_context_create binds the context to the CURRENT HIP device (hipGetDevice) and
+ *     creates the side stream there; every network-level entry point below takes the
+ *     context first and returns BLH_ERR_INVALID_ARGUMENT when another device is current.
+ *   - one context = one in-flight call: a context must not be used from two host threads
+ *     at once (use one context per thread / per model replica; contexts are cheap).
+ *   - kernel attributes (dynamic LDS size) are set once per device, thread-safely.
+ * The reference has no counterpart: it runs on PyTorch's per-process CUDA state
+ * (/root/reference/util/config.py:17 picks the one device).                              */
+typedef struct blh_context blh_context;
+int blh_context_create(blh_context** out);
+int blh_context_destroy(blh_context* ctx);
+typedef enum {
+  BLH_OPT_TWO_STREAM = 0, /* 1 (default): weight-gradient GEMMs on the context's side stream;
+                             0: single-stream order.  Results are bit-identical either way.  */
+  BLH_OPT_DEFER_SLABS = 1 /* 1: sum all split-K weight-gradient slabs in one launch at the end
+                             of backward (default 0: right after each GEMM)                  */
+} blh_option;
+int blh_context_set_option(blh_context* ctx, int32_t option, int32_t value);
+int blh_context_get_option(const blh_context* ctx, int32_t option);
+/* The side stream (hipStream_t as void*) the weight-gradient GEMMs run on; NULL when
+ * BLH_OPT_TWO_STREAM is 0.  See blh_backward.                                            */
+void* blh_context_side_stream(blh_context* ctx);
 
 /* ------------------------------------------------------------------------
  * Model description.  The reference hard-codes num_blocks=2, width=1024,
@@ -112,12 +139,18 @@ int64_t blh_workspace_bytes(const blh_model_desc* d, int64_t batch);
  * or keep_mask == NULL: counter-based Philox4x32-10 keyed by (seed, step,
  * layer, global row, column); the mask is regenerated in backward, never
  * stored.  row_offset is the global index of local row 0 (data parallel:
- * rank * per-rank batch), and must be a multiple of 32.                     */
+ * rank * per-rank batch), and must be a multiple of 32.  The mask depends only on
+ * (seed, step, layer_base + stage, global row, column).                     */
 typedef struct {
   const uint8_t* keep_mask; /* device, or NULL for Philox                    */
   uint64_t seed;
   uint64_t step;
   int64_t row_offset;
+  int32_t layer_base;       /* added to the stage index to form the Philox stream id: 0 for a
+                               BilinearUnit (stage i draws stream i); a process-unique id for a
+                               stand-alone heavy_linear, so that stacked stages of equal shape
+                               never share a mask                                            */
+  int32_t reserved;
 } blh_dropout;
 
 /* Device-resident step state for hipGraph replay.  A captured launch freezes by-value
@@ -141,14 +174,14 @@ typedef struct {
  * PyTorch's cumulative average (reset_statistics, model/bilinear.py:43-55).
  * Saves pre-BN outputs, activations and batch statistics in `workspace` for
  * blh_backward.  x: device [B,32]; pred: device [B,48] (written).           */
-int blh_forward_train(const blh_model_desc* d, void* stream, const float* params,
+int blh_forward_train(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params,
                       float* bn_running, int64_t* bn_num_batches_tracked, const float* x,
                       const blh_dropout* drop, float momentum, void* workspace,
                       int64_t workspace_bytes, float* pred, int64_t batch);
 
 /* Eval-mode forward (valid_bilinear.py:31,52): BN uses running stats, dropout
  * is the identity, nothing is saved.                                        */
-int blh_forward_eval(const blh_model_desc* d, void* stream, const float* params,
+int blh_forward_eval(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params,
                      const float* bn_running, const float* x, void* workspace,
                      int64_t workspace_bytes, float* pred, int64_t batch);
 
@@ -171,13 +204,12 @@ int blh_mse_loss_grad(void* stream, const float* pred, const float* target, int6
  * all-reduce of that bucket from it, overlapping the rest of backward.
  * The weight-gradient GEMMs run on a side stream owned by the library (next to the
  * data-gradient GEMM and the BatchNorm-backward kernels of the following stage); a reported
- * range is complete on THAT stream: blh_backward_side_stream() returns it (NULL when the
+ * range is complete on THAT stream: blh_context_side_stream(ctx) returns it (NULL when the
  * library runs single-stream, BLH_ONE_STREAM=1, and the range is complete on `stream`), and
  * the collective must be ordered behind it (e.g. make it the current stream while launching
  * the all-reduce).  blh_backward itself returns with `stream` waiting for the side stream. */
 typedef void (*blh_grad_ready_fn)(void* user, int64_t offset_floats, int64_t count_floats);
-void* blh_backward_side_stream(void);
-int blh_backward(const blh_model_desc* d, void* stream, const float* params, const float* x,
+int blh_backward(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params, const float* x,
                  const blh_dropout* drop, void* workspace, int64_t workspace_bytes,
                  const float* dpred, float* grads, int64_t batch, blh_grad_ready_fn on_ready,
                  void* user);
@@ -191,12 +223,12 @@ int blh_backward(const blh_model_desc* d, void* stream, const float* params, con
  * [sum dY*zhat | sum dY] (fp32, 2W).  With equal per-rank batches the result equals the
  * reference's single-device run on the concatenated batch (SURVEY.md hazard H5).        */
 typedef void (*blh_sync_fn)(void* user, void* device_buf, int64_t count, int32_t dtype);
-int blh_forward_train_sync(const blh_model_desc* d, void* stream, const float* params,
+int blh_forward_train_sync(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params,
                            float* bn_running, int64_t* bn_num_batches_tracked, const float* x,
                            const blh_dropout* drop, float momentum, void* workspace,
                            int64_t workspace_bytes, float* pred, int64_t batch,
                            int64_t global_batch, blh_sync_fn sync, void* user);
-int blh_backward_sync(const blh_model_desc* d, void* stream, const float* params, const float* x,
+int blh_backward_sync(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params, const float* x,
                       const blh_dropout* drop, void* workspace, int64_t workspace_bytes,
                       const float* dpred, float* grads, int64_t batch, blh_grad_ready_fn on_ready,
                       void* user, int64_t global_batch, blh_sync_fn sync, void* sync_user);
@@ -225,7 +257,7 @@ int blh_clip_adam_step(void* stream, float* params, float* grads, float* exp_avg
 /* ---- whole training step (single GPU) --------------------------------------------
  * The step body of train_bilinear.py:75-83 as one enqueue: forward_train, MSE,
  * backward, clip, Adam.  loss_out: device scalar.                            */
-int blh_train_step(const blh_model_desc* d, void* stream, float* params, float* grads,
+int blh_train_step(blh_context* ctx, const blh_model_desc* d, void* stream, float* params, float* grads,
                    float* exp_avg, float* exp_avg_sq, float* bn_running,
                    int64_t* bn_num_batches_tracked, const float* x, const float* target,
                    const blh_dropout* drop, float momentum, const blh_adam_hyper* hyper,
@@ -236,7 +268,7 @@ int blh_train_step(const blh_model_desc* d, void* stream, float* params, float* 
  * into a hipGraph and replay; drop->step is added to dev_state->rng_step.  Enqueues
  * blh_step_state_advance first.                                                        */
 int blh_step_state_advance(void* stream, blh_step_state* dev_state);
-int blh_train_step_captured(const blh_model_desc* d, void* stream, float* params, float* grads,
+int blh_train_step_captured(blh_context* ctx, const blh_model_desc* d, void* stream, float* params, float* grads,
                             float* exp_avg, float* exp_avg_sq, float* bn_running,
                             int64_t* bn_num_batches_tracked, const float* x, const float* target,
                             const blh_dropout* drop, float momentum, blh_step_state* dev_state,
@@ -250,13 +282,13 @@ int blh_train_step_captured(const blh_model_desc* d, void* stream, float* params
  * statistics, no dropout, nothing saved.  backward writes dW, db, dgamma, dbeta and, if d_in is
  * not NULL, the input gradient [B, in].  drop->keep_mask, if given, is [B, out].            */
 int64_t blh_heavy_workspace_bytes(int64_t batch, int32_t in_features, int32_t out_features);
-int blh_heavy_forward(void* stream, const float* a_in, const float* weight, const float* bias,
+int blh_heavy_forward(blh_context* ctx, void* stream, const float* a_in, const float* weight, const float* bias,
                       const float* gamma, const float* beta, float* running_mean,
                       float* running_var, int64_t* num_batches_tracked, const blh_dropout* drop,
                       float momentum, int32_t training, int32_t gemm_dtype, void* workspace,
                       int64_t workspace_bytes, float* a_out, int64_t batch, int32_t in_features,
                       int32_t out_features);
-int blh_heavy_backward(void* stream, const float* d_out, const float* a_in, const float* weight,
+int blh_heavy_backward(blh_context* ctx, void* stream, const float* d_out, const float* a_in, const float* weight,
                        const float* gamma, const blh_dropout* drop, int32_t gemm_dtype,
                        void* workspace, int64_t workspace_bytes, float* d_weight, float* d_bias,
                        float* d_gamma, float* d_beta, float* d_in, int64_t batch,

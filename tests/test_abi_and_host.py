@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(native):
         assert hasattr(native, name), "libbilinear_hip.so does not export %s" % name
     from bilinear_amd import _native
     assert sorted(_native.exported_names()) == decl, "ctypes table and header disagree"
-    assert native.blh_abi_version() == 1
+    assert native.blh_abi_version() == 2
     assert native.blh_status_string(0) == b"ok"
     assert native.blh_status_string(-4) == b"workspace too small"
 
@@ -61,8 +61,13 @@ def test_argument_validation_without_gpu(native):
     d = N.ModelDesc(2, 1024, 32, 48)
     drop = N.Dropout(None, 1, 0, 0)
     # NULL pointers / bad sizes are rejected before any HIP call
-    assert native.blh_forward_train(ctypes.byref(d), None, None, None, None, None, ctypes.byref(drop),
+    # (a NULL context is refused first: every network-level call needs a caller-owned context)
+    assert native.blh_forward_train(None, ctypes.byref(d), None, None, None, None, None, ctypes.byref(drop),
                                     0.1, None, 0, None, 64) == -1
+    assert native.blh_context_create(None) == -1
+    assert native.blh_context_destroy(None) == 0
+    assert native.blh_context_set_option(None, 0, 1) == -1
+    assert native.blh_context_side_stream(None) is None
     assert native.blh_gemm_f32(None, None, 0, 0, None, 0, 0, None, 0, 0, 0, 0, 1, None, None, 0) == -1
     drop_bad = N.Dropout(None, 1, 0, 5)          # Philox needs row_offset % 32 == 0
     ws = ctypes.create_string_buffer(512)
@@ -81,6 +86,10 @@ def test_module_surface_matches_reference():
     h = bilinear_amd.heavy_linear(32, 64)
     assert [type(m).__name__ for m in h] == ["Linear", "BatchNorm1d", "ReLU", "Dropout"]
     assert h[3].p == 0.5 and h[1].eps == 1e-5 and h[1].momentum == 0.1
+    # every stand-alone stage owns a Philox stream (stacked equal stages never share a mask),
+    # all above the stage indices a BilinearUnit uses (<= 32)
+    h2 = bilinear_amd.heavy_linear(32, 64)
+    assert h._stage_id != h2._stage_id and min(h._stage_id, h2._stage_id) > 32
     # reset_statistics (model/bilinear.py:43-55): cumulative average mode
     net.encode[1].running_mean.fill_(3.0)
     net.reset_statistics()

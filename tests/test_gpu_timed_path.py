@@ -1,0 +1,351 @@
+"""Oracle parity on the path ``bench.py`` times (run on the MI355X box: ``pytest -m gpu``).
+
+The small-batch tests of test_gpu_parity.py all take the split-K forward and the one-stream
+backward (fewer than 128 output tiles).  These tests run the SAME code ``bench.py`` measures —
+``BilinearUnit.train_step`` (blh_train_step) and the drop-in forward / backward at
+(2 blocks, width 1024) with B in {2048, 4096, 4100}: BatchNorm statistics in the GEMM epilogue
+merged over row tiles, the two-stream backward with double-buffered dZ, the in-place residual
+dgrad, Philox dropout regenerated in backward — and compare every observable of the reference's
+step body (/root/reference/train_bilinear.py:75-83: prediction, loss, every gradient, clip
+coefficient, Adam moments, parameters after the step, BatchNorm running statistics) with the fp64
+NumPy oracle and with the PyTorch CPU port, both pinned to the reference's golden vectors
+(tests/test_oracle_golden.py).  The dropout masks the kernels draw are materialised with
+blh_dropout_mask and replayed in the oracle.
+
+Also here: the per-GPU shapes of BASELINE configs 3-5 (4 blocks x 1024 at B=16384;
+8 blocks x 2048), and the bit-identity of the one-stream and two-stream schedules.
+
+Tolerances: north_star states 1e-3 rel for fp32; TIGHT = 1e-4 is what the kernels meet.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import is_prebn_bias
+from oracle import numpy_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-3
+TIGHT = 1e-4
+FP32_MODES = ["fp32", "bf16x3", "fp16x2"]
+LR = 1e-3
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _close(got, ref, rtol, what, atol=0.0):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    rms = np.sqrt((ref ** 2).mean()) if ref.size else 0.0
+    bound = rtol * (np.abs(ref) + rms) + atol
+    err = np.abs(got - ref)
+    worst = np.unravel_index(np.argmax(err - bound), err.shape) if ref.size else ()
+    assert (err <= bound).all(), "%s: |err|=%.3e > %.3e at %s (ref %.3e rms %.3e)" % (
+        what, err[worst], np.broadcast_to(bound, err.shape)[worst], worst, ref[worst], rms)
+
+
+def _state(nb, width, seed):
+    st = O.init_state(seed, nb, width)
+    rng = np.random.RandomState(seed + 1)
+    for k in st:        # non-trivial gamma / beta so that their gradients are exercised
+        if k.endswith(".1.weight"):
+            st[k] = (1.0 + 0.2 * rng.standard_normal(st[k].shape)).astype(np.float32)
+        if k.endswith(".1.bias"):
+            st[k] = (0.1 * rng.standard_normal(st[k].shape)).astype(np.float32)
+    return st
+
+
+def _build(st, dev, nb, width, mode, seed=4242):
+    import bilinear_amd
+    net = bilinear_amd.BilinearUnit(num_blocks=nb, width=width, gemm_dtype=mode)
+    sd = net.state_dict()
+    net.load_state_dict({k: torch.from_numpy(np.array(st[k])).reshape(sd[k].shape) for k in sd})
+    net = net.to(dev).train()
+    opt = bilinear_amd.Adam(net.parameters(), lr=LR, module=net)
+    net.engine.ensure(dev)
+    net.engine.seed = seed
+    net.engine.rng_step = 0
+    return net, opt
+
+
+def _philox_masks(net, step, batch):
+    """The keep-masks the kernels regenerate for dropout step ``step`` (uint8 [B,W] per stage)."""
+    from bilinear_amd import _native as N
+    eng = net.engine
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = []
+    for layer in range(eng.layout.num_heavy):
+        m = torch.empty(batch, eng.width, dtype=torch.uint8, device=eng.device)
+        d = N.Dropout(None, eng.seed, step, eng.row_offset)
+        assert N.lib().blh_dropout_mask(st, ctypes.byref(d), layer, batch, eng.width, m.data_ptr()) == 0
+        out.append(m.cpu().numpy())
+    return out
+
+
+_ORACLE_CACHE = {}
+
+
+def _oracle_step(nb, width, batch, rounding=None):
+    """One reference step in fp64 on the seeded inputs (cached across the GEMM modes)."""
+    key = (nb, width, batch, rounding)
+    if key not in _ORACLE_CACHE:
+        st = _state(nb, width, 100 + nb)
+        x, t = O.synthetic_batch(5, batch)
+        _ORACLE_CACHE.clear()            # one entry at a time: the caches are hundreds of MB
+        _ORACLE_CACHE[key] = dict(st0=st, x=x, t=t)
+    return _ORACLE_CACHE[key]
+
+
+def _run_oracle(entry, masks, rounding=None):
+    if "ref" in entry:
+        return entry["ref"]
+    st = {k: v.copy() for k, v in entry["st0"].items()}
+    keys = O.param_keys((sum(1 for k in st if k.endswith(".0.weight")) - 1) // 2)
+    opt = O.adam_init(st, keys)
+    O.set_gemm_rounding(rounding)
+    try:
+        r = O.train_step(st, opt, entry["x"], entry["t"], masks, LR, dtype=np.float64)
+    finally:
+        O.set_gemm_rounding(None)
+    r["state"] = st
+    r["opt"] = opt
+    r["keys"] = keys
+    entry["ref"] = r
+    return r
+
+
+def _adam_atol(g_clipped, v_ref, numel_rms, rtol):
+    """Adam's update lr*m_hat/(sqrt(v_hat)+eps) is sign-like, hence ill-conditioned where |g| is
+    tiny: a gradient error dg moves the parameter by up to 2*lr*dg/(sqrt(v_hat)+eps), capped at
+    2*lr (same bound as golden_util.Golden.adam_atol, first step)."""
+    dg = rtol * (np.abs(g_clipped) + numel_rms)
+    vhat = np.sqrt(np.maximum(v_ref, 0) / (1 - 0.999))
+    return 2 * LR * np.minimum(1.0, dg / (vhat + 1e-8))
+
+
+def _compare_fused_step(net, opt, pred, loss, r, rtol):
+    _close(pred.detach().cpu().numpy(), r["pred"], rtol, "pred")
+    assert abs(float(loss) - r["loss"]) <= rtol * r["loss"], (float(loss), r["loss"])
+    stats = opt.last_grad_norm_stats.cpu().numpy()
+    assert abs(stats[0] - r["total_norm"]) <= rtol * r["total_norm"], (stats, r["total_norm"])
+    assert abs(stats[1] - r["clip_coef"]) <= rtol * r["clip_coef"], (stats, r["clip_coef"])
+    for k, p in net.named_parameters():
+        g = p.grad.detach().cpu().numpy()
+        if is_prebn_bias(k):                  # mathematically zero (SURVEY.md hazard H2)
+            assert np.abs(g).max() < 1e-5 * max(1.0, r["clip_coef"]), k
+            continue
+        gref = np.asarray(r["grads"][k], np.float64)
+        _close(g, gref, 3 * rtol, "clipped grad " + k)
+        stp = opt.state[p]
+        m_ref = r["opt"]["exp_avg"][k]
+        v_ref = r["opt"]["exp_avg_sq"][k]
+        _close(stp["exp_avg"].cpu().numpy(), m_ref, 3 * rtol, "exp_avg " + k)
+        _close(stp["exp_avg_sq"].cpu().numpy(), v_ref, 6 * rtol, "exp_avg_sq " + k)
+        rms_g = float(np.sqrt((gref ** 2).mean()))
+        _close(p.detach().cpu().numpy(), r["state"][k], rtol, "param after Adam " + k,
+               atol=_adam_atol(gref, np.asarray(v_ref, np.float64), rms_g, 3 * rtol))
+    sd = net.state_dict()
+    for k in sd:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            _close(sd[k].cpu().numpy(), r["state"][k], rtol, k)
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == 1, k
+
+
+# ----------------------------------------------------------------------------
+# BASELINE configs[1] (2 blocks, width 1024) at the batch sizes of the non-split-K path
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", FP32_MODES)
+@pytest.mark.parametrize("batch", [2048, 4096, 4100])
+def test_timed_path_step_matches_oracle(batch, mode):
+    """blh_train_step exactly as bench.py runs it (Philox dropout, two-stream backward) against
+    the fp64 oracle replaying the same masks; then the drop-in forward / backward (raw gradients)
+    from the same initial state."""
+    dev = _dev()
+    nb, width = 2, 1024
+    entry = _oracle_step(nb, width, batch)
+    x, t = entry["x"], entry["t"]
+    xt, tt = torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev)
+
+    net, opt = _build(entry["st0"], dev, nb, width, mode)
+    masks = _philox_masks(net, 0, batch)
+    rate = float(np.mean([m.mean() for m in masks]))
+    assert abs(rate - 0.5) < 0.005, rate
+    r = _run_oracle(entry, masks)
+    pred, loss = net.train_step(opt, xt, tt, max_norm=1.0)
+    torch.cuda.synchronize()
+    _compare_fused_step(net, opt, pred, loss.item(), r, TIGHT)
+
+    # drop-in surface (autograd): raw gradients before clipping
+    net2, opt2 = _build(entry["st0"], dev, nb, width, mode)
+    opt2.zero_grad()
+    p2 = net2(xt)
+    l2 = torch.nn.functional.mse_loss(p2, tt)
+    l2.backward()
+    _close(p2.detach().cpu().numpy(), r["pred"], TIGHT, "drop-in pred")
+    assert abs(l2.item() - r["loss"]) <= TIGHT * r["loss"]
+    for k, p in net2.named_parameters():
+        if is_prebn_bias(k):
+            assert float(p.grad.abs().max()) < 1e-5, k
+            continue
+        _close(p.grad.cpu().numpy(), r["grads_raw"][k], 3 * TIGHT, "raw grad " + k)
+
+
+@pytest.mark.parametrize("batch", [4096])
+def test_timed_path_step_matches_torch_port(batch):
+    """The same step against the second pinned checker: plain PyTorch on the CPU
+    (oracle/torch_port.py) with the kernels' Philox masks injected into its Dropout modules."""
+    from oracle import torch_port as TP
+    dev = _dev()
+    nb, width = 2, 1024
+    entry = _oracle_step(nb, width, batch)
+    xt, tt = torch.from_numpy(entry["x"]), torch.from_numpy(entry["t"])
+    net, opt = _build(entry["st0"], dev, nb, width, "fp32")
+    masks = _philox_masks(net, 0, batch)
+    pred, loss = net.train_step(opt, xt.to(dev), tt.to(dev), max_norm=1.0)
+    torch.cuda.synchronize()
+
+    port = TP.LifterPort(nb, width)
+    TP.load_numpy_state(port, entry["st0"])
+    port.train()
+    inj = TP.MaskInjector(port)
+    inj.masks = [torch.from_numpy(m) for m in masks]
+    popt = torch.optim.Adam(port.parameters(), lr=LR)
+    ppred, ploss, ptotal = TP.train_step(port, popt, xt, tt)
+    inj.remove()
+    _close(pred.cpu().numpy(), ppred.detach().numpy(), TIGHT, "pred vs torch port")
+    assert abs(loss.item() - ploss.item()) <= TIGHT * ploss.item()
+    stats = opt.last_grad_norm_stats.cpu().numpy()
+    assert abs(stats[0] - float(ptotal)) <= TIGHT * float(ptotal)
+    pp = dict(port.named_parameters())
+    for k, p in net.named_parameters():
+        if is_prebn_bias(k):
+            continue
+        _close(p.grad.cpu().numpy(), pp[k].grad.numpy(), 3 * TIGHT, "clipped grad vs torch port " + k)
+    psd = port.state_dict()
+    sd = net.state_dict()
+    for k in sd:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            _close(sd[k].cpu().numpy(), psd[k].numpy(), TIGHT, k)
+
+
+@pytest.mark.parametrize("mode", FP32_MODES)
+def test_one_stream_and_two_stream_schedules_are_bit_identical(mode):
+    """The two-stream backward only re-orders independent kernels: every gradient, moment and
+    parameter must be bit-equal to the single-stream schedule."""
+    dev = _dev()
+    nb, width, batch = 2, 1024, 4096
+    entry = _oracle_step(nb, width, batch)
+    xt, tt = torch.from_numpy(entry["x"]).to(dev), torch.from_numpy(entry["t"]).to(dev)
+    out = {}
+    for two in (True, False):
+        net, opt = _build(entry["st0"], dev, nb, width, mode)
+        net.engine.set_two_stream(two)
+        for _ in range(2):
+            pred, loss = net.train_step(opt, xt, tt, max_norm=1.0)
+        torch.cuda.synchronize()
+        out[two] = (pred.clone(), net.engine.grads.clone(), net.engine.params.clone(),
+                    opt._exp_avg_sq.clone(), net.engine.bn_running.clone())
+    for a, b, what in zip(out[True], out[False], ("pred", "grads", "params", "exp_avg_sq", "running")):
+        assert torch.equal(a, b), what
+
+
+# ----------------------------------------------------------------------------
+# per-GPU shapes of BASELINE configs 3-5
+# ----------------------------------------------------------------------------
+def _forward_backward_check(nb, width, batch, mode, rounding, pred_tol, grad_l2_tol, decode_tol):
+    dev = _dev()
+    entry = _oracle_step(nb, width, batch, rounding)
+    x, t = entry["x"], entry["t"]
+    xt, tt = torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev)
+    net, opt = _build(entry["st0"], dev, nb, width, mode)
+    masks = _philox_masks(net, 0, batch)
+    r = _run_oracle(entry, masks, rounding)
+    opt.zero_grad()
+    pred = net(xt)
+    loss = torch.nn.functional.mse_loss(pred, tt)
+    loss.backward()
+    got = pred.detach().cpu().numpy().astype(np.float64)
+    rel = np.linalg.norm(got - r["pred"]) / np.linalg.norm(r["pred"])
+    assert rel <= pred_tol, ("pred", rel)
+    assert abs(loss.item() - r["loss"]) <= max(pred_tol, 1e-4) * r["loss"]
+    worst = 0.0
+    for k, p in net.named_parameters():
+        if is_prebn_bias(k):
+            continue
+        g = p.grad.cpu().numpy().astype(np.float64)
+        assert np.isfinite(g).all(), k
+        rel = np.linalg.norm(g - r["grads_raw"][k]) / np.linalg.norm(r["grads_raw"][k])
+        tol = decode_tol if k.startswith("decode") else grad_l2_tol
+        assert rel <= tol, (k, rel)
+        worst = max(worst, rel)
+    print("%dx%d B=%d %s: pred rel L2 %.2e, worst grad rel L2 %.2e" % (nb, width, batch, mode, rel, worst))
+    # size-independent properties at the same shape: pre-BN bias gradients vanish; a second
+    # forward with the same dropout step reproduces the prediction bit for bit
+    for name, off, shape in net.engine.layout.entries:
+        if is_prebn_bias(name):
+            assert net.engine.grads[off:off + shape[0]].abs().max().item() < 1e-5
+    net.engine.rng_step = 0
+    with torch.no_grad():
+        again = net(xt)
+    assert torch.equal(again, pred.detach())
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp16x2"])
+def test_config5_shape_8x2048_fp32_against_oracle(mode):
+    """8 blocks x width 2048 (BASELINE configs[4] network) at B=2048: 256 output tiles per GEMM,
+    i.e. the non-split-K / two-stream path at width 2048."""
+    _forward_backward_check(8, 2048, 2048, mode, None, 2e-4, 2e-3, 5e-4)
+
+
+def test_config5_shape_8x2048_bf16_against_oracle():
+    _forward_backward_check(8, 2048, 2048, "bf16", "bf16", 1e-2, 0.35, 5e-2)
+
+
+def test_config3_shape_4x1024_b16384_bf16_against_oracle():
+    """BASELINE configs[2]: 4 blocks x 1024, batch 16384, bf16 MFMA inputs."""
+    _forward_backward_check(4, 1024, 16384, "bf16", "bf16", 5e-3, 0.2, 2e-2)
+
+
+def test_config3_shape_4x1024_b16384_fp32_against_oracle():
+    _forward_backward_check(4, 1024, 16384, "fp32", None, 1e-4, 1e-3, 3e-4)
+
+
+# ----------------------------------------------------------------------------
+# forward state is single-buffered — a stale backward must raise, and stand-alone
+# stages must not share a dropout stream
+# ----------------------------------------------------------------------------
+def test_backward_of_an_overwritten_forward_raises():
+    import bilinear_amd
+    dev = _dev()
+    torch.manual_seed(0)
+    net, _, _, _ = bilinear_amd.load(dev, num_blocks=1, width=256)
+    net.train()
+    x1, x2 = torch.randn(64, 32, device=dev), torch.randn(64, 32, device=dev)
+    p1 = net(x1)
+    p2 = net(x2)
+    with pytest.raises(RuntimeError, match="overwritten"):
+        p1.sum().backward()
+    p2.sum().backward()          # the latest forward is still valid
+
+
+def test_standalone_stages_draw_different_masks():
+    import bilinear_amd
+    dev = _dev()
+    torch.manual_seed(1)
+    a = bilinear_amd.heavy_linear(64, 256).to(dev).train()
+    b = bilinear_amd.heavy_linear(64, 256).to(dev).train()
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(512, 64, device=dev)
+    ya, yb = a(x), b(x)
+    # same weights, same input, same seed and step: only the Philox stream id differs
+    za, zb = (ya == 0), (yb == 0)
+    assert (za != zb).float().mean().item() > 0.2
+    both = ~za & ~zb
+    assert torch.equal(ya[both], yb[both])
