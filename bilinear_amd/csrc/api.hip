@@ -105,11 +105,13 @@ struct Workspace {
 };
 
 struct Splits { int splits, k_per; };
+// every reduction slab is a whole number of K tiles of the widest kernel (gemm_f32_ring.h: 64)
+static constexpr int64_t SPLIT_GRAIN = 64;
 static Splits pick_splits(int64_t batch, int64_t tiles) {
   int64_t want = std::max<int64_t>(1, ceil_div(256, tiles));
   int64_t max_splits = std::max<int64_t>(1, batch / 128);
   int64_t s = std::min(want, max_splits);
-  int64_t k_per = round_up(ceil_div(batch, s), 32);
+  int64_t k_per = round_up(ceil_div(batch, s), SPLIT_GRAIN);
   s = ceil_div(batch, k_per);
   return Splits{(int)s, (int)k_per};
 }
@@ -120,8 +122,8 @@ static Splits pick_splits(int64_t batch, int64_t tiles) {
 static Splits small_m_splits(int64_t batch, int W, int K) {
   const int64_t tiles = ceil_div(batch, 128) * ceil_div(W, 128);
   if (tiles >= 128 || K < 64) return Splits{1, K};
-  int64_t s = std::min<int64_t>(ceil_div(256, tiles), K / 32);
-  int64_t k_per = round_up(ceil_div(K, s), 32);
+  int64_t s = std::min<int64_t>(ceil_div(256, tiles), K / SPLIT_GRAIN);
+  int64_t k_per = round_up(ceil_div(K, s), SPLIT_GRAIN);
   s = ceil_div(K, k_per);
   return Splits{(int)s, (int)k_per};
 }
@@ -130,7 +132,7 @@ static Splits small_m_splits(int64_t batch, int W, int K) {
 static Splits decode_fwd_splits(int64_t batch, int W) {
   int64_t want = std::max<int64_t>(1, ceil_div(256, ceil_div(batch, 128)));
   int64_t s = std::min<int64_t>(want, std::max<int64_t>(1, W / 128));
-  int64_t k_per = round_up(ceil_div(W, s), 32);
+  int64_t k_per = round_up(ceil_div(W, s), SPLIT_GRAIN);
   s = ceil_div(W, k_per);
   return Splits{(int)s, (int)k_per};
 }
@@ -998,7 +1000,7 @@ static int gemm_entry(int dtype, void* stream, const float* A, int64_t lda, int3
   GemmParams g{};
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.M = (int)M; g.N = (int)N; g.K = (int)K;
-  g.k_per_split = (splits > 1) ? (int)round_up(ceil_div(K, splits), 32) : (int)K;
+  g.k_per_split = (splits > 1) ? (int)round_up(ceil_div(K, splits), SPLIT_GRAIN) : (int)K;
   if (splits > 1 && (int64_t)g.k_per_split * (splits - 1) >= K) return BLH_ERR_SHAPE;
   g.c_split_stride = M * ldc;
   g.bias = bias; g.addend = addend; g.ldadd = ldadd;
@@ -1057,7 +1059,7 @@ int blh_gemm_fp16x2(void* stream, const float* A, int64_t lda, int32_t a_kmajor,
   GemmParams g{};
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.M = (int)M; g.N = (int)N; g.K = (int)K;
-  g.k_per_split = (splits > 1) ? (int)round_up(ceil_div(K, splits), 32) : (int)K;
+  g.k_per_split = (splits > 1) ? (int)round_up(ceil_div(K, splits), SPLIT_GRAIN) : (int)K;
   if (splits > 1 && (int64_t)g.k_per_split * (splits - 1) >= K) return BLH_ERR_SHAPE;
   g.c_split_stride = M * ldc;
   g.bias = bias; g.addend = addend; g.ldadd = ldadd;

@@ -51,6 +51,24 @@ __device__ __forceinline__ uint32_t keep_nibble(const DropoutSrc& d, DropState& 
   return patch_nibble(st.patch, (int)(grow & 31));
 }
 
+// Sum of in[s*ld + col] over s = first, first+stride, ... < S in fp64.  The loads of a batch of
+// U rows are issued together (clamped row index, select AFTER the load): these tiny reductions
+// are latency-bound, and a loop that waits for each load in turn pays one L2/Infinity-Cache round
+// trip per row (the round-1 colreduce: 16 dependent round trips = 11 us for 1 MB of partials).
+template <int U>
+__device__ __forceinline__ double strided_colsum(const float* __restrict__ in, int first, int stride,
+                                                 int S, int64_t ld, int col) {
+  double acc = 0.0;
+  for (int s0 = first; s0 < S; s0 += U * stride) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = in[(int64_t)min(s0 + u * stride, S - 1) * ld + col];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += (s0 + u * stride < S) ? (double)v[u] : 0.0;
+  }
+  return acc;
+}
+
 // ---------------------------------------------------------------------------
 // forward BN finalize: merge per-tile (mean, M2) partials (Chan et al.) into the
 // batch mean / biased variance; emit scale = gamma*invstd, shift = beta - mean*scale;
@@ -66,12 +84,21 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + cl;
   const bool ok = col < W;
+  // both passes read every tile partial of this column with the loads of 8 tiles in flight
+  constexpr int U = 8;
+  const int cc = ok ? col : 0;
   double acc = 0.0;
-  if (ok)
-    for (int t = sl; t < tiles; t += 8) {
+  for (int t0 = sl; t0 < tiles; t0 += 8 * U) {
+    float mu[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) mu[u] = part[((int64_t)min(t0 + 8 * u, tiles - 1) * 2 + 0) * W + cc];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + 8 * u;
       const double n = (double)min((int64_t)tile_rows, batch - (int64_t)t * tile_rows);
-      acc += n * (double)part[((int64_t)t * 2 + 0) * W + col];
+      if (t < tiles) acc += n * (double)mu[u];
     }
+  }
   red[sl][cl] = acc;
   __syncthreads();
   double mean = 0.0;
@@ -80,12 +107,22 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
   mean /= (double)batch;
   __syncthreads();
   acc = 0.0;
-  if (ok)
-    for (int t = sl; t < tiles; t += 8) {
-      const double n = (double)min((int64_t)tile_rows, batch - (int64_t)t * tile_rows);
-      const double d = (double)part[((int64_t)t * 2 + 0) * W + col] - mean;
-      acc += (double)part[((int64_t)t * 2 + 1) * W + col] + n * d * d;
+  for (int t0 = sl; t0 < tiles; t0 += 8 * U) {
+    float mu[U], m2t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t tt = min(t0 + 8 * u, tiles - 1);
+      mu[u] = part[(tt * 2 + 0) * W + cc];
+      m2t[u] = part[(tt * 2 + 1) * W + cc];
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + 8 * u;
+      const double n = (double)min((int64_t)tile_rows, batch - (int64_t)t * tile_rows);
+      const double d = (double)mu[u] - mean;
+      if (t < tiles) acc += (double)m2t[u] + n * d * d;
+    }
+  }
   red[sl][cl] = acc;
   __syncthreads();
   if (sl == 0 && ok) {
@@ -334,9 +371,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
   __shared__ double red[8][32];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + cl;
-  double acc = 0.0;
-  if (col < ncols)
-    for (int s = sl; s < S; s += 8) acc += (double)in[(int64_t)s * ld + col];
+  const double acc = strided_colsum<8>(in, sl, 8, S, ld, min(col, ncols - 1));
   red[sl][cl] = acc;
   __syncthreads();
   if (sl == 0 && col < ncols) {
@@ -372,9 +407,7 @@ __global__ __launch_bounds__(256) void bias_colreduce_kernel(const float* __rest
   const float* in = extra ? offs.extra_part : part + (int64_t)blockIdx.y * stage_stride;
   const int rows = extra ? offs.extra_S : S, cols = extra ? offs.extra_cols : W;
   const int64_t out = extra ? offs.extra_off : offs.off[blockIdx.y];
-  double acc = 0.0;
-  if (col < cols)
-    for (int s = sl; s < rows; s += 8) acc += (double)in[(int64_t)s * cols + col];
+  const double acc = strided_colsum<8>(in, sl, 8, rows, cols, min(col, cols - 1));
   red[sl][cl] = acc;
   __syncthreads();
   if (sl == 0 && col < cols) {
@@ -489,7 +522,16 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
        i += (int64_t)gridDim.x * blockDim.x) {
     float4 a = ld4(slabs + i * 4);
-    for (int s = 1; s < splits; ++s) {
+    int s = 1;
+    for (; s + 3 <= splits; s += 3) {   // three further slabs per round trip (4 splits = one)
+      const float4 b0 = ld4(slabs + (int64_t)(s + 0) * count + i * 4);
+      const float4 b1 = ld4(slabs + (int64_t)(s + 1) * count + i * 4);
+      const float4 b2 = ld4(slabs + (int64_t)(s + 2) * count + i * 4);
+      a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
+      a.x += b1.x; a.y += b1.y; a.z += b1.z; a.w += b1.w;
+      a.x += b2.x; a.y += b2.y; a.z += b2.z; a.w += b2.w;
+    }
+    for (; s < splits; ++s) {
       const float4 b = ld4(slabs + (int64_t)s * count + i * 4);
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }

@@ -4,6 +4,7 @@
 
 #include "gemm_bf16_kernel.h"
 #include "gemm_f32_kernel.h"
+#include "gemm_f32_ring.h"
 #include "gemm_split_kernel.h"
 #include "gemm_f16x2_kernel.h"
 
@@ -24,12 +25,21 @@ static int ensure_lds_attr(std::atomic<uint64_t>& done, const void* kern, size_t
   return BLH_OK;
 }
 
+// Ring geometry of the shipped fp32 kernel (gemm_f32_ring.h), chosen by tools/gemm_bench on
+// MI355X: K tile and ring depth of the 128x128 tile (the W x W Linears) and of the skinny tiles.
+static constexpr int RING_BKT_BIG = 64, RING_STAGES_BIG = 2;   // 68.0 / 66.4 / 68.7 us fwd / dgrad / wgrad at B=4096 (profiles/r02_gemm_variants.md)
+static constexpr int RING_BKT_SKINNY = 32, RING_STAGES_SKINNY = 3;
+
 template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int PIPE>
 static int launch_cfg(hipStream_t s, const GemmParams& p, int splits) {
   constexpr int NT = 64 * WM * WN;
-  constexpr size_t lds = gemm_lds_bytes<BM, BN, LA, LB, PIPE>();
+  constexpr bool BIG = (BM == 128 && BN == 128);
+  constexpr int BKT = BIG ? RING_BKT_BIG : RING_BKT_SKINNY;
+  constexpr int STAGES = BIG ? RING_STAGES_BIG : RING_STAGES_SKINNY;
+  constexpr size_t lds = gemm_ring_lds_bytes<BM, BN, BKT, STAGES>();
   static std::atomic<uint64_t> attr_done{0};
-  auto kern = gemm_f32_kernel<BM, BN, WM, WN, LA, LB, EPI, PIPE>;
+  if (splits > 1 && (p.k_per_split % BKT) != 0) return BLH_ERR_SHAPE;
+  auto kern = gemm_f32_ring_kernel<BM, BN, WM, WN, LA, LB, EPI, BKT, STAGES>;
   BLH_TRY(ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), lds));
   const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N, BN));
   dim3 grid(tiles, 1, splits);
@@ -38,8 +48,9 @@ static int launch_cfg(hipStream_t s, const GemmParams& p, int splits) {
   return BLH_OK;
 }
 
-// The library ships the LDS-DMA ring (PIPE 3, gemm_f32_kernel.h); the register-staged PIPE 1 is
-// built by tools/gemm_bench only.
+// The library ships the LDS-DMA ring kernel (gemm_f32_ring.h); the round-1 kernels of
+// gemm_f32_kernel.h (register-staged PIPE 1, per-lane-pointer ring PIPE 3) are built by
+// tools/gemm_bench only, as the A/B baseline.
 #define BLH_CASE(BM_, BN_, WM_, WN_, LA_, LB_, EPI_) \
   if (la == LA_ && lb == LB_ && epi == EPI_)         \
     return launch_cfg<BM_, BN_, WM_, WN_, LA_, LB_, EPI_, 3>(s, p, splits);

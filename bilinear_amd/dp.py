@@ -12,6 +12,10 @@ backward GEMMs of layers < l.  ``finish()`` makes the compute stream wait for al
 buckets and the (already averaged) gradients then feed the fused clip + Adam, which
 every rank runs identically (no parameter broadcast).
 
+The returned loss is the global batch's (a 1-float all-reduce behind the last bucket; every
+rank computes the same clip coefficient from the identical averaged gradients, so the gradient
+norm needs no exchange of its own).
+
 BatchNorm statistics are per-rank by default (the usual DDP semantics).  ``sync_bn=True``
 exchanges every stage's statistics across ranks (2W-element all-reduces, forward and
 backward), which reproduces the reference's single-device result on the concatenated
@@ -29,11 +33,15 @@ class GradBucketReducer:
     ``on_ready(offset, count)`` is called in backward order with contiguous ranges;
     ranges are merged until a bucket holds at least ``bucket_floats`` elements."""
 
-    def __init__(self, flat_grads, group=None, bucket_floats=1 << 20):
+    def __init__(self, flat_grads, group=None, bucket_floats=1 << 20, force_collectives=False):
         self.flat = flat_grads
         self.group = group
         self.bucket_floats = int(bucket_floats)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # world 1 normally skips the exchange; ``force_collectives`` issues it anyway (a one-GPU
+        # box can then run every RCCL call of the N-GPU step: ReduceOp.AVG, the side-stream hook,
+        # work.wait() ordering)
+        self.force = bool(force_collectives) and dist.is_initialized()
         self._pending = None        # (lo, hi) not yet launched
         self._works = []
         self.launched = []          # [(lo, hi)] of the last step, for tests
@@ -45,7 +53,7 @@ class GradBucketReducer:
 
     def _launch(self, lo, hi):
         self.launched.append((lo, hi))
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         view = self.flat[lo:hi]
         backend = dist.get_backend(self.group)
@@ -74,6 +82,19 @@ class GradBucketReducer:
             self._launch(plo, phi)
             self._pending = None
 
+    def reduce_scalars(self, tensor):
+        """Mean over ranks of a small tensor (the step's loss), launched like a
+        bucket: asynchronous, completed by finish()."""
+        if self.world == 1 and not self.force:
+            return
+        backend = dist.get_backend(self.group)
+        if backend == "nccl":
+            work = dist.all_reduce(tensor, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            self._works.append((work, None))
+        else:
+            work = dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._works.append((work, tensor))
+
     def finish(self):
         if self._pending is not None:
             self._launch(*self._pending)
@@ -96,7 +117,8 @@ class DataParallel:
     depend on the number of GPUs."""
 
     def __init__(self, module, optimizer, group=None, bucket_floats=1 << 20, max_norm=1.0,
-                 sync_bn=False):
+                 sync_bn=False, force_collectives=False):
+        self.force_collectives = bool(force_collectives)
         self.module = module
         self.optimizer = optimizer
         self.group = group
@@ -122,15 +144,20 @@ class DataParallel:
         opt = self.optimizer
         eng.ensure(x.device)
         if self._reducer is None or self._reducer.flat.data_ptr() != eng.grads.data_ptr():
-            self._reducer = GradBucketReducer(eng.grads, self.group, self.bucket_floats)
+            self._reducer = GradBucketReducer(eng.grads, self.group, self.bucket_floats,
+                                              force_collectives=self.force_collectives)
         batch = x.shape[0]
         eng.row_offset = self.rank * batch
-        sync = self._all_reduce_sum if (self.sync_bn and self.world > 1) else None
+        sync = self._all_reduce_sum if (self.sync_bn and (self.world > 1 or self.force_collectives)) else None
         gb = batch * self.world
         pred = eng.forward_train(x, sync=sync, global_batch=gb)
         loss, dpred = eng.mse_loss_grad(pred, target)
         self._reducer.begin()
         eng.backward(x, dpred, on_ready=self._reducer.on_ready, sync=sync, global_batch=gb)
+        # the reported loss is the GLOBAL batch's: mean of the per-rank means (equal shards), the
+        # 1-float all-reduce rides behind the last gradient bucket (the reference
+        # logs the loss of the whole batch, train_bilinear.py:86-88)
+        self._reducer.reduce_scalars(loss)
         self._reducer.finish()
         opt._ensure_moments(eng)
         g = opt.param_groups[0]

@@ -16,6 +16,17 @@ Also here: the per-GPU shapes of BASELINE configs 3-5 (4 blocks x 1024 at B=1638
 8 blocks x 2048), and the bit-identity of the one-stream and two-stream schedules.
 
 Tolerances: north_star states 1e-3 rel for fp32; TIGHT = 1e-4 is what the kernels meet.
+
+ReLU gates.  At B = 4096 a step evaluates 21 M ReLU gates; a handful of pre-activations lie
+within an fp32 ulp of zero, and there ANY two correct implementations (fp64 oracle, NumPy fp32
+oracle, PyTorch CPU, these kernels) may open the gate differently — a discrete O(1/sqrt(B))
+change of the gradients (measured: the NumPy fp32 oracle and the GPU both sit 2.8e-4 rel. L2 from
+the fp64 oracle on encode.0.weight at B = 4096, identically on every tensor; tools_dev/
+diag_grad_error.py).  The tight comparisons therefore (1) prove that the Philox path is
+bit-identical to the explicit-mask path replaying the same masks, and (2) compare the
+explicit-mask path with the oracle on masks in which the gates with |y| < 1e-4 are dropped
+(0.01 % of the elements), so that no gate decision depends on rounding.  The un-edited Philox
+run is still compared end to end at north_star's 1e-3.
 """
 import ctypes
 
@@ -86,6 +97,29 @@ def _philox_masks(net, step, batch):
         assert N.lib().blh_dropout_mask(st, ctypes.byref(d), layer, batch, eng.width, m.data_ptr()) == 0
         out.append(m.cpu().numpy())
     return out
+
+
+def _safe_masks(st0, x, masks, rounding=None, thr=1e-4):
+    """Masks with every element dropped whose ReLU gate is within ``thr`` of flipping in the fp64
+    forward (iterated: dropping an element moves the later stages)."""
+    masks = [m.copy() for m in masks]
+    O.set_gemm_rounding(rounding)
+    try:
+        for _ in range(8):
+            st = {k: v.copy() for k, v in st0.items()}
+            _, cache = O.forward(st, x, masks, training=True, dtype=np.float64)
+            changed = 0
+            for li, c in enumerate(cache["layers"]):
+                risky = (np.abs(c["y"]) < thr) & (masks[li] != 0)
+                n = int(risky.sum())
+                if n:
+                    masks[li][risky] = 0
+                    changed += n
+            if not changed:
+                return masks
+    finally:
+        O.set_gemm_rounding(None)
+    raise AssertionError("safe masks did not converge")
 
 
 _ORACLE_CACHE = {}
@@ -161,29 +195,42 @@ def _compare_fused_step(net, opt, pred, loss, r, rtol):
 # ----------------------------------------------------------------------------
 # BASELINE configs[1] (2 blocks, width 1024) at the batch sizes of the non-split-K path
 # ----------------------------------------------------------------------------
+def _entry_with_masks(nb, width, batch, dev, rounding=None):
+    """Seeded inputs + the Philox masks of dropout step 0 + their gate-safe edit + the fp64
+    reference step on the safe masks (cached across modes)."""
+    entry = _oracle_step(nb, width, batch, rounding)
+    if "philox" not in entry:
+        net, _ = _build(entry["st0"], dev, nb, width, "fp32")
+        entry["philox"] = _philox_masks(net, 0, batch)
+        entry["safe"] = _safe_masks(entry["st0"], entry["x"], entry["philox"], rounding)
+        dropped = sum(int((a != b).sum()) for a, b in zip(entry["philox"], entry["safe"]))
+        total = sum(m.size for m in entry["philox"])
+        print("gate-safe masks: %d of %d elements dropped" % (dropped, total))
+        assert dropped < 1e-3 * total
+    return entry
+
+
 @pytest.mark.parametrize("mode", FP32_MODES)
 @pytest.mark.parametrize("batch", [2048, 4096, 4100])
 def test_timed_path_step_matches_oracle(batch, mode):
-    """blh_train_step exactly as bench.py runs it (Philox dropout, two-stream backward) against
-    the fp64 oracle replaying the same masks; then the drop-in forward / backward (raw gradients)
-    from the same initial state."""
+    """blh_train_step exactly as bench.py runs it (non-split-K forward, two-stream backward)
+    against the fp64 oracle; then the drop-in forward / backward (raw gradients) from the same
+    initial state."""
     dev = _dev()
     nb, width = 2, 1024
-    entry = _oracle_step(nb, width, batch)
-    x, t = entry["x"], entry["t"]
-    xt, tt = torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev)
+    entry = _entry_with_masks(nb, width, batch, dev)
+    xt, tt = torch.from_numpy(entry["x"]).to(dev), torch.from_numpy(entry["t"]).to(dev)
+    r = _run_oracle(entry, entry["safe"])
 
     net, opt = _build(entry["st0"], dev, nb, width, mode)
-    masks = _philox_masks(net, 0, batch)
-    rate = float(np.mean([m.mean() for m in masks]))
-    assert abs(rate - 0.5) < 0.005, rate
-    r = _run_oracle(entry, masks)
+    net.engine.set_dropout_masks(entry["safe"])
     pred, loss = net.train_step(opt, xt, tt, max_norm=1.0)
     torch.cuda.synchronize()
     _compare_fused_step(net, opt, pred, loss.item(), r, TIGHT)
 
     # drop-in surface (autograd): raw gradients before clipping
     net2, opt2 = _build(entry["st0"], dev, nb, width, mode)
+    net2.engine.set_dropout_masks(entry["safe"])
     opt2.zero_grad()
     p2 = net2(xt)
     l2 = torch.nn.functional.mse_loss(p2, tt)
@@ -197,17 +244,49 @@ def test_timed_path_step_matches_oracle(batch, mode):
         _close(p.grad.cpu().numpy(), r["grads_raw"][k], 3 * TIGHT, "raw grad " + k)
 
 
+@pytest.mark.parametrize("mode", FP32_MODES)
+@pytest.mark.parametrize("batch", [4096, 4100])
+def test_timed_path_philox_equals_replayed_masks(batch, mode):
+    """The Philox path (masks generated in forward, regenerated in backward, never stored) must
+    be bit-identical to the explicit-mask path fed the materialised masks: predictions, every
+    gradient, Adam state.  Then the un-edited Philox step against the oracle at north_star's
+    1e-3 (a few ReLU gates within an ulp of zero may open differently, see the module docstring)."""
+    dev = _dev()
+    nb, width = 2, 1024
+    entry = _entry_with_masks(nb, width, batch, dev)
+    xt, tt = torch.from_numpy(entry["x"]).to(dev), torch.from_numpy(entry["t"]).to(dev)
+    out = []
+    for explicit in (False, True):
+        net, opt = _build(entry["st0"], dev, nb, width, mode)
+        if explicit:
+            net.engine.set_dropout_masks(entry["philox"])
+        pred, loss = net.train_step(opt, xt, tt, max_norm=1.0)
+        torch.cuda.synchronize()
+        out.append((pred.clone(), net.engine.grads.clone(), net.engine.params.clone(),
+                    opt._exp_avg.clone(), net.engine.bn_running.clone(), net, opt, loss.item()))
+    for a, b, what in zip(out[0][:5], out[1][:5], ("pred", "grads", "params", "exp_avg", "running")):
+        assert torch.equal(a, b), what
+    if mode == "fp32" and batch == 4096:
+        st = {k: v.copy() for k, v in entry["st0"].items()}
+        keys = O.param_keys(nb)
+        oopt = O.adam_init(st, keys)
+        r = O.train_step(st, oopt, entry["x"], entry["t"], entry["philox"], LR, dtype=np.float64)
+        r.update(state=st, opt=oopt, keys=keys)
+        _compare_fused_step(out[0][5], out[0][6], out[0][0], out[0][7], r, RTOL)
+
+
 @pytest.mark.parametrize("batch", [4096])
 def test_timed_path_step_matches_torch_port(batch):
     """The same step against the second pinned checker: plain PyTorch on the CPU
-    (oracle/torch_port.py) with the kernels' Philox masks injected into its Dropout modules."""
+    (oracle/torch_port.py) with the same masks injected into its Dropout modules."""
     from oracle import torch_port as TP
     dev = _dev()
     nb, width = 2, 1024
-    entry = _oracle_step(nb, width, batch)
+    entry = _entry_with_masks(nb, width, batch, dev)
     xt, tt = torch.from_numpy(entry["x"]), torch.from_numpy(entry["t"])
     net, opt = _build(entry["st0"], dev, nb, width, "fp32")
-    masks = _philox_masks(net, 0, batch)
+    masks = entry["safe"]
+    net.engine.set_dropout_masks(masks)
     pred, loss = net.train_step(opt, xt.to(dev), tt.to(dev), max_norm=1.0)
     torch.cuda.synchronize()
 
@@ -261,19 +340,19 @@ def test_one_stream_and_two_stream_schedules_are_bit_identical(mode):
 # ----------------------------------------------------------------------------
 def _forward_backward_check(nb, width, batch, mode, rounding, pred_tol, grad_l2_tol, decode_tol):
     dev = _dev()
-    entry = _oracle_step(nb, width, batch, rounding)
+    entry = _entry_with_masks(nb, width, batch, dev, rounding)
     x, t = entry["x"], entry["t"]
     xt, tt = torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev)
     net, opt = _build(entry["st0"], dev, nb, width, mode)
-    masks = _philox_masks(net, 0, batch)
-    r = _run_oracle(entry, masks, rounding)
+    r = _run_oracle(entry, entry["safe"], rounding)
+    net.engine.set_dropout_masks(entry["safe"])
     opt.zero_grad()
     pred = net(xt)
     loss = torch.nn.functional.mse_loss(pred, tt)
     loss.backward()
     got = pred.detach().cpu().numpy().astype(np.float64)
-    rel = np.linalg.norm(got - r["pred"]) / np.linalg.norm(r["pred"])
-    assert rel <= pred_tol, ("pred", rel)
+    prel = np.linalg.norm(got - r["pred"]) / np.linalg.norm(r["pred"])
+    assert prel <= pred_tol, ("pred", prel)
     assert abs(loss.item() - r["loss"]) <= max(pred_tol, 1e-4) * r["loss"]
     worst = 0.0
     for k, p in net.named_parameters():
@@ -285,16 +364,24 @@ def _forward_backward_check(nb, width, batch, mode, rounding, pred_tol, grad_l2_
         tol = decode_tol if k.startswith("decode") else grad_l2_tol
         assert rel <= tol, (k, rel)
         worst = max(worst, rel)
-    print("%dx%d B=%d %s: pred rel L2 %.2e, worst grad rel L2 %.2e" % (nb, width, batch, mode, rel, worst))
-    # size-independent properties at the same shape: pre-BN bias gradients vanish; a second
-    # forward with the same dropout step reproduces the prediction bit for bit
+    print("%dx%d B=%d %s: pred rel L2 %.2e, worst grad rel L2 %.2e" % (nb, width, batch, mode, prel, worst))
+    # size-independent properties at the same shape: pre-BN bias gradients vanish; the Philox
+    # path draws exactly the masks blh_dropout_mask materialises (bit-identical prediction and
+    # gradients to the explicit-mask path fed those masks)
     for name, off, shape in net.engine.layout.entries:
         if is_prebn_bias(name):
             assert net.engine.grads[off:off + shape[0]].abs().max().item() < 1e-5
-    net.engine.rng_step = 0
-    with torch.no_grad():
-        again = net(xt)
-    assert torch.equal(again, pred.detach())
+    outs = []
+    for explicit in (False, True):
+        n2, o2 = _build(entry["st0"], dev, nb, width, mode)
+        if explicit:
+            n2.engine.set_dropout_masks(entry["philox"])
+        o2.zero_grad()
+        p2 = n2(xt)
+        torch.nn.functional.mse_loss(p2, tt).backward()
+        torch.cuda.synchronize()
+        outs.append((p2.detach().clone(), n2.engine.grads.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 @pytest.mark.parametrize("mode", ["fp32", "fp16x2"])
