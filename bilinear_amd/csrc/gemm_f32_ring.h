@@ -151,7 +151,9 @@ __device__ __forceinline__ void ring_wait_vm_lgkm() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int BKT = 32, int STAGES = 3>
+// STAMP: diagnostic builds only (tools/gemm_bench): 100 MHz real-time / shader-clock stamps at
+// entry, main-loop start, main-loop end and kernel end, written to p.loss_part (8 u64 per WG).
+template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int BKT = 32, int STAGES = 3, int STAMP = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_ring_kernel(GemmParams p) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -163,6 +165,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_ring_kernel(GemmParams 
   using PB = RingPlan<LB, BN, NT, BKT>;
   constexpr int G = PA::CHUNKS + PB::CHUNKS;     // DMAs per thread per tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned long long stamp_entry = 0, stamp_c0 = 0, stamp_r0 = 0;
+  if (STAMP) stamp_entry = __builtin_amdgcn_s_memrealtime();
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -189,6 +193,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_ring_kernel(GemmParams 
   planA.init(p.A, p.lda, m0, p.M, kz0, k_end, tid);
   planB.init(p.B, p.ldb, n0, p.N, kz0, k_end, tid);
   float fa[2][TM][4], fb[2][TN][4];
+  if (STAMP) { stamp_c0 = __builtin_amdgcn_s_memtime(); stamp_r0 = __builtin_amdgcn_s_memrealtime(); }
 
   // prologue: tiles 0 .. STAGES-2 in flight; wait for tile 0 only
   if (nkt > 0) {
@@ -284,7 +289,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_ring_kernel(GemmParams 
   }
 #undef BLH_RING_MFMAS
   __syncthreads();
+  if (STAMP) {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.loss_part) + 8 * (blockIdx.x + gridDim.x * blockIdx.z);
+      o[0] = c1 - stamp_c0; o[1] = r1 - stamp_r0; o[2] = stamp_entry; o[3] = stamp_r0; o[4] = r1;
+    }
+  }
   gemm_epilogue<BM, BN, WM, WN, EPI>(acc, p, C, smem, m0, n0, tile_m, true);
+  if (STAMP) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long r2 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0)
+      (reinterpret_cast<unsigned long long*>(p.loss_part) + 8 * (blockIdx.x + gridDim.x * blockIdx.z))[5] = r2;
+  }
 }
 
 }  // namespace blh

@@ -55,6 +55,37 @@ float run_ring(const GemmParams& p, int splits, int reps) {
   return ms / reps;
 }
 
+// dgrad on one stream and wgrad on another, as the two-stream backward launches them: time per PAIR
+template <int BM, int BN, int WM, int WN, int BKT, int STAGES>
+float run_pair(const GemmParams& d, const GemmParams& w, int splits, int reps) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr size_t lds = gemm_ring_lds_bytes<BM, BN, BKT, STAGES>();
+  auto kd = gemm_f32_ring_kernel<BM, BN, WM, WN, ROWK, KROW, EPI_STORE, BKT, STAGES>;
+  auto kw = gemm_f32_ring_kernel<BM, BN, WM, WN, KROW, KROW, EPI_STORE, BKT, STAGES>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static hipStream_t sa = nullptr, sb = nullptr;
+  if (!sa) { CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking)); }
+  const int td = (int)(ceil_div(d.M, BM) * ceil_div(d.N, BN)), tw = (int)(ceil_div(w.M, BM) * ceil_div(w.N, BN));
+  hipEvent_t e0, e1, eb;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&eb));
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, sa));
+  CK(hipStreamWaitEvent(sb, e0, 0));
+  for (int i = 0; i < reps; ++i) {
+    hipLaunchKernelGGL(kd, dim3(td), dim3(NT), lds, sa, d);
+    hipLaunchKernelGGL(kw, dim3(tw, 1, splits), dim3(NT), lds, sb, w);
+  }
+  CK(hipEventRecord(eb, sb));
+  CK(hipStreamWaitEvent(sa, eb, 0));
+  CK(hipEventRecord(e1, sa));
+  CK(hipEventSynchronize(e1));
+  CK(hipGetLastError());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / reps;
+}
+
 // spot-check 64 output elements against a host fp64 dot product
 static double g_maxerr;
 void verify(const char* what, const std::vector<float>& hA, const std::vector<float>& hB, const std::vector<float>& hbias,
@@ -86,6 +117,7 @@ int main(int argc, char** argv) {
   float *A, *B, *C, *bias, *stat;
   const size_t act = (size_t)M * W;
   CK(hipMalloc(&A, act * 4)); CK(hipMalloc(&B, (size_t)W * W * 4)); CK(hipMalloc(&C, std::max(act, (size_t)16 * W * W) * 4));
+  float* C2; CK(hipMalloc(&C2, (size_t)16 * W * W * 4));
   CK(hipMalloc(&bias, W * 4)); CK(hipMalloc(&stat, (size_t)(M / 32 + 1) * 2 * W * 4));
   std::vector<float> h(act);
   const bool normal = getenv("BENCH_NORMAL") != nullptr;
@@ -134,6 +166,11 @@ int main(int argc, char** argv) {
     verify("wgrad", h, h, h, C, W, W, M, W, 2, splits);                                        \
     printf("%-22s fwd %7.1f us %6.1f TF | dgrad %7.1f us %6.1f TF | wgrad(x%d) %7.1f us %6.1f TF\n", name, \
            t1 * 1e3, flop / t1 / 1e9, t2 * 1e3, flop / t2 / 1e9, splits, t3 * 1e3, flop / t3 / 1e9); \
+    if (getenv("BENCH_PAIR")) {                                                                \
+      GemmParams w2 = w; w2.C = C2;                                                            \
+      float tp = run_pair<BM, BN, WM, WN, BKT, ST>(d, w2, splits, reps);                         \
+      printf("%-22s dgrad || wgrad on two streams: %7.1f us per pair (sum of the two alone %7.1f)\n", name, tp * 1e3, (t2 + t3) * 1e3); \
+    }                                                                                          \
   }
   // interleaved rounds in one process (guide rule 24): shipped r01 kernel vs the ring variants
   for (int round = 0; round < (getenv("BENCH_ROUNDS") ? atoi(getenv("BENCH_ROUNDS")) : 1); ++round) {
@@ -141,9 +178,43 @@ int main(int argc, char** argv) {
   RROW("ring 4x2 bk32 st3", 128, 128, 4, 2, 32, 3)
   RROW("ring 4x2 bk32 st4", 128, 128, 4, 2, 32, 4)
   RROW("ring 4x2 bk64 st2", 128, 128, 4, 2, 64, 2)
-  RROW("ring 2x4 bk32 st4", 128, 128, 2, 4, 32, 4)
-  RROW("ring 2x2 bk32 st4", 128, 128, 2, 2, 32, 4)
-  RROW("ring 2x2 bk64 st2", 128, 128, 2, 2, 64, 2)
+  RROW("ring 4x2 bk32 st2", 128, 128, 4, 2, 32, 2)
+  RROW("ring 2x2 bk32 st2", 128, 128, 2, 2, 32, 2)
+  }
+  {  // where the time of the shipped ring kernel goes: in-kernel stamps of the forward kernel
+    unsigned long long* st; CK(hipMalloc(&st, 4096 * 64));
+    auto stamped = [&](const char* name, auto kern, size_t lds, const GemmParams& base) {
+      GemmParams fs = base; fs.loss_part = reinterpret_cast<float*>(st);
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const int tiles = (int)(ceil_div(fs.M, 128) * ceil_div(fs.N, 128));
+      hipEvent_t e0v, e1v; CK(hipEventCreate(&e0v)); CK(hipEventCreate(&e1v));
+      for (int i = 0; i < 100; ++i) hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, 0, fs);
+      CK(hipEventRecord(e0v, 0));
+      for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, 0, fs);
+      CK(hipEventRecord(e1v, 0));
+      CK(hipDeviceSynchronize());
+      float msv; CK(hipEventElapsedTime(&msv, e0v, e1v));
+      std::vector<unsigned long long> hs(8 * tiles);
+      CK(hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost));
+      double cs = 0, rs = 0, pro = 0, epi = 0; unsigned long long e0 = ~0ull, e1 = 0, l1max = 0, emax = 0;
+      for (int i = 0; i < tiles; ++i) {
+        const unsigned long long* o = &hs[8 * i];
+        cs += o[0]; rs += o[1]; pro += o[3] - o[2]; epi += o[5] - o[4];
+        e0 = std::min(e0, o[2]); e1 = std::max(e1, o[5]); l1max = std::max(l1max, o[4]); emax = std::max(emax, o[2]);
+      }
+      const double ideal = 2.0 * fs.K * 128 * 128 / 2048.0 / 4.0 * 64.0;   // cycles: MFMAs per SIMD x 64
+      printf("%s: events %.1f us/launch | per WG: entry->loop %.2f us, main loop %.1f us (%.0f cycles, %.3f GHz, MFMA-ideal %.0f), epilogue %.2f us | span first entry -> last exit %.1f us, last entry +%.2f us, last loop end +%.1f us\n",
+             name, msv / 200 * 1e3, pro / tiles / 100.0, rs / tiles / 100.0, cs / tiles, cs / rs * 0.1, ideal,
+             epi / tiles / 100.0, (e1 - e0) / 100.0, (emax - e0) / 100.0, (l1max - e0) / 100.0);
+    };
+    stamped("STAMP ring bk64 st2 fwd  ", gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 64, 2, 1>, gemm_ring_lds_bytes<128, 128, 64, 2>(), f);
+    stamped("STAMP ring bk64 st2 dgrad", gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, KROW, EPI_STORE, 64, 2, 1>, gemm_ring_lds_bytes<128, 128, 64, 2>(), d);
+    stamped("STAMP ring bk32 st2 fwd  ", gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 32, 2, 1>, gemm_ring_lds_bytes<128, 128, 32, 2>(), f);
+    GemmParams f1 = f; f1.K = 64; f1.k_per_split = 64;   // fixed per-launch cost: one K tile
+    float tk = run_ring<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 64, 2>(f1, 1, 200);
+    GemmParams f2 = f; f2.K = 512; f2.k_per_split = 512;
+    float tk2 = run_ring<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 64, 2>(f2, 1, 200);
+    printf("ring bk64 st2 fwd at K=64: %.1f us ; K=512: %.1f us ; K=%d: see table (slope = main loop)\n", tk * 1e3, tk2 * 1e3, W);
   }
   if (getenv("BENCH_RING_ONLY")) { printf("max spot-check error %g\n", g_maxerr); return 0; }
   ROW("128x128 w4x2 pipe1", 128, 128, 4, 2, 1)
