@@ -23,9 +23,18 @@ int ew_num_row_chunks(int64_t batch) { return (int)ceil_div(batch, ew_row_chunk(
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
-// max |v| of a float4, folded into m
+// max |v| over the FINITE values of a float4, folded into m.  Inf / NaN elements do not take
+// part: the fp16-split GEMM derives its power-of-two scale from this maximum, and one overflowed
+// element must not push every finite value of the tensor out of fp16's range (the non-finite
+// element itself stays non-finite through the split and poisons only its own row / column, as
+// in the exact kernel).
+__device__ __forceinline__ float finite_abs(float x) {
+  const float a = fabsf(x);
+  return a <= 3.402823466e+38f ? a : 0.f;   // false for Inf and NaN
+}
 __device__ __forceinline__ float amax4(float m, float4 v) {
-  return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  return fmaxf(fmaxf(m, fmaxf(finite_abs(v.x), finite_abs(v.y))),
+               fmaxf(finite_abs(v.z), finite_abs(v.w)));
 }
 // one partial per wave (all 64 lanes must be active): part[wave_global]
 __device__ __forceinline__ void wave_amax_store(float m, float* __restrict__ part) {

@@ -106,10 +106,13 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(GemmParams p) {
   red_a = fmaxf(fmaxf(smem[0], smem[1]), fmaxf(smem[2], smem[3]));
   red_b = fmaxf(fmaxf(smem[4], smem[5]), fmaxf(smem[6], smem[7]));
   __syncthreads();
-  // e = 12 - floor(log2(amax)), clamped; amax == 0 (or denormal) -> e = 0
+  // e = 12 - floor(log2(amax)); amax == 0 (or denormal) -> e = 0.  The maxima are taken over
+  // finite values only (elementwise.hip: amax4), so ex <= 254 and e >= -115; the upper clamp keeps
+  // the un-scale factor 2^-e a normal float (e <= 126: tensors below 2^-114 keep full accuracy
+  // relative to 2^-126 * 2^13, i.e. to the smallest normal float — nothing is lost there either).
   auto scale_exp = [](float amax) {
     const int ex = (int)((__float_as_uint(amax) >> 23) & 0xffu);
-    return ex == 0 ? 0 : max(-100, min(100, 12 - (ex - 127)));
+    return (ex == 0 || ex == 255) ? 0 : max(-115, min(126, 12 - (ex - 127)));
   };
   const int ea = __builtin_amdgcn_readfirstlane(scale_exp(red_a));
   const int eb = __builtin_amdgcn_readfirstlane(scale_exp(red_b));

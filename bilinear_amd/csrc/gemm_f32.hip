@@ -26,16 +26,20 @@ static int ensure_lds_attr(std::atomic<uint64_t>& done, const void* kern, size_t
 }
 
 // Ring geometry of the shipped fp32 kernel (gemm_f32_ring.h), chosen by tools/gemm_bench on
-// MI355X: K tile and ring depth of the 128x128 tile (the W x W Linears) and of the skinny tiles.
-static constexpr int RING_BKT_BIG = 64, RING_STAGES_BIG = 2;   // 68.0 / 66.4 / 68.7 us fwd / dgrad / wgrad at B=4096 (profiles/r02_gemm_variants.md)
+// MI355X (profiles/r02_gemm_variants.md).  The 128x128 tile exists in two forms:
+//   * BK 64, 2 stages (128 KB LDS, one workgroup per CU): fewest barriers, the fastest form for a
+//     launch that is alone on the chip with at most one tile per CU — the forward Linear at
+//     B <= 4096 (67.5 us);
+//   * BK 32, 2 stages (64 KB LDS, TWO workgroups per CU): the fill / drain of one tile (prologue
+//     latency, epilogue, the 16.8 MB output burst) hides under the main loop of its co-resident
+//     neighbour — of the same launch when the grid has more tiles than CUs (B = 16384: 252 vs
+//     262 us), of the OTHER stream's launch in the two-stream backward (dgrad || wgrad pair 126.6
+//     vs 132.1 us).
 static constexpr int RING_BKT_SKINNY = 32, RING_STAGES_SKINNY = 3;
 
-template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int PIPE>
-static int launch_cfg(hipStream_t s, const GemmParams& p, int splits) {
+template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int BKT, int STAGES>
+static int launch_ring(hipStream_t s, const GemmParams& p, int splits) {
   constexpr int NT = 64 * WM * WN;
-  constexpr bool BIG = (BM == 128 && BN == 128);
-  constexpr int BKT = BIG ? RING_BKT_BIG : RING_BKT_SKINNY;
-  constexpr int STAGES = BIG ? RING_STAGES_BIG : RING_STAGES_SKINNY;
   constexpr size_t lds = gemm_ring_lds_bytes<BM, BN, BKT, STAGES>();
   static std::atomic<uint64_t> attr_done{0};
   if (splits > 1 && (p.k_per_split % BKT) != 0) return BLH_ERR_SHAPE;
@@ -46,6 +50,18 @@ static int launch_cfg(hipStream_t s, const GemmParams& p, int splits) {
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int PIPE>
+static int launch_cfg(hipStream_t s, const GemmParams& p, int splits) {
+  if constexpr (BM == 128 && BN == 128) {
+    const int64_t wgs = ceil_div(p.M, BM) * ceil_div(p.N, BN) * splits;
+    const bool forward = (LA == ROWK && LB == ROWK);
+    if (forward && wgs <= 256) return launch_ring<BM, BN, WM, WN, LA, LB, EPI, 64, 2>(s, p, splits);
+    return launch_ring<BM, BN, WM, WN, LA, LB, EPI, 32, 2>(s, p, splits);
+  } else {
+    return launch_ring<BM, BN, WM, WN, LA, LB, EPI, RING_BKT_SKINNY, RING_STAGES_SKINNY>(s, p, splits);
+  }
 }
 
 // The library ships the LDS-DMA ring kernel (gemm_f32_ring.h); the round-1 kernels of

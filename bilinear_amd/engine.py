@@ -17,6 +17,7 @@ import ctypes
 import torch
 
 from . import _native as N
+from . import ops as _ops  # noqa: F401  (registers torch.ops.bilinear_hip.*)
 
 IN_FEATURES = 32    # 2 * 16 joints, /root/reference/model/bilinear.py:20-22
 OUT_FEATURES = 48   # 3 * 16 joints, /root/reference/model/bilinear.py:29
@@ -194,6 +195,11 @@ class Engine:
             raise RuntimeError("need %d masks" % self.layout.num_heavy)
         self.masks = torch.stack(ms).contiguous()
 
+    def _op_args(self):
+        """(ctx, num_blocks, width, gemm_dtype) of the torch.ops.bilinear_hip.* schemas."""
+        d = self.layout.desc
+        return (int(self.ctx.handle.value), int(d.num_blocks), int(d.width), int(d.gemm_dtype))
+
     def _drop_struct(self, batch):
         if self.masks is not None:
             if self.masks.device != self.device:
@@ -240,14 +246,13 @@ class Engine:
             raise ValueError("Expected more than 1 value per channel when training, got input size %s"
                              % (tuple(x.shape),))
         ws = self.workspace(batch)
-        pred = torch.empty(batch, OUT_FEATURES, dtype=torch.float32, device=x.device)
         drop = self._drop_struct(batch)
         if sync is None:
-            N.check(N.lib().blh_forward_train(
-                self.ctx.handle, ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params),
-                N.ptr(self.bn_running), N.ptr(self.bn_nbt), N.ptr(x), ctypes.byref(drop),
-                self._momentum(), N.ptr(ws), ws.numel(), N.ptr(pred), batch), "blh_forward_train")
+            pred = torch.ops.bilinear_hip.forward_train(
+                x, self.params, self.bn_running, self.bn_nbt, ws, self.masks, *self._op_args(),
+                self.seed, self.rng_step, self.row_offset, self._momentum())
         else:
+            pred = torch.empty(batch, OUT_FEATURES, dtype=torch.float32, device=x.device)
             errors = []
             cb = self._sync_callback(ws, sync, errors)
             N.check(N.lib().blh_forward_train_sync(
@@ -270,12 +275,7 @@ class Engine:
         batch = x.shape[0]
         ws = self.workspace(batch)
         self._saved_batch = None       # eval overwrites the saved activations
-        pred = torch.empty(batch, OUT_FEATURES, dtype=torch.float32, device=x.device)
-        N.check(N.lib().blh_forward_eval(
-            self.ctx.handle, ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params),
-            N.ptr(self.bn_running), N.ptr(x), N.ptr(ws), ws.numel(), N.ptr(pred), batch),
-            "blh_forward_eval")
-        return pred
+        return torch.ops.bilinear_hip.eval_fwd(x, self.params, self.bn_running, ws, *self._op_args())
 
     def set_two_stream(self, enabled):
         """A/B switch of the two-stream backward (bit-identical results either way)."""
@@ -325,7 +325,12 @@ class Engine:
         else:
             cb = ctypes.cast(None, N.GradReadyFn)
         self._grad_ready_cb = cb       # keep alive during the call
-        if sync is None:
+        if sync is None and on_ready is None:
+            d = self._saved_drop
+            torch.ops.bilinear_hip.backward(
+                x, dpred, self.params, ws, self.grads, self.masks if d.keep_mask else None,
+                *self._op_args(), int(d.seed), int(d.step), int(d.row_offset))
+        elif sync is None:
             N.check(N.lib().blh_backward(
                 self.ctx.handle, ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params), N.ptr(x),
                 ctypes.byref(self._saved_drop), N.ptr(ws), ws.numel(), N.ptr(dpred),
@@ -374,16 +379,13 @@ class Engine:
         if tuple(target.shape) != (batch, OUT_FEATURES) or target.dtype != torch.float32:
             raise RuntimeError("bad target: %s %s" % (tuple(target.shape), target.dtype))
         ws = self.workspace(batch)
-        pred = torch.empty(batch, OUT_FEATURES, dtype=torch.float32, device=x.device)
-        loss = torch.empty((), dtype=torch.float32, device=x.device)
-        drop = self._drop_struct(batch)
-        hyper = N.AdamHyper(lr, betas[0], betas[1], eps, 0.0 if max_norm is None else max_norm, step)
-        N.check(N.lib().blh_train_step(
-            self.ctx.handle, ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params), N.ptr(self.grads),
-            N.ptr(exp_avg), N.ptr(exp_avg_sq), N.ptr(self.bn_running), N.ptr(self.bn_nbt),
-            N.ptr(x), N.ptr(target), ctypes.byref(drop), self._momentum(), ctypes.byref(hyper),
-            N.ptr(ws), ws.numel(), N.ptr(pred), N.ptr(loss), N.ptr(stats), batch),
-            "blh_train_step")
+        self._drop_struct(batch)          # validates explicit masks (shape, device)
+        pred, loss = torch.ops.bilinear_hip.train_step(
+            x, target, self.params, self.grads, exp_avg, exp_avg_sq, self.bn_running, self.bn_nbt,
+            ws, stats, self.masks, *self._op_args(), self.seed, self.rng_step, self.row_offset,
+            self._momentum(), float(lr), float(betas[0]), float(betas[1]), float(eps),
+            0.0 if max_norm is None else float(max_norm), int(step))
+        self.generation += 1
         self._saved_batch = None
         if self.masks is None:
             self.rng_step += 1

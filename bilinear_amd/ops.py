@@ -1,0 +1,137 @@
+"""``torch.ops.bilinear_hip.*`` — the C ABI of libbilinear_hip.so registered as PyTorch-ROCm
+custom operators (BASELINE.json north_star: "driven from Python through PyTorch-ROCm custom
+ops").  Each operator is a thin schema over ONE entry point of include/bilinear_hip.h; tensors
+supply device memory, the current HIP stream is taken from PyTorch, everything numerical happens
+in the library.  The drop-in module (bilinear_amd/model/bilinear.py) and the engine call these
+operators; the data-parallel paths that pass host callbacks (bucket hook, SyncBN exchange) go to
+the C ABI directly, since a callback has no operator-schema type.
+
+    pred = torch.ops.bilinear_hip.eval_fwd(x, params, bn_running, workspace, ctx, nb, W, dtype)
+    pred = torch.ops.bilinear_hip.forward_train(x, params, bn_running, bn_nbt, workspace, masks, ...)
+    torch.ops.bilinear_hip.backward(x, dpred, params, workspace, grads, masks, ...)
+    pred, loss = torch.ops.bilinear_hip.train_step(x, target, params, grads, exp_avg, ...)
+
+Reference call-sites: BilinearUnit.forward (/root/reference/model/bilinear.py:31-41, eval:
+valid_bilinear.py:31,52), loss.backward() (train_bilinear.py:79), the step body
+(train_bilinear.py:75-83).  ``ctx`` is the integer value of a ``blh_context*`` (bilinear_amd.
+_native.Context.handle.value).  There is no CPU implementation: calling an operator with CPU
+tensors raises (no kernel registered for the CPU dispatch key).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _native as N
+
+IN_FEATURES, OUT_FEATURES = 32, 48
+
+_LIB = torch.library.Library("bilinear_hip", "DEF")
+
+_LIB.define(
+    "eval_fwd(Tensor x, Tensor params, Tensor bn_running, Tensor(a!) workspace, int ctx, "
+    "int num_blocks, int width, int gemm_dtype) -> Tensor")
+_LIB.define(
+    "forward_train(Tensor x, Tensor params, Tensor(a!) bn_running, Tensor(b!) bn_nbt, "
+    "Tensor(c!) workspace, Tensor? masks, int ctx, int num_blocks, int width, int gemm_dtype, "
+    "int seed, int step, int row_offset, float momentum) -> Tensor")
+_LIB.define(
+    "backward(Tensor x, Tensor dpred, Tensor params, Tensor(a!) workspace, Tensor(b!) grads, "
+    "Tensor? masks, int ctx, int num_blocks, int width, int gemm_dtype, int seed, int step, "
+    "int row_offset) -> ()")
+_LIB.define(
+    "train_step(Tensor x, Tensor target, Tensor(a!) params, Tensor(b!) grads, Tensor(c!) exp_avg, "
+    "Tensor(d!) exp_avg_sq, Tensor(e!) bn_running, Tensor(f!) bn_nbt, Tensor(g!) workspace, "
+    "Tensor(h!)? stats, Tensor? masks, int ctx, int num_blocks, int width, int gemm_dtype, "
+    "int seed, int step, int row_offset, float momentum, float lr, float beta1, float beta2, "
+    "float eps, float max_norm, int adam_step) -> (Tensor, Tensor)")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _desc(num_blocks, width, gemm_dtype):
+    return N.ModelDesc(int(num_blocks), int(width), IN_FEATURES, OUT_FEATURES, int(gemm_dtype))
+
+
+def _drop(masks, seed, step, row_offset):
+    if masks is not None:
+        return N.Dropout(masks.data_ptr(), 0, 0, 0, 0, 0)
+    return N.Dropout(None, int(seed), int(step), int(row_offset), 0, 0)
+
+
+def _eval_fwd(x, params, bn_running, workspace, ctx, num_blocks, width, gemm_dtype):
+    batch = x.shape[0]
+    pred = torch.empty(batch, OUT_FEATURES, dtype=torch.float32, device=x.device)
+    d = _desc(num_blocks, width, gemm_dtype)
+    N.check(N.lib().blh_forward_eval(
+        ctypes.c_void_p(ctx), ctypes.byref(d), _stream(), N.ptr(params), N.ptr(bn_running), N.ptr(x),
+        N.ptr(workspace), workspace.numel(), N.ptr(pred), batch), "blh_forward_eval")
+    return pred
+
+
+def _forward_train(x, params, bn_running, bn_nbt, workspace, masks, ctx, num_blocks, width,
+                   gemm_dtype, seed, step, row_offset, momentum):
+    batch = x.shape[0]
+    pred = torch.empty(batch, OUT_FEATURES, dtype=torch.float32, device=x.device)
+    d = _desc(num_blocks, width, gemm_dtype)
+    drop = _drop(masks, seed, step, row_offset)
+    N.check(N.lib().blh_forward_train(
+        ctypes.c_void_p(ctx), ctypes.byref(d), _stream(), N.ptr(params), N.ptr(bn_running),
+        N.ptr(bn_nbt), N.ptr(x), ctypes.byref(drop), float(momentum), N.ptr(workspace),
+        workspace.numel(), N.ptr(pred), batch), "blh_forward_train")
+    return pred
+
+
+def _backward(x, dpred, params, workspace, grads, masks, ctx, num_blocks, width, gemm_dtype, seed,
+              step, row_offset):
+    batch = x.shape[0]
+    d = _desc(num_blocks, width, gemm_dtype)
+    drop = _drop(masks, seed, step, row_offset)
+    N.check(N.lib().blh_backward(
+        ctypes.c_void_p(ctx), ctypes.byref(d), _stream(), N.ptr(params), N.ptr(x),
+        ctypes.byref(drop), N.ptr(workspace), workspace.numel(), N.ptr(dpred), N.ptr(grads), batch,
+        ctypes.cast(None, N.GradReadyFn), None), "blh_backward")
+
+
+def _train_step(x, target, params, grads, exp_avg, exp_avg_sq, bn_running, bn_nbt, workspace,
+                stats, masks, ctx, num_blocks, width, gemm_dtype, seed, step, row_offset, momentum,
+                lr, beta1, beta2, eps, max_norm, adam_step):
+    batch = x.shape[0]
+    pred = torch.empty(batch, OUT_FEATURES, dtype=torch.float32, device=x.device)
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    d = _desc(num_blocks, width, gemm_dtype)
+    drop = _drop(masks, seed, step, row_offset)
+    hyper = N.AdamHyper(lr, beta1, beta2, eps, max_norm, int(adam_step))
+    N.check(N.lib().blh_train_step(
+        ctypes.c_void_p(ctx), ctypes.byref(d), _stream(), N.ptr(params), N.ptr(grads),
+        N.ptr(exp_avg), N.ptr(exp_avg_sq), N.ptr(bn_running), N.ptr(bn_nbt), N.ptr(x),
+        N.ptr(target), ctypes.byref(drop), float(momentum), ctypes.byref(hyper), N.ptr(workspace),
+        workspace.numel(), N.ptr(pred), N.ptr(loss), N.ptr(stats), batch), "blh_train_step")
+    return pred, loss
+
+
+# HIP device only ("CUDA" is PyTorch-ROCm's dispatch key for HIP tensors): no CPU kernels exist
+_LIB.impl("eval_fwd", _eval_fwd, "CUDA")
+_LIB.impl("forward_train", _forward_train, "CUDA")
+_LIB.impl("backward", _backward, "CUDA")
+_LIB.impl("train_step", _train_step, "CUDA")
+
+
+def _fake_pred(x, *args, **kwargs):
+    return x.new_empty((x.shape[0], OUT_FEATURES))
+
+
+def _fake_step(x, *args, **kwargs):
+    return x.new_empty((x.shape[0], OUT_FEATURES)), x.new_empty(())
+
+
+# shape functions (FakeTensor / torch.compile tracing; no arithmetic)
+torch.library.register_fake("bilinear_hip::eval_fwd", _fake_pred, lib=_LIB)
+torch.library.register_fake("bilinear_hip::forward_train", _fake_pred, lib=_LIB)
+torch.library.register_fake("bilinear_hip::backward", lambda *a, **k: None, lib=_LIB)
+torch.library.register_fake("bilinear_hip::train_step", _fake_step, lib=_LIB)
+
+OPS = ("eval_fwd", "forward_train", "backward", "train_step")

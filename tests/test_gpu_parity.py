@@ -190,6 +190,105 @@ def test_fp16x2_gemm_zero_operand_and_epilogues(native):
     assert float(c.abs().max()) == 0.0
 
 
+def _run_gemm(native, entry, A, B, ak, bk, splits=1):
+    dev = _dev()
+    M = A.shape[1] if ak else A.shape[0]
+    K = A.shape[0] if ak else A.shape[1]
+    N = B.shape[1] if bk else B.shape[0]
+    a, b = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    c = torch.full((splits, M, N), float("nan"), device=dev)
+    if entry == "fp16x2":
+        rc = _gemm_fp16x2(native, st, a, A.shape[1], ak, b, B.shape[1], bk, c, N, M, K, splits)
+    else:
+        rc = getattr(native, entry)(st, a.data_ptr(), A.shape[1], ak, b.data_ptr(), B.shape[1], bk,
+                                    c.data_ptr(), N, M, N, K, splits, None, None, 0)
+    assert rc == 0, native.blh_status_string(rc)
+    torch.cuda.synchronize()
+    return c.cpu().numpy().astype(np.float64).sum(axis=0)
+
+
+@pytest.mark.parametrize("entry", ["blh_gemm_bf16x3", "fp16x2"])
+@pytest.mark.parametrize("ak,bk,splits", [(0, 0, 1), (0, 1, 1), (1, 1, 4)])
+def test_split_gemm_non_finite_operands_poison_only_their_rows(native, entry, ak, bk, splits):
+    """Inf / NaN in an operand: the exact fp32 kernel produces non-finite values in the affected
+    output rows / columns only.  The split modes must do the same — in particular fp16x2's
+    per-tensor scale (from max |finite value|) must not be dragged to 2^-inf by one overflowed
+    element — and keep fp32 accuracy everywhere else."""
+    rng = np.random.RandomState(3)
+    M, N, K = 384, 256, 512
+    A = rng.standard_normal((K, M) if ak else (M, K)).astype(np.float32)
+    B = (0.05 * rng.standard_normal((K, N) if bk else (N, K))).astype(np.float32)
+    bad_rows, bad_cols = [5, 200], [17]
+
+    def put(arr, transposed, idx, k, val):      # element (row idx, reduction index k)
+        if transposed:
+            arr[k, idx] = val
+        else:
+            arr[idx, k] = val
+    put(A, ak, 5, 100, np.inf)
+    put(A, ak, 200, 7, np.nan)
+    put(B, bk, 17, 300, -np.inf)
+    exact = _run_gemm(native, "blh_gemm_f32", A, B, ak, bk, splits)
+    got = _run_gemm(native, entry, A, B, ak, bk, splits)
+    fin_exact = np.isfinite(exact)
+    assert not fin_exact[bad_rows].any() and not fin_exact[:, bad_cols].any()
+    clean = np.ones((M, N), bool)
+    clean[bad_rows] = False
+    clean[:, bad_cols] = False
+    assert fin_exact[clean].all()
+    # same finite / non-finite pattern, fp32-level values where finite
+    assert np.array_equal(np.isfinite(got), fin_exact)
+    A64 = np.where(np.isfinite(A), A, 0).astype(np.float64)
+    B64 = np.where(np.isfinite(B), B, 0).astype(np.float64)
+    ref = (A64.T if ak else A64) @ (B64 if bk else B64.T)
+    mag = np.abs(A64.T if ak else A64) @ np.abs(B64 if bk else B64.T)
+    assert (np.abs(got - ref)[clean] <= 2e-6 * mag[clean]).all()
+
+
+@pytest.mark.parametrize("ak,bk,splits", [(0, 0, 1), (1, 1, 4)])
+def test_fp16x2_gemm_range_edges(native, ak, bk, splits):
+    """fp16x2 scale logic at the ends of the fp32 range: a tensor whose largest magnitude is close
+    to FLT_MAX, a tensor of denormals (scale 1: they vanish, as far below 2^-126 * 2^13 as the
+    exact result itself is), an all-zero operand (the dZ of a dead layer) and a huge dynamic range
+    inside one tensor."""
+    rng = np.random.RandomState(9)
+    M, N, K = 256, 256, 256
+    shape_a, shape_b = ((K, M) if ak else (M, K)), ((K, N) if bk else (N, K))
+    B = (rng.standard_normal(shape_b) * 2.0 ** -20).astype(np.float32)
+    # (1) values up to 1e37 (products 1e31, sums finite in fp32)
+    A = (rng.standard_normal(shape_a) * 1e37 / 4).astype(np.float32)
+    A64, B64 = (A.T if ak else A).astype(np.float64), (B if bk else B.T).astype(np.float64)
+    got = _run_gemm(native, "fp16x2", A, B, ak, bk, splits)
+    exact = _run_gemm(native, "blh_gemm_f32", A, B, ak, bk, splits)
+    assert np.isfinite(exact).all() and np.isfinite(got).all()
+    mag = np.abs(A64) @ np.abs(B64)
+    assert (np.abs(got - A64 @ B64) <= 2e-6 * mag).all()
+    # (2) all-denormal operand: exact result is at most K * 1e-38 * |b|; fp16x2 returns zeros
+    Ad = (rng.standard_normal(shape_a) * 1e-39).astype(np.float32)
+    got = _run_gemm(native, "fp16x2", Ad, B, ak, bk, splits)
+    assert np.isfinite(got).all() and np.abs(got).max() <= 1e-36
+    # (3) all-zero operand -> exact zeros
+    got = _run_gemm(native, "fp16x2", np.zeros(shape_a, np.float32), B, ak, bk, splits)
+    assert np.abs(got).max() == 0.0
+    # (4) one element 2^40 times the rest: the small ones keep an absolute error of 2^-25 of the
+    #     scaled maximum, i.e. the error bound of an fp32 dot product containing the big term
+    A = rng.standard_normal(shape_a).astype(np.float32)
+    if ak:
+        A[3, 0] = 2.0 ** 40
+    else:
+        A[0, 3] = 2.0 ** 40
+    A64 = (A.T if ak else A).astype(np.float64)
+    got = _run_gemm(native, "fp16x2", A, B, ak, bk, splits)
+    exact = _run_gemm(native, "blh_gemm_f32", A, B, ak, bk, splits)
+    ref = A64 @ B64
+    # row 0 carries the big term; every other row only sees the tensor-wide scale
+    assert (np.abs(got[0] - ref[0]) <= 4e-7 * (np.abs(A64[0]) @ np.abs(B64))).all()
+    tiny_bound = 2.0 ** 40 * 2.0 ** -24 * np.abs(B64).max() * K
+    assert (np.abs(got[1:] - ref[1:]) <= tiny_bound).all()
+    assert np.isfinite(exact).all()
+
+
 @pytest.mark.parametrize("entry", ["blh_gemm_f32", "blh_gemm_bf16x3"])
 def test_gemm_bias_and_addend(native, entry):
     dev = _dev()
