@@ -266,6 +266,8 @@ def main():
                          "(1.25 vs 1.19 ms: the two-stream fork/join replays worse than it runs "
                          "eagerly) and equal at B=64, so eager is the default")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--one-stream", action="store_true",
+                    help="A/B: single-stream backward (BLH_OPT_TWO_STREAM = 0)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --batch is the GLOBAL batch, split evenly over the GPUs "
                          "(SURVEY.md 8(d)); default is weak scaling, --batch per GPU")
@@ -304,6 +306,9 @@ def main():
     net, opt, step, _ = bilinear_amd.load(dev, num_blocks=args.blocks, width=args.width,
                                           gemm_dtype=args.dtype)
     net.train()
+    if args.one_stream:
+        net.engine.ensure(dev)
+        net.engine.set_two_stream(False)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     x = torch.randn(args.batch, 32, device=dev, generator=g)
     t = torch.randn(args.batch, 48, device=dev, generator=g)

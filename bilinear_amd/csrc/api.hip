@@ -12,6 +12,7 @@
 namespace blh {
 
 thread_local int g_last_hip_error = 0;
+thread_local hipEvent_t tl_stop_event = nullptr;
 
 static constexpr int64_t ARENA_ALIGN = 64;   // floats (256 B)
 static constexpr int64_t WS_ALIGN = 256;     // bytes
@@ -408,6 +409,7 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
   // L2 / Infinity Cache.  Deferring all of them to the single grads_finish launch at the end
   // (BLH_DEFER_SLABS=1, kept for experiments) saves six launches but reads 68 MB of by then
   // cold slabs: measured 1.268 vs 1.253 ms/step, so it is off.
+  tl_stop_event = nullptr;
   const bool defer = (on_ready == nullptr) && ctx->defer_slabs;
   std::vector<GradRegion> wreg(nh + 1);
   // two streams: on by default (-3 % step)
@@ -415,10 +417,19 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
   hipStream_t s2 = two ? ctx->s2 : s;
   SyncCtx& g_sync = ctx->sync;
   blh_context& g_side = *ctx;
-  // fork: s2 continues after everything enqueued on s so far; wdone: marks wgrad(idx) complete
-  auto fork = [&](int idx) -> int {
+  // Fork: s2 continues behind a kernel of s.  Outside stream capture the event rides on that
+  // kernel's own completion signal (arm_fork before its launch, fork_wait after: common.h,
+  // tl_stop_event) instead of a marker packet behind it; under capture (events are graph edges
+  // there, not packets) it is recorded the ordinary way.  wdone: marks wgrad(idx) complete.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cap);
+  const bool attach = two && cap == hipStreamCaptureStatusNone;
+  auto arm_fork = [&](int idx) {
+    if (attach) tl_stop_event = g_side.ev_dz[idx];
+  };
+  auto fork_wait = [&](int idx) -> int {
     if (!two) return BLH_OK;
-    BLH_HIP_TRY(hipEventRecord(g_side.ev_dz[idx], s));
+    if (!attach) BLH_HIP_TRY(hipEventRecord(g_side.ev_dz[idx], s));
     BLH_HIP_TRY(hipStreamWaitEvent(s2, g_side.ev_dz[idx], 0));
     return BLH_OK;
   };
@@ -444,22 +455,26 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
     on_ready(user, off, cnt);
     return BLH_OK;
   };
-  // decode: dW = dP^T A_last, db = colsum(dP), dA_last = dP W_d
-  BLH_TRY(fork(nh));
-  BLH_TRY(wgrad(d->gemm_dtype, s2, TILE_64x128, dpred, OF, OF, ws.A[nh - 1], W, W, batch,
-                ceil_div(OF, 64) * ceil_div(W, 128), defer ? ws.stage_slabs[nh] : ws.slabs,
-                grads + L.dec_w, defer ? &wreg[nh] : nullptr));
-  BLH_TRY(wdone(nh));
-  if (!fused) BLH_TRY(launch_colsum(s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
-  BLH_TRY(ready(nh, L.dec_w, L.total - L.dec_w));
+  // decode: dA_last = dP W_d on the main stream first (it carries the fork event: the decode
+  // weight gradient then starts when it completes, next to the first BatchNorm-backward kernels),
+  // dW = dP^T A_last on the side stream, db = colsum(dP)
   {
     GemmParams g{};
     g.A = dpred; g.lda = OF;
     g.B = params + L.dec_w; g.ldb = W;
     g.C = ws.G0; g.ldc = W;
     g.M = (int)batch; g.N = W; g.K = OF; g.k_per_split = OF;
+    arm_fork(nh);
     BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, 1, d->gemm_dtype));
+    tl_stop_event = nullptr;
   }
+  BLH_TRY(fork_wait(nh));
+  BLH_TRY(wgrad(d->gemm_dtype, s2, TILE_64x128, dpred, OF, OF, ws.A[nh - 1], W, W, batch,
+                ceil_div(OF, 64) * ceil_div(W, 128), defer ? ws.stage_slabs[nh] : ws.slabs,
+                grads + L.dec_w, defer ? &wreg[nh] : nullptr));
+  BLH_TRY(wdone(nh));
+  if (!fused) BLH_TRY(launch_colsum(s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
+  BLH_TRY(ready(nh, L.dec_w, L.total - L.dec_w));
 
   for (int i = nh - 1; i >= 0; --i) {
     const HeavyOffsets& h = L.heavy[i];
@@ -488,22 +503,31 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
     if (two && i + 2 <= nh - 1)   // wgrad(i+2) read this dZ buffer
       BLH_HIP_TRY(hipStreamWaitEvent(s, g_side.ev_w[i + 2], 0));
     float* dz_amax = ws.amax_dZ[(two && (i & 1)) ? 1 : 0];
+    // stage 0 has no data gradient to overlap with: its weight gradient stays on the main stream
+    // (a fork + join there only adds two cross-queue latencies at the very end of backward)
+    const bool side = two && (i > 0 || on_ready != nullptr);
+    hipStream_t sw = side ? s2 : s;
+    if (side) arm_fork(i);
     BLH_TRY(launch_bn_bwd_apply(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W,
                                 params + h.gamma, dg, db, dzbuf,
                                 ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W, ds,
                                 norm_batch, dz_amax));
-    BLH_TRY(fork(i));
+    tl_stop_event = nullptr;
+    if (side) BLH_TRY(fork_wait(i));
     // Linear: db = colsum(dZ); dW = dZ^T a_in; d a_in = dZ W
     // (data parallel: the bucket hook needs this stage's bias gradient now; otherwise all
     //  stages are reduced by one launch after the loop)
     if (on_ready)   // on the side stream (after the fork): nothing on the main stream waits for it
-      BLH_TRY(launch_colreduce(s2, ws.dz_colsum_part + (int64_t)i * chunks * W, chunks, W, W,
+      BLH_TRY(launch_colreduce(sw, ws.dz_colsum_part + (int64_t)i * chunks * W, chunks, W, W,
                                grads + h.b));
     if (i == 0) {
-      BLH_TRY(wgrad(d->gemm_dtype, s2, TILE_128x32, dzbuf, W, W, x, d->in_features,
+      // (its slabs: the shared buffer is free once wgrad(1)'s sum has run — wait for the side
+      //  stream first when this launch is on the main stream)
+      if (two && !side) BLH_HIP_TRY(hipStreamWaitEvent(s, g_side.ev_w[1], 0));   // stage 1, or the decode (nh == 1)
+      BLH_TRY(wgrad(d->gemm_dtype, sw, TILE_128x32, dzbuf, W, W, x, d->in_features,
                     d->in_features, batch, ceil_div(W, 128) * ceil_div(d->in_features, 32),
                     defer ? ws.stage_slabs[0] : ws.slabs, grads + h.w, defer ? &wreg[0] : nullptr));
-      BLH_TRY(wdone(0));
+      if (side) BLH_TRY(wdone(0));
     } else {
       BLH_TRY(wgrad(d->gemm_dtype, s2, TILE_128x128, dzbuf, W, W, ws.A[i - 1], W, W, batch,
                     ceil_div(W, 128) * ceil_div(W, 128), defer ? ws.stage_slabs[i] : ws.slabs,
@@ -540,7 +564,8 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
       BLH_TRY(ready(i, h.w, end - h.w));
     }
   }
-  if (two) BLH_HIP_TRY(hipStreamWaitEvent(s, g_side.ev_w[0], 0));   // join: s2 is in order
+  // join: s2 is in order (stage 0 ran on the main stream unless the bucket hook wants the side one)
+  if (two) BLH_HIP_TRY(hipStreamWaitEvent(s, g_side.ev_w[on_ready != nullptr ? 0 : 1], 0));
   if (!on_ready) {   // (covers the no_defer A/B mode too: its regions are all plain)
     int64_t offs[32];
     if (nh > 32) return BLH_ERR_SHAPE;

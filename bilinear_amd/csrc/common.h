@@ -1,6 +1,7 @@
 // Shared declarations of the native library (host side).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/bilinear_hip.h"
@@ -23,6 +24,23 @@ extern thread_local int g_last_hip_error;
     int _s = (expr);             \
     if (_s != BLH_OK) return _s; \
   } while (0)
+
+// Fork without a marker packet.  An event a side stream has to wait for is normally recorded
+// with hipEventRecord BEHIND the producing kernel: an extra barrier packet in the queue, and the
+// next kernel of the producing stream starts ~7 us late (measured: gap in front of every dgrad of
+// the two-stream backward, profiles/r02_step_timeline.md).  Arming `tl_stop_event` makes the NEXT
+// kernel launched by this thread through launch_kernel() carry the event as its own completion
+// signal (hipExtLaunchKernelGGL stop event): no extra packet.  Set and consumed inside one call.
+extern thread_local hipEvent_t tl_stop_event;
+
+template <typename K, typename... Args>
+static inline void launch_kernel(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t s,
+                                 Args... args) {
+  hipEvent_t ev = tl_stop_event;
+  tl_stop_event = nullptr;
+  if (ev) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds, s, nullptr, ev, 0, args...);
+  else hipLaunchKernelGGL(kern, grid, block, lds, s, args...);
+}
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }

@@ -513,7 +513,7 @@ int launch_bn_bwd_apply(hipStream_t s, const float* dA, const float* Z, const fl
                         float* dz_colsum_part, int64_t batch, int W, const DropoutSrc& drop,
                         int64_t norm_batch, float* amax_part) {
   (void)gamma;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, ew_grid(batch, W), dim3(EW_THREADS), 0, s, dA, Z, scale,
+  launch_kernel(bn_bwd_apply_kernel, ew_grid(batch, W), dim3(EW_THREADS), 0, s, dA, Z, scale,
                      shift, mean, invstd, dgamma, dbeta, dZ, dz_colsum_part, batch, W,
                      ew_row_chunk(batch), drop, norm_batch, amax_part);
   BLH_HIP_TRY(hipGetLastError());

@@ -47,7 +47,7 @@ static int launch_ring(hipStream_t s, const GemmParams& p, int splits) {
   BLH_TRY(ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), lds));
   const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N, BN));
   dim3 grid(tiles, 1, splits);
-  hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);
+  launch_kernel(kern, grid, dim3(NT), lds, s, p);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
@@ -116,7 +116,7 @@ static int launch_cfg_bf16(hipStream_t s, const GemmParams& p, int splits) {
   auto kern = gemm_bf16_kernel<BM, BN, WM, WN, LA, LB, EPI>;
   BLH_TRY(ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), lds));
   const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N, BN));
-  hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(NT), lds, s, p);
+  launch_kernel(kern, dim3(tiles, 1, splits), dim3(NT), lds, s, p);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
@@ -160,7 +160,7 @@ static int launch_cfg_split(hipStream_t s, const GemmParams& p, int splits) {
   auto kern = gemm_split_kernel<128, 128, 2, 2, LA, LB, EPI>;
   BLH_TRY(ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), lds));
   const int tiles = (int)(ceil_div(p.M, 128) * ceil_div(p.N, 128));
-  hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(256), lds, s, p);
+  launch_kernel(kern, dim3(tiles, 1, splits), dim3(256), lds, s, p);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
@@ -191,7 +191,7 @@ static int launch_cfg_f16x2(hipStream_t s, const GemmParams& p, int splits) {
   auto kern = gemm_f16x2_kernel<LA, LB, EPI>;
   BLH_TRY(ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), lds));
   const int tiles = (int)(ceil_div(p.M, 128) * ceil_div(p.N, 128));
-  hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(256), lds, s, p);
+  launch_kernel(kern, dim3(tiles, 1, splits), dim3(256), lds, s, p);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }

@@ -87,3 +87,35 @@ def test_reference_pickles_round_trip(tmp_path):
     assert len(train) == 300 and len(valid) == 90
     with pytest.raises(ValueError):
         DevicePoseDataset({"part": np.zeros((4, 16, 2)), "S": np.zeros((4, 17, 3))}, "cpu")
+
+
+@pytest.mark.parametrize("protocol", ["GT", "SH", "SH+FT"])
+def test_from_pickles_selects_the_protocol_file(tmp_path, protocol):
+    """/root/reference/H36M/protocol.py:1-4 + H36M/data.py:31-34: the protocol only selects which
+    ``{task}_{protocol}.bin`` pair feeds the same path (GT: ground-truth 2D joints; SH / SH+FT:
+    joints detected by the (fine-tuned) hourglass).  Synthetic pickles of the reference's layout,
+    one pair per protocol with different 2D inputs and identical 3D targets."""
+    base_tr, base_va = synthetic_raw(600, seed=5), synthetic_raw(200, seed=6)
+    rng = np.random.RandomState(7)
+    for proto, noise in (("GT", 0.0), ("SH", 6.0), ("SH+FT", 3.0)):
+        for task, raw in (("train", base_tr), ("valid", base_va)):
+            r = dict(raw)
+            r["part"] = (raw["part"] + noise * rng.standard_normal(raw["part"].shape)).astype(np.float32).tolist()
+            r["S"] = raw["S"].tolist()                 # the reference stores python lists
+            with open(tmp_path / ("%s_%s.bin" % (task, proto)), "wb") as f:
+                pickle.dump(r, f)
+    train, valid = DevicePoseDataset.from_pickles(str(tmp_path), "cpu", protocol=protocol)
+    with open(tmp_path / ("train_%s.bin" % protocol), "rb") as f:
+        raw_tr = pickle.load(f)
+    with open(tmp_path / ("valid_%s.bin" % protocol), "rb") as f:
+        raw_va = pickle.load(f)
+    x, t, mt, st = _oracle_split(raw_tr, raw_va)
+    np.testing.assert_allclose(valid.x.numpy(), x, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(valid.t.numpy(), t, rtol=2e-5, atol=2e-5)
+    assert len(train) == 600 and len(valid) == 200
+    if protocol != "GT":     # detected joints differ from the ground truth, the 3D targets do not
+        gt_train, _ = DevicePoseDataset.from_pickles(str(tmp_path), "cpu", protocol="GT")
+        assert not torch.allclose(gt_train.x, train.x)
+        assert torch.allclose(gt_train.t, train.t)
+    with pytest.raises(FileNotFoundError):
+        DevicePoseDataset.from_pickles(str(tmp_path), "cpu", protocol="nope")

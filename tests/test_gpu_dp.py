@@ -178,3 +178,61 @@ def test_sync_bn_two_ranks_equal_single_device_on_full_batch(tmp_path):
         tol = 4.2e-3 if is_prebn_bias(name) else 1e-4
         err = np.abs(p0[off:off + n] - refp[off:off + n]).max()
         assert err <= tol, (name, err)
+
+
+# ----------------------------------------------------------------------------
+# RCCL itself (backend "nccl") on the one GPU of the box: world size 1 with the collectives
+# FORCED (DataParallel(force_collectives=True)), so that every call the N-GPU step makes —
+# ReduceOp.AVG on bucket views, launched from the grad-ready hook with the library's side stream
+# current; work.wait() ordering in finish(); the loss all-reduce; the SyncBN SUM exchanges on fp64
+# and fp32 buffers — executes on RCCL before an 8-GPU node ever sees it.
+# ----------------------------------------------------------------------------
+def _worker_rccl(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from bilinear_amd.dp import DataParallel
+        cfg = (1, 1024, 2048, "fp32")           # non-split-K path: side-stream weight gradients
+        x, t = _data(dev, cfg)
+        x, t = x[:cfg[2]].contiguous(), t[:cfg[2]].contiguous()
+        res = {}
+        for name, kw in (("dp", dict()), ("sync", dict(sync_bn=True))):
+            net, opt = _make(dev, cfg)
+            dp = DataParallel(net, opt, bucket_floats=200000, force_collectives=True, **kw)
+            assert dist.get_backend() == "nccl" and dp.world == 1
+            losses = []
+            for _ in range(3):
+                pred, loss = dp.train_step(x, t)
+                losses.append(float(loss.item()))
+            torch.cuda.synchronize()
+            assert len(dp._reducer.launched) >= 2
+            res[name] = (net.engine.params.clone(), net.engine.bn_running.clone(), losses)
+        # reference: the same three steps without any collective
+        net, opt = _make(dev, cfg)
+        dp0 = DataParallel(net, opt, bucket_floats=200000)
+        ref_losses = []
+        for _ in range(3):
+            pred, loss = dp0.train_step(x, t)
+            ref_losses.append(float(loss.item()))
+        torch.cuda.synchronize()
+        # averaging over one rank is the identity: bit-equal parameters and statistics
+        assert torch.equal(res["dp"][0], net.engine.params)
+        assert torch.equal(res["dp"][1], net.engine.bn_running)
+        assert res["dp"][2] == ref_losses
+        # SyncBN merges statistics through sum / sum-of-squares instead of the tile merge:
+        # equal to rounding
+        d = (res["sync"][0] - net.engine.params).abs().max().item()
+        assert d <= 5e-3, d          # pre-BN biases move by up to ~lr per step on noise (H2)
+        assert max(abs(a - b) for a, b in zip(res["sync"][2], ref_losses)) <= 1e-5 * ref_losses[0]
+        open(os.path.join(out_dir, "rccl_ok"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_world1_runs_every_collective_of_the_step(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_rccl, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    assert os.path.exists(tmp_path / "rccl_ok")
