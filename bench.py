@@ -224,6 +224,29 @@ def alt_mode_block(args, dev, x, t, alt):
     return out
 
 
+# BASELINE.json configs[i] -> (blocks, width, per-GPU batch, GEMM arithmetic, n_gpus the config names)
+BASELINE_CONFIGS = {
+    1: dict(blocks=2, width=1024, batch=4096, dtype="fp32", gpus=1,
+            text="2-block width 1024 batch 4096 fp32 on 1xMI355X, fused Linear+BN+ReLU+Dropout fwd/bwd"),
+    2: dict(blocks=4, width=1024, batch=16384, dtype="bf16", gpus=1,
+            text="4-block width 1024 batch 16384 bf16 on 1xMI355X, MFMA hidden GEMMs + fused Adam"),
+    3: dict(blocks=4, width=1024, batch=8192, dtype="bf16", gpus=8,
+            text="4-block width 1024 batch 65536 bf16, data-parallel 8xMI355X (8192 poses per GPU)"),
+    4: dict(blocks=8, width=2048, batch=16384, dtype="bf16", gpus=8,
+            text="8-block width 2048 batch 131072 bf16, 8xMI355X (16384 poses per GPU)"),
+}
+
+
+def workload_label(args, world):
+    """Names the BASELINE.json config only when the run really is that config."""
+    for idx, c in BASELINE_CONFIGS.items():
+        if (args.blocks, args.width, args.batch, args.dtype) == (c["blocks"], c["width"], c["batch"], c["dtype"]):
+            per_gpu = "" if world == c["gpus"] else " [per-GPU shape of the config, run on %d GPU%s]" % (
+                world, "" if world == 1 else "s")
+            return "BASELINE configs[%d]: %s%s" % (idx, c["text"], per_gpu)
+    return "custom: %d-block width %d, batch %d per GPU, %s" % (args.blocks, args.width, args.batch, args.dtype)
+
+
 def log(msg):
     print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
@@ -251,21 +274,26 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch")
-    ap.add_argument("--blocks", type=int, default=2)
-    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--config", type=int, choices=sorted(BASELINE_CONFIGS), default=1,
+                    help="BASELINE.json configs[i]: sets --blocks/--width/--batch/--dtype (explicit flags "
+                         "override); default 1 = the headline (2-block, width 1024, batch 4096, fp32)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch")
+    ap.add_argument("--blocks", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", choices=["fp32", "bf16", "bf16x3", "fp16x2"], default="fp32",
+    ap.add_argument("--dtype", choices=["fp32", "bf16", "bf16x3", "fp16x2"], default=None,
                     help="GEMM arithmetic: fp32 MFMA (BASELINE configs[1], default) or bf16 MFMA "
                          "inputs with fp32 accumulation and fp32 storage (configs 3-5)")
     ap.add_argument("--sync-bn", action="store_true",
                     help="N>1: BatchNorm statistics over the global batch (exact reference semantics)")
     ap.add_argument("--graph", action="store_true",
                     help="N=1: replay the hipGraph-captured step (bilinear_amd.CapturedTrainStep) "
-                         "instead of enqueuing it eagerly; measured slightly slower at B=4096 "
-                         "(1.25 vs 1.19 ms: the two-stream fork/join replays worse than it runs "
-                         "eagerly) and equal at B=64, so eager is the default")
+                         "instead of enqueuing it eagerly; slower at B=4096 (cross-queue graph edges "
+                         "cost 10-18 us each, profiles/r02_step_timeline.md) and equal at B=64, so "
+                         "eager is the default")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--graph-two-stream", action="store_true",
+                    help="--graph: capture the forked two-stream DAG (default: single-stream order)")
     ap.add_argument("--one-stream", action="store_true",
                     help="A/B: single-stream backward (BLH_OPT_TWO_STREAM = 0)")
     ap.add_argument("--strong", action="store_true",
@@ -275,6 +303,10 @@ def main():
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the extra timing of the bf16x3 GEMM mode (reported beside the headline)")
     args = ap.parse_args()
+    cfg = BASELINE_CONFIGS[args.config]
+    for key in ("blocks", "width", "batch", "dtype"):
+        if getattr(args, key) is None:
+            setattr(args, key, cfg[key])
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -314,7 +346,13 @@ def main():
     t = torch.randn(args.batch, 48, device=dev, generator=g)
     dp = DataParallel(net, opt, sync_bn=args.sync_bn) if world > 1 else None
     use_graph = (world == 1) and args.graph and not args.no_graph
-    captured = bilinear_amd.CapturedTrainStep(net, opt, args.batch, max_norm=1.0) if use_graph else None
+    captured = None
+    if use_graph:
+        captured = bilinear_amd.CapturedTrainStep(net, opt, args.batch, max_norm=1.0,
+                                                  two_stream=not args.one_stream and args.graph_two_stream)
+        captured.x.copy_(x)            # the batch lives in the graph's static input buffers
+        captured.t.copy_(t)
+        x, t = captured.x, captured.t
 
     def one_step():
         if dp is not None:
@@ -380,9 +418,9 @@ def main():
                       "bf16": "bf16 (MFMA inputs; fp32 accumulate and storage)"}[args.dtype],
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: %d-block width %d, batch %d per GPU, fp32, "
-                            "x~N(0,1)[B,32], t~N(0,1)[B,48], Kaiming-normal init" % (
-                                args.blocks, args.width, args.batch),
+                "workload": workload_label(args, world) + "; x~N(0,1)[B,32], t~N(0,1)[B,48], "
+                            "Kaiming-normal init",
+                "num_blocks": args.blocks, "width": args.width, "per_gpu_batch": args.batch,
                 "step": "zero_grad+forward+MSE+backward%s+clip_grad_norm(1)+Adam" % (
                     "+allreduce(grad)" if world > 1 else ""),
                 "global_batch": args.batch * world,

@@ -86,7 +86,9 @@ struct Workspace {
   std::vector<float*> Z, A;       // per heavy: pre-BN output, activation (skip added)
   std::vector<float*> bn_saved;   // per heavy: [4][W] mean, invstd, scale, shift
   float* stat_part;               // [tiles_m][2][W]
-  float* G0; float* G1; float* dZ; float* dZ2;
+  float* G0; float* G1;
+  std::vector<float*> dZ;         // per heavy stage: no buffer is reused inside one backward, so
+                                  // the side-stream weight gradients impose no wait on the main stream
   float* bn_part;                 // [chunks][2][W]
   float* dz_colsum_part;          // [stage][chunks][W]
   float* slabs;                   // split-K partial products
@@ -169,8 +171,7 @@ static Workspace carve(const blh_model_desc* d, int64_t batch, void* base) {
   ws.stat_part = (float*)take(ceil_div(batch, 64) * 2 * W * sizeof(float));
   ws.G0 = (float*)take(act);
   ws.G1 = (float*)take(act);
-  ws.dZ = (float*)take(act);
-  ws.dZ2 = (float*)take(act);
+  for (int i = 0; i < nh; ++i) ws.dZ.push_back((float*)take(act));
   const int64_t chunks = ew_num_row_chunks(batch);
   ws.bn_part = (float*)take(chunks * 2 * W * sizeof(float));
   ws.dz_colsum_part = (float*)take((int64_t)nh * chunks * W * sizeof(float));
@@ -499,10 +500,12 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
       g_sync.fn(g_sync.user, sb, 2 * (int64_t)W, 0);
       dg = sb; db = sb + W; norm_batch = g_sync.global_batch;
     }
-    float* dzbuf = (two && (i & 1)) ? ws.dZ2 : ws.dZ;
-    if (two && i + 2 <= nh - 1)   // wgrad(i+2) read this dZ buffer
+    float* dzbuf = ws.dZ[i];
+    float* dz_amax = ws.amax_dZ[i & 1];
+    // (the two amax partial buffers alternate: the fp16x2 wgrad(i+2) on the side stream may still
+    //  be reading the one bn_bwd_apply(i) is about to write)
+    if (two && dz_amax && i + 2 <= nh - 1)
       BLH_HIP_TRY(hipStreamWaitEvent(s, g_side.ev_w[i + 2], 0));
-    float* dz_amax = ws.amax_dZ[(two && (i & 1)) ? 1 : 0];
     // stage 0 has no data gradient to overlap with: its weight gradient stays on the main stream
     // (a fork + join there only adds two cross-queue latencies at the very end of backward)
     const bool side = two && (i > 0 || on_ready != nullptr);
@@ -629,7 +632,13 @@ int blh_context_create(blh_context** out) {
   };
   hipError_t e = hipGetDevice(&c->device);
   if (e != hipSuccess) return fail(e);
-  if ((e = hipStreamCreateWithFlags(&c->s2, hipStreamNonBlocking)) != hipSuccess) return fail(e);
+  // The side stream carries the weight-gradient GEMMs, which nothing in backward waits for: it
+  // gets the LOWEST priority, so that the main stream's data-gradient GEMM (the critical path:
+  // the next stage's BatchNorm backward needs its output) takes the CUs first and the weight
+  // gradient fills what is left — including the main stream's event gaps.
+  int prio_least = 0, prio_greatest = 0;
+  if ((e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest)) != hipSuccess) return fail(e);
+  if ((e = hipStreamCreateWithPriority(&c->s2, hipStreamNonBlocking, prio_least)) != hipSuccess) return fail(e);
   for (int i = 0; i < BLH_CTX_EVENTS; ++i) {
     if ((e = hipEventCreateWithFlags(&c->ev_dz[i], hipEventDisableTiming)) != hipSuccess) return fail(e);
     if ((e = hipEventCreateWithFlags(&c->ev_w[i], hipEventDisableTiming)) != hipSuccess) return fail(e);

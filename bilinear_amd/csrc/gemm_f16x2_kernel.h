@@ -119,8 +119,13 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(GemmParams p) {
   const float sa = __uint_as_float((uint32_t)(ea + 127) << 23);
   const float sb = __uint_as_float((uint32_t)(eb + 127) << 23);
   // (ea + eb can exceed the exponent range of one float: unscale in two exact steps)
-  const float un_a = __uint_as_float((uint32_t)(127 - ea) << 23);
-  const float un_b = __uint_as_float((uint32_t)(127 - eb) << 23);
+  // un-scale by 2^-(ea+eb) in two exact steps of half the exponent each: |ea + eb| can exceed the
+  // exponent range of one float, and with halves the intermediate acc * 2^u1 lies between acc and
+  // the final value on the log scale — whenever both of those are finite floats, so is it
+  // (un-scaling by 2^-ea then 2^-eb overflowed for a 1e37-sized operand times a 1e-6-sized one)
+  const int un_total = -(ea + eb), un_half = un_total / 2;
+  const float un_a = __uint_as_float((uint32_t)(127 + un_half) << 23);
+  const float un_b = __uint_as_float((uint32_t)(127 + (un_total - un_half)) << 23);
 
   store_all(ioa, ra[0], lds, sa);
   store_all(iob, rb[0], lds + A_EL, sb);

@@ -28,7 +28,15 @@ class CapturedTrainStep:
     lr-decay hook keeps working); ``opt`` state (exp_avg, exp_avg_sq, step) stays in sync.
     """
 
-    def __init__(self, module, optimizer, batch, max_norm=1.0, device=None):
+    def __init__(self, module, optimizer, batch, max_norm=1.0, device=None, two_stream=False):
+        """``two_stream=False`` (default): the graph is captured in the single-stream kernel order.
+        Measured on MI355X (profiles/r02_step_timeline.md): hipGraph replay spreads the forked
+        weight-gradient branch over up to four hardware queues and every cross-queue edge costs
+        10-18 us, so the two-stream DAG replays SLOWER (1.171 ms at B=4096) than its own
+        single-stream capture (1.141 ms) — eager enqueue, which keeps both streams on two queues
+        with CP-pipelined dispatch, is the fast form there (1.10 ms).  At the reference's batch
+        size (64) the step is bound by the ~5 us minimum duration of each of its ~55 kernels, and
+        replay equals eager (0.34 ms)."""
         eng = module.engine
         dev = torch.device(device) if device is not None else next(module.parameters()).device
         eng.ensure(dev)
@@ -55,6 +63,8 @@ class CapturedTrainStep:
         # Warm-up on a side stream (sets kernel attributes, touches every buffer) on a snapshot
         # of the training state, which is restored afterwards: building the graph must not
         # move the model.  Capture itself executes nothing.
+        was_two = eng.ctx.get_option(N.OPT_TWO_STREAM)
+        eng.ctx.set_option(N.OPT_TWO_STREAM, 1 if two_stream else 0)
         snap = [t.clone() for t in (eng.params, optimizer._exp_avg, optimizer._exp_avg_sq,
                                     eng.bn_running, eng.bn_nbt)]
         side = torch.cuda.Stream(device=dev)
@@ -70,6 +80,7 @@ class CapturedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._enqueue()
+        eng.ctx.set_option(N.OPT_TWO_STREAM, was_two)
 
     # -- device step state ------------------------------------------------------
     def _write_state(self):
@@ -119,8 +130,11 @@ class CapturedTrainStep:
         want = (float(self.opt.param_groups[0]["lr"]), int(self.opt._t), int(self.eng.rng_step))
         if want != self._mirror:
             self._write_state()
-        self.x.copy_(x, non_blocking=True)
-        self.t.copy_(target, non_blocking=True)
+        # (callers that fill ``self.x`` / ``self.t`` in place and pass them back pay no copy)
+        if x.data_ptr() != self.x.data_ptr():
+            self.x.copy_(x, non_blocking=True)
+        if target.data_ptr() != self.t.data_ptr():
+            self.t.copy_(target, non_blocking=True)
         self.graph.replay()
         self._after_step()
         return self.pred, self.loss
