@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "common.h"
+#include "gemm_bf16s_kernel.h"
 
 namespace blh {
 
@@ -548,6 +549,7 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
       }
       const Splits ds2 = small_m_splits(batch, W, W);
       float* dst = first_of_block ? ws.G0 : ws.G1;
+      g.prio = two ? 2 : 0;   // critical path: ahead of the side stream's weight-gradient GEMM
       if (ds2.splits > 1) {
         g.C = ws.slabs; g.c_split_stride = batch * (int64_t)W; g.k_per_split = ds2.k_per;
         BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, ds2.splits, d->gemm_dtype));
@@ -1125,6 +1127,36 @@ int blh_dropout_mask(void* stream, const blh_dropout* drop, int32_t layer, int64
   BLH_TRY(check_drop(drop));
   DropoutSrc d{nullptr, drop->seed, drop->step, drop->row_offset, drop->layer_base + layer, nullptr};
   return launch_dropout_mask((hipStream_t)stream, keep_out, batch, width, d);
+}
+
+int blh_gemm_bf16s(void* stream, const uint16_t* A, int64_t lda, int32_t a_kmajor, const uint16_t* B,
+                   int64_t ldb, int32_t b_kmajor, void* C, int64_t ldc, int32_t out_bf16, int64_t M,
+                   int64_t N, int64_t K, int32_t splits, const float* bias, const uint16_t* addend,
+                   int64_t ldadd, float* stat_part) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || splits < 1) return BLH_ERR_INVALID_ARGUMENT;
+  if (bias && addend) return BLH_ERR_INVALID_ARGUMENT;
+  if (splits > 1 && (bias || addend)) return BLH_ERR_INVALID_ARGUMENT;
+  if (stat_part && (!bias || splits > 1)) return BLH_ERR_INVALID_ARGUMENT;
+  GemmParamsH g{};
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.M = (int)M; g.N = (int)N; g.K = (int)K;
+  g.k_per_split = (splits > 1) ? (int)round_up(ceil_div(K, splits), SPLIT_GRAIN) : (int)K;
+  if (splits > 1 && (int64_t)g.k_per_split * (splits - 1) >= K) return BLH_ERR_SHAPE;
+  g.c_split_stride = M * ldc;
+  g.bias = bias; g.addend = addend; g.ldadd = ldadd; g.stat_part = stat_part;
+  const int epi = bias ? (stat_part ? EPI_BIAS_STATS : EPI_BIAS) : (addend ? EPI_ADD : EPI_STORE);
+  return launch_gemm_bf16s((hipStream_t)stream, a_kmajor ? KROW : ROWK, b_kmajor ? KROW : ROWK, epi,
+                           out_bf16 != 0, g, splits);
+}
+
+int blh_cast_f32_to_bf16(void* stream, const float* src, uint16_t* dst, int64_t count) {
+  if (!src || !dst || count <= 0) return BLH_ERR_INVALID_ARGUMENT;
+  return launch_cast_f32_bf16((hipStream_t)stream, src, dst, count);
+}
+
+int blh_cast_bf16_to_f32(void* stream, const uint16_t* src, float* dst, int64_t count) {
+  if (!src || !dst || count <= 0) return BLH_ERR_INVALID_ARGUMENT;
+  return launch_cast_bf16_f32((hipStream_t)stream, src, dst, count);
 }
 
 int blh_sum_slabs(void* stream, const float* slabs, int64_t count, int32_t splits, float* out) {

@@ -73,6 +73,11 @@ struct GemmParams {
   // gemm_dtype 3 (fp16 two-piece split): max |value| partials of each operand tensor
   const float* a_amax; int a_namax;
   const float* b_amax; int b_namax;
+  // Wave issue priority (s_setprio 0..3) of this launch.  Two GEMMs that share the chip from two
+  // streams also share every SIMD's matrix pipe; the one on the critical path (the data-gradient
+  // GEMM of the two-stream backward) runs at a higher priority so that it finishes at almost its
+  // stand-alone time while the other one (the weight gradient) fills the remaining issue slots.
+  int prio;
 };
 
 enum GemmTile : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_128x32 = 3 };

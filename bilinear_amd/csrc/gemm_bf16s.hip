@@ -1,0 +1,105 @@
+// Host-side dispatch of the bf16-storage GEMM (kernel: gemm_bf16s_kernel.h) and the cast kernels
+// between the fp32 master tensors and their bf16 images.
+#include <atomic>
+
+#include "gemm_bf16s_kernel.h"
+
+namespace blh {
+
+static int ensure_lds_attr_h(std::atomic<uint64_t>& done, const void* kern, size_t lds) {
+  int dev = 0;
+  BLH_HIP_TRY(hipGetDevice(&dev));
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    BLH_HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    done.fetch_or(bit, std::memory_order_release);
+  }
+  return BLH_OK;
+}
+
+// K tile / ring depth: 64 elements x 2 stages = 64 KB of LDS, two workgroups (8 waves) per CU
+static constexpr int H_BKE = BLH_H_BKE_DEFAULT, H_STAGES = BLH_H_STAGES_DEFAULT;
+
+template <int LA, int LB, int EPI, bool OUT_BF16>
+static int launch_h(hipStream_t s, const GemmParamsH& p, int splits) {
+  constexpr size_t lds = gemm_bf16s_lds_bytes<H_BKE, H_STAGES>();
+  static std::atomic<uint64_t> attr_done{0};
+  auto kern = gemm_bf16s_kernel<LA, LB, EPI, OUT_BF16, H_BKE, H_STAGES>;
+  BLH_TRY(ensure_lds_attr_h(attr_done, reinterpret_cast<const void*>(kern), lds));
+  const int tiles = (int)(ceil_div(p.M, 128) * ceil_div(p.N, 128));
+  launch_kernel(kern, dim3(tiles, 1, splits), dim3(256), lds, s, p);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+#define BLH_CASEH(LA_, LB_, EPI_, OUT_) \
+  if (la == LA_ && lb == LB_ && epi == EPI_ && out_bf16 == OUT_) return launch_h<LA_, LB_, EPI_, OUT_>(s, p, splits);
+
+int launch_gemm_bf16s(hipStream_t s, int la, int lb, int epi, bool out_bf16, const GemmParamsH& p,
+                      int splits) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || splits < 1) return BLH_ERR_INVALID_ARGUMENT;
+  // 16-byte DMA chunks: every contiguous extent a multiple of 8 elements, rows 16-byte aligned
+  if (p.K % 8 != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0) return BLH_ERR_SHAPE;
+  if (la == KROW && p.M % 8 != 0) return BLH_ERR_SHAPE;
+  if (lb == KROW && p.N % 8 != 0) return BLH_ERR_SHAPE;
+  if (out_bf16 && (p.N % 2 != 0 || p.ldc % 2 != 0)) return BLH_ERR_SHAPE;
+  if (splits > 1 && (p.k_per_split % H_BKE) != 0) return BLH_ERR_SHAPE;
+  if (((uintptr_t)p.A | (uintptr_t)p.B) & 15) return BLH_ERR_INVALID_ARGUMENT;
+  // 32-bit per-lane byte offsets inside one tile row panel
+  if ((int64_t)128 * std::max(p.lda, p.ldb) * 2 >= (1ll << 31)) return BLH_ERR_SHAPE;
+  BLH_CASEH(ROWK, ROWK, EPI_BIAS_STATS, true)    // forward (train): Z bf16 + BatchNorm partials
+  BLH_CASEH(ROWK, ROWK, EPI_BIAS, true)          // forward (eval)
+  BLH_CASEH(ROWK, ROWK, EPI_STORE, true)
+  BLH_CASEH(ROWK, ROWK, EPI_STORE, false)
+  BLH_CASEH(ROWK, KROW, EPI_STORE, true)         // dgrad
+  BLH_CASEH(ROWK, KROW, EPI_ADD, true)           // dgrad + block-skip gradient
+  BLH_CASEH(ROWK, KROW, EPI_STORE, false)
+  BLH_CASEH(KROW, KROW, EPI_STORE, false)        // wgrad: fp32 slabs
+  return BLH_ERR_INVALID_ARGUMENT;
+}
+#undef BLH_CASEH
+
+// ---- casts ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src,
+                                                            bf16_bits* __restrict__ dst, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = *reinterpret_cast<const float4*>(src + i * 4);
+    uint2 o;
+    o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(dst + i * 4) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_bits* __restrict__ src,
+                                                            float* __restrict__ dst, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const uint2 v = *reinterpret_cast<const uint2*>(src + i * 4);
+    float4 o;
+    o.x = __uint_as_float(v.x << 16); o.y = __uint_as_float(v.x & 0xffff0000u);
+    o.z = __uint_as_float(v.y << 16); o.w = __uint_as_float(v.y & 0xffff0000u);
+    *reinterpret_cast<float4*>(dst + i * 4) = o;
+  }
+}
+
+int launch_cast_f32_bf16(hipStream_t s, const float* src, uint16_t* dst, int64_t n) {
+  if (n % 4 != 0) return BLH_ERR_SHAPE;
+  const int64_t blocks = std::min<int64_t>(ceil_div(n / 4, 256), 4096);
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+int launch_cast_bf16_f32(hipStream_t s, const uint16_t* src, float* dst, int64_t n) {
+  if (n % 4 != 0) return BLH_ERR_SHAPE;
+  const int64_t blocks = std::min<int64_t>(ceil_div(n / 4, 256), 4096);
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+}  // namespace blh

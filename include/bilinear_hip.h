@@ -340,6 +340,20 @@ int blh_gemm_fp16x2(void* stream, const float* A, int64_t lda, int32_t a_kmajor,
                     int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc, int64_t M, int64_t N,
                     int64_t K, int32_t splits, const float* bias, const float* addend,
                     int64_t ldadd, void* workspace, int32_t maxima_ready);
+/* The GEMM of gemm_dtype = 4 ("bf16s": bf16 storage): A and B are bf16 IN MEMORY (uint16 bit
+ * patterns; lda / ldb / ldc in elements; 16-byte aligned bases; K and every contiguous extent a
+ * multiple of 8), bf16 MFMA with fp32 accumulation, C bf16 (out_bf16 != 0) or fp32.  Operand
+ * layouts as blh_gemm_f32.  bias fp32 [N] or NULL; addend bf16 [M][ldadd] or NULL (not both; not
+ * with splits > 1); stat_part (optional, with bias, splits == 1): per-128-row-tile column (mean,
+ * M2) of the fp32 values before rounding, [ceil(M/128)][2][N].  splits > 1 writes slabs
+ * [splits][M][ldc].                                                                          */
+int blh_gemm_bf16s(void* stream, const uint16_t* A, int64_t lda, int32_t a_kmajor, const uint16_t* B,
+                   int64_t ldb, int32_t b_kmajor, void* C, int64_t ldc, int32_t out_bf16, int64_t M,
+                   int64_t N, int64_t K, int32_t splits, const float* bias, const uint16_t* addend,
+                   int64_t ldadd, float* stat_part);
+/* fp32 <-> bf16 (round to nearest even) over `count` elements (multiple of 4).              */
+int blh_cast_f32_to_bf16(void* stream, const float* src, uint16_t* dst, int64_t count);
+int blh_cast_bf16_to_f32(void* stream, const uint16_t* src, float* dst, int64_t count);
 int blh_sum_slabs(void* stream, const float* slabs, int64_t count, int32_t splits, float* out);
 /* The forward kernel of one heavy_linear exactly as blh_forward_train launches it:
  * Z[M,N] = A[M,K] W[N,K]^T + bias, plus per-128-row-tile column statistics

@@ -1,0 +1,175 @@
+"""gemm_dtype = "bf16s" (bf16 storage, BASELINE configs 3-5) on the MI355X: kernel level.
+
+The bf16-storage GEMM reads bf16 operands straight from memory (LDS-DMA, transposing LDS reads
+for the operands whose reduction index is the memory row) and accumulates in fp32, so its result
+must equal the exact product of the bf16 operand VALUES to fp32 accumulation accuracy (2e-5 of
+sum |a b|), in every operand layout, with ragged M / N / K, split reductions, both output types
+and every epilogue."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _to_bf16_bits(a):
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16)
+
+
+def _bits_to_f32(b):
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+CASES = [
+    # M, N, K, a_kmajor, b_kmajor, splits
+    (256, 256, 128, 0, 0, 1),         # forward layout, full tiles
+    (4096, 1024, 1024, 0, 0, 1),      # hidden Linear forward at B = 4096
+    (300, 1024, 64, 0, 0, 1),         # ragged M, one K tile
+    (200, 1024, 1024, 0, 1, 1),       # dgrad
+    (264, 264, 200, 0, 1, 1),         # dgrad, ragged everything (K % 64 != 0)
+    (1024, 1024, 4096, 1, 1, 4),      # wgrad, split over the batch
+    (1024, 1024, 1000, 1, 1, 2),      # wgrad, ragged reduction
+    (136, 200, 328, 1, 1, 1),         # wgrad, ragged M / N
+    (64, 1024, 48, 0, 1, 1),          # K = 48 (one ragged tile)
+]
+
+
+@pytest.mark.parametrize("out_bf16", [0, 1])
+@pytest.mark.parametrize("M,N,K,ak,bk,splits", CASES)
+def test_gemm_bf16s_layouts(native, M, N, K, ak, bk, splits, out_bf16):
+    if out_bf16 and splits > 1:
+        pytest.skip("slabs are fp32")
+    dev = _dev()
+    rng = np.random.RandomState(M + 3 * N + 7 * K)
+    A = rng.standard_normal((K, M) if ak else (M, K)).astype(np.float32)
+    B = rng.standard_normal((K, N) if bk else (N, K)).astype(np.float32)
+    A[0] += 3.0                                        # asymmetric operands
+    Ab, Bb = _to_bf16_bits(A), _to_bf16_bits(B)
+    A64, B64 = _bits_to_f32(Ab).astype(np.float64), _bits_to_f32(Bb).astype(np.float64)
+    ref = (A64.T if ak else A64) @ (B64 if bk else B64.T)
+    mag = np.abs(A64.T if ak else A64) @ np.abs(B64 if bk else B64.T)
+    a = torch.from_numpy(Ab.view(np.int16)).to(dev)
+    b = torch.from_numpy(Bb.view(np.int16)).to(dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if out_bf16:
+        c = torch.full((M, N), -1, dtype=torch.int16, device=dev)
+    else:
+        c = torch.full((splits, M, N), float("nan"), device=dev)
+    rc = native.blh_gemm_bf16s(st, a.data_ptr(), A.shape[1], ak, b.data_ptr(), B.shape[1], bk,
+                               c.data_ptr(), N, out_bf16, M, N, K, splits, None, None, 0, None)
+    assert rc == 0, native.blh_status_string(rc)
+    torch.cuda.synchronize()
+    if out_bf16:
+        got = _bits_to_f32(c.cpu().numpy().view(np.uint16)).astype(np.float64)
+        # one rounding to bf16 on top of the fp32 accumulation
+        assert (np.abs(got - ref) <= 2.0 ** -8 * np.abs(ref) + 2e-5 * mag).all()
+    else:
+        got = c.cpu().numpy().astype(np.float64).sum(axis=0)
+        err = np.abs(got - ref) / mag
+        assert err.max() <= 2e-5, err.max()
+
+
+def test_gemm_bf16s_epilogues(native):
+    dev = _dev()
+    rng = np.random.RandomState(4)
+    M, N, K = 392, 384, 192
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (0.1 * rng.standard_normal((N, K))).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    add = rng.standard_normal((M, N)).astype(np.float32)
+    Ab, Wb, addb = _to_bf16_bits(A), _to_bf16_bits(W), _to_bf16_bits(add)
+    A64, W64 = _bits_to_f32(Ab).astype(np.float64), _bits_to_f32(Wb).astype(np.float64)
+    a = torch.from_numpy(Ab.view(np.int16)).to(dev)
+    w = torch.from_numpy(Wb.view(np.int16)).to(dev)
+    bt = torch.from_numpy(bias).to(dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # forward: + bias, bf16 out, BatchNorm tile partials of the un-rounded values
+    z = torch.empty(M, N, dtype=torch.int16, device=dev)
+    part = torch.empty((M + 127) // 128, 2, N, device=dev)
+    assert native.blh_gemm_bf16s(st, a.data_ptr(), K, 0, w.data_ptr(), K, 0, z.data_ptr(), N, 1, M, N, K,
+                                 1, bt.data_ptr(), None, 0, part.data_ptr()) == 0
+    torch.cuda.synchronize()
+    ref = A64 @ W64.T + bias
+    got = _bits_to_f32(z.cpu().numpy().view(np.uint16)).astype(np.float64)
+    assert (np.abs(got - ref) <= 2.0 ** -8 * np.abs(ref) + 1e-4).all()
+    p = part.cpu().numpy().astype(np.float64)
+    for t in range(p.shape[0]):
+        rows = ref[t * 128:(t + 1) * 128]
+        assert np.abs(p[t, 0] - rows.mean(0)).max() <= 1e-5 * (1 + np.abs(rows).max())
+        m2 = ((rows - rows.mean(0)) ** 2).sum(0)
+        assert np.abs(p[t, 1] - m2).max() <= 1e-4 * m2.max()
+    # dgrad + skip gradient: C = A * Wk + addend (bf16), may alias the addend buffer
+    Wk = (0.1 * rng.standard_normal((K, N))).astype(np.float32)
+    Wkb = _to_bf16_bits(Wk)
+    wk = torch.from_numpy(Wkb.view(np.int16)).to(dev)
+    g = torch.from_numpy(addb.view(np.int16)).to(dev)
+    assert native.blh_gemm_bf16s(st, a.data_ptr(), K, 0, wk.data_ptr(), N, 1, g.data_ptr(), N, 1, M, N, K,
+                                 1, None, g.data_ptr(), N, None) == 0
+    torch.cuda.synchronize()
+    ref = A64 @ _bits_to_f32(Wkb).astype(np.float64) + _bits_to_f32(addb).astype(np.float64)
+    got = _bits_to_f32(g.cpu().numpy().view(np.uint16)).astype(np.float64)
+    assert (np.abs(got - ref) <= 2.0 ** -8 * np.abs(ref) + 1e-4).all()
+
+
+def test_cast_round_trip(native):
+    dev = _dev()
+    rng = np.random.RandomState(1)
+    x = (rng.standard_normal(4096 * 33) * np.exp(3 * rng.standard_normal(4096 * 33))).astype(np.float32)
+    x[:4] = [np.inf, -np.inf, np.nan, 0.0]
+    xt = torch.from_numpy(x).to(dev)
+    b = torch.empty(x.size, dtype=torch.int16, device=dev)
+    y = torch.empty(x.size, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert native.blh_cast_f32_to_bf16(st, xt.data_ptr(), b.data_ptr(), x.size) == 0
+    assert native.blh_cast_bf16_to_f32(st, b.data_ptr(), y.data_ptr(), x.size) == 0
+    torch.cuda.synchronize()
+    want = _bits_to_f32(_to_bf16_bits(x[4:]))
+    assert np.array_equal(y.cpu().numpy()[4:], want)
+    head = y.cpu().numpy()[:4]
+    assert head[0] == np.inf and head[1] == -np.inf and np.isnan(head[2]) and head[3] == 0.0
+
+
+def test_gemm_bf16s_speed(native):
+    """Not a pass/fail on speed: prints the achieved TFLOP/s of the three contractions at the
+    config-3 shape (B = 16384, W = 1024) for the record (-s)."""
+    dev = _dev()
+    M, W = 16384, 1024
+    a = torch.randn(M, W, device=dev).to(torch.bfloat16)
+    w = (torch.randn(W, W, device=dev) * 0.03).to(torch.bfloat16)
+    bias = torch.randn(W, device=dev)
+    z = torch.empty(M, W, dtype=torch.bfloat16, device=dev)
+    part = torch.empty(M // 128, 2, W, device=dev)
+    slabs = torch.empty(4, W, W, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def fwd():
+        return native.blh_gemm_bf16s(st, a.data_ptr(), W, 0, w.data_ptr(), W, 0, z.data_ptr(), W, 1, M, W, W, 1,
+                                     bias.data_ptr(), None, 0, part.data_ptr())
+
+    def dgrad():
+        return native.blh_gemm_bf16s(st, a.data_ptr(), W, 0, w.data_ptr(), W, 1, z.data_ptr(), W, 1, M, W, W, 1,
+                                     None, None, 0, None)
+
+    def wgrad():
+        return native.blh_gemm_bf16s(st, a.data_ptr(), W, 1, z.data_ptr(), W, 1, slabs.data_ptr(), W, 0, W, W, M, 4,
+                                     None, None, 0, None)
+
+    for name, fn in (("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad)):
+        for _ in range(20):
+            assert fn() == 0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(100):
+            fn()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / 100
+        print("bf16s %s M=%d W=%d: %.1f us, %.0f TFLOP/s" % (name, M, W, ms * 1e3, 2.0 * M * W * W / ms / 1e9))
