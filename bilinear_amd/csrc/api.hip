@@ -507,18 +507,56 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
     //  be reading the one bn_bwd_apply(i) is about to write)
     if (two && dz_amax && i + 2 <= nh - 1)
       BLH_HIP_TRY(hipStreamWaitEvent(s, g_side.ev_w[i + 2], 0));
-    // stage 0 has no data gradient to overlap with: its weight gradient stays on the main stream
-    // (a fork + join there only adds two cross-queue latencies at the very end of backward)
+    // Schedule.  The weight gradient of stage i forks behind the DATA-gradient GEMM of stage i
+    // (not behind bn_bwd_apply(i), which would start both GEMMs together): it then runs next to
+    // the BatchNorm-backward kernels of stage i-1 — HBM-bound, leaving the matrix pipes idle —
+    // and next to the first part of dgrad(i-1), so that a stage costs the sum of its two GEMMs
+    // and nothing else (profiles/r02_step_timeline.md: started together, the two GEMMs split
+    // every CU 50/50, both end at the same time and the BatchNorm kernels run unaccompanied).
+    // Stage 0 has no data gradient: its weight gradient stays on the main stream (a fork + join
+    // there only adds two cross-queue latencies at the very end of backward) unless the
+    // data-parallel hook wants every range complete on the side stream.
     const bool side = two && (i > 0 || on_ready != nullptr);
     hipStream_t sw = side ? s2 : s;
-    if (side) arm_fork(i);
+    if (side && i == 0) arm_fork(i);
     BLH_TRY(launch_bn_bwd_apply(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W,
                                 params + h.gamma, dg, db, dzbuf,
                                 ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W, ds,
                                 norm_batch, dz_amax));
     tl_stop_event = nullptr;
-    if (side) BLH_TRY(fork_wait(i));
+    if (side && i == 0) BLH_TRY(fork_wait(i));
     // Linear: db = colsum(dZ); dW = dZ^T a_in; d a_in = dZ W
+    if (i > 0) {
+      GemmParams g{};
+      g.A = dzbuf; g.lda = W;
+      g.B = params + h.w; g.ldb = W;
+      g.M = (int)batch; g.N = W; g.K = W; g.k_per_split = W;
+      g.ldc = W;
+      if (dz_amax && ws.amax_W) {   // gemm_dtype 3
+        g.a_amax = dz_amax; g.a_namax = ws.amax_parts;
+        g.b_amax = ws.amax_W + (int64_t)i * WAMAX_PARTS; g.b_namax = WAMAX_PARTS;
+      }
+      const Splits ds2 = small_m_splits(batch, W, W);
+      float* dst = first_of_block ? ws.G0 : ws.G1;
+      if (ds2.splits > 1) {
+        g.C = ws.slabs; g.c_split_stride = batch * (int64_t)W; g.k_per_split = ds2.k_per;
+        BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, ds2.splits, d->gemm_dtype));
+        BLH_TRY(launch_sum_slabs_add(s, ws.slabs, batch * (int64_t)W, ds2.splits,
+                                     first_of_block ? ws.G0 : nullptr, dst));
+      } else {
+        if (side) arm_fork(i);
+        if (first_of_block) {
+          // d(block input) = dZ W + d(block output)   (skip path), in place in G0
+          g.C = ws.G0; g.addend = ws.G0; g.ldadd = W;
+          BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_ADD, g, 1, d->gemm_dtype));
+        } else {
+          g.C = ws.G1;
+          BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, 1, d->gemm_dtype));
+        }
+        tl_stop_event = nullptr;
+        if (side) BLH_TRY(fork_wait(i));
+      }
+    }
     // (data parallel: the bucket hook needs this stage's bias gradient now; otherwise all
     //  stages are reduced by one launch after the loop)
     if (on_ready)   // on the side stream (after the fork): nothing on the main stream waits for it
@@ -533,36 +571,11 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
                     defer ? ws.stage_slabs[0] : ws.slabs, grads + h.w, defer ? &wreg[0] : nullptr));
       if (side) BLH_TRY(wdone(0));
     } else {
-      BLH_TRY(wgrad(d->gemm_dtype, s2, TILE_128x128, dzbuf, W, W, ws.A[i - 1], W, W, batch,
+      BLH_TRY(wgrad(d->gemm_dtype, sw, TILE_128x128, dzbuf, W, W, ws.A[i - 1], W, W, batch,
                     ceil_div(W, 128) * ceil_div(W, 128), defer ? ws.stage_slabs[i] : ws.slabs,
                     grads + h.w, defer ? &wreg[i] : nullptr, dz_amax, ws.amax_A[i - 1],
                     ws.amax_parts));
       BLH_TRY(wdone(i));
-      GemmParams g{};
-      g.A = dzbuf; g.lda = W;
-      g.B = params + h.w; g.ldb = W;
-      g.M = (int)batch; g.N = W; g.K = W; g.k_per_split = W;
-      g.ldc = W;
-      if (dz_amax && ws.amax_W) {   // gemm_dtype 3
-        g.a_amax = dz_amax; g.a_namax = ws.amax_parts;
-        g.b_amax = ws.amax_W + (int64_t)i * WAMAX_PARTS; g.b_namax = WAMAX_PARTS;
-      }
-      const Splits ds2 = small_m_splits(batch, W, W);
-      float* dst = first_of_block ? ws.G0 : ws.G1;
-      g.prio = two ? 2 : 0;   // critical path: ahead of the side stream's weight-gradient GEMM
-      if (ds2.splits > 1) {
-        g.C = ws.slabs; g.c_split_stride = batch * (int64_t)W; g.k_per_split = ds2.k_per;
-        BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, ds2.splits, d->gemm_dtype));
-        BLH_TRY(launch_sum_slabs_add(s, ws.slabs, batch * (int64_t)W, ds2.splits,
-                                     first_of_block ? ws.G0 : nullptr, dst));
-      } else if (first_of_block) {
-        // d(block input) = dZ W + d(block output)   (skip path), in place in G0
-        g.C = ws.G0; g.addend = ws.G0; g.ldadd = W;
-        BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_ADD, g, 1, d->gemm_dtype));
-      } else {
-        g.C = ws.G1;
-        BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, 1, d->gemm_dtype));
-      }
     }
     if (on_ready) {
       const int64_t end = (i + 1 < nh) ? L.heavy[i + 1].w : L.dec_w;
@@ -634,13 +647,9 @@ int blh_context_create(blh_context** out) {
   };
   hipError_t e = hipGetDevice(&c->device);
   if (e != hipSuccess) return fail(e);
-  // The side stream carries the weight-gradient GEMMs, which nothing in backward waits for: it
-  // gets the LOWEST priority, so that the main stream's data-gradient GEMM (the critical path:
-  // the next stage's BatchNorm backward needs its output) takes the CUs first and the weight
-  // gradient fills what is left — including the main stream's event gaps.
-  int prio_least = 0, prio_greatest = 0;
-  if ((e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest)) != hipSuccess) return fail(e);
-  if ((e = hipStreamCreateWithPriority(&c->s2, hipStreamNonBlocking, prio_least)) != hipSuccess) return fail(e);
+  // (measured and not kept: a lowest-priority side stream, and s_setprio 2 in the data-gradient
+  //  GEMM: neither moves the 50/50 split of a CU's matrix pipes between two co-resident GEMMs)
+  if ((e = hipStreamCreateWithFlags(&c->s2, hipStreamNonBlocking)) != hipSuccess) return fail(e);
   for (int i = 0; i < BLH_CTX_EVENTS; ++i) {
     if ((e = hipEventCreateWithFlags(&c->ev_dz[i], hipEventDisableTiming)) != hipSuccess) return fail(e);
     if ((e = hipEventCreateWithFlags(&c->ev_w[i], hipEventDisableTiming)) != hipSuccess) return fail(e);

@@ -73,11 +73,6 @@ struct GemmParams {
   // gemm_dtype 3 (fp16 two-piece split): max |value| partials of each operand tensor
   const float* a_amax; int a_namax;
   const float* b_amax; int b_namax;
-  // Wave issue priority (s_setprio 0..3) of this launch.  Two GEMMs that share the chip from two
-  // streams also share every SIMD's matrix pipe; the one on the critical path (the data-gradient
-  // GEMM of the two-stream backward) runs at a higher priority so that it finishes at almost its
-  // stand-alone time while the other one (the weight gradient) fills the remaining issue slots.
-  int prio;
 };
 
 enum GemmTile : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_128x32 = 3 };
@@ -129,6 +124,26 @@ int launch_wamax(hipStream_t s, const float* W, int64_t w_stride, int layers, in
 int launch_bn_apply_train(hipStream_t s, const float* Z, const float* scale, const float* shift,
                           const float* skip, float* A, int64_t batch, int W,
                           const DropoutSrc& drop, int64_t* nbt, float* amax_part = nullptr);
+// gemm_dtype 4 (bf16 storage): the same kernels with bf16 [B,W] tensors.  Element types:
+enum ElemType : int { ET_F32 = 0, ET_BF16 = 1 };
+// (Z, skip, A) in {(f32,f32,f32), (bf16,bf16,bf16), (bf16,bf16,f32)}; train = batch statistics
+// + dropout, else running statistics (gamma .. running_var given, scale / shift null)
+int launch_bn_apply_t(hipStream_t s, bool train, const void* Z, int zt, const float* scale,
+                      const float* shift, const float* gamma, const float* beta,
+                      const float* running_mean, const float* running_var, const void* skip,
+                      int st, void* A, int at, int64_t batch, int W, const DropoutSrc& drop,
+                      int64_t* nbt);
+// (dA, Z) in {(f32,f32), (bf16,bf16)}
+int launch_bn_bwd_reduce_t(hipStream_t s, const void* dA, int gt, const void* Z, int zt,
+                           const float* scale, const float* shift, const float* mean,
+                           const float* invstd, float* part, int64_t batch, int W,
+                           const DropoutSrc& drop);
+// (dA, Z, dZ) in {(f32,f32,f32), (bf16,bf16,bf16), (bf16,bf16,f32)}
+int launch_bn_bwd_apply_t(hipStream_t s, const void* dA, int gt, const void* Z, int zt,
+                          const float* scale, const float* shift, const float* mean,
+                          const float* invstd, const float* dgamma, const float* dbeta, void* dZ,
+                          int dt, float* dz_colsum_part, int64_t batch, int W,
+                          const DropoutSrc& drop, int64_t norm_batch);
 // eval: scale/shift from running stats, no dropout
 int launch_bn_apply_eval(hipStream_t s, const float* Z, const float* gamma, const float* beta,
                          const float* running_mean, const float* running_var,

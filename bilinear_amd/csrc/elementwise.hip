@@ -23,6 +23,30 @@ int ew_num_row_chunks(int64_t batch) { return (int)ceil_div(batch, ew_row_chunk(
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// 4 consecutive elements of a [B,W] tensor stored as bf16 (gemm_dtype 4): 8 bytes per lane
+typedef uint16_t bf16_bits;
+__device__ __forceinline__ float4 ld4(const bf16_bits* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                     __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  bf2 b;
+  b[0] = (__bf16)lo; b[1] = (__bf16)hi;          // v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
+  return *reinterpret_cast<const uint32_t*>(&b);
+}
+__device__ __forceinline__ void st4(bf16_bits* p, float4 v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+}
+// what a consumer of the stored tensor will read back (identity for fp32 storage)
+__device__ __forceinline__ float4 as_stored(const float*, float4 v) { return v; }
+__device__ __forceinline__ float4 as_stored(const bf16_bits*, float4 v) {
+  const uint32_t a = pack_bf16x2(v.x, v.y), b = pack_bf16x2(v.z, v.w);
+  return make_float4(__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u),
+                     __uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u));
+}
+
 // max |v| over the FINITE values of a float4, folded into m.  Inf / NaN elements do not take
 // part: the fp16-split GEMM derives its power-of-two scale from this maximum, and one overflowed
 // element must not push every finite value of the tensor out of fp16's range (the non-finite
@@ -224,12 +248,12 @@ __device__ __forceinline__ float4 dropout_relu_bwd(float4 g, float4 z, float4 sc
 // ---------------------------------------------------------------------------
 // A = dropout(relu(Z*scale + shift)) (+ skip)
 // ---------------------------------------------------------------------------
-template <bool TRAIN>
+template <bool TRAIN, typename TZ = float, typename TS = float, typename TA = float>
 __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(
-    const float* __restrict__ Z, const float* __restrict__ scale, const float* __restrict__ shift,
+    const TZ* __restrict__ Z, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ running_mean, const float* __restrict__ running_var,
-    const float* __restrict__ skip, float* __restrict__ A, int64_t batch, int W, int row_chunk,
+    const TS* __restrict__ skip, TA* __restrict__ A, int64_t batch, int W, int row_chunk,
     DropoutSrc drop, int64_t* nbt, float* __restrict__ amax_part) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col = blockIdx.x * EW_COLS_PER_BLOCK + lane * 4;
@@ -291,7 +315,7 @@ int ew_num_amax_parts(int64_t batch, int W) {
 int launch_bn_apply_train(hipStream_t s, const float* Z, const float* scale, const float* shift,
                           const float* skip, float* A, int64_t batch, int W,
                           const DropoutSrc& drop, int64_t* nbt, float* amax_part) {
-  hipLaunchKernelGGL(bn_apply_kernel<true>, ew_grid(batch, W), dim3(EW_THREADS), 0, s, Z, scale,
+  hipLaunchKernelGGL((bn_apply_kernel<true, float, float, float>), ew_grid(batch, W), dim3(EW_THREADS), 0, s, Z, scale,
                      shift, nullptr, nullptr, nullptr, nullptr, skip, A, batch, W,
                      ew_row_chunk(batch), drop, nbt, amax_part);
   BLH_HIP_TRY(hipGetLastError());
@@ -302,9 +326,34 @@ int launch_bn_apply_eval(hipStream_t s, const float* Z, const float* gamma, cons
                          const float* running_mean, const float* running_var, const float* skip,
                          float* A, int64_t batch, int W, float* amax_part) {
   DropoutSrc none{nullptr, 0, 0, 0, 0, nullptr};
-  hipLaunchKernelGGL(bn_apply_kernel<false>, ew_grid(batch, W), dim3(EW_THREADS), 0, s, Z,
+  hipLaunchKernelGGL((bn_apply_kernel<false, float, float, float>), ew_grid(batch, W), dim3(EW_THREADS), 0, s, Z,
                      nullptr, nullptr, gamma, beta, running_mean, running_var, skip, A, batch, W,
                      ew_row_chunk(batch), none, nullptr, amax_part);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+int launch_bn_apply_t(hipStream_t s, bool train, const void* Z, int zt, const float* scale,
+                      const float* shift, const float* gamma, const float* beta,
+                      const float* running_mean, const float* running_var, const void* skip,
+                      int st, void* A, int at, int64_t batch, int W, const DropoutSrc& drop,
+                      int64_t* nbt) {
+  const dim3 grid = ew_grid(batch, W), block(EW_THREADS);
+  const int rc = ew_row_chunk(batch);
+#define BLH_APPLY(TRAIN_, TZ_, TS_, TA_)                                                            \
+  hipLaunchKernelGGL((bn_apply_kernel<TRAIN_, TZ_, TS_, TA_>), grid, block, 0, s, (const TZ_*)Z, scale, \
+                     shift, gamma, beta, running_mean, running_var, (const TS_*)skip, (TA_*)A, batch, \
+                     W, rc, drop, nbt, (float*)nullptr)
+  if (zt == ET_F32 && at == ET_F32 && (skip == nullptr || st == ET_F32)) {
+    if (train) BLH_APPLY(true, float, float, float); else BLH_APPLY(false, float, float, float);
+  } else if (zt == ET_BF16 && at == ET_BF16 && (skip == nullptr || st == ET_BF16)) {
+    if (train) BLH_APPLY(true, bf16_bits, bf16_bits, bf16_bits); else BLH_APPLY(false, bf16_bits, bf16_bits, bf16_bits);
+  } else if (zt == ET_BF16 && at == ET_F32 && (skip == nullptr || st == ET_BF16)) {
+    if (train) BLH_APPLY(true, bf16_bits, bf16_bits, float); else BLH_APPLY(false, bf16_bits, bf16_bits, float);
+  } else {
+    return BLH_ERR_INVALID_ARGUMENT;
+  }
+#undef BLH_APPLY
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
@@ -324,8 +373,9 @@ __device__ __forceinline__ void block_colsum_store(float4 v, float* red, float* 
 // backward pass 1: dY = dA * 2*keep * [y>0]; per-chunk column sums of dY*zhat, dY
 // part layout [chunk][2][W]: row 0 -> dgamma partial, row 1 -> dbeta partial
 // ---------------------------------------------------------------------------
+template <typename TG = float, typename TZ = float>
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
-    const float* __restrict__ dA, const float* __restrict__ Z, const float* __restrict__ scale,
+    const TG* __restrict__ dA, const TZ* __restrict__ Z, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ invstd, float* __restrict__ part, int64_t batch, int W,
     int row_chunk, DropoutSrc drop) {
@@ -365,8 +415,23 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
 int launch_bn_bwd_reduce(hipStream_t s, const float* dA, const float* Z, const float* scale,
                          const float* shift, const float* mean, const float* invstd, float* part,
                          int64_t batch, int W, const DropoutSrc& drop) {
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, ew_grid(batch, W), dim3(EW_THREADS), 0, s, dA, Z,
-                     scale, shift, mean, invstd, part, batch, W, ew_row_chunk(batch), drop);
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float>), ew_grid(batch, W), dim3(EW_THREADS), 0,
+                     s, dA, Z, scale, shift, mean, invstd, part, batch, W, ew_row_chunk(batch), drop);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+int launch_bn_bwd_reduce_t(hipStream_t s, const void* dA, int gt, const void* Z, int zt,
+                           const float* scale, const float* shift, const float* mean,
+                           const float* invstd, float* part, int64_t batch, int W,
+                           const DropoutSrc& drop) {
+  if (gt == ET_F32 && zt == ET_F32)
+    return launch_bn_bwd_reduce(s, (const float*)dA, (const float*)Z, scale, shift, mean, invstd, part,
+                                batch, W, drop);
+  if (gt != ET_BF16 || zt != ET_BF16) return BLH_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_bits, bf16_bits>), ew_grid(batch, W), dim3(EW_THREADS),
+                     0, s, (const bf16_bits*)dA, (const bf16_bits*)Z, scale, shift, mean, invstd, part,
+                     batch, W, ew_row_chunk(batch), drop);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
@@ -454,11 +519,12 @@ int launch_bn_bwd_finalize(hipStream_t s, const float* part, int chunks, int W, 
 // backward pass 2: dZ = gamma*invstd*(dY - dbeta/B - zhat*dgamma/B)
 // plus per-chunk column sums of dZ (the Linear bias gradient)
 // ---------------------------------------------------------------------------
+template <typename TG = float, typename TZ = float, typename TD = float>
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
-    const float* __restrict__ dA, const float* __restrict__ Z, const float* __restrict__ scale,
+    const TG* __restrict__ dA, const TZ* __restrict__ Z, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ dgamma,
-    const float* __restrict__ dbeta, float* __restrict__ dZ, float* __restrict__ colsum_part,
+    const float* __restrict__ dbeta, TD* __restrict__ dZ, float* __restrict__ colsum_part,
     int64_t batch, int W, int row_chunk, DropoutSrc drop, int64_t norm_batch,
     float* __restrict__ amax_part) {
   __shared__ __attribute__((aligned(16))) float red[4 * 256];
@@ -497,6 +563,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
         o.z = sc.z * (dy.z - c1.z - ((z[i].z - mu.z) * is.z) * c2.z);
         o.w = sc.w * (dy.w - c1.w - ((z[i].w - mu.w) * is.w) * c2.w);
         if (r < batch) {
+          o = as_stored(dZ, o);     // the Linear-bias gradient sums what the wgrad GEMM will read
           cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
           st4(dZ + r * W + col, o);
           am = amax4(am, o);
@@ -513,9 +580,33 @@ int launch_bn_bwd_apply(hipStream_t s, const float* dA, const float* Z, const fl
                         float* dz_colsum_part, int64_t batch, int W, const DropoutSrc& drop,
                         int64_t norm_batch, float* amax_part) {
   (void)gamma;
-  launch_kernel(bn_bwd_apply_kernel, ew_grid(batch, W), dim3(EW_THREADS), 0, s, dA, Z, scale,
+  launch_kernel(bn_bwd_apply_kernel<float, float, float>, ew_grid(batch, W), dim3(EW_THREADS), 0, s, dA, Z, scale,
                      shift, mean, invstd, dgamma, dbeta, dZ, dz_colsum_part, batch, W,
                      ew_row_chunk(batch), drop, norm_batch, amax_part);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+int launch_bn_bwd_apply_t(hipStream_t s, const void* dA, int gt, const void* Z, int zt,
+                          const float* scale, const float* shift, const float* mean,
+                          const float* invstd, const float* dgamma, const float* dbeta, void* dZ,
+                          int dt, float* dz_colsum_part, int64_t batch, int W,
+                          const DropoutSrc& drop, int64_t norm_batch) {
+  if (gt == ET_F32 && zt == ET_F32 && dt == ET_F32)
+    return launch_bn_bwd_apply(s, (const float*)dA, (const float*)Z, scale, shift, mean, invstd, nullptr,
+                               dgamma, dbeta, (float*)dZ, dz_colsum_part, batch, W, drop, norm_batch);
+  if (gt != ET_BF16 || zt != ET_BF16) return BLH_ERR_INVALID_ARGUMENT;
+  const dim3 grid = ew_grid(batch, W), block(EW_THREADS);
+  if (dt == ET_BF16)
+    launch_kernel(bn_bwd_apply_kernel<bf16_bits, bf16_bits, bf16_bits>, grid, block, 0, s,
+                  (const bf16_bits*)dA, (const bf16_bits*)Z, scale, shift, mean, invstd, dgamma, dbeta,
+                  (bf16_bits*)dZ, dz_colsum_part, batch, W, ew_row_chunk(batch), drop, norm_batch,
+                  (float*)nullptr);
+  else
+    launch_kernel(bn_bwd_apply_kernel<bf16_bits, bf16_bits, float>, grid, block, 0, s,
+                  (const bf16_bits*)dA, (const bf16_bits*)Z, scale, shift, mean, invstd, dgamma, dbeta,
+                  (float*)dZ, dz_colsum_part, batch, W, ew_row_chunk(batch), drop, norm_batch,
+                  (float*)nullptr);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }

@@ -168,9 +168,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_ring_kernel(GemmParams 
   unsigned long long stamp_entry = 0, stamp_c0 = 0, stamp_r0 = 0;
   if (STAMP) stamp_entry = __builtin_amdgcn_s_memrealtime();
 
-  if (p.prio >= 2) __builtin_amdgcn_s_setprio(2);          // (the operand is an immediate)
-  else if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (p.N + BN - 1) / BN;
