@@ -43,7 +43,7 @@ static int check_desc(const blh_model_desc* d) {
     return BLH_ERR_SHAPE;
   if (d->out_features > 64) return BLH_ERR_SHAPE;   // decode uses one 64-wide column tile
   if (1 + 2 * d->num_blocks > 32) return BLH_ERR_SHAPE;
-  if (d->gemm_dtype < 0 || d->gemm_dtype > 3) return BLH_ERR_INVALID_ARGUMENT;
+  if (d->gemm_dtype < 0 || d->gemm_dtype > 4) return BLH_ERR_INVALID_ARGUMENT;
   return BLH_OK;
 }
 
@@ -507,24 +507,26 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
     //  be reading the one bn_bwd_apply(i) is about to write)
     if (two && dz_amax && i + 2 <= nh - 1)
       BLH_HIP_TRY(hipStreamWaitEvent(s, g_side.ev_w[i + 2], 0));
-    // Schedule.  The weight gradient of stage i forks behind the DATA-gradient GEMM of stage i
-    // (not behind bn_bwd_apply(i), which would start both GEMMs together): it then runs next to
-    // the BatchNorm-backward kernels of stage i-1 — HBM-bound, leaving the matrix pipes idle —
-    // and next to the first part of dgrad(i-1), so that a stage costs the sum of its two GEMMs
-    // and nothing else (profiles/r02_step_timeline.md: started together, the two GEMMs split
-    // every CU 50/50, both end at the same time and the BatchNorm kernels run unaccompanied).
+    // Schedule.  The weight gradient of stage i forks behind bn_bwd_apply(i): it starts together
+    // with the data-gradient GEMM of the stage (two workgroups per CU, the pair costs 127 us
+    // against 134 us one after the other) and its tail covers the BatchNorm-backward kernels of
+    // stage i-1.  Measured and not kept (profiles/r02_step_timeline.md): forking behind the
+    // data-gradient GEMM instead, so that the weight gradient runs next to the HBM-bound
+    // BatchNorm kernels — beside a GEMM that owns every CU's matrix pipe bn_bwd_apply takes
+    // 60 us instead of 10 (its Philox / BN arithmetic loses the vector issue slots), and the step
+    // comes out at 1.107 ms against 1.095 ms.
     // Stage 0 has no data gradient: its weight gradient stays on the main stream (a fork + join
     // there only adds two cross-queue latencies at the very end of backward) unless the
     // data-parallel hook wants every range complete on the side stream.
     const bool side = two && (i > 0 || on_ready != nullptr);
     hipStream_t sw = side ? s2 : s;
-    if (side && i == 0) arm_fork(i);
+    if (side) arm_fork(i);
     BLH_TRY(launch_bn_bwd_apply(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W,
                                 params + h.gamma, dg, db, dzbuf,
                                 ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W, ds,
                                 norm_batch, dz_amax));
     tl_stop_event = nullptr;
-    if (side && i == 0) BLH_TRY(fork_wait(i));
+    if (side) BLH_TRY(fork_wait(i));
     // Linear: db = colsum(dZ); dW = dZ^T a_in; d a_in = dZ W
     if (i > 0) {
       GemmParams g{};
@@ -544,7 +546,6 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
         BLH_TRY(launch_sum_slabs_add(s, ws.slabs, batch * (int64_t)W, ds2.splits,
                                      first_of_block ? ws.G0 : nullptr, dst));
       } else {
-        if (side) arm_fork(i);
         if (first_of_block) {
           // d(block input) = dZ W + d(block output)   (skip path), in place in G0
           g.C = ws.G0; g.addend = ws.G0; g.ldadd = W;
@@ -553,8 +554,6 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
           g.C = ws.G1;
           BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, 1, d->gemm_dtype));
         }
-        tl_stop_event = nullptr;
-        if (side) BLH_TRY(fork_wait(i));
       }
     }
     // (data parallel: the bucket hook needs this stage's bias gradient now; otherwise all
@@ -609,6 +608,205 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
     push(L.dec_w + (int64_t)OF * W, L.total, nullptr);
     BLH_TRY(launch_grads_finish(s, grads, R, L.total / 4, fused ? fused->sumsq_part : nullptr,
                                 fused ? fused->sumsq_nparts : nullptr));
+  }
+  return BLH_OK;
+}
+
+
+// =================================================================================================
+// gemm_dtype 4 — "bf16s": bf16 storage (BASELINE configs 3-5).  Every [B,W] tensor (pre-BN output
+// Z, activation A, gradients G / dZ), the network input and a shadow of all parameters are bf16
+// in HBM; every contraction runs on gemm_bf16s_kernel.h (bf16 MFMA, fp32 accumulate, operands fed
+// by LDS-DMA without any conversion); BatchNorm statistics (from the fp32 accumulators, before
+// rounding), the parameters, their gradients (fp32 slabs of the weight-gradient GEMM), Adam and
+// the loss stay fp32.  Gradients need no loss scaling: bf16 keeps fp32's exponent range.
+// =================================================================================================
+struct WorkspaceH {
+  uint16_t* wsh;                    // bf16 image of the whole parameter arena (refreshed per forward)
+  uint16_t* xh;                     // [B][in] network input
+  std::vector<uint16_t*> Z, A, dZ;  // per heavy stage, [B][W]
+  std::vector<float*> bn_saved;     // per heavy stage [4][W]
+  uint16_t* G0; uint16_t* G1;
+  float* stat_part; float* bn_part; float* dz_colsum_part; float* slabs;
+  float* dpred; uint16_t* dpredh;   // [B][out] fp32 and its bf16 image
+  float* loss_part; double* sumsq_part; float* colsum_part;
+  int64_t bytes;
+};
+
+static int64_t slab_floats_h(const blh_model_desc* d, int64_t batch) {
+  const int64_t W = d->width;
+  const Splits hs = pick_splits(batch, ceil_div(W, 128) * ceil_div(W, 128));
+  const Splits es = pick_splits(batch, ceil_div(W, 128));
+  int64_t m = hs.splits * W * W;
+  m = std::max(m, es.splits * W * (int64_t)d->in_features);
+  m = std::max(m, es.splits * (int64_t)d->out_features * W);
+  return m;
+}
+
+static WorkspaceH carve_h(const blh_model_desc* d, int64_t batch, void* base) {
+  WorkspaceH ws;
+  const int nh = 1 + 2 * d->num_blocks;
+  const int64_t W = d->width;
+  char* p = (char*)base;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) {
+    char* r = p ? p + off : nullptr;
+    off += round_up(bytes, WS_ALIGN);
+    return r;
+  };
+  const int64_t act = batch * W * 2;
+  ws.wsh = (uint16_t*)take(make_layout(d).total * 2);
+  ws.xh = (uint16_t*)take(batch * d->in_features * 2);
+  for (int i = 0; i < nh; ++i) ws.Z.push_back((uint16_t*)take(act));
+  for (int i = 0; i < nh; ++i) ws.A.push_back((uint16_t*)take(act));
+  for (int i = 0; i < nh; ++i) ws.dZ.push_back((uint16_t*)take(act));
+  for (int i = 0; i < nh; ++i) ws.bn_saved.push_back((float*)take(4 * W * sizeof(float)));
+  ws.G0 = (uint16_t*)take(act);
+  ws.G1 = (uint16_t*)take(act);
+  ws.stat_part = (float*)take(ceil_div(batch, 64) * 2 * W * sizeof(float));
+  const int64_t chunks = ew_num_row_chunks(batch);
+  ws.bn_part = (float*)take(chunks * 2 * W * sizeof(float));
+  ws.dz_colsum_part = (float*)take((int64_t)nh * chunks * W * sizeof(float));
+  ws.slabs = (float*)take(slab_floats_h(d, batch) * sizeof(float));
+  ws.dpred = (float*)take(batch * d->out_features * sizeof(float));
+  ws.dpredh = (uint16_t*)take(batch * d->out_features * 2);
+  ws.loss_part = (float*)take(4096 * sizeof(float));
+  ws.sumsq_part = (double*)take(SUMSQ_MAX_PARTS * sizeof(double));
+  ws.colsum_part = (float*)take(ceil_div(batch, 256) * d->out_features * sizeof(float));
+  ws.bytes = off;
+  return ws;
+}
+
+static int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
+                     float* bn_running, int64_t* nbt, const float* x, const blh_dropout* drop,
+                     float momentum, const WorkspaceH& ws, float* pred, int64_t batch, bool train) {
+  if (ctx->sync.fn) return BLH_ERR_INVALID_ARGUMENT;   // SyncBN is not built for bf16 storage
+  const ArenaLayout L = make_layout(d);
+  const int nh = (int)L.heavy.size();
+  const int W = d->width, OF = d->out_features, IF = d->in_features;
+  const int tiles_m = (int)ceil_div(batch, 128);
+  // bf16 images of the parameters (the GEMMs read the weights from it) and of the input
+  BLH_TRY(launch_cast_f32_bf16(s, params, ws.wsh, L.total));
+  BLH_TRY(launch_cast_f32_bf16(s, x, ws.xh, batch * IF));
+  for (int i = 0; i < nh; ++i) {
+    const HeavyOffsets& h = L.heavy[i];
+    GemmParamsH g{};
+    g.A = (i == 0) ? ws.xh : ws.A[i - 1]; g.lda = h.fan_in;
+    g.B = ws.wsh + h.w; g.ldb = h.fan_in;
+    g.C = ws.Z[i]; g.ldc = W;
+    g.M = (int)batch; g.N = W; g.K = h.fan_in; g.k_per_split = h.fan_in;
+    g.bias = params + h.b; g.stat_part = ws.stat_part;
+    BLH_TRY(launch_gemm_bf16s(s, ROWK, ROWK, train ? EPI_BIAS_STATS : EPI_BIAS, true, g, 1));
+    const uint16_t* skip = (i >= 2 && (i % 2) == 0) ? ws.A[i - 2] : nullptr;
+    float* rm = bn_running + ((int64_t)i * 2 + 0) * W;
+    float* rv = bn_running + ((int64_t)i * 2 + 1) * W;
+    if (train) {
+      float* sv = ws.bn_saved[i];
+      BLH_TRY(launch_bn_fwd_finalize(s, ws.stat_part, tiles_m, 128, batch, W, params + h.gamma,
+                                     params + h.beta, rm, rv, nbt + i, momentum, sv, sv + W,
+                                     sv + 2 * W, sv + 3 * W));
+      BLH_TRY(launch_bn_apply_t(s, true, ws.Z[i], ET_BF16, sv + 2 * W, sv + 3 * W, nullptr, nullptr,
+                                nullptr, nullptr, skip, ET_BF16, ws.A[i], ET_BF16, batch, W,
+                                layer_drop(ctx, drop, i, batch, W), nbt + i));
+    } else {
+      DropoutSrc none{nullptr, 0, 0, 0, 0, nullptr};
+      BLH_TRY(launch_bn_apply_t(s, false, ws.Z[i], ET_BF16, nullptr, nullptr, params + h.gamma,
+                                params + h.beta, rm, rv, skip, ET_BF16, ws.A[i], ET_BF16, batch, W,
+                                none, nullptr));
+    }
+  }
+  // decode (model/bilinear.py:39): N = 48 is one (ragged) column tile of the same kernel
+  GemmParamsH g{};
+  g.A = ws.A[nh - 1]; g.lda = W;
+  g.B = ws.wsh + L.dec_w; g.ldb = W;
+  g.C = pred; g.ldc = OF;
+  g.M = (int)batch; g.N = OF; g.K = W; g.k_per_split = W;
+  g.bias = params + L.dec_b;
+  return launch_gemm_bf16s(s, ROWK, ROWK, EPI_BIAS, false, g, 1);
+}
+
+// dW = dZ^T act (both bf16, reduction over the batch split into fp32 slabs), summed into `out`
+static int wgrad_h(hipStream_t s, const uint16_t* dZ, int64_t ld_dz, int M, const uint16_t* act,
+                   int64_t ld_act, int N, int64_t batch, float* slabs, float* out) {
+  const Splits sp = pick_splits(batch, ceil_div(M, 128) * ceil_div(N, 128));
+  GemmParamsH g{};
+  g.A = dZ; g.lda = ld_dz; g.B = act; g.ldb = ld_act;
+  g.M = M; g.N = N; g.K = (int)batch; g.k_per_split = sp.k_per; g.ldc = N;
+  if (sp.splits == 1) {
+    g.C = out;
+    return launch_gemm_bf16s(s, KROW, KROW, EPI_STORE, false, g, 1);
+  }
+  g.C = slabs; g.c_split_stride = (int64_t)M * N;
+  BLH_TRY(launch_gemm_bf16s(s, KROW, KROW, EPI_STORE, false, g, sp.splits));
+  return launch_sum_slabs(s, slabs, (int64_t)M * N, sp.splits, out);
+}
+
+static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
+                      const blh_dropout* drop, const WorkspaceH& ws, const float* dpred,
+                      float* grads, int64_t batch, blh_grad_ready_fn on_ready, void* user) {
+  if (ctx->sync.fn) return BLH_ERR_INVALID_ARGUMENT;
+  const ArenaLayout L = make_layout(d);
+  const int nh = (int)L.heavy.size();
+  const int W = d->width, OF = d->out_features, IF = d->in_features;
+  const int chunks = ew_num_row_chunks(batch);
+  // single stream: a reported range is complete on `s`; a two-stream context promised "complete
+  // on the side stream", so that one is made to wait
+  auto ready = [&](int idx, int64_t off, int64_t cnt) -> int {
+    if (!on_ready) return BLH_OK;
+    if (ctx->two_stream) {
+      BLH_HIP_TRY(hipEventRecord(ctx->ev_r[idx], s));
+      BLH_HIP_TRY(hipStreamWaitEvent(ctx->s2, ctx->ev_r[idx], 0));
+    }
+    on_ready(user, off, cnt);
+    return BLH_OK;
+  };
+  // decode: dW = dP^T A_last, db = colsum(dP), dA_last = dP W_d
+  BLH_TRY(launch_cast_f32_bf16(s, dpred, ws.dpredh, batch * OF));
+  BLH_TRY(wgrad_h(s, ws.dpredh, OF, OF, ws.A[nh - 1], W, W, batch, ws.slabs, grads + L.dec_w));
+  BLH_TRY(launch_colsum(s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
+  BLH_TRY(ready(nh, L.dec_w, L.total - L.dec_w));
+  {
+    GemmParamsH g{};
+    g.A = ws.dpredh; g.lda = OF;
+    g.B = ws.wsh + L.dec_w; g.ldb = W;
+    g.C = ws.G0; g.ldc = W;
+    g.M = (int)batch; g.N = W; g.K = OF; g.k_per_split = OF;
+    BLH_TRY(launch_gemm_bf16s(s, ROWK, KROW, EPI_STORE, true, g, 1));
+  }
+  for (int i = nh - 1; i >= 0; --i) {
+    const HeavyOffsets& h = L.heavy[i];
+    const bool first_of_block = (i >= 1) && (i % 2 == 1);
+    const uint16_t* dA = first_of_block ? ws.G1 : ws.G0;
+    const float* sv = ws.bn_saved[i];
+    const DropoutSrc ds = layer_drop(ctx, drop, i, batch, W);
+    BLH_TRY(launch_bn_bwd_reduce_t(s, dA, ET_BF16, ws.Z[i], ET_BF16, sv + 2 * W, sv + 3 * W, sv,
+                                   sv + W, ws.bn_part, batch, W, ds));
+    BLH_TRY(launch_bn_bwd_finalize(s, ws.bn_part, chunks, W, grads + h.gamma, grads + h.beta));
+    BLH_TRY(launch_bn_bwd_apply_t(s, dA, ET_BF16, ws.Z[i], ET_BF16, sv + 2 * W, sv + 3 * W, sv,
+                                  sv + W, grads + h.gamma, grads + h.beta, ws.dZ[i], ET_BF16,
+                                  ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W, ds, batch));
+    BLH_TRY(launch_colreduce(s, ws.dz_colsum_part + (int64_t)i * chunks * W, chunks, W, W,
+                             grads + h.b));
+    if (i > 0) {
+      GemmParamsH g{};
+      g.A = ws.dZ[i]; g.lda = W;
+      g.B = ws.wsh + h.w; g.ldb = W;
+      g.M = (int)batch; g.N = W; g.K = W; g.k_per_split = W; g.ldc = W;
+      if (first_of_block) {   // d(block input) = dZ W + d(block output), in place in G0
+        g.C = ws.G0; g.addend = ws.G0; g.ldadd = W;
+        BLH_TRY(launch_gemm_bf16s(s, ROWK, KROW, EPI_ADD, true, g, 1));
+      } else {
+        g.C = ws.G1;
+        BLH_TRY(launch_gemm_bf16s(s, ROWK, KROW, EPI_STORE, true, g, 1));
+      }
+      BLH_TRY(wgrad_h(s, ws.dZ[i], W, W, ws.A[i - 1], W, W, batch, ws.slabs, grads + h.w));
+    } else {
+      BLH_TRY(wgrad_h(s, ws.dZ[0], W, W, ws.xh, IF, IF, batch, ws.slabs, grads + h.w));
+    }
+    if (on_ready) {
+      const int64_t end = (i + 1 < nh) ? L.heavy[i + 1].w : L.dec_w;
+      BLH_TRY(ready(i, h.w, end - h.w));
+    }
   }
   return BLH_OK;
 }
@@ -730,7 +928,7 @@ int64_t blh_bn_running_floats(const blh_model_desc* d) {
 int64_t blh_workspace_bytes(const blh_model_desc* d, int64_t batch) {
   if (check_desc(d) != BLH_OK) return check_desc(d);
   if (batch <= 0) return BLH_ERR_INVALID_ARGUMENT;
-  return carve(d, batch, nullptr).bytes;
+  return d->gemm_dtype == 4 ? carve_h(d, batch, nullptr).bytes : carve(d, batch, nullptr).bytes;
 }
 
 static int check_common(const blh_context* ctx, const blh_model_desc* d, const void* ws,
@@ -739,7 +937,10 @@ static int check_common(const blh_context* ctx, const blh_model_desc* d, const v
   BLH_TRY(check_desc(d));
   if (batch <= 0 || batch > (1 << 30)) return BLH_ERR_INVALID_ARGUMENT;
   if (!ws || ((uintptr_t)ws % WS_ALIGN) != 0) return BLH_ERR_INVALID_ARGUMENT;
-  if (ws_bytes < carve(d, batch, nullptr).bytes) return BLH_ERR_WORKSPACE;
+  const int64_t need = d->gemm_dtype == 4 ? carve_h(d, batch, nullptr).bytes : carve(d, batch, nullptr).bytes;
+  if (ws_bytes < need) return BLH_ERR_WORKSPACE;
+  if (d->gemm_dtype == 4 && (d->width % 128 != 0 || d->in_features % 8 != 0 || d->out_features % 8 != 0))
+    return BLH_ERR_SHAPE;
   return BLH_OK;
 }
 
@@ -757,6 +958,9 @@ int blh_forward_train(blh_context* ctx, const blh_model_desc* d, void* stream, c
   BLH_TRY(check_drop(drop));
   if (!params || !bn_running || !bn_nbt || !x || !pred) return BLH_ERR_INVALID_ARGUMENT;
   if (batch < 2) return BLH_ERR_SHAPE;   // BatchNorm1d needs > 1 value per channel in training
+  if (d->gemm_dtype == 4)
+    return forward_h(ctx, d, (hipStream_t)stream, params, bn_running, bn_nbt, x, drop, momentum,
+                     carve_h(d, batch, workspace), pred, batch, true);
   const Workspace ws = carve(d, batch, workspace);
   return forward_impl(ctx, d, (hipStream_t)stream, params, bn_running, bn_nbt, x, drop, momentum, ws,
                       pred, batch, true, nullptr, 0.f, nullptr, nullptr);
@@ -767,8 +971,11 @@ int blh_forward_eval(blh_context* ctx, const blh_model_desc* d, void* stream, co
                      int64_t workspace_bytes, float* pred, int64_t batch) {
   BLH_TRY(check_common(ctx, d, workspace, workspace_bytes, batch));
   if (!params || !bn_running || !x || !pred) return BLH_ERR_INVALID_ARGUMENT;
-  const Workspace ws = carve(d, batch, workspace);
   blh_dropout none{nullptr, 0, 0, 0, 0, 0};
+  if (d->gemm_dtype == 4)
+    return forward_h(ctx, d, (hipStream_t)stream, params, const_cast<float*>(bn_running), nullptr, x,
+                     &none, 0.f, carve_h(d, batch, workspace), pred, batch, false);
+  const Workspace ws = carve(d, batch, workspace);
   return forward_impl(ctx, d, (hipStream_t)stream, params, const_cast<float*>(bn_running), nullptr, x,
                       &none, 0.f, ws, pred, batch, false, nullptr, 0.f, nullptr, nullptr);
 }
@@ -795,6 +1002,9 @@ int blh_backward(blh_context* ctx, const blh_model_desc* d, void* stream, const 
   BLH_TRY(check_common(ctx, d, workspace, workspace_bytes, batch));
   BLH_TRY(check_drop(drop));
   if (!params || !x || !dpred || !grads) return BLH_ERR_INVALID_ARGUMENT;
+  if (d->gemm_dtype == 4)
+    return backward_h(ctx, d, (hipStream_t)stream, params, drop, carve_h(d, batch, workspace), dpred,
+                      grads, batch, on_ready, user);
   const Workspace ws = carve(d, batch, workspace);
   return backward_impl(ctx, d, (hipStream_t)stream, params, x, drop, ws, dpred, grads, batch,
                        on_ready, user);
@@ -836,9 +1046,21 @@ int blh_train_step(blh_context* ctx, const blh_model_desc* d, void* stream, floa
     return BLH_ERR_INVALID_ARGUMENT;
   if (batch < 2) return BLH_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  const Workspace ws = carve(d, batch, workspace);
   const double denom = (double)batch * d->out_features;
   int nparts = 0;
+  if (d->gemm_dtype == 4) {   // bf16 storage: forward, MSE, backward, norm, clip + Adam
+    const WorkspaceH wh = carve_h(d, batch, workspace);
+    const int64_t count = make_layout(d).total;
+    int np = 0;
+    BLH_TRY(forward_h(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, wh, pred, batch, true));
+    BLH_TRY(launch_mse(s, pred, target, batch * d->out_features, (float)(2.0 / denom), wh.dpred,
+                       wh.loss_part, &nparts));
+    BLH_TRY(backward_h(ctx, d, s, params, drop, wh, wh.dpred, grads, batch, nullptr, nullptr));
+    BLH_TRY(launch_sumsq(s, grads, count, wh.sumsq_part, &np));
+    return launch_clip_adam(s, params, grads, exp_avg, exp_avg_sq, count, *hyper, wh.sumsq_part, np,
+                            stats_out, LossFinish{wh.loss_part, nparts, denom, loss_out});
+  }
+  const Workspace ws = carve(d, batch, workspace);
   BLH_TRY(forward_impl(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
                        target, (float)(2.0 / denom), ws.loss_part, &nparts));
   int np = 0;
@@ -1016,7 +1238,6 @@ int blh_train_step_captured(blh_context* ctx, const blh_model_desc* d, void* str
     return BLH_ERR_INVALID_ARGUMENT;
   if (batch < 2) return BLH_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  const Workspace ws = carve(d, batch, workspace);
   const double denom = (double)batch * d->out_features;
   int nparts = 0, np = 0;
   BLH_TRY(launch_step_state_advance(s, dev_state));
@@ -1025,6 +1246,19 @@ int blh_train_step_captured(blh_context* ctx, const blh_model_desc* d, void* str
     StepDevGuard(blh_context* c_, const uint64_t* p) : c(c_) { c->step_dev = p; }
     ~StepDevGuard() { c->step_dev = nullptr; }
   } guard(ctx, &dev_state->rng_step);
+  if (d->gemm_dtype == 4) {
+    const WorkspaceH wh = carve_h(d, batch, workspace);
+    const int64_t count = make_layout(d).total;
+    BLH_TRY(forward_h(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, wh, pred, batch, true));
+    BLH_TRY(launch_mse(s, pred, target, batch * d->out_features, (float)(2.0 / denom), wh.dpred,
+                       wh.loss_part, &nparts));
+    BLH_TRY(backward_h(ctx, d, s, params, drop, wh, wh.dpred, grads, batch, nullptr, nullptr));
+    BLH_TRY(launch_sumsq(s, grads, count, wh.sumsq_part, &np));
+    return launch_clip_adam_dev(s, params, grads, exp_avg, exp_avg_sq, count, dev_state,
+                                wh.sumsq_part, np, stats_out,
+                                LossFinish{wh.loss_part, nparts, denom, loss_out});
+  }
+  const Workspace ws = carve(d, batch, workspace);
   BLH_TRY(forward_impl(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
                        target, (float)(2.0 / denom), ws.loss_part, &nparts));
   const FusedBackward fb{nparts, ws.sumsq_part, &np};

@@ -106,7 +106,14 @@ typedef struct {
                               from its largest magnitude (gathered by the kernels that produce
                               it), so fp16's exponent range is never left; contractions whose
                               operands carry no such maximum (encode, decode, stand-alone
-                              stages) run as in mode 2                                   */
+                              stages) run as in mode 2;
+                           4: "bf16s" — bf16 STORAGE (BASELINE configs 3-5): every [B,W] tensor
+                              (pre-BN outputs, activations, their gradients), the network input and
+                              a shadow of the parameters are bf16 in device memory (inside the
+                              workspace); all contractions run on bf16 MFMA with fp32 accumulation,
+                              operands fed by LDS-DMA without conversion; BatchNorm statistics
+                              (taken from the fp32 accumulators), parameters, their gradients,
+                              Adam and the loss stay fp32.  width % 128 == 0.  No SyncBN.      */
 } blh_model_desc;
 
 /* Number of heavy_linear stages = 1 + 2*num_blocks (encode + hidden). */
