@@ -73,6 +73,8 @@ def gemm_rooflines(batch, width, reps, dtype="fp32"):
                 ready[slot] = 1
                 return rc
             return call
+    if dtype == "bf16s":
+        return gemm_rooflines_bf16s(batch, width, reps)
     A = torch.randn(batch, width, device=dev)
     Wt = torch.randn(width, width, device=dev) * 0.03
     bias = torch.randn(width, device=dev)
@@ -118,6 +120,41 @@ def gemm_rooflines(batch, width, reps, dtype="fp32"):
     return out
 
 
+def gemm_rooflines_bf16s(batch, width, reps):
+    """The three contractions of a hidden Linear in bf16 storage (gemm_bf16s_kernel.h)."""
+    from bilinear_amd import _native as N
+    lib = N.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    A = torch.randn(batch, width, device=dev).to(torch.bfloat16)
+    Wt = (torch.randn(width, width, device=dev) * 0.03).to(torch.bfloat16)
+    bias = torch.randn(width, device=dev)
+    Z = torch.empty(batch, width, dtype=torch.bfloat16, device=dev)
+    stat = torch.empty((batch + 127) // 128, 2, width, device=dev)
+    splits = max(1, min((256 * 128 * 128) // (width * width), batch // 128))
+    slabs = torch.empty(splits, width, width, device=dev)
+    flop = 2.0 * batch * width * width
+
+    def fwd():
+        N.check(lib.blh_gemm_bf16s(st, A.data_ptr(), width, 0, Wt.data_ptr(), width, 0, Z.data_ptr(), width, 1,
+                                   batch, width, width, 1, bias.data_ptr(), None, 0, stat.data_ptr()), "fwd")
+
+    def dgrad():
+        N.check(lib.blh_gemm_bf16s(st, A.data_ptr(), width, 0, Wt.data_ptr(), width, 1, Z.data_ptr(), width, 1,
+                                   batch, width, width, 1, None, None, 0, None), "dgrad")
+
+    def wgrad():
+        N.check(lib.blh_gemm_bf16s(st, A.data_ptr(), width, 1, Z.data_ptr(), width, 1, slabs.data_ptr(), width, 0,
+                                   width, width, batch, splits, None, None, 0, None), "wgrad")
+
+    out = {}
+    time_kernel(fwd, 3 * reps)
+    for name, fn in (("linear_fwd", fwd), ("linear_dgrad", dgrad), ("linear_wgrad", wgrad)):
+        ms = time_kernel(fn, reps)
+        out[name] = {"ms": ms, "tflops": flop / ms / 1e9}
+    return out
+
+
 def recorded_traffic(batch, width):
     """HBM traffic of the dominant kernel (bytes per launch).  bench.py cannot run the PMC
     passes itself; the figure comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
@@ -144,6 +181,15 @@ def roofline_block(args, dom):
             "traffic": recorded_traffic(args.batch, args.width),
             "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json)",
             "avg_launch_ms": dom["ms"], "flop_per_launch": flop,
+        }
+    if args.dtype == "bf16s":
+        return {
+            "kernel": "gemm_bf16s_kernel<ROWK,ROWK,BIAS_STATS,bf16 out> (Linear %dx%d forward, M=%d, bf16 storage)" % (
+                args.width, args.width, args.batch),
+            "bound": "mfma", "achieved": dom["tflops"], "peak": BF16_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": dom["tflops"] / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
+            "avg_launch_ms": dom["ms"], "flop_per_launch": flop,
+            "algorithmic_bytes_per_launch": 2.0 * (2 * args.batch * args.width + args.width * args.width),
         }
     if args.dtype == "fp16x2":
         peak = BF16_MFMA_PEAK_TFLOPS / 3.0   # f16 MFMA peak = bf16 MFMA peak; three MFMAs per product
@@ -228,11 +274,11 @@ def alt_mode_block(args, dev, x, t, alt):
 BASELINE_CONFIGS = {
     1: dict(blocks=2, width=1024, batch=4096, dtype="fp32", gpus=1,
             text="2-block width 1024 batch 4096 fp32 on 1xMI355X, fused Linear+BN+ReLU+Dropout fwd/bwd"),
-    2: dict(blocks=4, width=1024, batch=16384, dtype="bf16", gpus=1,
+    2: dict(blocks=4, width=1024, batch=16384, dtype="bf16s", gpus=1,
             text="4-block width 1024 batch 16384 bf16 on 1xMI355X, MFMA hidden GEMMs + fused Adam"),
-    3: dict(blocks=4, width=1024, batch=8192, dtype="bf16", gpus=8,
+    3: dict(blocks=4, width=1024, batch=8192, dtype="bf16s", gpus=8,
             text="4-block width 1024 batch 65536 bf16, data-parallel 8xMI355X (8192 poses per GPU)"),
-    4: dict(blocks=8, width=2048, batch=16384, dtype="bf16", gpus=8,
+    4: dict(blocks=8, width=2048, batch=16384, dtype="bf16s", gpus=8,
             text="8-block width 2048 batch 131072 bf16, 8xMI355X (16384 poses per GPU)"),
 }
 
@@ -281,7 +327,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", choices=["fp32", "bf16", "bf16x3", "fp16x2"], default=None,
+    ap.add_argument("--dtype", choices=["fp32", "bf16s", "bf16", "bf16x3", "fp16x2"], default=None,
                     help="GEMM arithmetic: fp32 MFMA (BASELINE configs[1], default) or bf16 MFMA "
                          "inputs with fp32 accumulation and fp32 storage (configs 3-5)")
     ap.add_argument("--sync-bn", action="store_true",
@@ -415,6 +461,8 @@ def main():
             "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x3": "f32 (operands split into 3 bf16 pieces, bf16 MFMA, fp32 accumulate)",
                       "fp16x2": "f32 (operands split into 2 scaled fp16 pieces, f16 MFMA, fp32 accumulate)",
+                      "bf16s": "bf16 (activations / gradients / weight shadow stored in bf16, bf16 MFMA, fp32 "
+                               "accumulate, fp32 master weights + BatchNorm statistics + Adam)",
                       "bf16": "bf16 (MFMA inputs; fp32 accumulate and storage)"}[args.dtype],
             "data": "synthetic",
             "config": {

@@ -137,9 +137,15 @@ _GEMM_ROUND = None
 
 
 def set_gemm_rounding(mode):
-    """mode None (fp32/fp64 exact operands) or "bf16" (round-to-nearest-even to bfloat16)."""
+    """mode None (fp32/fp64 exact operands), "bf16" (the two operands of every contraction are
+    rounded to bfloat16, round-to-nearest-even; every tensor is otherwise kept exact — the build's
+    gemm_dtype "bf16") or "bf16s" (bf16 STORAGE, the build's gemm_dtype "bf16s": besides the
+    operands, every tensor the build keeps in bf16 is rounded where the build stores it — the
+    network input, the pre-BN output z (AFTER the batch statistics were taken from the un-rounded
+    values), the activation a (after ReLU, dropout and the residual add), the gradient of the
+    prediction as the decode contractions read it, and the gradients dA / dZ)."""
     global _GEMM_ROUND
-    assert mode in (None, "bf16")
+    assert mode in (None, "bf16", "bf16s")
     _GEMM_ROUND = mode
 
 
@@ -152,9 +158,14 @@ def round_bf16(a):
 
 def _mm(a, b):
     """a @ b with the configured operand rounding."""
-    if _GEMM_ROUND == "bf16":
+    if _GEMM_ROUND in ("bf16", "bf16s"):
         return round_bf16(a) @ round_bf16(b)
     return a @ b
+
+
+def _st(a):
+    """A tensor as the build stores it: rounded to bf16 in "bf16s" mode, unchanged otherwise."""
+    return round_bf16(a) if _GEMM_ROUND == "bf16s" else a
 
 
 # --------------------------------------------------------------------------
@@ -190,7 +201,9 @@ def _heavy_fwd(st, h, a_in, mask, training, dtype, update_running, momentum):
                                         + f * unbiased).astype(st[h + ".1.running_var"].dtype)
         mu = mu.astype(dtype)
         invstd = (1.0 / np.sqrt(var + BN_EPS)).astype(dtype)
+        z = _st(z)          # ("bf16s": the statistics above come from the un-rounded values)
     else:
+        z = _st(z)
         mu = st[h + ".1.running_mean"].astype(dtype)
         invstd = (1.0 / np.sqrt(st[h + ".1.running_var"].astype(np.float64) + BN_EPS)).astype(dtype)
     zhat = (z - mu) * invstd
@@ -215,10 +228,11 @@ def forward(st, x, masks=None, training=True, dtype=np.float32,
     dtype = np.dtype(dtype).type
     num_blocks = (sum(1 for k in st if k.endswith(".0.weight")) - 1) // 2
     names = heavy_names(num_blocks)
-    a = np.asarray(x, dtype)
+    a = _st(np.asarray(x, dtype))
     caches = []
     a, c = _heavy_fwd(st, names[0], a, None if masks is None else masks[0],
                       training, dtype, update_running, momentum)
+    a = _st(a)
     caches.append(c)
     li = 1
     for _ in range(num_blocks):
@@ -226,9 +240,11 @@ def forward(st, x, masks=None, training=True, dtype=np.float32,
         for _l in range(2):
             a, c = _heavy_fwd(st, names[li], a, None if masks is None else masks[li],
                               training, dtype, update_running, momentum)
+            if _l == 0:
+                a = _st(a)
             caches.append(c)
             li += 1
-        a = a + skip                                   # model/bilinear.py:38
+        a = _st(a + skip)                              # model/bilinear.py:38
     Wd = st["decode.weight"].astype(dtype)
     bd = st["decode.bias"].astype(dtype)
     pred = _mm(a, Wd.T) + bd                           # model/bilinear.py:39
@@ -265,7 +281,7 @@ def _heavy_bwd(st, h, c, d_a, dtype, need_dx=True):
     dbeta = dY.astype(np.float64).sum(axis=0)
     dZ = (gamma * c["invstd"]) * (dY - (dbeta / n).astype(dtype)
                                   - c["zhat"] * (dgamma / n).astype(dtype))
-    dZ = dZ.astype(dtype)
+    dZ = _st(dZ.astype(dtype))
     g = {
         h + ".0.weight": _mm(dZ.T, c["a_in"]),
         h + ".0.bias": dZ.sum(axis=0, dtype=np.float64).astype(dtype),
@@ -285,15 +301,17 @@ def backward(st, cache, dpred, dtype=np.float32):
     Wd = st["decode.weight"].astype(dtype)
     grads["decode.weight"] = _mm(dpred.T, cache["a_last"])
     grads["decode.bias"] = dpred.sum(axis=0, dtype=np.float64).astype(dtype)
-    d_a = _mm(dpred, Wd)
+    d_a = _st(_mm(dpred, Wd))
     li = len(names) - 1
     for _ in range(nb):
         d_skip = d_a                                    # a = block(a) + skip
         for _l in range(2):
             d_a, g = _heavy_bwd(st, names[li], cache["layers"][li], d_a, dtype)
+            if _l == 0:
+                d_a = _st(d_a)
             grads.update(g)
             li -= 1
-        d_a = d_a + d_skip
+        d_a = _st(d_a + d_skip)
     _, g = _heavy_bwd(st, names[0], cache["layers"][0], d_a, dtype, need_dx=False)
     grads.update(g)
     return grads
