@@ -288,6 +288,7 @@ static int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s
     g.bias = params + h.b;
     g.stat_part = ws.stat_part;
     const Splits fs = small_m_splits(batch, W, h.fan_in);
+    const bool enc64 = train && i == 0 && fs.splits == 1 && h.fan_in <= 32 && batch >= 2048;
     if (fs.splits > 1) {
       // small batch: too few 128x128 output tiles to fill the chip and each would walk the
       // whole reduction alone (latency-bound), so cut the reduction across workgroups and
@@ -308,6 +309,10 @@ static int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s
       g.addend = (i >= 2 && (i % 2) == 0) ? ws.A[i - 2] : nullptr; g.ldadd = W;
       BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, EPI_BN_RELU, g, 1, d->gemm_dtype));
       continue;
+    } else if (enc64) {
+      // encode (K = 32): one K tile, the kernel is all prologue + 16.8 MB of output; 64-row tiles
+      // put two workgroups on every CU, so one's DMA wait overlaps the other's stores
+      BLH_TRY(launch_gemm(s, TILE_64x128, ROWK, ROWK, EPI_BIAS_STATS, g, 1, d->gemm_dtype));
     } else {
       BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, train ? EPI_BIAS_STATS : EPI_BIAS, g, 1,
                           d->gemm_dtype));
@@ -319,8 +324,8 @@ static int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s
     if (train) {
       float* sv = ws.bn_saved[i];
       // (the small-batch path produced one statistics tile covering all rows)
-      const int st_tiles = fs.splits > 1 ? 1 : tiles_m;
-      const int st_rows = fs.splits > 1 ? (int)batch : 128;
+      const int st_tiles = fs.splits > 1 ? 1 : (enc64 ? (int)ceil_div(batch, 64) : tiles_m);
+      const int st_rows = fs.splits > 1 ? (int)batch : (enc64 ? 64 : 128);
       if (ctx->sync.fn) {
         BLH_TRY(launch_bn_fwd_local_sums(s, ws.stat_part, st_tiles, st_rows, batch, W, ws.sync_buf));
         ctx->sync.fn(ctx->sync.user, ws.sync_buf, 2 * (int64_t)W, 1);
@@ -467,7 +472,9 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
     g.C = ws.G0; g.ldc = W;
     g.M = (int)batch; g.N = W; g.K = OF; g.k_per_split = OF;
     arm_fork(nh);
-    BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, 1, d->gemm_dtype));
+    // (K = 48: two K tiles and 16.8 MB of output; 64-row tiles = two workgroups per CU)
+    BLH_TRY(launch_gemm(s, batch >= 2048 ? TILE_64x128 : TILE_128x128, ROWK, KROW, EPI_STORE, g, 1,
+                        d->gemm_dtype));
     tl_stop_event = nullptr;
   }
   BLH_TRY(fork_wait(nh));

@@ -49,6 +49,7 @@ int launch_gemm_bf16s(hipStream_t s, int la, int lb, int epi, bool out_bf16, con
   if ((int64_t)128 * std::max(p.lda, p.ldb) * 2 >= (1ll << 31)) return BLH_ERR_SHAPE;
   BLH_CASEH(ROWK, ROWK, EPI_BIAS_STATS, true)    // forward (train): Z bf16 + BatchNorm partials
   BLH_CASEH(ROWK, ROWK, EPI_BIAS, true)          // forward (eval)
+  BLH_CASEH(ROWK, ROWK, EPI_BIAS, false)         // decode forward: fp32 prediction
   BLH_CASEH(ROWK, ROWK, EPI_STORE, true)
   BLH_CASEH(ROWK, ROWK, EPI_STORE, false)
   BLH_CASEH(ROWK, KROW, EPI_STORE, true)         // dgrad

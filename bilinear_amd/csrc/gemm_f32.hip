@@ -57,7 +57,8 @@ static int launch_cfg(hipStream_t s, const GemmParams& p, int splits) {
   if constexpr (BM == 128 && BN == 128) {
     const int64_t wgs = ceil_div(p.M, BM) * ceil_div(p.N, BN) * splits;
     const bool forward = (LA == ROWK && LB == ROWK);
-    if (forward && wgs <= 256) return launch_ring<BM, BN, WM, WN, LA, LB, EPI, 64, 2>(s, p, splits);
+    // (K <= 32, the encode Linear: a 64-deep K tile would be half zero page)
+    if (forward && wgs <= 256 && p.K > 32) return launch_ring<BM, BN, WM, WN, LA, LB, EPI, 64, 2>(s, p, splits);
     return launch_ring<BM, BN, WM, WN, LA, LB, EPI, 32, 2>(s, p, splits);
   } else {
     return launch_ring<BM, BN, WM, WN, LA, LB, EPI, RING_BKT_SKINNY, RING_STAGES_SKINNY>(s, p, splits);
@@ -92,6 +93,7 @@ static int launch_128x64(hipStream_t s, int la, int lb, int epi, const GemmParam
   return BLH_ERR_INVALID_ARGUMENT;
 }
 static int launch_64x128(hipStream_t s, int la, int lb, int epi, const GemmParams& p, int splits) {
+  BLH_CASE(64, 128, 2, 2, ROWK, ROWK, EPI_BIAS_STATS)    // encode forward (K = 32): 2 workgroups per CU
   BLH_CASE(64, 128, 2, 2, KROW, KROW, EPI_STORE)         // decode wgrad (M = 48)
   BLH_CASE(64, 128, 2, 2, ROWK, ROWK, EPI_STORE)
   BLH_CASE(64, 128, 2, 2, ROWK, ROWK, EPI_BIAS)
