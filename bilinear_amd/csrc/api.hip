@@ -288,7 +288,7 @@ static int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s
     g.bias = params + h.b;
     g.stat_part = ws.stat_part;
     const Splits fs = small_m_splits(batch, W, h.fan_in);
-    const bool enc64 = train && i == 0 && fs.splits == 1 && h.fan_in <= 32 && batch >= 2048;
+    const bool enc64 = train && i == 0 && fs.splits == 1 && h.fan_in <= 32 && batch >= 2048 && d->gemm_dtype != 1;
     if (fs.splits > 1) {
       // small batch: too few 128x128 output tiles to fill the chip and each would walk the
       // whole reduction alone (latency-bound), so cut the reduction across workgroups and
@@ -473,7 +473,7 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
     g.M = (int)batch; g.N = W; g.K = OF; g.k_per_split = OF;
     arm_fork(nh);
     // (K = 48: two K tiles and 16.8 MB of output; 64-row tiles = two workgroups per CU)
-    BLH_TRY(launch_gemm(s, batch >= 2048 ? TILE_64x128 : TILE_128x128, ROWK, KROW, EPI_STORE, g, 1,
+    BLH_TRY(launch_gemm(s, (batch >= 2048 && d->gemm_dtype != 1) ? TILE_64x128 : TILE_128x128, ROWK, KROW, EPI_STORE, g, 1,
                         d->gemm_dtype));
     tl_stop_event = nullptr;
   }

@@ -199,30 +199,27 @@ __device__ inline void gemm_epilogue_h(f32x16 (&acc)[2][2], const GemmParamsH& p
         for (int r = 0; r < 16; ++r) acc[i][jn][r] += bv;
     }
   }
-  if (EPI == EPI_ADD) {
-    float add[TM][TN][16];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2);
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) {
-          const int col = col_w + jn * 32;
-          add[i][jn][r] = (row < p.M && col < p.N) ? bf16_to_f32(p.addend[(int64_t)row * p.ldadd + col]) : 0.f;
-        }
-      }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int jn = 0; jn < TN; ++jn)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][jn][r] += add[i][jn][r];
-  }
-
+  static_assert(EPI != EPI_ADD || OUT_BF16, "the skip-gradient epilogue writes bf16");
   if (OUT_BF16) {
     bf16_bits* __restrict__ C = reinterpret_cast<bf16_bits*>(Cv);
     const bool odd = lane & 1;
+    // EPI_ADD: the addend pair of every (row, column pair) this lane will store, all loads
+    // issued before the first use (one memory latency for the tile, not one per element); the
+    // addend may alias C (in-place residual gradient): a lane reads exactly the pair it writes
+    uint32_t addpk[TM][TN][8];
+    if (EPI == EPI_ADD) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int row = row_w + i * 32 + ((r + (odd ? 1 : 0)) & 3) + 8 * (r >> 2);
+            const int col = col_w + jn * 32 - (odd ? 1 : 0);
+            addpk[i][jn][r >> 1] = (row < p.M && col < p.N)
+                ? *reinterpret_cast<const uint32_t*>(p.addend + (int64_t)row * p.ldadd + col) : 0u;
+          }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -233,8 +230,12 @@ __device__ inline void gemm_epilogue_h(f32x16 (&acc)[2][2], const GemmParamsH& p
           // and receives the even neighbour's v[r+1]
           const float give = odd ? acc[i][jn][r] : acc[i][jn][r + 1];
           const float got = __shfl_xor(give, 1);
-          const float lo = odd ? got : acc[i][jn][r];
-          const float hi = odd ? acc[i][jn][r + 1] : got;
+          float lo = odd ? got : acc[i][jn][r];
+          float hi = odd ? acc[i][jn][r + 1] : got;
+          if (EPI == EPI_ADD) {
+            lo += __uint_as_float(addpk[i][jn][r >> 1] << 16);
+            hi += __uint_as_float(addpk[i][jn][r >> 1] & 0xffff0000u);
+          }
           const int row = row_w + i * 32 + ((r + (odd ? 1 : 0)) & 3) + 8 * (r >> 2);
           const int col = col_w + jn * 32 - (odd ? 1 : 0);     // even column of the pair
           if (row < p.M && col < p.N) {                        // N is even: the pair is in range

@@ -1,0 +1,71 @@
+// Developer tool (not part of the library): K-tile / ring-depth variants of the bf16-storage GEMM
+// at the config-3 / config-5 shapes.  hipcc -O3 --offload-arch=gfx950 tools/bf16s_bench.hip -o bf16s_bench
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../gemm_bf16s_kernel.h"
+
+using namespace blh;
+thread_local int blh::g_last_hip_error = 0;
+thread_local hipEvent_t blh::tl_stop_event = nullptr;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+template <int LA, int LB, int EPI, bool OB, int BKE, int ST>
+float run(const GemmParamsH& p, int splits, int reps) {
+  constexpr size_t lds = gemm_bf16s_lds_bytes<BKE, ST>();
+  auto kern = gemm_bf16s_kernel<LA, LB, EPI, OB, BKE, ST>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int tiles = (int)(ceil_div(p.M, 128) * ceil_div(p.N, 128));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(256), lds, 0, p);
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(256), lds, 0, p);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  CK(hipGetLastError());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / reps;
+}
+
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 16384, W = argc > 2 ? atoi(argv[2]) : 1024;
+  const int reps = argc > 3 ? atoi(argv[3]) : 100;
+  uint16_t *A, *B, *C; float *bias, *stat, *slab;
+  CK(hipMalloc(&A, (size_t)M * W * 2)); CK(hipMalloc(&B, (size_t)W * W * 2)); CK(hipMalloc(&C, (size_t)M * W * 2));
+  CK(hipMalloc(&bias, W * 4)); CK(hipMalloc(&stat, (size_t)(M / 64 + 1) * 2 * W * 4)); CK(hipMalloc(&slab, (size_t)16 * W * W * 4));
+  std::vector<uint16_t> h((size_t)M * W);
+  for (auto& v : h) { float f = (float)rand() / RAND_MAX - 0.5f; uint32_t u; memcpy(&u, &f, 4); v = (uint16_t)(u >> 16); }
+  CK(hipMemcpy(A, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(B, h.data(), (size_t)W * W * 2, hipMemcpyHostToDevice));
+  CK(hipMemset(bias, 0, W * 4));
+  const double flop = 2.0 * M * W * (double)W;
+  GemmParamsH f{};
+  f.A = A; f.lda = W; f.B = B; f.ldb = W; f.C = C; f.ldc = W; f.M = M; f.N = W; f.K = W; f.k_per_split = W;
+  f.bias = bias; f.stat_part = stat;
+  GemmParamsH d = f;
+  GemmParamsH w{};
+  w.A = A; w.lda = W; w.B = A; w.ldb = W; w.C = slab; w.ldc = W; w.M = W; w.N = W; w.K = M;
+  const int tiles = (W / 128) * (W / 128);
+  const int splits = std::max(1, std::min(256 / tiles, M / 128));
+  w.k_per_split = (int)round_up(ceil_div(M, splits), 128); w.c_split_stride = (int64_t)W * W;
+#define ROW(BKE, ST)                                                                                    \
+  {                                                                                                     \
+    float t1 = run<ROWK, ROWK, EPI_BIAS_STATS, true, BKE, ST>(f, 1, reps);                              \
+    float t2 = run<ROWK, KROW, EPI_STORE, true, BKE, ST>(d, 1, reps);                                   \
+    float t3 = run<KROW, KROW, EPI_STORE, false, BKE, ST>(w, splits, reps);                             \
+    printf("bk%-3d st%d (%3d KB LDS)  fwd %7.1f us %6.0f TF | dgrad %7.1f us %6.0f TF | wgrad(x%d) %7.1f us %6.0f TF\n", \
+           BKE, ST, (int)(gemm_bf16s_lds_bytes<BKE, ST>() / 1024), t1 * 1e3, flop / t1 / 1e9, t2 * 1e3,     \
+           flop / t2 / 1e9, splits, t3 * 1e3, flop / t3 / 1e9);                                        \
+  }
+  for (int round = 0; round < 2; ++round) {
+    ROW(64, 2)
+    ROW(64, 3)
+    ROW(64, 4)
+    ROW(128, 2)
+  }
+  return 0;
+}
