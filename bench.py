@@ -155,6 +155,58 @@ def gemm_rooflines_bf16s(batch, width, reps):
     return out
 
 
+def skinny_rooflines(batch, width, reps):
+    """HBM roofline of the skinny projections (BASELINE north_star: "achieved HBM GB/s on the skinny
+    32-wide input / output projections"), each exactly as the step launches it (blh_skinny_*), timed
+    live with HIP events.  Algorithmic bytes per pose (weights amortised over
+    the batch): encode fwd 32 s + W s; decode fwd + MSE W s + 48 s (target) + 2 * 48 s (pred, dpred);
+    decode bwd 48 s + W s (reads) + W s (dA); encode wgrad W s + 32 s."""
+    from bilinear_amd import _native as N
+    lib = N.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    IF, OF, W, B = 32, 48, width, batch
+    x = torch.randn(B, IF, device=dev)
+    W0 = torch.randn(W, IF, device=dev) * 0.25
+    b0 = torch.randn(W, device=dev)
+    Z = torch.empty(B, W, device=dev)
+    part = torch.empty((B + 63) // 64, 2, W, device=dev)
+    A = torch.randn(B, W, device=dev)
+    Wd = torch.randn(OF, W, device=dev) * 0.05
+    bd = torch.randn(OF, device=dev)
+    t = torch.randn(B, OF, device=dev)
+    pred, dpred = torch.empty(B, OF, device=dev), torch.empty(B, OF, device=dev)
+    loss = torch.zeros((), device=dev)
+    dWd, dA = torch.empty(OF, W, device=dev), torch.empty(B, W, device=dev)
+    dW0 = torch.empty(W, IF, device=dev)
+    wsb = lib.blh_skinny_workspace_bytes(B, W, IF, OF)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    rows = ctypes.c_int32(0)
+    ops = [
+        ("encode_fwd (Linear 32->%d + BatchNorm partials)" % W, 4.0 * B * (IF + W),
+         lambda: lib.blh_skinny_encode_fwd(st, x.data_ptr(), W0.data_ptr(), b0.data_ptr(), Z.data_ptr(),
+                                           part.data_ptr(), ctypes.byref(rows), B, W, IF)),
+        ("decode_fwd_mse (Linear %d->48 + MSE loss + dpred)" % W, 4.0 * B * (W + 3 * OF),
+         lambda: lib.blh_skinny_decode_fwd_mse(st, A.data_ptr(), Wd.data_ptr(), bd.data_ptr(), t.data_ptr(),
+                                               pred.data_ptr(), dpred.data_ptr(), loss.data_ptr(),
+                                               ws.data_ptr(), wsb, B, W, OF)),
+        ("decode_bwd (dWd = dP^T A, dA = dP Wd)", 4.0 * B * (OF + 2 * W),
+         lambda: lib.blh_skinny_decode_bwd(st, dpred.data_ptr(), A.data_ptr(), Wd.data_ptr(), dWd.data_ptr(),
+                                           dA.data_ptr(), ws.data_ptr(), wsb, B, W, OF)),
+        ("encode_wgrad (dW0 = dZ^T x)", 4.0 * B * (W + IF),
+         lambda: lib.blh_skinny_encode_wgrad(st, Z.data_ptr(), x.data_ptr(), dW0.data_ptr(), ws.data_ptr(),
+                                             wsb, B, W, IF)),
+    ]
+    out = []
+    for name, nbytes, fn in ops:
+        N.check(fn(), name)
+        ms = time_kernel(fn, reps)
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        out.append({"op": name, "algorithmic_bytes": nbytes, "avg_us": 1e3 * ms, "achieved": gbs,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bound": "hbm"})
+    return out
+
+
 def recorded_traffic(batch, width):
     """HBM traffic of the dominant kernel (bytes per launch).  bench.py cannot run the PMC
     passes itself; the figure comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
@@ -483,6 +535,7 @@ def main():
             "step_tflops": poses * (fwd + bwd) / 1e12,
             "step_frac_of_fp32_mfma_peak": poses * (fwd + bwd) / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
             "roofline": roofline_block(args, dom),
+            "roofline_hbm": skinny_rooflines(args.batch, args.width, reps=300),
             "kernels": kern,
         }
         if world == 1 and args.dtype == "fp32" and not args.no_alt:

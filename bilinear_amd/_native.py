@@ -112,6 +112,12 @@ _SIGNATURES = {
                                 c_void_p, c_int64, c_int64, c_int64, c_int64, c_int32, c_void_p,
                                 c_void_p, c_int64, c_void_p, c_int32]),
     "blh_sum_slabs": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "blh_skinny_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32, c_int32]),
+    "blh_skinny_encode_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      POINTER(c_int32), c_int64, c_int32, c_int32]),
+    "blh_skinny_decode_fwd_mse": (c_int, [c_void_p] * 9 + [c_int64, c_int64, c_int32, c_int32]),
+    "blh_skinny_decode_bwd": (c_int, [c_void_p] * 7 + [c_int64, c_int64, c_int32, c_int32]),
+    "blh_skinny_encode_wgrad": (c_int, [c_void_p] * 5 + [c_int64, c_int64, c_int32, c_int32]),
     "blh_gemm_bf16s": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
                                c_void_p, c_int64, c_int32, c_int64, c_int64, c_int64, c_int32,
                                c_void_p, c_void_p, c_int64, c_void_p]),

@@ -348,6 +348,16 @@ static int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s
   // over W is split across workgroups (slabs) and a small kernel adds the slabs, the bias and,
   // in the fused step, the MSE loss / gradient (train_bilinear.py:78).
   const int OF = d->out_features;
+  if (d->gemm_dtype != 1 && decode_fwd_supported(batch, W, OF)) {
+    // purpose-built kernel (skinny.hip): reads A once, no slabs, bias + MSE + dpred + the loss and
+    // decode-bias partials in the same launch
+    int np = 0;
+    BLH_TRY(launch_decode_fwd_mse(s, ws.A[nh - 1], params + L.dec_w, params + L.dec_b, target, pred,
+                                  target ? ws.dpred : nullptr, loss_part,
+                                  target ? ws.dec_bias_part : nullptr, batch, W, OF, mse_scale, &np));
+    if (loss_nparts) *loss_nparts = np;
+    return BLH_OK;
+  }
   const Splits sp = decode_fwd_splits(batch, W);
   GemmParams g{};
   g.A = ws.A[nh - 1]; g.lda = W;
@@ -1407,6 +1417,75 @@ int blh_cast_f32_to_bf16(void* stream, const float* src, uint16_t* dst, int64_t 
 int blh_cast_bf16_to_f32(void* stream, const uint16_t* src, float* dst, int64_t count) {
   if (!src || !dst || count <= 0) return BLH_ERR_INVALID_ARGUMENT;
   return launch_cast_bf16_f32((hipStream_t)stream, src, dst, count);
+}
+
+// ---- the skinny projections exactly as the step launches them (profiling / unit tests) -----
+static int64_t skinny_slab_floats(int64_t batch, int W, int IF, int OF) {
+  const Splits es = pick_splits(batch, ceil_div(W, 128) * ceil_div(IF, 32));
+  const Splits ds = pick_splits(batch, ceil_div(OF, 64) * ceil_div(W, 128));
+  int64_t m = std::max<int64_t>(es.splits * (int64_t)W * IF, ds.splits * (int64_t)OF * W);
+  m = std::max<int64_t>(m, decode_fwd_splits(batch, W).splits * batch * OF);
+  return m + 1026 * (int64_t)OF + 4096;     // + decode-bias partials + loss partials
+}
+
+int64_t blh_skinny_workspace_bytes(int64_t batch, int32_t width, int32_t in_features,
+                                   int32_t out_features) {
+  if (batch <= 0 || width <= 0 || in_features <= 0 || out_features <= 0) return BLH_ERR_INVALID_ARGUMENT;
+  return skinny_slab_floats(batch, width, in_features, out_features) * (int64_t)sizeof(float);
+}
+
+int blh_skinny_encode_fwd(void* stream, const float* x, const float* W0, const float* b0, float* Z,
+                          float* stat_part, int32_t* stat_tile_rows, int64_t batch, int32_t width,
+                          int32_t in_features) {
+  if (!x || !W0 || !b0 || !Z || !stat_part || batch <= 0) return BLH_ERR_INVALID_ARGUMENT;
+  GemmParams g{};
+  g.A = x; g.lda = in_features; g.B = W0; g.ldb = in_features; g.C = Z; g.ldc = width;
+  g.M = (int)batch; g.N = width; g.K = in_features; g.k_per_split = in_features;
+  g.bias = b0; g.stat_part = stat_part;
+  const bool enc64 = in_features <= 32 && batch >= 2048;
+  if (stat_tile_rows) *stat_tile_rows = enc64 ? 64 : 128;
+  return launch_gemm((hipStream_t)stream, enc64 ? TILE_64x128 : TILE_128x128, ROWK, ROWK,
+                     EPI_BIAS_STATS, g, 1, 0);
+}
+
+int blh_skinny_decode_fwd_mse(void* stream, const float* A, const float* Wd, const float* bd,
+                              const float* target, float* pred, float* dpred, float* loss_out,
+                              void* workspace, int64_t workspace_bytes, int64_t batch, int32_t width,
+                              int32_t out_features) {
+  if (!A || !Wd || !bd || !target || !pred || !dpred || !loss_out || !workspace || batch <= 0)
+    return BLH_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < blh_skinny_workspace_bytes(batch, width, 32, out_features)) return BLH_ERR_WORKSPACE;
+  if (!decode_fwd_supported(batch, width, out_features)) return BLH_ERR_SHAPE;
+  float* part = (float*)workspace;              // [1026*OF] bias partials, then loss partials
+  float* loss_part = part + 1026 * (int64_t)out_features;
+  const double denom = (double)batch * out_features;
+  int np = 0;
+  BLH_TRY(launch_decode_fwd_mse((hipStream_t)stream, A, Wd, bd, target, pred, dpred, loss_part, part,
+                                batch, width, out_features, (float)(2.0 / denom), &np));
+  return launch_loss_finalize((hipStream_t)stream, loss_part, np, denom, loss_out);
+}
+
+int blh_skinny_decode_bwd(void* stream, const float* dpred, const float* A, const float* Wd,
+                          float* dWd, float* dA, void* workspace, int64_t workspace_bytes,
+                          int64_t batch, int32_t width, int32_t out_features) {
+  if (!dpred || !A || !Wd || !dWd || !dA || !workspace || batch <= 0) return BLH_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < blh_skinny_workspace_bytes(batch, width, 32, out_features)) return BLH_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int W = width, OF = out_features;
+  BLH_TRY(wgrad(0, s, TILE_64x128, dpred, OF, OF, A, W, W, batch, ceil_div(OF, 64) * ceil_div(W, 128),
+                (float*)workspace, dWd, nullptr));
+  GemmParams g{};
+  g.A = dpred; g.lda = OF; g.B = Wd; g.ldb = W; g.C = dA; g.ldc = W;
+  g.M = (int)batch; g.N = W; g.K = OF; g.k_per_split = OF;
+  return launch_gemm(s, batch >= 2048 ? TILE_64x128 : TILE_128x128, ROWK, KROW, EPI_STORE, g, 1, 0);
+}
+
+int blh_skinny_encode_wgrad(void* stream, const float* dZ, const float* x, float* dW0, void* workspace,
+                            int64_t workspace_bytes, int64_t batch, int32_t width, int32_t in_features) {
+  if (!dZ || !x || !dW0 || !workspace || batch <= 0) return BLH_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < blh_skinny_workspace_bytes(batch, width, in_features, 48)) return BLH_ERR_WORKSPACE;
+  return wgrad(0, (hipStream_t)stream, TILE_128x32, dZ, width, width, x, in_features, in_features, batch,
+               ceil_div(width, 128) * ceil_div(in_features, 32), (float*)workspace, dW0, nullptr);
 }
 
 int blh_sum_slabs(void* stream, const float* slabs, int64_t count, int32_t splits, float* out) {

@@ -219,6 +219,11 @@ int launch_decode_finish(hipStream_t s, const float* slabs, int splits, int64_t 
                          int out_features, const float* bias, float* pred, const float* target,
                          float scale, float* dpred, float* loss_part, int* nparts,
                          float* dbias_part = nullptr);
+// skinny.hip: decode forward fused with the MSE loss (pred, dpred, loss / decode-bias partials)
+bool decode_fwd_supported(int64_t batch, int W, int OF);
+int launch_decode_fwd_mse(hipStream_t s, const float* A, const float* Wd, const float* bd,
+                          const float* target, float* pred, float* dpred, float* loss_part,
+                          float* dbias_part, int64_t batch, int W, int OF, float scale, int* nparts);
 int launch_mpjpe(hipStream_t s, const float* pred, const float* target, const float* mean,
                  const float* stddev, int64_t batch, int joints, float* dist);
 int launch_segment_sum(hipStream_t s, const float* dist, const int32_t* ids, int64_t batch,

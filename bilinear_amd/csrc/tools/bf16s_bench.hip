@@ -2,6 +2,7 @@
 // at the config-3 / config-5 shapes.  hipcc -O3 --offload-arch=gfx950 tools/bf16s_bench.hip -o bf16s_bench
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../gemm_bf16s_kernel.h"

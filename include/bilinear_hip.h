@@ -361,6 +361,28 @@ int blh_gemm_bf16s(void* stream, const uint16_t* A, int64_t lda, int32_t a_kmajo
 /* fp32 <-> bf16 (round to nearest even) over `count` elements (multiple of 4).              */
 int blh_cast_f32_to_bf16(void* stream, const float* src, uint16_t* dst, int64_t count);
 int blh_cast_bf16_to_f32(void* stream, const uint16_t* src, float* dst, int64_t count);
+/* The four skinny (HBM-bound) projections exactly as the training step launches them, for
+ * profiling and unit tests (fp32).  model/bilinear.py:22 (encode, 32 -> W) and :29 (decode,
+ * W -> 48) with train_bilinear.py:78 (MSELoss) fused into the decode forward.
+ *   encode_fwd      Z[B,W] = x[B,in] W0^T + b0, BatchNorm partials per `*stat_tile_rows`-row tile
+ *   decode_fwd_mse  pred = A Wd^T + bd ; dpred = 2 (pred - target)/(B out) ; *loss_out = MSE
+ *   decode_bwd      dWd[out,W] = dpred^T A ; dA[B,W] = dpred Wd
+ *   encode_wgrad    dW0[W,in] = dZ^T x
+ * `workspace`: blh_skinny_workspace_bytes (split-reduction slabs, partials).               */
+int64_t blh_skinny_workspace_bytes(int64_t batch, int32_t width, int32_t in_features,
+                                   int32_t out_features);
+int blh_skinny_encode_fwd(void* stream, const float* x, const float* W0, const float* b0, float* Z,
+                          float* stat_part, int32_t* stat_tile_rows, int64_t batch, int32_t width,
+                          int32_t in_features);
+int blh_skinny_decode_fwd_mse(void* stream, const float* A, const float* Wd, const float* bd,
+                              const float* target, float* pred, float* dpred, float* loss_out,
+                              void* workspace, int64_t workspace_bytes, int64_t batch, int32_t width,
+                              int32_t out_features);
+int blh_skinny_decode_bwd(void* stream, const float* dpred, const float* A, const float* Wd,
+                          float* dWd, float* dA, void* workspace, int64_t workspace_bytes,
+                          int64_t batch, int32_t width, int32_t out_features);
+int blh_skinny_encode_wgrad(void* stream, const float* dZ, const float* x, float* dW0, void* workspace,
+                            int64_t workspace_bytes, int64_t batch, int32_t width, int32_t in_features);
 int blh_sum_slabs(void* stream, const float* slabs, int64_t count, int32_t splits, float* out);
 /* The forward kernel of one heavy_linear exactly as blh_forward_train launches it:
  * Z[M,N] = A[M,K] W[N,K]^T + bias, plus per-128-row-tile column statistics

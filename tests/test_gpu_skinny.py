@@ -1,0 +1,102 @@
+"""The skinny (HBM-bound) projections of the lifter, exactly as the training step launches them
+(blh_skinny_* entry points), against fp64 NumPy: encode forward with BatchNorm partials, decode
+forward fused with the MSE loss, decode backward (weight + data gradient), encode weight gradient.
+Reference call-sites: /root/reference/model/bilinear.py:22,29,39; train_bilinear.py:78-79."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _close(got, ref, rtol, what):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    rms = np.sqrt((ref ** 2).mean())
+    err = np.abs(got - ref)
+    bound = rtol * (np.abs(ref) + rms)
+    assert (err <= bound).all(), "%s: max excess %.3e" % (what, (err - bound).max())
+
+
+@pytest.mark.parametrize("batch,width", [(4096, 1024), (4100, 1024), (300, 256), (16384, 2048), (40000, 512)])
+def test_decode_forward_fused_mse(native, batch, width):
+    dev = _dev()
+    rng = np.random.RandomState(batch + width)
+    OF = 48
+    A = rng.standard_normal((batch, width)).astype(np.float32)
+    A[:, 0] += 2.0
+    Wd = (rng.standard_normal((OF, width)) * 0.05).astype(np.float32)
+    bd = rng.standard_normal(OF).astype(np.float32)
+    t = rng.standard_normal((batch, OF)).astype(np.float32)
+    a, w, b, tt = (torch.from_numpy(v).to(dev) for v in (A, Wd, bd, t))
+    pred = torch.full((batch, OF), float("nan"), device=dev)
+    dpred = torch.full((batch, OF), float("nan"), device=dev)
+    loss = torch.zeros((), device=dev)
+    wsb = native.blh_skinny_workspace_bytes(batch, width, 32, OF)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = native.blh_skinny_decode_fwd_mse(st, a.data_ptr(), w.data_ptr(), b.data_ptr(), tt.data_ptr(),
+                                          pred.data_ptr(), dpred.data_ptr(), loss.data_ptr(), ws.data_ptr(),
+                                          wsb, batch, width, OF)
+    assert rc == 0, native.blh_status_string(rc)
+    torch.cuda.synchronize()
+    ref = A.astype(np.float64) @ Wd.T.astype(np.float64) + bd
+    _close(pred.cpu().numpy(), ref, 2e-5, "pred")
+    d = ref - t
+    _close(dpred.cpu().numpy(), 2 * d / d.size, 1e-4, "dpred")
+    assert abs(loss.item() - (d ** 2).mean()) <= 1e-5 * (d ** 2).mean()
+
+
+@pytest.mark.parametrize("batch", [4096, 4100, 640])
+def test_decode_backward_and_encode_kernels(native, batch):
+    dev = _dev()
+    rng = np.random.RandomState(batch)
+    W, OF, IF = 1024, 48, 32
+    A = rng.standard_normal((batch, W)).astype(np.float32)
+    Wd = (rng.standard_normal((OF, W)) * 0.05).astype(np.float32)
+    dP = (rng.standard_normal((batch, OF)) * 1e-3).astype(np.float32)
+    x = rng.standard_normal((batch, IF)).astype(np.float32)
+    W0 = (rng.standard_normal((W, IF)) * 0.25).astype(np.float32)
+    b0 = rng.standard_normal(W).astype(np.float32)
+    dZ = (rng.standard_normal((batch, W)) * 1e-3).astype(np.float32)
+    a, wd, dp, xt, w0, bt, dz = (torch.from_numpy(v).to(dev) for v in (A, Wd, dP, x, W0, b0, dZ))
+    wsb = native.blh_skinny_workspace_bytes(batch, W, IF, OF)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # decode backward
+    dWd = torch.full((OF, W), float("nan"), device=dev)
+    dA = torch.full((batch, W), float("nan"), device=dev)
+    assert native.blh_skinny_decode_bwd(st, dp.data_ptr(), a.data_ptr(), wd.data_ptr(), dWd.data_ptr(),
+                                        dA.data_ptr(), ws.data_ptr(), wsb, batch, W, OF) == 0
+    torch.cuda.synchronize()
+    _close(dWd.cpu().numpy(), dP.T.astype(np.float64) @ A.astype(np.float64), 3e-5, "dWd")
+    _close(dA.cpu().numpy(), dP.astype(np.float64) @ Wd.astype(np.float64), 3e-5, "dA")
+    # encode forward + BatchNorm tile partials
+    Z = torch.full((batch, W), float("nan"), device=dev)
+    part = torch.zeros((batch + 63) // 64, 2, W, device=dev)
+    rows = ctypes.c_int32(0)
+    assert native.blh_skinny_encode_fwd(st, xt.data_ptr(), w0.data_ptr(), bt.data_ptr(), Z.data_ptr(),
+                                        part.data_ptr(), ctypes.byref(rows), batch, W, IF) == 0
+    torch.cuda.synchronize()
+    zr = x.astype(np.float64) @ W0.T.astype(np.float64) + b0
+    _close(Z.cpu().numpy(), zr, 2e-5, "Z")
+    tr = rows.value
+    assert tr in (64, 128)
+    p = part.cpu().numpy().astype(np.float64)
+    for ti in range((batch + tr - 1) // tr):
+        blk = zr[ti * tr:(ti + 1) * tr]
+        assert np.abs(p[ti, 0] - blk.mean(0)).max() <= 1e-5 * (1 + np.abs(blk).max())
+        m2 = ((blk - blk.mean(0)) ** 2).sum(0)
+        assert np.abs(p[ti, 1] - m2).max() <= 1e-4 * m2.max() + 1e-6
+    # encode weight gradient
+    dW0 = torch.full((W, IF), float("nan"), device=dev)
+    assert native.blh_skinny_encode_wgrad(st, dz.data_ptr(), xt.data_ptr(), dW0.data_ptr(), ws.data_ptr(), wsb,
+                                          batch, W, IF) == 0
+    torch.cuda.synchronize()
+    _close(dW0.cpu().numpy(), dZ.T.astype(np.float64) @ x.astype(np.float64), 3e-5, "dW0")
