@@ -681,7 +681,7 @@ static WorkspaceH carve_h(const blh_model_desc* d, int64_t batch, void* base) {
   ws.G0 = (uint16_t*)take(act);
   ws.G1 = (uint16_t*)take(act);
   ws.stat_part = (float*)take(ceil_div(batch, 64) * 2 * W * sizeof(float));
-  const int64_t chunks = ew_num_row_chunks(batch);
+  const int64_t chunks = ew_num_row_chunks_h(batch);
   ws.bn_part = (float*)take(chunks * 2 * W * sizeof(float));
   ws.dz_colsum_part = (float*)take((int64_t)nh * chunks * W * sizeof(float));
   ws.slabs = (float*)take(slab_floats_h(d, batch) * sizeof(float));
@@ -745,7 +745,9 @@ static int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, c
 // dW = dZ^T act (both bf16, reduction over the batch split into fp32 slabs), summed into `out`
 static int wgrad_h(hipStream_t s, const uint16_t* dZ, int64_t ld_dz, int M, const uint16_t* act,
                    int64_t ld_act, int N, int64_t batch, float* slabs, float* out) {
-  const Splits sp = pick_splits(batch, ceil_div(M, 128) * ceil_div(N, 128));
+  Splits sp = pick_splits(batch, ceil_div(M, 128) * ceil_div(N, 128));
+  sp.k_per = (int)round_up(sp.k_per, 128);               // whole 128-deep K tiles per slab
+  sp.splits = (int)ceil_div(batch, sp.k_per);
   GemmParamsH g{};
   g.A = dZ; g.lda = ld_dz; g.B = act; g.ldb = ld_act;
   g.M = M; g.N = N; g.K = (int)batch; g.k_per_split = sp.k_per; g.ldc = N;
@@ -765,7 +767,7 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
   const ArenaLayout L = make_layout(d);
   const int nh = (int)L.heavy.size();
   const int W = d->width, OF = d->out_features, IF = d->in_features;
-  const int chunks = ew_num_row_chunks(batch);
+  const int chunks = ew_num_row_chunks_h(batch);
   // single stream: a reported range is complete on `s`; a two-stream context promised "complete
   // on the side stream", so that one is made to wait
   auto ready = [&](int idx, int64_t off, int64_t cnt) -> int {
@@ -1400,7 +1402,7 @@ int blh_gemm_bf16s(void* stream, const uint16_t* A, int64_t lda, int32_t a_kmajo
   GemmParamsH g{};
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.M = (int)M; g.N = (int)N; g.K = (int)K;
-  g.k_per_split = (splits > 1) ? (int)round_up(ceil_div(K, splits), SPLIT_GRAIN) : (int)K;
+  g.k_per_split = (splits > 1) ? (int)round_up(ceil_div(K, splits), 128) : (int)K;
   if (splits > 1 && (int64_t)g.k_per_split * (splits - 1) >= K) return BLH_ERR_SHAPE;
   g.c_split_stride = M * ldc;
   g.bias = bias; g.addend = addend; g.ldadd = ldadd; g.stat_part = stat_part;

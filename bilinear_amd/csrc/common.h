@@ -106,6 +106,10 @@ __host__ __device__ inline uint64_t dropout_step(const DropoutSrc& d) {
 static constexpr int EW_COLS_PER_BLOCK = 256;    // 64 lanes x float4, 4 waves share the rows
 int ew_row_chunk(int64_t batch);                 // rows handled by one block (multiple of 32)
 int ew_num_row_chunks(int64_t batch);
+// bf16-storage kernels (512 columns per block): smaller row chunks, up to 1024 of them, so that
+// the grid still holds several blocks per CU at W = 1024
+int ew_row_chunk_h(int64_t batch);
+int ew_num_row_chunks_h(int64_t batch);
 
 // forward BN: merge per-tile (mean, M2) -> batch mean / invstd, scale/shift, running stats
 int launch_bn_fwd_finalize(hipStream_t s, const float* stat_part, int tiles, int tile_rows,

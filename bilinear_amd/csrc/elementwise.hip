@@ -19,6 +19,10 @@ int ew_row_chunk(int64_t batch) {
   return (int)(32 * std::max<int64_t>(1, ceil_div(batch, 32 * 128)));
 }
 int ew_num_row_chunks(int64_t batch) { return (int)ceil_div(batch, ew_row_chunk(batch)); }
+int ew_row_chunk_h(int64_t batch) {
+  return (int)(32 * std::max<int64_t>(1, ceil_div(batch, 32 * 1024)));
+}
+int ew_num_row_chunks_h(int64_t batch) { return (int)ceil_div(batch, ew_row_chunk_h(batch)); }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -363,7 +367,7 @@ __device__ __forceinline__ float4 drop4(float4 a, uint32_t nib) {
   return a;
 }
 static dim3 ew_grid_h(int64_t batch, int W) {
-  return dim3((unsigned)ceil_div(W, H_COLS_PER_BLOCK), (unsigned)ew_num_row_chunks(batch));
+  return dim3((unsigned)ceil_div(W, H_COLS_PER_BLOCK), (unsigned)ew_num_row_chunks_h(batch));
 }
 
 // sum the per-lane 2 x float4 partials of the block's 4 waves: out[col0 .. col0+511]
@@ -575,11 +579,11 @@ int launch_bn_apply_t(hipStream_t s, bool train, const void* Z, int zt, const fl
     if (train)
       hipLaunchKernelGGL(bn_apply_h_kernel<true>, ew_grid_h(batch, W), block, 0, s, (const bf16_bits*)Z,
                          scale, shift, gamma, beta, running_mean, running_var, (const bf16_bits*)skip,
-                         (bf16_bits*)A, batch, W, rc, drop, nbt);
+                         (bf16_bits*)A, batch, W, ew_row_chunk_h(batch), drop, nbt);
     else
       hipLaunchKernelGGL(bn_apply_h_kernel<false>, ew_grid_h(batch, W), block, 0, s, (const bf16_bits*)Z,
                          scale, shift, gamma, beta, running_mean, running_var, (const bf16_bits*)skip,
-                         (bf16_bits*)A, batch, W, rc, drop, nbt);
+                         (bf16_bits*)A, batch, W, ew_row_chunk_h(batch), drop, nbt);
   } else if (zt == ET_BF16 && at == ET_F32 && (skip == nullptr || st == ET_BF16)) {
     if (train) BLH_APPLY(true, bf16_bits, bf16_bits, float); else BLH_APPLY(false, bf16_bits, bf16_bits, float);
   } else {
@@ -663,7 +667,7 @@ int launch_bn_bwd_reduce_t(hipStream_t s, const void* dA, int gt, const void* Z,
   if (gt != ET_BF16 || zt != ET_BF16 || W % 8 != 0) return BLH_ERR_INVALID_ARGUMENT;
   hipLaunchKernelGGL(bn_bwd_reduce_h_kernel, ew_grid_h(batch, W), dim3(EW_THREADS), 0, s,
                      (const bf16_bits*)dA, (const bf16_bits*)Z, scale, shift, mean, invstd, part, batch, W,
-                     ew_row_chunk(batch), drop);
+                     ew_row_chunk_h(batch), drop);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
@@ -832,7 +836,7 @@ int launch_bn_bwd_apply_t(hipStream_t s, const void* dA, int gt, const void* Z, 
   if (dt == ET_BF16 && W % 8 == 0)
     launch_kernel(bn_bwd_apply_h_kernel, ew_grid_h(batch, W), block, 0, s, (const bf16_bits*)dA,
                   (const bf16_bits*)Z, scale, shift, mean, invstd, dgamma, dbeta, (bf16_bits*)dZ,
-                  dz_colsum_part, batch, W, ew_row_chunk(batch), drop, norm_batch);
+                  dz_colsum_part, batch, W, ew_row_chunk_h(batch), drop, norm_batch);
   else if (dt == ET_BF16)
     return BLH_ERR_SHAPE;
   else

@@ -17,11 +17,15 @@ static int ensure_lds_attr_h(std::atomic<uint64_t>& done, const void* kern, size
   return BLH_OK;
 }
 
-// K tile / ring depth: 64 elements x 2 stages = 64 KB of LDS, two workgroups (8 waves) per CU
-static constexpr int H_BKE = BLH_H_BKE_DEFAULT, H_STAGES = BLH_H_STAGES_DEFAULT;
-
+// K tile / ring depth, measured with tools/bf16s_bench (profiles/r02_bf16s_gemm.md):
+//   forward / dgrad (a ROWK operand): 64 elements x 2 stages = 64 KB of LDS, two workgroups
+//   (8 waves) per CU: 664 / 695 TFLOP/s at B = 16384, W = 1024 (96 / 128 KB variants: 470-495);
+//   wgrad (both operands through the transposing read): 128 x 2 stages, one workgroup per CU:
+//   697 TFLOP/s (64 x 2: 628).
 template <int LA, int LB, int EPI, bool OUT_BF16>
 static int launch_h(hipStream_t s, const GemmParamsH& p, int splits) {
+  constexpr int H_BKE = (LA == KROW && LB == KROW) ? 128 : 64, H_STAGES = 2;
+  if (splits > 1 && (p.k_per_split % H_BKE) != 0) return BLH_ERR_SHAPE;
   constexpr size_t lds = gemm_bf16s_lds_bytes<H_BKE, H_STAGES>();
   static std::atomic<uint64_t> attr_done{0};
   auto kern = gemm_bf16s_kernel<LA, LB, EPI, OUT_BF16, H_BKE, H_STAGES>;
@@ -43,7 +47,6 @@ int launch_gemm_bf16s(hipStream_t s, int la, int lb, int epi, bool out_bf16, con
   if (la == KROW && p.M % 8 != 0) return BLH_ERR_SHAPE;
   if (lb == KROW && p.N % 8 != 0) return BLH_ERR_SHAPE;
   if (out_bf16 && (p.N % 2 != 0 || p.ldc % 2 != 0)) return BLH_ERR_SHAPE;
-  if (splits > 1 && (p.k_per_split % H_BKE) != 0) return BLH_ERR_SHAPE;
   if (((uintptr_t)p.A | (uintptr_t)p.B) & 15) return BLH_ERR_INVALID_ARGUMENT;
   // 32-bit per-lane byte offsets inside one tile row panel
   if ((int64_t)128 * std::max(p.lda, p.ldb) * 2 >= (1ll << 31)) return BLH_ERR_SHAPE;
