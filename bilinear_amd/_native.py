@@ -94,6 +94,9 @@ _SIGNATURES = {
     "blh_mpjpe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                           c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "blh_step_state_advance": (c_int, [c_void_p, c_void_p]),
+    "blh_context_set_step_state": (c_int, [c_void_p, c_void_p]),
+    "blh_clip_adam_step_captured": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                            c_void_p, c_void_p, c_int64, c_void_p]),
     "blh_train_step_captured": (c_int, [c_void_p, POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         POINTER(Dropout), c_float, c_void_p, c_void_p, c_int64,

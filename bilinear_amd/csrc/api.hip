@@ -1239,6 +1239,25 @@ int blh_mpjpe(void* stream, const float* pred, const float* target, const float*
   return BLH_OK;
 }
 
+int blh_context_set_step_state(blh_context* ctx, const blh_step_state* dev_state) {
+  if (!ctx) return BLH_ERR_INVALID_ARGUMENT;
+  ctx->step_dev = dev_state ? &dev_state->rng_step : nullptr;
+  return BLH_OK;
+}
+
+int blh_clip_adam_step_captured(void* stream, float* params, float* grads, float* exp_avg,
+                                float* exp_avg_sq, int64_t count, const blh_step_state* dev_state,
+                                void* workspace, int64_t workspace_bytes, float* stats_out) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !dev_state || !workspace || count <= 0)
+    return BLH_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < SCRATCH_BYTES) return BLH_ERR_WORKSPACE;
+  const Scratch sc = carve_scratch(workspace);
+  int nparts = 0;
+  BLH_TRY(launch_sumsq((hipStream_t)stream, grads, count, sc.sumsq_part, &nparts));
+  return launch_clip_adam_dev((hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, count, dev_state,
+                              sc.sumsq_part, nparts, stats_out);
+}
+
 int blh_step_state_advance(void* stream, blh_step_state* dev_state) {
   if (!dev_state) return BLH_ERR_INVALID_ARGUMENT;
   return launch_step_state_advance((hipStream_t)stream, dev_state);

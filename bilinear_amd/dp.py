@@ -33,7 +33,14 @@ class GradBucketReducer:
     ``on_ready(offset, count)`` is called in backward order with contiguous ranges;
     ranges are merged until a bucket holds at least ``bucket_floats`` elements."""
 
-    def __init__(self, flat_grads, group=None, bucket_floats=1 << 20, force_collectives=False):
+    def __init__(self, flat_grads, group=None, bucket_floats=1 << 20, force_collectives=False,
+                 compress=None):
+        """``compress="bf16"``: every bucket is cast to bf16 (round to nearest even, HIP kernel),
+        averaged in bf16 and cast back — half the bytes on every xGMI link (configs 3-5)."""
+        if compress not in (None, "bf16"):
+            raise ValueError("compress must be None or 'bf16'")
+        self.compress = compress
+        self._half = None
         self.flat = flat_grads
         self.group = group
         self.bucket_floats = int(bucket_floats)
@@ -57,6 +64,15 @@ class GradBucketReducer:
             return
         view = self.flat[lo:hi]
         backend = dist.get_backend(self.group)
+        if self.compress == "bf16":
+            if self._half is None:
+                self._half = torch.empty(self.flat.numel(), dtype=torch.bfloat16, device=self.flat.device)
+            half = self._half[lo:hi]
+            self._cast(view, half, to_half=True)
+            op = dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM
+            work = dist.all_reduce(half, op=op, group=self.group, async_op=True)
+            self._works.append((work, ("half", lo, hi, backend != "nccl")))
+            return
         if backend == "nccl":
             work = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
             self._works.append((work, None))
@@ -101,9 +117,34 @@ class GradBucketReducer:
             self._pending = None
         for work, view in self._works:
             work.wait()
-            if view is not None:
+            if isinstance(view, tuple):            # compressed bucket: back to the fp32 arena
+                _, lo, hi, divide = view
+                self._cast(self.flat[lo:hi], self._half[lo:hi], to_half=False)
+                if divide:
+                    self.flat[lo:hi].div_(self.world)
+            elif view is not None:
                 view.div_(self.world)
         self._works = []
+
+    @staticmethod
+    def _cast(full, half, to_half):
+        """fp32 <-> bf16 on the current stream: the library's cast kernels on a HIP device
+        (bucket bounds are multiples of 64 elements), torch on the CPU (gloo tests)."""
+        if full.is_cuda:
+            import ctypes
+
+            from . import _native as N
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            if to_half:
+                N.check(N.lib().blh_cast_f32_to_bf16(st, N.ptr(full), N.ptr(half), full.numel()),
+                        "blh_cast_f32_to_bf16")
+            else:
+                N.check(N.lib().blh_cast_bf16_to_f32(st, N.ptr(half), N.ptr(full), full.numel()),
+                        "blh_cast_bf16_to_f32")
+        elif to_half:
+            half.copy_(full)
+        else:
+            full.copy_(half)
 
 
 class DataParallel:
@@ -117,8 +158,9 @@ class DataParallel:
     depend on the number of GPUs."""
 
     def __init__(self, module, optimizer, group=None, bucket_floats=1 << 20, max_norm=1.0,
-                 sync_bn=False, force_collectives=False):
+                 sync_bn=False, force_collectives=False, compress=None):
         self.force_collectives = bool(force_collectives)
+        self.compress = compress
         self.module = module
         self.optimizer = optimizer
         self.group = group
@@ -145,7 +187,8 @@ class DataParallel:
         eng.ensure(x.device)
         if self._reducer is None or self._reducer.flat.data_ptr() != eng.grads.data_ptr():
             self._reducer = GradBucketReducer(eng.grads, self.group, self.bucket_floats,
-                                              force_collectives=self.force_collectives)
+                                              force_collectives=self.force_collectives,
+                                              compress=self.compress)
         batch = x.shape[0]
         eng.row_offset = self.rank * batch
         sync = self._all_reduce_sum if (self.sync_bn and (self.world > 1 or self.force_collectives)) else None
@@ -166,3 +209,110 @@ class DataParallel:
                       self.max_norm, opt._t, opt._stats)
         opt._sync_step_state(eng)
         return pred, loss
+
+
+class CapturedDataParallelStep:
+    """The data-parallel step as ONE hipGraph (BASELINE configs[4]: "overlapped all-reduce +
+    hipGraph-captured train step"): forward, MSE, backward with the bucket all-reduces launched
+    from the grad-ready hook (RCCL calls are captured like kernels: torch's process group joins the
+    capture through events), clip + Adam.  Everything that changes per step lives in device memory
+    (``blh_step_state``: Adam step count and bias corrections, learning rate, dropout step —
+    advanced by the first node of the graph), the batch in static input buffers.
+
+        step = CapturedDataParallelStep(dp, per_rank_batch)
+        pred, loss = step(x_local, t_local)
+
+    BatchNorm statistics are per rank (SyncBN's host callbacks are not captured)."""
+
+    def __init__(self, dp, batch):
+        import ctypes
+
+        from . import _native as N
+        if dp.sync_bn:
+            raise RuntimeError("SyncBN is not capturable; use per-rank statistics")
+        self.dp, self.batch = dp, int(batch)
+        eng, opt = dp.module.engine, dp.optimizer
+        dev = next(dp.module.parameters()).device
+        eng.ensure(dev)
+        opt._ensure_moments(eng)
+        self.eng, self.opt = eng, opt
+        self.x = torch.zeros(batch, 32, dtype=torch.float32, device=dev)
+        self.t = torch.zeros(batch, 48, dtype=torch.float32, device=dev)
+        self.state = torch.zeros(ctypes.sizeof(N.StepState), dtype=torch.uint8, device=dev)
+        self._mirror = None
+        self._write_state()
+        eng.workspace(batch)
+        eng.scratch()
+        snap = [t.clone() for t in (eng.params, opt._exp_avg, opt._exp_avg_sq, eng.bn_running, eng.bn_nbt)]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):              # warm-up (kernel attributes, RCCL channels)
+            self._enqueue()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        for dst, src in zip((eng.params, opt._exp_avg, opt._exp_avg_sq, eng.bn_running, eng.bn_nbt), snap):
+            dst.copy_(src)
+        self._write_state()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.pred, self.loss = self._enqueue()
+
+    def _write_state(self):
+        from . import _native as N
+        g = self.opt.param_groups[0]
+        rng = int(self.eng.rng_step)
+        st = N.StepState(float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
+                         0.0 if self.dp.max_norm is None else float(self.dp.max_norm), int(self.opt._t),
+                         rng - 1 if rng > 0 else 2 ** 64 - 1, 0.0, 0.0)
+        host = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8)
+        self.state.copy_(host)                      # synchronous: rare (lr changes, out-of-band steps)
+        self._mirror = (float(g["lr"]), int(self.opt._t), rng)
+
+    def _enqueue(self):
+        import ctypes
+
+        from . import _native as N
+        dp, eng, opt = self.dp, self.eng, self.opt
+        lib = N.lib()
+        if dp._reducer is None or dp._reducer.flat.data_ptr() != eng.grads.data_ptr():
+            dp._reducer = GradBucketReducer(eng.grads, dp.group, dp.bucket_floats,
+                                            force_collectives=dp.force_collectives, compress=dp.compress)
+        N.check(lib.blh_step_state_advance(eng._stream(), N.ptr(self.state)), "blh_step_state_advance")
+        N.check(lib.blh_context_set_step_state(eng.ctx.handle, N.ptr(self.state)), "blh_context_set_step_state")
+        try:
+            eng.row_offset = dp.rank * self.batch
+            saved_step = eng.rng_step
+            eng.rng_step = 0                        # the device counter supplies the step
+            pred = eng.forward_train(self.x)
+            loss, dpred = eng.mse_loss_grad(pred, self.t)
+            dp._reducer.begin()
+            eng.backward(self.x, dpred, on_ready=dp._reducer.on_ready)
+            dp._reducer.reduce_scalars(loss)
+            dp._reducer.finish()
+            eng.rng_step = saved_step
+        finally:
+            N.check(lib.blh_context_set_step_state(eng.ctx.handle, None), "blh_context_set_step_state")
+        sc = eng.scratch()
+        N.check(lib.blh_clip_adam_step_captured(
+            eng._stream(), N.ptr(eng.params), N.ptr(eng.grads), N.ptr(opt._exp_avg), N.ptr(opt._exp_avg_sq),
+            eng.layout.total, N.ptr(self.state), N.ptr(sc), sc.numel(), N.ptr(opt._stats)),
+            "blh_clip_adam_step_captured")
+        return pred, loss
+
+    @torch.no_grad()
+    def __call__(self, x, target):
+        want = (float(self.opt.param_groups[0]["lr"]), int(self.opt._t), int(self.eng.rng_step))
+        if want != self._mirror:
+            self._write_state()
+        if x.data_ptr() != self.x.data_ptr():
+            self.x.copy_(x, non_blocking=True)
+        if target.data_ptr() != self.t.data_ptr():
+            self.t.copy_(target, non_blocking=True)
+        self.graph.replay()
+        self.opt._t += 1
+        self.opt._sync_step_state(self.eng)
+        self.eng.rng_step += 1
+        self.eng._saved_batch = None
+        self.eng.generation += 1
+        self._mirror = (self._mirror[0], int(self.opt._t), int(self.eng.rng_step))
+        return self.pred, self.loss

@@ -282,6 +282,18 @@ int blh_train_step_captured(blh_context* ctx, const blh_model_desc* d, void* str
                             void* workspace, int64_t workspace_bytes, float* pred,
                             float* loss_out, float* stats_out, int64_t batch);
 
+/* Pieces of the captured step for callers that interleave their own work (the data-parallel
+ * step puts the RCCL all-reduces between backward and the optimiser):
+ *   blh_context_set_step_state(ctx, dev_state): while dev_state is not NULL every forward /
+ *     backward entry point called with this context adds dev_state->rng_step (device memory) to
+ *     drop->step, exactly as blh_train_step_captured does — set it around a stream capture;
+ *   blh_clip_adam_step_captured: blh_clip_adam_step with the hyper-parameters, the step count and
+ *     the bias corrections read from dev_state (advance it first: blh_step_state_advance).     */
+int blh_context_set_step_state(blh_context* ctx, const blh_step_state* dev_state);
+int blh_clip_adam_step_captured(void* stream, float* params, float* grads, float* exp_avg,
+                                float* exp_avg_sq, int64_t count, const blh_step_state* dev_state,
+                                void* workspace, int64_t workspace_bytes, float* stats_out);
+
 /* ---- one heavy_linear stage on its own --------------------------------------------------
  * model/bilinear.py:7-13 as a stand-alone module: a_out = Dropout(ReLU(BN(a_in W^T + b))).
  * in/out features must be multiples of 4.  `workspace` (blh_heavy_workspace_bytes) keeps the

@@ -105,3 +105,36 @@ def test_bucket_merging_single_process():
         red.on_ready(lo, hi - lo)
     red.finish()
     assert red.launched == [(700, 1000), (200, 700), (0, 200)]
+
+
+def _worker_bf16(rank, world, port, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bilinear_amd.dp import GradBucketReducer
+        g = torch.Generator().manual_seed(100 + rank)
+        flat = torch.randn(4096, generator=g) * 1e-3
+        mine = flat.clone()
+        both = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        red = GradBucketReducer(flat, bucket_floats=1024, compress="bf16")
+        red.begin()
+        for lo in (3072, 2048, 1024, 0):
+            red.on_ready(lo, 1024)
+        red.finish()
+        want = 0.5 * (both[0].to(torch.bfloat16).float() + both[1].to(torch.bfloat16).float())
+        # sum of two bf16 values, rounded once to bf16 by the reduction, halved exactly
+        assert torch.allclose(flat, want, rtol=2 ** -7, atol=0)
+        assert len(red.launched) == 4
+        open(os.path.join(result_dir, "bf16_ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_compressed_buckets_world2_gloo(tmp_path):
+    """compress="bf16": buckets travel as bf16 (half the bytes), average = mean of the rounded
+    shards to one bf16 rounding."""
+    port = _free_port()
+    mp.spawn(_worker_bf16, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "bf16_ok0") and os.path.exists(tmp_path / "bf16_ok1")

@@ -227,6 +227,40 @@ def _worker_rccl(rank, world, port, out_dir):
         d = (res["sync"][0] - net.engine.params).abs().max().item()
         assert d <= 5e-3, d          # pre-BN biases move by up to ~lr per step on noise (H2)
         assert max(abs(a - b) for a, b in zip(res["sync"][2], ref_losses)) <= 1e-5 * ref_losses[0]
+
+        # the whole data-parallel step as one hipGraph, RCCL all-reduces captured with it
+        from bilinear_amd.dp import CapturedDataParallelStep
+        net_c, opt_c = _make(dev, cfg)
+        dpc = DataParallel(net_c, opt_c, bucket_floats=200000, force_collectives=True)
+        cap = CapturedDataParallelStep(dpc, cfg[2])
+        cap_losses = []
+        for i in range(3):
+            if i == 2:                           # lr-decay hook between replays
+                opt_c.param_groups[0]["lr"] = 5e-4
+            pred, loss = cap(x, t)
+            cap_losses.append(float(loss.item()))
+        net_e, opt_e = _make(dev, cfg)
+        dpe = DataParallel(net_e, opt_e, bucket_floats=200000)
+        for i in range(3):
+            if i == 2:
+                opt_e.param_groups[0]["lr"] = 5e-4
+            pe, le = dpe.train_step(x, t)
+        torch.cuda.synchronize()
+        assert torch.equal(net_c.engine.params, net_e.engine.params), "captured DP step != eager DP step"
+        assert torch.equal(opt_c._exp_avg_sq, opt_e._exp_avg_sq)
+        assert cap_losses[-1] == float(le.item())
+        assert int(net_c.encode[1].num_batches_tracked) == 3 and opt_c._t == 3
+
+        # bf16-compressed gradient buckets (configs 3-5): same step to bf16 accuracy
+        net_h, opt_h = _make(dev, cfg)
+        dph = DataParallel(net_h, opt_h, bucket_floats=200000, force_collectives=True, compress="bf16")
+        dph.train_step(x, t)
+        net_f, opt_f = _make(dev, cfg)
+        DataParallel(net_f, opt_f, bucket_floats=200000).train_step(x, t)
+        torch.cuda.synchronize()
+        gh, gf = net_h.engine.grads, net_f.engine.grads
+        rel = ((gh - gf).norm() / gf.norm()).item()
+        assert 0 < rel < 1e-2, rel                 # clipped gradients differ by bf16 rounding only
         open(os.path.join(out_dir, "rccl_ok"), "w").write("ok")
     finally:
         dist.destroy_process_group()
