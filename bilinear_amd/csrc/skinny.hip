@@ -51,17 +51,20 @@ __global__ __launch_bounds__(256) void decode_fwd_mse_kernel(
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // 16 k per step; two steps of loads in flight
-  for (int k = 0; k < kq; k += 32) {
-    float4 a[2][RT], b[2][NT];
+  // 32 k per chunk (two k-steps of 16), register double buffer: the loads of chunk c+1 are in
+  // flight while the MFMAs of chunk c issue (one wave per SIMD: nothing else hides the latency)
+  float4 a[2][2][RT], b[2][2][NT];
+  auto load_chunk = [&](int buf, int k) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
-      for (int i = 0; i < RT; ++i) a[u][i] = *reinterpret_cast<const float4*>(arow[i] + k + 16 * u);
+      for (int i = 0; i < RT; ++i) a[buf][u][i] = *reinterpret_cast<const float4*>(arow[i] + k + 16 * u);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
-        if (t < ntiles) b[u][t] = *reinterpret_cast<const float4*>(wrow[t] + k + 16 * u);
+        if (t < ntiles) b[buf][u][t] = *reinterpret_cast<const float4*>(wrow[t] + k + 16 * u);
     }
+  };
+  auto mfma_chunk = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -69,11 +72,20 @@ __global__ __launch_bounds__(256) void decode_fwd_mse_kernel(
 #pragma unroll
         for (int t = 0; t < NT; ++t)
           if (t < ntiles) {
-            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].x, b[u][t].x, acc[i][t], 0, 0, 0);
-            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].y, b[u][t].y, acc[i][t], 0, 0, 0);
-            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].z, b[u][t].z, acc[i][t], 0, 0, 0);
-            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].w, b[u][t].w, acc[i][t], 0, 0, 0);
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[buf][u][i].x, b[buf][u][t].x, acc[i][t], 0, 0, 0);
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[buf][u][i].y, b[buf][u][t].y, acc[i][t], 0, 0, 0);
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[buf][u][i].z, b[buf][u][t].z, acc[i][t], 0, 0, 0);
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[buf][u][i].w, b[buf][u][t].w, acc[i][t], 0, 0, 0);
           }
+  };
+  load_chunk(0, 0);
+  for (int k = 0; k < kq; k += 64) {       // kq % 64 == 0 (W % 256 == 0) or the tail below
+    if (k + 32 < kq) load_chunk(1, k + 32);
+    mfma_chunk(0);
+    if (k + 32 < kq) {
+      if (k + 64 < kq) load_chunk(0, k + 64);
+      mfma_chunk(1);
+    }
   }
   // C layout of the 16x16 MFMA: column = lane & 15, row = 4 (lane >> 4) + reg
 #pragma unroll
@@ -140,7 +152,8 @@ int decode_fwd_rows_per_block(int64_t batch) {
 }
 
 bool decode_fwd_supported(int64_t batch, int W, int OF) {
-  return W % 64 == 0 && OF % 4 == 0 && OF >= 4 && OF <= 64 && ceil_div(batch, 64) <= 1024;
+  // (a wave's share of the reduction, W / 4, is walked in chunks of 32)
+  return W % 128 == 0 && OF % 4 == 0 && OF >= 4 && OF <= 64 && ceil_div(batch, 64) <= 1024;
 }
 
 int launch_decode_fwd_mse(hipStream_t s, const float* A, const float* Wd, const float* bd,
