@@ -188,7 +188,7 @@ def skinny_rooflines(batch, width, reps):
                                            part.data_ptr(), ctypes.byref(rows), B, W, IF)),
         ("decode_fwd_mse (Linear %d->48 + MSE loss + dpred)" % W, 4.0 * B * (W + 3 * OF),
          lambda: lib.blh_skinny_decode_fwd_mse(st, A.data_ptr(), Wd.data_ptr(), bd.data_ptr(), t.data_ptr(),
-                                               pred.data_ptr(), dpred.data_ptr(), loss.data_ptr(),
+                                               pred.data_ptr(), dpred.data_ptr(), None,
                                                ws.data_ptr(), wsb, B, W, OF)),
         ("decode_bwd (dWd = dP^T A, dA = dP Wd)", 4.0 * B * (OF + 2 * W),
          lambda: lib.blh_skinny_decode_bwd(st, dpred.data_ptr(), A.data_ptr(), Wd.data_ptr(), dWd.data_ptr(),

@@ -1473,7 +1473,7 @@ int blh_skinny_decode_fwd_mse(void* stream, const float* A, const float* Wd, con
                               const float* target, float* pred, float* dpred, float* loss_out,
                               void* workspace, int64_t workspace_bytes, int64_t batch, int32_t width,
                               int32_t out_features) {
-  if (!A || !Wd || !bd || !target || !pred || !dpred || !loss_out || !workspace || batch <= 0)
+  if (!A || !Wd || !bd || !target || !pred || !dpred || !workspace || batch <= 0)
     return BLH_ERR_INVALID_ARGUMENT;
   if (workspace_bytes < blh_skinny_workspace_bytes(batch, width, 32, out_features)) return BLH_ERR_WORKSPACE;
   if (!decode_fwd_supported(batch, width, out_features)) return BLH_ERR_SHAPE;
@@ -1483,7 +1483,8 @@ int blh_skinny_decode_fwd_mse(void* stream, const float* A, const float* Wd, con
   int np = 0;
   BLH_TRY(launch_decode_fwd_mse((hipStream_t)stream, A, Wd, bd, target, pred, dpred, loss_part, part,
                                 batch, width, out_features, (float)(2.0 / denom), &np));
-  return launch_loss_finalize((hipStream_t)stream, loss_part, np, denom, loss_out);
+  // (the training step folds this tiny reduction into the optimiser kernel; NULL skips it)
+  return loss_out ? launch_loss_finalize((hipStream_t)stream, loss_part, np, denom, loss_out) : BLH_OK;
 }
 
 int blh_skinny_decode_bwd(void* stream, const float* dpred, const float* A, const float* Wd,

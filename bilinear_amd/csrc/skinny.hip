@@ -7,34 +7,36 @@
 // MFMA GEMM needed a split reduction (8 slabs of [B,48]) plus a finishing kernel for it, because
 // a 128-row tile with N = 48 leaves only B/128 workgroups.
 //
-// Structure: workgroup = 4 waves over 16*RT rows; the four waves split the reduction index
-// (K/4 each), so that 1024 waves — one per SIMD at B = 4096 — stream disjoint 16-byte pieces of A
+// Structure: workgroup = 8 waves over 16*RT rows; the eight waves split the reduction index
+// (K/8 each), so that 2048 waves — two per SIMD at B = 4096 — stream disjoint 16-byte pieces of A
 // straight into registers (no LDS staging: nothing is shared between waves) and feed
 // v_mfma_f32_16x16x4_f32 (exact fp32; 48 = 3 column tiles of 16, no padding waste).  A lane's
 // float4 (4 consecutive k of its row) serves 4 MFMAs: MFMA j contracts k = k0 + 4 q + j over the
 // four lane quarters q, the same map on both operands.  Wd (196 KB) is re-read by every workgroup
-// from L2.  The four partial accumulators meet in LDS, then 256 threads finish 16*RT x 48 outputs.
+// from L2.  The eight partial accumulators meet in LDS, then 256 threads finish 16*RT x 48 outputs.
 #include "common.h"
 
 namespace blh {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+static constexpr int DEC_WAVES = 8;     // the reduction index is split over this many waves
+
 template <int RT>
-__global__ __launch_bounds__(256) void decode_fwd_mse_kernel(
+__global__ __launch_bounds__(64 * DEC_WAVES) void decode_fwd_mse_kernel(
     const float* __restrict__ A, const float* __restrict__ Wd, const float* __restrict__ bd,
     const float* __restrict__ target, float* __restrict__ pred, float* __restrict__ dpred,
     float* __restrict__ loss_part, float* __restrict__ dbias_part, int64_t batch, int W, int OF,
     float scale) {
   constexpr int ROWS = 16 * RT, NT = 4;             // up to 4 column tiles (OF <= 64)
-  __shared__ __attribute__((aligned(16))) float red[4][ROWS][64];
+  __shared__ __attribute__((aligned(16))) float red[DEC_WAVES][ROWS][64];
   __shared__ float colred[16][64];
-  __shared__ float lossred[4];
+  __shared__ float lossred[DEC_WAVES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * ROWS;
   const int ntiles = (OF + 15) >> 4;
-  const int kq = W >> 2;                            // reduction range of one wave (W % 64 == 0)
+  const int kq = W / DEC_WAVES;                     // reduction range of one wave (multiple of 32)
   const int kbeg = wave * kq;
 
   const float* arow[RT];
@@ -97,12 +99,12 @@ __global__ __launch_bounds__(256) void decode_fwd_mse_kernel(
         for (int g = 0; g < 4; ++g) red[wave][i * 16 + 4 * q + g][t * 16 + r] = acc[i][t][g];
   __syncthreads();
 
-  // finish: thread = (row, 4 columns); 16 column groups x 16 rows per pass
-  const int cg = tid & 15, rr = tid >> 4;
+  // finish: thread = (row, 4 columns); 16 column groups x 16 rows per pass (the first 256 threads)
+  const int cg = tid & 15, rr = (tid >> 4) & 15;
   const int col = cg * 4;
   float sq = 0.f;
   float4 dsum = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (col < OF) {
+  if (col < OF && tid < 256) {
     const float4 bv = *reinterpret_cast<const float4*>(bd + col);
 #pragma unroll
     for (int pass = 0; pass < RT; ++pass) {
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void decode_fwd_mse_kernel(
       const int64_t row = row0 + lr;
       float4 v = bv;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
+      for (int w = 0; w < DEC_WAVES; ++w) {
         const float4 u = *reinterpret_cast<const float4*>(&red[w][lr][col]);
         v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
       }
@@ -132,9 +134,9 @@ __global__ __launch_bounds__(256) void decode_fwd_mse_kernel(
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
     if (lane == 0) lossred[wave] = sq;
-    *reinterpret_cast<float4*>(&colred[rr][col]) = dsum;
+    if (tid < 256) *reinterpret_cast<float4*>(&colred[rr][col]) = dsum;
     __syncthreads();
-    if (tid == 0) loss_part[blockIdx.x] = (lossred[0] + lossred[1]) + (lossred[2] + lossred[3]);
+    if (tid == 0) loss_part[blockIdx.x] = (lossred[0] + lossred[1]) + (lossred[2] + lossred[3]);   // waves 4.. hold no rows
     if (dbias_part && tid < OF) {
       float s = 0.f;
 #pragma unroll
@@ -152,8 +154,8 @@ int decode_fwd_rows_per_block(int64_t batch) {
 }
 
 bool decode_fwd_supported(int64_t batch, int W, int OF) {
-  // (a wave's share of the reduction, W / 4, is walked in chunks of 32)
-  return W % 128 == 0 && OF % 4 == 0 && OF >= 4 && OF <= 64 && ceil_div(batch, 64) <= 1024;
+  // (a wave's share of the reduction, W / 8, is walked in chunks of 32)
+  return W % (32 * DEC_WAVES) == 0 && OF % 4 == 0 && OF >= 4 && OF <= 64 && ceil_div(batch, 64) <= 1024;
 }
 
 int launch_decode_fwd_mse(hipStream_t s, const float* A, const float* Wd, const float* bd,
@@ -163,13 +165,13 @@ int launch_decode_fwd_mse(hipStream_t s, const float* A, const float* Wd, const 
   const int rows = decode_fwd_rows_per_block(batch);
   const int blocks = (int)ceil_div(batch, rows);
   if (rows == 16)
-    hipLaunchKernelGGL(decode_fwd_mse_kernel<1>, dim3(blocks), dim3(256), 0, s, A, Wd, bd, target, pred,
+    hipLaunchKernelGGL(decode_fwd_mse_kernel<1>, dim3(blocks), dim3(64 * DEC_WAVES), 0, s, A, Wd, bd, target, pred,
                        dpred, loss_part, dbias_part, batch, W, OF, scale);
   else if (rows == 32)
-    hipLaunchKernelGGL(decode_fwd_mse_kernel<2>, dim3(blocks), dim3(256), 0, s, A, Wd, bd, target, pred,
+    hipLaunchKernelGGL(decode_fwd_mse_kernel<2>, dim3(blocks), dim3(64 * DEC_WAVES), 0, s, A, Wd, bd, target, pred,
                        dpred, loss_part, dbias_part, batch, W, OF, scale);
   else
-    hipLaunchKernelGGL(decode_fwd_mse_kernel<4>, dim3(blocks), dim3(256), 0, s, A, Wd, bd, target, pred,
+    hipLaunchKernelGGL(decode_fwd_mse_kernel<4>, dim3(blocks), dim3(64 * DEC_WAVES), 0, s, A, Wd, bd, target, pred,
                        dpred, loss_part, dbias_part, batch, W, OF, scale);
   BLH_HIP_TRY(hipGetLastError());
   if (nparts) *nparts = blocks;

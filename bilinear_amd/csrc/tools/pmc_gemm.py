@@ -1,8 +1,18 @@
 #!/usr/bin/env python3
-"""Developer tool: launch the forward GEMM of the W x W Linear in its three fp32-accurate forms of the W x W Linear a few times so that
-`PYTHONPATH=. rocprofv3 --pmc ... -- python3 bilinear_amd/csrc/tools/pmc_gemm.py` can attribute counters to them; with `--sum DIR`
-summarise a counter_collection.csv directory per kernel."""
-import csv, ctypes, glob, sys, collections
+"""Developer tool: launch the hidden-layer GEMMs exactly as the library ships them (fp32 ring
+kernel: forward with BatchNorm partials, dgrad, wgrad; bf16-storage kernel: forward) a few times,
+so that
+
+    PYTHONPATH=. rocprofv3 --pmc <counters> --kernel-trace --output-format csv -d <dir> -- \
+        python3 bilinear_amd/csrc/tools/pmc_gemm.py [B [W]]
+
+can attribute counters to them; `pmc_gemm.py --sum <dir>` prints the mean per launch of every
+counter per kernel (summed over the chip)."""
+import collections
+import csv
+import ctypes
+import glob
+import sys
 
 
 def summarise(d):
@@ -12,7 +22,7 @@ def summarise(d):
             n = r["Kernel_Name"]
             if "gemm" not in n:
                 continue
-            n = n.replace("void blh::", "").split("(")[0][:70]
+            n = n.replace("void blh::", "").split("(")[0][:80]
             acc[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for n in sorted(acc):
         print(n)
@@ -28,18 +38,27 @@ def main():
     from bilinear_amd import _native as N
     lib = N.lib()
     dev = torch.device("cuda:0")
-    B, W = 4096, 1024
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    W = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    A = torch.randn(B, W, device=dev); Wt = torch.randn(W, W, device=dev) * 0.03
-    bias = torch.randn(W, device=dev); Z = torch.empty(B, W, device=dev)
-    ws16 = torch.empty(lib.blh_gemm_fp16x2_workspace_bytes(), dtype=torch.uint8, device=dev)
-    for i in range(12):
-        N.check(lib.blh_gemm_fp16x2(st, A.data_ptr(), W, 0, Wt.data_ptr(), W, 0, Z.data_ptr(), W, B, W, W, 1,
-                                    bias.data_ptr(), None, 0, ws16.data_ptr(), 1 if i else 0), "fp16x2 gemm")
-        N.check(lib.blh_gemm_bf16x3(st, A.data_ptr(), W, 0, Wt.data_ptr(), W, 0, Z.data_ptr(), W, B, W, W, 1,
-                                    bias.data_ptr(), None, 0), "split gemm")
-        N.check(lib.blh_gemm_f32(st, A.data_ptr(), W, 0, Wt.data_ptr(), W, 0, Z.data_ptr(), W, B, W, W, 1,
-                                 bias.data_ptr(), None, 0), "f32 gemm")
+    A = torch.randn(B, W, device=dev)
+    Wt = torch.randn(W, W, device=dev) * 0.03
+    bias = torch.randn(W, device=dev)
+    Z = torch.empty(B, W, device=dev)
+    stat = torch.empty((B + 127) // 128, 2, W, device=dev)
+    splits = max(1, min((256 * 128 * 128) // (W * W), B // 128))
+    slabs = torch.empty(splits, W, W, device=dev)
+    Ah, Wh = A.to(torch.bfloat16), Wt.to(torch.bfloat16)
+    Zh = torch.empty(B, W, dtype=torch.bfloat16, device=dev)
+    for _ in range(12):
+        N.check(lib.blh_linear_fwd_stats(st, A.data_ptr(), Wt.data_ptr(), bias.data_ptr(), Z.data_ptr(),
+                                         stat.data_ptr(), B, W, W), "fwd")
+        N.check(lib.blh_gemm_f32(st, A.data_ptr(), W, 0, Wt.data_ptr(), W, 1, Z.data_ptr(), W, B, W, W, 1,
+                                 None, None, 0), "dgrad")
+        N.check(lib.blh_gemm_f32(st, A.data_ptr(), W, 1, Z.data_ptr(), W, 1, slabs.data_ptr(), W, W, W, B,
+                                 splits, None, None, 0), "wgrad")
+        N.check(lib.blh_gemm_bf16s(st, Ah.data_ptr(), W, 0, Wh.data_ptr(), W, 0, Zh.data_ptr(), W, 1, B, W, W, 1,
+                                   bias.data_ptr(), None, 0, stat.data_ptr()), "bf16s fwd")
     torch.cuda.synchronize()
 
 

@@ -378,6 +378,7 @@ int blh_cast_bf16_to_f32(void* stream, const uint16_t* src, float* dst, int64_t 
  * W -> 48) with train_bilinear.py:78 (MSELoss) fused into the decode forward.
  *   encode_fwd      Z[B,W] = x[B,in] W0^T + b0, BatchNorm partials per `*stat_tile_rows`-row tile
  *   decode_fwd_mse  pred = A Wd^T + bd ; dpred = 2 (pred - target)/(B out) ; *loss_out = MSE
+ *                   (loss_out may be NULL: the partial sums stay in the workspace)
  *   decode_bwd      dWd[out,W] = dpred^T A ; dA[B,W] = dpred Wd
  *   encode_wgrad    dW0[W,in] = dZ^T x
  * `workspace`: blh_skinny_workspace_bytes (split-reduction slabs, partials).               */
