@@ -9,215 +9,12 @@
 
 #include "common.h"
 #include "gemm_bf16s_kernel.h"
+#include "api_layout.h"
 
 namespace blh {
 
 thread_local int g_last_hip_error = 0;
 thread_local hipEvent_t tl_stop_event = nullptr;
-
-static constexpr int64_t ARENA_ALIGN = 64;   // floats (256 B)
-static constexpr int64_t WS_ALIGN = 256;     // bytes
-
-struct TensorInfo {
-  char name[64];
-  int64_t offset, rows, cols;
-};
-
-struct HeavyOffsets {
-  int64_t w, b, gamma, beta;
-  int fan_in;
-};
-
-struct ArenaLayout {
-  std::vector<TensorInfo> tensors;
-  std::vector<HeavyOffsets> heavy;
-  int64_t dec_w, dec_b;
-  int64_t total;
-};
-
-static int check_desc(const blh_model_desc* d) {
-  if (!d) return BLH_ERR_INVALID_ARGUMENT;
-  if (d->num_blocks < 0 || d->width <= 0 || d->in_features <= 0 || d->out_features <= 0)
-    return BLH_ERR_INVALID_ARGUMENT;
-  if (d->width % 64 != 0 || d->in_features % 4 != 0 || d->out_features % 4 != 0)
-    return BLH_ERR_SHAPE;
-  if (d->out_features > 64) return BLH_ERR_SHAPE;   // decode uses one 64-wide column tile
-  if (1 + 2 * d->num_blocks > 32) return BLH_ERR_SHAPE;
-  if (d->gemm_dtype < 0 || d->gemm_dtype > 4) return BLH_ERR_INVALID_ARGUMENT;
-  return BLH_OK;
-}
-
-static void heavy_prefix(int i, char* buf, size_t cap) {
-  if (i == 0) snprintf(buf, cap, "encode");
-  else snprintf(buf, cap, "bilinear.%d.%d", (i - 1) / 2, (i - 1) % 2);
-}
-
-static ArenaLayout make_layout(const blh_model_desc* d) {
-  ArenaLayout L;
-  int64_t off = 0;
-  const int nh = 1 + 2 * d->num_blocks;
-  auto add = [&](const char* prefix, const char* leaf, int64_t rows, int64_t cols) {
-    TensorInfo t;
-    snprintf(t.name, sizeof(t.name), "%s.%s", prefix, leaf);
-    t.offset = off; t.rows = rows; t.cols = cols;
-    L.tensors.push_back(t);
-    const int64_t at = off;
-    off = round_up(off + rows * cols, ARENA_ALIGN);
-    return at;
-  };
-  for (int i = 0; i < nh; ++i) {
-    char pre[48];
-    heavy_prefix(i, pre, sizeof(pre));
-    HeavyOffsets h;
-    h.fan_in = (i == 0) ? d->in_features : d->width;
-    h.w = add(pre, "0.weight", d->width, h.fan_in);
-    h.b = add(pre, "0.bias", d->width, 1);
-    h.gamma = add(pre, "1.weight", d->width, 1);
-    h.beta = add(pre, "1.bias", d->width, 1);
-    L.heavy.push_back(h);
-  }
-  L.dec_w = add("decode", "weight", d->out_features, d->width);
-  L.dec_b = add("decode", "bias", d->out_features, 1);
-  L.total = off;
-  return L;
-}
-
-// ------------------------------------------------------------ workspace ----
-struct Workspace {
-  std::vector<float*> Z, A;       // per heavy: pre-BN output, activation (skip added)
-  std::vector<float*> bn_saved;   // per heavy: [4][W] mean, invstd, scale, shift
-  float* stat_part;               // [tiles_m][2][W]
-  float* G0; float* G1;
-  std::vector<float*> dZ;         // per heavy stage: no buffer is reused inside one backward, so
-                                  // the side-stream weight gradients impose no wait on the main stream
-  float* bn_part;                 // [chunks][2][W]
-  float* dz_colsum_part;          // [stage][chunks][W]
-  float* slabs;                   // split-K partial products
-  float* dpred;                   // [B][out]
-  float* loss_part;               // [4096]
-  double* sumsq_part;             // [1024]
-  float* colsum_part;             // [ceil(B/256)][out]
-  double* sync_buf;               // [2][W] fp64 (SyncBN exchange; also used as float [2][W])
-  std::vector<float*> stage_slabs; // per stage (+ decode): split-K wgrad slabs kept until grads_finish
-  float* dec_bias_part;           // [blocks][out] partial sums of dpred (fused step)
-  // gemm_dtype 3: max |value| partials of the GEMM operand tensors (see gemm_f16x2_kernel.h)
-  std::vector<float*> amax_A;     // per heavy stage: activation A_l (written by bn_apply)
-  float* amax_dZ[2];              // dZ / dZ2 (written by bn_bwd_apply)
-  float* amax_W;                  // [nh][WAMAX_PARTS], hidden weights (stage 0 unused)
-  int amax_parts;
-  int64_t bytes;
-};
-
-struct Splits { int splits, k_per; };
-// every reduction slab is a whole number of K tiles of the widest kernel (gemm_f32_ring.h: 64)
-static constexpr int64_t SPLIT_GRAIN = 64;
-static Splits pick_splits(int64_t batch, int64_t tiles) {
-  int64_t want = std::max<int64_t>(1, ceil_div(256, tiles));
-  int64_t max_splits = std::max<int64_t>(1, batch / 128);
-  int64_t s = std::min(want, max_splits);
-  int64_t k_per = round_up(ceil_div(batch, s), SPLIT_GRAIN);
-  s = ceil_div(batch, k_per);
-  return Splits{(int)s, (int)k_per};
-}
-
-// Small-batch Linear forward / dgrad (M = batch rows, N = W columns, reduction K): when the
-// 128x128 output tiles cover less than half of the 256 CUs, split the reduction so that about
-// one workgroup per CU is in flight.  Returns splits == 1 for the ordinary path.
-static Splits small_m_splits(int64_t batch, int W, int K) {
-  const int64_t tiles = ceil_div(batch, 128) * ceil_div(W, 128);
-  if (tiles >= 128 || K < 64) return Splits{1, K};
-  int64_t s = std::min<int64_t>(ceil_div(256, tiles), K / SPLIT_GRAIN);
-  int64_t k_per = round_up(ceil_div(K, s), SPLIT_GRAIN);
-  s = ceil_div(K, k_per);
-  return Splits{(int)s, (int)k_per};
-}
-
-// decode forward: split W so that (B/128) * splits is about one workgroup per CU
-static Splits decode_fwd_splits(int64_t batch, int W) {
-  int64_t want = std::max<int64_t>(1, ceil_div(256, ceil_div(batch, 128)));
-  int64_t s = std::min<int64_t>(want, std::max<int64_t>(1, W / 128));
-  int64_t k_per = round_up(ceil_div(W, s), SPLIT_GRAIN);
-  s = ceil_div(W, k_per);
-  return Splits{(int)s, (int)k_per};
-}
-
-static int64_t slab_floats(const blh_model_desc* d, int64_t batch) {
-  const int64_t W = d->width;
-  const Splits hs = pick_splits(batch, ceil_div(W, 128) * ceil_div(W, 128));
-  const Splits es = pick_splits(batch, ceil_div(W, 128) * ceil_div(d->in_features, 32));
-  const Splits ds = pick_splits(batch, ceil_div(d->out_features, 64) * ceil_div(W, 128));
-  int64_t m = hs.splits * W * W;
-  m = std::max(m, es.splits * W * (int64_t)d->in_features);
-  m = std::max(m, ds.splits * (int64_t)d->out_features * W);
-  m = std::max(m, decode_fwd_splits(batch, d->width).splits * batch * d->out_features);
-  m = std::max(m, small_m_splits(batch, d->width, d->width).splits * batch * W);
-  return m;
-}
-
-static Workspace carve(const blh_model_desc* d, int64_t batch, void* base) {
-  Workspace ws;
-  const int nh = 1 + 2 * d->num_blocks;
-  const int64_t W = d->width;
-  char* p = (char*)base;
-  int64_t off = 0;
-  auto take = [&](int64_t bytes) {
-    char* r = p ? p + off : nullptr;
-    off += round_up(bytes, WS_ALIGN);
-    return r;
-  };
-  const int64_t act = batch * W * (int64_t)sizeof(float);
-  for (int i = 0; i < nh; ++i) ws.Z.push_back((float*)take(act));
-  for (int i = 0; i < nh; ++i) ws.A.push_back((float*)take(act));
-  for (int i = 0; i < nh; ++i) ws.bn_saved.push_back((float*)take(4 * W * sizeof(float)));
-  ws.stat_part = (float*)take(ceil_div(batch, 64) * 2 * W * sizeof(float));
-  ws.G0 = (float*)take(act);
-  ws.G1 = (float*)take(act);
-  for (int i = 0; i < nh; ++i) ws.dZ.push_back((float*)take(act));
-  const int64_t chunks = ew_num_row_chunks(batch);
-  ws.bn_part = (float*)take(chunks * 2 * W * sizeof(float));
-  ws.dz_colsum_part = (float*)take((int64_t)nh * chunks * W * sizeof(float));
-  ws.slabs = (float*)take(slab_floats(d, batch) * sizeof(float));
-  ws.dpred = (float*)take(batch * d->out_features * sizeof(float));
-  ws.loss_part = (float*)take(4096 * sizeof(float));
-  ws.sumsq_part = (double*)take(SUMSQ_MAX_PARTS * sizeof(double));
-  ws.colsum_part = (float*)take(ceil_div(batch, 256) * d->out_features * sizeof(float));
-  ws.sync_buf = (double*)take(2 * W * sizeof(double));
-  for (int i = 0; i <= nh; ++i) {
-    int64_t M, N, tiles;
-    if (i == nh) { M = d->out_features; N = W; tiles = ceil_div(M, 64) * ceil_div(N, 128); }
-    else if (i == 0) { M = W; N = d->in_features; tiles = ceil_div(M, 128) * ceil_div(N, 32); }
-    else { M = W; N = W; tiles = ceil_div(M, 128) * ceil_div(N, 128); }
-    const Splits sp = pick_splits(batch, tiles);
-    ws.stage_slabs.push_back(sp.splits > 1 ? (float*)take(sp.splits * M * N * sizeof(float)) : nullptr);
-  }
-  ws.dec_bias_part = (float*)take(1026 * d->out_features * sizeof(float));
-  ws.amax_parts = 0;
-  ws.amax_dZ[0] = ws.amax_dZ[1] = ws.amax_W = nullptr;
-  if (d->gemm_dtype == 3) {
-    ws.amax_parts = ew_num_amax_parts(batch, (int)W);
-    for (int i = 0; i < nh; ++i) ws.amax_A.push_back((float*)take(ws.amax_parts * sizeof(float)));
-    ws.amax_dZ[0] = (float*)take(ws.amax_parts * sizeof(float));
-    ws.amax_dZ[1] = (float*)take(ws.amax_parts * sizeof(float));
-    ws.amax_W = (float*)take((int64_t)nh * WAMAX_PARTS * sizeof(float));
-  } else {
-    for (int i = 0; i < nh; ++i) ws.amax_A.push_back(nullptr);
-  }
-  ws.bytes = off;
-  return ws;
-}
-
-// small scratch for entry points that take only a workspace pointer (no model)
-struct Scratch {
-  float* loss_part;
-  double* sumsq_part;
-};
-static constexpr int64_t SCRATCH_BYTES = 4096 * sizeof(float) + SUMSQ_MAX_PARTS * sizeof(double);
-static Scratch carve_scratch(void* base) {
-  Scratch s;
-  s.loss_part = (float*)base;
-  s.sumsq_part = (double*)((char*)base + 4096 * sizeof(float));
-  return s;
-}
 
 // SyncBN plumbing of the current call (data parallel): statistics over `global_batch` rows,
 // exchanged by the host callback
@@ -638,62 +435,6 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
 // rounding), the parameters, their gradients (fp32 slabs of the weight-gradient GEMM), Adam and
 // the loss stay fp32.  Gradients need no loss scaling: bf16 keeps fp32's exponent range.
 // =================================================================================================
-struct WorkspaceH {
-  uint16_t* wsh;                    // bf16 image of the whole parameter arena (refreshed per forward)
-  uint16_t* xh;                     // [B][in] network input
-  std::vector<uint16_t*> Z, A, dZ;  // per heavy stage, [B][W]
-  std::vector<float*> bn_saved;     // per heavy stage [4][W]
-  uint16_t* G0; uint16_t* G1;
-  float* stat_part; float* bn_part; float* dz_colsum_part; float* slabs;
-  float* dpred; uint16_t* dpredh;   // [B][out] fp32 and its bf16 image
-  float* loss_part; double* sumsq_part; float* colsum_part;
-  int64_t bytes;
-};
-
-static int64_t slab_floats_h(const blh_model_desc* d, int64_t batch) {
-  const int64_t W = d->width;
-  const Splits hs = pick_splits(batch, ceil_div(W, 128) * ceil_div(W, 128));
-  const Splits es = pick_splits(batch, ceil_div(W, 128));
-  int64_t m = hs.splits * W * W;
-  m = std::max(m, es.splits * W * (int64_t)d->in_features);
-  m = std::max(m, es.splits * (int64_t)d->out_features * W);
-  return m;
-}
-
-static WorkspaceH carve_h(const blh_model_desc* d, int64_t batch, void* base) {
-  WorkspaceH ws;
-  const int nh = 1 + 2 * d->num_blocks;
-  const int64_t W = d->width;
-  char* p = (char*)base;
-  int64_t off = 0;
-  auto take = [&](int64_t bytes) {
-    char* r = p ? p + off : nullptr;
-    off += round_up(bytes, WS_ALIGN);
-    return r;
-  };
-  const int64_t act = batch * W * 2;
-  ws.wsh = (uint16_t*)take(make_layout(d).total * 2);
-  ws.xh = (uint16_t*)take(batch * d->in_features * 2);
-  for (int i = 0; i < nh; ++i) ws.Z.push_back((uint16_t*)take(act));
-  for (int i = 0; i < nh; ++i) ws.A.push_back((uint16_t*)take(act));
-  for (int i = 0; i < nh; ++i) ws.dZ.push_back((uint16_t*)take(act));
-  for (int i = 0; i < nh; ++i) ws.bn_saved.push_back((float*)take(4 * W * sizeof(float)));
-  ws.G0 = (uint16_t*)take(act);
-  ws.G1 = (uint16_t*)take(act);
-  ws.stat_part = (float*)take(ceil_div(batch, 64) * 2 * W * sizeof(float));
-  const int64_t chunks = ew_num_row_chunks_h(batch);
-  ws.bn_part = (float*)take(chunks * 2 * W * sizeof(float));
-  ws.dz_colsum_part = (float*)take((int64_t)nh * chunks * W * sizeof(float));
-  ws.slabs = (float*)take(slab_floats_h(d, batch) * sizeof(float));
-  ws.dpred = (float*)take(batch * d->out_features * sizeof(float));
-  ws.dpredh = (uint16_t*)take(batch * d->out_features * 2);
-  ws.loss_part = (float*)take(4096 * sizeof(float));
-  ws.sumsq_part = (double*)take(SUMSQ_MAX_PARTS * sizeof(double));
-  ws.colsum_part = (float*)take(ceil_div(batch, 256) * d->out_features * sizeof(float));
-  ws.bytes = off;
-  return ws;
-}
-
 static int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
                      float* bn_running, int64_t* nbt, const float* x, const blh_dropout* drop,
                      float momentum, const WorkspaceH& ws, float* pred, int64_t batch, bool train) {

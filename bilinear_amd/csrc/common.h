@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/bilinear_hip.h"
+#include "host_util.h"
 
 namespace blh {
 
@@ -42,8 +43,6 @@ static inline void launch_kernel(K kern, dim3 grid, dim3 block, size_t lds, hipS
   else hipLaunchKernelGGL(kern, grid, block, lds, s, args...);
 }
 
-static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
-static inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 
 // ---------------------------------------------------------------- GEMM -----
 enum Layout : int { ROWK = 0, KROW = 1 };
@@ -103,13 +102,7 @@ __host__ __device__ inline uint64_t dropout_step(const DropoutSrc& d) {
 #endif
 }
 
-static constexpr int EW_COLS_PER_BLOCK = 256;    // 64 lanes x float4, 4 waves share the rows
-int ew_row_chunk(int64_t batch);                 // rows handled by one block (multiple of 32)
-int ew_num_row_chunks(int64_t batch);
-// bf16-storage kernels (512 columns per block): smaller row chunks, up to 1024 of them, so that
-// the grid still holds several blocks per CU at W = 1024
-int ew_row_chunk_h(int64_t batch);
-int ew_num_row_chunks_h(int64_t batch);
+// (row chunking of the streaming kernels: host_util.h)
 
 // forward BN: merge per-tile (mean, M2) -> batch mean / invstd, scale/shift, running stats
 int launch_bn_fwd_finalize(hipStream_t s, const float* stat_part, int tiles, int tile_rows,
@@ -121,8 +114,6 @@ int launch_bn_fwd_finalize(hipStream_t s, const float* stat_part, int tiles, int
 // (nbt, if not null, is incremented once: num_batches_tracked of this BN layer)
 // gemm_dtype 3: the streaming BatchNorm kernels can emit max |value| partials of what they write
 // (one per wave: ew_num_amax_parts() floats), from which the fp16-split GEMM picks its scale
-int ew_num_amax_parts(int64_t batch, int W);
-static constexpr int WAMAX_PARTS = 64;
 int launch_wamax(hipStream_t s, const float* W, int64_t w_stride, int layers, int64_t count,
                  float* part);
 int launch_bn_apply_train(hipStream_t s, const float* Z, const float* scale, const float* shift,
@@ -233,6 +224,5 @@ int launch_mpjpe(hipStream_t s, const float* pred, const float* target, const fl
 int launch_segment_sum(hipStream_t s, const float* dist, const int32_t* ids, int64_t batch,
                        int segments, double* sum, int64_t* count);
 int launch_dropout_mask(hipStream_t s, uint8_t* out, int64_t batch, int W, const DropoutSrc& drop);
-static constexpr int SUMSQ_MAX_PARTS = 1024;
 
 }  // namespace blh

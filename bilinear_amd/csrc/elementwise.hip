@@ -6,6 +6,8 @@
 // (one float4 = 16 B per lane, a wave reads 1 KiB contiguous) and walks down the
 // rows of its row-chunk, so column reductions need no cross-thread traffic and a
 // Philox call (128 keep-bits = 32 rows x 4 columns) is shared by a whole patch.
+#include <cstdlib>
+
 #include "common.h"
 #include "philox.h"
 
@@ -13,16 +15,6 @@ namespace blh {
 
 static constexpr int EW_THREADS = 256;
 static constexpr float BN_EPS = 1e-5f;
-
-int ew_row_chunk(int64_t batch) {
-  // whole 32-row Philox patches; at most 128 row chunks (partials of the column sums)
-  return (int)(32 * std::max<int64_t>(1, ceil_div(batch, 32 * 128)));
-}
-int ew_num_row_chunks(int64_t batch) { return (int)ceil_div(batch, ew_row_chunk(batch)); }
-int ew_row_chunk_h(int64_t batch) {
-  return (int)(32 * std::max<int64_t>(1, ceil_div(batch, 32 * 1024)));
-}
-int ew_num_row_chunks_h(int64_t batch) { return (int)ceil_div(batch, ew_row_chunk_h(batch)); }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -310,10 +302,6 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(
 
 static dim3 ew_grid(int64_t batch, int W) {
   return dim3((unsigned)ceil_div(W, EW_COLS_PER_BLOCK), (unsigned)ew_num_row_chunks(batch));
-}
-
-int ew_num_amax_parts(int64_t batch, int W) {
-  return (int)(ceil_div(W, EW_COLS_PER_BLOCK) * ew_num_row_chunks(batch) * (EW_THREADS / 64));
 }
 
 int launch_bn_apply_train(hipStream_t s, const float* Z, const float* scale, const float* shift,
