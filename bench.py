@@ -210,12 +210,12 @@ def skinny_rooflines(batch, width, reps):
 def recorded_traffic(batch, width):
     """HBM traffic of the dominant kernel (bytes per launch).  bench.py cannot run the PMC
     passes itself; the figure comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    runs of this very command (profiles/r01_traffic.json, gfx950 correction applied there) and
+    runs of the same kernel (profiles/r02_traffic.json, gfx950 correction applied there) and
     is only reported for the shape it was measured on."""
     if (batch, width) != (4096, 1024):
         return None
     try:
-        with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as f:
+        with open(os.path.join(REPO, "profiles", "r02_traffic.json")) as f:
             return json.load(f)["kernels"]["linear_fwd"]["traffic_bytes"]
     except (OSError, KeyError, ValueError):
         return None
@@ -226,12 +226,12 @@ def roofline_block(args, dom):
     flop = 2.0 * args.batch * args.width * args.width
     if args.dtype == "fp32":
         return {
-            "kernel": "gemm_f32_kernel<128,128,4,2,ROWK,ROWK,BIAS_STATS,PIPE=3> (Linear %dx%d forward, M=%d)" % (
+            "kernel": "gemm_f32_ring_kernel<128,128,4,2,ROWK,ROWK,BIAS_STATS> (Linear %dx%d forward, M=%d)" % (
                 args.width, args.width, args.batch),
             "bound": "mfma", "achieved": dom["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": dom["tflops"] / FP32_MFMA_PEAK_TFLOPS,
             "traffic": recorded_traffic(args.batch, args.width),
-            "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json)",
+            "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r02_traffic.json)",
             "avg_launch_ms": dom["ms"], "flop_per_launch": flop,
         }
     if args.dtype == "bf16s":
