@@ -164,6 +164,7 @@ def lib():
 
 OPT_TWO_STREAM = 0
 OPT_DEFER_SLABS = 1
+OPT_LATE_FORK = 2
 
 
 class Context:

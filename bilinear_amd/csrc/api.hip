@@ -32,6 +32,7 @@ struct blh_context {
   hipEvent_t ev_dz[BLH_CTX_EVENTS], ev_w[BLH_CTX_EVENTS], ev_r[BLH_CTX_EVENTS];
   bool two_stream = true;
   bool defer_slabs = false;
+  bool late_fork = true;    // BLH_OPT_LATE_FORK
   // per-call state (set by the entry point for the duration of the call)
   blh::SyncCtx sync = {nullptr, nullptr, 0};
   const uint64_t* step_dev = nullptr;
@@ -321,26 +322,28 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
     //  be reading the one bn_bwd_apply(i) is about to write)
     if (two && dz_amax && i + 2 <= nh - 1)
       BLH_HIP_TRY(hipStreamWaitEvent(s, g_side.ev_w[i + 2], 0));
-    // Schedule.  The weight gradient of stage i forks behind bn_bwd_apply(i): it starts together
-    // with the data-gradient GEMM of the stage (two workgroups per CU, the pair costs 127 us
-    // against 134 us one after the other) and its tail covers the BatchNorm-backward kernels of
-    // stage i-1.  Measured and not kept (profiles/r02_step_timeline.md): forking behind the
-    // data-gradient GEMM instead, so that the weight gradient runs next to the HBM-bound
-    // BatchNorm kernels — beside a GEMM that owns every CU's matrix pipe bn_bwd_apply takes
-    // 60 us instead of 10 (its Philox / BN arithmetic loses the vector issue slots), and the step
-    // comes out at 1.107 ms against 1.095 ms.
+    // Schedule (profiles/r02_step_timeline.md).  The weight gradient of stage i forks behind the
+    // data-gradient GEMM of the stage (BLH_OPT_LATE_FORK, default): that GEMM runs alone at full
+    // speed, and the weight gradient then runs beside the HBM-bound BatchNorm-backward kernels of
+    // stage i-1 (which raise their wave priority, elementwise.hip) and the first half of the next
+    // data-gradient GEMM: 148 us per stage.  With the option off it forks behind bn_bwd_apply(i) and
+    // starts together with the data-gradient GEMM (two workgroups per CU, 127 us per pair against
+    // 134 us one after the other, but the BatchNorm chain then sits between two GEMM pairs): 158 us
+    // per stage, step 1.091 against 1.078 ms.
     // Stage 0 has no data gradient: its weight gradient stays on the main stream (a fork + join
     // there only adds two cross-queue latencies at the very end of backward) unless the
     // data-parallel hook wants every range complete on the side stream.
     const bool side = two && (i > 0 || on_ready != nullptr);
+    const bool fork_late = side && ctx->late_fork && i > 0 && small_m_splits(batch, W, W).splits == 1;
     hipStream_t sw = side ? s2 : s;
-    if (side) arm_fork(i);
+    if (side && !fork_late) arm_fork(i);
     BLH_TRY(launch_bn_bwd_apply(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W,
                                 params + h.gamma, dg, db, dzbuf,
                                 ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W, ds,
                                 norm_batch, dz_amax));
     tl_stop_event = nullptr;
-    if (side) BLH_TRY(fork_wait(i));
+    if (side && !fork_late) BLH_TRY(fork_wait(i));
+    if (fork_late) arm_fork(i);
     // Linear: db = colsum(dZ); dW = dZ^T a_in; d a_in = dZ W
     if (i > 0) {
       GemmParams g{};
@@ -370,6 +373,8 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
         }
       }
     }
+    tl_stop_event = nullptr;
+    if (fork_late) BLH_TRY(fork_wait(i));
     // (data parallel: the bucket hook needs this stage's bias gradient now; otherwise all
     //  stages are reduced by one launch after the loop)
     if (on_ready)   // on the side stream (after the fork): nothing on the main stream waits for it
@@ -616,6 +621,7 @@ int blh_context_create(blh_context** out) {
   // A/B switches for experiments (the documented way is blh_context_set_option)
   c->two_stream = getenv("BLH_ONE_STREAM") == nullptr;
   c->defer_slabs = getenv("BLH_DEFER_SLABS") != nullptr;
+  c->late_fork = getenv("BLH_EARLY_FORK") == nullptr;
   *out = c;
   return BLH_OK;
 }
@@ -637,6 +643,7 @@ int blh_context_set_option(blh_context* c, int32_t option, int32_t value) {
   switch (option) {
     case BLH_OPT_TWO_STREAM: c->two_stream = value != 0; return BLH_OK;
     case BLH_OPT_DEFER_SLABS: c->defer_slabs = value != 0; return BLH_OK;
+    case BLH_OPT_LATE_FORK: c->late_fork = value != 0; return BLH_OK;
   }
   return BLH_ERR_INVALID_ARGUMENT;
 }
@@ -646,6 +653,7 @@ int blh_context_get_option(const blh_context* c, int32_t option) {
   switch (option) {
     case BLH_OPT_TWO_STREAM: return c->two_stream ? 1 : 0;
     case BLH_OPT_DEFER_SLABS: return c->defer_slabs ? 1 : 0;
+    case BLH_OPT_LATE_FORK: return c->late_fork ? 1 : 0;
   }
   return BLH_ERR_INVALID_ARGUMENT;
 }

@@ -13,6 +13,13 @@
 
 namespace blh {
 
+// The BatchNorm-backward kernels run beside the weight-gradient GEMM of the previous stage (two-stream
+// backward).  At equal priority the GEMM's waves win most issue slots and bn_bwd_apply takes 60 us
+// instead of 10; raised to the highest wave priority it takes 37 us and the GEMM loses nothing
+// measurable (it is bound by the matrix pipe, not by issue): step 1.101 -> 1.078 ms
+// (profiles/r02_step_timeline.md).  Harmless when the kernel runs alone.
+#define BLH_EW_PRIO() __builtin_amdgcn_s_setprio(3)
+
 static constexpr int EW_THREADS = 256;
 static constexpr float BN_EPS = 1e-5f;
 
@@ -603,6 +610,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
     const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ invstd, float* __restrict__ part, int64_t batch, int W,
     int row_chunk, DropoutSrc drop) {
+  BLH_EW_PRIO();
   __shared__ __attribute__((aligned(16))) float red[4 * 256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col0 = blockIdx.x * EW_COLS_PER_BLOCK;
@@ -666,6 +674,7 @@ int launch_bn_bwd_reduce_t(hipStream_t s, const void* dA, int gt, const void* Z,
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ in, int S,
                                                         int64_t ld, int ncols,
                                                         float* __restrict__ out) {
+  BLH_EW_PRIO();
   __shared__ double red[8][32];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + cl;
@@ -751,6 +760,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
     const float* __restrict__ dbeta, TD* __restrict__ dZ, float* __restrict__ colsum_part,
     int64_t batch, int W, int row_chunk, DropoutSrc drop, int64_t norm_batch,
     float* __restrict__ amax_part) {
+  BLH_EW_PRIO();
   __shared__ __attribute__((aligned(16))) float red[4 * 256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col0 = blockIdx.x * EW_COLS_PER_BLOCK;

@@ -160,7 +160,7 @@ int main(int argc, char** argv) {
     float t2 = run_ring<BM, BN, WM, WN, ROWK, KROW, EPI_STORE, BKT, ST>(d, 1, reps);                         \
     verify("dgrad", h, h, h, C, M, W, W, W, 1, 1);                                             \
     int tiles = (int)(ceil_div(W, BM) * ceil_div(W, BN));                                      \
-    int splits = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(256, tiles), 16));      \
+    int splits = (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div((BM * BN <= 64 * 128) ? 512 : 256, tiles), 16));      \
     w.k_per_split = (int)round_up(ceil_div(M, splits), 64); w.c_split_stride = (int64_t)W * W; \
     float t3 = run_ring<BM, BN, WM, WN, KROW, KROW, EPI_STORE, BKT, ST>(w, splits, reps);                    \
     verify("wgrad", h, h, h, C, W, W, M, W, 2, splits);                                        \
@@ -180,6 +180,10 @@ int main(int argc, char** argv) {
   RROW("ring 4x2 bk64 st2", 128, 128, 4, 2, 64, 2)
   RROW("ring 4x2 bk32 st2", 128, 128, 4, 2, 32, 2)
   RROW("ring 2x2 bk32 st2", 128, 128, 2, 2, 32, 2)
+  RROW("ring 64x128 2x2 bk32 st2", 64, 128, 2, 2, 32, 2)
+  RROW("ring 64x128 2x2 bk32 st3", 64, 128, 2, 2, 32, 3)
+  RROW("ring 128x64 2x2 bk32 st3", 128, 64, 2, 2, 32, 3)
+  RROW("ring 64x128 2x2 bk64 st2", 64, 128, 2, 2, 64, 2)
   }
   {  // where the time of the shipped ring kernel goes: in-kernel stamps of the forward kernel
     unsigned long long* st; CK(hipMalloc(&st, 4096 * 64));

@@ -72,8 +72,12 @@ int blh_context_destroy(blh_context* ctx);
 typedef enum {
   BLH_OPT_TWO_STREAM = 0, /* 1 (default): weight-gradient GEMMs on the context's side stream;
                              0: single-stream order.  Results are bit-identical either way.  */
-  BLH_OPT_DEFER_SLABS = 1 /* 1: sum all split-K weight-gradient slabs in one launch at the end
-                             of backward (default 0: right after each GEMM)                  */
+  BLH_OPT_DEFER_SLABS = 1, /* 1: sum all split-K weight-gradient slabs in one launch at the end
+                              of backward (default 0: right after each GEMM)                 */
+  BLH_OPT_LATE_FORK = 2   /* 1 (default): a stage's weight-gradient GEMM starts behind its
+                             data-gradient GEMM and runs beside the next stage's BatchNorm
+                             backward; 0: it starts together with the data-gradient GEMM.
+                             Scheduling only: results are bit-identical.                     */
 } blh_option;
 int blh_context_set_option(blh_context* ctx, int32_t option, int32_t value);
 int blh_context_get_option(const blh_context* ctx, int32_t option);

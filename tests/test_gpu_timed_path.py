@@ -308,17 +308,22 @@ def test_one_stream_and_two_stream_schedules_are_bit_identical(mode):
     nb, width, batch = 2, 1024, 4096
     entry = _oracle_step(nb, width, batch)
     xt, tt = torch.from_numpy(entry["x"]).to(dev), torch.from_numpy(entry["t"]).to(dev)
+    from bilinear_amd import _native as N
     out = {}
-    for two in (True, False):
+    # (two streams, late fork) = the default; (two streams, early fork); single stream
+    for sched in ((True, 1), (True, 0), (False, 1)):
         net, opt = _build(entry["st0"], dev, nb, width, mode)
-        net.engine.set_two_stream(two)
+        net.engine.set_two_stream(sched[0])
+        net.engine.ctx.set_option(N.OPT_LATE_FORK, sched[1])
+        assert net.engine.ctx.get_option(N.OPT_LATE_FORK) == sched[1]
         for _ in range(2):
             pred, loss = net.train_step(opt, xt, tt, max_norm=1.0)
         torch.cuda.synchronize()
-        out[two] = (pred.clone(), net.engine.grads.clone(), net.engine.params.clone(),
-                    opt._exp_avg_sq.clone(), net.engine.bn_running.clone())
-    for a, b, what in zip(out[True], out[False], ("pred", "grads", "params", "exp_avg_sq", "running")):
-        assert torch.equal(a, b), what
+        out[sched] = (pred.clone(), net.engine.grads.clone(), net.engine.params.clone(),
+                      opt._exp_avg_sq.clone(), net.engine.bn_running.clone())
+    for other in ((True, 0), (False, 1)):
+        for a, b, what in zip(out[(True, 1)], out[other], ("pred", "grads", "params", "exp_avg_sq", "running")):
+            assert torch.equal(a, b), (other, what)
 
 
 # ----------------------------------------------------------------------------
