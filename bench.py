@@ -397,6 +397,8 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --batch is the GLOBAL batch, split evenly over the GPUs "
                          "(SURVEY.md 8(d)); default is weak scaling, --batch per GPU")
+    ap.add_argument("--no-strong-line", action="store_true",
+                    help="with --gpus N > 1: skip the extra strong-scaling measurement")
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the extra timing of the bf16x3 GEMM mode (reported beside the headline)")
@@ -479,6 +481,37 @@ def main():
     final_loss = float(loss.item())
     log("timed %d steps: %.3f ms/step" % (args.steps, 1e3 * elapsed / args.steps))
 
+    # Under --gpus N the headline is weak scaling (per-GPU batch fixed).  SURVEY.md 8(d) also asks
+    # for the strong-scaling curve of the headline shape (global batch fixed at the config's batch,
+    # split N ways): measured right here with the same barrier / max-over-ranks protocol and
+    # reported as a sub-object, so one driver run per N yields both curves.
+    strong = None
+    if world > 1 and not args.strong and not args.no_strong_line and cfg["batch"] % (32 * world) == 0:
+        sb = cfg["batch"] // world
+        torch.manual_seed(1)
+        net_s, opt_s, _, _ = bilinear_amd.load(dev, num_blocks=args.blocks, width=args.width,
+                                               gemm_dtype=args.dtype)
+        net_s.train()
+        dp_s = DataParallel(net_s, opt_s, sync_bn=args.sync_bn)
+        xs, ts = x[:sb].contiguous(), t[:sb].contiguous()
+        n_s = max(20, min(args.steps, 300))
+        for _ in range(max(5, min(args.warmup, 50))):
+            dp_s.train_step(xs, ts)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_s):
+            dp_s.train_step(xs, ts)
+        dist.barrier()
+        torch.cuda.synchronize()
+        el = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        el = float(el.item())
+        strong = {"scaling": "strong", "global_batch": sb * world, "per_gpu_batch": sb, "steps": n_s,
+                  "ms_per_step": 1e3 * el / n_s, "value": sb * world * n_s / el, "unit": "poses/s"}
+        log("strong scaling (global batch %d): %.3f ms/step" % (sb * world, strong["ms_per_step"]))
+        del dp_s, net_s, opt_s
+
     # fwd+bwd only (no optimiser), single rank view, for the record
     def fwd_bwd():
         opt.zero_grad()
@@ -538,6 +571,8 @@ def main():
             "roofline_hbm": skinny_rooflines(args.batch, args.width, reps=300),
             "kernels": kern,
         }
+        if strong is not None:
+            result["strong_scaling"] = strong
         if world == 1 and args.dtype == "fp32" and not args.no_alt:
             result["fp32_on_16bit_mfma"] = {m: alt_mode_block(args, dev, x, t, m) for m in ("bf16x3", "fp16x2")}
         if world == 1 and not args.no_cpu_baseline:
