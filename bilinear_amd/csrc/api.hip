@@ -381,12 +381,13 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
       BLH_TRY(launch_colreduce(sw, ws.dz_colsum_part + (int64_t)i * chunks * W, chunks, W, W,
                                grads + h.b));
     if (i == 0) {
-      // (its slabs: the shared buffer is free once wgrad(1)'s sum has run — wait for the side
-      //  stream first when this launch is on the main stream)
-      if (two && !side) BLH_HIP_TRY(hipStreamWaitEvent(s, g_side.ev_w[1], 0));   // stage 1, or the decode (nh == 1)
+      // (on the main stream it takes its own slab buffer: the shared one may still be in use by
+      //  wgrad(1) on the side stream, and waiting for that costs a cross-queue latency of ~10 us
+      //  at the very end of backward)
       BLH_TRY(wgrad(d->gemm_dtype, sw, TILE_128x32, dzbuf, W, W, x, d->in_features,
                     d->in_features, batch, ceil_div(W, 128) * ceil_div(d->in_features, 32),
-                    defer ? ws.stage_slabs[0] : ws.slabs, grads + h.w, defer ? &wreg[0] : nullptr));
+                    (defer || (two && !side)) ? ws.stage_slabs[0] : ws.slabs, grads + h.w,
+                    defer ? &wreg[0] : nullptr));
       if (side) BLH_TRY(wdone(0));
     } else {
       BLH_TRY(wgrad(d->gemm_dtype, sw, TILE_128x128, dzbuf, W, W, ws.A[i - 1], W, W, batch,
