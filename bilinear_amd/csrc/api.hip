@@ -25,7 +25,6 @@ struct SyncCtx { blh_sync_fn fn; void* user; int64_t global_batch; };
 // Caller-owned context (include/bilinear_hip.h): the side stream of the two-stream backward with
 // its fork / join events, the option flags, and the per-call plumbing (SyncBN callback, device
 // address of the captured step's dropout counter).  Bound to one device; one call at a time.
-static constexpr int BLH_CTX_COUNTERS = 1024;
 static constexpr int BLH_CTX_EVENTS = 34;      // 1 + 2*num_blocks <= 32 stages, + decode, + spare
 struct blh_context {
   int device = -1;
@@ -34,8 +33,6 @@ struct blh_context {
   bool two_stream = true;
   bool defer_slabs = false;
   bool late_fork = true;    // BLH_OPT_LATE_FORK
-  bool fused_finalize = true;   // BLH_OPT_FUSED_FINALIZE
-  unsigned int* counters = nullptr;   // device, BLH_CTX_COUNTERS zeros: arrival counters of the fused finalizes
   // per-call state (set by the entry point for the duration of the call)
   blh::SyncCtx sync = {nullptr, nullptr, 0};
   const uint64_t* step_dev = nullptr;
@@ -90,20 +87,6 @@ static int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s
     g.stat_part = ws.stat_part;
     const Splits fs = small_m_splits(batch, W, h.fan_in);
     const bool enc64 = train && i == 0 && fs.splits == 1 && h.fan_in <= 32 && batch >= 2048 && d->gemm_dtype != 1;
-    // BatchNorm finalize inside the GEMM (the last workgroup of each column tile merges the tile
-    // statistics, gemm_epilogue.h): one launch less in the dependent chain of the stage
-    float* rm = bn_running + ((int64_t)i * 2 + 0) * W;
-    float* rv = bn_running + ((int64_t)i * 2 + 1) * W;
-    const bool fuse_fin = train && ctx->fused_finalize && !ctx->sync.fn && fs.splits == 1 &&
-                          ceil_div(W, 32) <= BLH_CTX_COUNTERS;
-    if (fuse_fin) {
-      const int st_rows = enc64 ? 64 : 128;
-      g.fin.gamma = params + h.gamma; g.fin.beta = params + h.beta;
-      g.fin.running_mean = rm; g.fin.running_var = rv; g.fin.nbt = nbt + i;
-      g.fin.saved = ws.bn_saved[i]; g.fin.counters = ctx->counters;
-      g.fin.batch = batch; g.fin.tiles = (int)ceil_div(batch, st_rows); g.fin.tile_rows = st_rows;
-      g.fin.momentum = momentum;
-    }
     if (fs.splits > 1) {
       // small batch: too few 128x128 output tiles to fill the chip and each would walk the
       // whole reduction alone (latency-bound), so cut the reduction across workgroups and
@@ -134,6 +117,8 @@ static int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s
     }
     // second stage of a block adds the block input (model/bilinear.py:36-38)
     const float* skip = (i >= 2 && (i % 2) == 0) ? ws.A[i - 2] : nullptr;
+    float* rm = bn_running + ((int64_t)i * 2 + 0) * W;
+    float* rv = bn_running + ((int64_t)i * 2 + 1) * W;
     if (train) {
       float* sv = ws.bn_saved[i];
       // (the small-batch path produced one statistics tile covering all rows)
@@ -145,7 +130,7 @@ static int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s
         BLH_TRY(launch_bn_fwd_finalize_sums(s, ws.sync_buf, ctx->sync.global_batch, W,
                                             params + h.gamma, params + h.beta, rm, rv, nbt + i,
                                             momentum, sv, sv + W, sv + 2 * W, sv + 3 * W));
-      } else if (!fuse_fin) {
+      } else {
         BLH_TRY(launch_bn_fwd_finalize(s, ws.stat_part, st_tiles, st_rows, batch, W,
                                        params + h.gamma, params + h.beta, rm, rv, nbt + i,
                                        momentum, sv, sv + W, sv + 2 * W, sv + 3 * W));
@@ -638,11 +623,6 @@ int blh_context_create(blh_context** out) {
   c->two_stream = getenv("BLH_ONE_STREAM") == nullptr;
   c->defer_slabs = getenv("BLH_DEFER_SLABS") != nullptr;
   c->late_fork = getenv("BLH_EARLY_FORK") == nullptr;
-  c->fused_finalize = getenv("BLH_NO_FUSED_FINALIZE") == nullptr;
-  // arrival counters of the fused finalize epilogues: zero now, and every kernel that uses one
-  // leaves it at zero (the only device memory the library owns; 4 KB)
-  if ((e = hipMalloc(&c->counters, BLH_CTX_COUNTERS * sizeof(unsigned int))) != hipSuccess) return fail(e);
-  if ((e = hipMemset(c->counters, 0, BLH_CTX_COUNTERS * sizeof(unsigned int))) != hipSuccess) return fail(e);
   *out = c;
   return BLH_OK;
 }
@@ -655,7 +635,6 @@ int blh_context_destroy(blh_context* c) {
     if (c->ev_r[i]) (void)hipEventDestroy(c->ev_r[i]);
   }
   if (c->s2) (void)hipStreamDestroy(c->s2);
-  if (c->counters) (void)hipFree(c->counters);
   delete c;
   return BLH_OK;
 }
@@ -666,7 +645,6 @@ int blh_context_set_option(blh_context* c, int32_t option, int32_t value) {
     case BLH_OPT_TWO_STREAM: c->two_stream = value != 0; return BLH_OK;
     case BLH_OPT_DEFER_SLABS: c->defer_slabs = value != 0; return BLH_OK;
     case BLH_OPT_LATE_FORK: c->late_fork = value != 0; return BLH_OK;
-    case BLH_OPT_FUSED_FINALIZE: c->fused_finalize = value != 0; return BLH_OK;
   }
   return BLH_ERR_INVALID_ARGUMENT;
 }
@@ -677,7 +655,6 @@ int blh_context_get_option(const blh_context* c, int32_t option) {
     case BLH_OPT_TWO_STREAM: return c->two_stream ? 1 : 0;
     case BLH_OPT_DEFER_SLABS: return c->defer_slabs ? 1 : 0;
     case BLH_OPT_LATE_FORK: return c->late_fork ? 1 : 0;
-    case BLH_OPT_FUSED_FINALIZE: return c->fused_finalize ? 1 : 0;
   }
   return BLH_ERR_INVALID_ARGUMENT;
 }

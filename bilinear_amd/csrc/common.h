@@ -54,21 +54,6 @@ enum Epilogue : int {
   EPI_BN_RELU = 4      // eval forward: C = relu(bn_eval(acc + bias[n])) (+ addend[m][n], the block skip)
 };
 
-// BatchNorm forward finalize fused into the EPI_BIAS_STATS epilogue (bn_finalize.h): enabled when
-// `counters` is set.  counters[tile_n] counts the finished row tiles of column tile tile_n; the
-// workgroup that brings it to `tiles` merges the partials of that column tile and resets it.
-static constexpr float BN_EPS = 1e-5f;
-struct BnFin {
-  const float* gamma; const float* beta;
-  float* running_mean; float* running_var;
-  const int64_t* nbt;
-  float* saved;             // [4][W]: mean, invstd, scale, shift
-  unsigned int* counters;   // [ceil(N / BN)], zero between launches (owned by the blh_context)
-  int64_t batch;
-  int tiles, tile_rows;
-  float momentum;
-};
-
 struct GemmParams {
   const float* A;
   const float* B;
@@ -87,7 +72,6 @@ struct GemmParams {
   // gemm_dtype 3 (fp16 two-piece split): max |value| partials of each operand tensor
   const float* a_amax; int a_namax;
   const float* b_amax; int b_namax;
-  BnFin fin;                // EPI_BIAS_STATS only
 };
 
 enum GemmTile : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_128x32 = 3 };

@@ -9,7 +9,6 @@
 #include <cstdlib>
 
 #include "common.h"
-#include "bn_finalize.h"
 #include "philox.h"
 
 namespace blh {
@@ -22,6 +21,7 @@ namespace blh {
 #define BLH_EW_PRIO() __builtin_amdgcn_s_setprio(3)
 
 static constexpr int EW_THREADS = 256;
+static constexpr float BN_EPS = 1e-5f;
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -111,10 +111,73 @@ __device__ __forceinline__ double strided_colsum(const float* __restrict__ in, i
 // update running stats (unbiased variance, PyTorch BatchNorm1d semantics).
 // block = 32 columns x 8 tile-slices.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __restrict__ part, int tiles,
-                                                              int tile_rows, int64_t batch, int W, BnFin f) {
-  __shared__ double red[8 * 32];
-  bn_finalize_cols<256, 32>(part, tiles, tile_rows, batch, W, blockIdx.x * 32, f, red);
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
+    const float* __restrict__ part, int tiles, int tile_rows, int64_t batch, int W,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+    float* running_var, const int64_t* nbt, float momentum, float* saved_mean,
+    float* saved_invstd, float* scale, float* shift) {
+  __shared__ double red[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cl;
+  const bool ok = col < W;
+  // both passes read every tile partial of this column with the loads of 8 tiles in flight
+  constexpr int U = 8;
+  const int cc = ok ? col : 0;
+  double acc = 0.0;
+  for (int t0 = sl; t0 < tiles; t0 += 8 * U) {
+    float mu[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) mu[u] = part[((int64_t)min(t0 + 8 * u, tiles - 1) * 2 + 0) * W + cc];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + 8 * u;
+      const double n = (double)min((int64_t)tile_rows, batch - (int64_t)t * tile_rows);
+      if (t < tiles) acc += n * (double)mu[u];
+    }
+  }
+  red[sl][cl] = acc;
+  __syncthreads();
+  double mean = 0.0;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) mean += red[s][cl];
+  mean /= (double)batch;
+  __syncthreads();
+  acc = 0.0;
+  for (int t0 = sl; t0 < tiles; t0 += 8 * U) {
+    float mu[U], m2t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t tt = min(t0 + 8 * u, tiles - 1);
+      mu[u] = part[(tt * 2 + 0) * W + cc];
+      m2t[u] = part[(tt * 2 + 1) * W + cc];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + 8 * u;
+      const double n = (double)min((int64_t)tile_rows, batch - (int64_t)t * tile_rows);
+      const double d = (double)mu[u] - mean;
+      if (t < tiles) acc += (double)m2t[u] + n * d * d;
+    }
+  }
+  red[sl][cl] = acc;
+  __syncthreads();
+  if (sl == 0 && ok) {
+    double m2 = 0.0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) m2 += red[s][cl];
+    const double var = m2 / (double)batch;
+    const float invstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
+    const float mu = (float)mean;
+    const float sc = gamma[col] * invstd;
+    saved_mean[col] = mu;
+    saved_invstd[col] = invstd;
+    scale[col] = sc;
+    shift[col] = beta[col] - mu * sc;
+    const double f = (momentum >= 0.f) ? (double)momentum : 1.0 / (double)(nbt[0] + 1);
+    const double unbiased = m2 / (double)(batch > 1 ? batch - 1 : 1);
+    running_mean[col] = (float)((1.0 - f) * (double)running_mean[col] + f * mean);
+    running_var[col] = (float)((1.0 - f) * (double)running_var[col] + f * unbiased);
+  }
 }
 
 int launch_bn_fwd_finalize(hipStream_t s, const float* stat_part, int tiles, int tile_rows,
@@ -122,13 +185,9 @@ int launch_bn_fwd_finalize(hipStream_t s, const float* stat_part, int tiles, int
                            float* running_mean, float* running_var, int64_t* nbt,
                            float momentum, float* saved_mean, float* saved_invstd, float* scale,
                            float* shift) {
-  if (saved_invstd != saved_mean + W || scale != saved_mean + 2 * W || shift != saved_mean + 3 * W)
-    return BLH_ERR_INVALID_ARGUMENT;   // the four saved vectors are one [4][W] block
-  BnFin f{};
-  f.gamma = gamma; f.beta = beta; f.running_mean = running_mean; f.running_var = running_var;
-  f.nbt = nbt; f.saved = saved_mean; f.momentum = momentum;
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((unsigned)ceil_div(W, 32)), dim3(256), 0, s,
-                     stat_part, tiles, tile_rows, batch, W, f);
+                     stat_part, tiles, tile_rows, batch, W, gamma, beta, running_mean,
+                     running_var, nbt, momentum, saved_mean, saved_invstd, scale, shift);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }

@@ -6,7 +6,6 @@
 //   See gemm_f32_kernel.h for the contractions it serves.
 #pragma once
 #include "common.h"
-#include "bn_finalize.h"
 
 namespace blh {
 
@@ -146,44 +145,9 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], 
 #pragma unroll
         for (int w = 0; w < WM; ++w) m2 += red[w * BN + wn * (TN * 32) + jn * 32 + lc];
         if (col < p.N) {
-          float* pm = p.stat_part + ((int64_t)tile_m * 2 + 0) * p.N + col;
-          float* pv = p.stat_part + ((int64_t)tile_m * 2 + 1) * p.N + col;
-          if (p.fin.counters) {   // read by another workgroup of this launch: write through
-            __hip_atomic_store(pm, mean[jn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(pv, m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } else {
-            *pm = mean[jn];
-            *pv = m2;
-          }
+          p.stat_part[((int64_t)tile_m * 2 + 0) * p.N + col] = mean[jn];
+          p.stat_part[((int64_t)tile_m * 2 + 1) * p.N + col] = m2;
         }
-      }
-    }
-    if (p.fin.counters) {
-      // Fused finalize: the last workgroup of this column tile to get here merges the partials
-      // of all row tiles (threadfence-reduction pattern).  The XCDs' L2s are not coherent with
-      // each other, so the partials travel as agent-scope atomic stores / loads (write-through,
-      // cache-bypassing) and the only ordering needed is "my partial stores have completed
-      // before the counter moves": s_waitcnt vmcnt(0) in the storing waves + the barrier.  (A
-      // release fence here costs a whole-L2 write-back per wave: +20 us per launch, measured.)
-      constexpr int NT = 64 * WM * WN;
-      static_assert(NT % BN == 0, "finalize slices");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      int* flag = reinterpret_cast<int*>(smem);           // (red is dead: every wave passed the barrier)
-      const int tile_n = n0 / BN;
-      if (tid == 0) {
-        const unsigned old = __hip_atomic_fetch_add(p.fin.counters + tile_n, 1u, __ATOMIC_RELAXED,
-                                                    __HIP_MEMORY_SCOPE_AGENT);
-        *flag = (old + 1u == (unsigned)p.fin.tiles) ? 1 : 0;
-      }
-      __syncthreads();
-      const bool last = *flag != 0;
-      __syncthreads();
-      if (last) {
-        bn_finalize_cols<NT, BN, true>(p.stat_part, p.fin.tiles, p.fin.tile_rows, p.fin.batch, p.N, n0, p.fin,
-                                 reinterpret_cast<double*>(smem));
-        if (tid == 0)
-          __hip_atomic_store(p.fin.counters + tile_n, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }

@@ -20,8 +20,7 @@
  *   - plain pointers and sizes; no torch types.  Every pointer marked "device"
  *     is a HIP device pointer owned by the caller (PyTorch allocations in the
  *     shipped host code); the library never frees or retains caller memory
- *     beyond the call, and allocates nothing on the device outside blh_context_create
- *     (4 KB of arrival counters per context).
+ *     beyond the call, and allocates nothing on the device.
  *   - `stream` is a hipStream_t passed as void*; every entry point only
  *     enqueues work on it (no host synchronisation, no allocation), so calls
  *     are asynchronous and hipGraph-capturable.
@@ -75,14 +74,10 @@ typedef enum {
                              0: single-stream order.  Results are bit-identical either way.  */
   BLH_OPT_DEFER_SLABS = 1, /* 1: sum all split-K weight-gradient slabs in one launch at the end
                               of backward (default 0: right after each GEMM)                 */
-  BLH_OPT_LATE_FORK = 2,  /* 1 (default): a stage's weight-gradient GEMM starts behind its
+  BLH_OPT_LATE_FORK = 2   /* 1 (default): a stage's weight-gradient GEMM starts behind its
                              data-gradient GEMM and runs beside the next stage's BatchNorm
                              backward; 0: it starts together with the data-gradient GEMM.
                              Scheduling only: results are bit-identical.                     */
-  BLH_OPT_FUSED_FINALIZE = 3 /* 1 (default): the BatchNorm statistics of a stage are finalised
-                             inside its Linear GEMM by the last workgroup of each column tile
-                             (arrival counters in 4 KB of device memory owned by the context);
-                             0: by a separate kernel.                                          */
 } blh_option;
 int blh_context_set_option(blh_context* ctx, int32_t option, int32_t value);
 int blh_context_get_option(const blh_context* ctx, int32_t option);

@@ -326,38 +326,6 @@ def test_one_stream_and_two_stream_schedules_are_bit_identical(mode):
             assert torch.equal(a, b), (other, what)
 
 
-@pytest.mark.parametrize("batch", [4096, 2048 + 64, 16384])
-def test_fused_batchnorm_finalize_matches_the_separate_kernel(batch):
-    """BLH_OPT_FUSED_FINALIZE: the last workgroup of each column tile of the Linear GEMM merges the
-    BatchNorm tile statistics.  Same algorithm as bn_fwd_finalize_kernel (fp64 Chan merge), only
-    the order of the fp64 additions differs: saved statistics, running statistics and everything
-    downstream agree to fp32 rounding, run after run (the arrival counters reset themselves)."""
-    from bilinear_amd import _native as N
-    dev = _dev()
-    nb, width = 2, 1024
-    st0 = _state(nb, width, 5)
-    rng = np.random.RandomState(11)
-    xt = torch.from_numpy(rng.randn(batch, 32).astype(np.float32)).to(dev)
-    tt = torch.from_numpy(rng.randn(batch, 48).astype(np.float32)).to(dev)
-    out = {}
-    for fused in (1, 0):
-        net, opt = _build(st0, dev, nb, width, "fp32")
-        net.engine.ctx.set_option(N.OPT_FUSED_FINALIZE, fused)
-        assert net.engine.ctx.get_option(N.OPT_FUSED_FINALIZE) == fused
-        losses = []
-        for _ in range(3):
-            pred, loss = net.train_step(opt, xt, tt, max_norm=1.0)
-            losses.append(float(loss))
-        torch.cuda.synchronize()
-        out[fused] = (pred.clone(), net.engine.grads.clone(), net.engine.params.clone(),
-                      net.engine.bn_running.clone(), torch.tensor(losses))
-    for a, b, what in zip(out[1], out[0], ("pred", "grads", "params", "running", "losses")):
-        a, b = a.double().cpu(), b.double().cpu()
-        rel = float((a - b).norm() / b.norm())
-        assert rel < 2e-6, (what, rel)
-    assert torch.isfinite(out[1][0]).all()
-
-
 # ----------------------------------------------------------------------------
 # per-GPU shapes of BASELINE configs 3-5
 # ----------------------------------------------------------------------------
