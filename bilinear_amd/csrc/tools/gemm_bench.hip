@@ -206,13 +206,17 @@ int main(int argc, char** argv) {
         cs += o[0]; rs += o[1]; pro += o[3] - o[2]; epi += o[5] - o[4];
         e0 = std::min(e0, o[2]); e1 = std::max(e1, o[5]); l1max = std::max(l1max, o[4]); emax = std::max(emax, o[2]);
       }
-      const double ideal = 2.0 * fs.K * 128 * 128 / 2048.0 / 4.0 * 64.0;   // cycles: MFMAs per SIMD x 64
+      const double ideal = 2.0 * fs.K * 128 * 128 / 2048.0 / 4.0 * 64.0 / 2.0;   // (2 FLOP per multiply-add)   // cycles: MFMAs per SIMD x 64
       printf("%s: events %.1f us/launch | per WG: entry->loop %.2f us, main loop %.1f us (%.0f cycles, %.3f GHz, MFMA-ideal %.0f), epilogue %.2f us | span first entry -> last exit %.1f us, last entry +%.2f us, last loop end +%.1f us\n",
              name, msv / 200 * 1e3, pro / tiles / 100.0, rs / tiles / 100.0, cs / tiles, cs / rs * 0.1, ideal,
              epi / tiles / 100.0, (e1 - e0) / 100.0, (emax - e0) / 100.0, (l1max - e0) / 100.0);
     };
     stamped("STAMP ring bk64 st2 fwd  ", gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 64, 2, 1>, gemm_ring_lds_bytes<128, 128, 64, 2>(), f);
     stamped("STAMP ring bk64 st2 dgrad", gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, KROW, EPI_STORE, 64, 2, 1>, gemm_ring_lds_bytes<128, 128, 64, 2>(), d);
+    stamped("ABL no barrier  bk64 st2 ", gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 64, 2, 2>, gemm_ring_lds_bytes<128, 128, 64, 2>(), f);
+    stamped("ABL no DMA      bk64 st2 ", gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 64, 2, 3>, gemm_ring_lds_bytes<128, 128, 64, 2>(), f);
+    stamped("ABL no ds_read  bk64 st2 ", gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 64, 2, 4>, gemm_ring_lds_bytes<128, 128, 64, 2>(), f);
+    stamped("ABL no wait+bar bk64 st2 ", gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 64, 2, 5>, gemm_ring_lds_bytes<128, 128, 64, 2>(), f);
     stamped("STAMP ring bk32 st2 fwd  ", gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 32, 2, 1>, gemm_ring_lds_bytes<128, 128, 32, 2>(), f);
     GemmParams f1 = f; f1.K = 64; f1.k_per_split = 64;   // fixed per-launch cost: one K tile
     float tk = run_ring<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 64, 2>(f1, 1, 200);
