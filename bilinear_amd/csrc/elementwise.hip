@@ -377,8 +377,14 @@ __device__ __forceinline__ void block_colsum_store_h(float4 v0, float4 v1, float
     if (col0 + t < W) out[col0 + t] = (red[t] + red[512 + t]) + (red[1024 + t] + red[1536 + t]);
 }
 
+// Occupancy of the bf16 streaming kernels.  They are latency-bound (PMC: 66 % of the wave cycles
+// wait for memory) and the compiler's first choice of 180-258 VGPRs left one or two waves per
+// SIMD; BLH_EW_H_WAVES waves per SIMD are requested instead (second __launch_bounds__ argument).
+#ifndef BLH_EW_H_WAVES
+#define BLH_EW_H_WAVES 2
+#endif
 template <bool TRAIN>
-__global__ __launch_bounds__(EW_THREADS) void bn_apply_h_kernel(
+__global__ __launch_bounds__(EW_THREADS, BLH_EW_H_WAVES) void bn_apply_h_kernel(
     const bf16_bits* __restrict__ Z, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ running_mean, const float* __restrict__ running_var,
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_h_kernel(
   }
 }
 
-__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_h_kernel(
+__global__ __launch_bounds__(EW_THREADS, BLH_EW_H_WAVES) void bn_bwd_reduce_h_kernel(
     const bf16_bits* __restrict__ dA, const bf16_bits* __restrict__ Z, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ invstd, float* __restrict__ part, int64_t batch, int W,
@@ -491,7 +497,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_h_kernel(
   block_colsum_store_h(sb[0], sb[1], red, part + ((int64_t)blockIdx.y * 2 + 1) * W, col0, W);
 }
 
-__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_h_kernel(
+__global__ __launch_bounds__(EW_THREADS, BLH_EW_H_WAVES) void bn_bwd_apply_h_kernel(
     const bf16_bits* __restrict__ dA, const bf16_bits* __restrict__ Z, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ dgamma,
