@@ -68,14 +68,6 @@ template <int BKE>
 __device__ __forceinline__ int rowk_swz_h(int row) {     // 16-B chunk key of a ROWK image
   return (BKE * 2 == 128) ? ((row >> 1) & 7) : (row & 15);
 }
-// ROWK image of a 32-element K tile (64-byte rows): two rows share one 128-byte "super row" of 8
-// chunks (chunk index = 4 * (row & 1) + chunk of the row), swizzled with the 128-byte-row key of the
-// super row.  Returns the 16-B slot of (row, chunk); conflict-free for ds_read_b128 by the same
-// argument as the 128-byte rows (the 16 lanes served together see 8 distinct keys x 2 halves).
-__device__ __forceinline__ int rowk32_slot(int row, int chunk) {
-  const int S = row >> 1;
-  return S * 8 + ((((row & 1) << 2) + chunk) ^ ((S >> 1) & 7));
-}
 __device__ __forceinline__ int krow_swz_h(int k) { return ((k & 3) << 2) | ((k >> 2) & 3); }
 
 // LDS-DMA plan of one operand: like RingPlan (gemm_f32_ring.h) for 2-byte elements
@@ -83,7 +75,7 @@ template <int LAYOUT, int R, int NT, int BKE>
 struct RingPlanH {
   static constexpr int CHUNKS = (R * BKE / 8) / NT;   // 16-B chunks per thread per tile
   static_assert((R * BKE / 8) % NT == 0, "tile not divisible among threads");
-  static_assert(LAYOUT == ROWK || R == 128, "KROW image has 256-byte k rows (the wide tiles keep the KROW operand on the 128 side)");
+  static_assert(LAYOUT == ROWK || R == 128, "KROW image has 256-byte k rows");
   uint32_t voff[CHUNKS];
   int koff[CHUNKS];
   const bf16_bits* sbase;
@@ -106,13 +98,7 @@ struct RingPlanH {
 #pragma unroll
     for (int p = 0; p < CHUNKS; ++p) {
       const int q = tid + p * NT;
-      if (LAYOUT == ROWK && BKE == 32) {
-        // linear LDS slot q holds (row, chunk) with rowk32_slot(row, chunk) == q
-        const int S = q >> 3, c8 = (q & 7) ^ ((S >> 1) & 7);
-        const int r = 2 * S + (c8 >> 2), kk = (c8 & 3) << 3;
-        koff[p] = kk;
-        voff[p] = (uint32_t)(((int64_t)min(r, last) * ld + kk) * 2);
-      } else if (LAYOUT == ROWK) {
+      if (LAYOUT == ROWK) {
         constexpr int CPR = BKE / 8;
         const int r = q / CPR, c = q % CPR;
         const int kk = (c ^ rowk_swz_h<BKE>(r)) << 3;
@@ -157,11 +143,8 @@ __device__ inline void read_frags_h(bf16x8_t (&frag)[T], const bf16_bits* lds, i
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int row = row_base + t * 32 + lr;
-      if (BKE == 32)
-        frag[t] = *reinterpret_cast<const bf16x8_t*>(lds + (rowk32_slot(row, 2 * kk + h) << 3));
-      else
-        frag[t] = *reinterpret_cast<const bf16x8_t*>(
-            lds + row * BKE + (((2 * kk + h) ^ rowk_swz_h<BKE>(row)) << 3));
+      frag[t] = *reinterpret_cast<const bf16x8_t*>(
+          lds + row * BKE + (((2 * kk + h) ^ rowk_swz_h<BKE>(row)) << 3));
     }
   } else {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
@@ -189,21 +172,21 @@ int launch_gemm_bf16s(hipStream_t s, int la, int lb, int epi, bool out_bf16, con
 int launch_cast_f32_bf16(hipStream_t s, const float* src, uint16_t* dst, int64_t n);
 int launch_cast_bf16_f32(hipStream_t s, const uint16_t* src, float* dst, int64_t n);
 
-template <int BKE, int STAGES, int TM = 2, int TN = 2>
-constexpr size_t gemm_bf16s_lds_bytes() { return (size_t)STAGES * (64 * TM + 64 * TN) * BKE * 2; }
+template <int BKE, int STAGES>
+constexpr size_t gemm_bf16s_lds_bytes() { return (size_t)STAGES * (128 + 128) * BKE * 2; }
 
 // ---- epilogue: fp32 accumulators -> bf16 / fp32 C -------------------------------------------
 // OUT_BF16: consecutive-column pairs are exchanged between neighbouring lanes so that a lane
 // stores 4 bytes (even lanes row r, odd lanes row r + 1).
-template <int EPI, bool OUT_BF16, int TM = 2, int TN = 2>
-__device__ inline void gemm_epilogue_h(f32x16 (&acc)[TM][TN], const GemmParamsH& p, void* Cv, float* smem,
+template <int EPI, bool OUT_BF16>
+__device__ inline void gemm_epilogue_h(f32x16 (&acc)[2][2], const GemmParamsH& p, void* Cv, float* smem,
                                        int m0, int n0, int tile_m) {
-  constexpr int BM = 64 * TM, BN = 64 * TN, WM = 2;
+  constexpr int BN = 128, WM = 2, TM = 2, TN = 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int h = lane >> 5, lc = lane & 31;
-  const int row_w = m0 + wm * (32 * TM) + 4 * h;
-  const int col_w = n0 + wn * (32 * TN) + lc;
+  const int row_w = m0 + wm * 64 + 4 * h;
+  const int col_w = n0 + wn * 64 + lc;
 
   if (EPI == EPI_BIAS || EPI == EPI_BIAS_STATS) {
 #pragma unroll
@@ -223,21 +206,22 @@ __device__ inline void gemm_epilogue_h(f32x16 (&acc)[TM][TN], const GemmParamsH&
     // EPI_ADD: the addend pair of every (row, column pair) this lane will store, all loads
     // issued before the first use (one memory latency for the tile, not one per element); the
     // addend may alias C (in-place residual gradient): a lane reads exactly the pair it writes
-    // (one 32-row band of sub-tiles at a time: the loads of a band are in flight together)
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-    uint32_t addpk[TN][8];
+    uint32_t addpk[TM][TN][8];
     if (EPI == EPI_ADD) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
             const int row = row_w + i * 32 + ((r + (odd ? 1 : 0)) & 3) + 8 * (r >> 2);
             const int col = col_w + jn * 32 - (odd ? 1 : 0);
-            addpk[jn][r >> 1] = (row < p.M && col < p.N)
+            addpk[i][jn][r >> 1] = (row < p.M && col < p.N)
                 ? *reinterpret_cast<const uint32_t*>(p.addend + (int64_t)row * p.ldadd + col) : 0u;
           }
     }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
@@ -249,8 +233,8 @@ __device__ inline void gemm_epilogue_h(f32x16 (&acc)[TM][TN], const GemmParamsH&
           float lo = odd ? got : acc[i][jn][r];
           float hi = odd ? acc[i][jn][r + 1] : got;
           if (EPI == EPI_ADD) {
-            lo += __uint_as_float(addpk[jn][r >> 1] << 16);
-            hi += __uint_as_float(addpk[jn][r >> 1] & 0xffff0000u);
+            lo += __uint_as_float(addpk[i][jn][r >> 1] << 16);
+            hi += __uint_as_float(addpk[i][jn][r >> 1] & 0xffff0000u);
           }
           const int row = row_w + i * 32 + ((r + (odd ? 1 : 0)) & 3) + 8 * (r >> 2);
           const int col = col_w + jn * 32 - (odd ? 1 : 0);     // even column of the pair
@@ -259,7 +243,6 @@ __device__ inline void gemm_epilogue_h(f32x16 (&acc)[TM][TN], const GemmParamsH&
             *reinterpret_cast<uint32_t*>(C + (int64_t)row * p.ldc + col) = packed;
           }
         }
-    }
   } else {
     float* __restrict__ C = reinterpret_cast<float*>(Cv);
 #pragma unroll
@@ -278,7 +261,7 @@ __device__ inline void gemm_epilogue_h(f32x16 (&acc)[TM][TN], const GemmParamsH&
   if (EPI == EPI_BIAS_STATS) {
     // per-tile column (mean, M2) of the fp32 values (before rounding to bf16), as gemm_epilogue.h
     float* red = smem;   // [WM][BN]
-    const int cnt = min(BM, p.M - m0);
+    const int cnt = min(128, p.M - m0);
     float mean[TN];
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
@@ -291,14 +274,14 @@ __device__ inline void gemm_epilogue_h(f32x16 (&acc)[TM][TN], const GemmParamsH&
           if (row < p.M) s += acc[i][jn][r];
         }
       s += __shfl_xor(s, 32);
-      if (h == 0) red[wm * BN + wn * (32 * TN) + jn * 32 + lc] = s;
+      if (h == 0) red[wm * BN + wn * 64 + jn * 32 + lc] = s;
     }
     lds_barrier();
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
       float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < WM; ++w) t += red[w * BN + wn * (32 * TN) + jn * 32 + lc];
+      for (int w = 0; w < WM; ++w) t += red[w * BN + wn * 64 + jn * 32 + lc];
       mean[jn] = t / (float)cnt;
     }
     lds_barrier();
@@ -314,7 +297,7 @@ __device__ inline void gemm_epilogue_h(f32x16 (&acc)[TM][TN], const GemmParamsH&
           if (row < p.M) s += dlt * dlt;
         }
       s += __shfl_xor(s, 32);
-      if (h == 0) red[wm * BN + wn * (32 * TN) + jn * 32 + lc] = s;
+      if (h == 0) red[wm * BN + wn * 64 + jn * 32 + lc] = s;
     }
     lds_barrier();
     if (wm == 0 && h == 0) {
@@ -323,7 +306,7 @@ __device__ inline void gemm_epilogue_h(f32x16 (&acc)[TM][TN], const GemmParamsH&
         const int col = col_w + jn * 32;
         float m2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < WM; ++w) m2 += red[w * BN + wn * (32 * TN) + jn * 32 + lc];
+        for (int w = 0; w < WM; ++w) m2 += red[w * BN + wn * 64 + jn * 32 + lc];
         if (col < p.N) {
           p.stat_part[((int64_t)tile_m * 2 + 0) * p.N + col] = mean[jn];
           p.stat_part[((int64_t)tile_m * 2 + 1) * p.N + col] = m2;
@@ -333,13 +316,9 @@ __device__ inline void gemm_epilogue_h(f32x16 (&acc)[TM][TN], const GemmParamsH&
   }
 }
 
-// TM x TN = 32x32 MFMA sub-tiles per wave: 2 x 2 (tile 128 x 128, the default) up to 4 x 4
-// (256 x 256: 256 accumulator registers per lane, one wave per SIMD).
-// ABL: diagnostic ablations of the steady-state loop (tools/bf16s_bench; results are wrong, only the
-// time is read): 1 = no DMA issue, 2 = no wait + barrier, 3 = no fragment reads, 4 = no MFMAs.
-template <int LA, int LB, int EPI, bool OUT_BF16, int BKE = 64, int STAGES = 2, int TM = 2, int TN = 2, int ABL = 0>
+template <int LA, int LB, int EPI, bool OUT_BF16, int BKE = 64, int STAGES = 2>
 __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmParamsH p) {
-  constexpr int BM = 64 * TM, BN = 64 * TN, NT = 256;
+  constexpr int BM = 128, BN = 128, NT = 256, TM = 2, TN = 2;
   static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
   constexpr int RING = (BM + BN) * BKE;          // elements per stage
   constexpr int NG = BKE / 16;                   // k-steps per tile
@@ -390,12 +369,11 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmParamsH p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    read_frags_h<LA, BM, TM, BKE>(fa[0], lds, wm * (32 * TM), 0, lane);
-    read_frags_h<LB, BN, TN, BKE>(fb[0], lds + BM * BKE, wn * (32 * TN), 0, lane);
+    read_frags_h<LA, BM, TM, BKE>(fa[0], lds, wm * 64, 0, lane);
+    read_frags_h<LB, BN, TN, BKE>(fb[0], lds + BM * BKE, wn * 64, 0, lane);
   }
 
 #define BLH_H_MFMAS(CUR)                                                                        \
-  if (ABL != 4)                                                                                 \
   _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                \
   _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                             \
     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[CUR][i], fb[CUR][jn], acc[i][jn], 0, 0, 0);
@@ -408,7 +386,7 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmParamsH p) {
     const bf16_bits* sB = sA + BM * BKE;
     const bf16_bits* nA = lds + st_nxt * RING;
     __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): free here, keeps hipcc's counts exact
-    if (kt + STAGES - 1 < nkt && ABL != 1) {
+    if (kt + STAGES - 1 < nkt) {
       const int k0 = kz0 + (kt + STAGES - 1) * BKE;
       planA.issue(lds0 + st_new * (RING * 2), k0, k_end);
       planB.issue(lds0 + st_new * (RING * 2) + BM * BKE * 2, k0, k_end);
@@ -416,24 +394,22 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmParamsH p) {
 #pragma unroll
     for (int s = 0; s < NG; ++s) {
       const int cur = s & 1, nxt = cur ^ 1;
-      if (ABL == 3) {
-      } else if (s < NG - 1) {
-        read_frags_h<LA, BM, TM, BKE>(fa[nxt], sA, wm * (32 * TM), s + 1, lane);
-        read_frags_h<LB, BN, TN, BKE>(fb[nxt], sB, wn * (32 * TN), s + 1, lane);
+      if (s < NG - 1) {
+        read_frags_h<LA, BM, TM, BKE>(fa[nxt], sA, wm * 64, s + 1, lane);
+        read_frags_h<LB, BN, TN, BKE>(fb[nxt], sB, wn * 64, s + 1, lane);
       } else {
-        read_frags_h<LA, BM, TM, BKE>(fa[nxt], nA, wm * (32 * TM), 0, lane);
-        read_frags_h<LB, BN, TN, BKE>(fb[nxt], nA + BM * BKE, wn * (32 * TN), 0, lane);
+        read_frags_h<LA, BM, TM, BKE>(fa[nxt], nA, wm * 64, 0, lane);
+        read_frags_h<LB, BN, TN, BKE>(fb[nxt], nA + BM * BKE, wn * 64, 0, lane);
       }
       __builtin_amdgcn_sched_barrier(0);
       BLH_H_MFMAS(cur)
       __builtin_amdgcn_sched_barrier(0);
       if (s == NG - 2) {
         const int ahead = min(nkt - 1, kt + STAGES - 1) - (kt + 1);
-        if (ABL == 2) {
-        } else if (STAGES >= 4 && ahead >= 2) ring_wait_vm_lgkm<2 * G>();
+        if (STAGES >= 4 && ahead >= 2) ring_wait_vm_lgkm<2 * G>();
         else if (STAGES >= 3 && ahead >= 1) ring_wait_vm_lgkm<G>();
         else ring_wait_vm_lgkm<0>();
-        if (ABL != 2) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
     }
@@ -447,8 +423,8 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmParamsH p) {
     for (int s = 0; s < NG; ++s) {
       const int cur = s & 1, nxt = cur ^ 1;
       if (s < NG - 1) {
-        read_frags_h<LA, BM, TM, BKE>(fa[nxt], sA, wm * (32 * TM), s + 1, lane);
-        read_frags_h<LB, BN, TN, BKE>(fb[nxt], sB, wn * (32 * TN), s + 1, lane);
+        read_frags_h<LA, BM, TM, BKE>(fa[nxt], sA, wm * 64, s + 1, lane);
+        read_frags_h<LB, BN, TN, BKE>(fb[nxt], sB, wn * 64, s + 1, lane);
       }
       __builtin_amdgcn_sched_barrier(0);
       BLH_H_MFMAS(cur)
@@ -457,7 +433,7 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmParamsH p) {
   }
 #undef BLH_H_MFMAS
   __syncthreads();
-  gemm_epilogue_h<EPI, OUT_BF16, TM, TN>(acc, p, C, smem, m0, n0, tile_m);
+  gemm_epilogue_h<EPI, OUT_BF16>(acc, p, C, smem, m0, n0, tile_m);
 }
 
 }  // namespace blh
