@@ -220,6 +220,25 @@ __device__ inline int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
+// Split grids (the weight gradient: gridDim.z = S batch slabs of the same tiles_m x tiles_n output).
+// With xcd_remap alone every XCD owns one band of output rows for ALL slabs, i.e. it reads its
+// column panel of the first operand and the WHOLE second operand: 168 MB of HBM-side reads per
+// 1024^2 launch at B = 4096 against 50 MB algorithmic (profiles/r02_pmc_gemm.md).  Here an XCD owns
+// ONE slab (S | 8: XCD j -> slab j % S) and, when S < 8, one of the 8 / S bands of output rows:
+// each XCD then reads a 1/S slice of the batch rows once.  Returns false (and leaves tile / slab
+// alone) when the grid does not divide that way.  Assumes what xcd_remap assumes: workgroups are
+// handed to the XCDs round-robin in linear order (gridDim.x % 8 == 0 keeps that independent of z).
+__device__ inline bool xcd_remap_split(int bx, int bz, int gx, int S, int tiles_m, int tiles_n,
+                                       int* tile, int* slab) {
+  if ((gx & 7) || S < 2 || S > 8 || (8 % S) || (tiles_m % (8 / S)) || tiles_m * tiles_n != gx) return false;
+  const int xcd = bx & 7, idx = bx >> 3;           // idx < gx / 8
+  const int slot = bz * (gx >> 3) + idx;           // < gx * S / 8 workgroups of this XCD
+  const int band_rows = tiles_m / (8 / S);         // output-tile rows per band
+  *slab = xcd % S;
+  *tile = ((xcd / S) * band_rows + slot / tiles_n) * tiles_n + slot % tiles_n;
+  return true;
+}
+
 template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int PIPE = 1, int STAMP = 0, int ABLATE = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmParams p) {
   constexpr int NT = 64 * WM * WN;

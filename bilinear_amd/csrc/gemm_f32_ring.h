@@ -176,12 +176,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_ring_kernel(GemmParams 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  int tile = 0, slab = blockIdx.z;
+  if (!(gridDim.z > 1 && xcd_remap_split(blockIdx.x, blockIdx.z, gridDim.x, gridDim.z, (p.M + BM - 1) / BM,
+                                         tiles_n, &tile, &slab)))
+    tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int kz0 = blockIdx.z * p.k_per_split;
+  const int kz0 = slab * p.k_per_split;
   const int k_end = min(p.K, kz0 + p.k_per_split);
-  float* __restrict__ C = p.C + (int64_t)blockIdx.z * p.c_split_stride;
+  float* __restrict__ C = p.C + (int64_t)slab * p.c_split_stride;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_ring_kernel(GemmParams 
   if (STAMP) {
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (tid == 0) {
-      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.loss_part) + 8 * (blockIdx.x + gridDim.x * blockIdx.z);
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.loss_part) + 8 * (blockIdx.x + gridDim.x * blockIdx.z);   // (any order)
       o[0] = c1 - stamp_c0; o[1] = r1 - stamp_r0; o[2] = stamp_entry; o[3] = stamp_r0; o[4] = r1;
     }
   }
