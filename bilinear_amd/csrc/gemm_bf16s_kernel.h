@@ -332,13 +332,16 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmParamsH p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  int tile = 0, slab = blockIdx.z;   // (split grids: slab-major XCD mapping, gemm_f32_kernel.h)
+  if (!(gridDim.z > 1 && xcd_remap_split(blockIdx.x, blockIdx.z, gridDim.x, gridDim.z, (p.M + BM - 1) / BM,
+                                         tiles_n, &tile, &slab)))
+    tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int kz0 = blockIdx.z * p.k_per_split;
+  const int kz0 = slab * p.k_per_split;
   const int k_end = min(p.K, kz0 + p.k_per_split);
-  void* C = OUT_BF16 ? (void*)(reinterpret_cast<bf16_bits*>(p.C) + (int64_t)blockIdx.z * p.c_split_stride)
-                     : (void*)(reinterpret_cast<float*>(p.C) + (int64_t)blockIdx.z * p.c_split_stride);
+  void* C = OUT_BF16 ? (void*)(reinterpret_cast<bf16_bits*>(p.C) + (int64_t)slab * p.c_split_stride)
+                     : (void*)(reinterpret_cast<float*>(p.C) + (int64_t)slab * p.c_split_stride);
 
   f32x16 acc[TM][TN];
 #pragma unroll
