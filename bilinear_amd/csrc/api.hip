@@ -515,8 +515,24 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
   const int nh = (int)L.heavy.size();
   const int W = d->width, OF = d->out_features, IF = d->in_features;
   const int chunks = ew_num_row_chunks_h(batch);
-  // single stream: a reported range is complete on `s`; a two-stream context promised "complete
-  // on the side stream", so that one is made to wait
+  // Two streams as in backward_impl: every weight-gradient GEMM (+ its slab sum) runs on the
+  // context's side stream — in order there, so they share one slab buffer — forked behind the
+  // data-gradient GEMM of its stage (BLH_OPT_LATE_FORK) or behind bn_bwd_apply; one join at the end.
+  tl_stop_event = nullptr;
+  const bool two = ctx->two_stream;
+  hipStream_t s2 = two ? ctx->s2 : s;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cap);
+  const bool attach = two && cap == hipStreamCaptureStatusNone;
+  auto arm_fork = [&](int idx) { if (attach) tl_stop_event = ctx->ev_dz[idx]; };
+  auto fork_wait = [&](int idx, bool attached) -> int {   // s2 continues behind the last kernel of s
+    if (!two) return BLH_OK;
+    if (!(attached && attach)) BLH_HIP_TRY(hipEventRecord(ctx->ev_dz[idx], s));
+    BLH_HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_dz[idx], 0));
+    return BLH_OK;
+  };
+  // a reported range: weight gradient on the side stream, bias / gamma / beta on the main one;
+  // the side stream waits for the main one, so the range is complete ON THE SIDE STREAM
   auto ready = [&](int idx, int64_t off, int64_t cnt) -> int {
     if (!on_ready) return BLH_OK;
     if (ctx->two_stream) {
@@ -526,19 +542,22 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
     on_ready(user, off, cnt);
     return BLH_OK;
   };
-  // decode: dW = dP^T A_last, db = colsum(dP), dA_last = dP W_d
+  // decode: dA_last = dP W_d (carries the first fork), dW = dP^T A_last, db = colsum(dP)
   BLH_TRY(launch_cast_f32_bf16(s, dpred, ws.dpredh, batch * OF));
-  BLH_TRY(wgrad_h(s, ws.dpredh, OF, OF, ws.A[nh - 1], W, W, batch, ws.slabs, grads + L.dec_w));
-  BLH_TRY(launch_colsum(s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
-  BLH_TRY(ready(nh, L.dec_w, L.total - L.dec_w));
   {
     GemmParamsH g{};
     g.A = ws.dpredh; g.lda = OF;
     g.B = ws.wsh + L.dec_w; g.ldb = W;
     g.C = ws.G0; g.ldc = W;
     g.M = (int)batch; g.N = W; g.K = OF; g.k_per_split = OF;
+    arm_fork(nh);
     BLH_TRY(launch_gemm_bf16s(s, ROWK, KROW, EPI_STORE, true, g, 1));
+    tl_stop_event = nullptr;
   }
+  BLH_TRY(fork_wait(nh, true));
+  BLH_TRY(wgrad_h(s2, ws.dpredh, OF, OF, ws.A[nh - 1], W, W, batch, ws.slabs, grads + L.dec_w));
+  BLH_TRY(launch_colsum(s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
+  BLH_TRY(ready(nh, L.dec_w, L.total - L.dec_w));
   for (int i = nh - 1; i >= 0; --i) {
     const HeavyOffsets& h = L.heavy[i];
     const bool first_of_block = (i >= 1) && (i % 2 == 1);
@@ -551,6 +570,8 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
     BLH_TRY(launch_bn_bwd_apply_t(s, dA, ET_BF16, ws.Z[i], ET_BF16, sv + 2 * W, sv + 3 * W, sv,
                                   sv + W, grads + h.gamma, grads + h.beta, ws.dZ[i], ET_BF16,
                                   ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W, ds, batch));
+    const bool late = two && ctx->late_fork && i > 0;
+    if (two && !late) BLH_TRY(fork_wait(i, false));       // behind bn_bwd_apply (marker event)
     BLH_TRY(launch_colreduce(s, ws.dz_colsum_part + (int64_t)i * chunks * W, chunks, W, W,
                              grads + h.b));
     if (i > 0) {
@@ -558,6 +579,7 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
       g.A = ws.dZ[i]; g.lda = W;
       g.B = ws.wsh + h.w; g.ldb = W;
       g.M = (int)batch; g.N = W; g.K = W; g.k_per_split = W; g.ldc = W;
+      if (late) arm_fork(i);
       if (first_of_block) {   // d(block input) = dZ W + d(block output), in place in G0
         g.C = ws.G0; g.addend = ws.G0; g.ldadd = W;
         BLH_TRY(launch_gemm_bf16s(s, ROWK, KROW, EPI_ADD, true, g, 1));
@@ -565,14 +587,20 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
         g.C = ws.G1;
         BLH_TRY(launch_gemm_bf16s(s, ROWK, KROW, EPI_STORE, true, g, 1));
       }
-      BLH_TRY(wgrad_h(s, ws.dZ[i], W, W, ws.A[i - 1], W, W, batch, ws.slabs, grads + h.w));
+      tl_stop_event = nullptr;
+      if (late) BLH_TRY(fork_wait(i, true));
+      BLH_TRY(wgrad_h(s2, ws.dZ[i], W, W, ws.A[i - 1], W, W, batch, ws.slabs, grads + h.w));
     } else {
-      BLH_TRY(wgrad_h(s, ws.dZ[0], W, W, ws.xh, IF, IF, batch, ws.slabs, grads + h.w));
+      BLH_TRY(wgrad_h(s2, ws.dZ[0], W, W, ws.xh, IF, IF, batch, ws.slabs, grads + h.w));
     }
     if (on_ready) {
       const int64_t end = (i + 1 < nh) ? L.heavy[i + 1].w : L.dec_w;
       BLH_TRY(ready(i, h.w, end - h.w));
     }
+  }
+  if (two) {   // join: the side stream is in order, its last kernel is stage 0's slab sum
+    BLH_HIP_TRY(hipEventRecord(ctx->ev_w[0], s2));
+    BLH_HIP_TRY(hipStreamWaitEvent(s, ctx->ev_w[0], 0));
   }
   return BLH_OK;
 }

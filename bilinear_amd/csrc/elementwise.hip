@@ -450,6 +450,7 @@ __global__ __launch_bounds__(EW_THREADS, BLH_EW_H_WAVES) void bn_bwd_reduce_h_ke
     const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ invstd, float* __restrict__ part, int64_t batch, int W,
     int row_chunk, DropoutSrc drop) {
+  BLH_EW_PRIO();
   __shared__ __attribute__((aligned(16))) float red[4 * 512];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col0 = blockIdx.x * H_COLS_PER_BLOCK;
@@ -503,6 +504,7 @@ __global__ __launch_bounds__(EW_THREADS, BLH_EW_H_WAVES) void bn_bwd_apply_h_ker
     const float* __restrict__ invstd, const float* __restrict__ dgamma,
     const float* __restrict__ dbeta, bf16_bits* __restrict__ dZ, float* __restrict__ colsum_part,
     int64_t batch, int W, int row_chunk, DropoutSrc drop, int64_t norm_batch) {
+  BLH_EW_PRIO();
   __shared__ __attribute__((aligned(16))) float red[4 * 512];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col0 = blockIdx.x * H_COLS_PER_BLOCK;

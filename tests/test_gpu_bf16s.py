@@ -269,3 +269,37 @@ def test_bf16s_fused_step_learns_and_is_deterministic():
     with torch.no_grad():
         a, b = net(x), net(x)
     assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
+def test_bf16s_backward_schedules_are_bit_identical():
+    """Two-stream backward of the bf16-storage path (weight gradients on the side stream, forked
+    behind the data-gradient GEMM or behind bn_bwd_apply) only re-orders independent kernels:
+    every gradient, moment and parameter is bit-equal to the single-stream order, through the
+    fused step and through autograd (blh_backward)."""
+    import bilinear_amd
+    from bilinear_amd import _native as N
+    dev = _dev()
+    x, t = (torch.randn(8192, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(3)),
+            torch.randn(8192, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(4)))
+    out = {}
+    for sched in ((True, 1), (True, 0), (False, 1)):
+        torch.manual_seed(0)
+        net, opt, _, _ = bilinear_amd.load(dev, num_blocks=2, width=1024, gemm_dtype="bf16s")
+        net.train()
+        net.engine.ensure(dev)
+        net.engine.seed = 11
+        net.engine.set_two_stream(sched[0])
+        net.engine.ctx.set_option(N.OPT_LATE_FORK, sched[1])
+        for _ in range(2):
+            pred, loss = net.train_step(opt, x, t, max_norm=1.0)
+        # autograd path (blh_backward) on the third step
+        opt.zero_grad()
+        p3 = net(x)
+        torch.nn.functional.mse_loss(p3, t).backward()
+        torch.cuda.synchronize()
+        out[sched] = (pred.clone(), net.engine.params.clone(), opt._exp_avg_sq.clone(),
+                      net.engine.grads.clone(), p3.detach().clone())
+    for other in ((True, 0), (False, 1)):
+        for a, b, what in zip(out[(True, 1)], out[other], ("pred", "params", "exp_avg_sq", "grads", "pred3")):
+            assert torch.equal(a, b), (other, what)
+    assert torch.isfinite(out[(True, 1)][3]).all()

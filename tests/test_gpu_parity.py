@@ -55,6 +55,14 @@ GEMM_CASES = [
     (1024, 32, 1000, 1, 1, 8),        # encode wgrad: N = 32, ragged reduction
     (48, 1024, 777, 1, 1, 1),         # decode wgrad: M = 48, odd batch
     (132, 200, 36, 1, 0, 1),
+    # split grids that take the slab-major XCD mapping (xcd_remap_split: tiles % 8 == 0, S | 8,
+    # tiles_m % (8 / S) == 0); every (tile, slab) must be produced exactly once (NaN-initialised C)
+    (1024, 1024, 1024, 1, 1, 2),
+    (1024, 1024, 2048, 1, 1, 8),
+    (2048, 2048, 256, 1, 1, 2),
+    (128, 1024, 1024, 0, 0, 8),       # small-batch forward: one row of tiles, split-K
+    (512, 512, 1024, 1, 1, 4),        # 16 tiles, 4 slabs: two bands of output rows
+    (384, 1024, 512, 1, 1, 4),        # 24 tiles: tiles_m = 3 does not divide -> plain mapping
 ]
 
 
