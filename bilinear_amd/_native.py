@@ -165,7 +165,6 @@ def lib():
 OPT_TWO_STREAM = 0
 OPT_DEFER_SLABS = 1
 OPT_LATE_FORK = 2
-OPT_EPILOGUE_REDUCE = 3
 
 
 class Context:

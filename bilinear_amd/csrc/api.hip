@@ -33,7 +33,6 @@ struct blh_context {
   bool two_stream = true;
   bool defer_slabs = false;
   bool late_fork = true;    // BLH_OPT_LATE_FORK
-  bool epilogue_reduce = true;   // BLH_OPT_EPILOGUE_REDUCE
   // per-call state (set by the entry point for the duration of the call)
   blh::SyncCtx sync = {nullptr, nullptr, 0};
   const uint64_t* step_dev = nullptr;
@@ -271,20 +270,6 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
     on_ready(user, off, cnt);
     return BLH_OK;
   };
-  // BatchNorm-backward column sums of stage j computed by the GEMM that produces its dA (BnBwdRed,
-  // common.h): fills g.red and returns the number of row tiles (= partial rows), or 0 when the
-  // pass stays with bn_bwd_reduce_kernel (option off, misaligned shard, partial buffer too small)
-  auto epilogue_reduce = [&](GemmParams& g, int j, int tile_rows) -> int {
-    const int tiles = (int)ceil_div(batch, tile_rows);
-    if (!ctx->epilogue_reduce || (drop->row_offset & 31) != 0 || tiles > chunks) return 0;
-    const float* svj = ws.bn_saved[j];
-    g.red.Z = ws.Z[j]; g.red.ldz = W;
-    g.red.scale = svj + 2 * W; g.red.shift = svj + 3 * W; g.red.mean = svj; g.red.invstd = svj + W;
-    g.red.part = ws.bn_part;
-    g.red.drop = layer_drop(ctx, drop, j, batch, W);
-    return tiles;
-  };
-  int red_tiles = 0;   // > 0: the sums of the stage about to be processed are already in ws.bn_part
   // decode: dA_last = dP W_d on the main stream first (it carries the fork event: the decode
   // weight gradient then starts when it completes, next to the first BatchNorm-backward kernels),
   // dW = dP^T A_last on the side stream, db = colsum(dP)
@@ -294,7 +279,6 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
     g.B = params + L.dec_w; g.ldb = W;
     g.C = ws.G0; g.ldc = W;
     g.M = (int)batch; g.N = W; g.K = OF; g.k_per_split = OF;
-    red_tiles = epilogue_reduce(g, nh - 1, (batch >= 2048 && d->gemm_dtype != 1) ? 64 : 128);
     arm_fork(nh);
     // (K = 48: two K tiles and 16.8 MB of output; 64-row tiles = two workgroups per CU)
     BLH_TRY(launch_gemm(s, (batch >= 2048 && d->gemm_dtype != 1) ? TILE_64x128 : TILE_128x128, ROWK, KROW, EPI_STORE, g, 1,
@@ -317,12 +301,9 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
     const float* dA = first_of_block ? ws.G1 : ws.G0;
     const float* sv = ws.bn_saved[i];
     const DropoutSrc ds = layer_drop(ctx, drop, i, batch, W);
-    if (red_tiles == 0)
-      BLH_TRY(launch_bn_bwd_reduce(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W, ws.bn_part,
-                                   batch, W, ds));
-    BLH_TRY(launch_bn_bwd_finalize(s, ws.bn_part, red_tiles ? red_tiles : chunks, W, grads + h.gamma,
-                                   grads + h.beta));
-    red_tiles = 0;
+    BLH_TRY(launch_bn_bwd_reduce(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W, ws.bn_part,
+                                 batch, W, ds));
+    BLH_TRY(launch_bn_bwd_finalize(s, ws.bn_part, chunks, W, grads + h.gamma, grads + h.beta));
     const float* dg = grads + h.gamma;
     const float* db = grads + h.beta;
     int64_t norm_batch = batch;
@@ -382,7 +363,6 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
         BLH_TRY(launch_sum_slabs_add(s, ws.slabs, batch * (int64_t)W, ds2.splits,
                                      first_of_block ? ws.G0 : nullptr, dst));
       } else {
-        red_tiles = epilogue_reduce(g, i - 1, 128);
         if (first_of_block) {
           // d(block input) = dZ W + d(block output)   (skip path), in place in G0
           g.C = ws.G0; g.addend = ws.G0; g.ldadd = W;
@@ -671,7 +651,6 @@ int blh_context_create(blh_context** out) {
   c->two_stream = getenv("BLH_ONE_STREAM") == nullptr;
   c->defer_slabs = getenv("BLH_DEFER_SLABS") != nullptr;
   c->late_fork = getenv("BLH_EARLY_FORK") == nullptr;
-  c->epilogue_reduce = getenv("BLH_NO_EPILOGUE_REDUCE") == nullptr;
   *out = c;
   return BLH_OK;
 }
@@ -694,7 +673,6 @@ int blh_context_set_option(blh_context* c, int32_t option, int32_t value) {
     case BLH_OPT_TWO_STREAM: c->two_stream = value != 0; return BLH_OK;
     case BLH_OPT_DEFER_SLABS: c->defer_slabs = value != 0; return BLH_OK;
     case BLH_OPT_LATE_FORK: c->late_fork = value != 0; return BLH_OK;
-    case BLH_OPT_EPILOGUE_REDUCE: c->epilogue_reduce = value != 0; return BLH_OK;
   }
   return BLH_ERR_INVALID_ARGUMENT;
 }
@@ -705,7 +683,6 @@ int blh_context_get_option(const blh_context* c, int32_t option) {
     case BLH_OPT_TWO_STREAM: return c->two_stream ? 1 : 0;
     case BLH_OPT_DEFER_SLABS: return c->defer_slabs ? 1 : 0;
     case BLH_OPT_LATE_FORK: return c->late_fork ? 1 : 0;
-    case BLH_OPT_EPILOGUE_REDUCE: return c->epilogue_reduce ? 1 : 0;
   }
   return BLH_ERR_INVALID_ARGUMENT;
 }

@@ -54,36 +54,6 @@ enum Epilogue : int {
   EPI_BN_RELU = 4      // eval forward: C = relu(bn_eval(acc + bias[n])) (+ addend[m][n], the block skip)
 };
 
-struct DropoutSrc {
-  const uint8_t* keep;   // [B][W] for this layer, or nullptr -> Philox
-  uint64_t seed, step;
-  int64_t row_offset;
-  int layer;
-  // hipGraph replay: the dropout step lives in device memory (blh_step_state.rng_step) and is
-  // added to `step`, so that a captured launch draws a fresh mask on every replay
-  const uint64_t* step_dev;
-};
-__host__ __device__ inline uint64_t dropout_step(const DropoutSrc& d) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return d.step + (d.step_dev ? *d.step_dev : 0ull);
-#else
-  return d.step;
-#endif
-}
-
-// BatchNorm-backward column sums computed in the epilogue of the data-gradient GEMM that PRODUCES
-// dA (EPI_STORE / EPI_ADD; SURVEY.md K9 "reductions in the epilogue"): C is the gradient w.r.t. the
-// output of a heavy_linear stage whose pre-BN output Z, saved statistics and dropout stream are
-// given here; the epilogue emits per-row-tile partials of sum dY*zhat and sum dY (dY = C * 2*keep *
-// [BN(Z) > 0]) in the layout bn_bwd_reduce_kernel writes, and that kernel's pass over dA and Z is
-// not launched.  Enabled when part != nullptr; drop.row_offset must be a multiple of 32.
-struct BnBwdRed {
-  const float* Z; int64_t ldz;
-  const float* scale; const float* shift; const float* mean; const float* invstd;   // [N]
-  float* part;              // [tiles_m][2][N]
-  DropoutSrc drop;
-};
-
 struct GemmParams {
   const float* A;
   const float* B;
@@ -102,7 +72,6 @@ struct GemmParams {
   // gemm_dtype 3 (fp16 two-piece split): max |value| partials of each operand tensor
   const float* a_amax; int a_namax;
   const float* b_amax; int b_namax;
-  BnBwdRed red;             // EPI_STORE / EPI_ADD only
 };
 
 enum GemmTile : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_128x32 = 3 };
@@ -116,7 +85,23 @@ int launch_gemm(hipStream_t s, GemmTile tile, int la, int lb, int epi, const Gem
                 int splits, int dtype = 0);
 
 // ---------------------------------------------------------- elementwise ----
-// (DropoutSrc: above, next to GemmParams)
+struct DropoutSrc {
+  const uint8_t* keep;   // [B][W] for this layer, or nullptr -> Philox
+  uint64_t seed, step;
+  int64_t row_offset;
+  int layer;
+  // hipGraph replay: the dropout step lives in device memory (blh_step_state.rng_step) and is
+  // added to `step`, so that a captured launch draws a fresh mask on every replay
+  const uint64_t* step_dev;
+};
+__host__ __device__ inline uint64_t dropout_step(const DropoutSrc& d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return d.step + (d.step_dev ? *d.step_dev : 0ull);
+#else
+  return d.step;
+#endif
+}
+
 // (row chunking of the streaming kernels: host_util.h)
 
 // forward BN: merge per-tile (mean, M2) -> batch mean / invstd, scale/shift, running stats

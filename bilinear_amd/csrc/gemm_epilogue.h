@@ -6,7 +6,6 @@
 //   See gemm_f32_kernel.h for the contractions it serves.
 #pragma once
 #include "common.h"
-#include "philox.h"
 
 namespace blh {
 
@@ -93,78 +92,6 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], 
         if (row < p.M && col < p.N && is_cons) C[(int64_t)row * p.ldc + col] = acc[i][jn][r];
       }
     }
-
-  if ((EPI == EPI_STORE || EPI == EPI_ADD) && p.red.part != nullptr) {
-    // BatchNorm-backward column sums of the stage that consumes C (BnBwdRed, common.h), while the
-    // stores above drain.  One Philox call per 32x32 sub-tile = the 32-row x 4-column patch that
-    // contains this lane's column; the lane's 16 rows of it are 8 (r >> 2) + 4 h + (r & 3).
-    const BnBwdRed& q = p.red;
-    float zz[TM][TN][16];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2);
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) {
-          const int col = col_w + jn * 32;
-          zz[i][jn][r] = (row < p.M && col < p.N) ? q.Z[(int64_t)row * q.ldz + col] : 0.f;
-        }
-      }
-    float sgam[TN], sbet[TN];
-#pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-      const int col = col_w + jn * 32;
-      const bool okc = col < p.N;
-      const int cc = okc ? col : 0;
-      const float sc = q.scale[cc], sh = q.shift[cc], mu = q.mean[cc], is = q.invstd[cc];
-      float sg = 0.f, sb = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row0 = m0 + wm * (TM * 32) + i * 32;            // first row of the sub-tile
-        Philox128 pm;
-        if (!q.drop.keep) pm = dropout_patch(q.drop.seed, dropout_step(q.drop), q.drop.layer, row0 + q.drop.row_offset, cc);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2);
-          bool keep;
-          if (q.drop.keep) keep = (row < p.M && okc) ? q.drop.keep[(int64_t)row * p.N + col] != 0 : false;
-          else keep = (pm.w[r >> 2] >> ((4 * h + (r & 3)) * 4 + (cc & 3))) & 1u;
-          const float z = zz[i][jn][r];
-          const float dy = (keep && fmaf(z, sc, sh) > 0.f && row < p.M && okc) ? acc[i][jn][r] * 2.f : 0.f;
-          sb += dy;
-          sg += dy * ((z - mu) * is);
-        }
-      }
-      sg += __shfl_xor(sg, 32);
-      sb += __shfl_xor(sb, 32);
-      sgam[jn] = sg; sbet[jn] = sb;
-    }
-    float* red = smem;   // [2][WM][BN]; stage buffers are dead (barrier closed the main loop)
-#pragma unroll
-    for (int jn = 0; jn < TN; ++jn)
-      if (h == 0 && is_cons) {
-        red[wm * BN + wn * (TN * 32) + jn * 32 + lc] = sgam[jn];
-        red[(WM + wm) * BN + wn * (TN * 32) + jn * 32 + lc] = sbet[jn];
-      }
-    lds_barrier();
-    if (wm == 0 && h == 0 && is_cons) {
-#pragma unroll
-      for (int jn = 0; jn < TN; ++jn) {
-        const int col = col_w + jn * 32;
-        float g = 0.f, b = 0.f;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) {
-          g += red[w * BN + wn * (TN * 32) + jn * 32 + lc];
-          b += red[(WM + w) * BN + wn * (TN * 32) + jn * 32 + lc];
-        }
-        if (col < p.N) {
-          q.part[((int64_t)tile_m * 2 + 0) * p.N + col] = g;
-          q.part[((int64_t)tile_m * 2 + 1) * p.N + col] = b;
-        }
-      }
-    }
-  }
 
   if (EPI == EPI_BIAS_STATS) {
     // Per-tile column statistics in the shifted (Welford/Chan) form: tile mean and

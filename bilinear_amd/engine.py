@@ -145,7 +145,7 @@ class Engine:
             old = self.ctx
             self.ctx = N.Context(device)
             if old is not None:    # keep the options across a device move
-                for opt in (N.OPT_TWO_STREAM, N.OPT_DEFER_SLABS, N.OPT_LATE_FORK, N.OPT_EPILOGUE_REDUCE):
+                for opt in (N.OPT_TWO_STREAM, N.OPT_DEFER_SLABS, N.OPT_LATE_FORK):
                     self.ctx.set_option(opt, old.get_option(opt))
         self.device = device
         self._workspace = None

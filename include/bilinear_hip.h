@@ -74,14 +74,10 @@ typedef enum {
                              0: single-stream order.  Results are bit-identical either way.  */
   BLH_OPT_DEFER_SLABS = 1, /* 1: sum all split-K weight-gradient slabs in one launch at the end
                               of backward (default 0: right after each GEMM)                 */
-  BLH_OPT_LATE_FORK = 2,  /* 1 (default): a stage's weight-gradient GEMM starts behind its
+  BLH_OPT_LATE_FORK = 2   /* 1 (default): a stage's weight-gradient GEMM starts behind its
                              data-gradient GEMM and runs beside the next stage's BatchNorm
                              backward; 0: it starts together with the data-gradient GEMM.
                              Scheduling only: results are bit-identical.                     */
-  BLH_OPT_EPILOGUE_REDUCE = 3 /* 1 (default): the BatchNorm-backward column sums of a stage are
-                             computed in the epilogue of the data-gradient GEMM that produces its
-                             input gradient (one pass over [B,W] less per stage); 0: by the
-                             separate reduction kernel.  Same sums, different summation order.   */
 } blh_option;
 int blh_context_set_option(blh_context* ctx, int32_t option, int32_t value);
 int blh_context_get_option(const blh_context* ctx, int32_t option);
