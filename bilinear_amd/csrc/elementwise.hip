@@ -105,6 +105,26 @@ __device__ __forceinline__ double strided_colsum(const float* __restrict__ in, i
   return acc;
 }
 
+// batch mean / M2 of one column -> saved statistics, scale / shift, running statistics
+__device__ __forceinline__ void bn_finalize_store(double mean, double m2, int64_t batch, int col,
+                                                  const float* gamma, const float* beta,
+                                                  float* running_mean, float* running_var,
+                                                  const int64_t* nbt, float momentum, float* saved_mean,
+                                                  float* saved_invstd, float* scale, float* shift) {
+  const double var = m2 / (double)batch;
+  const float invstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
+  const float mu = (float)mean;
+  const float sc = gamma[col] * invstd;
+  saved_mean[col] = mu;
+  saved_invstd[col] = invstd;
+  scale[col] = sc;
+  shift[col] = beta[col] - mu * sc;
+  const double f = (momentum >= 0.f) ? (double)momentum : 1.0 / (double)(nbt[0] + 1);
+  const double unbiased = m2 / (double)(batch > 1 ? batch - 1 : 1);
+  running_mean[col] = (float)((1.0 - f) * (double)running_mean[col] + f * mean);
+  running_var[col] = (float)((1.0 - f) * (double)running_var[col] + f * unbiased);
+}
+
 // ---------------------------------------------------------------------------
 // forward BN finalize: merge per-tile (mean, M2) partials (Chan et al.) into the
 // batch mean / biased variance; emit scale = gamma*invstd, shift = beta - mean*scale;
@@ -123,6 +143,50 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
   // both passes read every tile partial of this column with the loads of 8 tiles in flight
   constexpr int U = 8;
   const int cc = ok ? col : 0;
+  if (tiles <= 8 * U) {
+    // the usual case (batch <= 8192 at 128-row tiles): every partial this thread needs, (mean, M2) of
+    // up to U tiles, is requested at once and kept in registers for the second step — one memory
+    // round trip instead of two (this kernel is nothing but latency)
+    float mu[U], m2t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t tt = min(sl + 8 * u, tiles - 1);
+      mu[u] = part[(tt * 2 + 0) * W + cc];
+      m2t[u] = part[(tt * 2 + 1) * W + cc];
+    }
+    double acc1 = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = sl + 8 * u;
+      const double n = (double)min((int64_t)tile_rows, batch - (int64_t)t * tile_rows);
+      if (t < tiles) acc1 += n * (double)mu[u];
+    }
+    red[sl][cl] = acc1;
+    __syncthreads();
+    double mean1 = 0.0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) mean1 += red[s][cl];
+    mean1 /= (double)batch;
+    __syncthreads();
+    double acc2 = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = sl + 8 * u;
+      const double n = (double)min((int64_t)tile_rows, batch - (int64_t)t * tile_rows);
+      const double d = (double)mu[u] - mean1;
+      if (t < tiles) acc2 += (double)m2t[u] + n * d * d;
+    }
+    red[sl][cl] = acc2;
+    __syncthreads();
+    if (sl == 0 && ok) {
+      double m2 = 0.0;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) m2 += red[s][cl];
+      bn_finalize_store(mean1, m2, batch, col, gamma, beta, running_mean, running_var, nbt, momentum,
+                        saved_mean, saved_invstd, scale, shift);
+    }
+    return;
+  }
   double acc = 0.0;
   for (int t0 = sl; t0 < tiles; t0 += 8 * U) {
     float mu[U];
@@ -165,18 +229,8 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
     double m2 = 0.0;
 #pragma unroll
     for (int s = 0; s < 8; ++s) m2 += red[s][cl];
-    const double var = m2 / (double)batch;
-    const float invstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
-    const float mu = (float)mean;
-    const float sc = gamma[col] * invstd;
-    saved_mean[col] = mu;
-    saved_invstd[col] = invstd;
-    scale[col] = sc;
-    shift[col] = beta[col] - mu * sc;
-    const double f = (momentum >= 0.f) ? (double)momentum : 1.0 / (double)(nbt[0] + 1);
-    const double unbiased = m2 / (double)(batch > 1 ? batch - 1 : 1);
-    running_mean[col] = (float)((1.0 - f) * (double)running_mean[col] + f * mean);
-    running_var[col] = (float)((1.0 - f) * (double)running_var[col] + f * unbiased);
+    bn_finalize_store(mean, m2, batch, col, gamma, beta, running_mean, running_var, nbt, momentum,
+                      saved_mean, saved_invstd, scale, shift);
   }
 }
 
@@ -1599,6 +1653,22 @@ __global__ __launch_bounds__(256) void grads_finish_kernel(float* __restrict__ g
   double acc = 0.0;
   const int64_t end = min(reg.cnt4, base + R.items_per_block);
   float facc = 0.f;
+  if (reg.splits == 0) {
+    // plain region (the default: slabs were summed right after each weight-gradient GEMM): the
+    // loads of 8 strides are requested together — one memory round trip per 8 float4, not 8
+    double dacc = 0.0;
+    for (int64_t i0 = base + threadIdx.x; i0 < end; i0 += 8 * 256) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ld4(grads + (reg.off4 + min(i0 + u * 256, end - 1)) * 4);
+      float f = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * 256 < end) f += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
+      dacc += (double)f;
+    }
+    acc = dacc;
+  } else {
   for (int64_t i = base + threadIdx.x; i < end; i += 256) {
     float4 v;
     if (reg.splits > 0) {
@@ -1623,6 +1693,7 @@ __global__ __launch_bounds__(256) void grads_finish_kernel(float* __restrict__ g
     facc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
   }
   acc = (double)facc;   // <= 8 float4 per thread: fp32 partial, fp64 from here on
+  }
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (int o = 128; o >= 1; o >>= 1) {
