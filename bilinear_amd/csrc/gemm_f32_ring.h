@@ -157,7 +157,8 @@ __device__ __forceinline__ void ring_wait_vm_lgkm() {
 // the timing is read): 2 = no barrier, 3 = no DMA issue, 4 = no fragment reads, 5 = no wait + barrier.
 // Measured (M = 4096, N = K = 1024, bk64 x 2): full loop 146.3 k cycles against the MFMA-ideal
 // 131.1 k; without the barrier 141.6 k, without the DMA 139.4 k, without the fragment reads
-// 143.1 k: no single part explains the last 6 % (back-to-back MFMAs alone measure ~4 % above ideal).
+// 143.1 k: no single part explains the last 6 % (round 1 measured 33.4 cycles per 32-cycle bf16 MFMA in a loop of
+// MFMAs and fragment reads only: back-to-back issue itself sits ~4 % above the instruction's pass count).
 template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int BKT = 32, int STAGES = 3, int STAMP = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_ring_kernel(GemmParams p) {
   constexpr int NT = 64 * WM * WN;
