@@ -154,11 +154,13 @@ __device__ __forceinline__ void ring_wait_vm_lgkm() {
 // STAMP: diagnostic builds only (tools/gemm_bench): 100 MHz real-time / shader-clock stamps at
 // entry, main-loop start, main-loop end and kernel end, written to p.loss_part (8 u64 per WG).
 // STAMP 2..5 additionally ablate one part of the steady-state loop (results are then wrong; only
-// the timing is read): 2 = no barrier, 3 = no DMA issue, 4 = no fragment reads, 5 = no wait + barrier.
+// the timing is read): 2 = no barrier, 3 = no DMA issue, 4 = no fragment reads, 5 = no wait + barrier,
+// 6 = none of them (MFMAs only).
 // Measured (M = 4096, N = K = 1024, bk64 x 2): full loop 146.3 k cycles against the MFMA-ideal
 // 131.1 k; without the barrier 141.6 k, without the DMA 139.4 k, without the fragment reads
 // 143.1 k: no single part explains the last 6 % (round 1 measured 33.4 cycles per 32-cycle bf16 MFMA in a loop of
 // MFMAs and fragment reads only: back-to-back issue itself sits ~4 % above the instruction's pass count).
+// STAMP 6 (MFMAs only): 134.6 k cycles, 62.8 us per launch = the ceiling of this launch shape (0.87 of peak).
 template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int BKT = 32, int STAGES = 3, int STAMP = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_ring_kernel(GemmParams p) {
   constexpr int NT = 64 * WM * WN;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_ring_kernel(GemmParams 
     __builtin_amdgcn_s_waitcnt(0xC07F);
     // the stage being refilled is the one read in iteration kt-1: every wave's reads of it were
     // retired (lgkmcnt(0)) before that iteration's barrier
-    if (kt + STAGES - 1 < nkt && STAMP != 3) {
+    if (kt + STAGES - 1 < nkt && STAMP != 3 && STAMP != 6) {
       const int k0 = kz0 + (kt + STAGES - 1) * BKT;
       planA.issue(lds0 + st_new * (RING * 4), k0, k_end);
       planB.issue(lds0 + st_new * (RING * 4) + BM * BKT * 4, k0, k_end);
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_ring_kernel(GemmParams 
 #pragma unroll
     for (int s = 0; s < NG; ++s) {
       const int cur = s & 1, nxt = cur ^ 1;
-      if (STAMP == 4) {
+      if (STAMP == 4 || STAMP == 6) {
         // (ablation: fragments are not re-read)
       } else if (s < NG - 1) {
         ring_read_frags<LA, BM, TM, BKT>(fa[nxt], sA, wm * (TM * 32), s + 1, lane);
@@ -273,12 +275,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_ring_kernel(GemmParams 
         // tile kt+1 must have landed (it is read from the next k-group on); tiles kt+2 ..
         // kt+STAGES-1, as far as they exist, stay in flight across the barrier
         const int ahead = min(nkt - 1, kt + STAGES - 1) - (kt + 1);
-        if (STAMP == 5) {
+        if (STAMP == 5 || STAMP == 6) {
           // (ablation: neither wait nor barrier)
         } else if (STAGES >= 4 && ahead >= 2) ring_wait_vm_lgkm<2 * G>();
         else if (STAGES >= 3 && ahead >= 1) ring_wait_vm_lgkm<G>();
         else ring_wait_vm_lgkm<0>();
-        if (STAMP != 2 && STAMP != 5) __builtin_amdgcn_s_barrier();
+        if (STAMP != 2 && STAMP != 5 && STAMP != 6) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
     }

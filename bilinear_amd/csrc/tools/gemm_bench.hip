@@ -217,6 +217,7 @@ int main(int argc, char** argv) {
     stamped("ABL no DMA      bk64 st2 ", gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 64, 2, 3>, gemm_ring_lds_bytes<128, 128, 64, 2>(), f);
     stamped("ABL no ds_read  bk64 st2 ", gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 64, 2, 4>, gemm_ring_lds_bytes<128, 128, 64, 2>(), f);
     stamped("ABL no wait+bar bk64 st2 ", gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 64, 2, 5>, gemm_ring_lds_bytes<128, 128, 64, 2>(), f);
+    stamped("ABL MFMAs only  bk64 st2 ", gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 64, 2, 6>, gemm_ring_lds_bytes<128, 128, 64, 2>(), f);
     stamped("STAMP ring bk32 st2 fwd  ", gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 32, 2, 1>, gemm_ring_lds_bytes<128, 128, 32, 2>(), f);
     GemmParams f1 = f; f1.K = 64; f1.k_per_split = 64;   // fixed per-launch cost: one K tile
     float tk = run_ring<128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS, 64, 2>(f1, 1, 200);
