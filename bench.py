@@ -221,6 +221,16 @@ def recorded_traffic(batch, width):
         return None
 
 
+def recorded_ceiling(batch, width):
+    if (batch, width) != (4096, 1024):
+        return None
+    try:
+        with open(os.path.join(REPO, "profiles", "r02_traffic.json")) as f:
+            return json.load(f)["kernels"]["linear_fwd"]["shape_ceiling"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def roofline_block(args, dom):
     """Roofline of the dominant kernel (the WxW Linear forward GEMM at M = batch)."""
     flop = 2.0 * args.batch * args.width * args.width
@@ -233,6 +243,9 @@ def roofline_block(args, dom):
             "traffic": recorded_traffic(args.batch, args.width),
             "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r02_traffic.json)",
             "avg_launch_ms": dom["ms"], "flop_per_launch": flop,
+            # what a kernel of this launch shape (one 128x128 tile per CU) can reach at all: the
+            # same kernel with its loop reduced to the MFMAs, measured (profiles/r02_traffic.json)
+            "shape_ceiling": recorded_ceiling(args.batch, args.width),
         }
     if args.dtype == "bf16s":
         return {
