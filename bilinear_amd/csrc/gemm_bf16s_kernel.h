@@ -200,45 +200,88 @@ __device__ inline void gemm_epilogue_h(f32x16 (&acc)[2][2], const GemmParamsH& p
     }
   }
   static_assert(EPI != EPI_ADD || OUT_BF16, "the skip-gradient epilogue writes bf16");
-  if (OUT_BF16) {
+  // ---- C stores.  Measured (tools/bf16s_bench, M = 16384, W = 1024): writing the tile straight
+  // from the MFMA register layout — a lane owns 4 consecutive ROWS of one column, so even with
+  // neighbouring lanes exchanging values a store instruction covers four 64-byte row segments —
+  // cost 20 us of a 59 us forward GEMM (the same kernel without its C stores: 38 us).  The tile
+  // therefore goes through LDS (free after the main loop): fp32 values, 64 rows at a time (the
+  // two wave rows in turn), row pitch 136 floats (conflict-free for the 32-lane row writes of both
+  // lane halves); then every thread reads 8 (bf16 out) or 4 (fp32 out) consecutive columns of one
+  // row and issues ONE 16-byte store: a wave writes four full 256-byte (512-byte) rows per
+  // instruction.  The skip-gradient addend (EPI_ADD) is loaded with the same 16-byte pattern and
+  // added in fp32 before the single rounding to bf16; it may alias C (in place): a thread reads
+  // exactly the 16 bytes it then writes.
+  constexpr int SP = 136;                         // staging row pitch in floats
+  constexpr int VEC = OUT_BF16 ? 8 : 4;           // columns per 16-byte store
+  const bool vec_ok = (p.N % VEC == 0) && (p.ldc % VEC == 0) && ((reinterpret_cast<uintptr_t>(Cv) & 15) == 0) &&
+                      (EPI != EPI_ADD || ((p.ldadd % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.addend) & 15) == 0)));
+  if (vec_ok) {
+    float* stg = smem;                            // [64][SP] floats = 34 KB
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (wm == half) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              stg[(i * 32 + 8 * (r >> 2) + 4 * h + (r & 3)) * SP + wn * 64 + jn * 32 + lc] = acc[i][jn][r];
+      }
+      __syncthreads();
+      constexpr int CPR = BN / VEC;               // 16-byte chunks per tile row
+#pragma unroll
+      for (int q0 = 0; q0 < 64 * CPR; q0 += 256) {
+        const int q = q0 + tid;
+        const int lrow = q / CPR, cv = (q % CPR) * VEC;
+        const int row = m0 + half * 64 + lrow, col = n0 + cv;
+        if (row < p.M && col < p.N) {
+          const float4 v0 = *reinterpret_cast<const float4*>(stg + lrow * SP + cv);
+          if (OUT_BF16) {
+            const float4 v1 = *reinterpret_cast<const float4*>(stg + lrow * SP + cv + 4);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            if (EPI == EPI_ADD) {
+              const uint4 ad = *reinterpret_cast<const uint4*>(p.addend + (int64_t)row * p.ldadd + col);
+              v[0] += __uint_as_float(ad.x << 16); v[1] += __uint_as_float(ad.x & 0xffff0000u);
+              v[2] += __uint_as_float(ad.y << 16); v[3] += __uint_as_float(ad.y & 0xffff0000u);
+              v[4] += __uint_as_float(ad.z << 16); v[5] += __uint_as_float(ad.z & 0xffff0000u);
+              v[6] += __uint_as_float(ad.w << 16); v[7] += __uint_as_float(ad.w & 0xffff0000u);
+            }
+            uint4 o;
+            o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+            o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            o.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+            o.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_bits*>(Cv) + (int64_t)row * p.ldc + col) = o;
+          } else {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (int64_t)row * p.ldc + col) = v0;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  } else if (OUT_BF16) {
+    // (shapes without 16-byte rows: element pairs, neighbouring lanes exchanging values)
     bf16_bits* __restrict__ C = reinterpret_cast<bf16_bits*>(Cv);
     const bool odd = lane & 1;
-    // EPI_ADD: the addend pair of every (row, column pair) this lane will store, all loads
-    // issued before the first use (one memory latency for the tile, not one per element); the
-    // addend may alias C (in-place residual gradient): a lane reads exactly the pair it writes
-    uint32_t addpk[TM][TN][8];
-    if (EPI == EPI_ADD) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn)
-#pragma unroll
-          for (int r = 0; r < 16; r += 2) {
-            const int row = row_w + i * 32 + ((r + (odd ? 1 : 0)) & 3) + 8 * (r >> 2);
-            const int col = col_w + jn * 32 - (odd ? 1 : 0);
-            addpk[i][jn][r >> 1] = (row < p.M && col < p.N)
-                ? *reinterpret_cast<const uint32_t*>(p.addend + (int64_t)row * p.ldadd + col) : 0u;
-          }
-    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          // even lane keeps v[r] and receives the odd neighbour's v[r]; odd lane keeps v[r+1]
-          // and receives the even neighbour's v[r+1]
           const float give = odd ? acc[i][jn][r] : acc[i][jn][r + 1];
           const float got = __shfl_xor(give, 1);
           float lo = odd ? got : acc[i][jn][r];
           float hi = odd ? acc[i][jn][r + 1] : got;
-          if (EPI == EPI_ADD) {
-            lo += __uint_as_float(addpk[i][jn][r >> 1] << 16);
-            hi += __uint_as_float(addpk[i][jn][r >> 1] & 0xffff0000u);
-          }
           const int row = row_w + i * 32 + ((r + (odd ? 1 : 0)) & 3) + 8 * (r >> 2);
           const int col = col_w + jn * 32 - (odd ? 1 : 0);     // even column of the pair
           if (row < p.M && col < p.N) {                        // N is even: the pair is in range
+            if (EPI == EPI_ADD) {
+              const uint32_t ad = *reinterpret_cast<const uint32_t*>(p.addend + (int64_t)row * p.ldadd + col);
+              lo += __uint_as_float(ad << 16);
+              hi += __uint_as_float(ad & 0xffff0000u);
+            }
             const uint32_t packed = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
             *reinterpret_cast<uint32_t*>(C + (int64_t)row * p.ldc + col) = packed;
           }
