@@ -572,8 +572,11 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
                                   ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W, ds, batch));
     const bool late = two && ctx->late_fork && i > 0;
     if (two && !late) BLH_TRY(fork_wait(i, false));       // behind bn_bwd_apply (marker event)
-    BLH_TRY(launch_colreduce(s, ws.dz_colsum_part + (int64_t)i * chunks * W, chunks, W, W,
-                             grads + h.b));
+    // (data parallel: the bucket hook needs this stage's bias gradient now; otherwise all stages
+    //  are reduced by one launch after the loop, as in backward_impl)
+    if (on_ready)
+      BLH_TRY(launch_colreduce(s, ws.dz_colsum_part + (int64_t)i * chunks * W, chunks, W, W,
+                               grads + h.b));
     if (i > 0) {
       GemmParamsH g{};
       g.A = ws.dZ[i]; g.lda = W;
@@ -597,6 +600,13 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
       const int64_t end = (i + 1 < nh) ? L.heavy[i + 1].w : L.dec_w;
       BLH_TRY(ready(i, h.w, end - h.w));
     }
+  }
+  if (!on_ready) {
+    int64_t offs[32];
+    if (nh > 32) return BLH_ERR_SHAPE;
+    for (int i = 0; i < nh; ++i) offs[i] = L.heavy[i].b;
+    BLH_TRY(launch_bias_colreduce(s, ws.dz_colsum_part, (int64_t)chunks * W, chunks, W, nh, offs, grads,
+                                  nullptr, 0, 0, 0));
   }
   if (two) {   // join: the side stream is in order, its last kernel is stage 0's slab sum
     BLH_HIP_TRY(hipEventRecord(ctx->ev_w[0], s2));

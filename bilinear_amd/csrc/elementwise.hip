@@ -7,6 +7,7 @@
 // rows of its row-chunk, so column reductions need no cross-thread traffic and a
 // Philox call (128 keep-bits = 32 rows x 4 columns) is shared by a whole patch.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "philox.h"
@@ -143,20 +144,21 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
   // both passes read every tile partial of this column with the loads of 8 tiles in flight
   constexpr int U = 8;
   const int cc = ok ? col : 0;
-  if (tiles <= 8 * U) {
-    // the usual case (batch <= 8192 at 128-row tiles): every partial this thread needs, (mean, M2) of
-    // up to U tiles, is requested at once and kept in registers for the second step — one memory
-    // round trip instead of two (this kernel is nothing but latency)
-    float mu[U], m2t[U];
+  auto fast = [&](auto uc) {
+    // every partial this thread needs — (mean, M2) of up to UF tiles — is requested at once and
+    // kept in registers for the second step: one memory round trip instead of two (this kernel is
+    // nothing but latency).  UF = 8 covers 64 tiles (batch <= 8192 at 128-row tiles), 16 covers 128.
+    constexpr int UF = decltype(uc)::value;
+    float mu[UF], m2t[UF];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < UF; ++u) {
       const int64_t tt = min(sl + 8 * u, tiles - 1);
       mu[u] = part[(tt * 2 + 0) * W + cc];
       m2t[u] = part[(tt * 2 + 1) * W + cc];
     }
     double acc1 = 0.0;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < UF; ++u) {
       const int t = sl + 8 * u;
       const double n = (double)min((int64_t)tile_rows, batch - (int64_t)t * tile_rows);
       if (t < tiles) acc1 += n * (double)mu[u];
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
     __syncthreads();
     double acc2 = 0.0;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < UF; ++u) {
       const int t = sl + 8 * u;
       const double n = (double)min((int64_t)tile_rows, batch - (int64_t)t * tile_rows);
       const double d = (double)mu[u] - mean1;
@@ -185,6 +187,9 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
       bn_finalize_store(mean1, m2, batch, col, gamma, beta, running_mean, running_var, nbt, momentum,
                         saved_mean, saved_invstd, scale, shift);
     }
+  };
+  if (tiles <= 64) { fast(std::integral_constant<int, 8>{}); return; }
+  if (tiles <= 128) { fast(std::integral_constant<int, 16>{});
     return;
   }
   double acc = 0.0;
