@@ -60,15 +60,19 @@ int main(int argc, char** argv) {
     }
   };
   const char* names[] = {"copy [B,W] D2D", "bn_bwd_apply (mask)", "bn_bwd_apply (Philox)", "bn_bwd_reduce (Philox)", "bn_apply train (Philox)"};
+  GemmParams dh = d; dh.M = M / 2;            // half the tiles: half of the CUs stay free of GEMM workgroups
+  GemmParams f = d; f.B = A;                   // forward layout (ROWK, ROWK): bk64 x 2 stages, 128 KB LDS
   auto gemm = [&](int kind) {
     if (kind == 1) launch_gemm(sa, TILE_128x128, KROW, KROW, EPI_STORE, w, 4, 0);
     if (kind == 2) launch_gemm(sa, TILE_128x128, ROWK, KROW, EPI_STORE, d, 1, 0);
+    if (kind == 3) launch_gemm(sa, TILE_128x128, ROWK, KROW, EPI_STORE, dh, 1, 0);
+    if (kind == 4) launch_gemm(sa, TILE_128x128, ROWK, ROWK, EPI_STORE, f, 1, 0);
   };
-  const char* gnames[] = {"alone", "beside wgrad", "beside dgrad"};
+  const char* gnames[] = {"alone", "beside wgrad", "beside dgrad", "beside dgrad M/2", "beside fwd bk64"};
   hipEvent_t e0, e1, ea0, ea1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&ea0)); CK(hipEventCreate(&ea1));
   for (int round = 0; round < 2; ++round)
-    for (int kind = 0; kind < 3; ++kind)
+    for (int kind = 0; kind < 5; ++kind)
       for (int which = 0; which < 5; ++which) {
         CK(hipDeviceSynchronize());
         // stream A: enough GEMMs to outlast the probes (70 us each); stream B: the probes
