@@ -155,7 +155,7 @@ __device__ __forceinline__ void ring_wait_vm_lgkm() {
 // entry, main-loop start, main-loop end and kernel end, written to p.loss_part (8 u64 per WG).
 // STAMP 2..5 additionally ablate one part of the steady-state loop (results are then wrong; only
 // the timing is read): 2 = no barrier, 3 = no DMA issue, 4 = no fragment reads, 5 = no wait + barrier,
-// 6 = none of them (MFMAs only).
+// 6 = none of them (MFMAs only), 7 = no MFMAs (DMA, fragment reads and barriers only).
 // Measured (M = 4096, N = K = 1024, bk64 x 2): full loop 146.3 k cycles against the MFMA-ideal
 // 131.1 k; without the barrier 141.6 k, without the DMA 139.4 k, without the fragment reads
 // 143.1 k: no single part explains the last 6 % (round 1 measured 33.4 cycles per 32-cycle bf16 MFMA in a loop of
@@ -229,6 +229,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_ring_kernel(GemmParams 
   // round-1 kernel): the register double buffer is defeated and every k-group boundary exposes
   // the LDS latency, with both waves of a SIMD in lockstep.
 #define BLH_RING_MFMAS(CUR)                                                                     \
+  if (STAMP != 7)                                                                               \
   _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                 \
   _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                \
   _Pragma("unroll") for (int jn = 0; jn < TN; ++jn)                                             \

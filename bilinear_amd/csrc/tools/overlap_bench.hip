@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../common.h"
+#include "../gemm_f32_ring.h"
 
 using namespace blh;
 thread_local int blh::g_last_hip_error = 0;
@@ -68,17 +69,41 @@ int main(int argc, char** argv) {
     if (kind == 3) launch_gemm(sa, TILE_128x128, ROWK, KROW, EPI_STORE, dh, 1, 0);
     if (kind == 4) launch_gemm(sa, TILE_128x128, ROWK, ROWK, EPI_STORE, f, 1, 0);
   };
-  const char* gnames[] = {"alone", "beside wgrad", "beside dgrad", "beside dgrad M/2", "beside fwd bk64"};
+  // ablated interferers (dgrad shape): which half of the GEMM hurts a co-resident streaming kernel?
+  unsigned long long* stamps; CK(hipMalloc(&stamps, 4096 * 64));
+  GemmParams ds = d; ds.loss_part = reinterpret_cast<float*>(stamps);
+  auto abl = [&](auto kern) {
+    constexpr size_t lds = gemm_ring_lds_bytes<128, 128, 32, 2>();
+    static bool once = false;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    (void)once;
+    hipLaunchKernelGGL(kern, dim3((M / 128) * (W / 128)), dim3(512), lds, sa, ds);
+  };
+  auto gemm_full = gemm;
+  auto gemm2 = [&](int kind) {
+    if (kind <= 4) gemm_full(kind);
+    if (kind == 5) abl(gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, KROW, EPI_STORE, 32, 2, 6>);   // MFMAs only
+    if (kind == 6) abl(gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, KROW, EPI_STORE, 32, 2, 7>);   // no MFMAs
+    if (kind == 7) abl(gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, KROW, EPI_STORE, 32, 2, 3>);   // no DMA
+  };
+      if (kind == 8) launch(gemm_f32_ring_kernel<128, 128, 4, 2, KROW, KROW, EPI_STORE, 32, 2, 0, 1>);
+      if (kind == 9) launch(gemm_f32_ring_kernel<128, 128, 4, 2, KROW, KROW, EPI_STORE, 32, 2, 0, 2>);
+      if (kind == 10) launch(gemm_f32_ring_kernel<128, 128, 4, 2, KROW, KROW, EPI_STORE, 32, 2, 0, 3>);
+    }
+  };
+  const char* gnames[] = {"alone", "beside wgrad", "beside dgrad", "beside dgrad M/2", "beside fwd bk64",
+                          "beside MFMA-only", "beside no-MFMA", "beside no-DMA"};
   hipEvent_t e0, e1, ea0, ea1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&ea0)); CK(hipEventCreate(&ea1));
   for (int round = 0; round < 2; ++round)
-    for (int kind = 0; kind < 5; ++kind)
+    for (int kind = 0; kind < 8; ++kind)
       for (int which = 0; which < 5; ++which) {
+        if (kind >= 5 && which != 0 && which != 2) continue;
         CK(hipDeviceSynchronize());
         // stream A: enough GEMMs to outlast the probes (70 us each); stream B: the probes
         const int ngemm = kind ? reps : 0;
         CK(hipEventRecord(ea0, sa));
-        for (int i = 0; i < ngemm; ++i) gemm(kind);
+        for (int i = 0; i < ngemm; ++i) gemm2(kind);
         CK(hipEventRecord(ea1, sa));
         CK(hipEventRecord(e0, sb));
         for (int i = 0; i < reps; ++i) probe(which);
