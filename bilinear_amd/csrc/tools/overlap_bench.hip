@@ -86,11 +86,6 @@ int main(int argc, char** argv) {
     if (kind == 6) abl(gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, KROW, EPI_STORE, 32, 2, 7>);   // no MFMAs
     if (kind == 7) abl(gemm_f32_ring_kernel<128, 128, 4, 2, ROWK, KROW, EPI_STORE, 32, 2, 3>);   // no DMA
   };
-      if (kind == 8) launch(gemm_f32_ring_kernel<128, 128, 4, 2, KROW, KROW, EPI_STORE, 32, 2, 0, 1>);
-      if (kind == 9) launch(gemm_f32_ring_kernel<128, 128, 4, 2, KROW, KROW, EPI_STORE, 32, 2, 0, 2>);
-      if (kind == 10) launch(gemm_f32_ring_kernel<128, 128, 4, 2, KROW, KROW, EPI_STORE, 32, 2, 0, 3>);
-    }
-  };
   const char* gnames[] = {"alone", "beside wgrad", "beside dgrad", "beside dgrad M/2", "beside fwd bk64",
                           "beside MFMA-only", "beside no-MFMA", "beside no-DMA"};
   hipEvent_t e0, e1, ea0, ea1;
