@@ -437,26 +437,46 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    import bilinear_amd
+    from bilinear_amd.dp import DataParallel
+
+    # Model state, optimiser moments, workspace and the batch are allocated BEFORE the RCCL
+    # communicator exists.  Measured on the one-GPU box (world-size-1 RCCL group):
+    # the same step runs 10 % slower (1.17 vs 1.06 ms) for as long as the process lives when its
+    # tensors are the first allocations made after an eager init_process_group("nccl", device_id=...),
+    # and at full speed when they exist beforehand (or when 512 MB of something else is allocated
+    # in between): whatever RCCL sets up taints the memory handed out right after it.
+    torch.manual_seed(1)          # identical init on every rank
+    net, opt, step, _ = bilinear_amd.load(dev, num_blocks=args.blocks, width=args.width,
+                                          gemm_dtype=args.dtype)
+    net.train()
+    net.engine.ensure(dev)
+    if args.one_stream:
+        net.engine.set_two_stream(False)
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    x = torch.randn(args.batch, 32, device=dev, generator=g)
+    t = torch.randn(args.batch, 48, device=dev, generator=g)
     if world > 1:
+        net.engine.workspace(args.batch)      # activations / gradient staging for this batch
+        opt._ensure_moments(net.engine)       # exp_avg / exp_avg_sq arenas
+        strong_pre = None
+        if not args.strong and not args.no_strong_line and cfg["batch"] % (32 * world) == 0:
+            # (the second model of the strong-scaling sub-measurement, for the same reason)
+            torch.manual_seed(1)
+            net_s, opt_s, _, _ = bilinear_amd.load(dev, num_blocks=args.blocks, width=args.width,
+                                                   gemm_dtype=args.dtype)
+            net_s.train()
+            net_s.engine.ensure(dev)
+            net_s.engine.workspace(cfg["batch"] // world)
+            opt_s._ensure_moments(net_s.engine)
+            strong_pre = (net_s, opt_s)
+        torch.cuda.synchronize()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-
-    import bilinear_amd
-    from bilinear_amd.dp import DataParallel
-
-    torch.manual_seed(1)          # identical init on every rank
-    net, opt, step, _ = bilinear_amd.load(dev, num_blocks=args.blocks, width=args.width,
-                                          gemm_dtype=args.dtype)
-    net.train()
-    if args.one_stream:
-        net.engine.ensure(dev)
-        net.engine.set_two_stream(False)
-    g = torch.Generator(device=dev).manual_seed(1000 + rank)
-    x = torch.randn(args.batch, 32, device=dev, generator=g)
-    t = torch.randn(args.batch, 48, device=dev, generator=g)
     dp = DataParallel(net, opt, sync_bn=args.sync_bn) if world > 1 else None
     use_graph = (world == 1) and args.graph and not args.no_graph
     captured = None
@@ -499,12 +519,9 @@ def main():
     # split N ways): measured right here with the same barrier / max-over-ranks protocol and
     # reported as a sub-object, so one driver run per N yields both curves.
     strong = None
-    if world > 1 and not args.strong and not args.no_strong_line and cfg["batch"] % (32 * world) == 0:
+    if world > 1 and strong_pre is not None:
         sb = cfg["batch"] // world
-        torch.manual_seed(1)
-        net_s, opt_s, _, _ = bilinear_amd.load(dev, num_blocks=args.blocks, width=args.width,
-                                               gemm_dtype=args.dtype)
-        net_s.train()
+        net_s, opt_s = strong_pre
         dp_s = DataParallel(net_s, opt_s, sync_bn=args.sync_bn)
         xs, ts = x[:sb].contiguous(), t[:sb].contiguous()
         n_s = max(20, min(args.steps, 300))
