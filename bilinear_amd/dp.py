@@ -155,7 +155,13 @@ class DataParallel:
 
     ``x_local`` is this rank's row slice of the global batch.  Dropout uses the
     global row index (rank * local_batch), so the Philox mask of a row does not
-    depend on the number of GPUs."""
+    depend on the number of GPUs.
+    Allocation order: build the module, its optimizer and (``engine.workspace(batch)``,
+    ``optimizer._ensure_moments(engine)``) their device state BEFORE creating an eager RCCL
+    communicator (``init_process_group("nccl", device_id=...)``): tensors that are the first
+    allocations after the communicator ran every kernel 10 % slower on the MI355X box this
+    was measured on; bench.py shows the order.
+    """
 
     def __init__(self, module, optimizer, group=None, bucket_floats=1 << 20, max_norm=1.0,
                  sync_bn=False, force_collectives=False, compress=None):
