@@ -261,6 +261,34 @@ def _worker_rccl(rank, world, port, out_dir):
         gh, gf = net_h.engine.grads, net_f.engine.grads
         rel = ((gh - gf).norm() / gf.norm()).item()
         assert 0 < rel < 1e-2, rel                 # clipped gradients differ by bf16 rounding only
+
+        # bf16-storage mode (BASELINE configs[3], [4]: bf16, data parallel): the bucket hook of
+        # blh_backward in gemm_dtype 4 (backward_h: weight gradients on the side stream, ranges
+        # complete there), forced RCCL collectives == no collectives bit for bit, and the
+        # data-parallel step == the fused single-GPU step to rounding
+        cfg_h = (2, 1024, 4096, "bf16s")
+        xh, th = _data(dev, cfg_h)
+        xh, th = xh[:cfg_h[2]].contiguous(), th[:cfg_h[2]].contiguous()
+        outs = {}
+        for name, kw in (("forced", dict(force_collectives=True)), ("plain", dict())):
+            net_b, opt_b = _make(dev, cfg_h)
+            dpb = DataParallel(net_b, opt_b, bucket_floats=1 << 20, **kw)
+            ls = []
+            for _ in range(3):
+                pb, lb = dpb.train_step(xh, th)
+                ls.append(float(lb.item()))
+            torch.cuda.synchronize()
+            if name == "forced":
+                assert len(dpb._reducer.launched) >= 2
+            outs[name] = (net_b.engine.params.clone(), ls)
+        assert torch.equal(outs["forced"][0], outs["plain"][0]) and outs["forced"][1] == outs["plain"][1]
+        net_s, opt_s = _make(dev, cfg_h)
+        ls = [float(net_s.train_step(opt_s, xh, th, max_norm=1.0)[1].item()) for _ in range(3)]
+        torch.cuda.synchronize()
+        assert all(np.isfinite(ls)) and ls[-1] < ls[0]
+        assert max(abs(a - b) for a, b in zip(ls, outs["plain"][1])) <= 2e-3 * ls[0], (ls, outs["plain"][1])
+        rel = ((net_s.engine.params - outs["plain"][0]).norm() / outs["plain"][0].norm()).item()
+        assert rel < 1e-3, rel
         open(os.path.join(out_dir, "rccl_ok"), "w").write("ok")
     finally:
         dist.destroy_process_group()
