@@ -106,6 +106,8 @@ class DevicePoseDataset:
     def from_pickles(data_dir, device, protocol="GT", seed=0):
         """(train, valid) from the reference's files ``{data_dir}/{task}_{protocol}.bin``
         (H36M/data.py:31-34)."""
+        if protocol not in ("GT", "SH", "SH+FT"):      # H36M/data.py:22 asserts the same set
+            raise ValueError("protocol must be 'GT', 'SH' or 'SH+FT', got %r" % (protocol,))
         raws = {}
         for task in ("train", "valid"):
             path = os.path.join(data_dir, "%s_%s.bin" % (task, protocol))

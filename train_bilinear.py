@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--data-dir", default=None,
                     help="Human3.6M directory holding the reference's train_GT.bin / valid_GT.bin; "
                          "the split is preprocessed once and kept on the device")
+    ap.add_argument("--protocol", choices=["GT", "SH", "SH+FT"], default="GT",
+                    help="which 2D input the pickles hold (/root/reference/H36M/protocol.py:1-4): ground truth, "
+                         "stacked-hourglass detections, fine-tuned detections; selects {task}_{protocol}.bin")
     ap.add_argument("--synthetic-poses", type=int, default=0,
                     help="no dataset: N synthetic raw annotations through the same device pipeline")
     args = ap.parse_args()
@@ -63,7 +66,7 @@ def main():
     # H36M.Dataset + DataLoader(shuffle=True) (train_bilinear.py:33-43) as one device-resident split
     dataset = None
     if args.data_dir:
-        dataset, _ = DevicePoseDataset.from_pickles(args.data_dir, device)
+        dataset, _ = DevicePoseDataset.from_pickles(args.data_dir, device, protocol=args.protocol)
     elif args.synthetic_poses:
         dataset = DevicePoseDataset(synthetic_raw(args.synthetic_poses, seed=0), device)
     data = SyntheticPoses(args.steps_per_epoch, args.batch_size, device)

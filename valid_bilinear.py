@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--batch-size", type=int, default=64)
     ap.add_argument("--save-root", default="save")
     ap.add_argument("--data-dir", default=None, help="Human3.6M directory with train_GT.bin / valid_GT.bin")
+    ap.add_argument("--protocol", choices=["GT", "SH", "SH+FT"], default="GT",
+                    help="which 2D input the pickles hold (/root/reference/H36M/protocol.py:1-4): ground truth, "
+                         "stacked-hourglass detections, fine-tuned detections; selects {task}_{protocol}.bin")
     ap.add_argument("--synthetic-poses", type=int, default=0,
                     help="no dataset: N synthetic raw annotations through the same device pipeline "
                          "(use the value train_bilinear.py was run with)")
@@ -37,7 +40,7 @@ def main():
 
     valid = None
     if args.data_dir:
-        _, valid = DevicePoseDataset.from_pickles(args.data_dir, device)
+        _, valid = DevicePoseDataset.from_pickles(args.data_dir, device, protocol=args.protocol)
     elif args.synthetic_poses:
         train = DevicePoseDataset(synthetic_raw(args.synthetic_poses, seed=0), device)
         valid = DevicePoseDataset(synthetic_raw(max(1, args.synthetic_poses // 4), seed=1), device, stats_from=train)
