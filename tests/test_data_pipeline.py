@@ -2,6 +2,7 @@
 /root/reference/H36M/data.py: joint selection, root-centring, train-split z-scoring, action
 decoding, DataLoader batch semantics, pickle round trip.  Runs on the CPU device (torch ops);
 the GPU variant lives in test_gpu_parity.py."""
+import os
 import pickle
 
 import numpy as np
@@ -117,5 +118,8 @@ def test_from_pickles_selects_the_protocol_file(tmp_path, protocol):
         gt_train, _ = DevicePoseDataset.from_pickles(str(tmp_path), "cpu", protocol="GT")
         assert not torch.allclose(gt_train.x, train.x)
         assert torch.allclose(gt_train.t, train.t)
-    with pytest.raises(FileNotFoundError):
+    with pytest.raises(ValueError):       # H36M/data.py:22 asserts protocol in {GT, SH, SH+FT}
         DevicePoseDataset.from_pickles(str(tmp_path), "cpu", protocol="nope")
+    os.remove(tmp_path / ("valid_%s.bin" % protocol))
+    with pytest.raises(FileNotFoundError):
+        DevicePoseDataset.from_pickles(str(tmp_path), "cpu", protocol=protocol)
