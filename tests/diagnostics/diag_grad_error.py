@@ -1,8 +1,9 @@
 """Developer diagnostic: per-parameter relative L2 error of the raw gradients against the fp64
 oracle, for several batch sizes / schedules / dropout sources."""
 import sys, os, ctypes
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+_TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))        # tests/
+sys.path.insert(0, os.path.dirname(_TESTS))                                   # repository root
+sys.path.insert(0, _TESTS)
 import numpy as np, torch
 from oracle import numpy_oracle as O
 import test_gpu_timed_path as T

@@ -22,7 +22,7 @@ within an fp32 ulp of zero, and there ANY two correct implementations (fp64 orac
 oracle, PyTorch CPU, these kernels) may open the gate differently — a discrete O(1/sqrt(B))
 change of the gradients (measured: the NumPy fp32 oracle and the GPU both sit 2.8e-4 rel. L2 from
 the fp64 oracle on encode.0.weight at B = 4096, identically on every tensor; tools_dev/
-diag_grad_error.py).  The tight comparisons therefore (1) prove that the Philox path is
+tests/diagnostics/diag_grad_error.py).  The tight comparisons therefore (1) prove that the Philox path is
 bit-identical to the explicit-mask path replaying the same masks, and (2) compare the
 explicit-mask path with the oracle on masks in which the gates with |y| < 1e-4 are dropped
 (0.01 % of the elements), so that no gate decision depends on rounding.  The un-edited Philox
