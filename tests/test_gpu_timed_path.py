@@ -21,7 +21,7 @@ ReLU gates.  At B = 4096 a step evaluates 21 M ReLU gates; a handful of pre-acti
 within an fp32 ulp of zero, and there ANY two correct implementations (fp64 oracle, NumPy fp32
 oracle, PyTorch CPU, these kernels) may open the gate differently — a discrete O(1/sqrt(B))
 change of the gradients (measured: the NumPy fp32 oracle and the GPU both sit 2.8e-4 rel. L2 from
-the fp64 oracle on encode.0.weight at B = 4096, identically on every tensor; tools_dev/
+the fp64 oracle on encode.0.weight at B = 4096, identically on every tensor;
 tests/diagnostics/diag_grad_error.py).  The tight comparisons therefore (1) prove that the Philox path is
 bit-identical to the explicit-mask path replaying the same masks, and (2) compare the
 explicit-mask path with the oracle on masks in which the gates with |y| < 1e-4 are dropped
