@@ -2,7 +2,8 @@
 """Benchmark of the lifter training step on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
+     --gpus N ...,  or bare: bench.py then starts the N ranks itself, before any GPU call)
 
 A "step" is the whole step body of /root/reference/train_bilinear.py:75-83 on one
 synthetic batch resident in HBM: zero_grad, forward, MSELoss, backward,
@@ -14,12 +15,17 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline     : achieved fraction of the fp32-MFMA peak of the dominant kernel
                  (the 1024x1024 Linear forward GEMM), timed live with HIP events;
   cpu_baseline : oracle/torch_port.py (plain PyTorch on the host cores) on the same
-                 workload, bounded sample, rank 0 at N = 1 only.
+                 workload, bounded sample, rank 0 at N = 1 only;
+  configs      : (default N = 1 run) the other single-GPU BASELINE.json shapes — configs[2] and the
+                 per-GPU shapes of configs[3] / configs[4], bf16 storage — each with its own
+                 ms_per_step / value / roofline, so that one driver run shows every config.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -118,6 +124,18 @@ def gemm_rooflines(batch, width, reps, dtype="fp32"):
         ms = time_kernel(fn, reps)
         out[name] = {"ms": ms, "tflops": flop / ms / 1e9}
     return out
+
+
+def bf16s_kernel_name(batch, width):
+    """Which bf16-storage GEMM the library picks for the forward contraction at this shape."""
+    try:
+        from bilinear_amd import _native as N
+        fn = getattr(N.lib(), "blh_gemm_bf16s_variant", None)
+        if fn is not None and fn(batch, width, width, 0, 0) == 256:
+            return "gemm_bf16s_256_kernel"
+    except Exception:   # noqa: BLE001  (naming only)
+        pass
+    return "gemm_bf16s_kernel"
 
 
 def gemm_rooflines_bf16s(batch, width, reps):
@@ -221,6 +239,21 @@ def recorded_traffic(batch, width):
         return None
 
 
+def recorded_traffic_bf16s(batch, width):
+    """PMC traffic (bytes per launch) of the bf16-storage forward GEMM at (M = batch, N = K =
+    width), from the committed rocprofv3 --pmc runs (profiles/r03_bf16s_traffic.json; the newest
+    record wins).  None for shapes that were not profiled."""
+    for name in ("r03_bf16s_traffic.json",):
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as f:
+                rec = json.load(f)["linear_fwd"].get("%dx%d" % (batch, width))
+            if rec:
+                return rec["traffic_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
+    return None
+
+
 def recorded_ceiling(batch, width):
     if (batch, width) != (4096, 1024):
         return None
@@ -249,10 +282,12 @@ def roofline_block(args, dom):
         }
     if args.dtype == "bf16s":
         return {
-            "kernel": "gemm_bf16s_kernel<ROWK,ROWK,BIAS_STATS,bf16 out> (Linear %dx%d forward, M=%d, bf16 storage)" % (
-                args.width, args.width, args.batch),
+            "kernel": "%s<ROWK,ROWK,BIAS_STATS,bf16 out> (Linear %dx%d forward, M=%d, bf16 storage)" % (
+                bf16s_kernel_name(args.batch, args.width), args.width, args.width, args.batch),
             "bound": "mfma", "achieved": dom["tflops"], "peak": BF16_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": dom["tflops"] / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
+            "unit": "TFLOP/s", "frac": dom["tflops"] / BF16_MFMA_PEAK_TFLOPS,
+            "traffic": recorded_traffic_bf16s(args.batch, args.width),
+            "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r03_bf16s_traffic.json)",
             "avg_launch_ms": dom["ms"], "flop_per_launch": flop,
             "algorithmic_bytes_per_launch": 2.0 * (2 * args.batch * args.width + args.width * args.width),
         }
@@ -380,6 +415,110 @@ def host_cores():
     return max(1, min(n, 16))
 
 
+def _free_port():
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def self_launch(n):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks as children of this
+    process (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) BEFORE anything here
+    has touched the GPU, let rank 0's JSON line through on stdout, and exit with the children's
+    return code.  (Nothing is exec'ed: a process that has initialised HIP must never be replaced.)"""
+    rehearse = os.environ.get("BLH_BENCH_REHEARSE") == "1"
+    have = torch.cuda.device_count()          # does not initialise the GPU
+    if have < n and not rehearse:
+        raise SystemExit("bench.py --gpus %d: this node exposes %d GPU%s (set BLH_BENCH_REHEARSE=1 to "
+                         "rehearse the multi-rank control flow on one GPU over gloo)" % (n, have, "" if have == 1 else "s"))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    log("self-launch: %s" % " ".join(cmd))
+    # rank 0's JSON line goes to stdout; anything else a library printed there (gloo / RCCL banners)
+    # goes to stderr, so that stdout carries exactly the one line of the contract
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    raise SystemExit(proc.wait())
+
+
+def pre_ramp(one_step, min_ms):
+    """Un-timed steps until at least ``min_ms`` of wall time have passed with the GPU busy: the
+    first ~50 ms after an idle period run at a lower DVFS state (10-15 % slow), and a driver run of
+    20 steps after 5 warm-up steps (27 ms of GPU work) would otherwise be timed inside the ramp.
+    The driver's --warmup steps still follow; nothing is removed from the timed region."""
+    if min_ms <= 0:
+        return 0.0, 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        for _ in range(10):
+            one_step()
+        n += 10
+        torch.cuda.synchronize()
+        el = 1e3 * (time.perf_counter() - t0)
+        if el >= min_ms:
+            return el, n
+
+
+def config_block(idx, dev, steps, ramp_ms):
+    """One BASELINE.json config on this GPU (bf16 storage): whole step timed like the headline
+    (pre-ramp, ``steps`` steps bracketed by synchronize), plus the roofline of its dominant kernel."""
+    import bilinear_amd
+    c = BASELINE_CONFIGS[idx]
+    a = argparse.Namespace(blocks=c["blocks"], width=c["width"], batch=c["batch"], dtype=c["dtype"])
+    torch.manual_seed(1)
+    net, opt, _, _ = bilinear_amd.load(dev, num_blocks=a.blocks, width=a.width, gemm_dtype=a.dtype)
+    net.train()
+    g = torch.Generator(device=dev).manual_seed(1000)
+    x = torch.randn(a.batch, 32, device=dev, generator=g)
+    t = torch.randn(a.batch, 48, device=dev, generator=g)
+
+    def one_step():
+        return net.train_step(opt, x, t, max_norm=1.0)
+    ramp, ramp_steps = pre_ramp(one_step, ramp_ms)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _, loss = one_step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    final = float(loss.item())
+    fwd, bwd = flops_per_pose(a.blocks, a.width)
+    poses = a.batch * steps / el
+    kern = gemm_rooflines(a.batch, a.width, reps=200, dtype=a.dtype)
+    out = {
+        "workload": workload_label(a, 1) + "; x~N(0,1)[B,32], t~N(0,1)[B,48], Kaiming-normal init",
+        "value": poses, "unit": "poses/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
+        "pre_ramp_ms": ramp, "dtype": DTYPE_TEXT[a.dtype], "final_loss": final,
+        "num_blocks": a.blocks, "width": a.width, "per_gpu_batch": a.batch,
+        "step": "zero_grad+forward+MSE+backward+clip_grad_norm(1)+Adam",
+        "step_tflops": poses * (fwd + bwd) / 1e12,
+        "step_frac_of_bf16_mfma_peak": poses * (fwd + bwd) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+        "roofline": roofline_block(a, kern["linear_fwd"]),
+        "kernels": kern,
+    }
+    del net, opt, x, t
+    torch.cuda.empty_cache()
+    return out
+
+
+DTYPE_TEXT = {"fp32": "f32", "bf16x3": "f32 (operands split into 3 bf16 pieces, bf16 MFMA, fp32 accumulate)",
+              "fp16x2": "f32 (operands split into 2 scaled fp16 pieces, f16 MFMA, fp32 accumulate)",
+              "bf16s": "bf16 (activations / gradients / weight shadow stored in bf16, bf16 MFMA, fp32 "
+                       "accumulate, fp32 master weights + BatchNorm statistics + Adam)",
+              "bf16": "bf16 (MFMA inputs; fp32 accumulate and storage)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -415,7 +554,14 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the extra timing of the bf16x3 GEMM mode (reported beside the headline)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="N=1, default config: skip the per-config blocks (configs[2], per-GPU shapes of "
+                         "configs[3] and configs[4])")
+    ap.add_argument("--config-steps", type=int, default=100, help="timed steps of each per-config block")
+    ap.add_argument("--pre-ramp-ms", type=float, default=200.0,
+                    help="un-timed steps before --warmup until this much wall time has passed (clock ramp)")
     args = ap.parse_args()
+    explicit_shape = any(getattr(args, k) is not None for k in ("blocks", "width", "batch", "dtype"))
     cfg = BASELINE_CONFIGS[args.config]
     for key in ("blocks", "width", "batch", "dtype"):
         if getattr(args, key) is None:
@@ -424,8 +570,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)                 # does not return
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.strong:
         if args.batch % (32 * world) != 0:
             raise SystemExit("--strong needs a global batch divisible by 32 * n_gpus")
@@ -494,7 +642,8 @@ def main():
             return captured(x, t)
         return net.train_step(opt, x, t, max_norm=1.0)
 
-    log("model built, warm-up")
+    log("model built, pre-ramp + warm-up")
+    ramp_ms, ramp_steps = pre_ramp(one_step, args.pre_ramp_ms)
     for _ in range(args.warmup):
         one_step()
     if world > 1:
@@ -574,11 +723,9 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16x3": "f32 (operands split into 3 bf16 pieces, bf16 MFMA, fp32 accumulate)",
-                      "fp16x2": "f32 (operands split into 2 scaled fp16 pieces, f16 MFMA, fp32 accumulate)",
-                      "bf16s": "bf16 (activations / gradients / weight shadow stored in bf16, bf16 MFMA, fp32 "
-                               "accumulate, fp32 master weights + BatchNorm statistics + Adam)",
-                      "bf16": "bf16 (MFMA inputs; fp32 accumulate and storage)"}[args.dtype],
+            "dtype": DTYPE_TEXT[args.dtype],
+            "pre_ramp_ms": ramp_ms,
+            "pre_ramp_steps": ramp_steps,
             "data": "synthetic",
             "config": {
                 "workload": workload_label(args, world) + "; x~N(0,1)[B,32], t~N(0,1)[B,48], "
@@ -605,6 +752,16 @@ def main():
             result["strong_scaling"] = strong
         if world == 1 and args.dtype == "fp32" and not args.no_alt:
             result["fp32_on_16bit_mfma"] = {m: alt_mode_block(args, dev, x, t, m) for m in ("bf16x3", "fp16x2")}
+        if world == 1 and args.config == 1 and not explicit_shape and not args.no_configs and not use_graph:
+            # the other BASELINE.json configs that fit one GPU, each measured like the headline
+            # (the headline's model is released first: configs[4] wants ~3 GB of workspace)
+            blocks = {}
+            for idx in (2, 3, 4):
+                b = config_block(idx, dev, args.config_steps, args.pre_ramp_ms)
+                blocks["configs[%d]" % idx] = b
+                log("configs[%d]: %.3f ms/step, %.3g poses/s, fwd GEMM %.0f TFLOP/s" % (
+                    idx, b["ms_per_step"], b["value"], b["roofline"]["achieved"]))
+            result["configs"] = blocks
         if world == 1 and not args.no_cpu_baseline:
             from oracle import torch_port as TP
             cores = host_cores()

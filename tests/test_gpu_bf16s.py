@@ -39,6 +39,17 @@ CASES = [
     (1024, 1024, 1000, 1, 1, 2),      # wgrad, ragged reduction
     (136, 200, 328, 1, 1, 1),         # wgrad, ragged M / N
     (64, 1024, 48, 0, 1, 1),          # K = 48 (one ragged tile)
+    # width 2048 (BASELINE configs[4]) and the large-batch tile shapes (M >= 8192 selects the
+    # 256 x 256 kernel where one exists)
+    (512, 2048, 2048, 0, 0, 1),       # hidden Linear forward, W = 2048
+    (384, 2048, 2048, 0, 1, 1),       # dgrad, W = 2048, ragged M
+    (2048, 2048, 1536, 1, 1, 3),      # wgrad, W = 2048, split over the batch
+    (8192, 1024, 1024, 0, 0, 1),      # forward at M = 8192
+    (8192, 1024, 1024, 0, 1, 1),      # dgrad at M = 8192
+    (8200, 2048, 2048, 0, 0, 1),      # forward, W = 2048, ragged last row tile
+    (8320, 1024, 1024, 0, 1, 1),      # dgrad, ragged last row tile (M % 256 = 128)
+    (1024, 1024, 16384, 1, 1, 4),     # wgrad at B = 16384
+    (2048, 2048, 16384, 1, 1, 1),     # wgrad, W = 2048, B = 16384, one slab
 ]
 
 

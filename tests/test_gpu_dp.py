@@ -289,6 +289,32 @@ def _worker_rccl(rank, world, port, out_dir):
         assert max(abs(a - b) for a, b in zip(ls, outs["plain"][1])) <= 2e-3 * ls[0], (ls, outs["plain"][1])
         rel = ((net_s.engine.params - outs["plain"][0]).norm() / outs["plain"][0].norm()).item()
         assert rel < 1e-3, rel
+
+        # ... and captured (BASELINE configs[4]: "overlapped all-reduce + hipGraph-captured train
+        # step", bf16): forward + backward + the RCCL bucket all-reduces + clip + Adam of the
+        # bf16-storage step as one hipGraph == the eager data-parallel step, bit for bit
+        net_c, opt_c = _make(dev, cfg_h)
+        dpc = DataParallel(net_c, opt_c, bucket_floats=1 << 20, force_collectives=True)
+        cap = CapturedDataParallelStep(dpc, cfg_h[2])
+        cl = []
+        for i in range(3):
+            if i == 2:
+                opt_c.param_groups[0]["lr"] = 5e-4
+            pc, lc = cap(xh, th)
+            cl.append(float(lc.item()))
+        net_e, opt_e = _make(dev, cfg_h)
+        dpe = DataParallel(net_e, opt_e, bucket_floats=1 << 20)
+        el = []
+        for i in range(3):
+            if i == 2:
+                opt_e.param_groups[0]["lr"] = 5e-4
+            pe, le = dpe.train_step(xh, th)
+            el.append(float(le.item()))
+        torch.cuda.synchronize()
+        assert cl == el, (cl, el)
+        assert torch.equal(net_c.engine.params, net_e.engine.params), "captured bf16s DP step != eager"
+        assert torch.equal(opt_c._exp_avg_sq, opt_e._exp_avg_sq)
+        assert torch.equal(net_c.engine.bn_running, net_e.engine.bn_running)
         open(os.path.join(out_dir, "rccl_ok"), "w").write("ok")
     finally:
         dist.destroy_process_group()

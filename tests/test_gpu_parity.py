@@ -608,14 +608,17 @@ def test_cpu_input_is_rejected():
 # ----------------------------------------------------------------------------
 # hipGraph-captured step == eager fused step
 # ----------------------------------------------------------------------------
-@pytest.mark.parametrize("batch,mode", [(64, "fp32"), (512, "fp32"), (256, "fp16x2"), (256, "bf16x3")])
-def test_captured_step_matches_eager(batch, mode):
+@pytest.mark.parametrize("batch,mode,nb", [(64, "fp32", 2), (512, "fp32", 2), (256, "fp16x2", 2), (256, "bf16x3", 2),
+                                           (4096, "fp32", 2),         # BASELINE configs[1]: the non-split-K path
+                                           (16384, "bf16s", 4),       # BASELINE configs[2]
+                                           (2048, "bf16s", 1)])
+def test_captured_step_matches_eager(batch, mode, nb):
     import bilinear_amd
     dev = _dev()
 
     def make():
         torch.manual_seed(5)
-        net, opt, _, _ = bilinear_amd.load(dev, gemm_dtype=mode)
+        net, opt, _, _ = bilinear_amd.load(dev, num_blocks=nb, gemm_dtype=mode)
         net.train()
         net.engine.seed = 99
         return net, opt
