@@ -130,8 +130,7 @@ def bf16s_kernel_name(batch, width):
     """Which bf16-storage GEMM the library picks for the forward contraction at this shape."""
     try:
         from bilinear_amd import _native as N
-        fn = getattr(N.lib(), "blh_gemm_bf16s_variant", None)
-        if fn is not None and fn(batch, width, width, 0, 0) == 256:
+        if N.lib().blh_gemm_bf16s_tile(batch, width, width, 0, 0, 1, 1) == 256:
             return "gemm_bf16s_256_kernel"
     except Exception:   # noqa: BLE001  (naming only)
         pass

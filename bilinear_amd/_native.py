@@ -30,13 +30,13 @@ class Dropout(Structure):
 
 
 class AdamHyper(Structure):
-    _fields_ = [("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
-                ("max_norm", c_float), ("step", c_int32)]
+    _fields_ = [("lr", c_double), ("beta1", c_double), ("beta2", c_double), ("eps", c_double),
+                ("max_norm", c_double), ("step", c_int32), ("reserved", c_int32)]
 
 
 class StepState(Structure):
-    _fields_ = [("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
-                ("max_norm", c_float), ("step", c_int32), ("rng_step", c_uint64),
+    _fields_ = [("lr", c_double), ("beta1", c_double), ("beta2", c_double), ("eps", c_double),
+                ("max_norm", c_double), ("rng_step", c_uint64), ("step", c_int32), ("reserved", c_int32),
                 ("step_size", c_float), ("bc2_sqrt", c_float)]
 
 
@@ -97,6 +97,7 @@ _SIGNATURES = {
     "blh_context_set_step_state": (c_int, [c_void_p, c_void_p]),
     "blh_clip_adam_step_captured": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                             c_void_p, c_void_p, c_int64, c_void_p]),
+    "blh_gemm_bf16s_tile": (c_int32, [c_int64, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32]),
     "blh_train_step_captured": (c_int, [c_void_p, POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         POINTER(Dropout), c_float, c_void_p, c_void_p, c_int64,

@@ -461,12 +461,15 @@ static int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, c
     g.M = (int)batch; g.N = W; g.K = h.fan_in; g.k_per_split = h.fan_in;
     g.bias = params + h.b; g.stat_part = ws.stat_part;
     BLH_TRY(launch_gemm_bf16s(s, ROWK, ROWK, train ? EPI_BIAS_STATS : EPI_BIAS, true, g, 1));
+    // (BatchNorm partials: one (mean, M2) pair per row tile of the kernel that ran, 128 or 256 rows)
+    const int st_rows = gemm_bf16s_pick_tile(ROWK, ROWK, true, g, 1);
+    const int st_tiles = (int)ceil_div(batch, st_rows);
     const uint16_t* skip = (i >= 2 && (i % 2) == 0) ? ws.A[i - 2] : nullptr;
     float* rm = bn_running + ((int64_t)i * 2 + 0) * W;
     float* rv = bn_running + ((int64_t)i * 2 + 1) * W;
     if (train) {
       float* sv = ws.bn_saved[i];
-      BLH_TRY(launch_bn_fwd_finalize(s, ws.stat_part, tiles_m, 128, batch, W, params + h.gamma,
+      BLH_TRY(launch_bn_fwd_finalize(s, ws.stat_part, st_tiles, st_rows, batch, W, params + h.gamma,
                                      params + h.beta, rm, rv, nbt + i, momentum, sv, sv + W,
                                      sv + 2 * W, sv + 3 * W));
       BLH_TRY(launch_bn_apply_t(s, true, ws.Z[i], ET_BF16, sv + 2 * W, sv + 3 * W, nullptr, nullptr,
@@ -1216,6 +1219,17 @@ int blh_gemm_bf16s(void* stream, const uint16_t* A, int64_t lda, int32_t a_kmajo
   const int epi = bias ? (stat_part ? EPI_BIAS_STATS : EPI_BIAS) : (addend ? EPI_ADD : EPI_STORE);
   return launch_gemm_bf16s((hipStream_t)stream, a_kmajor ? KROW : ROWK, b_kmajor ? KROW : ROWK, epi,
                            out_bf16 != 0, g, splits);
+}
+
+int32_t blh_gemm_bf16s_tile(int64_t M, int64_t N, int64_t K, int32_t a_kmajor, int32_t b_kmajor,
+                            int32_t out_bf16, int32_t splits) {
+  if (M <= 0 || N <= 0 || K <= 0 || splits < 1) return BLH_ERR_INVALID_ARGUMENT;
+  GemmParamsH g{};   // contiguous operands, aligned pointers
+  g.lda = a_kmajor ? M : K; g.ldb = b_kmajor ? N : K; g.ldc = N;
+  g.M = (int)M; g.N = (int)N; g.K = (int)K;
+  g.k_per_split = (splits > 1) ? (int)round_up(ceil_div(K, splits), 128) : (int)K;
+  g.c_split_stride = M * N;
+  return gemm_bf16s_pick_tile(a_kmajor ? KROW : ROWK, b_kmajor ? KROW : ROWK, out_bf16 != 0, g, splits);
 }
 
 int blh_cast_f32_to_bf16(void* stream, const float* src, uint16_t* dst, int64_t count) {

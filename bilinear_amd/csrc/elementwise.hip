@@ -1238,14 +1238,15 @@ int launch_clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int6
                      float* stats_out, LossFinish lf) {
   if (count % 4 != 0) return BLH_ERR_SHAPE;
   if (h.step < 1) return BLH_ERR_INVALID_ARGUMENT;
-  const double bc1 = 1.0 - pow((double)h.beta1, (double)h.step);
-  const double bc2 = 1.0 - pow((double)h.beta2, (double)h.step);
-  const float step_size = (float)((double)h.lr / bc1);
+  // torch.optim.Adam forms these scalars in double (Python floats) and rounds each once
+  const double bc1 = 1.0 - pow(h.beta1, (double)h.step);
+  const double bc2 = 1.0 - pow(h.beta2, (double)h.step);
+  const float step_size = (float)(h.lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
   const int blocks = (int)std::min<int64_t>(ceil_div(count / 4, 256), 2048);
   hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, count,
-                     (float)(1.0 - (double)h.beta1), h.beta2, (float)(1.0 - (double)h.beta2),
-                     step_size, bc2_sqrt, h.eps, h.max_norm, sumsq_part, nparts, stats_out, lf);
+                     (float)(1.0 - h.beta1), (float)h.beta2, (float)(1.0 - h.beta2),
+                     step_size, bc2_sqrt, (float)h.eps, (float)h.max_norm, sumsq_part, nparts, stats_out, lf);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
@@ -1417,9 +1418,9 @@ __global__ void step_state_advance_kernel(blh_step_state* st) {
     const int t = st->step + 1;
     st->step = t;
     st->rng_step += 1;
-    const double bc1 = 1.0 - pow((double)st->beta1, (double)t);
-    const double bc2 = 1.0 - pow((double)st->beta2, (double)t);
-    st->step_size = (float)((double)st->lr / bc1);
+    const double bc1 = 1.0 - pow(st->beta1, (double)t);
+    const double bc2 = 1.0 - pow(st->beta2, (double)t);
+    st->step_size = (float)(st->lr / bc1);
     st->bc2_sqrt = (float)sqrt(bc2);
   }
 }
@@ -1445,16 +1446,16 @@ __global__ __launch_bounds__(256) void clip_adam_dev_kernel(
     __syncthreads();
   }
   const float total_norm = (float)sqrt(sh[0]);
-  const float max_norm = st->max_norm;
+  const float max_norm = (float)st->max_norm;
   float coef = 1.0f;
   if (max_norm > 0.f) coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);
   if (stats_out && blockIdx.x == 0 && threadIdx.x == 0) {
     stats_out[0] = total_norm;
     stats_out[1] = coef;
   }
-  const float one_minus_b1 = (float)(1.0 - (double)st->beta1), b2 = st->beta2,
-              one_minus_b2 = (float)(1.0 - (double)st->beta2), step_size = st->step_size,
-              bc2_sqrt = st->bc2_sqrt, eps = st->eps;
+  const float one_minus_b1 = (float)(1.0 - st->beta1), b2 = (float)st->beta2,
+              one_minus_b2 = (float)(1.0 - st->beta2), step_size = st->step_size,
+              bc2_sqrt = st->bc2_sqrt, eps = (float)st->eps;
   const int64_t n4 = count >> 2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
        i += (int64_t)gridDim.x * blockDim.x) {

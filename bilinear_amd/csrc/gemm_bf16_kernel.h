@@ -15,7 +15,7 @@
 #pragma once
 #include "common.h"
 #include "gemm_epilogue.h"
-#include "gemm_f32_kernel.h"   // xcd_remap
+#include "gemm_dma.h"          // g_zero16, lds_dma16_asm, xcd_remap
 
 namespace blh {
 

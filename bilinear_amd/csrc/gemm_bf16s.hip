@@ -2,7 +2,10 @@
 // between the fp32 master tensors and their bf16 images.
 #include <atomic>
 
+#include <cstdlib>
+
 #include "gemm_bf16s_kernel.h"
+#include "gemm_bf16s_256.h"
 
 namespace blh {
 
@@ -36,8 +39,50 @@ static int launch_h(hipStream_t s, const GemmParamsH& p, int splits) {
   return BLH_OK;
 }
 
-#define BLH_CASEH(LA_, LB_, EPI_, OUT_) \
-  if (la == LA_ && lb == LB_ && epi == EPI_ && out_bf16 == OUT_) return launch_h<LA_, LB_, EPI_, OUT_>(s, p, splits);
+template <int LA, int LB, int EPI, bool OUT_BF16>
+static int launch_h256(hipStream_t s, const GemmParamsH& p, int splits) {
+  static std::atomic<uint64_t> attr_done{0};
+  auto kern = gemm_bf16s_256_kernel<LA, LB, EPI, OUT_BF16>;
+  BLH_TRY(ensure_lds_attr_h(attr_done, reinterpret_cast<const void*>(kern), H256_LDS_BYTES));
+  const int tiles = (int)(ceil_div(p.M, 256) * (p.N / 256));
+  launch_kernel(kern, dim3(tiles, 1, splits), dim3(512), H256_LDS_BYTES, s, p);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+// Which kernel serves a contraction: 256 (gemm_bf16s_256.h: 256 x 256 tiles, one workgroup per
+// CU, 8-phase schedule) when the launch has enough tiles to fill the chip and its shape meets that
+// kernel's restrictions, else 128 (gemm_bf16s_kernel.h).  BLH_BF16S_TILE = 128 | 256 forces one
+// (256 only where the shape allows it) for A/B measurements.
+static int forced_tile() {
+  static const int v = [] {
+    const char* e = getenv("BLH_BF16S_TILE");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
+int gemm_bf16s_pick_tile(int la, int lb, bool out_bf16, const GemmParamsH& p, int splits) {
+  const int vec = out_bf16 ? 8 : 4;
+  const int64_t extent = (splits > 1) ? p.k_per_split : p.K;
+  const bool shape_ok = (p.N % 256 == 0) && extent >= 128 && (extent % 128 == 0) &&
+                        (splits == 1 || (int64_t)splits * p.k_per_split == p.K) &&
+                        (p.ldc % vec == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                        (!p.addend || ((p.ldadd % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.addend) & 15) == 0))) &&
+                        (!out_bf16 || splits == 1 || (p.c_split_stride % 8 == 0)) &&
+                        (out_bf16 || splits == 1 || (p.c_split_stride % 4 == 0)) &&
+                        ((int64_t)256 * std::max(p.lda, p.ldb) * 2 < (1ll << 31)) &&
+                        (la == ROWK || p.M % 256 == 0);
+  if (!shape_ok) return 128;
+  const int force = forced_tile();
+  if (force == 128 || force == 256) return force;
+  const int64_t wgs = ceil_div(p.M, 256) * (p.N / 256) * splits;
+  return wgs >= 224 ? 256 : 128;        // (fewer: the 128 x 128 grid fills the 256 CUs better)
+}
+
+#define BLH_CASEH(LA_, LB_, EPI_, OUT_)                                          \
+  if (la == LA_ && lb == LB_ && epi == EPI_ && out_bf16 == OUT_)                 \
+    return tile256 ? launch_h256<LA_, LB_, EPI_, OUT_>(s, p, splits) : launch_h<LA_, LB_, EPI_, OUT_>(s, p, splits);
 
 int launch_gemm_bf16s(hipStream_t s, int la, int lb, int epi, bool out_bf16, const GemmParamsH& p,
                       int splits) {
@@ -50,6 +95,7 @@ int launch_gemm_bf16s(hipStream_t s, int la, int lb, int epi, bool out_bf16, con
   if (((uintptr_t)p.A | (uintptr_t)p.B) & 15) return BLH_ERR_INVALID_ARGUMENT;
   // 32-bit per-lane byte offsets inside one tile row panel
   if ((int64_t)128 * std::max(p.lda, p.ldb) * 2 >= (1ll << 31)) return BLH_ERR_SHAPE;
+  const bool tile256 = gemm_bf16s_pick_tile(la, lb, out_bf16, p, splits) == 256;
   BLH_CASEH(ROWK, ROWK, EPI_BIAS_STATS, true)    // forward (train): Z bf16 + BatchNorm partials
   BLH_CASEH(ROWK, ROWK, EPI_BIAS, true)          // forward (eval)
   BLH_CASEH(ROWK, ROWK, EPI_BIAS, false)         // decode forward: fp32 prediction

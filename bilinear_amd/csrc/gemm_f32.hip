@@ -1,9 +1,8 @@
-// Host-side dispatch of the fp32 MFMA GEMM (kernel templates: gemm_f32_kernel.h).
+// Host-side dispatch of the fp32 MFMA GEMM (kernel template: gemm_f32_ring.h).
 #include <atomic>
 #include <cstdlib>
 
 #include "gemm_bf16_kernel.h"
-#include "gemm_f32_kernel.h"
 #include "gemm_f32_ring.h"
 #include "gemm_split_kernel.h"
 #include "gemm_f16x2_kernel.h"
@@ -231,7 +230,7 @@ int launch_gemm(hipStream_t s, GemmTile tile, int la, int lb, int epi, const Gem
   if ((la == ROWK || lb == ROWK) && p.K % 4 != 0) return BLH_ERR_SHAPE;
   if (la == KROW && p.M % 4 != 0) return BLH_ERR_SHAPE;
   if (lb == KROW && p.N % 4 != 0) return BLH_ERR_SHAPE;
-  if (splits > 1 && (p.k_per_split % BK != 0)) return BLH_ERR_SHAPE;
+  if (splits > 1 && (p.k_per_split % 32 != 0)) return BLH_ERR_SHAPE;   // whole 32-deep K tiles per slab
   if (dtype == 1) return launch_bf16(s, tile, la, lb, epi, p, splits);
   // the split kernels take reductions in whole K tiles of 32 (every slab); other shapes (the
   // K = 48 decode dgrad) run on the exact kernel

@@ -25,7 +25,7 @@
 #include "common.h"
 #include "gemm_bf16_kernel.h"   // bf16x8_t
 #include "gemm_epilogue.h"
-#include "gemm_f32_kernel.h"    // xcd_remap
+#include "gemm_dma.h"          // g_zero16, lds_dma16_asm, xcd_remap
 
 namespace blh {
 

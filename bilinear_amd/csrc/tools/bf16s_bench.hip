@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../gemm_bf16s_kernel.h"
+#include "../gemm_bf16s_256.h"
 
 using namespace blh;
 thread_local int blh::g_last_hip_error = 0;
@@ -32,12 +33,30 @@ float run(const GemmParamsH& p, int splits, int reps) {
   return ms / reps;
 }
 
+template <int LA, int LB, int EPI, bool OB>
+float run256(const GemmParamsH& p, int splits, int reps) {
+  auto kern = gemm_bf16s_256_kernel<LA, LB, EPI, OB>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)H256_LDS_BYTES));
+  const int tiles = (int)(ceil_div(p.M, 256) * (p.N / 256));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(512), H256_LDS_BYTES, 0, p);
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(512), H256_LDS_BYTES, 0, p);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  CK(hipGetLastError());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / reps;
+}
+
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 16384, W = argc > 2 ? atoi(argv[2]) : 1024;
   const int reps = argc > 3 ? atoi(argv[3]) : 100;
   uint16_t *A, *B, *C; float *bias, *stat, *slab;
   CK(hipMalloc(&A, (size_t)M * W * 2)); CK(hipMalloc(&B, (size_t)W * W * 2)); CK(hipMalloc(&C, (size_t)M * W * 2));
-  CK(hipMalloc(&bias, W * 4)); CK(hipMalloc(&stat, (size_t)(M / 64 + 1) * 2 * W * 4)); CK(hipMalloc(&slab, (size_t)16 * W * W * 4));
+  CK(hipMalloc(&bias, W * 4)); CK(hipMalloc(&stat, (size_t)(M / 64 + 1) * 2 * W * 4)); CK(hipMalloc(&slab, (size_t)64 * W * W * 4));
   std::vector<uint16_t> h((size_t)M * W);
   for (auto& v : h) { float f = (float)rand() / RAND_MAX - 0.5f; uint32_t u; memcpy(&u, &f, 4); v = (uint16_t)(u >> 16); }
   CK(hipMemcpy(A, h.data(), h.size() * 2, hipMemcpyHostToDevice));
@@ -62,11 +81,21 @@ int main(int argc, char** argv) {
            BKE, ST, (int)(gemm_bf16s_lds_bytes<BKE, ST>() / 1024), t1 * 1e3, flop / t1 / 1e9, t2 * 1e3,     \
            flop / t2 / 1e9, splits, t3 * 1e3, flop / t3 / 1e9);                                        \
   }
-  for (int round = 0; round < 2; ++round) {
-    ROW(64, 2)
-    ROW(64, 3)
-    ROW(64, 4)
-    ROW(128, 2)
+  const int tiles256 = (W / 256) * (W / 256);
+  const int splits256 = std::max(1, std::min(256 / tiles256, M / 128));
+  GemmParamsH w2 = w;
+  w2.k_per_split = (int)round_up(ceil_div(M, splits256), 128);
+  const bool only256 = argc > 4;
+  for (int round = 0; round < 3; ++round) {
+    if (!only256) {
+      ROW(64, 2)
+      if (round == 0) { ROW(64, 3) ROW(128, 2) }
+    }
+    float t1 = run256<ROWK, ROWK, EPI_BIAS_STATS, true>(f, 1, reps);
+    float t2 = run256<ROWK, KROW, EPI_STORE, true>(d, 1, reps);
+    float t3 = run256<KROW, KROW, EPI_STORE, false>(w2, splits256, reps);
+    printf("256x256 8-phase (128 KB LDS)  fwd %7.1f us %6.0f TF | dgrad %7.1f us %6.0f TF | wgrad(x%d) %7.1f us %6.0f TF\n",
+           t1 * 1e3, flop / t1 / 1e9, t2 * 1e3, flop / t2 / 1e9, splits256, t3 * 1e3, flop / t3 / 1e9);
   }
   return 0;
 }

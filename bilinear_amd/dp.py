@@ -268,8 +268,8 @@ class CapturedDataParallelStep:
         g = self.opt.param_groups[0]
         rng = int(self.eng.rng_step)
         st = N.StepState(float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
-                         0.0 if self.dp.max_norm is None else float(self.dp.max_norm), int(self.opt._t),
-                         rng - 1 if rng > 0 else 2 ** 64 - 1, 0.0, 0.0)
+                         0.0 if self.dp.max_norm is None else float(self.dp.max_norm),
+                         rng - 1 if rng > 0 else 2 ** 64 - 1, int(self.opt._t), 0, 0.0, 0.0)
         host = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8)
         self.state.copy_(host)                      # synchronous: rare (lr changes, out-of-band steps)
         self._mirror = (float(g["lr"]), int(self.opt._t), rng)

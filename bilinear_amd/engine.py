@@ -361,7 +361,7 @@ class Engine:
         return loss, dpred
 
     def clip_adam(self, exp_avg, exp_avg_sq, lr, betas, eps, max_norm, step, stats=None):
-        hyper = N.AdamHyper(lr, betas[0], betas[1], eps, 0.0 if max_norm is None else max_norm, step)
+        hyper = N.AdamHyper(lr, betas[0], betas[1], eps, 0.0 if max_norm is None else max_norm, step, 0)
         sc = self.scratch()
         N.check(N.lib().blh_clip_adam_step(
             self._stream(), N.ptr(self.params), N.ptr(self.grads), N.ptr(exp_avg),

@@ -86,8 +86,8 @@ class CapturedTrainStep:
     def _write_state(self):
         g = self.opt.param_groups[0]
         st = N.StepState(float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], self.max_norm,
-                         int(self.opt._t), int(self.eng.rng_step) - 1 if self.eng.rng_step > 0 else 2 ** 64 - 1,
-                         0.0, 0.0)
+                         int(self.eng.rng_step) - 1 if self.eng.rng_step > 0 else 2 ** 64 - 1,
+                         int(self.opt._t), 0, 0.0, 0.0)
         # rng_step holds (next dropout step - 1): blh_step_state_advance adds 1 before use
         raw = bytes(st)
         slot = self._host_slot

@@ -104,7 +104,7 @@ def _train_step(x, target, params, grads, exp_avg, exp_avg_sq, bn_running, bn_nb
     loss = torch.empty((), dtype=torch.float32, device=x.device)
     d = _desc(num_blocks, width, gemm_dtype)
     drop = _drop(masks, seed, step, row_offset)
-    hyper = N.AdamHyper(lr, beta1, beta2, eps, max_norm, int(adam_step))
+    hyper = N.AdamHyper(lr, beta1, beta2, eps, max_norm, int(adam_step), 0)
     N.check(N.lib().blh_train_step(
         ctypes.c_void_p(ctx), ctypes.byref(d), _stream(), N.ptr(params), N.ptr(grads),
         N.ptr(exp_avg), N.ptr(exp_avg_sq), N.ptr(bn_running), N.ptr(bn_nbt), N.ptr(x),

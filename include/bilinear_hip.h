@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define BLH_ABI_VERSION 2
+#define BLH_ABI_VERSION 3
 
 typedef enum {
   BLH_OK = 0,
@@ -171,10 +171,11 @@ typedef struct {
  * step_size = lr/(1-beta1^t) and bc2_sqrt = sqrt(1-beta2^t).  The host rewrites `lr`
  * (the lr-decay hook, train_bilinear.py:66-70) with a plain async copy between replays.   */
 typedef struct {
-  float lr, beta1, beta2, eps, max_norm;
-  int32_t step;      /* number of completed Adam updates                  */
+  double lr, beta1, beta2, eps, max_norm; /* as blh_adam_hyper (doubles: see there)      */
   uint64_t rng_step; /* dropout step used by the NEXT forward minus one   */
-  float step_size, bc2_sqrt;
+  int32_t step;      /* number of completed Adam updates                  */
+  int32_t reserved;
+  float step_size, bc2_sqrt;              /* derived by blh_step_state_advance            */
 } blh_step_state;
 
 /* ---- forward ---------------------------------------------------------------
@@ -252,10 +253,14 @@ int blh_backward_sync(blh_context* ctx, const blh_model_desc* d, void* stream, c
  *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
  * `step` is t (1-based, after increment).  max_norm <= 0 disables clipping.
  * grads are rewritten with the clipped values (as the reference's .grad is).
- * stats_out (device float[2], optional): total_norm, clip coefficient.      */
+ * stats_out (device float[2], optional): total_norm, clip coefficient.
+ * The hyper-parameters are doubles, as the Python floats torch.optim.Adam computes with: it forms
+ * 1-b1, 1-b2, lr/(1-b1^t) and sqrt(1-b2^t) in double and rounds each ONCE to the tensors' fp32
+ * (with a float b2 = 0.999f, 1-b2 would be 0.99998713e-3 instead of 1e-3: 1.3e-5 off in exp_avg_sq). */
 typedef struct {
-  float lr, beta1, beta2, eps, max_norm;
+  double lr, beta1, beta2, eps, max_norm;
   int32_t step;
+  int32_t reserved;
 } blh_adam_hyper;
 /* nn.utils.clip_grad_norm_ alone (train_bilinear.py:81): scales `grads` in place;
  * stats_out (device float[2], optional) = total_norm, coefficient.           */
@@ -367,13 +372,20 @@ int blh_gemm_fp16x2(void* stream, const float* A, int64_t lda, int32_t a_kmajor,
  * patterns; lda / ldb / ldc in elements; 16-byte aligned bases; K and every contiguous extent a
  * multiple of 8), bf16 MFMA with fp32 accumulation, C bf16 (out_bf16 != 0) or fp32.  Operand
  * layouts as blh_gemm_f32.  bias fp32 [N] or NULL; addend bf16 [M][ldadd] or NULL (not both; not
- * with splits > 1); stat_part (optional, with bias, splits == 1): per-128-row-tile column (mean,
- * M2) of the fp32 values before rounding, [ceil(M/128)][2][N].  splits > 1 writes slabs
- * [splits][M][ldc].                                                                          */
+ * with splits > 1); stat_part (optional, with bias, splits == 1): per-row-tile column (mean,
+ * M2) of the fp32 values before rounding, [ceil(M/T)][2][N] with T = blh_gemm_bf16s_tile(...)
+ * rows per tile.  splits > 1 writes slabs [splits][M][ldc].
+ * Two kernels serve it: 128 x 128 tiles (any shape) and, for launches with enough tiles to fill
+ * the chip (N % 256 == 0, reduction slabs % 128 == 0), 256 x 256 tiles with the 8-phase
+ * schedule; blh_gemm_bf16s_tile says which one a contraction of contiguous operands takes
+ * (128 or 256; the environment variable BLH_BF16S_TILE = 128 | 256 forces one where the shape
+ * allows it, for A/B measurements).                                                          */
 int blh_gemm_bf16s(void* stream, const uint16_t* A, int64_t lda, int32_t a_kmajor, const uint16_t* B,
                    int64_t ldb, int32_t b_kmajor, void* C, int64_t ldc, int32_t out_bf16, int64_t M,
                    int64_t N, int64_t K, int32_t splits, const float* bias, const uint16_t* addend,
                    int64_t ldadd, float* stat_part);
+int32_t blh_gemm_bf16s_tile(int64_t M, int64_t N, int64_t K, int32_t a_kmajor, int32_t b_kmajor,
+                            int32_t out_bf16, int32_t splits);
 /* fp32 <-> bf16 (round to nearest even) over `count` elements (multiple of 4).              */
 int blh_cast_f32_to_bf16(void* stream, const float* src, uint16_t* dst, int64_t count);
 int blh_cast_bf16_to_f32(void* stream, const uint16_t* src, float* dst, int64_t count);

@@ -88,10 +88,12 @@ def test_gemm_bf16s_layouts(native, M, N, K, ak, bk, splits, out_bf16):
         assert err.max() <= 2e-5, err.max()
 
 
-def test_gemm_bf16s_epilogues(native):
+@pytest.mark.parametrize("M,N,K", [(392, 384, 192), (8392, 768, 256)])
+def test_gemm_bf16s_epilogues(native, M, N, K):
+    """(392, 384, 192): the 128 x 128 kernel; (8392, 768, 256): the 256 x 256 kernel (33 x 3 tiles,
+    a ragged last row tile of 200 rows)."""
     dev = _dev()
     rng = np.random.RandomState(4)
-    M, N, K = 392, 384, 192
     A = rng.standard_normal((M, K)).astype(np.float32)
     W = (0.1 * rng.standard_normal((N, K))).astype(np.float32)
     bias = rng.standard_normal(N).astype(np.float32)
@@ -104,7 +106,8 @@ def test_gemm_bf16s_epilogues(native):
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     # forward: + bias, bf16 out, BatchNorm tile partials of the un-rounded values
     z = torch.empty(M, N, dtype=torch.int16, device=dev)
-    part = torch.empty((M + 127) // 128, 2, N, device=dev)
+    T = native.blh_gemm_bf16s_tile(M, N, K, 0, 0, 1, 1)          # rows per statistics tile
+    part = torch.empty((M + T - 1) // T, 2, N, device=dev)
     assert native.blh_gemm_bf16s(st, a.data_ptr(), K, 0, w.data_ptr(), K, 0, z.data_ptr(), N, 1, M, N, K,
                                  1, bt.data_ptr(), None, 0, part.data_ptr()) == 0
     torch.cuda.synchronize()
@@ -113,7 +116,7 @@ def test_gemm_bf16s_epilogues(native):
     assert (np.abs(got - ref) <= 2.0 ** -8 * np.abs(ref) + 1e-4).all()
     p = part.cpu().numpy().astype(np.float64)
     for t in range(p.shape[0]):
-        rows = ref[t * 128:(t + 1) * 128]
+        rows = ref[t * T:(t + 1) * T]
         assert np.abs(p[t, 0] - rows.mean(0)).max() <= 1e-5 * (1 + np.abs(rows).max())
         m2 = ((rows - rows.mean(0)) ** 2).sum(0)
         assert np.abs(p[t, 1] - m2).max() <= 1e-4 * m2.max()
