@@ -441,6 +441,12 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
 // rounding), the parameters, their gradients (fp32 slabs of the weight-gradient GEMM), Adam and
 // the loss stay fp32.  Gradients need no loss scaling: bf16 keeps fp32's exponent range.
 // =================================================================================================
+// BLH_BN_H = 1 selects the first-generation bf16 BatchNorm kernels (elementwise.hip) for A/B runs
+static int bn_h_gen() {
+  static const int v = [] { const char* e = getenv("BLH_BN_H"); return (e && atoi(e) == 1) ? 1 : 2; }();
+  return v;
+}
+
 static int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
                      float* bn_running, int64_t* nbt, const float* x, const blh_dropout* drop,
                      float momentum, const WorkspaceH& ws, float* pred, int64_t batch, bool train) {
@@ -448,7 +454,6 @@ static int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, c
   const ArenaLayout L = make_layout(d);
   const int nh = (int)L.heavy.size();
   const int W = d->width, OF = d->out_features, IF = d->in_features;
-  const int tiles_m = (int)ceil_div(batch, 128);
   // bf16 images of the parameters (the GEMMs read the weights from it) and of the input
   BLH_TRY(launch_cast_f32_bf16(s, params, ws.wsh, L.total));
   BLH_TRY(launch_cast_f32_bf16(s, x, ws.xh, batch * IF));
@@ -472,14 +477,23 @@ static int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, c
       BLH_TRY(launch_bn_fwd_finalize(s, ws.stat_part, st_tiles, st_rows, batch, W, params + h.gamma,
                                      params + h.beta, rm, rv, nbt + i, momentum, sv, sv + W,
                                      sv + 2 * W, sv + 3 * W));
-      BLH_TRY(launch_bn_apply_t(s, true, ws.Z[i], ET_BF16, sv + 2 * W, sv + 3 * W, nullptr, nullptr,
-                                nullptr, nullptr, skip, ET_BF16, ws.A[i], ET_BF16, batch, W,
-                                layer_drop(ctx, drop, i, batch, W), nbt + i));
+      if (bn_h_gen() == 1)
+        BLH_TRY(launch_bn_apply_t(s, true, ws.Z[i], ET_BF16, sv + 2 * W, sv + 3 * W, nullptr, nullptr,
+                                  nullptr, nullptr, skip, ET_BF16, ws.A[i], ET_BF16, batch, W,
+                                  layer_drop(ctx, drop, i, batch, W), nbt + i));
+      else
+        BLH_TRY(launch_bn_apply_h2(s, true, ws.Z[i], sv + 2 * W, sv + 3 * W, nullptr, nullptr, nullptr,
+                                   nullptr, skip, ws.A[i], ws.keep[i], batch, W,
+                                   layer_drop(ctx, drop, i, batch, W), nbt + i));
     } else {
       DropoutSrc none{nullptr, 0, 0, 0, 0, nullptr};
-      BLH_TRY(launch_bn_apply_t(s, false, ws.Z[i], ET_BF16, nullptr, nullptr, params + h.gamma,
-                                params + h.beta, rm, rv, skip, ET_BF16, ws.A[i], ET_BF16, batch, W,
-                                none, nullptr));
+      if (bn_h_gen() == 1)
+        BLH_TRY(launch_bn_apply_t(s, false, ws.Z[i], ET_BF16, nullptr, nullptr, params + h.gamma,
+                                  params + h.beta, rm, rv, skip, ET_BF16, ws.A[i], ET_BF16, batch, W,
+                                  none, nullptr));
+      else
+        BLH_TRY(launch_bn_apply_h2(s, false, ws.Z[i], nullptr, nullptr, params + h.gamma, params + h.beta,
+                                   rm, rv, skip, ws.A[i], nullptr, batch, W, none, nullptr));
     }
   }
   // decode (model/bilinear.py:39): N = 48 is one (ragged) column tile of the same kernel
@@ -495,9 +509,7 @@ static int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, c
 // dW = dZ^T act (both bf16, reduction over the batch split into fp32 slabs), summed into `out`
 static int wgrad_h(hipStream_t s, const uint16_t* dZ, int64_t ld_dz, int M, const uint16_t* act,
                    int64_t ld_act, int N, int64_t batch, float* slabs, float* out) {
-  Splits sp = pick_splits(batch, ceil_div(M, 128) * ceil_div(N, 128));
-  sp.k_per = (int)round_up(sp.k_per, 128);               // whole 128-deep K tiles per slab
-  sp.splits = (int)ceil_div(batch, sp.k_per);
+  const Splits sp = wgrad_plan_h(M, N, batch);
   GemmParamsH g{};
   g.A = dZ; g.lda = ld_dz; g.B = act; g.ldb = ld_act;
   g.M = M; g.N = N; g.K = (int)batch; g.k_per_split = sp.k_per; g.ldc = N;
@@ -567,12 +579,20 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
     const uint16_t* dA = first_of_block ? ws.G1 : ws.G0;
     const float* sv = ws.bn_saved[i];
     const DropoutSrc ds = layer_drop(ctx, drop, i, batch, W);
-    BLH_TRY(launch_bn_bwd_reduce_t(s, dA, ET_BF16, ws.Z[i], ET_BF16, sv + 2 * W, sv + 3 * W, sv,
-                                   sv + W, ws.bn_part, batch, W, ds));
-    BLH_TRY(launch_bn_bwd_finalize(s, ws.bn_part, chunks, W, grads + h.gamma, grads + h.beta));
-    BLH_TRY(launch_bn_bwd_apply_t(s, dA, ET_BF16, ws.Z[i], ET_BF16, sv + 2 * W, sv + 3 * W, sv,
-                                  sv + W, grads + h.gamma, grads + h.beta, ws.dZ[i], ET_BF16,
-                                  ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W, ds, batch));
+    if (bn_h_gen() == 1) {
+      BLH_TRY(launch_bn_bwd_reduce_t(s, dA, ET_BF16, ws.Z[i], ET_BF16, sv + 2 * W, sv + 3 * W, sv,
+                                     sv + W, ws.bn_part, batch, W, ds));
+      BLH_TRY(launch_bn_bwd_finalize(s, ws.bn_part, chunks, W, grads + h.gamma, grads + h.beta));
+      BLH_TRY(launch_bn_bwd_apply_t(s, dA, ET_BF16, ws.Z[i], ET_BF16, sv + 2 * W, sv + 3 * W, sv,
+                                    sv + W, grads + h.gamma, grads + h.beta, ws.dZ[i], ET_BF16,
+                                    ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W, ds, batch));
+    } else {   // keep bits written by the forward (bn_bf16.hip)
+      BLH_TRY(launch_bn_bwd_reduce_h2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, ws.keep[i], ws.bn_part, batch, W));
+      BLH_TRY(launch_bn_bwd_finalize_h2(s, ws.bn_part, chunks, W, sv, sv + W, grads + h.gamma, grads + h.beta));
+      BLH_TRY(launch_bn_bwd_apply_h2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W, grads + h.gamma,
+                                     grads + h.beta, ws.keep[i], ws.dZ[i],
+                                     ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W, batch));
+    }
     const bool late = two && ctx->late_fork && i > 0;
     if (two && !late) BLH_TRY(fork_wait(i, false));       // behind bn_bwd_apply (marker event)
     // (data parallel: the bucket hook needs this stage's bias gradient now; otherwise all stages

@@ -223,6 +223,7 @@ struct WorkspaceH {
   uint16_t* xh;                     // [B][in] network input
   std::vector<uint16_t*> Z, A, dZ;  // per heavy stage, [B][W]
   std::vector<float*> bn_saved;     // per heavy stage [4][W]
+  std::vector<uint32_t*> keep;      // per heavy stage: dropout keep bits [ceil(B/4)][W/8] (bn_bf16.hip)
   uint16_t* G0; uint16_t* G1;
   float* stat_part; float* bn_part; float* dz_colsum_part; float* slabs;
   float* dpred; uint16_t* dpredh;   // [B][out] fp32 and its bf16 image
@@ -230,13 +231,29 @@ struct WorkspaceH {
   int64_t bytes;
 };
 
+// Batch slabs of a bf16-storage weight gradient dW[M][N] = dZ^T act (reduction over the batch).
+// Outputs with at least 64 tiles of 256 x 256 (W >= 2048) run on the 256 x 256 kernel
+// (gemm_bf16s_256.h: 1.43 PFLOP/s against 0.7-0.9 for the 128 x 128 kernel at W = 2048) with at most
+// 4 equal slabs of whole 128-deep steps; smaller outputs would need 16 slabs to fill the chip with
+// such tiles (64 MB of fp32 slabs at W = 1024) and stay on the 128 x 128 kernel with about one
+// workgroup per CU, slabs of whole 128-deep K tiles.
+static Splits wgrad_plan_h(int64_t M, int64_t N, int64_t batch) {
+  if (M % 256 == 0 && N % 256 == 0 && (M / 256) * (N / 256) >= 64) {
+    int64_t s = std::max<int64_t>(1, 256 / ((M / 256) * (N / 256)));
+    while (s > 1 && batch % (s * 128) != 0) s >>= 1;
+    if (batch % (s * 128) == 0) return Splits{(int)s, (int)(batch / s)};
+  }
+  Splits sp = pick_splits(batch, ceil_div(M, 128) * ceil_div(N, 128));
+  sp.k_per = (int)round_up(sp.k_per, 128);
+  sp.splits = (int)ceil_div(batch, sp.k_per);
+  return sp;
+}
+
 static int64_t slab_floats_h(const blh_model_desc* d, int64_t batch) {
   const int64_t W = d->width;
-  const Splits hs = pick_splits(batch, ceil_div(W, 128) * ceil_div(W, 128));
-  const Splits es = pick_splits(batch, ceil_div(W, 128));
-  int64_t m = hs.splits * W * W;
-  m = std::max(m, es.splits * W * (int64_t)d->in_features);
-  m = std::max(m, es.splits * (int64_t)d->out_features * W);
+  int64_t m = wgrad_plan_h(W, W, batch).splits * W * W;
+  m = std::max(m, wgrad_plan_h(W, d->in_features, batch).splits * W * (int64_t)d->in_features);
+  m = std::max(m, wgrad_plan_h(d->out_features, W, batch).splits * (int64_t)d->out_features * W);
   return m;
 }
 
@@ -258,6 +275,7 @@ static WorkspaceH carve_h(const blh_model_desc* d, int64_t batch, void* base) {
   for (int i = 0; i < nh; ++i) ws.A.push_back((uint16_t*)take(act));
   for (int i = 0; i < nh; ++i) ws.dZ.push_back((uint16_t*)take(act));
   for (int i = 0; i < nh; ++i) ws.bn_saved.push_back((float*)take(4 * W * sizeof(float)));
+  for (int i = 0; i < nh; ++i) ws.keep.push_back((uint32_t*)take(ceil_div(batch, 4) * (W / 8) * 4));
   ws.G0 = (uint16_t*)take(act);
   ws.G1 = (uint16_t*)take(act);
   ws.stat_part = (float*)take(ceil_div(batch, 64) * 2 * W * sizeof(float));

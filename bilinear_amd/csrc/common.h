@@ -139,6 +139,22 @@ int launch_bn_bwd_apply_t(hipStream_t s, const void* dA, int gt, const void* Z, 
                           const float* invstd, const float* dgamma, const float* dbeta, void* dZ,
                           int dt, float* dz_colsum_part, int64_t batch, int W,
                           const DropoutSrc& drop, int64_t norm_batch);
+// bf16-storage path, second generation (bn_bf16.hip): the forward writes one keep bit per element
+// (keepbits: [ceil(B/4)][W/8] words, bn_keepbits_words), the backward kernels read them
+int64_t bn_keepbits_words(int64_t batch, int W);
+int launch_bn_apply_h2(hipStream_t s, bool train, const uint16_t* Z, const float* scale, const float* shift,
+                       const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, const uint16_t* skip, uint16_t* A, uint32_t* keepbits,
+                       int64_t batch, int W, const DropoutSrc& drop, int64_t* nbt);
+// part [chunks][2][W]: sum dY z, sum dY (chunks = ew_num_row_chunks_h(batch))
+int launch_bn_bwd_reduce_h2(hipStream_t s, const uint16_t* dA, const uint16_t* Z, const float* scale,
+                            const float* shift, const uint32_t* keepbits, float* part, int64_t batch, int W);
+int launch_bn_bwd_finalize_h2(hipStream_t s, const float* part, int chunks, int W, const float* mean,
+                              const float* invstd, float* dgamma, float* dbeta);
+int launch_bn_bwd_apply_h2(hipStream_t s, const uint16_t* dA, const uint16_t* Z, const float* scale,
+                           const float* shift, const float* mean, const float* invstd, const float* dgamma,
+                           const float* dbeta, const uint32_t* keepbits, uint16_t* dZ, float* colsum_part,
+                           int64_t batch, int W, int64_t norm_batch);
 // eval: scale/shift from running stats, no dropout
 int launch_bn_apply_eval(hipStream_t s, const float* Z, const float* gamma, const float* beta,
                          const float* running_mean, const float* running_var,

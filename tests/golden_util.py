@@ -130,7 +130,8 @@ def safe_masks(st0, x, masks, rounding=None, thr=1e-4):
     masks = [np.array(m, dtype=np.uint8, copy=True) for m in masks]
     O.set_gemm_rounding(rounding)
     try:
-        for _ in range(8):
+        # (stage l is final once stages < l are: at most one pass per stage, plus the check)
+        for _ in range(max(8, len(masks) + 2)):
             st = {k: v.copy() for k, v in st0.items()}
             _, cache = O.forward(st, x, masks, training=True, dtype=np.float64)
             changed = 0
