@@ -135,11 +135,13 @@ static int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s
                                        params + h.gamma, params + h.beta, rm, rv, nbt + i,
                                        momentum, sv, sv + W, sv + 2 * W, sv + 3 * W));
       }
-      BLH_TRY(launch_bn_apply_train(s, ws.Z[i], sv + 2 * W, sv + 3 * W, skip, ws.A[i], batch, W,
-                                    layer_drop(ctx, drop, i, batch, W), nbt + i, ws.amax_A[i]));
+      BLH_TRY(launch_bn_apply_f2(s, true, ws.Z[i], sv + 2 * W, sv + 3 * W, nullptr, nullptr, nullptr,
+                                 nullptr, skip, ws.A[i], ws.keep[i], batch, W,
+                                 layer_drop(ctx, drop, i, batch, W), nbt + i, ws.amax_A[i]));
     } else {
-      BLH_TRY(launch_bn_apply_eval(s, ws.Z[i], params + h.gamma, params + h.beta, rm, rv, skip,
-                                   ws.A[i], batch, W, ws.amax_A[i]));
+      DropoutSrc none{nullptr, 0, 0, 0, 0, nullptr};
+      BLH_TRY(launch_bn_apply_f2(s, false, ws.Z[i], nullptr, nullptr, params + h.gamma, params + h.beta,
+                                 rm, rv, skip, ws.A[i], nullptr, batch, W, none, nullptr, ws.amax_A[i]));
     }
   }
   // decode (model/bilinear.py:39): N = 48 gives only B/128 output tiles, so the reduction
@@ -300,10 +302,9 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
     const bool first_of_block = (i >= 1) && (i % 2 == 1);
     const float* dA = first_of_block ? ws.G1 : ws.G0;
     const float* sv = ws.bn_saved[i];
-    const DropoutSrc ds = layer_drop(ctx, drop, i, batch, W);
-    BLH_TRY(launch_bn_bwd_reduce(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W, ws.bn_part,
-                                 batch, W, ds));
-    BLH_TRY(launch_bn_bwd_finalize(s, ws.bn_part, chunks, W, grads + h.gamma, grads + h.beta));
+    // (dropout: the keep bits the forward wrote, ws.keep[i])
+    BLH_TRY(launch_bn_bwd_reduce_f2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, ws.keep[i], ws.bn_part, batch, W));
+    BLH_TRY(launch_bn_bwd_finalize_h2(s, ws.bn_part, chunks, W, sv, sv + W, grads + h.gamma, grads + h.beta));
     const float* dg = grads + h.gamma;
     const float* db = grads + h.beta;
     int64_t norm_batch = batch;
@@ -337,10 +338,9 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
     const bool fork_late = side && ctx->late_fork && i > 0 && small_m_splits(batch, W, W).splits == 1;
     hipStream_t sw = side ? s2 : s;
     if (side && !fork_late) arm_fork(i);
-    BLH_TRY(launch_bn_bwd_apply(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W,
-                                params + h.gamma, dg, db, dzbuf,
-                                ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W, ds,
-                                norm_batch, dz_amax));
+    BLH_TRY(launch_bn_bwd_apply_f2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W, dg, db, ws.keep[i],
+                                   dzbuf, ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W,
+                                   norm_batch, dz_amax));
     tl_stop_event = nullptr;
     if (side && !fork_late) BLH_TRY(fork_wait(i));
     if (fork_late) arm_fork(i);
@@ -934,6 +934,7 @@ int blh_backward_sync(blh_context* ctx, const blh_model_desc* d, void* stream, c
 // heavy_linear (model/bilinear.py:7-13) on its own: Linear -> BatchNorm1d -> ReLU -> Dropout.
 struct HeavyWs {
   float* Z; float* dZ; float* saved; float* stat_part; float* bn_part; float* dz_part; float* slabs;
+  uint32_t* keep;
   int64_t bytes;
 };
 static HeavyWs carve_heavy(int64_t batch, int in_f, int out_f, void* base) {
@@ -954,6 +955,7 @@ static HeavyWs carve_heavy(int64_t batch, int in_f, int out_f, void* base) {
   w.dz_part = (float*)take(chunks * out_f * sizeof(float));
   const Splits sp = pick_splits(batch, ceil_div(out_f, 128) * ceil_div(in_f, 128));
   w.slabs = (float*)take((int64_t)sp.splits * out_f * in_f * sizeof(float));
+  w.keep = (uint32_t*)take(ceil_div(batch, 8) * (out_f / 4) * 4);
   w.bytes = off;
   return w;
 }
@@ -988,16 +990,18 @@ int blh_heavy_forward(blh_context* ctx, void* stream, const float* a_in, const f
   g.bias = bias; g.stat_part = w.stat_part;
   BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, training ? EPI_BIAS_STATS : EPI_BIAS, g, 1,
                       gemm_dtype));
-  if (!training)
-    return launch_bn_apply_eval(s, w.Z, gamma, beta, running_mean, running_var, nullptr, a_out,
-                                batch, W);
+  if (!training) {
+    DropoutSrc none{nullptr, 0, 0, 0, 0, nullptr};
+    return launch_bn_apply_f2(s, false, w.Z, nullptr, nullptr, gamma, beta, running_mean, running_var,
+                              nullptr, a_out, nullptr, batch, W, none, nullptr);
+  }
   float* sv = w.saved;
   BLH_TRY(launch_bn_fwd_finalize(s, w.stat_part, (int)ceil_div(batch, 128), 128, batch, W, gamma,
                                  beta, running_mean, running_var, num_batches_tracked, momentum, sv,
                                  sv + W, sv + 2 * W, sv + 3 * W));
   DropoutSrc ds{drop->keep_mask, drop->seed, drop->step, drop->row_offset, drop->layer_base, nullptr};
-  return launch_bn_apply_train(s, w.Z, sv + 2 * W, sv + 3 * W, nullptr, a_out, batch, W, ds,
-                               num_batches_tracked);
+  return launch_bn_apply_f2(s, true, w.Z, sv + 2 * W, sv + 3 * W, nullptr, nullptr, nullptr, nullptr,
+                            nullptr, a_out, w.keep, batch, W, ds, num_batches_tracked);
 }
 
 int blh_heavy_backward(blh_context* ctx, void* stream, const float* d_out, const float* a_in, const float* weight,
@@ -1017,12 +1021,11 @@ int blh_heavy_backward(blh_context* ctx, void* stream, const float* d_out, const
   const int W = out_features;
   const int chunks = ew_num_row_chunks(batch);
   const float* sv = w.saved;
-  DropoutSrc ds{drop->keep_mask, drop->seed, drop->step, drop->row_offset, drop->layer_base, nullptr};
-  BLH_TRY(launch_bn_bwd_reduce(s, d_out, w.Z, sv + 2 * W, sv + 3 * W, sv, sv + W, w.bn_part, batch,
-                               W, ds));
-  BLH_TRY(launch_bn_bwd_finalize(s, w.bn_part, chunks, W, d_gamma, d_beta));
-  BLH_TRY(launch_bn_bwd_apply(s, d_out, w.Z, sv + 2 * W, sv + 3 * W, sv, sv + W, gamma, d_gamma,
-                              d_beta, w.dZ, w.dz_part, batch, W, ds, batch));
+  // (the dropout mask of the stage is in w.keep, written by blh_heavy_forward)
+  BLH_TRY(launch_bn_bwd_reduce_f2(s, d_out, w.Z, sv + 2 * W, sv + 3 * W, w.keep, w.bn_part, batch, W));
+  BLH_TRY(launch_bn_bwd_finalize_h2(s, w.bn_part, chunks, W, sv, sv + W, d_gamma, d_beta));
+  BLH_TRY(launch_bn_bwd_apply_f2(s, d_out, w.Z, sv + 2 * W, sv + 3 * W, sv, sv + W, d_gamma, d_beta, w.keep,
+                                 w.dZ, w.dz_part, batch, W, batch));
   BLH_TRY(launch_colreduce(s, w.dz_part, chunks, W, W, d_bias));
   BLH_TRY(wgrad(gemm_dtype, s, TILE_128x128, w.dZ, W, W, a_in, in_features, in_features, batch,
                 ceil_div(W, 128) * ceil_div(in_features, 128), w.slabs, d_weight, nullptr));

@@ -83,6 +83,7 @@ static ArenaLayout make_layout(const blh_model_desc* d) {
 struct Workspace {
   std::vector<float*> Z, A;       // per heavy: pre-BN output, activation (skip added)
   std::vector<float*> bn_saved;   // per heavy: [4][W] mean, invstd, scale, shift
+  std::vector<uint32_t*> keep;    // per heavy: dropout keep bits [ceil(B/8)][W/4] words (bn_f32.hip)
   float* stat_part;               // [tiles_m][2][W]
   float* G0; float* G1;
   std::vector<float*> dZ;         // per heavy stage: no buffer is reused inside one backward, so
@@ -166,6 +167,7 @@ static Workspace carve(const blh_model_desc* d, int64_t batch, void* base) {
   for (int i = 0; i < nh; ++i) ws.Z.push_back((float*)take(act));
   for (int i = 0; i < nh; ++i) ws.A.push_back((float*)take(act));
   for (int i = 0; i < nh; ++i) ws.bn_saved.push_back((float*)take(4 * W * sizeof(float)));
+  for (int i = 0; i < nh; ++i) ws.keep.push_back((uint32_t*)take(ceil_div(batch, 8) * (W / 4) * 4));
   ws.stat_part = (float*)take(ceil_div(batch, 64) * 2 * W * sizeof(float));
   ws.G0 = (float*)take(act);
   ws.G1 = (float*)take(act);

@@ -155,6 +155,19 @@ int launch_bn_bwd_apply_h2(hipStream_t s, const uint16_t* dA, const uint16_t* Z,
                            const float* shift, const float* mean, const float* invstd, const float* dgamma,
                            const float* dbeta, const uint32_t* keepbits, uint16_t* dZ, float* colsum_part,
                            int64_t batch, int W, int64_t norm_batch);
+// fp32-storage path, second generation (bn_f32.hip): keepbits [ceil(B/8)][W/4] words
+int64_t bn_keepbits_words_f32(int64_t batch, int W);
+int launch_bn_apply_f2(hipStream_t s, bool train, const float* Z, const float* scale, const float* shift,
+                       const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, const float* skip, float* A, uint32_t* keepbits,
+                       int64_t batch, int W, const DropoutSrc& drop, int64_t* nbt, float* amax_part = nullptr);
+// part [chunks][2][W]: sum dY z, sum dY (chunks = ew_num_row_chunks(batch)); finalize: launch_bn_bwd_finalize_h2
+int launch_bn_bwd_reduce_f2(hipStream_t s, const float* dA, const float* Z, const float* scale,
+                            const float* shift, const uint32_t* keepbits, float* part, int64_t batch, int W);
+int launch_bn_bwd_apply_f2(hipStream_t s, const float* dA, const float* Z, const float* scale,
+                           const float* shift, const float* mean, const float* invstd, const float* dgamma,
+                           const float* dbeta, const uint32_t* keepbits, float* dZ, float* colsum_part,
+                           int64_t batch, int W, int64_t norm_batch, float* amax_part = nullptr);
 // eval: scale/shift from running stats, no dropout
 int launch_bn_apply_eval(hipStream_t s, const float* Z, const float* gamma, const float* beta,
                          const float* running_mean, const float* running_var,
