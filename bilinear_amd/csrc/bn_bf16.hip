@@ -222,35 +222,36 @@ __global__ __launch_bounds__(H2_THREADS, BLH_H2_WAVES) void bn_bwd_reduce_h2_ker
 }
 
 // dgamma[c] = invstd (sum_s S1 - mean sum_s S2), dbeta[c] = sum_s S2; fp64 (the subtraction cancels
-// when |mean| >> 1 / invstd).  block = 32 columns x 8 slices.
+// when |mean| >> 1 / invstd).  block = 16 columns x 16 slices; a thread requests up to 8 rows of
+// both sums at once (these tiny reductions are latency-bound: one round trip per batch of loads).
 __global__ __launch_bounds__(256) void bn_bwd_finalize_h2_kernel(const float* __restrict__ part, int S, int W,
                                                                  const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd,
                                                                  float* __restrict__ dgamma,
                                                                  float* __restrict__ dbeta) {
-  __shared__ double r1[8][32], r2[8][32];
-  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int col = blockIdx.x * 32 + cl;
+  __shared__ double r1[16][16], r2[16][16];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + cl;
   double a1 = 0.0, a2 = 0.0;
   if (col < W)
-    for (int s0 = sl; s0 < S; s0 += 8 * 4) {      // 4 independent row loads in flight per tensor
-      float v1[4], v2[4];
+    for (int s0 = sl; s0 < S; s0 += 16 * 8) {
+      float v1[8], v2[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int s = min(s0 + 8 * u, S - 1);
+      for (int u = 0; u < 8; ++u) {
+        const int s = min(s0 + 16 * u, S - 1);
         v1[u] = part[((int64_t)s * 2 + 0) * W + col];
         v2[u] = part[((int64_t)s * 2 + 1) * W + col];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (s0 + 8 * u < S) { a1 += (double)v1[u]; a2 += (double)v2[u]; }
+      for (int u = 0; u < 8; ++u)
+        if (s0 + 16 * u < S) { a1 += (double)v1[u]; a2 += (double)v2[u]; }
     }
   r1[sl][cl] = a1; r2[sl][cl] = a2;
   __syncthreads();
   if (sl == 0 && col < W) {
     double t1 = 0.0, t2 = 0.0;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) { t1 += r1[s][cl]; t2 += r2[s][cl]; }
+    for (int s = 0; s < 16; ++s) { t1 += r1[s][cl]; t2 += r2[s][cl]; }
     dgamma[col] = (float)((double)invstd[col] * (t1 - (double)mean[col] * t2));
     dbeta[col] = (float)t2;
   }
@@ -357,7 +358,7 @@ int launch_bn_bwd_reduce_h2(hipStream_t s, const uint16_t* dA, const uint16_t* Z
 
 int launch_bn_bwd_finalize_h2(hipStream_t s, const float* part, int chunks, int W, const float* mean,
                               const float* invstd, float* dgamma, float* dbeta) {
-  hipLaunchKernelGGL(bn_bwd_finalize_h2_kernel, dim3((unsigned)ceil_div(W, 32)), dim3(256), 0, s, part, chunks,
+  hipLaunchKernelGGL(bn_bwd_finalize_h2_kernel, dim3((unsigned)ceil_div(W, 16)), dim3(256), 0, s, part, chunks,
                      W, mean, invstd, dgamma, dbeta);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
