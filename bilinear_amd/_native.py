@@ -63,6 +63,17 @@ _SIGNATURES = {
     "blh_forward_train": (c_int, [c_void_p, POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, POINTER(Dropout), c_float, c_void_p, c_int64,
                                   c_void_p, c_int64]),
+    "blh_clip_adam_step_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                        c_int64, POINTER(AdamHyper), c_void_p, c_int64, c_void_p]),
+    "blh_refresh_param_shadow": (c_int, [c_void_p, POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_int64,
+                                         c_int64]),
+    "blh_forward_train_loss": (c_int, [c_void_p, POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, POINTER(Dropout), c_float, c_void_p, c_int64,
+                                       c_void_p, c_void_p, c_int64]),
+    "blh_forward_train_loss_sync": (c_int, [c_void_p, POINTER(ModelDesc), c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, c_void_p, POINTER(Dropout), c_float,
+                                            c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
+                                            SyncFn, c_void_p]),
     "blh_forward_eval": (c_int, [c_void_p, POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int64, c_void_p, c_int64]),
     "blh_mse_loss_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double,
@@ -166,6 +177,7 @@ def lib():
 OPT_TWO_STREAM = 0
 OPT_DEFER_SLABS = 1
 OPT_LATE_FORK = 2
+OPT_PERSISTENT_SHADOW = 3
 
 
 class Context:

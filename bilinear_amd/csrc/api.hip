@@ -36,6 +36,15 @@ struct blh_context {
   // per-call state (set by the entry point for the duration of the call)
   blh::SyncCtx sync = {nullptr, nullptr, 0};
   const uint64_t* step_dev = nullptr;
+  // left by blh_forward_train_loss for blh_backward(dpred == NULL): rows of that forward and the
+  // number of decode-bias / loss partial rows its decode kernel wrote (0: none)
+  int64_t loss_batch = 0;
+  int loss_nparts = 0;
+  // BLH_OPT_PERSISTENT_SHADOW: the (params, workspace) whose bf16 parameter image the last fused
+  // step's Adam kernel left up to date (nullptr: none)
+  bool persistent_shadow = false;
+  const void* shadow_params = nullptr;
+  const void* shadow_ws = nullptr;
 };
 
 namespace blh {
@@ -293,6 +302,8 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
                 grads + L.dec_w, defer ? &wreg[nh] : nullptr));
   BLH_TRY(wdone(nh));
   if (!fused) BLH_TRY(launch_colsum(s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
+  else if (on_ready)   // (the hook wants the decode range complete now; else: one batched launch at the end)
+    BLH_TRY(launch_colreduce(s, ws.dec_bias_part, fused->dec_bias_S, OF, OF, grads + L.dec_b));
   BLH_TRY(ready(nh, L.dec_w, L.total - L.dec_w));
 
   for (int i = nh - 1; i >= 0; --i) {
@@ -449,13 +460,15 @@ static int bn_h_gen() {
 
 static int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
                      float* bn_running, int64_t* nbt, const float* x, const blh_dropout* drop,
-                     float momentum, const WorkspaceH& ws, float* pred, int64_t batch, bool train) {
-  if (ctx->sync.fn) return BLH_ERR_INVALID_ARGUMENT;   // SyncBN is not built for bf16 storage
+                     float momentum, const WorkspaceH& ws, float* pred, int64_t batch, bool train,
+                     bool shadow_valid = false) {
   const ArenaLayout L = make_layout(d);
   const int nh = (int)L.heavy.size();
   const int W = d->width, OF = d->out_features, IF = d->in_features;
   // bf16 images of the parameters (the GEMMs read the weights from it) and of the input
-  BLH_TRY(launch_cast_f32_bf16(s, params, ws.wsh, L.total));
+  // (shadow_valid: the previous fused step's Adam kernel wrote it, BLH_OPT_PERSISTENT_SHADOW)
+  ctx->shadow_params = ctx->shadow_ws = nullptr;
+  if (!shadow_valid) BLH_TRY(launch_cast_f32_bf16(s, params, ws.wsh, L.total));
   BLH_TRY(launch_cast_f32_bf16(s, x, ws.xh, batch * IF));
   for (int i = 0; i < nh; ++i) {
     const HeavyOffsets& h = L.heavy[i];
@@ -474,9 +487,17 @@ static int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, c
     float* rv = bn_running + ((int64_t)i * 2 + 1) * W;
     if (train) {
       float* sv = ws.bn_saved[i];
-      BLH_TRY(launch_bn_fwd_finalize(s, ws.stat_part, st_tiles, st_rows, batch, W, params + h.gamma,
-                                     params + h.beta, rm, rv, nbt + i, momentum, sv, sv + W,
-                                     sv + 2 * W, sv + 3 * W));
+      if (ctx->sync.fn) {   // SyncBN: statistics over the global batch (fp64 sums exchanged by the host)
+        BLH_TRY(launch_bn_fwd_local_sums(s, ws.stat_part, st_tiles, st_rows, batch, W, ws.sync_buf));
+        ctx->sync.fn(ctx->sync.user, ws.sync_buf, 2 * (int64_t)W, 1);
+        BLH_TRY(launch_bn_fwd_finalize_sums(s, ws.sync_buf, ctx->sync.global_batch, W, params + h.gamma,
+                                            params + h.beta, rm, rv, nbt + i, momentum, sv, sv + W,
+                                            sv + 2 * W, sv + 3 * W));
+      } else {
+        BLH_TRY(launch_bn_fwd_finalize(s, ws.stat_part, st_tiles, st_rows, batch, W, params + h.gamma,
+                                       params + h.beta, rm, rv, nbt + i, momentum, sv, sv + W,
+                                       sv + 2 * W, sv + 3 * W));
+      }
       if (bn_h_gen() == 1)
         BLH_TRY(launch_bn_apply_t(s, true, ws.Z[i], ET_BF16, sv + 2 * W, sv + 3 * W, nullptr, nullptr,
                                   nullptr, nullptr, skip, ET_BF16, ws.A[i], ET_BF16, batch, W,
@@ -525,7 +546,6 @@ static int wgrad_h(hipStream_t s, const uint16_t* dZ, int64_t ld_dz, int M, cons
 static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
                       const blh_dropout* drop, const WorkspaceH& ws, const float* dpred,
                       float* grads, int64_t batch, blh_grad_ready_fn on_ready, void* user) {
-  if (ctx->sync.fn) return BLH_ERR_INVALID_ARGUMENT;
   const ArenaLayout L = make_layout(d);
   const int nh = (int)L.heavy.size();
   const int W = d->width, OF = d->out_features, IF = d->in_features;
@@ -534,7 +554,7 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
   // context's side stream — in order there, so they share one slab buffer — forked behind the
   // data-gradient GEMM of its stage (BLH_OPT_LATE_FORK) or behind bn_bwd_apply; one join at the end.
   tl_stop_event = nullptr;
-  const bool two = ctx->two_stream;
+  const bool two = ctx->two_stream && !ctx->sync.fn;   // (SyncBN: the exchanges are enqueued on `s`)
   hipStream_t s2 = two ? ctx->s2 : s;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &cap);
@@ -589,9 +609,21 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
     } else {   // keep bits written by the forward (bn_bf16.hip)
       BLH_TRY(launch_bn_bwd_reduce_h2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, ws.keep[i], ws.bn_part, batch, W));
       BLH_TRY(launch_bn_bwd_finalize_h2(s, ws.bn_part, chunks, W, sv, sv + W, grads + h.gamma, grads + h.beta));
-      BLH_TRY(launch_bn_bwd_apply_h2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W, grads + h.gamma,
-                                     grads + h.beta, ws.keep[i], ws.dZ[i],
-                                     ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W, batch));
+      const float* dg = grads + h.gamma;
+      const float* db = grads + h.beta;
+      int64_t norm_batch = batch;
+      if (ctx->sync.fn) {
+        // SyncBN: the parameter gradients keep the LOCAL sums (averaged later with the rest of the
+        // arena); the BatchNorm backward itself needs the sums over the global batch
+        float* sb = reinterpret_cast<float*>(ws.sync_buf);
+        BLH_HIP_TRY(hipMemcpyAsync(sb, grads + h.gamma, W * sizeof(float), hipMemcpyDeviceToDevice, s));
+        BLH_HIP_TRY(hipMemcpyAsync(sb + W, grads + h.beta, W * sizeof(float), hipMemcpyDeviceToDevice, s));
+        ctx->sync.fn(ctx->sync.user, sb, 2 * (int64_t)W, 0);
+        dg = sb; db = sb + W; norm_batch = ctx->sync.global_batch;
+      }
+      BLH_TRY(launch_bn_bwd_apply_h2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W, dg, db, ws.keep[i],
+                                     ws.dZ[i], ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W,
+                                     norm_batch));
     }
     const bool late = two && ctx->late_fork && i > 0;
     if (two && !late) BLH_TRY(fork_wait(i, false));       // behind bn_bwd_apply (marker event)
@@ -706,6 +738,10 @@ int blh_context_set_option(blh_context* c, int32_t option, int32_t value) {
     case BLH_OPT_TWO_STREAM: c->two_stream = value != 0; return BLH_OK;
     case BLH_OPT_DEFER_SLABS: c->defer_slabs = value != 0; return BLH_OK;
     case BLH_OPT_LATE_FORK: c->late_fork = value != 0; return BLH_OK;
+    case BLH_OPT_PERSISTENT_SHADOW:
+      c->persistent_shadow = value != 0;
+      c->shadow_params = c->shadow_ws = nullptr;
+      return BLH_OK;
   }
   return BLH_ERR_INVALID_ARGUMENT;
 }
@@ -716,6 +752,7 @@ int blh_context_get_option(const blh_context* c, int32_t option) {
     case BLH_OPT_TWO_STREAM: return c->two_stream ? 1 : 0;
     case BLH_OPT_DEFER_SLABS: return c->defer_slabs ? 1 : 0;
     case BLH_OPT_LATE_FORK: return c->late_fork ? 1 : 0;
+    case BLH_OPT_PERSISTENT_SHADOW: return c->persistent_shadow ? 1 : 0;
   }
   return BLH_ERR_INVALID_ARGUMENT;
 }
@@ -796,6 +833,35 @@ int blh_forward_train(blh_context* ctx, const blh_model_desc* d, void* stream, c
                       pred, batch, true, nullptr, 0.f, nullptr, nullptr);
 }
 
+int blh_forward_train_loss(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params,
+                           float* bn_running, int64_t* bn_nbt, const float* x, const float* target,
+                           const blh_dropout* drop, float momentum, void* workspace,
+                           int64_t workspace_bytes, float* pred, float* loss_out, int64_t batch) {
+  BLH_TRY(check_common(ctx, d, workspace, workspace_bytes, batch));
+  BLH_TRY(check_drop(drop));
+  if (!params || !bn_running || !bn_nbt || !x || !target || !pred || !loss_out) return BLH_ERR_INVALID_ARGUMENT;
+  if (batch < 2) return BLH_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const double denom = (double)batch * d->out_features;
+  int nparts = 0;
+  ctx->loss_batch = 0;
+  if (d->gemm_dtype == 4) {
+    const WorkspaceH wh = carve_h(d, batch, workspace);
+    BLH_TRY(forward_h(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, wh, pred, batch, true));
+    BLH_TRY(launch_mse(s, pred, target, batch * d->out_features, (float)(2.0 / denom), wh.dpred,
+                       wh.loss_part, &nparts));
+    BLH_TRY(launch_loss_finalize(s, wh.loss_part, nparts, denom, loss_out));
+    ctx->loss_batch = batch; ctx->loss_nparts = 0;
+    return BLH_OK;
+  }
+  const Workspace ws = carve(d, batch, workspace);
+  BLH_TRY(forward_impl(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
+                       target, (float)(2.0 / denom), ws.loss_part, &nparts));
+  BLH_TRY(launch_loss_finalize(s, ws.loss_part, nparts, denom, loss_out));
+  ctx->loss_batch = batch; ctx->loss_nparts = nparts;
+  return BLH_OK;
+}
+
 int blh_forward_eval(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params,
                      const float* bn_running, const float* x, void* workspace,
                      int64_t workspace_bytes, float* pred, int64_t batch) {
@@ -831,13 +897,25 @@ int blh_backward(blh_context* ctx, const blh_model_desc* d, void* stream, const 
                  void* user) {
   BLH_TRY(check_common(ctx, d, workspace, workspace_bytes, batch));
   BLH_TRY(check_drop(drop));
-  if (!params || !x || !dpred || !grads) return BLH_ERR_INVALID_ARGUMENT;
-  if (d->gemm_dtype == 4)
-    return backward_h(ctx, d, (hipStream_t)stream, params, drop, carve_h(d, batch, workspace), dpred,
-                      grads, batch, on_ready, user);
+  if (!params || !x || !grads) return BLH_ERR_INVALID_ARGUMENT;
+  // dpred == NULL: the loss gradient blh_forward_train_loss left in the workspace
+  const bool from_loss = dpred == nullptr;
+  if (from_loss && ctx->loss_batch != batch) return BLH_ERR_INVALID_ARGUMENT;
+  const int loss_nparts = ctx->loss_nparts;
+  ctx->loss_batch = 0;
+  if (d->gemm_dtype == 4) {
+    const WorkspaceH wh = carve_h(d, batch, workspace);
+    return backward_h(ctx, d, (hipStream_t)stream, params, drop, wh, from_loss ? wh.dpred : dpred, grads,
+                      batch, on_ready, user);
+  }
   const Workspace ws = carve(d, batch, workspace);
-  return backward_impl(ctx, d, (hipStream_t)stream, params, x, drop, ws, dpred, grads, batch,
-                       on_ready, user);
+  if (from_loss && loss_nparts > 0) {   // decode-bias partials of the fused decode kernel
+    const FusedBackward fb{loss_nparts, nullptr, nullptr};
+    return backward_impl(ctx, d, (hipStream_t)stream, params, x, drop, ws, ws.dpred, grads, batch,
+                         on_ready, user, &fb);
+  }
+  return backward_impl(ctx, d, (hipStream_t)stream, params, x, drop, ws, from_loss ? ws.dpred : dpred,
+                       grads, batch, on_ready, user);
 }
 
 int blh_clip_adam_step(void* stream, float* params, float* grads, float* exp_avg,
@@ -851,6 +929,30 @@ int blh_clip_adam_step(void* stream, float* params, float* grads, float* exp_avg
   BLH_TRY(launch_sumsq((hipStream_t)stream, grads, count, sc.sumsq_part, &nparts));
   return launch_clip_adam((hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, count, *hyper,
                           sc.sumsq_part, nparts, stats_out);
+}
+
+int blh_clip_adam_step_bf16(void* stream, float* params, const uint16_t* grads_bf16, float grad_scale,
+                            float* grads, float* exp_avg, float* exp_avg_sq, int64_t count,
+                            const blh_adam_hyper* hyper, void* workspace, int64_t workspace_bytes,
+                            float* stats_out) {
+  if (!params || !grads_bf16 || !grads || !exp_avg || !exp_avg_sq || !hyper || !workspace || count <= 0)
+    return BLH_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < SCRATCH_BYTES) return BLH_ERR_WORKSPACE;
+  const Scratch sc = carve_scratch(workspace);
+  int nparts = 0;
+  BLH_TRY(launch_sumsq_bf16((hipStream_t)stream, grads_bf16, count, grad_scale, sc.sumsq_part, &nparts));
+  return launch_clip_adam_bf16((hipStream_t)stream, params, grads_bf16, grad_scale, grads, exp_avg, exp_avg_sq,
+                               count, *hyper, sc.sumsq_part, nparts, stats_out);
+}
+
+int blh_refresh_param_shadow(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params,
+                             void* workspace, int64_t workspace_bytes, int64_t batch) {
+  BLH_TRY(check_common(ctx, d, workspace, workspace_bytes, batch));
+  if (!params || d->gemm_dtype != 4) return BLH_ERR_INVALID_ARGUMENT;
+  const WorkspaceH wh = carve_h(d, batch, workspace);
+  BLH_TRY(launch_cast_f32_bf16((hipStream_t)stream, params, wh.wsh, make_layout(d).total));
+  if (ctx->persistent_shadow) { ctx->shadow_params = params; ctx->shadow_ws = workspace; }
+  return BLH_OK;
 }
 
 int blh_clip_grad_norm(void* stream, float* grads, int64_t count, float max_norm, void* workspace,
@@ -882,13 +984,18 @@ int blh_train_step(blh_context* ctx, const blh_model_desc* d, void* stream, floa
     const WorkspaceH wh = carve_h(d, batch, workspace);
     const int64_t count = make_layout(d).total;
     int np = 0;
-    BLH_TRY(forward_h(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, wh, pred, batch, true));
+    const bool keep = ctx->persistent_shadow;
+    const bool valid = keep && ctx->shadow_params == params && ctx->shadow_ws == workspace;
+    BLH_TRY(forward_h(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, wh, pred, batch, true, valid));
     BLH_TRY(launch_mse(s, pred, target, batch * d->out_features, (float)(2.0 / denom), wh.dpred,
                        wh.loss_part, &nparts));
     BLH_TRY(backward_h(ctx, d, s, params, drop, wh, wh.dpred, grads, batch, nullptr, nullptr));
     BLH_TRY(launch_sumsq(s, grads, count, wh.sumsq_part, &np));
-    return launch_clip_adam(s, params, grads, exp_avg, exp_avg_sq, count, *hyper, wh.sumsq_part, np,
-                            stats_out, LossFinish{wh.loss_part, nparts, denom, loss_out});
+    BLH_TRY(launch_clip_adam(s, params, grads, exp_avg, exp_avg_sq, count, *hyper, wh.sumsq_part, np,
+                             stats_out, LossFinish{wh.loss_part, nparts, denom, loss_out},
+                             keep ? wh.wsh : nullptr));
+    if (keep) { ctx->shadow_params = params; ctx->shadow_ws = workspace; }
+    return BLH_OK;
   }
   const Workspace ws = carve(d, batch, workspace);
   BLH_TRY(forward_impl(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
@@ -914,6 +1021,21 @@ int blh_forward_train_sync(blh_context* ctx, const blh_model_desc* d, void* stre
   } guard(ctx, sync, user, global_batch);
   return blh_forward_train(ctx, d, stream, params, bn_running, bn_nbt, x, drop, momentum, workspace,
                            workspace_bytes, pred, batch);
+}
+
+int blh_forward_train_loss_sync(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params,
+                                float* bn_running, int64_t* bn_nbt, const float* x, const float* target,
+                                const blh_dropout* drop, float momentum, void* workspace,
+                                int64_t workspace_bytes, float* pred, float* loss_out, int64_t batch,
+                                int64_t global_batch, blh_sync_fn sync, void* user) {
+  if (!ctx || !sync || global_batch < batch) return BLH_ERR_INVALID_ARGUMENT;
+  struct Guard {
+    blh_context* c;
+    Guard(blh_context* c_, blh_sync_fn f, void* u, int64_t g) : c(c_) { c->sync = SyncCtx{f, u, g}; }
+    ~Guard() { c->sync = SyncCtx{nullptr, nullptr, 0}; }
+  } guard(ctx, sync, user, global_batch);
+  return blh_forward_train_loss(ctx, d, stream, params, bn_running, bn_nbt, x, target, drop, momentum,
+                                workspace, workspace_bytes, pred, loss_out, batch);
 }
 
 int blh_backward_sync(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params, const float* x,
@@ -1101,14 +1223,18 @@ int blh_train_step_captured(blh_context* ctx, const blh_model_desc* d, void* str
   if (d->gemm_dtype == 4) {
     const WorkspaceH wh = carve_h(d, batch, workspace);
     const int64_t count = make_layout(d).total;
-    BLH_TRY(forward_h(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, wh, pred, batch, true));
+    // (a captured step is replayed as recorded: with BLH_OPT_PERSISTENT_SHADOW the capture holds
+    //  no arena re-cast — the caller refreshes the image before the first replay and after any
+    //  out-of-band parameter change with blh_refresh_param_shadow)
+    const bool keep = ctx->persistent_shadow;
+    BLH_TRY(forward_h(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, wh, pred, batch, true, keep));
     BLH_TRY(launch_mse(s, pred, target, batch * d->out_features, (float)(2.0 / denom), wh.dpred,
                        wh.loss_part, &nparts));
     BLH_TRY(backward_h(ctx, d, s, params, drop, wh, wh.dpred, grads, batch, nullptr, nullptr));
     BLH_TRY(launch_sumsq(s, grads, count, wh.sumsq_part, &np));
     return launch_clip_adam_dev(s, params, grads, exp_avg, exp_avg_sq, count, dev_state,
                                 wh.sumsq_part, np, stats_out,
-                                LossFinish{wh.loss_part, nparts, denom, loss_out});
+                                LossFinish{wh.loss_part, nparts, denom, loss_out}, keep ? wh.wsh : nullptr);
   }
   const Workspace ws = carve(d, batch, workspace);
   BLH_TRY(forward_impl(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,

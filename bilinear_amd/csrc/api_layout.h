@@ -230,6 +230,7 @@ struct WorkspaceH {
   float* stat_part; float* bn_part; float* dz_colsum_part; float* slabs;
   float* dpred; uint16_t* dpredh;   // [B][out] fp32 and its bf16 image
   float* loss_part; double* sumsq_part; float* colsum_part;
+  double* sync_buf;                 // [2][W] fp64 (SyncBN exchange; its first 2W floats in backward)
   int64_t bytes;
 };
 
@@ -290,6 +291,7 @@ static WorkspaceH carve_h(const blh_model_desc* d, int64_t batch, void* base) {
   ws.loss_part = (float*)take(4096 * sizeof(float));
   ws.sumsq_part = (double*)take(SUMSQ_MAX_PARTS * sizeof(double));
   ws.colsum_part = (float*)take(ceil_div(batch, 256) * d->out_features * sizeof(float));
+  ws.sync_buf = (double*)take(2 * W * sizeof(double));
   ws.bytes = off;
   return ws;
 }

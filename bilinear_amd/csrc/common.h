@@ -221,9 +221,17 @@ int launch_mse(hipStream_t s, const float* pred, const float* target, int64_t n,
 // loss = sum(part[0..n)) / denom, finished by block 0 of the optimiser kernel (part == nullptr: off)
 struct LossFinish { const float* part; int n; double denom; float* out; };
 int launch_sumsq(hipStream_t s, const float* g, int64_t count, double* part, int* nparts);
+// shadow (optional): bf16 image of the updated parameters (the bf16-storage forward's weights)
 int launch_clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count,
                      const blh_adam_hyper& h, const double* sumsq_part, int nparts,
-                     float* stats_out, LossFinish lf = LossFinish{nullptr, 0, 1.0, nullptr});
+                     float* stats_out, LossFinish lf = LossFinish{nullptr, 0, 1.0, nullptr},
+                     uint16_t* shadow = nullptr);
+// the gradient arrives as bf16 (compressed data-parallel buckets) times gscale; gout (fp32 arena)
+// receives the clipped gradient
+int launch_sumsq_bf16(hipStream_t s, const uint16_t* g, int64_t count, float gscale, double* part, int* nparts);
+int launch_clip_adam_bf16(hipStream_t s, float* p, const uint16_t* g_bf16, float gscale, float* gout, float* m,
+                          float* v, int64_t count, const blh_adam_hyper& h, const double* sumsq_part,
+                          int nparts, float* stats_out, uint16_t* shadow = nullptr);
 // one launch at the end of backward: sum every stage's split-K weight-gradient slabs into the
 // arena and produce the sum-of-squares partials of the whole arena
 struct GradRegion { int64_t off4, cnt4; const float* slabs; int splits; int first_block; };
@@ -235,7 +243,8 @@ int launch_grads_finish(hipStream_t s, float* grads, GradRegions& R, int64_t tot
 int launch_step_state_advance(hipStream_t s, blh_step_state* st);
 int launch_clip_adam_dev(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count,
                          const blh_step_state* st, const double* sumsq_part, int nparts,
-                         float* stats_out, LossFinish lf = LossFinish{nullptr, 0, 1.0, nullptr});
+                         float* stats_out, LossFinish lf = LossFinish{nullptr, 0, 1.0, nullptr},
+                         uint16_t* shadow = nullptr);
 int launch_clip_scale(hipStream_t s, float* g, int64_t count, float max_norm,
                       const double* sumsq_part, int nparts, float* stats_out);
 // pred = sum(slabs) + bias (+ fused MSE when target != nullptr)

@@ -1149,14 +1149,16 @@ int launch_loss_finalize(hipStream_t s, const float* part, int n, double denom, 
 // ---------------------------------------------------------------------------
 // optimiser: global L2 norm partials, then fused clip + Adam over the flat arena
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t count,
+template <typename TG>
+__global__ __launch_bounds__(256) void sumsq_kernel(const TG* __restrict__ g, int64_t count, float gscale,
                                                     double* __restrict__ part) {
   __shared__ double sh[256];
   double acc = 0.0;
   const int64_t n4 = count >> 2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const float4 v = ld4(g + i * 4);
+    float4 v = ld4(g + i * 4);
+    v.x *= gscale; v.y *= gscale; v.z *= gscale; v.w *= gscale;
     acc += (double)(v.x * v.x + v.y * v.y) + (double)(v.z * v.z + v.w * v.w);
   }
   sh[threadIdx.x] = acc;
@@ -1171,7 +1173,16 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 int launch_sumsq(hipStream_t s, const float* g, int64_t count, double* part, int* nparts) {
   if (count % 4 != 0) return BLH_ERR_SHAPE;
   const int blocks = (int)std::min<int64_t>(ceil_div(count / 4, 256 * 4), SUMSQ_MAX_PARTS);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, s, g, count, part);
+  hipLaunchKernelGGL(sumsq_kernel<float>, dim3(blocks), dim3(256), 0, s, g, count, 1.0f, part);
+  BLH_HIP_TRY(hipGetLastError());
+  *nparts = blocks;
+  return BLH_OK;
+}
+
+int launch_sumsq_bf16(hipStream_t s, const uint16_t* g, int64_t count, float gscale, double* part, int* nparts) {
+  if (count % 4 != 0) return BLH_ERR_SHAPE;
+  const int blocks = (int)std::min<int64_t>(ceil_div(count / 4, 256 * 4), SUMSQ_MAX_PARTS);
+  hipLaunchKernelGGL(sumsq_kernel<bf16_bits>, dim3(blocks), dim3(256), 0, s, g, count, gscale, part);
   BLH_HIP_TRY(hipGetLastError());
   *nparts = blocks;
   return BLH_OK;
@@ -1193,12 +1204,19 @@ __device__ __forceinline__ void finish_loss(const LossFinish& lf, double* sh) {
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void clip_adam_kernel(
-    float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-    int64_t count, float one_minus_b1, float b2, float one_minus_b2, float step_size,
-    float bc2_sqrt, float eps, float max_norm, const double* __restrict__ sumsq_part, int nparts,
-    float* stats_out, LossFinish lf) {
-  __shared__ double sh[256];
+// clip + Adam over the flat arena.  gin: the gradient as it arrives (fp32 arena, or the bf16 buckets
+// of the compressed data-parallel exchange, times gscale); gout: the fp32 arena, which receives the
+// clipped gradient (the reference's .grad after clip_grad_norm_); shadow (optional): the bf16 image
+// of the updated parameters for the next bf16-storage forward.
+struct AdamConsts { float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, max_norm; };
+
+template <typename TG>
+__device__ __forceinline__ void clip_adam_body(float* __restrict__ p, const TG* gin, float* gout,
+                                               float* __restrict__ m, float* __restrict__ v, int64_t count,
+                                               const AdamConsts c, float gscale,
+                                               const double* __restrict__ sumsq_part, int nparts,
+                                               float* stats_out, const LossFinish& lf,
+                                               bf16_bits* __restrict__ shadow, double* sh) {
   finish_loss(lf, sh);
   double a = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 256) a += sumsq_part[i];
@@ -1210,43 +1228,69 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(
   }
   const float total_norm = (float)sqrt(sh[0]);
   float coef = 1.0f;
-  if (max_norm > 0.f) coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);
+  if (c.max_norm > 0.f) coef = fminf(c.max_norm / (total_norm + 1e-6f), 1.0f);
   if (stats_out && blockIdx.x == 0 && threadIdx.x == 0) {
     stats_out[0] = total_norm;
     stats_out[1] = coef;
   }
+  const float gmul = coef * gscale;      // (gscale == 1 on the fp32 path: bit-identical to coef)
   const int64_t n4 = count >> 2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
        i += (int64_t)gridDim.x * blockDim.x) {
-    float4 gv = ld4(g + i * 4), mv = ld4(m + i * 4), vv = ld4(v + i * 4), pv = ld4(p + i * 4);
+    float4 gv = ld4(gin + i * 4), mv = ld4(m + i * 4), vv = ld4(v + i * 4), pv = ld4(p + i * 4);
     float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x; float* pp = &pv.x;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float gg = gp[k] * coef;
+      const float gg = gp[k] * gmul;
       gp[k] = gg;
-      mp[k] = mp[k] + (gg - mp[k]) * one_minus_b1;
-      vp[k] = vp[k] * b2 + (one_minus_b2 * gg) * gg;
-      const float denom = sqrtf(vp[k]) / bc2_sqrt + eps;
-      pp[k] = pp[k] - step_size * (mp[k] / denom);
+      mp[k] = mp[k] + (gg - mp[k]) * c.one_minus_b1;
+      vp[k] = vp[k] * c.b2 + (c.one_minus_b2 * gg) * gg;
+      const float denom = sqrtf(vp[k]) / c.bc2_sqrt + c.eps;
+      pp[k] = pp[k] - c.step_size * (mp[k] / denom);
     }
-    st4(g + i * 4, gv); st4(m + i * 4, mv); st4(v + i * 4, vv); st4(p + i * 4, pv);
+    st4(gout + i * 4, gv); st4(m + i * 4, mv); st4(v + i * 4, vv); st4(p + i * 4, pv);
+    if (shadow) st4(shadow + i * 4, pv);
   }
+}
+
+template <typename TG>
+__global__ __launch_bounds__(256) void clip_adam_kernel(
+    float* __restrict__ p, const TG* gin, float* gout, float* __restrict__ m, float* __restrict__ v,
+    int64_t count, AdamConsts c, float gscale, const double* __restrict__ sumsq_part, int nparts,
+    float* stats_out, LossFinish lf, bf16_bits* __restrict__ shadow) {
+  __shared__ double sh[256];
+  clip_adam_body<TG>(p, gin, gout, m, v, count, c, gscale, sumsq_part, nparts, stats_out, lf, shadow, sh);
+}
+
+static AdamConsts adam_consts(const blh_adam_hyper& h) {
+  // torch.optim.Adam forms these scalars in double (Python floats) and rounds each once
+  const double bc1 = 1.0 - pow(h.beta1, (double)h.step);
+  const double bc2 = 1.0 - pow(h.beta2, (double)h.step);
+  return AdamConsts{(float)(1.0 - h.beta1), (float)h.beta2, (float)(1.0 - h.beta2), (float)(h.lr / bc1),
+                    (float)sqrt(bc2), (float)h.eps, (float)h.max_norm};
 }
 
 int launch_clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count,
                      const blh_adam_hyper& h, const double* sumsq_part, int nparts,
-                     float* stats_out, LossFinish lf) {
+                     float* stats_out, LossFinish lf, uint16_t* shadow) {
   if (count % 4 != 0) return BLH_ERR_SHAPE;
   if (h.step < 1) return BLH_ERR_INVALID_ARGUMENT;
-  // torch.optim.Adam forms these scalars in double (Python floats) and rounds each once
-  const double bc1 = 1.0 - pow(h.beta1, (double)h.step);
-  const double bc2 = 1.0 - pow(h.beta2, (double)h.step);
-  const float step_size = (float)(h.lr / bc1);
-  const float bc2_sqrt = (float)sqrt(bc2);
   const int blocks = (int)std::min<int64_t>(ceil_div(count / 4, 256), 2048);
-  hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, count,
-                     (float)(1.0 - h.beta1), (float)h.beta2, (float)(1.0 - h.beta2),
-                     step_size, bc2_sqrt, (float)h.eps, (float)h.max_norm, sumsq_part, nparts, stats_out, lf);
+  hipLaunchKernelGGL(clip_adam_kernel<float>, dim3(blocks), dim3(256), 0, s, p, (const float*)g, g, m, v, count,
+                     adam_consts(h), 1.0f, sumsq_part, nparts, stats_out, lf, shadow);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+int launch_clip_adam_bf16(hipStream_t s, float* p, const uint16_t* g_bf16, float gscale, float* gout, float* m,
+                          float* v, int64_t count, const blh_adam_hyper& h, const double* sumsq_part,
+                          int nparts, float* stats_out, uint16_t* shadow) {
+  if (count % 4 != 0) return BLH_ERR_SHAPE;
+  if (h.step < 1) return BLH_ERR_INVALID_ARGUMENT;
+  const int blocks = (int)std::min<int64_t>(ceil_div(count / 4, 256), 2048);
+  hipLaunchKernelGGL(clip_adam_kernel<bf16_bits>, dim3(blocks), dim3(256), 0, s, p, g_bf16, gout, m, v, count,
+                     adam_consts(h), gscale, sumsq_part, nparts, stats_out,
+                     LossFinish{nullptr, 0, 1.0, nullptr}, shadow);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
@@ -1432,55 +1476,22 @@ int launch_step_state_advance(hipStream_t s, blh_step_state* st) {
 }
 
 __global__ __launch_bounds__(256) void clip_adam_dev_kernel(
-    float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+    float* __restrict__ p, float* g, float* __restrict__ m, float* __restrict__ v,
     int64_t count, const blh_step_state* __restrict__ st, const double* __restrict__ sumsq_part,
-    int nparts, float* stats_out, LossFinish lf) {
+    int nparts, float* stats_out, LossFinish lf, bf16_bits* __restrict__ shadow) {
   __shared__ double sh[256];
-  finish_loss(lf, sh);
-  double a = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += 256) a += sumsq_part[i];
-  sh[threadIdx.x] = a;
-  __syncthreads();
-  for (int o = 128; o >= 1; o >>= 1) {
-    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-    __syncthreads();
-  }
-  const float total_norm = (float)sqrt(sh[0]);
-  const float max_norm = (float)st->max_norm;
-  float coef = 1.0f;
-  if (max_norm > 0.f) coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);
-  if (stats_out && blockIdx.x == 0 && threadIdx.x == 0) {
-    stats_out[0] = total_norm;
-    stats_out[1] = coef;
-  }
-  const float one_minus_b1 = (float)(1.0 - st->beta1), b2 = (float)st->beta2,
-              one_minus_b2 = (float)(1.0 - st->beta2), step_size = st->step_size,
-              bc2_sqrt = st->bc2_sqrt, eps = (float)st->eps;
-  const int64_t n4 = count >> 2;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    float4 gv = ld4(g + i * 4), mv = ld4(m + i * 4), vv = ld4(v + i * 4), pv = ld4(p + i * 4);
-    float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x; float* pp = &pv.x;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float gg = gp[k] * coef;
-      gp[k] = gg;
-      mp[k] = mp[k] + (gg - mp[k]) * one_minus_b1;
-      vp[k] = vp[k] * b2 + (one_minus_b2 * gg) * gg;
-      const float denom = sqrtf(vp[k]) / bc2_sqrt + eps;
-      pp[k] = pp[k] - step_size * (mp[k] / denom);
-    }
-    st4(g + i * 4, gv); st4(m + i * 4, mv); st4(v + i * 4, vv); st4(p + i * 4, pv);
-  }
+  const AdamConsts c{(float)(1.0 - st->beta1), (float)st->beta2, (float)(1.0 - st->beta2), st->step_size,
+                     st->bc2_sqrt, (float)st->eps, (float)st->max_norm};
+  clip_adam_body<float>(p, g, g, m, v, count, c, 1.0f, sumsq_part, nparts, stats_out, lf, shadow, sh);
 }
 
 int launch_clip_adam_dev(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count,
                          const blh_step_state* st, const double* sumsq_part, int nparts,
-                         float* stats_out, LossFinish lf) {
+                         float* stats_out, LossFinish lf, uint16_t* shadow) {
   if (count % 4 != 0) return BLH_ERR_SHAPE;
   const int blocks = (int)std::min<int64_t>(ceil_div(count / 4, 256), 2048);
   hipLaunchKernelGGL(clip_adam_dev_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, count, st,
-                     sumsq_part, nparts, stats_out, lf);
+                     sumsq_part, nparts, stats_out, lf, shadow);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }

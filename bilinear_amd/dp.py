@@ -111,20 +111,29 @@ class GradBucketReducer:
             work = dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._works.append((work, tensor))
 
-    def finish(self):
+    def finish(self, cast_back=True):
+        """Wait for every launched collective.  Compressed buckets: ``cast_back=True`` writes the
+        averaged bf16 values back into the fp32 arena; ``cast_back=False`` leaves them in
+        ``self._half`` for an optimiser that reads bf16 gradients (Engine.clip_adam_bf16) and
+        returns the factor still to be applied (1 / world when the backend summed)."""
         if self._pending is not None:
             self._launch(*self._pending)
             self._pending = None
+        scale = 1.0
         for work, view in self._works:
             work.wait()
-            if isinstance(view, tuple):            # compressed bucket: back to the fp32 arena
+            if isinstance(view, tuple):            # compressed bucket
                 _, lo, hi, divide = view
-                self._cast(self.flat[lo:hi], self._half[lo:hi], to_half=False)
-                if divide:
-                    self.flat[lo:hi].div_(self.world)
+                if cast_back:
+                    self._cast(self.flat[lo:hi], self._half[lo:hi], to_half=False)
+                    if divide:
+                        self.flat[lo:hi].div_(self.world)
+                elif divide:
+                    scale = 1.0 / self.world
             elif view is not None:
                 view.div_(self.world)
         self._works = []
+        return scale
 
     @staticmethod
     def _cast(full, half, to_half):
@@ -199,20 +208,29 @@ class DataParallel:
         eng.row_offset = self.rank * batch
         sync = self._all_reduce_sum if (self.sync_bn and (self.world > 1 or self.force_collectives)) else None
         gb = batch * self.world
-        pred = eng.forward_train(x, sync=sync, global_batch=gb)
-        loss, dpred = eng.mse_loss_grad(pred, target)
+        # forward + MSE as the fused single-GPU step runs them (one enqueue; the loss gradient stays
+        # in the workspace for backward)
+        pred, loss = eng.forward_train_loss(x, target, sync=sync, global_batch=gb)
         self._reducer.begin()
-        eng.backward(x, dpred, on_ready=self._reducer.on_ready, sync=sync, global_batch=gb)
-        # the reported loss is the GLOBAL batch's: mean of the per-rank means (equal shards), the
-        # 1-float all-reduce rides behind the last gradient bucket (the reference
-        # logs the loss of the whole batch, train_bilinear.py:86-88)
+        eng.backward(x, None, on_ready=self._reducer.on_ready, sync=sync, global_batch=gb)
+        # bf16 buckets on a HIP device stay bf16: norm, clip and Adam read them directly
+        half_direct = self.compress == "bf16" and eng.grads.is_cuda and (self.world > 1 or self.force_collectives)
+        gscale = self._reducer.finish(cast_back=not half_direct)
+        # the reported loss is the GLOBAL batch's: mean of the per-rank means (equal shards; the
+        # reference logs the loss of the whole batch, train_bilinear.py:86-88).  Its 1-float
+        # all-reduce is launched behind the last gradient bucket and awaited AFTER clip + Adam, which
+        # do not need it: one small collective less on the critical path
         self._reducer.reduce_scalars(loss)
-        self._reducer.finish()
         opt._ensure_moments(eng)
         g = opt.param_groups[0]
         opt._t += 1
-        eng.clip_adam(opt._exp_avg, opt._exp_avg_sq, float(g["lr"]), g["betas"], g["eps"],
-                      self.max_norm, opt._t, opt._stats)
+        if half_direct:
+            eng.clip_adam_bf16(self._reducer._half, gscale, opt._exp_avg, opt._exp_avg_sq, float(g["lr"]),
+                               g["betas"], g["eps"], self.max_norm, opt._t, opt._stats)
+        else:
+            eng.clip_adam(opt._exp_avg, opt._exp_avg_sq, float(g["lr"]), g["betas"], g["eps"],
+                          self.max_norm, opt._t, opt._stats)
+        self._reducer.finish()
         opt._sync_step_state(eng)
         return pred, loss
 
@@ -289,12 +307,11 @@ class CapturedDataParallelStep:
             eng.row_offset = dp.rank * self.batch
             saved_step = eng.rng_step
             eng.rng_step = 0                        # the device counter supplies the step
-            pred = eng.forward_train(self.x)
-            loss, dpred = eng.mse_loss_grad(pred, self.t)
+            pred, loss = eng.forward_train_loss(self.x, self.t)
             dp._reducer.begin()
-            eng.backward(self.x, dpred, on_ready=dp._reducer.on_ready)
-            dp._reducer.reduce_scalars(loss)
+            eng.backward(self.x, None, on_ready=dp._reducer.on_ready)
             dp._reducer.finish()
+            dp._reducer.reduce_scalars(loss)
             eng.rng_step = saved_step
         finally:
             N.check(lib.blh_context_set_step_state(eng.ctx.handle, None), "blh_context_set_step_state")
@@ -303,6 +320,7 @@ class CapturedDataParallelStep:
             eng._stream(), N.ptr(eng.params), N.ptr(eng.grads), N.ptr(opt._exp_avg), N.ptr(opt._exp_avg_sq),
             eng.layout.total, N.ptr(self.state), N.ptr(sc), sc.numel(), N.ptr(opt._stats)),
             "blh_clip_adam_step_captured")
+        dp._reducer.finish()                        # (the loss all-reduce: behind clip + Adam)
         return pred, loss
 
     @torch.no_grad()

@@ -85,6 +85,7 @@ class Engine:
         self.grad_ready_hook = None    # callable(offset, count): data-parallel bucket hook
         self.ctx = None                # N.Context on self.device (side stream, events, options)
         self.generation = 0            # counts train-mode forwards (guards backward, see _LifterFunction)
+        self.shadow_epoch = 0          # counts invalidations of the persistent bf16 weight image
 
     # ---------------------------------------------------------------- arenas --
     def _named_params(self):
@@ -145,11 +146,12 @@ class Engine:
             old = self.ctx
             self.ctx = N.Context(device)
             if old is not None:    # keep the options across a device move
-                for opt in (N.OPT_TWO_STREAM, N.OPT_DEFER_SLABS, N.OPT_LATE_FORK):
+                for opt in (N.OPT_TWO_STREAM, N.OPT_DEFER_SLABS, N.OPT_LATE_FORK, N.OPT_PERSISTENT_SHADOW):
                     self.ctx.set_option(opt, old.get_option(opt))
         self.device = device
         self._workspace = None
         self._saved_batch = None
+        self.invalidate_shadow()
 
     def ensure(self, device):
         _require_hip(device)
@@ -269,6 +271,47 @@ class Engine:
             self.rng_step += 1
         return pred
 
+    def forward_train_loss(self, x, target, sync=None, global_batch=None):
+        """Train-mode forward + nn.MSELoss (train_bilinear.py:76,78) in one enqueue, as the fused
+        step runs them: returns (pred, loss); the loss gradient stays in the workspace and the
+        next ``backward(x, None, ...)`` picks it up (blh_forward_train_loss)."""
+        x = self._check_input(x)
+        self.ensure(x.device)
+        batch = x.shape[0]
+        if batch < 2:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s"
+                             % (tuple(x.shape),))
+        target = target.contiguous()
+        if tuple(target.shape) != (batch, OUT_FEATURES) or target.dtype != torch.float32:
+            raise RuntimeError("bad target: %s %s" % (tuple(target.shape), target.dtype))
+        ws = self.workspace(batch)
+        drop = self._drop_struct(batch)
+        pred = torch.empty(batch, OUT_FEATURES, dtype=torch.float32, device=x.device)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        lib = N.lib()
+        if sync is None:
+            N.check(lib.blh_forward_train_loss(
+                self.ctx.handle, ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params),
+                N.ptr(self.bn_running), N.ptr(self.bn_nbt), N.ptr(x), N.ptr(target), ctypes.byref(drop),
+                self._momentum(), N.ptr(ws), ws.numel(), N.ptr(pred), N.ptr(loss), batch),
+                "blh_forward_train_loss")
+        else:
+            errors = []
+            cb = self._sync_callback(ws, sync, errors)
+            N.check(lib.blh_forward_train_loss_sync(
+                self.ctx.handle, ctypes.byref(self.layout.desc), self._stream(), N.ptr(self.params),
+                N.ptr(self.bn_running), N.ptr(self.bn_nbt), N.ptr(x), N.ptr(target), ctypes.byref(drop),
+                self._momentum(), N.ptr(ws), ws.numel(), N.ptr(pred), N.ptr(loss), batch,
+                int(global_batch), cb, None), "blh_forward_train_loss_sync")
+            if errors:
+                raise errors[0]
+        self._saved_batch = batch
+        self._saved_drop = drop
+        self.generation += 1
+        if self.masks is None:
+            self.rng_step += 1
+        return pred, loss
+
     def forward_eval(self, x):
         x = self._check_input(x)
         self.ensure(x.device)
@@ -276,6 +319,36 @@ class Engine:
         ws = self.workspace(batch)
         self._saved_batch = None       # eval overwrites the saved activations
         return torch.ops.bilinear_hip.eval_fwd(x, self.params, self.bn_running, ws, *self._op_args())
+
+    def set_persistent_shadow(self, enabled):
+        """gemm_dtype "bf16s" only (BLH_OPT_PERSISTENT_SHADOW; default off): the fused train step's
+        Adam kernel also writes the bf16 image of the updated weights and the next fused step skips
+        re-casting the whole fp32 arena.  CONTRACT: between two ``train_step`` calls the parameters
+        are written by nothing else — checkpoint loads, ``.apply(init)``, ``optimizer.step()`` and
+        moving the module are handled here (they drop the image); code that edits parameter
+        storage behind PyTorch's back (``p.data.mul_()``, raw pointers) must call
+        ``invalidate_shadow()``."""
+        if self.ctx is None:
+            raise RuntimeError("the engine is not on a device yet")
+        self.ctx.set_option(N.OPT_PERSISTENT_SHADOW, 1 if enabled else 0)
+
+    def invalidate_shadow(self):
+        """Drop the bf16 weight image kept under ``set_persistent_shadow``: the next fused step
+        re-casts the arena."""
+        self.shadow_epoch = getattr(self, "shadow_epoch", 0) + 1   # (captured steps compare it)
+        if self.ctx is not None:
+            self.ctx.set_option(N.OPT_PERSISTENT_SHADOW, self.ctx.get_option(N.OPT_PERSISTENT_SHADOW))
+
+    def clip_adam_bf16(self, grads_bf16, grad_scale, exp_avg, exp_avg_sq, lr, betas, eps, max_norm, step,
+                       stats=None):
+        """clip + Adam reading the gradient from the bf16 buckets of the compressed data-parallel
+        exchange (times ``grad_scale``); the fp32 gradient arena receives the clipped values."""
+        hyper = N.AdamHyper(lr, betas[0], betas[1], eps, 0.0 if max_norm is None else max_norm, step, 0)
+        sc = self.scratch()
+        N.check(N.lib().blh_clip_adam_step_bf16(
+            self._stream(), N.ptr(self.params), N.ptr(grads_bf16), float(grad_scale), N.ptr(self.grads),
+            N.ptr(exp_avg), N.ptr(exp_avg_sq), self.layout.total, ctypes.byref(hyper), N.ptr(sc),
+            sc.numel(), N.ptr(stats)), "blh_clip_adam_step_bf16")
 
     def set_two_stream(self, enabled):
         """A/B switch of the two-stream backward (bit-identical results either way)."""
@@ -297,9 +370,10 @@ class Engine:
         if self._saved_batch != batch:
             raise RuntimeError("backward called without a matching train-mode forward "
                                "(the workspace holds the activations of the last forward only)")
-        dpred = dpred.contiguous()
-        if tuple(dpred.shape) != (batch, OUT_FEATURES) or dpred.dtype != torch.float32:
-            raise RuntimeError("bad output gradient: %s %s" % (tuple(dpred.shape), dpred.dtype))
+        if dpred is not None:      # (None: the loss gradient forward_train_loss left in the workspace)
+            dpred = dpred.contiguous()
+            if tuple(dpred.shape) != (batch, OUT_FEATURES) or dpred.dtype != torch.float32:
+                raise RuntimeError("bad output gradient: %s %s" % (tuple(dpred.shape), dpred.dtype))
         ws = self.workspace(batch)
         errors = []
         if on_ready is not None:
@@ -325,7 +399,7 @@ class Engine:
         else:
             cb = ctypes.cast(None, N.GradReadyFn)
         self._grad_ready_cb = cb       # keep alive during the call
-        if sync is None and on_ready is None:
+        if sync is None and on_ready is None and dpred is not None:
             d = self._saved_drop
             torch.ops.bilinear_hip.backward(
                 x, dpred, self.params, ws, self.grads, self.masks if d.keep_mask else None,
@@ -363,6 +437,7 @@ class Engine:
     def clip_adam(self, exp_avg, exp_avg_sq, lr, betas, eps, max_norm, step, stats=None):
         hyper = N.AdamHyper(lr, betas[0], betas[1], eps, 0.0 if max_norm is None else max_norm, step, 0)
         sc = self.scratch()
+        self.invalidate_shadow()
         N.check(N.lib().blh_clip_adam_step(
             self._stream(), N.ptr(self.params), N.ptr(self.grads), N.ptr(exp_avg),
             N.ptr(exp_avg_sq), self.layout.total, ctypes.byref(hyper), N.ptr(sc), sc.numel(),

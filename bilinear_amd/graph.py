@@ -28,7 +28,8 @@ class CapturedTrainStep:
     lr-decay hook keeps working); ``opt`` state (exp_avg, exp_avg_sq, step) stays in sync.
     """
 
-    def __init__(self, module, optimizer, batch, max_norm=1.0, device=None, two_stream=False):
+    def __init__(self, module, optimizer, batch, max_norm=1.0, device=None, two_stream=False,
+                 persistent_shadow=False):
         """``two_stream=False`` (default): the graph is captured in the single-stream kernel order.
         Measured on MI355X (profiles/r02_step_timeline.md): hipGraph replay spreads the forked
         weight-gradient branch over up to four hardware queues and every cross-queue edge costs
@@ -41,6 +42,12 @@ class CapturedTrainStep:
         dev = torch.device(device) if device is not None else next(module.parameters()).device
         eng.ensure(dev)
         optimizer._ensure_moments(eng)
+        # gemm_dtype "bf16s": Adam writes the bf16 weight image, the graph holds no arena re-cast
+        # (Engine.set_persistent_shadow; the image is refreshed here whenever the host-side mirror
+        # shows that something else moved the training state)
+        self.persistent_shadow = bool(persistent_shadow) and eng.layout.desc.gemm_dtype == 4
+        if self.persistent_shadow:
+            eng.set_persistent_shadow(True)
         if eng.masks is not None:
             raise RuntimeError("explicit dropout masks cannot be captured; use the Philox stream")
         self.module, self.opt, self.eng, self.batch = module, optimizer, eng, int(batch)
@@ -77,6 +84,7 @@ class CapturedTrainStep:
                              eng.bn_running, eng.bn_nbt), snap):
             dst.copy_(src)
         self._write_state()
+        self._refresh_shadow()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._enqueue()
@@ -100,6 +108,14 @@ class CapturedTrainStep:
         ev.record()
         self._host_event[slot] = ev
         self._mirror = (float(g["lr"]), int(self.opt._t), int(self.eng.rng_step))
+
+    def _refresh_shadow(self):
+        self._shadow_epoch = self.eng.shadow_epoch
+        if self.persistent_shadow:
+            eng = self.eng
+            N.check(N.lib().blh_refresh_param_shadow(
+                eng.ctx.handle, ctypes.byref(eng.layout.desc), eng._stream(), N.ptr(eng.params),
+                N.ptr(self.ws), self.ws.numel(), self.batch), "blh_refresh_param_shadow")
 
     def _enqueue(self):
         eng, opt = self.eng, self.opt
@@ -130,6 +146,9 @@ class CapturedTrainStep:
         want = (float(self.opt.param_groups[0]["lr"]), int(self.opt._t), int(self.eng.rng_step))
         if want != self._mirror:
             self._write_state()
+            self._refresh_shadow()          # an out-of-band step moved the parameters too
+        elif self._shadow_epoch != self.eng.shadow_epoch:
+            self._refresh_shadow()          # a checkpoint load / re-initialisation wrote the parameters
         # (callers that fill ``self.x`` / ``self.t`` in place and pass them back pay no copy)
         if x.data_ptr() != self.x.data_ptr():
             self.x.copy_(x, non_blocking=True)

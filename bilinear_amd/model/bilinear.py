@@ -217,6 +217,26 @@ class BilinearUnit(nn.Module):
             return _LifterFunction.apply(in_tensor, eng, *params)
         return eng.forward_train(in_tensor)
 
+    # parameter writes that do not go through the fused step drop the bf16 weight image kept under
+    # Engine.set_persistent_shadow (a no-op otherwise)
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        if self._engine is not None:
+            self._engine.invalidate_shadow()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if self._engine is not None:
+            self._engine.invalidate_shadow()
+        return out
+
+    def apply(self, fn):
+        out = super().apply(fn)
+        if self._engine is not None:
+            self._engine.invalidate_shadow()
+        return out
+
     def reset_statistics(self):
         """model/bilinear.py:43-55: reset every BN's running stats and switch it to
         the cumulative moving average (momentum=None)."""

@@ -74,10 +74,19 @@ typedef enum {
                              0: single-stream order.  Results are bit-identical either way.  */
   BLH_OPT_DEFER_SLABS = 1, /* 1: sum all split-K weight-gradient slabs in one launch at the end
                               of backward (default 0: right after each GEMM)                 */
-  BLH_OPT_LATE_FORK = 2   /* 1 (default): a stage's weight-gradient GEMM starts behind its
+  BLH_OPT_LATE_FORK = 2,  /* 1 (default): a stage's weight-gradient GEMM starts behind its
                              data-gradient GEMM and runs beside the next stage's BatchNorm
                              backward; 0: it starts together with the data-gradient GEMM.
                              Scheduling only: results are bit-identical.                     */
+  BLH_OPT_PERSISTENT_SHADOW = 3
+                          /* gemm_dtype 4 only, default 0.  1: the Adam kernel of blh_train_step /
+                             blh_train_step_captured also writes the bf16 image of the updated
+                             parameters (fused Adam -> bf16 weight re-cast), and the NEXT
+                             fused step on the same context, parameter arena and workspace skips
+                             its own re-cast of the arena.  The caller promises that nothing else
+                             writes `params` between two such steps; setting the option (to any
+                             value) or calling any other forward entry point discards the image.
+                             Results are bit-identical (the same rounding of the same values).  */
 } blh_option;
 int blh_context_set_option(blh_context* ctx, int32_t option, int32_t value);
 int blh_context_get_option(const blh_context* ctx, int32_t option);
@@ -226,6 +235,19 @@ int blh_backward(blh_context* ctx, const blh_model_desc* d, void* stream, const 
                  const float* dpred, float* grads, int64_t batch, blh_grad_ready_fn on_ready,
                  void* user);
 
+/* Forward (train mode) + nn.MSELoss (train_bilinear.py:76,78) as one enqueue — what the fused
+ * blh_train_step runs, for callers that put their own work between forward and backward (the
+ * data-parallel step launches RCCL all-reduces from blh_backward's hook).  As blh_forward_train,
+ * plus: loss_out (device scalar) = mean((pred - target)^2) over this call's rows, and the
+ * gradient of that loss with respect to the prediction is left in `workspace`: a following
+ * blh_backward / blh_backward_sync on the same context, workspace and batch with dpred == NULL
+ * uses it (and takes the decode-bias partial sums the fused decode kernel produced).        */
+int blh_forward_train_loss(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params,
+                           float* bn_running, int64_t* bn_num_batches_tracked, const float* x,
+                           const float* target, const blh_dropout* drop, float momentum,
+                           void* workspace, int64_t workspace_bytes, float* pred, float* loss_out,
+                           int64_t batch);
+
 /* ---- SyncBN variants (data parallel with statistics over the GLOBAL batch) -------------
  * Same as blh_forward_train / blh_backward, except that every BatchNorm's statistics are
  * exchanged across ranks: `sync` is called on the host, once per stage, right after the
@@ -240,6 +262,11 @@ int blh_forward_train_sync(blh_context* ctx, const blh_model_desc* d, void* stre
                            const blh_dropout* drop, float momentum, void* workspace,
                            int64_t workspace_bytes, float* pred, int64_t batch,
                            int64_t global_batch, blh_sync_fn sync, void* user);
+int blh_forward_train_loss_sync(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params,
+                                float* bn_running, int64_t* bn_num_batches_tracked, const float* x,
+                                const float* target, const blh_dropout* drop, float momentum,
+                                void* workspace, int64_t workspace_bytes, float* pred, float* loss_out,
+                                int64_t batch, int64_t global_batch, blh_sync_fn sync, void* user);
 int blh_backward_sync(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params, const float* x,
                       const blh_dropout* drop, void* workspace, int64_t workspace_bytes,
                       const float* dpred, float* grads, int64_t batch, blh_grad_ready_fn on_ready,
@@ -269,6 +296,13 @@ int blh_clip_grad_norm(void* stream, float* grads, int64_t count, float max_norm
 int blh_clip_adam_step(void* stream, float* params, float* grads, float* exp_avg,
                        float* exp_avg_sq, int64_t count, const blh_adam_hyper* hyper,
                        void* workspace, int64_t workspace_bytes, float* stats_out);
+/* The same with the gradient given as bf16 (the compressed buckets of the data-parallel exchange,
+ * averaged on the wire in bf16) times grad_scale: norm, clip and Adam read the bf16 values
+ * directly (no cast back to the fp32 arena); `grads` (fp32 arena) receives the clipped gradient. */
+int blh_clip_adam_step_bf16(void* stream, float* params, const uint16_t* grads_bf16, float grad_scale,
+                            float* grads, float* exp_avg, float* exp_avg_sq, int64_t count,
+                            const blh_adam_hyper* hyper, void* workspace, int64_t workspace_bytes,
+                            float* stats_out);
 
 /* ---- whole training step (single GPU) --------------------------------------------
  * The step body of train_bilinear.py:75-83 as one enqueue: forward_train, MSE,
@@ -290,6 +324,12 @@ int blh_train_step_captured(blh_context* ctx, const blh_model_desc* d, void* str
                             const blh_dropout* drop, float momentum, blh_step_state* dev_state,
                             void* workspace, int64_t workspace_bytes, float* pred,
                             float* loss_out, float* stats_out, int64_t batch);
+
+/* gemm_dtype 4: re-cast the fp32 parameter arena into the workspace's bf16 image now.  Needed only
+ * with BLH_OPT_PERSISTENT_SHADOW: before the first replay of a captured step, and after anything
+ * but a fused step wrote `params`.                                                            */
+int blh_refresh_param_shadow(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params,
+                             void* workspace, int64_t workspace_bytes, int64_t batch);
 
 /* Pieces of the captured step for callers that interleave their own work (the data-parallel
  * step puts the RCCL all-reduces between backward and the optimiser):

@@ -317,3 +317,46 @@ def test_bf16s_backward_schedules_are_bit_identical():
         for a, b, what in zip(out[(True, 1)], out[other], ("pred", "params", "exp_avg_sq", "grads", "pred3")):
             assert torch.equal(a, b), (other, what)
     assert torch.isfinite(out[(True, 1)][3]).all()
+
+
+def test_persistent_shadow_is_bit_identical_and_invalidated_by_parameter_writes():
+    """BLH_OPT_PERSISTENT_SHADOW (fused Adam -> bf16 weight image): the same steps with
+    and without it are bit-identical — through plain fused steps, a load_state_dict between two
+    steps (the module drops the image), an unfused optimizer.step, and a captured graph that
+    holds no arena re-cast."""
+    import bilinear_amd
+    dev = _dev()
+    x, t = (torch.randn(2048, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(3)),
+            torch.randn(2048, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(4)))
+
+    def run(persistent, captured=False):
+        torch.manual_seed(0)
+        net, opt, _, _ = bilinear_amd.load(dev, num_blocks=1, width=1024, gemm_dtype="bf16s")
+        net.train()
+        net.engine.ensure(dev)
+        net.engine.seed = 5
+        step = None
+        if captured:
+            step = bilinear_amd.CapturedTrainStep(net, opt, 2048, persistent_shadow=persistent)
+        elif persistent:
+            net.engine.set_persistent_shadow(True)
+        losses = []
+        for i in range(6):
+            if i == 2:          # a checkpoint load between two steps: scaled weights
+                sd = {k: (v * 0.5 if v.dtype.is_floating_point and k.endswith("0.weight") else v)
+                      for k, v in net.state_dict().items()}
+                net.load_state_dict(sd)
+            if i == 4 and not captured:      # the drop-in path in between: forward, backward, optimizer.step
+                opt.zero_grad()
+                torch.nn.functional.mse_loss(net(x), t).backward()
+                opt.step()
+            pred, loss = step(x, t) if captured else net.train_step(opt, x, t, max_norm=1.0)
+            losses.append(loss.item())
+        torch.cuda.synchronize()
+        return losses, net.engine.params.clone(), pred.clone()
+
+    for captured in (False, True):
+        a = run(False, captured)
+        b = run(True, captured)
+        assert a[0] == b[0], (captured, a[0], b[0])
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), captured

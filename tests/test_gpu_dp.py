@@ -180,6 +180,70 @@ def test_sync_bn_two_ranks_equal_single_device_on_full_batch(tmp_path):
         assert err <= tol, (name, err)
 
 
+# SyncBN in bf16 storage (BASELINE configs[3], [4]: bf16, data parallel): two
+# ranks with statistics over the global batch against the single-device step on the
+# concatenated batch.  One step (so that no Adam-amplified rounding noise enters); the GEMMs
+# are row-independent, so what differs is the merge order of the statistics (fp64 sums across
+# ranks against the per-tile merge) and, through it, a few bf16 rounding flips: bf16-level
+# tolerances.  Without the exchange the per-rank statistics (96 of 192 rows) put the
+# predictions ~10 % apart.
+CFG_SYNC_H = (2, 256, 96, "bf16s")
+
+
+def _worker_sync_h(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bilinear_amd.dp import DataParallel
+        dev = torch.device("cuda:0")
+        cfg = CFG_SYNC_H
+        net, opt = _make(dev, cfg)
+        x, t = _data(dev, cfg)
+        dp = DataParallel(net, opt, bucket_floats=50000, sync_bn=True)
+        sl = slice(rank * cfg[2], (rank + 1) * cfg[2])
+        pred, loss = dp.train_step(x[sl], t[sl])
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, "hgrads%d.npy" % rank), net.engine.grads.cpu().numpy())
+        np.save(os.path.join(out_dir, "hbn%d.npy" % rank), net.engine.bn_running.cpu().numpy())
+        np.save(os.path.join(out_dir, "hpred%d.npy" % rank), pred.cpu().numpy())
+        np.save(os.path.join(out_dir, "hloss%d.npy" % rank), np.array([float(loss.item())]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_bn_bf16s_two_ranks_equal_single_device_on_full_batch(tmp_path):
+    from golden_util import is_prebn_bias
+    port = _free_port()
+    mp.spawn(_worker_sync_h, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = np.load(tmp_path / "hgrads0.npy"), np.load(tmp_path / "hgrads1.npy")
+    assert np.array_equal(g0, g1), "averaged gradients differ between the replicas"
+    assert np.array_equal(np.load(tmp_path / "hbn0.npy"), np.load(tmp_path / "hbn1.npy"))
+
+    dev = torch.device("cuda:0")
+    net, opt = _make(dev, CFG_SYNC_H)
+    x, t = _data(dev, CFG_SYNC_H)
+    pred, loss = net.train_step(opt, x, t, max_norm=1.0)          # one device, the whole batch
+    torch.cuda.synchronize()
+    ref = pred.cpu().numpy().astype(np.float64)
+    both = np.concatenate([np.load(tmp_path / "hpred0.npy"), np.load(tmp_path / "hpred1.npy")]).astype(np.float64)
+    rel = np.linalg.norm(both - ref) / np.linalg.norm(ref)
+    assert rel <= 5e-3, rel
+    assert abs(float(np.load(tmp_path / "hloss0.npy")[0]) - loss.item()) <= 2e-3 * loss.item()
+    rbn = net.engine.bn_running.cpu().numpy()
+    assert np.abs(np.load(tmp_path / "hbn0.npy") - rbn).max() <= 1e-4 * (1 + np.abs(rbn).max())
+    refg = net.engine.grads.cpu().numpy().astype(np.float64)      # clipped, like the replicas'
+    worst = 0.0
+    for name, off, shape in net.engine.layout.entries:
+        if is_prebn_bias(name):
+            continue
+        n = int(np.prod(shape))
+        r = np.linalg.norm(g0[off:off + n] - refg[off:off + n]) / np.linalg.norm(refg[off:off + n])
+        worst = max(worst, r)
+        assert r <= 3e-2, (name, r)
+    print("SyncBN bf16s, 2 ranks vs 1 device: pred rel L2 %.2e, worst gradient rel L2 %.2e" % (rel, worst))
+
+
 # ----------------------------------------------------------------------------
 # RCCL itself (backend "nccl") on the one GPU of the box: world size 1 with the collectives
 # FORCED (DataParallel(force_collectives=True)), so that every call the N-GPU step makes —
