@@ -166,6 +166,8 @@ __device__ inline void gemm_epilogue_256(f32x4 (&acc)[2][2][4][2], const GemmPar
   // (quadrant row, wave row) pair: fp32 values, row pitch 260 floats (the two 16-lane groups of a
   // ds_write_b32 half-wave sit 4 rows = 16 banks apart), then every thread moves 16-byte pieces
   // of whole rows: a wave writes two full 512-byte (bf16) or 1024-byte (fp32) rows per instruction.
+  // (Measured and not kept: 128 rows per pass at pitch 256 — half the barriers, 2-way ds_write_b32
+  //  conflicts: 32.6 / 30.4 us against 31.6 / 28.8 us forward / dgrad at M = 16384, W = 1024.)
   constexpr int SP = 260;
   constexpr int VEC = OUT_BF16 ? 8 : 4;
   constexpr int CPR = 256 / VEC;
@@ -214,14 +216,18 @@ __device__ inline void gemm_epilogue_256(f32x4 (&acc)[2][2][4][2], const GemmPar
         }
       }
     }
-    __syncthreads();
+    if (ps < 3 || EPI == EPI_BIAS_STATS) __syncthreads();
   }
 
   if (EPI == EPI_BIAS_STATS) {
-    // per-tile column (mean, M2) over the tile's 256 rows, from the fp32 values (before rounding)
-    float* red = smem;                  // [2 wave rows][256 columns]
-    const int cnt = min(256, p.M - m0);
-    float mean[2][2];
+    // per-tile column (mean, M2) over the tile's 256 rows, from the fp32 values (before rounding).
+    // Each wave row (128 of the rows) forms its own (n, mean, M2) in registers + two shuffles; one
+    // LDS exchange merges the two with Chan's formula.
+    float* red = smem;                  // [2 wave rows][256 columns][mean, M2]
+    int nrow = 0;                       // valid rows of this wave row (wave-uniform)
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm) nrow += max(0, min(64, p.M - (m0 + qm * 128 + wr * 64)));
+    const float inv_n = nrow > 0 ? 1.0f / (float)nrow : 0.f;
 #pragma unroll
     for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
@@ -238,22 +244,8 @@ __device__ inline void gemm_epilogue_256(f32x4 (&acc)[2][2][4][2], const GemmPar
             }
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
-        if (g == 0) red[wr * 256 + qn * 128 + wc * 32 + j * 16 + c16] = s;
-      }
-    lds_barrier();
-#pragma unroll
-    for (int qn = 0; qn < 2; ++qn)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int lc = qn * 128 + wc * 32 + j * 16 + c16;
-        mean[qn][j] = (red[lc] + red[256 + lc]) / (float)cnt;
-      }
-    lds_barrier();
-#pragma unroll
-    for (int qn = 0; qn < 2; ++qn)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float s = 0.f;
+        const float mean = s * inv_n;
+        float q = 0.f;
 #pragma unroll
         for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
@@ -261,22 +253,36 @@ __device__ inline void gemm_epilogue_256(f32x4 (&acc)[2][2][4][2], const GemmPar
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int row = m0 + qm * 128 + wr * 64 + i * 16 + 4 * g + r;
-              const float dlt = acc[qm][qn][i][j][r] - mean[qn][j];
-              if (row < p.M) s += dlt * dlt;
+              const float dlt = acc[qm][qn][i][j][r] - mean;
+              if (row < p.M) q += dlt * dlt;
             }
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        if (g == 0) red[wr * 256 + qn * 128 + wc * 32 + j * 16 + c16] = s;
+        q += __shfl_xor(q, 16);
+        q += __shfl_xor(q, 32);
+        if (g == 0) {
+          const int lc = qn * 128 + wc * 32 + j * 16 + c16;
+          red[(wr * 256 + lc) * 2 + 0] = mean;
+          red[(wr * 256 + lc) * 2 + 1] = q;
+        }
       }
     lds_barrier();
     if (wr == 0 && g == 0) {
+      const int n0r = nrow;             // this wave row's count; the other one's:
+      int n1r = 0;
+#pragma unroll
+      for (int qm = 0; qm < 2; ++qm) n1r += max(0, min(64, p.M - (m0 + qm * 128 + 64)));
 #pragma unroll
       for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int lc = qn * 128 + wc * 32 + j * 16 + c16;
-          p.stat_part[((int64_t)tile_m * 2 + 0) * p.N + n0 + lc] = mean[qn][j];
-          p.stat_part[((int64_t)tile_m * 2 + 1) * p.N + n0 + lc] = red[lc] + red[256 + lc];
+          const float ma = red[lc * 2], qa = red[lc * 2 + 1];
+          const float mb = red[(256 + lc) * 2], qb = red[(256 + lc) * 2 + 1];
+          const float na = (float)n0r, nb = (float)n1r, nt = na + nb;
+          const float d = mb - ma;
+          const float mean = ma + d * (nb / nt);
+          const float m2 = qa + qb + d * d * (na * nb / nt);
+          p.stat_part[((int64_t)tile_m * 2 + 0) * p.N + n0 + lc] = mean;
+          p.stat_part[((int64_t)tile_m * 2 + 1) * p.N + n0 + lc] = m2;
         }
     }
   }

@@ -50,15 +50,30 @@ def main():
     slabs = torch.empty(splits, W, W, device=dev)
     Ah, Wh = A.to(torch.bfloat16), Wt.to(torch.bfloat16)
     Zh = torch.empty(B, W, dtype=torch.bfloat16, device=dev)
+    Gh = torch.randn(B, W, device=dev).to(torch.bfloat16)
+    # weight gradient in bf16 storage: the batch slabs api_layout.h (wgrad_plan_h) picks
+    t256 = (W // 256) * (W // 256)
+    if t256 >= 64 and B % (max(1, 256 // t256) * 128) == 0:
+        hsplits = max(1, 256 // t256)
+    else:
+        hsplits = max(1, min((256 * 128 * 128) // (W * W), B // 128))
+    hslabs = torch.empty(hsplits, W, W, device=dev)
+    only_h = len(sys.argv) > 3 and sys.argv[3] == "bf16s"
     for _ in range(12):
+        N.check(lib.blh_gemm_bf16s(st, Ah.data_ptr(), W, 0, Wh.data_ptr(), W, 0, Zh.data_ptr(), W, 1, B, W, W, 1,
+                                   bias.data_ptr(), None, 0, stat.data_ptr()), "bf16s fwd")
+        N.check(lib.blh_gemm_bf16s(st, Gh.data_ptr(), W, 0, Wh.data_ptr(), W, 1, Zh.data_ptr(), W, 1, B, W, W, 1,
+                                   None, None, 0, None), "bf16s dgrad")
+        N.check(lib.blh_gemm_bf16s(st, Gh.data_ptr(), W, 1, Ah.data_ptr(), W, 1, hslabs.data_ptr(), W, 0, W, W, B,
+                                   hsplits, None, None, 0, None), "bf16s wgrad")
+        if only_h:
+            continue
         N.check(lib.blh_linear_fwd_stats(st, A.data_ptr(), Wt.data_ptr(), bias.data_ptr(), Z.data_ptr(),
                                          stat.data_ptr(), B, W, W), "fwd")
         N.check(lib.blh_gemm_f32(st, A.data_ptr(), W, 0, Wt.data_ptr(), W, 1, Z.data_ptr(), W, B, W, W, 1,
                                  None, None, 0), "dgrad")
         N.check(lib.blh_gemm_f32(st, A.data_ptr(), W, 1, Z.data_ptr(), W, 1, slabs.data_ptr(), W, W, W, B,
                                  splits, None, None, 0), "wgrad")
-        N.check(lib.blh_gemm_bf16s(st, Ah.data_ptr(), W, 0, Wh.data_ptr(), W, 0, Zh.data_ptr(), W, 1, B, W, W, 1,
-                                   bias.data_ptr(), None, 0, stat.data_ptr()), "bf16s fwd")
     torch.cuda.synchronize()
 
 
