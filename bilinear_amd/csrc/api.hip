@@ -461,7 +461,8 @@ static int bn_h_gen() {
 static int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
                      float* bn_running, int64_t* nbt, const float* x, const blh_dropout* drop,
                      float momentum, const WorkspaceH& ws, float* pred, int64_t batch, bool train,
-                     bool shadow_valid = false) {
+                     bool shadow_valid = false, const float* target = nullptr, float mse_scale = 0.f,
+                     int* loss_nparts = nullptr) {
   const ArenaLayout L = make_layout(d);
   const int nh = (int)L.heavy.size();
   const int W = d->width, OF = d->out_features, IF = d->in_features;
@@ -517,8 +518,20 @@ static int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, c
                                    rm, rv, skip, ws.A[i], nullptr, batch, W, none, nullptr));
     }
   }
-  // decode (model/bilinear.py:39): N = 48 is one (ragged) column tile of the same kernel
-  GemmParamsH g{};
+  // decode (model/bilinear.py:39) fused with nn.MSELoss (train_bilinear.py:78) when a target is given:
+  // skinny.hip's purpose-built kernel reads A once and writes pred, dpred (fp32 and bf16), the loss
+  // partials and the decode-bias partials; *loss_nparts = their row count (0: the generic path ran)
+  if (loss_nparts) *loss_nparts = 0;
+  if (decode_fwd_supported(batch, W, OF)) {
+    int np = 0;
+    BLH_TRY(launch_decode_fwd_mse_h(s, ws.A[nh - 1], ws.wsh + L.dec_w, params + L.dec_b, target, pred,
+                                    target ? ws.dpred : nullptr, target ? ws.dpredh : nullptr,
+                                    target ? ws.loss_part : nullptr, target ? ws.dec_bias_part : nullptr,
+                                    batch, W, OF, mse_scale, &np));
+    if (loss_nparts && target) *loss_nparts = np;
+    return BLH_OK;
+  }
+  GemmParamsH g{};   // (shapes the skinny kernel does not take: N = 48 as one ragged column tile)
   g.A = ws.A[nh - 1]; g.lda = W;
   g.B = ws.wsh + L.dec_w; g.ldb = W;
   g.C = pred; g.ldc = OF;
@@ -543,9 +556,12 @@ static int wgrad_h(hipStream_t s, const uint16_t* dZ, int64_t ld_dz, int M, cons
   return launch_sum_slabs(s, slabs, (int64_t)M * N, sp.splits, out);
 }
 
+// dec_bias_S > 0: the forward ran the fused decode + MSE kernel: ws.dpredh and the decode-bias
+// partials (dec_bias_S rows of ws.dec_bias_part) are already there
 static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
                       const blh_dropout* drop, const WorkspaceH& ws, const float* dpred,
-                      float* grads, int64_t batch, blh_grad_ready_fn on_ready, void* user) {
+                      float* grads, int64_t batch, blh_grad_ready_fn on_ready, void* user,
+                      int dec_bias_S = 0) {
   const ArenaLayout L = make_layout(d);
   const int nh = (int)L.heavy.size();
   const int W = d->width, OF = d->out_features, IF = d->in_features;
@@ -578,7 +594,7 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
     return BLH_OK;
   };
   // decode: dA_last = dP W_d (carries the first fork), dW = dP^T A_last, db = colsum(dP)
-  BLH_TRY(launch_cast_f32_bf16(s, dpred, ws.dpredh, batch * OF));
+  if (dec_bias_S == 0) BLH_TRY(launch_cast_f32_bf16(s, dpred, ws.dpredh, batch * OF));
   {
     GemmParamsH g{};
     g.A = ws.dpredh; g.lda = OF;
@@ -591,7 +607,8 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
   }
   BLH_TRY(fork_wait(nh, true));
   BLH_TRY(wgrad_h(s2, ws.dpredh, OF, OF, ws.A[nh - 1], W, W, batch, ws.slabs, grads + L.dec_w));
-  BLH_TRY(launch_colsum(s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
+  if (dec_bias_S == 0) BLH_TRY(launch_colsum(s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
+  else if (on_ready) BLH_TRY(launch_colreduce(s, ws.dec_bias_part, dec_bias_S, OF, OF, grads + L.dec_b));
   BLH_TRY(ready(nh, L.dec_w, L.total - L.dec_w));
   for (int i = nh - 1; i >= 0; --i) {
     const HeavyOffsets& h = L.heavy[i];
@@ -661,7 +678,7 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
     if (nh > 32) return BLH_ERR_SHAPE;
     for (int i = 0; i < nh; ++i) offs[i] = L.heavy[i].b;
     BLH_TRY(launch_bias_colreduce(s, ws.dz_colsum_part, (int64_t)chunks * W, chunks, W, nh, offs, grads,
-                                  nullptr, 0, 0, 0));
+                                  dec_bias_S > 0 ? ws.dec_bias_part : nullptr, dec_bias_S, OF, L.dec_b));
   }
   if (two) {   // join: the side stream is in order, its last kernel is stage 0's slab sum
     BLH_HIP_TRY(hipEventRecord(ctx->ev_w[0], s2));
@@ -847,11 +864,14 @@ int blh_forward_train_loss(blh_context* ctx, const blh_model_desc* d, void* stre
   ctx->loss_batch = 0;
   if (d->gemm_dtype == 4) {
     const WorkspaceH wh = carve_h(d, batch, workspace);
-    BLH_TRY(forward_h(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, wh, pred, batch, true));
-    BLH_TRY(launch_mse(s, pred, target, batch * d->out_features, (float)(2.0 / denom), wh.dpred,
-                       wh.loss_part, &nparts));
+    int dec_S = 0;
+    BLH_TRY(forward_h(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, wh, pred, batch, true, false,
+                      target, (float)(2.0 / denom), &dec_S));
+    if (dec_S > 0) nparts = dec_S;
+    else BLH_TRY(launch_mse(s, pred, target, batch * d->out_features, (float)(2.0 / denom), wh.dpred,
+                            wh.loss_part, &nparts));
     BLH_TRY(launch_loss_finalize(s, wh.loss_part, nparts, denom, loss_out));
-    ctx->loss_batch = batch; ctx->loss_nparts = 0;
+    ctx->loss_batch = batch; ctx->loss_nparts = dec_S;
     return BLH_OK;
   }
   const Workspace ws = carve(d, batch, workspace);
@@ -906,7 +926,7 @@ int blh_backward(blh_context* ctx, const blh_model_desc* d, void* stream, const 
   if (d->gemm_dtype == 4) {
     const WorkspaceH wh = carve_h(d, batch, workspace);
     return backward_h(ctx, d, (hipStream_t)stream, params, drop, wh, from_loss ? wh.dpred : dpred, grads,
-                      batch, on_ready, user);
+                      batch, on_ready, user, from_loss ? loss_nparts : 0);
   }
   const Workspace ws = carve(d, batch, workspace);
   if (from_loss && loss_nparts > 0) {   // decode-bias partials of the fused decode kernel
@@ -986,10 +1006,13 @@ int blh_train_step(blh_context* ctx, const blh_model_desc* d, void* stream, floa
     int np = 0;
     const bool keep = ctx->persistent_shadow;
     const bool valid = keep && ctx->shadow_params == params && ctx->shadow_ws == workspace;
-    BLH_TRY(forward_h(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, wh, pred, batch, true, valid));
-    BLH_TRY(launch_mse(s, pred, target, batch * d->out_features, (float)(2.0 / denom), wh.dpred,
-                       wh.loss_part, &nparts));
-    BLH_TRY(backward_h(ctx, d, s, params, drop, wh, wh.dpred, grads, batch, nullptr, nullptr));
+    int dec_S = 0;
+    BLH_TRY(forward_h(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, wh, pred, batch, true, valid,
+                      target, (float)(2.0 / denom), &dec_S));
+    if (dec_S > 0) nparts = dec_S;
+    else BLH_TRY(launch_mse(s, pred, target, batch * d->out_features, (float)(2.0 / denom), wh.dpred,
+                            wh.loss_part, &nparts));
+    BLH_TRY(backward_h(ctx, d, s, params, drop, wh, wh.dpred, grads, batch, nullptr, nullptr, dec_S));
     BLH_TRY(launch_sumsq(s, grads, count, wh.sumsq_part, &np));
     BLH_TRY(launch_clip_adam(s, params, grads, exp_avg, exp_avg_sq, count, *hyper, wh.sumsq_part, np,
                              stats_out, LossFinish{wh.loss_part, nparts, denom, loss_out},
@@ -1227,10 +1250,13 @@ int blh_train_step_captured(blh_context* ctx, const blh_model_desc* d, void* str
     //  no arena re-cast — the caller refreshes the image before the first replay and after any
     //  out-of-band parameter change with blh_refresh_param_shadow)
     const bool keep = ctx->persistent_shadow;
-    BLH_TRY(forward_h(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, wh, pred, batch, true, keep));
-    BLH_TRY(launch_mse(s, pred, target, batch * d->out_features, (float)(2.0 / denom), wh.dpred,
-                       wh.loss_part, &nparts));
-    BLH_TRY(backward_h(ctx, d, s, params, drop, wh, wh.dpred, grads, batch, nullptr, nullptr));
+    int dec_S = 0;
+    BLH_TRY(forward_h(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, wh, pred, batch, true, keep,
+                      target, (float)(2.0 / denom), &dec_S));
+    if (dec_S > 0) nparts = dec_S;
+    else BLH_TRY(launch_mse(s, pred, target, batch * d->out_features, (float)(2.0 / denom), wh.dpred,
+                            wh.loss_part, &nparts));
+    BLH_TRY(backward_h(ctx, d, s, params, drop, wh, wh.dpred, grads, batch, nullptr, nullptr, dec_S));
     BLH_TRY(launch_sumsq(s, grads, count, wh.sumsq_part, &np));
     return launch_clip_adam_dev(s, params, grads, exp_avg, exp_avg_sq, count, dev_state,
                                 wh.sumsq_part, np, stats_out,

@@ -231,6 +231,7 @@ struct WorkspaceH {
   float* dpred; uint16_t* dpredh;   // [B][out] fp32 and its bf16 image
   float* loss_part; double* sumsq_part; float* colsum_part;
   double* sync_buf;                 // [2][W] fp64 (SyncBN exchange; its first 2W floats in backward)
+  float* dec_bias_part;             // [blocks][out] partial sums of dpred (fused decode + MSE kernel)
   int64_t bytes;
 };
 
@@ -240,8 +241,16 @@ struct WorkspaceH {
 // 4 equal slabs of whole 128-deep steps; smaller outputs would need 16 slabs to fill the chip with
 // such tiles (64 MB of fp32 slabs at W = 1024) and stay on the 128 x 128 kernel with about one
 // workgroup per CU, slabs of whole 128-deep K tiles.
+static int64_t wgrad256_min_tiles() {
+  static const int64_t v = [] {            // BLH_WGRAD256_MIN_TILES: developer tuning knob
+    const char* e = std::getenv("BLH_WGRAD256_MIN_TILES");
+    const int n = e ? std::atoi(e) : 0;
+    return (int64_t)((n >= 1 && n <= 4096) ? n : 64);
+  }();
+  return v;
+}
 static Splits wgrad_plan_h(int64_t M, int64_t N, int64_t batch) {
-  if (M % 256 == 0 && N % 256 == 0 && (M / 256) * (N / 256) >= 64) {
+  if (M % 256 == 0 && N % 256 == 0 && (M / 256) * (N / 256) >= wgrad256_min_tiles()) {
     int64_t s = std::max<int64_t>(1, 256 / ((M / 256) * (N / 256)));
     while (s > 1 && batch % (s * 128) != 0) s >>= 1;
     if (batch % (s * 128) == 0) return Splits{(int)s, (int)(batch / s)};
@@ -292,6 +301,7 @@ static WorkspaceH carve_h(const blh_model_desc* d, int64_t batch, void* base) {
   ws.sumsq_part = (double*)take(SUMSQ_MAX_PARTS * sizeof(double));
   ws.colsum_part = (float*)take(ceil_div(batch, 256) * d->out_features * sizeof(float));
   ws.sync_buf = (double*)take(2 * W * sizeof(double));
+  ws.dec_bias_part = (float*)take(1026 * d->out_features * sizeof(float));
   ws.bytes = off;
   return ws;
 }

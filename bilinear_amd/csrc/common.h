@@ -257,6 +257,11 @@ bool decode_fwd_supported(int64_t batch, int W, int OF);
 int launch_decode_fwd_mse(hipStream_t s, const float* A, const float* Wd, const float* bd,
                           const float* target, float* pred, float* dpred, float* loss_part,
                           float* dbias_part, int64_t batch, int W, int OF, float scale, int* nparts);
+// bf16 storage: A and the bf16 image of Wd; also writes dpred as bf16 (operand of the decode backward)
+int launch_decode_fwd_mse_h(hipStream_t s, const uint16_t* A, const uint16_t* Wd, const float* bd,
+                            const float* target, float* pred, float* dpred, uint16_t* dpred_h,
+                            float* loss_part, float* dbias_part, int64_t batch, int W, int OF, float scale,
+                            int* nparts);
 int launch_mpjpe(hipStream_t s, const float* pred, const float* target, const float* mean,
                  const float* stddev, int64_t batch, int joints, float* dist);
 int launch_segment_sum(hipStream_t s, const float* dist, const int32_t* ids, int64_t batch,

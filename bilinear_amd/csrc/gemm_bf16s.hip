@@ -79,7 +79,7 @@ int gemm_bf16s_pick_tile(int la, int lb, bool out_bf16, const GemmParamsH& p, in
   const int64_t wgs = ceil_div(p.M, 256) * (p.N / 256) * splits;
   // fewer workgroups: the 128 x 128 grid fills the 256 CUs better.  Weight gradients (both
   // operands KROW, fp32 slabs): only with at most 4 slabs (api_layout.h: wgrad_plan_h)
-  if (la == KROW && splits > 4) return 128;
+  if (la == KROW && splits > 4 && !getenv("BLH_WGRAD256_MIN_TILES")) return 128;
   return wgs >= 224 ? 256 : 128;
 }
 

@@ -146,6 +146,140 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void decode_fwd_mse_kernel(
   }
 }
 
+// ---- bf16 storage (gemm_dtype 4): the same kernel for bf16 A and the bf16 image of Wd ----------
+// A lane's 16 bytes (8 consecutive k of its row) are exactly one operand of
+// v_mfma_f32_16x16x32_bf16 (lane l: row l & 15, k = 8 (l >> 4) + j), for A and for Wd alike: the
+// reduction range of a wave (W / 8) is walked in k-steps of 32 straight from global memory.
+// Besides pred / dpred (fp32) it writes dpred as bf16, the operand of the decode backward GEMMs.
+typedef __bf16 dec_bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int RT>
+__global__ __launch_bounds__(64 * DEC_WAVES) void decode_fwd_mse_h_kernel(
+    const uint16_t* __restrict__ A, const uint16_t* __restrict__ Wd, const float* __restrict__ bd,
+    const float* __restrict__ target, float* __restrict__ pred, float* __restrict__ dpred,
+    uint16_t* __restrict__ dpred_h, float* __restrict__ loss_part, float* __restrict__ dbias_part,
+    int64_t batch, int W, int OF, float scale) {
+  constexpr int ROWS = 16 * RT, NT = 4;
+  __shared__ __attribute__((aligned(16))) float red[DEC_WAVES][ROWS][64];
+  __shared__ float colred[16][64];
+  __shared__ float lossred[DEC_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+  const int ntiles = (OF + 15) >> 4;
+  const int kq = W / DEC_WAVES;                     // reduction range of one wave (multiple of 32)
+  const int kbeg = wave * kq;
+
+  const uint16_t* arow[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+    arow[t] = A + min(row0 + t * 16 + r, batch - 1) * (int64_t)W + kbeg + 8 * q;   // clamped rows are never stored
+  const uint16_t* wrow[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wrow[t] = Wd + (int64_t)min(t * 16 + r, OF - 1) * W + kbeg + 8 * q;
+
+  f32x4_t acc[RT][NT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // two k-steps (64 k) per chunk, register double buffer
+  uint4 a[2][2][RT], b[2][2][NT];
+  auto load_chunk = [&](int buf, int k) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int kk = min(k + 32 * u, kq - 32);      // (kq % 64 == 32: the second k-step of the last chunk is unused)
+#pragma unroll
+      for (int i = 0; i < RT; ++i) a[buf][u][i] = *reinterpret_cast<const uint4*>(arow[i] + kk);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (t < ntiles) b[buf][u][t] = *reinterpret_cast<const uint4*>(wrow[t] + kk);
+    }
+  };
+  auto mfma_chunk = [&](int buf, int k) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (k + 32 * u < kq)
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            if (t < ntiles) {
+              union { uint4 u4; dec_bf16x8 v; } ua, ub;
+              ua.u4 = a[buf][u][i]; ub.u4 = b[buf][u][t];
+              acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[i][t], 0, 0, 0);
+            }
+  };
+  load_chunk(0, 0);
+  for (int k = 0; k < kq; k += 128) {
+    if (k + 64 < kq) load_chunk(1, k + 64);
+    mfma_chunk(0, k);
+    if (k + 64 < kq) {
+      if (k + 128 < kq) load_chunk(0, k + 128);
+      mfma_chunk(1, k + 64);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if (t < ntiles)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) red[wave][i * 16 + 4 * q + g][t * 16 + r] = acc[i][t][g];
+  __syncthreads();
+
+  const int cg = tid & 15, rr = (tid >> 4) & 15;
+  const int col = cg * 4;
+  float sq = 0.f;
+  float4 dsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < OF && tid < 256) {
+    const float4 bv = *reinterpret_cast<const float4*>(bd + col);
+#pragma unroll
+    for (int pass = 0; pass < RT; ++pass) {
+      const int lr = pass * 16 + rr;
+      const int64_t row = row0 + lr;
+      float4 v = bv;
+#pragma unroll
+      for (int w = 0; w < DEC_WAVES; ++w) {
+        const float4 u = *reinterpret_cast<const float4*>(&red[w][lr][col]);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      if (row < batch) {
+        *reinterpret_cast<float4*>(pred + row * OF + col) = v;
+        if (target) {
+          const float4 t = *reinterpret_cast<const float4*>(target + row * OF + col);
+          float4 d = make_float4(v.x - t.x, v.y - t.y, v.z - t.z, v.w - t.w);
+          sq += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+          d.x *= scale; d.y *= scale; d.z *= scale; d.w *= scale;
+          dsum.x += d.x; dsum.y += d.y; dsum.z += d.z; dsum.w += d.w;
+          *reinterpret_cast<float4*>(dpred + row * OF + col) = d;
+          typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+          const bf2 lo = {(__bf16)d.x, (__bf16)d.y}, hi = {(__bf16)d.z, (__bf16)d.w};
+          uint2 o;
+          o.x = *reinterpret_cast<const uint32_t*>(&lo);
+          o.y = *reinterpret_cast<const uint32_t*>(&hi);
+          *reinterpret_cast<uint2*>(dpred_h + row * OF + col) = o;
+        }
+      }
+    }
+  }
+  if (target) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
+    if (lane == 0) lossred[wave] = sq;
+    if (tid < 256) *reinterpret_cast<float4*>(&colred[rr][col]) = dsum;
+    __syncthreads();
+    if (tid == 0) loss_part[blockIdx.x] = (lossred[0] + lossred[1]) + (lossred[2] + lossred[3]);
+    if (dbias_part && tid < OF) {
+      float s = 0.f;
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) s += colred[k2][tid];
+      dbias_part[(int64_t)blockIdx.x * OF + tid] = s;
+    }
+  }
+}
+
 // rows per workgroup so that the block count (= number of loss / bias partials) stays <= 1024
 int decode_fwd_rows_per_block(int64_t batch) {
   int rt = 1;
@@ -173,6 +307,27 @@ int launch_decode_fwd_mse(hipStream_t s, const float* A, const float* Wd, const 
   else
     hipLaunchKernelGGL(decode_fwd_mse_kernel<4>, dim3(blocks), dim3(64 * DEC_WAVES), 0, s, A, Wd, bd, target, pred,
                        dpred, loss_part, dbias_part, batch, W, OF, scale);
+  BLH_HIP_TRY(hipGetLastError());
+  if (nparts) *nparts = blocks;
+  return BLH_OK;
+}
+
+int launch_decode_fwd_mse_h(hipStream_t s, const uint16_t* A, const uint16_t* Wd, const float* bd,
+                            const float* target, float* pred, float* dpred, uint16_t* dpred_h,
+                            float* loss_part, float* dbias_part, int64_t batch, int W, int OF, float scale,
+                            int* nparts) {
+  if (!decode_fwd_supported(batch, W, OF) || W % 8 != 0 || OF % 4 != 0) return BLH_ERR_SHAPE;
+  const int rows = decode_fwd_rows_per_block(batch);
+  const int blocks = (int)ceil_div(batch, rows);
+  if (rows == 16)
+    hipLaunchKernelGGL(decode_fwd_mse_h_kernel<1>, dim3(blocks), dim3(64 * DEC_WAVES), 0, s, A, Wd, bd, target,
+                       pred, dpred, dpred_h, loss_part, dbias_part, batch, W, OF, scale);
+  else if (rows == 32)
+    hipLaunchKernelGGL(decode_fwd_mse_h_kernel<2>, dim3(blocks), dim3(64 * DEC_WAVES), 0, s, A, Wd, bd, target,
+                       pred, dpred, dpred_h, loss_part, dbias_part, batch, W, OF, scale);
+  else
+    hipLaunchKernelGGL(decode_fwd_mse_h_kernel<4>, dim3(blocks), dim3(64 * DEC_WAVES), 0, s, A, Wd, bd, target,
+                       pred, dpred, dpred_h, loss_part, dbias_part, batch, W, OF, scale);
   BLH_HIP_TRY(hipGetLastError());
   if (nparts) *nparts = blocks;
   return BLH_OK;
