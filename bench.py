@@ -553,6 +553,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the extra timing of the bf16x3 GEMM mode (reported beside the headline)")
+    ap.add_argument("--persistent-shadow", action="store_true",
+                    help="bf16s: Adam writes the bf16 weight image, the next step skips the arena re-cast "
+                         "(Engine.set_persistent_shadow; opt-in contract, see its docstring)")
     ap.add_argument("--no-configs", action="store_true",
                     help="N=1, default config: skip the per-config blocks (configs[2], per-GPU shapes of "
                          "configs[3] and configs[4])")
@@ -601,6 +604,8 @@ def main():
     net.engine.ensure(dev)
     if args.one_stream:
         net.engine.set_two_stream(False)
+    if args.persistent_shadow and args.dtype == "bf16s":
+        net.engine.set_persistent_shadow(True)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     x = torch.randn(args.batch, 32, device=dev, generator=g)
     t = torch.randn(args.batch, 48, device=dev, generator=g)
@@ -629,7 +634,8 @@ def main():
     captured = None
     if use_graph:
         captured = bilinear_amd.CapturedTrainStep(net, opt, args.batch, max_norm=1.0,
-                                                  two_stream=not args.one_stream and args.graph_two_stream)
+                                                  two_stream=not args.one_stream and args.graph_two_stream,
+                                                  persistent_shadow=args.persistent_shadow)
         captured.x.copy_(x)            # the batch lives in the graph's static input buffers
         captured.t.copy_(t)
         x, t = captured.x, captured.t
@@ -736,8 +742,10 @@ def main():
                 "parallelism": "dp%d" % world,
                 "dropout": "philox",
                 "batchnorm": ("sync (global batch)" if args.sync_bn else "per-rank statistics") if world > 1 else "single device",
-                "launch": "hipGraph replay (1 launch/step)" if use_graph
-                          else "eager (~55 launches/step, weight-gradient GEMMs on a side stream)",
+                "launch": ("hipGraph replay (1 launch/step)" if use_graph
+                           else "eager (~55 launches/step, weight-gradient GEMMs on a side stream)") + (
+                               "; Adam writes the bf16 weight image (persistent shadow)"
+                               if args.persistent_shadow and args.dtype == "bf16s" else ""),
             },
             "final_loss": final_loss,
             "fwd_bwd_only": {"ms_per_step": fb_ms, "poses_per_s": args.batch / (fb_ms / 1e3)},

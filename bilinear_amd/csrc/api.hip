@@ -452,12 +452,6 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
 // rounding), the parameters, their gradients (fp32 slabs of the weight-gradient GEMM), Adam and
 // the loss stay fp32.  Gradients need no loss scaling: bf16 keeps fp32's exponent range.
 // =================================================================================================
-// BLH_BN_H = 1 selects the first-generation bf16 BatchNorm kernels (elementwise.hip) for A/B runs
-static int bn_h_gen() {
-  static const int v = [] { const char* e = getenv("BLH_BN_H"); return (e && atoi(e) == 1) ? 1 : 2; }();
-  return v;
-}
-
 static int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
                      float* bn_running, int64_t* nbt, const float* x, const blh_dropout* drop,
                      float momentum, const WorkspaceH& ws, float* pred, int64_t batch, bool train,
@@ -499,23 +493,13 @@ static int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, c
                                        params + h.beta, rm, rv, nbt + i, momentum, sv, sv + W,
                                        sv + 2 * W, sv + 3 * W));
       }
-      if (bn_h_gen() == 1)
-        BLH_TRY(launch_bn_apply_t(s, true, ws.Z[i], ET_BF16, sv + 2 * W, sv + 3 * W, nullptr, nullptr,
-                                  nullptr, nullptr, skip, ET_BF16, ws.A[i], ET_BF16, batch, W,
-                                  layer_drop(ctx, drop, i, batch, W), nbt + i));
-      else
-        BLH_TRY(launch_bn_apply_h2(s, true, ws.Z[i], sv + 2 * W, sv + 3 * W, nullptr, nullptr, nullptr,
-                                   nullptr, skip, ws.A[i], ws.keep[i], batch, W,
-                                   layer_drop(ctx, drop, i, batch, W), nbt + i));
+      BLH_TRY(launch_bn_apply_h2(s, true, ws.Z[i], sv + 2 * W, sv + 3 * W, nullptr, nullptr, nullptr,
+                                 nullptr, skip, ws.A[i], ws.keep[i], batch, W,
+                                 layer_drop(ctx, drop, i, batch, W), nbt + i));
     } else {
       DropoutSrc none{nullptr, 0, 0, 0, 0, nullptr};
-      if (bn_h_gen() == 1)
-        BLH_TRY(launch_bn_apply_t(s, false, ws.Z[i], ET_BF16, nullptr, nullptr, params + h.gamma,
-                                  params + h.beta, rm, rv, skip, ET_BF16, ws.A[i], ET_BF16, batch, W,
-                                  none, nullptr));
-      else
-        BLH_TRY(launch_bn_apply_h2(s, false, ws.Z[i], nullptr, nullptr, params + h.gamma, params + h.beta,
-                                   rm, rv, skip, ws.A[i], nullptr, batch, W, none, nullptr));
+      BLH_TRY(launch_bn_apply_h2(s, false, ws.Z[i], nullptr, nullptr, params + h.gamma, params + h.beta,
+                                 rm, rv, skip, ws.A[i], nullptr, batch, W, none, nullptr));
     }
   }
   // decode (model/bilinear.py:39) fused with nn.MSELoss (train_bilinear.py:78) when a target is given:
@@ -615,15 +599,7 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
     const bool first_of_block = (i >= 1) && (i % 2 == 1);
     const uint16_t* dA = first_of_block ? ws.G1 : ws.G0;
     const float* sv = ws.bn_saved[i];
-    const DropoutSrc ds = layer_drop(ctx, drop, i, batch, W);
-    if (bn_h_gen() == 1) {
-      BLH_TRY(launch_bn_bwd_reduce_t(s, dA, ET_BF16, ws.Z[i], ET_BF16, sv + 2 * W, sv + 3 * W, sv,
-                                     sv + W, ws.bn_part, batch, W, ds));
-      BLH_TRY(launch_bn_bwd_finalize(s, ws.bn_part, chunks, W, grads + h.gamma, grads + h.beta));
-      BLH_TRY(launch_bn_bwd_apply_t(s, dA, ET_BF16, ws.Z[i], ET_BF16, sv + 2 * W, sv + 3 * W, sv,
-                                    sv + W, grads + h.gamma, grads + h.beta, ws.dZ[i], ET_BF16,
-                                    ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W, ds, batch));
-    } else {   // keep bits written by the forward (bn_bf16.hip)
+    {   // dropout: the keep bits the forward wrote (bn_bf16.hip)
       BLH_TRY(launch_bn_bwd_reduce_h2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, ws.keep[i], ws.bn_part, batch, W));
       BLH_TRY(launch_bn_bwd_finalize_h2(s, ws.bn_part, chunks, W, sv, sv + W, grads + h.gamma, grads + h.beta));
       const float* dg = grads + h.gamma;

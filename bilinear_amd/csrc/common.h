@@ -110,35 +110,10 @@ int launch_bn_fwd_finalize(hipStream_t s, const float* stat_part, int tiles, int
                            float* running_mean, float* running_var, int64_t* nbt,
                            float momentum, float* saved_mean, float* saved_invstd,
                            float* scale, float* shift);
-// A = dropout(relu(Z*scale+shift)) (+ skip)
-// (nbt, if not null, is incremented once: num_batches_tracked of this BN layer)
 // gemm_dtype 3: the streaming BatchNorm kernels can emit max |value| partials of what they write
 // (one per wave: ew_num_amax_parts() floats), from which the fp16-split GEMM picks its scale
 int launch_wamax(hipStream_t s, const float* W, int64_t w_stride, int layers, int64_t count,
                  float* part);
-int launch_bn_apply_train(hipStream_t s, const float* Z, const float* scale, const float* shift,
-                          const float* skip, float* A, int64_t batch, int W,
-                          const DropoutSrc& drop, int64_t* nbt, float* amax_part = nullptr);
-// gemm_dtype 4 (bf16 storage): the same kernels with bf16 [B,W] tensors.  Element types:
-enum ElemType : int { ET_F32 = 0, ET_BF16 = 1 };
-// (Z, skip, A) in {(f32,f32,f32), (bf16,bf16,bf16), (bf16,bf16,f32)}; train = batch statistics
-// + dropout, else running statistics (gamma .. running_var given, scale / shift null)
-int launch_bn_apply_t(hipStream_t s, bool train, const void* Z, int zt, const float* scale,
-                      const float* shift, const float* gamma, const float* beta,
-                      const float* running_mean, const float* running_var, const void* skip,
-                      int st, void* A, int at, int64_t batch, int W, const DropoutSrc& drop,
-                      int64_t* nbt);
-// (dA, Z) in {(f32,f32), (bf16,bf16)}
-int launch_bn_bwd_reduce_t(hipStream_t s, const void* dA, int gt, const void* Z, int zt,
-                           const float* scale, const float* shift, const float* mean,
-                           const float* invstd, float* part, int64_t batch, int W,
-                           const DropoutSrc& drop);
-// (dA, Z, dZ) in {(f32,f32,f32), (bf16,bf16,bf16), (bf16,bf16,f32)}
-int launch_bn_bwd_apply_t(hipStream_t s, const void* dA, int gt, const void* Z, int zt,
-                          const float* scale, const float* shift, const float* mean,
-                          const float* invstd, const float* dgamma, const float* dbeta, void* dZ,
-                          int dt, float* dz_colsum_part, int64_t batch, int W,
-                          const DropoutSrc& drop, int64_t norm_batch);
 // bf16-storage path, second generation (bn_bf16.hip): the forward writes one keep bit per element
 // (keepbits: [ceil(B/4)][W/8] words, bn_keepbits_words), the backward kernels read them
 int64_t bn_keepbits_words(int64_t batch, int W);
@@ -168,24 +143,6 @@ int launch_bn_bwd_apply_f2(hipStream_t s, const float* dA, const float* Z, const
                            const float* shift, const float* mean, const float* invstd, const float* dgamma,
                            const float* dbeta, const uint32_t* keepbits, float* dZ, float* colsum_part,
                            int64_t batch, int W, int64_t norm_batch, float* amax_part = nullptr);
-// eval: scale/shift from running stats, no dropout
-int launch_bn_apply_eval(hipStream_t s, const float* Z, const float* gamma, const float* beta,
-                         const float* running_mean, const float* running_var,
-                         const float* skip, float* A, int64_t batch, int W,
-                         float* amax_part = nullptr);
-// backward pass 1: partial column sums of dY and dY*zhat
-int launch_bn_bwd_reduce(hipStream_t s, const float* dA, const float* Z, const float* scale,
-                         const float* shift, const float* mean, const float* invstd,
-                         float* part, int64_t batch, int W, const DropoutSrc& drop);
-// finalize: dgamma, dbeta (into the grad arena) from partials
-int launch_bn_bwd_finalize(hipStream_t s, const float* part, int chunks, int W, float* dgamma,
-                           float* dbeta);
-// backward pass 2: dZ = gamma*invstd*(dY - dbeta/B - zhat*dgamma/B); partial column sums of dZ
-int launch_bn_bwd_apply(hipStream_t s, const float* dA, const float* Z, const float* scale,
-                        const float* shift, const float* mean, const float* invstd,
-                        const float* gamma, const float* dgamma, const float* dbeta, float* dZ,
-                        float* dz_colsum_part, int64_t batch, int W, const DropoutSrc& drop,
-                        int64_t norm_batch, float* amax_part = nullptr);
 // SyncBN: local fp64 column sums [sum z | sum z^2] -> (host all-reduce) -> finalize
 int launch_bn_fwd_local_sums(hipStream_t s, const float* stat_part, int tiles, int tile_rows,
                              int64_t batch, int W, double* sums);

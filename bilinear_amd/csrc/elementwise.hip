@@ -251,489 +251,8 @@ int launch_bn_fwd_finalize(hipStream_t s, const float* stat_part, int tiles, int
   return BLH_OK;
 }
 
-// ---------------------------------------------------------------------------
-// Streaming kernels over [B,W] tensors.  Block = 256 threads = 4 waves; a block owns a
-// tile of 256 columns (64 lanes x float4: a wave reads 1 KiB contiguous per row) x
-// `row_chunk` rows (a multiple of 32).  Inside each 32-row patch wave w takes rows
-// w, w+4, ..., w+28: eight independent 16-B loads per tensor in flight per lane
-// (>= 32 KiB per block), and one Philox call (32 rows x 4 columns) per lane per patch.
-// ---------------------------------------------------------------------------
-static constexpr int PATCH_ROWS = 32;
-static constexpr int ROWS_PER_LANE = 8;     // PATCH_ROWS / 4 waves
+// (The streaming BatchNorm-apply / BatchNorm-backward kernels live in bn_f32.hip and bn_bf16.hip.)
 
-struct PatchMask {
-  uint32_t nib[ROWS_PER_LANE];
-};
-
-// keep nibbles of this lane's 8 rows of the patch starting at local row `base`
-__device__ __forceinline__ PatchMask patch_mask(const DropoutSrc& d, int64_t base, int w, int col,
-                                                int W, int64_t batch) {
-  PatchMask m;
-  if (d.keep) {
-#pragma unroll
-    for (int i = 0; i < ROWS_PER_LANE; ++i) {
-      const int64_t r = base + w + 4 * i;
-      uint32_t n = 0;
-      if (r < batch) {
-        const uchar4 k = *reinterpret_cast<const uchar4*>(d.keep + r * (int64_t)W + col);
-        n = (k.x ? 1u : 0u) | (k.y ? 2u : 0u) | (k.z ? 4u : 0u) | (k.w ? 8u : 0u);
-      }
-      m.nib[i] = n;
-    }
-  } else {
-    const Philox128 p = dropout_patch(d.seed, dropout_step(d), d.layer, base + d.row_offset, col);
-    // row w + 4i (w < 4): word i>>1 (compile-time), nibble w + 4*(i&1)
-#pragma unroll
-    for (int i = 0; i < ROWS_PER_LANE; ++i) m.nib[i] = (p.w[i >> 1] >> (4 * (w + 4 * (i & 1)))) & 0xFu;
-  }
-  return m;
-}
-
-__device__ __forceinline__ float4 relu_bn(float4 z, float4 sc, float4 sh) {
-  float4 a;
-  a.x = fmaxf(fmaf(z.x, sc.x, sh.x), 0.f); a.y = fmaxf(fmaf(z.y, sc.y, sh.y), 0.f);
-  a.z = fmaxf(fmaf(z.z, sc.z, sh.z), 0.f); a.w = fmaxf(fmaf(z.w, sc.w, sh.w), 0.f);
-  return a;
-}
-
-// dY = dA * 2*keep * [y > 0]
-__device__ __forceinline__ float4 dropout_relu_bwd(float4 g, float4 z, float4 sc, float4 sh,
-                                                   uint32_t nib) {
-  float4 dy;
-  dy.x = ((nib & 1u) && (fmaf(z.x, sc.x, sh.x) > 0.f)) ? g.x * 2.f : 0.f;
-  dy.y = ((nib & 2u) && (fmaf(z.y, sc.y, sh.y) > 0.f)) ? g.y * 2.f : 0.f;
-  dy.z = ((nib & 4u) && (fmaf(z.z, sc.z, sh.z) > 0.f)) ? g.z * 2.f : 0.f;
-  dy.w = ((nib & 8u) && (fmaf(z.w, sc.w, sh.w) > 0.f)) ? g.w * 2.f : 0.f;
-  return dy;
-}
-
-// ---------------------------------------------------------------------------
-// A = dropout(relu(Z*scale + shift)) (+ skip)
-// ---------------------------------------------------------------------------
-template <bool TRAIN, typename TZ = float, typename TS = float, typename TA = float>
-__global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(
-    const TZ* __restrict__ Z, const float* __restrict__ scale, const float* __restrict__ shift,
-    const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ running_mean, const float* __restrict__ running_var,
-    const TS* __restrict__ skip, TA* __restrict__ A, int64_t batch, int W, int row_chunk,
-    DropoutSrc drop, int64_t* nbt, float* __restrict__ amax_part) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int col = blockIdx.x * EW_COLS_PER_BLOCK + lane * 4;
-  if (TRAIN && nbt && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) nbt[0] += 1;
-  float am = 0.f;
-  const bool okc = col < W;        // (no early return: the amax reduction needs whole waves)
-  const int cc = okc ? col : 0;
-  float4 sc, sh;
-  if (TRAIN) {
-    sc = ld4(scale + cc);
-    sh = ld4(shift + cc);
-  } else {
-    const float4 g = ld4(gamma + cc), b = ld4(beta + cc), rm = ld4(running_mean + cc),
-                 rv = ld4(running_var + cc);
-    sc.x = g.x * (1.0f / sqrtf(rv.x + BN_EPS)); sc.y = g.y * (1.0f / sqrtf(rv.y + BN_EPS));
-    sc.z = g.z * (1.0f / sqrtf(rv.z + BN_EPS)); sc.w = g.w * (1.0f / sqrtf(rv.w + BN_EPS));
-    sh.x = b.x - rm.x * sc.x; sh.y = b.y - rm.y * sc.y;
-    sh.z = b.z - rm.z * sc.z; sh.w = b.w - rm.w * sc.w;
-  }
-  const int64_t r0 = (int64_t)blockIdx.y * row_chunk;
-  const int64_t r1 = min(batch, r0 + row_chunk);
-  for (int64_t base = r0; okc && base < r1; base += PATCH_ROWS) {
-    float4 z[ROWS_PER_LANE], k[ROWS_PER_LANE];
-#pragma unroll
-    for (int i = 0; i < ROWS_PER_LANE; ++i) {
-      const int64_t r = base + w + 4 * i;
-      z[i] = (r < batch) ? ld4(Z + r * W + col) : make_float4(0, 0, 0, 0);
-      k[i] = (skip && r < batch) ? ld4(skip + r * W + col) : make_float4(0, 0, 0, 0);
-    }
-    PatchMask pm;
-    if (TRAIN) pm = patch_mask(drop, base, w, col, W, batch);
-#pragma unroll
-    for (int i = 0; i < ROWS_PER_LANE; ++i) {
-      const int64_t r = base + w + 4 * i;
-      float4 a = relu_bn(z[i], sc, sh);
-      if (TRAIN) {
-        const uint32_t nib = pm.nib[i];
-        a.x = (nib & 1u) ? a.x * 2.f : 0.f; a.y = (nib & 2u) ? a.y * 2.f : 0.f;
-        a.z = (nib & 4u) ? a.z * 2.f : 0.f; a.w = (nib & 8u) ? a.w * 2.f : 0.f;
-      }
-      a.x += k[i].x; a.y += k[i].y; a.z += k[i].z; a.w += k[i].w;
-      if (r < batch) {
-        st4(A + r * W + col, a);
-        am = amax4(am, a);
-      }
-    }
-  }
-  if (amax_part) wave_amax_store(am, amax_part);
-}
-
-static dim3 ew_grid(int64_t batch, int W) {
-  return dim3((unsigned)ceil_div(W, EW_COLS_PER_BLOCK), (unsigned)ew_num_row_chunks(batch));
-}
-
-int launch_bn_apply_train(hipStream_t s, const float* Z, const float* scale, const float* shift,
-                          const float* skip, float* A, int64_t batch, int W,
-                          const DropoutSrc& drop, int64_t* nbt, float* amax_part) {
-  hipLaunchKernelGGL((bn_apply_kernel<true, float, float, float>), ew_grid(batch, W), dim3(EW_THREADS), 0, s, Z, scale,
-                     shift, nullptr, nullptr, nullptr, nullptr, skip, A, batch, W,
-                     ew_row_chunk(batch), drop, nbt, amax_part);
-  BLH_HIP_TRY(hipGetLastError());
-  return BLH_OK;
-}
-
-int launch_bn_apply_eval(hipStream_t s, const float* Z, const float* gamma, const float* beta,
-                         const float* running_mean, const float* running_var, const float* skip,
-                         float* A, int64_t batch, int W, float* amax_part) {
-  DropoutSrc none{nullptr, 0, 0, 0, 0, nullptr};
-  hipLaunchKernelGGL((bn_apply_kernel<false, float, float, float>), ew_grid(batch, W), dim3(EW_THREADS), 0, s, Z,
-                     nullptr, nullptr, gamma, beta, running_mean, running_var, skip, A, batch, W,
-                     ew_row_chunk(batch), none, nullptr, amax_part);
-  BLH_HIP_TRY(hipGetLastError());
-  return BLH_OK;
-}
-
-
-// ---------------------------------------------------------------------------
-// bf16-storage forms of the three streaming BatchNorm kernels (gemm_dtype 4).  Same arithmetic
-// and the same Philox patches as the fp32 kernels above; a lane owns EIGHT consecutive columns
-// (16 bytes of bf16: 8-byte accesses reach only 0.55-0.7 of the 16-byte rate), i.e. two Philox
-// patches side by side, a wave covers 512 columns (1 KiB) of a row, and the 8 rows a lane owns in
-// a 32-row patch are processed four at a time to keep the register count of the fp32 kernels.
-// ---------------------------------------------------------------------------
-static constexpr int H_COLS_PER_BLOCK = 512;
-
-__device__ __forceinline__ void ld8(const bf16_bits* p, float4& a, float4& b) {
-  const uint4 v = *reinterpret_cast<const uint4*>(p);
-  a = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
-                  __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
-  b = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u),
-                  __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u));
-}
-__device__ __forceinline__ void st8(bf16_bits* p, float4 a, float4 b) {
-  *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w),
-                                            pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
-}
-__device__ __forceinline__ float4 add4(float4 a, float4 b) {
-  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-}
-__device__ __forceinline__ float4 drop4(float4 a, uint32_t nib) {
-  a.x = (nib & 1u) ? a.x * 2.f : 0.f; a.y = (nib & 2u) ? a.y * 2.f : 0.f;
-  a.z = (nib & 4u) ? a.z * 2.f : 0.f; a.w = (nib & 8u) ? a.w * 2.f : 0.f;
-  return a;
-}
-static dim3 ew_grid_h(int64_t batch, int W) {
-  return dim3((unsigned)ceil_div(W, H_COLS_PER_BLOCK), (unsigned)ew_num_row_chunks_h(batch));
-}
-
-// sum the per-lane 2 x float4 partials of the block's 4 waves: out[col0 .. col0+511]
-__device__ __forceinline__ void block_colsum_store_h(float4 v0, float4 v1, float* red, float* out,
-                                                     int col0, int W) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  __syncthreads();
-  reinterpret_cast<float4*>(red)[w * 128 + lane * 2 + 0] = v0;
-  reinterpret_cast<float4*>(red)[w * 128 + lane * 2 + 1] = v1;
-  __syncthreads();
-  for (int t = threadIdx.x; t < 512; t += EW_THREADS)
-    if (col0 + t < W) out[col0 + t] = (red[t] + red[512 + t]) + (red[1024 + t] + red[1536 + t]);
-}
-
-// Occupancy of the bf16 streaming kernels.  They are latency-bound (PMC: 66 % of the wave cycles
-// wait for memory) and the compiler's first choice of 180-258 VGPRs left one or two waves per
-// SIMD; BLH_EW_H_WAVES waves per SIMD are requested instead (second __launch_bounds__ argument).
-#ifndef BLH_EW_H_WAVES
-#define BLH_EW_H_WAVES 2
-#endif
-template <bool TRAIN>
-__global__ __launch_bounds__(EW_THREADS, BLH_EW_H_WAVES) void bn_apply_h_kernel(
-    const bf16_bits* __restrict__ Z, const float* __restrict__ scale, const float* __restrict__ shift,
-    const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ running_mean, const float* __restrict__ running_var,
-    const bf16_bits* __restrict__ skip, bf16_bits* __restrict__ A, int64_t batch, int W, int row_chunk,
-    DropoutSrc drop, int64_t* nbt) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int col = blockIdx.x * H_COLS_PER_BLOCK + lane * 8;
-  if (TRAIN && nbt && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) nbt[0] += 1;
-  if (col >= W) return;
-  float4 sc[2], sh[2];
-#pragma unroll
-  for (int v = 0; v < 2; ++v) {
-    const int c = col + 4 * v;
-    if (TRAIN) {
-      sc[v] = ld4(scale + c);
-      sh[v] = ld4(shift + c);
-    } else {
-      const float4 g = ld4(gamma + c), b = ld4(beta + c), rm = ld4(running_mean + c), rv = ld4(running_var + c);
-      sc[v].x = g.x * (1.0f / sqrtf(rv.x + BN_EPS)); sc[v].y = g.y * (1.0f / sqrtf(rv.y + BN_EPS));
-      sc[v].z = g.z * (1.0f / sqrtf(rv.z + BN_EPS)); sc[v].w = g.w * (1.0f / sqrtf(rv.w + BN_EPS));
-      sh[v].x = b.x - rm.x * sc[v].x; sh[v].y = b.y - rm.y * sc[v].y;
-      sh[v].z = b.z - rm.z * sc[v].z; sh[v].w = b.w - rm.w * sc[v].w;
-    }
-  }
-  const int64_t r0 = (int64_t)blockIdx.y * row_chunk;
-  const int64_t r1 = min(batch, r0 + row_chunk);
-  for (int64_t base = r0; base < r1; base += PATCH_ROWS) {
-    PatchMask pm[2];
-    if (TRAIN) {
-      pm[0] = patch_mask(drop, base, w, col, W, batch);
-      pm[1] = patch_mask(drop, base, w, col + 4, W, batch);
-    }
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      float4 z[4][2], k[4][2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t r = base + w + 4 * (4 * hf + i);
-        z[i][0] = z[i][1] = k[i][0] = k[i][1] = make_float4(0, 0, 0, 0);
-        if (r < batch) {
-          ld8(Z + r * W + col, z[i][0], z[i][1]);
-          if (skip) ld8(skip + r * W + col, k[i][0], k[i][1]);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t r = base + w + 4 * (4 * hf + i);
-        float4 a[2];
-#pragma unroll
-        for (int v = 0; v < 2; ++v) {
-          a[v] = relu_bn(z[i][v], sc[v], sh[v]);
-          if (TRAIN) a[v] = drop4(a[v], pm[v].nib[4 * hf + i]);
-          a[v] = add4(a[v], k[i][v]);
-        }
-        if (r < batch) st8(A + r * W + col, a[0], a[1]);
-      }
-    }
-  }
-}
-
-__global__ __launch_bounds__(EW_THREADS, BLH_EW_H_WAVES) void bn_bwd_reduce_h_kernel(
-    const bf16_bits* __restrict__ dA, const bf16_bits* __restrict__ Z, const float* __restrict__ scale,
-    const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ invstd, float* __restrict__ part, int64_t batch, int W,
-    int row_chunk, DropoutSrc drop) {
-  BLH_EW_PRIO();
-  __shared__ __attribute__((aligned(16))) float red[4 * 512];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int col0 = blockIdx.x * H_COLS_PER_BLOCK;
-  const int col = col0 + lane * 8;
-  const bool ok = col < W;
-  const int cc = ok ? col : 0;
-  float4 sc[2], sh[2], mu[2], is[2], sg[2], sb[2];
-#pragma unroll
-  for (int v = 0; v < 2; ++v) {
-    sc[v] = ld4(scale + cc + 4 * v); sh[v] = ld4(shift + cc + 4 * v);
-    mu[v] = ld4(mean + cc + 4 * v); is[v] = ld4(invstd + cc + 4 * v);
-    sg[v] = sb[v] = make_float4(0, 0, 0, 0);
-  }
-  const int64_t r0 = (int64_t)blockIdx.y * row_chunk;
-  const int64_t r1 = min(batch, r0 + row_chunk);
-  if (ok)
-    for (int64_t base = r0; base < r1; base += PATCH_ROWS) {
-      PatchMask pm[2];
-      pm[0] = patch_mask(drop, base, w, col, W, batch);
-      pm[1] = patch_mask(drop, base, w, col + 4, W, batch);
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        float4 z[4][2], g[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int64_t r = base + w + 4 * (4 * hf + i);
-          z[i][0] = z[i][1] = g[i][0] = g[i][1] = make_float4(0, 0, 0, 0);
-          if (r < batch) {
-            ld8(Z + r * W + col, z[i][0], z[i][1]);
-            ld8(dA + r * W + col, g[i][0], g[i][1]);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int v = 0; v < 2; ++v) {
-            const float4 dy = dropout_relu_bwd(g[i][v], z[i][v], sc[v], sh[v], pm[v].nib[4 * hf + i]);
-            sb[v] = add4(sb[v], dy);
-            sg[v].x += dy.x * ((z[i][v].x - mu[v].x) * is[v].x); sg[v].y += dy.y * ((z[i][v].y - mu[v].y) * is[v].y);
-            sg[v].z += dy.z * ((z[i][v].z - mu[v].z) * is[v].z); sg[v].w += dy.w * ((z[i][v].w - mu[v].w) * is[v].w);
-          }
-      }
-    }
-  block_colsum_store_h(sg[0], sg[1], red, part + ((int64_t)blockIdx.y * 2 + 0) * W, col0, W);
-  block_colsum_store_h(sb[0], sb[1], red, part + ((int64_t)blockIdx.y * 2 + 1) * W, col0, W);
-}
-
-__global__ __launch_bounds__(EW_THREADS, BLH_EW_H_WAVES) void bn_bwd_apply_h_kernel(
-    const bf16_bits* __restrict__ dA, const bf16_bits* __restrict__ Z, const float* __restrict__ scale,
-    const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ invstd, const float* __restrict__ dgamma,
-    const float* __restrict__ dbeta, bf16_bits* __restrict__ dZ, float* __restrict__ colsum_part,
-    int64_t batch, int W, int row_chunk, DropoutSrc drop, int64_t norm_batch) {
-  BLH_EW_PRIO();
-  __shared__ __attribute__((aligned(16))) float red[4 * 512];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int col0 = blockIdx.x * H_COLS_PER_BLOCK;
-  const int col = col0 + lane * 8;
-  const bool ok = col < W;
-  const int cc = ok ? col : 0;
-  const float inv_b = 1.0f / (float)norm_batch;
-  float4 sc[2], sh[2], mu[2], is[2], c1[2], c2[2], cs[2];
-#pragma unroll
-  for (int v = 0; v < 2; ++v) {
-    sc[v] = ld4(scale + cc + 4 * v); sh[v] = ld4(shift + cc + 4 * v);
-    mu[v] = ld4(mean + cc + 4 * v); is[v] = ld4(invstd + cc + 4 * v);
-    c1[v] = ld4(dbeta + cc + 4 * v); c2[v] = ld4(dgamma + cc + 4 * v);
-    c1[v].x *= inv_b; c1[v].y *= inv_b; c1[v].z *= inv_b; c1[v].w *= inv_b;
-    c2[v].x *= inv_b; c2[v].y *= inv_b; c2[v].z *= inv_b; c2[v].w *= inv_b;
-    cs[v] = make_float4(0, 0, 0, 0);
-  }
-  const int64_t r0 = (int64_t)blockIdx.y * row_chunk;
-  const int64_t r1 = min(batch, r0 + row_chunk);
-  if (ok)
-    for (int64_t base = r0; base < r1; base += PATCH_ROWS) {
-      PatchMask pm[2];
-      pm[0] = patch_mask(drop, base, w, col, W, batch);
-      pm[1] = patch_mask(drop, base, w, col + 4, W, batch);
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        float4 z[4][2], g[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int64_t r = base + w + 4 * (4 * hf + i);
-          z[i][0] = z[i][1] = g[i][0] = g[i][1] = make_float4(0, 0, 0, 0);
-          if (r < batch) {
-            ld8(Z + r * W + col, z[i][0], z[i][1]);
-            ld8(dA + r * W + col, g[i][0], g[i][1]);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int64_t r = base + w + 4 * (4 * hf + i);
-          float4 o[2];
-#pragma unroll
-          for (int v = 0; v < 2; ++v) {
-            const float4 dy = dropout_relu_bwd(g[i][v], z[i][v], sc[v], sh[v], pm[v].nib[4 * hf + i]);
-            o[v].x = sc[v].x * (dy.x - c1[v].x - ((z[i][v].x - mu[v].x) * is[v].x) * c2[v].x);
-            o[v].y = sc[v].y * (dy.y - c1[v].y - ((z[i][v].y - mu[v].y) * is[v].y) * c2[v].y);
-            o[v].z = sc[v].z * (dy.z - c1[v].z - ((z[i][v].z - mu[v].z) * is[v].z) * c2[v].z);
-            o[v].w = sc[v].w * (dy.w - c1[v].w - ((z[i][v].w - mu[v].w) * is[v].w) * c2[v].w);
-            o[v] = as_stored(dZ, o[v]);   // the bias gradient sums what the wgrad GEMM will read
-          }
-          if (r < batch) {
-            cs[0] = add4(cs[0], o[0]);
-            cs[1] = add4(cs[1], o[1]);
-            st8(dZ + r * W + col, o[0], o[1]);
-          }
-        }
-      }
-    }
-  block_colsum_store_h(cs[0], cs[1], red, colsum_part + (int64_t)blockIdx.y * W, col0, W);
-}
-
-int launch_bn_apply_t(hipStream_t s, bool train, const void* Z, int zt, const float* scale,
-                      const float* shift, const float* gamma, const float* beta,
-                      const float* running_mean, const float* running_var, const void* skip,
-                      int st, void* A, int at, int64_t batch, int W, const DropoutSrc& drop,
-                      int64_t* nbt) {
-  const dim3 grid = ew_grid(batch, W), block(EW_THREADS);
-  const int rc = ew_row_chunk(batch);
-#define BLH_APPLY(TRAIN_, TZ_, TS_, TA_)                                                            \
-  hipLaunchKernelGGL((bn_apply_kernel<TRAIN_, TZ_, TS_, TA_>), grid, block, 0, s, (const TZ_*)Z, scale, \
-                     shift, gamma, beta, running_mean, running_var, (const TS_*)skip, (TA_*)A, batch, \
-                     W, rc, drop, nbt, (float*)nullptr)
-  if (zt == ET_F32 && at == ET_F32 && (skip == nullptr || st == ET_F32)) {
-    if (train) BLH_APPLY(true, float, float, float); else BLH_APPLY(false, float, float, float);
-  } else if (zt == ET_BF16 && at == ET_BF16 && (skip == nullptr || st == ET_BF16) && W % 8 == 0) {
-    if (train)
-      hipLaunchKernelGGL(bn_apply_h_kernel<true>, ew_grid_h(batch, W), block, 0, s, (const bf16_bits*)Z,
-                         scale, shift, gamma, beta, running_mean, running_var, (const bf16_bits*)skip,
-                         (bf16_bits*)A, batch, W, ew_row_chunk_h(batch), drop, nbt);
-    else
-      hipLaunchKernelGGL(bn_apply_h_kernel<false>, ew_grid_h(batch, W), block, 0, s, (const bf16_bits*)Z,
-                         scale, shift, gamma, beta, running_mean, running_var, (const bf16_bits*)skip,
-                         (bf16_bits*)A, batch, W, ew_row_chunk_h(batch), drop, nbt);
-  } else if (zt == ET_BF16 && at == ET_F32 && (skip == nullptr || st == ET_BF16)) {
-    if (train) BLH_APPLY(true, bf16_bits, bf16_bits, float); else BLH_APPLY(false, bf16_bits, bf16_bits, float);
-  } else {
-    return BLH_ERR_INVALID_ARGUMENT;
-  }
-#undef BLH_APPLY
-  BLH_HIP_TRY(hipGetLastError());
-  return BLH_OK;
-}
-
-// sum the per-lane float4 partials of the block's 4 waves and write one row of
-// `out` (256 floats at out[col0 .. col0+255]); red = [4][256] floats of LDS
-__device__ __forceinline__ void block_colsum_store(float4 v, float* red, float* out, int col0, int W) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  __syncthreads();
-  reinterpret_cast<float4*>(red)[w * 64 + lane] = v;
-  __syncthreads();
-  const int t = threadIdx.x;
-  if (col0 + t < W) out[col0 + t] = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
-}
-
-// ---------------------------------------------------------------------------
-// backward pass 1: dY = dA * 2*keep * [y>0]; per-chunk column sums of dY*zhat, dY
-// part layout [chunk][2][W]: row 0 -> dgamma partial, row 1 -> dbeta partial
-// ---------------------------------------------------------------------------
-template <typename TG = float, typename TZ = float>
-__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
-    const TG* __restrict__ dA, const TZ* __restrict__ Z, const float* __restrict__ scale,
-    const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ invstd, float* __restrict__ part, int64_t batch, int W,
-    int row_chunk, DropoutSrc drop) {
-  BLH_EW_PRIO();
-  __shared__ __attribute__((aligned(16))) float red[4 * 256];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int col0 = blockIdx.x * EW_COLS_PER_BLOCK;
-  const int col = col0 + lane * 4;
-  const bool ok = col < W;
-  const int cc = ok ? col : 0;
-  const float4 sc = ld4(scale + cc), sh = ld4(shift + cc), mu = ld4(mean + cc),
-               is = ld4(invstd + cc);
-  const int64_t r0 = (int64_t)blockIdx.y * row_chunk;
-  const int64_t r1 = min(batch, r0 + row_chunk);
-  float4 sg = make_float4(0, 0, 0, 0), sb = make_float4(0, 0, 0, 0);
-  if (ok)
-    for (int64_t base = r0; base < r1; base += PATCH_ROWS) {
-      float4 z[ROWS_PER_LANE], g[ROWS_PER_LANE];
-#pragma unroll
-      for (int i = 0; i < ROWS_PER_LANE; ++i) {
-        const int64_t r = base + w + 4 * i;
-        z[i] = (r < batch) ? ld4(Z + r * W + col) : make_float4(0, 0, 0, 0);
-        g[i] = (r < batch) ? ld4(dA + r * W + col) : make_float4(0, 0, 0, 0);
-      }
-      const PatchMask pm = patch_mask(drop, base, w, col, W, batch);
-#pragma unroll
-      for (int i = 0; i < ROWS_PER_LANE; ++i) {
-        const float4 dy = dropout_relu_bwd(g[i], z[i], sc, sh, pm.nib[i]);
-        sb.x += dy.x; sb.y += dy.y; sb.z += dy.z; sb.w += dy.w;
-        sg.x += dy.x * ((z[i].x - mu.x) * is.x); sg.y += dy.y * ((z[i].y - mu.y) * is.y);
-        sg.z += dy.z * ((z[i].z - mu.z) * is.z); sg.w += dy.w * ((z[i].w - mu.w) * is.w);
-      }
-    }
-  block_colsum_store(sg, red, part + ((int64_t)blockIdx.y * 2 + 0) * W, col0, W);
-  block_colsum_store(sb, red, part + ((int64_t)blockIdx.y * 2 + 1) * W, col0, W);
-}
-
-int launch_bn_bwd_reduce(hipStream_t s, const float* dA, const float* Z, const float* scale,
-                         const float* shift, const float* mean, const float* invstd, float* part,
-                         int64_t batch, int W, const DropoutSrc& drop) {
-  hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float>), ew_grid(batch, W), dim3(EW_THREADS), 0,
-                     s, dA, Z, scale, shift, mean, invstd, part, batch, W, ew_row_chunk(batch), drop);
-  BLH_HIP_TRY(hipGetLastError());
-  return BLH_OK;
-}
-
-int launch_bn_bwd_reduce_t(hipStream_t s, const void* dA, int gt, const void* Z, int zt,
-                           const float* scale, const float* shift, const float* mean,
-                           const float* invstd, float* part, int64_t batch, int W,
-                           const DropoutSrc& drop) {
-  if (gt == ET_F32 && zt == ET_F32)
-    return launch_bn_bwd_reduce(s, (const float*)dA, (const float*)Z, scale, shift, mean, invstd, part,
-                                batch, W, drop);
-  if (gt != ET_BF16 || zt != ET_BF16 || W % 8 != 0) return BLH_ERR_INVALID_ARGUMENT;
-  hipLaunchKernelGGL(bn_bwd_reduce_h_kernel, ew_grid_h(batch, W), dim3(EW_THREADS), 0, s,
-                     (const bf16_bits*)dA, (const bf16_bits*)Z, scale, shift, mean, invstd, part, batch, W,
-                     ew_row_chunk_h(batch), drop);
-  BLH_HIP_TRY(hipGetLastError());
-  return BLH_OK;
-}
 
 // ---------------------------------------------------------------------------
 // out[c] = sum_s in[s][c], c < ncols.  block = 32 columns x 8 slices, fp64 sums.
@@ -807,111 +326,6 @@ int launch_bias_colreduce(hipStream_t s, const float* part, int64_t stage_stride
   return BLH_OK;
 }
 
-int launch_bn_bwd_finalize(hipStream_t s, const float* part, int chunks, int W, float* dgamma,
-                           float* dbeta) {
-  // part is [chunks][2][W]; dgamma and dbeta are adjacent in the arena when W % 64 == 0
-  if (dbeta == dgamma + W) return launch_colreduce(s, part, chunks, 2 * (int64_t)W, 2 * W, dgamma);
-  BLH_TRY(launch_colreduce(s, part, chunks, 2 * (int64_t)W, W, dgamma));
-  return launch_colreduce(s, part + W, chunks, 2 * (int64_t)W, W, dbeta);
-}
-
-// ---------------------------------------------------------------------------
-// backward pass 2: dZ = gamma*invstd*(dY - dbeta/B - zhat*dgamma/B)
-// plus per-chunk column sums of dZ (the Linear bias gradient)
-// ---------------------------------------------------------------------------
-template <typename TG = float, typename TZ = float, typename TD = float>
-__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
-    const TG* __restrict__ dA, const TZ* __restrict__ Z, const float* __restrict__ scale,
-    const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ invstd, const float* __restrict__ dgamma,
-    const float* __restrict__ dbeta, TD* __restrict__ dZ, float* __restrict__ colsum_part,
-    int64_t batch, int W, int row_chunk, DropoutSrc drop, int64_t norm_batch,
-    float* __restrict__ amax_part) {
-  BLH_EW_PRIO();
-  __shared__ __attribute__((aligned(16))) float red[4 * 256];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int col0 = blockIdx.x * EW_COLS_PER_BLOCK;
-  const int col = col0 + lane * 4;
-  const bool ok = col < W;
-  const int cc = ok ? col : 0;
-  const float4 sc = ld4(scale + cc), sh = ld4(shift + cc), mu = ld4(mean + cc),
-               is = ld4(invstd + cc);
-  const float inv_b = 1.0f / (float)norm_batch;   // rows the statistics were taken over
-  float4 c1 = ld4(dbeta + cc), c2 = ld4(dgamma + cc);
-  c1.x *= inv_b; c1.y *= inv_b; c1.z *= inv_b; c1.w *= inv_b;
-  c2.x *= inv_b; c2.y *= inv_b; c2.z *= inv_b; c2.w *= inv_b;
-  const int64_t r0 = (int64_t)blockIdx.y * row_chunk;
-  const int64_t r1 = min(batch, r0 + row_chunk);
-  float4 cs = make_float4(0, 0, 0, 0);
-  float am = 0.f;
-  if (ok)
-    for (int64_t base = r0; base < r1; base += PATCH_ROWS) {
-      float4 z[ROWS_PER_LANE], g[ROWS_PER_LANE];
-#pragma unroll
-      for (int i = 0; i < ROWS_PER_LANE; ++i) {
-        const int64_t r = base + w + 4 * i;
-        z[i] = (r < batch) ? ld4(Z + r * W + col) : make_float4(0, 0, 0, 0);
-        g[i] = (r < batch) ? ld4(dA + r * W + col) : make_float4(0, 0, 0, 0);
-      }
-      const PatchMask pm = patch_mask(drop, base, w, col, W, batch);
-#pragma unroll
-      for (int i = 0; i < ROWS_PER_LANE; ++i) {
-        const int64_t r = base + w + 4 * i;
-        const float4 dy = dropout_relu_bwd(g[i], z[i], sc, sh, pm.nib[i]);
-        float4 o;   // scale = gamma*invstd
-        o.x = sc.x * (dy.x - c1.x - ((z[i].x - mu.x) * is.x) * c2.x);
-        o.y = sc.y * (dy.y - c1.y - ((z[i].y - mu.y) * is.y) * c2.y);
-        o.z = sc.z * (dy.z - c1.z - ((z[i].z - mu.z) * is.z) * c2.z);
-        o.w = sc.w * (dy.w - c1.w - ((z[i].w - mu.w) * is.w) * c2.w);
-        if (r < batch) {
-          o = as_stored(dZ, o);     // the Linear-bias gradient sums what the wgrad GEMM will read
-          cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
-          st4(dZ + r * W + col, o);
-          am = amax4(am, o);
-        }
-      }
-    }
-  block_colsum_store(cs, red, colsum_part + (int64_t)blockIdx.y * W, col0, W);
-  if (amax_part) wave_amax_store(am, amax_part);
-}
-
-int launch_bn_bwd_apply(hipStream_t s, const float* dA, const float* Z, const float* scale,
-                        const float* shift, const float* mean, const float* invstd,
-                        const float* gamma, const float* dgamma, const float* dbeta, float* dZ,
-                        float* dz_colsum_part, int64_t batch, int W, const DropoutSrc& drop,
-                        int64_t norm_batch, float* amax_part) {
-  (void)gamma;
-  launch_kernel(bn_bwd_apply_kernel<float, float, float>, ew_grid(batch, W), dim3(EW_THREADS), 0, s, dA, Z, scale,
-                     shift, mean, invstd, dgamma, dbeta, dZ, dz_colsum_part, batch, W,
-                     ew_row_chunk(batch), drop, norm_batch, amax_part);
-  BLH_HIP_TRY(hipGetLastError());
-  return BLH_OK;
-}
-
-int launch_bn_bwd_apply_t(hipStream_t s, const void* dA, int gt, const void* Z, int zt,
-                          const float* scale, const float* shift, const float* mean,
-                          const float* invstd, const float* dgamma, const float* dbeta, void* dZ,
-                          int dt, float* dz_colsum_part, int64_t batch, int W,
-                          const DropoutSrc& drop, int64_t norm_batch) {
-  if (gt == ET_F32 && zt == ET_F32 && dt == ET_F32)
-    return launch_bn_bwd_apply(s, (const float*)dA, (const float*)Z, scale, shift, mean, invstd, nullptr,
-                               dgamma, dbeta, (float*)dZ, dz_colsum_part, batch, W, drop, norm_batch);
-  if (gt != ET_BF16 || zt != ET_BF16) return BLH_ERR_INVALID_ARGUMENT;
-  const dim3 grid = ew_grid(batch, W), block(EW_THREADS);
-  if (dt == ET_BF16 && W % 8 == 0)
-    launch_kernel(bn_bwd_apply_h_kernel, ew_grid_h(batch, W), block, 0, s, (const bf16_bits*)dA,
-                  (const bf16_bits*)Z, scale, shift, mean, invstd, dgamma, dbeta, (bf16_bits*)dZ,
-                  dz_colsum_part, batch, W, ew_row_chunk_h(batch), drop, norm_batch);
-  else if (dt == ET_BF16)
-    return BLH_ERR_SHAPE;
-  else
-    launch_kernel(bn_bwd_apply_kernel<bf16_bits, bf16_bits, float>, grid, block, 0, s,
-                  (const bf16_bits*)dA, (const bf16_bits*)Z, scale, shift, mean, invstd, dgamma, dbeta,
-                  (float*)dZ, dz_colsum_part, batch, W, ew_row_chunk(batch), drop, norm_batch,
-                  (float*)nullptr);
-  BLH_HIP_TRY(hipGetLastError());
-  return BLH_OK;
-}
 
 // ---------------------------------------------------------------------------
 // out = sum of `splits` slabs (split-K partial products of the wgrad GEMM)

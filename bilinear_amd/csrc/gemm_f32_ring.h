@@ -161,7 +161,13 @@ __device__ __forceinline__ void ring_wait_vm_lgkm() {
 // 143.1 k: no single part explains the last 6 % (round 1 measured 33.4 cycles per 32-cycle bf16 MFMA in a loop of
 // MFMAs and fragment reads only: back-to-back issue itself sits ~4 % above the instruction's pass count).
 // STAMP 6 (MFMAs only): 134.6 k cycles, 62.8 us per launch = the ceiling of this launch shape (0.87 of peak).
-template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int BKT = 32, int STAGES = 3, int STAMP = 0>
+// PRE (experiment, tools/k3_bench; never 1 in the library): SURVEY K3 "normalise on load" — the A
+// operand is the PRE-BatchNorm tensor Z of the producing stage and BatchNorm-apply + ReLU (+ the
+// dropout factor 2) run on the A fragments between the LDS read and the MFMAs, with the per-feature
+// (= per k) scale / shift in an LDS table behind the ring (p.bn_gamma = 2 scale, p.bn_beta = 2 shift).
+// Measured at M = 4096, N = K = 1024 (profiles/r03_k3_normalise_on_load.md).
+template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int BKT = 32, int STAGES = 3, int STAMP = 0,
+          int PRE = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_ring_kernel(GemmParams p) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -205,6 +211,31 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_ring_kernel(GemmParams 
   planB.init(p.B, p.ldb, n0, p.N, kz0, k_end, tid);
   float fa[2][TM][4], fb[2][TN][4];
   if (STAMP) { stamp_c0 = __builtin_amdgcn_s_memtime(); stamp_r0 = __builtin_amdgcn_s_memrealtime(); }
+  // PRE: scale / shift table [2][K] behind the ring, per-lane prefetch registers for one k-group
+  float* pre_tab = smem + STAGES * RING;
+  float4 psc[2], psh[2];
+  if (PRE) {
+    for (int k = tid; k < p.K; k += NT) { pre_tab[k] = p.bn_gamma[k]; pre_tab[p.K + k] = p.bn_beta[k]; }
+    __syncthreads();
+  }
+  auto pre_load = [&](int buf, int kbase) {   // this lane's 4 k of the k-group starting at kbase
+    if (PRE) {
+      const int k = min(kbase + 4 * (lane >> 5), p.K - 4);
+      psc[buf] = *reinterpret_cast<const float4*>(pre_tab + k);
+      psh[buf] = *reinterpret_cast<const float4*>(pre_tab + p.K + k);
+    }
+  };
+  auto pre_apply = [&](int buf) {
+    if (PRE) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        fa[buf][i][0] = fmaxf(fmaf(fa[buf][i][0], psc[buf].x, psh[buf].x), 0.f);
+        fa[buf][i][1] = fmaxf(fmaf(fa[buf][i][1], psc[buf].y, psh[buf].y), 0.f);
+        fa[buf][i][2] = fmaxf(fmaf(fa[buf][i][2], psc[buf].z, psh[buf].z), 0.f);
+        fa[buf][i][3] = fmaxf(fmaf(fa[buf][i][3], psc[buf].w, psh[buf].w), 0.f);
+      }
+    }
+  };
 
   // prologue: tiles 0 .. STAGES-2 in flight; wait for tile 0 only
   if (nkt > 0) {
@@ -222,6 +253,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_ring_kernel(GemmParams 
     asm volatile("" ::: "memory");
     ring_read_frags<LA, BM, TM, BKT>(fa[0], smem, wm * (TM * 32), 0, lane);
     ring_read_frags<LB, BN, TN, BKT>(fb[0], smem + BM * BKT, wn * (TN * 32), 0, lane);
+    pre_load(0, kz0);
   }
   // One k-group: issue the fragment reads of the NEXT group, then the MFMAs of this one.
   // The order is pinned with sched_barrier: left alone, hipcc sinks the ds_reads below the MFMAs
@@ -265,11 +297,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_ring_kernel(GemmParams 
       } else if (s < NG - 1) {
         ring_read_frags<LA, BM, TM, BKT>(fa[nxt], sA, wm * (TM * 32), s + 1, lane);
         ring_read_frags<LB, BN, TN, BKT>(fb[nxt], sB, wn * (TN * 32), s + 1, lane);
+        pre_load(nxt, kz0 + kt * BKT + 8 * (s + 1));
       } else {
         ring_read_frags<LA, BM, TM, BKT>(fa[nxt], nA, wm * (TM * 32), 0, lane);
         ring_read_frags<LB, BN, TN, BKT>(fb[nxt], nA + BM * BKT, wn * (TN * 32), 0, lane);
+        pre_load(nxt, kz0 + (kt + 1) * BKT);
       }
       __builtin_amdgcn_sched_barrier(0);
+      pre_apply(cur);
       BLH_RING_MFMAS(cur)
       __builtin_amdgcn_sched_barrier(0);
       if (s == NG - 2) {
@@ -297,8 +332,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_ring_kernel(GemmParams 
       if (s < NG - 1) {
         ring_read_frags<LA, BM, TM, BKT>(fa[nxt], sA, wm * (TM * 32), s + 1, lane);
         ring_read_frags<LB, BN, TN, BKT>(fb[nxt], sB, wn * (TN * 32), s + 1, lane);
+        pre_load(nxt, kz0 + (nkt - 1) * BKT + 8 * (s + 1));
       }
       __builtin_amdgcn_sched_barrier(0);
+      pre_apply(cur);
       BLH_RING_MFMAS(cur)
       __builtin_amdgcn_sched_barrier(0);
     }

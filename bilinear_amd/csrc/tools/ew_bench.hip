@@ -2,8 +2,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include "../elementwise.hip"
+#include "../bn_f32.hip"
+#include "../bn_bf16.hip"
 using namespace blh;
 thread_local int blh::g_last_hip_error = 0;
+thread_local hipEvent_t blh::tl_stop_event = nullptr;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
 __global__ void copy4(const float4* __restrict__ a, float4* __restrict__ b, size_t n) {
@@ -27,32 +30,33 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&Z, n * 4)); CK(hipMalloc(&A, n * 4)); CK(hipMalloc(&S, n * 4)); CK(hipMalloc(&G, n * 4));
   CK(hipMalloc(&vec, 8 * W * 4)); CK(hipMalloc(&part, (size_t)512 * 2 * W * 4));
   CK(hipMemset(Z, 0, n * 4)); CK(hipMemset(S, 0, n * 4)); CK(hipMemset(G, 0, n * 4)); CK(hipMemset(vec, 0, 8 * W * 4));
-  DropoutSrc d{nullptr, 1, 2, 0, 1};
+  DropoutSrc d{nullptr, 1, 2, 0, 1, nullptr};
+  uint32_t* kb; CK(hipMalloc(&kb, bn_keepbits_words_f32(B, W) * 4));
   const double mb = n * 4 / 1e6;
   float t;
   t = timeit([&] { hipLaunchKernelGGL(copy4, dim3(2048), dim3(256), 0, 0, (const float4*)Z, (float4*)A, n / 4); });
   printf("copy4 (2048 blocks)        %7.1f us  %6.2f TB/s\n", t, 2 * mb / t);
   t = timeit([&] { hipLaunchKernelGGL(copy4, dim3(512), dim3(256), 0, 0, (const float4*)Z, (float4*)A, n / 4); });
   printf("copy4 (512 blocks)         %7.1f us  %6.2f TB/s\n", t, 2 * mb / t);
-  t = timeit([&] { launch_bn_apply_train(0, Z, vec, vec + W, nullptr, A, B, W, d, nullptr); });
+  t = timeit([&] { launch_bn_apply_f2(0, true, Z, vec, vec + W, nullptr, nullptr, nullptr, nullptr, nullptr, A, kb, B, W, d, nullptr); });
   printf("bn_apply philox            %7.1f us  %6.2f TB/s\n", t, 2 * mb / t);
   uint8_t* keep; CK(hipMalloc(&keep, n)); CK(hipMemset(keep, 1, n));
-  DropoutSrc dk{keep, 0, 0, 0, 1};
-  t = timeit([&] { launch_bn_apply_train(0, Z, vec, vec + W, nullptr, A, B, W, dk, nullptr); });
+  DropoutSrc dk{keep, 0, 0, 0, 1, nullptr};
+  t = timeit([&] { launch_bn_apply_f2(0, true, Z, vec, vec + W, nullptr, nullptr, nullptr, nullptr, nullptr, A, kb, B, W, dk, nullptr); });
   printf("bn_apply explicit mask     %7.1f us  %6.2f TB/s\n", t, 2.25 * mb / t);
   for (int rep = 0; rep < 3; ++rep) {
-    t = timeit([&] { launch_bn_apply_train(0, Z, vec, vec + W, nullptr, A, B, W, d, nullptr); }, 200);
+    t = timeit([&] { launch_bn_apply_f2(0, true, Z, vec, vec + W, nullptr, nullptr, nullptr, nullptr, nullptr, A, kb, B, W, d, nullptr); }, 200);
     printf("bn_apply philox x200       %7.1f us\n", t);
   }
   t = timeit([&] { launch_dropout_mask(0, keep, B, W, d); });
   printf("dropout_mask kernel        %7.1f us\n", t);
-  t = timeit([&] { launch_bn_apply_train(0, Z, vec, vec + W, S, A, B, W, d, nullptr); });
+  t = timeit([&] { launch_bn_apply_f2(0, true, Z, vec, vec + W, nullptr, nullptr, nullptr, nullptr, S, A, kb, B, W, d, nullptr); });
   printf("bn_apply philox + skip     %7.1f us  %6.2f TB/s\n", t, 3 * mb / t);
-  t = timeit([&] { launch_bn_apply_eval(0, Z, vec, vec + W, vec + 2 * W, vec + 3 * W, nullptr, A, B, W); });
+  t = timeit([&] { launch_bn_apply_f2(0, false, Z, nullptr, nullptr, vec, vec + W, vec + 2 * W, vec + 3 * W, nullptr, A, nullptr, B, W, d, nullptr); });
   printf("bn_apply eval (no philox)  %7.1f us  %6.2f TB/s\n", t, 2 * mb / t);
-  t = timeit([&] { launch_bn_bwd_reduce(0, G, Z, vec, vec + W, vec + 2 * W, vec + 3 * W, part, B, W, d); });
+  t = timeit([&] { launch_bn_bwd_reduce_f2(0, G, Z, vec, vec + W, kb, part, B, W); });
   printf("bn_bwd_reduce              %7.1f us  %6.2f TB/s\n", t, 2 * mb / t);
-  t = timeit([&] { launch_bn_bwd_apply(0, G, Z, vec, vec + W, vec + 2 * W, vec + 3 * W, vec, vec + 4 * W, vec + 5 * W, A, part, B, W, d); });
+  t = timeit([&] { launch_bn_bwd_apply_f2(0, G, Z, vec, vec + W, vec + 2 * W, vec + 3 * W, vec + 4 * W, vec + 5 * W, kb, A, part, B, W, B); });
   printf("bn_bwd_apply               %7.1f us  %6.2f TB/s\n", t, 3 * mb / t);
   t = timeit([&] { launch_colreduce(0, part, 128, 2 * W, 2 * W, vec + 6 * W); });
   printf("colreduce 128x%d          %7.1f us\n", 2 * W, t);

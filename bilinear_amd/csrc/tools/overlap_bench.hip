@@ -47,17 +47,18 @@ int main(int argc, char** argv) {
   d.A = dZ; d.lda = W; d.B = A; d.ldb = W; d.C = copy_dst; d.ldc = W; d.M = M; d.N = W; d.K = W; d.k_per_split = W;
 
   DropoutSrc philox{}; philox.keep = nullptr; philox.seed = 7; philox.step = 3; philox.layer = 2;
-  DropoutSrc mask = philox; mask.keep = keep;
+  DropoutSrc mask = philox; mask.keep = keep; (void)mask;
+  uint32_t* keepbits; CK(hipMalloc(&keepbits, bn_keepbits_words_f32(M, W) * 4)); CK(hipMemset(keepbits, 0x5a, bn_keepbits_words_f32(M, W) * 4));
   const float *scale = vec, *shift = vec + W, *mean = vec + 2 * W, *invstd = vec + 3 * W, *gamma = vec + 4 * W,
               *dgamma = vec + 5 * W, *dbeta = vec + 6 * W;
 
   auto probe = [&](int which) {
     switch (which) {
       case 0: CK(hipMemcpyAsync(copy_dst, dA, act * 4, hipMemcpyDeviceToDevice, sb)); break;
-      case 1: launch_bn_bwd_apply(sb, dA, Z, scale, shift, mean, invstd, gamma, dgamma, dbeta, copy_dst, colsum, M, W, mask, M); break;
-      case 2: launch_bn_bwd_apply(sb, dA, Z, scale, shift, mean, invstd, gamma, dgamma, dbeta, copy_dst, colsum, M, W, philox, M); break;
-      case 3: launch_bn_bwd_reduce(sb, dA, Z, scale, shift, mean, invstd, part, M, W, philox); break;
-      case 4: launch_bn_apply_train(sb, Z, scale, shift, nullptr, copy_dst, M, W, philox, nullptr); break;
+      case 1: launch_bn_bwd_apply_f2(sb, dA, Z, scale, shift, mean, invstd, dgamma, dbeta, keepbits, copy_dst, colsum, M, W, M); break;
+      case 2: launch_bn_bwd_apply_f2(sb, dA, Z, scale, shift, mean, invstd, dgamma, dbeta, keepbits, copy_dst, colsum, M, W, M); break;
+      case 3: launch_bn_bwd_reduce_f2(sb, dA, Z, scale, shift, keepbits, part, M, W); break;
+      case 4: launch_bn_apply_f2(sb, true, Z, scale, shift, nullptr, nullptr, nullptr, nullptr, nullptr, copy_dst, keepbits, M, W, philox, nullptr); break;
     }
   };
   const char* names[] = {"copy [B,W] D2D", "bn_bwd_apply (mask)", "bn_bwd_apply (Philox)", "bn_bwd_reduce (Philox)", "bn_apply train (Philox)"};
