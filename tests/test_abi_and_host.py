@@ -156,3 +156,30 @@ def test_host_layout_logic_under_sanitizers():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "host sanitize ok" in out.stdout
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr
+
+
+def test_custom_ops_trace_through_their_fake_implementations():
+    """torch.ops.bilinear_hip.* carry shape functions (register_fake): under FakeTensorMode — what
+    torch.compile / export trace with — every operator returns tensors of the right shape and
+    dtype without touching a device (no kernel runs: there is no CPU implementation at all)."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+
+    import bilinear_amd.ops  # noqa: F401  (registers the operators)
+    with FakeTensorMode():
+        B, W, total = 64, 1024, 4291840
+        x = torch.empty(B, 32)
+        t = torch.empty(B, 48)
+        params, grads, m, v = (torch.empty(total) for _ in range(4))
+        running = torch.empty(5, 2, W)
+        nbt = torch.empty(5, dtype=torch.int64)
+        ws = torch.empty(1 << 20, dtype=torch.uint8)
+        stats = torch.empty(2)
+        pred = torch.ops.bilinear_hip.eval_fwd(x, params, running, ws, 0, 2, W, 0)
+        assert tuple(pred.shape) == (B, 48) and pred.dtype == torch.float32
+        pred = torch.ops.bilinear_hip.forward_train(x, params, running, nbt, ws, None, 0, 2, W, 0, 1, 0, 0, 0.1)
+        assert tuple(pred.shape) == (B, 48)
+        assert torch.ops.bilinear_hip.backward(x, pred, params, ws, grads, None, 0, 2, W, 0, 1, 0, 0) is None
+        pred, loss = torch.ops.bilinear_hip.train_step(x, t, params, grads, m, v, running, nbt, ws, stats, None,
+                                                       0, 2, W, 0, 1, 0, 0, 0.1, 1e-3, 0.9, 0.999, 1e-8, 1.0, 1)
+        assert tuple(pred.shape) == (B, 48) and tuple(loss.shape) == ()

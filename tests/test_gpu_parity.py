@@ -1007,3 +1007,43 @@ def test_fp16x2_mode_keeps_fp32_accuracy_when_magnitudes_move(loss_scale, gamma_
         g = p.grad.cpu().numpy()
         assert np.isfinite(g).all(), k
         _close(g, ref_grads[k], TIGHT * 3, "grad " + k)
+
+
+# ----------------------------------------------------------------------------
+# torch.compile: the fused step as a custom operator inside a compiled function
+# ----------------------------------------------------------------------------
+def test_train_step_operator_under_torch_compile_fullgraph():
+    """``torch.ops.bilinear_hip.train_step`` inside ``torch.compile(fullgraph=True)``: dynamo traces
+    through the operator's fake implementation (no graph break) and the compiled function runs the
+    same native step as the eager call, bit for bit."""
+    import bilinear_amd
+    dev = _dev()
+    x = torch.randn(256, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    t = torch.randn(256, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+
+    def make():
+        torch.manual_seed(3)
+        net, opt, _, _ = bilinear_amd.load(dev, num_blocks=1, width=256)
+        net.train()
+        eng = net.engine
+        eng.ensure(dev)
+        eng.seed = 11
+        opt._ensure_moments(eng)
+        return net, opt, eng
+
+    def step(x, t, params, grads, m, v, running, nbt, ws, stats, args):
+        return torch.ops.bilinear_hip.train_step(x, t, params, grads, m, v, running, nbt, ws, stats, None, *args)
+
+    outs = []
+    for compiled in (False, True):
+        net, opt, eng = make()
+        ws = eng.workspace(256)
+        args = eng._op_args() + (eng.seed, 0, 0, 0.1, 1e-3, 0.9, 0.999, 1e-8, 1.0, 1)
+        fn = torch.compile(step, fullgraph=True, backend="aot_eager") if compiled else step
+        with torch.no_grad():
+            pred, loss = fn(x, t, eng.params, eng.grads, opt._exp_avg, opt._exp_avg_sq, eng.bn_running,
+                            eng.bn_nbt, ws, opt._stats, args)
+        torch.cuda.synchronize()
+        outs.append((pred.clone(), loss.clone(), eng.params.clone(), opt._exp_avg_sq.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
