@@ -32,7 +32,7 @@ struct blh_context {
   hipEvent_t ev_dz[BLH_CTX_EVENTS], ev_w[BLH_CTX_EVENTS], ev_r[BLH_CTX_EVENTS];
   bool two_stream = true;
   bool defer_slabs = false;
-  bool late_fork = true;    // BLH_OPT_LATE_FORK
+  int late_fork = 2;        // BLH_OPT_LATE_FORK: 0 early, 1 late, 2 auto
   // per-call state (set by the entry point for the duration of the call)
   blh::SyncCtx sync = {nullptr, nullptr, 0};
   const uint64_t* step_dev = nullptr;
@@ -241,6 +241,15 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
   // two streams: on by default (-3 % step)
   const bool two = ctx->two_stream && !ctx->sync.fn && !defer && small_m_splits(batch, W, W).splits == 1;
   hipStream_t s2 = two ? ctx->s2 : s;
+  // auto (fp32 kernels): early.  The data-gradient launch fills the chip's LDS — 256 workgroups of the
+  // 128 KB form (gemm_f32_backward_exclusive) or >= 512 of the 64 KB form — so the weight gradient
+  // cannot become resident beside it: the dispatcher places its workgroups as the data gradient's
+  // retire, nothing waits for a cross-queue signal, and the BatchNorm chain of the next stage runs
+  // beside the weight gradient.  Measured early vs late: B 2048 0.80 / 0.87, B 4096 1.032 / 1.054,
+  // B 8192 1.88 / 1.98, B 16384 3.59 / 3.62 ms (profiles/r03_backward_schedule.md).  The split-
+  // precision modes keep the late fork they were measured with.
+  bool late_policy = ctx->late_fork != 0;
+  if (ctx->late_fork == 2 && d->gemm_dtype == 0) late_policy = false;
   SyncCtx& g_sync = ctx->sync;
   blh_context& g_side = *ctx;
   // Fork: s2 continues behind a kernel of s.  Outside stream capture the event rides on that
@@ -346,7 +355,7 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
     // there only adds two cross-queue latencies at the very end of backward) unless the
     // data-parallel hook wants every range complete on the side stream.
     const bool side = two && (i > 0 || on_ready != nullptr);
-    const bool fork_late = side && ctx->late_fork && i > 0 && small_m_splits(batch, W, W).splits == 1;
+    const bool fork_late = side && late_policy && i > 0 && small_m_splits(batch, W, W).splits == 1;
     hipStream_t sw = side ? s2 : s;
     if (side && !fork_late) arm_fork(i);
     BLH_TRY(launch_bn_bwd_apply_f2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W, dg, db, ws.keep[i],
@@ -550,6 +559,16 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
   const int nh = (int)L.heavy.size();
   const int W = d->width, OF = d->out_features, IF = d->in_features;
   const int chunks = ew_num_row_chunks_h(batch);
+  // BLH_OPT_LATE_FORK auto, as in backward_impl: early when the data-gradient launch is one round of
+  // workgroups (256 of the 256x256 kernel, 512 of the 128x128 one; configs[2], configs[3] per GPU),
+  // late when it is several (configs[4]: 7.78 against 7.91 ms)
+  bool late_policy = ctx->late_fork != 0;
+  if (ctx->late_fork == 2) {
+    GemmParamsH gp{};
+    gp.M = (int)batch; gp.N = W; gp.K = W; gp.k_per_split = W; gp.lda = gp.ldb = gp.ldc = W;
+    const int tile = gemm_bf16s_pick_tile(ROWK, KROW, true, gp, 1);
+    late_policy = ceil_div(batch, tile) * ceil_div(W, tile) > (tile == 256 ? 256 : 512);
+  }
   // Two streams as in backward_impl: every weight-gradient GEMM (+ its slab sum) runs on the
   // context's side stream — in order there, so they share one slab buffer — forked behind the
   // data-gradient GEMM of its stage (BLH_OPT_LATE_FORK) or behind bn_bwd_apply; one join at the end.
@@ -618,7 +637,7 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
                                      ws.dZ[i], ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W,
                                      norm_batch));
     }
-    const bool late = two && ctx->late_fork && i > 0;
+    const bool late = two && late_policy && i > 0;
     if (two && !late) BLH_TRY(fork_wait(i, false));       // behind bn_bwd_apply (marker event)
     // (data parallel: the bucket hook needs this stage's bias gradient now; otherwise all stages
     //  are reduced by one launch after the loop, as in backward_impl)
@@ -708,7 +727,7 @@ int blh_context_create(blh_context** out) {
   // A/B switches for experiments (the documented way is blh_context_set_option)
   c->two_stream = getenv("BLH_ONE_STREAM") == nullptr;
   c->defer_slabs = getenv("BLH_DEFER_SLABS") != nullptr;
-  c->late_fork = getenv("BLH_EARLY_FORK") == nullptr;
+  c->late_fork = getenv("BLH_EARLY_FORK") ? 0 : (getenv("BLH_LATE_FORK") ? 1 : 2);
   *out = c;
   return BLH_OK;
 }
@@ -730,7 +749,10 @@ int blh_context_set_option(blh_context* c, int32_t option, int32_t value) {
   switch (option) {
     case BLH_OPT_TWO_STREAM: c->two_stream = value != 0; return BLH_OK;
     case BLH_OPT_DEFER_SLABS: c->defer_slabs = value != 0; return BLH_OK;
-    case BLH_OPT_LATE_FORK: c->late_fork = value != 0; return BLH_OK;
+    case BLH_OPT_LATE_FORK:
+      if (value < 0 || value > 2) return BLH_ERR_INVALID_ARGUMENT;
+      c->late_fork = value;
+      return BLH_OK;
     case BLH_OPT_PERSISTENT_SHADOW:
       c->persistent_shadow = value != 0;
       c->shadow_params = c->shadow_ws = nullptr;
@@ -744,7 +766,7 @@ int blh_context_get_option(const blh_context* c, int32_t option) {
   switch (option) {
     case BLH_OPT_TWO_STREAM: return c->two_stream ? 1 : 0;
     case BLH_OPT_DEFER_SLABS: return c->defer_slabs ? 1 : 0;
-    case BLH_OPT_LATE_FORK: return c->late_fork ? 1 : 0;
+    case BLH_OPT_LATE_FORK: return c->late_fork;
     case BLH_OPT_PERSISTENT_SHADOW: return c->persistent_shadow ? 1 : 0;
   }
   return BLH_ERR_INVALID_ARGUMENT;

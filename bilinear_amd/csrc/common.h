@@ -45,6 +45,9 @@ static inline void launch_kernel(K kern, dim3 grid, dim3 block, size_t lds, hipS
 
 
 // ---------------------------------------------------------------- GEMM -----
+// fp32 backward GEMMs: does a launch of `wgs` 128x128 workgroups take the one-workgroup-per-CU
+// (128 KB LDS) form?  (gemm_f32.hip; the backward scheduler forks early when it does)
+bool gemm_f32_backward_exclusive(int64_t wgs, int K, int k_per_launch_slice);
 enum Layout : int { ROWK = 0, KROW = 1 };
 enum Epilogue : int {
   EPI_STORE = 0,       // C = acc                         (split-K slabs, plain)

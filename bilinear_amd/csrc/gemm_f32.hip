@@ -36,6 +36,19 @@ static int ensure_lds_attr(std::atomic<uint64_t>& done, const void* kern, size_t
 //     vs 132.1 us).
 static constexpr int RING_BKT_SKINNY = 32, RING_STAGES_SKINNY = 3;
 
+// The backward pair (data gradient on the main stream, weight gradient on the side stream).  When each
+// of the two launches is at most one workgroup per CU (B x W <= 4 Mi at 128x128 tiles), both take the
+// 128 KB form: they cannot share a CU, so the workgroup dispatcher itself serialises them — the
+// weight-gradient workgroups are placed CU by CU as the data-gradient workgroups retire (no cross-queue
+// latency, no 50/50 split of a CU's matrix pipes), each GEMM runs at its solo rate and the HBM-bound
+// BatchNorm-backward chain of the next stage runs beside the weight gradient.  Step 1.035 against
+// 1.057 ms at configs[1] (profiles/r03_backward_schedule.md).  BLH_F32_BWD_EXCL=0: the 64 KB form
+// everywhere (A/B knob).
+bool gemm_f32_backward_exclusive(int64_t wgs, int K, int k_per_launch_slice) {
+  static const bool off = [] { const char* e = getenv("BLH_F32_BWD_EXCL"); return e && e[0] == '0'; }();
+  return !off && wgs <= 256 && K > 32 && (k_per_launch_slice % 64) == 0;
+}
+
 template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI, int BKT, int STAGES>
 static int launch_ring(hipStream_t s, const GemmParams& p, int splits) {
   constexpr int NT = 64 * WM * WN;
@@ -58,6 +71,10 @@ static int launch_cfg(hipStream_t s, const GemmParams& p, int splits) {
     const bool forward = (LA == ROWK && LB == ROWK);
     // (K <= 32, the encode Linear: a 64-deep K tile would be half zero page)
     if (forward && wgs <= 256 && p.K > 32) return launch_ring<BM, BN, WM, WN, LA, LB, EPI, 64, 2>(s, p, splits);
+    // backward GEMMs of a launch that covers the chip once: also the one-workgroup-per-CU form, see
+    // gemm_f32_backward_exclusive()
+    if (!forward && gemm_f32_backward_exclusive(wgs, p.K, splits > 1 ? p.k_per_split : p.K))
+      return launch_ring<BM, BN, WM, WN, LA, LB, EPI, 64, 2>(s, p, splits);
     return launch_ring<BM, BN, WM, WN, LA, LB, EPI, 32, 2>(s, p, splits);
   } else {
     return launch_ring<BM, BN, WM, WN, LA, LB, EPI, RING_BKT_SKINNY, RING_STAGES_SKINNY>(s, p, splits);

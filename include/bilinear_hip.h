@@ -74,9 +74,12 @@ typedef enum {
                              0: single-stream order.  Results are bit-identical either way.  */
   BLH_OPT_DEFER_SLABS = 1, /* 1: sum all split-K weight-gradient slabs in one launch at the end
                               of backward (default 0: right after each GEMM)                 */
-  BLH_OPT_LATE_FORK = 2,  /* 1 (default): a stage's weight-gradient GEMM starts behind its
-                             data-gradient GEMM and runs beside the next stage's BatchNorm
-                             backward; 0: it starts together with the data-gradient GEMM.
+  BLH_OPT_LATE_FORK = 2,  /* when a stage's weight-gradient GEMM is handed to the side stream.
+                             1: behind its data-gradient GEMM (it runs beside the next stage's
+                             BatchNorm backward); 0: behind bn_bwd_apply, together with the
+                             data-gradient GEMM; 2 (default): 0 where both GEMMs are launches of
+                             at most one 128 KB-LDS workgroup per CU — the dispatcher then runs
+                             them one after the other without a cross-queue latency — else 1.
                              Scheduling only: results are bit-identical.                     */
   BLH_OPT_PERSISTENT_SHADOW = 3
                           /* gemm_dtype 4 only, default 0.  1: the Adam kernel of blh_train_step /

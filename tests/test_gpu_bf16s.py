@@ -296,7 +296,7 @@ def test_bf16s_backward_schedules_are_bit_identical():
     x, t = (torch.randn(8192, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(3)),
             torch.randn(8192, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(4)))
     out = {}
-    for sched in ((True, 1), (True, 0), (False, 1)):
+    for sched in ((True, 1), (True, 0), (True, 2), (False, 1)):
         torch.manual_seed(0)
         net, opt, _, _ = bilinear_amd.load(dev, num_blocks=2, width=1024, gemm_dtype="bf16s")
         net.train()
@@ -313,7 +313,7 @@ def test_bf16s_backward_schedules_are_bit_identical():
         torch.cuda.synchronize()
         out[sched] = (pred.clone(), net.engine.params.clone(), opt._exp_avg_sq.clone(),
                       net.engine.grads.clone(), p3.detach().clone())
-    for other in ((True, 0), (False, 1)):
+    for other in ((True, 0), (True, 2), (False, 1)):
         for a, b, what in zip(out[(True, 1)], out[other], ("pred", "params", "exp_avg_sq", "grads", "pred3")):
             assert torch.equal(a, b), (other, what)
     assert torch.isfinite(out[(True, 1)][3]).all()

@@ -318,8 +318,8 @@ def test_one_stream_and_two_stream_schedules_are_bit_identical(mode):
     xt, tt = torch.from_numpy(entry["x"]).to(dev), torch.from_numpy(entry["t"]).to(dev)
     from bilinear_amd import _native as N
     out = {}
-    # (two streams, late fork) = the default; (two streams, early fork); single stream
-    for sched in ((True, 1), (True, 0), (False, 1)):
+    # two streams: late fork, early fork, auto (the default: api.hip picks per shape); single stream
+    for sched in ((True, 1), (True, 0), (True, 2), (False, 1)):
         net, opt = _build(entry["st0"], dev, nb, width, mode)
         net.engine.set_two_stream(sched[0])
         net.engine.ctx.set_option(N.OPT_LATE_FORK, sched[1])
@@ -329,7 +329,7 @@ def test_one_stream_and_two_stream_schedules_are_bit_identical(mode):
         torch.cuda.synchronize()
         out[sched] = (pred.clone(), net.engine.grads.clone(), net.engine.params.clone(),
                       opt._exp_avg_sq.clone(), net.engine.bn_running.clone())
-    for other in ((True, 0), (False, 1)):
+    for other in ((True, 0), (True, 2), (False, 1)):
         for a, b, what in zip(out[(True, 1)], out[other], ("pred", "grads", "params", "exp_avg_sq", "running")):
             assert torch.equal(a, b), (other, what)
 
