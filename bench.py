@@ -556,6 +556,10 @@ def main():
     ap.add_argument("--persistent-shadow", action="store_true",
                     help="bf16s: Adam writes the bf16 weight image, the next step skips the arena re-cast "
                          "(Engine.set_persistent_shadow; opt-in contract, see its docstring)")
+    ap.add_argument("--rehearse-rccl", action="store_true",
+                    help="developer: at --gpus 1, run the multi-GPU code path (RCCL group of one rank, "
+                         "data-parallel driver with every collective issued) — what the step costs before "
+                         "the wire; the line says so in config.parallelism")
     ap.add_argument("--no-configs", action="store_true",
                     help="N=1, default config: skip the per-config blocks (configs[2], per-GPU shapes of "
                          "configs[3] and configs[4])")
@@ -585,18 +589,28 @@ def main():
     rehearse = os.environ.get("BLH_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
+    multi = world > 1 or args.rehearse_rccl
+    if args.rehearse_rccl:
+        if world != 1:
+            raise SystemExit("--rehearse-rccl is a --gpus 1 mode")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     import bilinear_amd
     from bilinear_amd.dp import DataParallel
 
-    # Model state, optimiser moments, workspace and the batch are allocated BEFORE the RCCL
-    # communicator exists.  Measured on the one-GPU box (world-size-1 RCCL group):
-    # the same step runs 10 % slower (1.17 vs 1.06 ms) for as long as the process lives when its
-    # tensors are the first allocations made after an eager init_process_group("nccl", device_id=...),
-    # and at full speed when they exist beforehand (or when 512 MB of something else is allocated
-    # in between): whatever RCCL sets up taints the memory handed out right after it.
+    # Order of set-up under RCCL: the process group first (eagerly: device_id), everything else after it.
+    # Round 2 built the model first, on a world-size-1 measurement that read 10 % slow the other way
+    # round; that was the side stream sharing a hardware queue with torch's default stream (api.hip,
+    # blh_context_create), not the allocation order.  With the model first this flow runs 2.3-3.0 ms
+    # per step instead of 1.14 (python bench.py --rehearse-rccl; profiles/r03_dp_overhead.md).
+    init_first = os.environ.get("BLH_BENCH_INIT_LAST") != "1"
+    if multi and init_first:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo") if rehearse else dist.init_process_group("nccl", device_id=dev)
     torch.manual_seed(1)          # identical init on every rank
     net, opt, step, _ = bilinear_amd.load(dev, num_blocks=args.blocks, width=args.width,
                                           gemm_dtype=args.dtype)
@@ -609,7 +623,7 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     x = torch.randn(args.batch, 32, device=dev, generator=g)
     t = torch.randn(args.batch, 48, device=dev, generator=g)
-    if world > 1:
+    if multi:
         net.engine.workspace(args.batch)      # activations / gradient staging for this batch
         opt._ensure_moments(net.engine)       # exp_avg / exp_avg_sq arenas
         strong_pre = None
@@ -624,13 +638,11 @@ def main():
             opt_s._ensure_moments(net_s.engine)
             strong_pre = (net_s, opt_s)
         torch.cuda.synchronize()
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-    dp = DataParallel(net, opt, sync_bn=args.sync_bn) if world > 1 else None
-    use_graph = (world == 1) and args.graph and not args.no_graph
+        if not init_first:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo") if rehearse else dist.init_process_group("nccl", device_id=dev)
+    dp = DataParallel(net, opt, sync_bn=args.sync_bn, force_collectives=args.rehearse_rccl) if multi else None
+    use_graph = (not multi) and args.graph and not args.no_graph
     captured = None
     if use_graph:
         captured = bilinear_amd.CapturedTrainStep(net, opt, args.batch, max_norm=1.0,
@@ -647,21 +659,25 @@ def main():
             return captured(x, t)
         return net.train_step(opt, x, t, max_norm=1.0)
 
+    # the data-parallel loops run on the driver's own high-priority stream (dp.stream: hardware queues)
+    if dp is not None and dp.stream is not None:
+        dp.stream.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(dp.stream)
     log("model built, pre-ramp + warm-up")
     ramp_ms, ramp_steps = pre_ramp(one_step, args.pre_ramp_ms)
     for _ in range(args.warmup):
         one_step()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pred, loss = one_step()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -673,10 +689,10 @@ def main():
     # split N ways): measured right here with the same barrier / max-over-ranks protocol and
     # reported as a sub-object, so one driver run per N yields both curves.
     strong = None
-    if world > 1 and strong_pre is not None:
+    if multi and strong_pre is not None:
         sb = cfg["batch"] // world
         net_s, opt_s = strong_pre
-        dp_s = DataParallel(net_s, opt_s, sync_bn=args.sync_bn)
+        dp_s = DataParallel(net_s, opt_s, sync_bn=args.sync_bn, force_collectives=args.rehearse_rccl)
         xs, ts = x[:sb].contiguous(), t[:sb].contiguous()
         n_s = max(20, min(args.steps, 300))
         for _ in range(max(5, min(args.warmup, 50))):
@@ -695,6 +711,10 @@ def main():
                   "ms_per_step": 1e3 * el / n_s, "value": sb * world * n_s / el, "unit": "poses/s"}
         log("strong scaling (global batch %d): %.3f ms/step" % (sb * world, strong["ms_per_step"]))
         del dp_s, net_s, opt_s
+
+    if dp is not None and dp.stream is not None:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
 
     # fwd+bwd only (no optimiser), single rank view, for the record
     def fwd_bwd():
@@ -737,9 +757,10 @@ def main():
                             "Kaiming-normal init",
                 "num_blocks": args.blocks, "width": args.width, "per_gpu_batch": args.batch,
                 "step": "zero_grad+forward+MSE+backward%s+clip_grad_norm(1)+Adam" % (
-                    "+allreduce(grad)" if world > 1 else ""),
+                    "+allreduce(grad)" if multi else ""),
                 "global_batch": args.batch * world,
-                "parallelism": "dp%d" % world,
+                "parallelism": "dp%d%s" % (world, " (RCCL group of one rank, every collective issued)"
+                                           if args.rehearse_rccl else ""),
                 "dropout": "philox",
                 "batchnorm": ("sync (global batch)" if args.sync_bn else "per-rank statistics") if world > 1 else "single device",
                 "launch": ("hipGraph replay (1 launch/step)" if use_graph
@@ -783,7 +804,7 @@ def main():
                 "ms_per_step": cpu["ms_per_step"],
             }
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -7,6 +7,7 @@
 #include <new>
 #include <vector>
 
+#include <mutex>
 #include "common.h"
 #include "gemm_bf16s_kernel.h"
 #include "api_layout.h"
@@ -422,14 +423,18 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
     }
   }
   // join: s2 is in order (stage 0 ran on the main stream unless the bucket hook wants the side one)
-  if (two) BLH_HIP_TRY(hipStreamWaitEvent(s, g_side.ev_w[on_ready != nullptr ? 0 : 1], 0));
-  if (!on_ready) {   // (covers the no_defer A/B mode too: its regions are all plain)
+  // (the bias reduction needs nothing from the side stream: it goes in front of the join, whose
+  //  cross-queue wait costs the main stream ~9 us even when the signal is already there)
+  if (!on_ready) {
     int64_t offs[32];
     if (nh > 32) return BLH_ERR_SHAPE;
     for (int i = 0; i < nh; ++i) offs[i] = L.heavy[i].b;
     BLH_TRY(launch_bias_colreduce(s, ws.dz_colsum_part, (int64_t)chunks * W, chunks, W, nh, offs,
                                   grads, fused ? ws.dec_bias_part : nullptr,
                                   fused ? fused->dec_bias_S : 0, OF, L.dec_b));
+  }
+  if (two) BLH_HIP_TRY(hipStreamWaitEvent(s, g_side.ev_w[on_ready != nullptr ? 0 : 1], 0));
+  if (!on_ready) {   // (covers the no_defer A/B mode too: its regions are all plain)
     // regions in arena order: [weight (slabs or plain)] [bias, gamma, beta (plain)] per stage,
     // then decode weight and decode bias (+ tail padding)
     GradRegions R{};
@@ -703,6 +708,39 @@ const char* blh_status_string(int status) {
 int blh_last_hip_error(void) { return g_last_hip_error; }
 int blh_abi_version(void) { return BLH_ABI_VERSION; }
 
+// The process-wide side streams (see blh_context_create).
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_side_mu;
+hipStream_t g_side_stream[kMaxDevices] = {};
+int g_side_refs[kMaxDevices] = {};
+
+hipError_t side_stream_acquire(int device, hipStream_t* out) {
+  if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  if (g_side_refs[device] == 0) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const char* pr = getenv("BLH_SIDE_PRIORITY");   // "normal": the round-2 behaviour (A/B knob)
+    const hipError_t e = (pr && !strcmp(pr, "normal"))
+                             ? hipStreamCreateWithFlags(&g_side_stream[device], hipStreamNonBlocking)
+                             : hipStreamCreateWithPriority(&g_side_stream[device], hipStreamNonBlocking, least);
+    if (e != hipSuccess) return e;
+  }
+  ++g_side_refs[device];
+  *out = g_side_stream[device];
+  return hipSuccess;
+}
+void side_stream_release(int device) {
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  if (device < 0 || device >= kMaxDevices || g_side_refs[device] == 0) return;
+  if (--g_side_refs[device] == 0) {
+    (void)hipStreamDestroy(g_side_stream[device]);
+    g_side_stream[device] = nullptr;
+  }
+}
+}  // namespace
+
 int blh_context_create(blh_context** out) {
   if (!out) return BLH_ERR_INVALID_ARGUMENT;
   *out = nullptr;
@@ -718,7 +756,21 @@ int blh_context_create(blh_context** out) {
   if (e != hipSuccess) return fail(e);
   // (measured and not kept: a lowest-priority side stream, and s_setprio 2 in the data-gradient
   //  GEMM: neither moves the 50/50 split of a CU's matrix pipes between two co-resident GEMMs)
-  if ((e = hipStreamCreateWithFlags(&c->s2, hipStreamNonBlocking)) != hipSuccess) return fail(e);
+  // The side stream is created at the LOWEST priority — not for the priority (measured: it does not
+  // move the split of a CU between two co-resident GEMMs, nor any step time of the fused path) but for
+  // the hardware queue.  HIP maps the streams of one priority level onto a small pool of hardware
+  // queues (4 by default) and streams that share one run in submission order.  A process that has
+  // created an RCCL communicator through torch holds some 64 normal- and high-priority pool streams;
+  // a normal-priority side stream then lands on the main stream's queue or on the collective stream's,
+  // and the "two-stream" backward runs serialised: 1.26-1.40 ms against 1.07-1.14 ms for the
+  // data-parallel step at configs[1] (profiles/r03_dp_overhead.md).  Nothing else uses the lowest level.
+  // ... and it is ONE stream per device and process, shared by every context of that device
+  // (reference-counted): each additional hardware queue a process keeps busy brings it closer to the
+  // point where the queue scheduler starts time-slicing queues, and kernels of ALL of them then run
+  // 1.5-5x longer (a second context + a high-priority compute stream + RCCL's stream was enough:
+  // 2.27 against 1.14 ms per data-parallel step).  Contexts are used one call at a time; two threads
+  // driving two contexts of one device merely take turns on the side stream.
+  if ((e = side_stream_acquire(c->device, &c->s2)) != hipSuccess) return fail(e);
   for (int i = 0; i < BLH_CTX_EVENTS; ++i) {
     if ((e = hipEventCreateWithFlags(&c->ev_dz[i], hipEventDisableTiming)) != hipSuccess) return fail(e);
     if ((e = hipEventCreateWithFlags(&c->ev_w[i], hipEventDisableTiming)) != hipSuccess) return fail(e);
@@ -739,7 +791,7 @@ int blh_context_destroy(blh_context* c) {
     if (c->ev_w[i]) (void)hipEventDestroy(c->ev_w[i]);
     if (c->ev_r[i]) (void)hipEventDestroy(c->ev_r[i]);
   }
-  if (c->s2) (void)hipStreamDestroy(c->s2);
+  if (c->s2) side_stream_release(c->device);
   delete c;
   return BLH_OK;
 }

@@ -27,6 +27,9 @@ import torch
 import torch.distributed as dist
 
 
+_COMPUTE_STREAMS = {}     # device -> the high-priority compute stream of DataParallel.stream
+
+
 class GradBucketReducer:
     """Bucketed, overlapped all-reduce (mean) over a flat gradient tensor.
 
@@ -165,11 +168,11 @@ class DataParallel:
     ``x_local`` is this rank's row slice of the global batch.  Dropout uses the
     global row index (rank * local_batch), so the Philox mask of a row does not
     depend on the number of GPUs.
-    Allocation order: build the module, its optimizer and (``engine.workspace(batch)``,
-    ``optimizer._ensure_moments(engine)``) their device state BEFORE creating an eager RCCL
-    communicator (``init_process_group("nccl", device_id=...)``): tensors that are the first
-    allocations after the communicator ran every kernel 10 % slower on the MI355X box this
-    was measured on; bench.py shows the order.
+    Order of set-up on a HIP device: create the RCCL process group FIRST
+    (``init_process_group("nccl", device_id=...)``), then the module, its optimizer and this driver.
+    Measured at world size 1 with every collective issued (``bench.py --rehearse-rccl``,
+    profiles/r03_dp_overhead.md): 1.14-1.16 ms per configs[1] step in this order, 2.3-3.0 ms with the
+    module first.  See also ``stream``.
     """
 
     def __init__(self, module, optimizer, group=None, bucket_floats=1 << 20, max_norm=1.0,
@@ -185,6 +188,29 @@ class DataParallel:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._reducer = None
+        self._stream = None
+
+    @property
+    def stream(self):
+        """The stream the step's kernels run on (HIP devices): a HIGH-priority stream of the driver's
+        own.  HIP maps the streams of one priority level onto a few hardware queues, and streams on
+        one queue run in submission order; torch's process group launches its RCCL kernels from a
+        normal-priority pool stream, which as often as not shares its queue with torch's default
+        stream — the bucket all-reduces (which wait for the side stream's weight gradients) and the
+        main-stream kernels then serialise each other: 1.40 instead of 1.14 ms per step
+        (profiles/r03_dp_overhead.md).  With compute on the high level, the weight gradients on the
+        library's lowest-level side stream and the collectives on the normal level, the three never
+        share a queue.  ``train_step`` hops onto this stream and back; a loop that runs entirely
+        under ``with torch.cuda.stream(dp.stream):`` skips the two hops."""
+        dev = self.module.engine.device
+        if dev is None or dev.type != "cuda":
+            return None
+        if self._stream is None or self._stream.device != dev:
+            # one per device and process: every driver object shares it
+            if dev not in _COMPUTE_STREAMS:
+                _COMPUTE_STREAMS[dev] = torch.cuda.Stream(device=dev, priority=-1)
+            self._stream = _COMPUTE_STREAMS[dev]
+        return self._stream
 
     def _all_reduce_sum(self, tensor):
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
@@ -197,9 +223,20 @@ class DataParallel:
 
     @torch.no_grad()
     def train_step(self, x, target):
+        self.module.engine.ensure(x.device)
+        st = self.stream
+        if st is None or torch.cuda.current_stream(x.device) == st:
+            return self._train_step(x, target)
+        cur = torch.cuda.current_stream(x.device)
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            out = self._train_step(x, target)
+        cur.wait_stream(st)
+        return out
+
+    def _train_step(self, x, target):
         eng = self.module.engine
         opt = self.optimizer
-        eng.ensure(x.device)
         if self._reducer is None or self._reducer.flat.data_ptr() != eng.grads.data_ptr():
             self._reducer = GradBucketReducer(eng.grads, self.group, self.bucket_floats,
                                               force_collectives=self.force_collectives,
