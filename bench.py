@@ -652,7 +652,15 @@ def main():
         captured.t.copy_(t)
         x, t = captured.x, captured.t
 
+    dp_captured = None
+    if dp is not None and args.graph and not args.no_graph and not args.sync_bn:
+        # the data-parallel step as one hipGraph (RCCL calls captured like kernels)
+        from bilinear_amd.dp import CapturedDataParallelStep
+        dp_captured = CapturedDataParallelStep(dp, args.batch)
+
     def one_step():
+        if dp_captured is not None:
+            return dp_captured(x, t)
         if dp is not None:
             return dp.train_step(x, t)
         if captured is not None:
@@ -763,7 +771,7 @@ def main():
                                            if args.rehearse_rccl else ""),
                 "dropout": "philox",
                 "batchnorm": ("sync (global batch)" if args.sync_bn else "per-rank statistics") if world > 1 else "single device",
-                "launch": ("hipGraph replay (1 launch/step)" if use_graph
+                "launch": ("hipGraph replay (1 launch/step)" if (use_graph or dp_captured is not None)
                            else "eager (~55 launches/step, weight-gradient GEMMs on a side stream)") + (
                                "; Adam writes the bf16 weight image (persistent shadow)"
                                if args.persistent_shadow and args.dtype == "bf16s" else ""),

@@ -281,8 +281,8 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
   auto ready = [&](int idx, int64_t off, int64_t cnt) -> int {
     if (!on_ready) return BLH_OK;
     if (two) {
-      BLH_HIP_TRY(hipEventRecord(g_side.ev_r[idx], s));
-      BLH_HIP_TRY(hipStreamWaitEvent(s2, g_side.ev_r[idx], 0));
+      // nothing to do: every part of the range was produced on the side stream behind the stage's
+      // fork (weight gradient, bias reduction) or on the main stream in front of it (gamma / beta)
     } else if (ctx->two_stream) {   // small-batch / SyncBN call of a two-stream context: the
       // range is complete on `s`; keep the contract "complete on the side stream"
       BLH_HIP_TRY(hipEventRecord(g_side.ev_r[idx], s));
@@ -311,9 +311,10 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
                 ceil_div(OF, 64) * ceil_div(W, 128), defer ? ws.stage_slabs[nh] : ws.slabs,
                 grads + L.dec_w, defer ? &wreg[nh] : nullptr));
   BLH_TRY(wdone(nh));
-  if (!fused) BLH_TRY(launch_colsum(s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
+  // (decode bias: on the side stream under a hook — behind the fork, its inputs are older than that)
+  if (!fused) BLH_TRY(launch_colsum(on_ready ? s2 : s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
   else if (on_ready)   // (the hook wants the decode range complete now; else: one batched launch at the end)
-    BLH_TRY(launch_colreduce(s, ws.dec_bias_part, fused->dec_bias_S, OF, OF, grads + L.dec_b));
+    BLH_TRY(launch_colreduce(s2, ws.dec_bias_part, fused->dec_bias_S, OF, OF, grads + L.dec_b));
   BLH_TRY(ready(nh, L.dec_w, L.total - L.dec_w));
 
   for (int i = nh - 1; i >= 0; --i) {
@@ -594,10 +595,12 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
   // the side stream waits for the main one, so the range is complete ON THE SIDE STREAM
   auto ready = [&](int idx, int64_t off, int64_t cnt) -> int {
     if (!on_ready) return BLH_OK;
-    if (ctx->two_stream) {
+    if (!two && ctx->two_stream) {   // (SyncBN call of a two-stream context: produced on `s`)
       BLH_HIP_TRY(hipEventRecord(ctx->ev_r[idx], s));
       BLH_HIP_TRY(hipStreamWaitEvent(ctx->s2, ctx->ev_r[idx], 0));
     }
+    // two streams: every part of the range was produced on the side stream behind the stage's fork
+    // (weight gradient, bias reduction) or on the main stream in front of it (gamma / beta)
     on_ready(user, off, cnt);
     return BLH_OK;
   };
@@ -615,8 +618,8 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
   }
   BLH_TRY(fork_wait(nh, true));
   BLH_TRY(wgrad_h(s2, ws.dpredh, OF, OF, ws.A[nh - 1], W, W, batch, ws.slabs, grads + L.dec_w));
-  if (dec_bias_S == 0) BLH_TRY(launch_colsum(s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
-  else if (on_ready) BLH_TRY(launch_colreduce(s, ws.dec_bias_part, dec_bias_S, OF, OF, grads + L.dec_b));
+  if (dec_bias_S == 0) BLH_TRY(launch_colsum(on_ready ? s2 : s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
+  else if (on_ready) BLH_TRY(launch_colreduce(s2, ws.dec_bias_part, dec_bias_S, OF, OF, grads + L.dec_b));
   BLH_TRY(ready(nh, L.dec_w, L.total - L.dec_w));
   for (int i = nh - 1; i >= 0; --i) {
     const HeavyOffsets& h = L.heavy[i];
@@ -644,11 +647,15 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
     }
     const bool late = two && late_policy && i > 0;
     if (two && !late) BLH_TRY(fork_wait(i, false));       // behind bn_bwd_apply (marker event)
-    // (data parallel: the bucket hook needs this stage's bias gradient now; otherwise all stages
-    //  are reduced by one launch after the loop, as in backward_impl)
-    if (on_ready)
-      BLH_TRY(launch_colreduce(s, ws.dz_colsum_part + (int64_t)i * chunks * W, chunks, W, W,
-                               grads + h.b));
+    // (data parallel: the bucket hook needs this stage's bias gradient now — on the side stream, in
+    //  front of the stage's weight gradient: nothing on the main stream waits for it; otherwise all
+    //  stages are reduced by one launch after the loop, as in backward_impl)
+    auto bias_now = [&]() -> int {
+      return on_ready ? launch_colreduce(s2, ws.dz_colsum_part + (int64_t)i * chunks * W, chunks, W, W,
+                                         grads + h.b)
+                      : BLH_OK;
+    };
+    if (!late) BLH_TRY(bias_now());
     if (i > 0) {
       GemmParamsH g{};
       g.A = ws.dZ[i]; g.lda = W;
@@ -663,7 +670,10 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
         BLH_TRY(launch_gemm_bf16s(s, ROWK, KROW, EPI_STORE, true, g, 1));
       }
       tl_stop_event = nullptr;
-      if (late) BLH_TRY(fork_wait(i, true));
+      if (late) {
+        BLH_TRY(fork_wait(i, true));
+        BLH_TRY(bias_now());
+      }
       BLH_TRY(wgrad_h(s2, ws.dZ[i], W, W, ws.A[i - 1], W, W, batch, ws.slabs, grads + h.w));
     } else {
       BLH_TRY(wgrad_h(s2, ws.dZ[0], W, W, ws.xh, IF, IF, batch, ws.slabs, grads + h.w));
