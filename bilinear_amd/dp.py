@@ -36,7 +36,7 @@ class GradBucketReducer:
     ``on_ready(offset, count)`` is called in backward order with contiguous ranges;
     ranges are merged until a bucket holds at least ``bucket_floats`` elements."""
 
-    def __init__(self, flat_grads, group=None, bucket_floats=1 << 20, force_collectives=False,
+    def __init__(self, flat_grads, group=None, bucket_floats=None, force_collectives=False,
                  compress=None):
         """``compress="bf16"``: every bucket is cast to bf16 (round to nearest even, HIP kernel),
         averaged in bf16 and cast back — half the bytes on every xGMI link (configs 3-5)."""
@@ -46,7 +46,12 @@ class GradBucketReducer:
         self._half = None
         self.flat = flat_grads
         self.group = group
-        self.bucket_floats = int(bucket_floats)
+        # default: about four buckets per step, none under 1 Mi elements — a bucket per 1024x1024 stage
+        # costs one trip back to Python and one RCCL launch per stage (nine at configs[2], seventeen at
+        # configs[4]) for no more overlap: the first quarter of the arena is on the wire after a
+        # quarter of backward either way, and xGMI rings are per-link bound, so fewer, larger
+        # collectives are the cheaper ones
+        self.bucket_floats = int(bucket_floats) if bucket_floats else max(1 << 20, flat_grads.numel() // 4)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # world 1 normally skips the exchange; ``force_collectives`` issues it anyway (a one-GPU
         # box can then run every RCCL call of the N-GPU step: ReduceOp.AVG, the side-stream hook,
@@ -175,7 +180,7 @@ class DataParallel:
     module first.  See also ``stream``.
     """
 
-    def __init__(self, module, optimizer, group=None, bucket_floats=1 << 20, max_norm=1.0,
+    def __init__(self, module, optimizer, group=None, bucket_floats=None, max_norm=1.0,
                  sync_bn=False, force_collectives=False, compress=None):
         self.force_collectives = bool(force_collectives)
         self.compress = compress
