@@ -148,7 +148,14 @@ def gemm_rooflines_bf16s(batch, width, reps):
     bias = torch.randn(width, device=dev)
     Z = torch.empty(batch, width, dtype=torch.bfloat16, device=dev)
     stat = torch.empty((batch + 127) // 128, 2, width, device=dev)
-    splits = max(1, min((256 * 128 * 128) // (width * width), batch // 128))
+    # batch slabs of the weight gradient as the step plans them (api_layout.h: wgrad_plan_h)
+    t256 = (width // 256) ** 2
+    if width % 256 == 0 and t256 >= 64:
+        splits = max(1, 256 // t256)
+        while splits > 1 and batch % (splits * 128) != 0:
+            splits //= 2
+    else:
+        splits = max(1, min((256 * 128 * 128) // (width * width), batch // 128))
     slabs = torch.empty(splits, width, width, device=dev)
     flop = 2.0 * batch * width * width
 
