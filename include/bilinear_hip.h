@@ -55,11 +55,17 @@ int blh_last_hip_error(void);
 int blh_abi_version(void);
 
 /* ------------------------------------------------------------------------
- * Context.  Everything the library owns on a device lives in a caller-owned blh_context:
- * the side stream + fork/join events of the two-stream backward, the per-call SyncBN /
- * captured-step plumbing and the option flags.  There is no process-global device state.
+ * Context.  Everything the library owns on a device is reached through a caller-owned
+ * blh_context: the fork/join events of the two-stream backward, the per-call SyncBN /
+ * captured-step plumbing, the option flags, and a reference to the side stream.  The side
+ * stream is the ONE process-wide object of the library: one lowest-priority stream per device,
+ * shared (reference-counted) by all contexts of that device.  HIP maps the streams of one
+ * priority level onto a few hardware queues, and streams on one queue run in submission
+ * order; a per-context, normal-priority side stream shared its queue with the caller's
+ * stream or with RCCL's in any process that had created a communicator, which serialised
+ * the backward.  Nothing else uses the lowest level.
  *   - blh_context_create binds the context to the CURRENT HIP device (hipGetDevice) and
- *     creates the side stream there; every network-level entry point below takes the
+ *     acquires that device's side stream; every network-level entry point below takes the
  *     context first and returns BLH_ERR_INVALID_ARGUMENT when another device is current.
  *   - one context = one in-flight call: a context must not be used from two host threads
  *     at once (use one context per thread / per model replica; contexts are cheap).
