@@ -172,6 +172,20 @@ __device__ inline void gemm_epilogue_256(f32x4 (&acc)[2][2][4][2], const GemmPar
   constexpr int VEC = OUT_BF16 ? 8 : 4;
   constexpr int CPR = 256 / VEC;
   float* stg = smem;
+  // skip-gradient addend: all 16 pieces of this thread (4 passes x 4) are requested here, in front of
+  // the staging passes, so that their latency is paid once per tile and not once per pass
+  uint4 adv[(EPI == EPI_ADD && OUT_BF16) ? 4 : 1][(EPI == EPI_ADD && OUT_BF16) ? 4 : 1];
+  if constexpr (EPI == EPI_ADD && OUT_BF16) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int q = it * 512 + tid;
+        const int row = m0 + (ps >> 1) * 128 + (ps & 1) * 64 + q / CPR, col = n0 + (q % CPR) * VEC;
+        adv[ps][it] = row < p.M ? *reinterpret_cast<const uint4*>(p.addend + (int64_t)row * p.ldadd + col)
+                                : uint4{0u, 0u, 0u, 0u};
+      }
+  }
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
     const int qm = ps >> 1, wrp = ps & 1;
@@ -198,8 +212,8 @@ __device__ inline void gemm_epilogue_256(f32x4 (&acc)[2][2][4][2], const GemmPar
         if (OUT_BF16) {
           const float4 v1 = *reinterpret_cast<const float4*>(stg + lrow * SP + cv + 4);
           float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-          if (EPI == EPI_ADD) {
-            const uint4 ad = *reinterpret_cast<const uint4*>(p.addend + (int64_t)row * p.ldadd + col);
+          if constexpr (EPI == EPI_ADD) {
+            const uint4 ad = adv[ps][q0 / 512];
             v[0] += __uint_as_float(ad.x << 16); v[1] += __uint_as_float(ad.x & 0xffff0000u);
             v[2] += __uint_as_float(ad.y << 16); v[3] += __uint_as_float(ad.y & 0xffff0000u);
             v[4] += __uint_as_float(ad.z << 16); v[5] += __uint_as_float(ad.z & 0xffff0000u);

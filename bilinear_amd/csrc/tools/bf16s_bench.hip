@@ -86,6 +86,20 @@ int main(int argc, char** argv) {
   GemmParamsH w2 = w;
   w2.k_per_split = (int)round_up(ceil_div(M, splits256), 128);
   const bool only256 = argc > 4;
+  if (getenv("WGRAD_SWEEP")) {   // weight gradient only: slab counts x kernels
+    for (int round = 0; round < 2; ++round)
+      for (int sp : {2, 4, 8, 16}) {
+        GemmParamsH ws = w;
+        ws.k_per_split = (int)round_up(ceil_div(M, sp), 128);
+        if ((int64_t)ws.k_per_split * sp != M) continue;
+        float a = run<KROW, KROW, EPI_STORE, false, 64, 2>(ws, sp, reps);
+        float b = run<KROW, KROW, EPI_STORE, false, 128, 2>(ws, sp, reps);
+        float c = run256<KROW, KROW, EPI_STORE, false>(ws, sp, reps);
+        printf("wgrad x%-2d  128x128 bk64 %6.1f us %5.0f TF | 128x128 bk128 %6.1f us %5.0f TF | 256x256 %6.1f us %5.0f TF\n",
+               sp, a * 1e3, flop / a / 1e9, b * 1e3, flop / b / 1e9, c * 1e3, flop / c / 1e9);
+      }
+    return 0;
+  }
   for (int round = 0; round < 3; ++round) {
     if (!only256) {
       ROW(64, 2)
