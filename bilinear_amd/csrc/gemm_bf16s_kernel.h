@@ -219,6 +219,21 @@ __device__ inline void gemm_epilogue_h(f32x16 (&acc)[2][2], const GemmParamsH& p
                       (EPI != EPI_ADD || ((p.ldadd % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.addend) & 15) == 0)));
   if (vec_ok) {
     float* stg = smem;                            // [64][SP] floats = 34 KB
+    // (EPI_ADD: the thread's 8 addend pieces are requested here, once, in front of the staging passes)
+    constexpr bool PREADD = (EPI == EPI_ADD) && OUT_BF16;
+    uint4 adv[PREADD ? 2 : 1][PREADD ? 4 : 1];
+    if constexpr (PREADD) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int q = it * 256 + tid;
+          const int row = m0 + half * 64 + q / (BN / VEC), col = n0 + (q % (BN / VEC)) * VEC;
+          adv[half][it] = (row < p.M && col < p.N)
+                              ? *reinterpret_cast<const uint4*>(p.addend + (int64_t)row * p.ldadd + col)
+                              : uint4{0u, 0u, 0u, 0u};
+        }
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       if (wm == half) {
@@ -242,8 +257,8 @@ __device__ inline void gemm_epilogue_h(f32x16 (&acc)[2][2], const GemmParamsH& p
           if (OUT_BF16) {
             const float4 v1 = *reinterpret_cast<const float4*>(stg + lrow * SP + cv + 4);
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            if (EPI == EPI_ADD) {
-              const uint4 ad = *reinterpret_cast<const uint4*>(p.addend + (int64_t)row * p.ldadd + col);
+            if constexpr (EPI == EPI_ADD) {
+              const uint4 ad = adv[half][q0 / 256];
               v[0] += __uint_as_float(ad.x << 16); v[1] += __uint_as_float(ad.x & 0xffff0000u);
               v[2] += __uint_as_float(ad.y << 16); v[3] += __uint_as_float(ad.y & 0xffff0000u);
               v[4] += __uint_as_float(ad.z << 16); v[5] += __uint_as_float(ad.z & 0xffff0000u);
