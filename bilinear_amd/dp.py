@@ -208,8 +208,12 @@ class DataParallel:
         share a queue.  ``train_step`` hops onto this stream and back; a loop that runs entirely
         under ``with torch.cuda.stream(dp.stream):`` skips the two hops."""
         dev = self.module.engine.device
-        if dev is None or dev.type != "cuda":
+        if dev is None:                      # (the engine binds to a device at its first call)
+            dev = next(self.module.parameters()).device
+        if dev.type != "cuda":
             return None
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
         if self._stream is None or self._stream.device != dev:
             # one per device and process: every driver object shares it
             if dev not in _COMPUTE_STREAMS:

@@ -292,6 +292,23 @@ def _worker_rccl(rank, world, port, out_dir):
         assert d <= 5e-3, d          # pre-BN biases move by up to ~lr per step on noise (H2)
         assert max(abs(a - b) for a, b in zip(res["sync"][2], ref_losses)) <= 1e-5 * ref_losses[0]
 
+        # the driver's own high-priority stream (DataParallel.stream: hardware queues): a
+        # loop that runs under it (what bench.py does) == train_step hopping onto it from the default
+        # stream, bit for bit; every driver of the process shares the one stream
+        net_u, opt_u = _make(dev, cfg)
+        dpu = DataParallel(net_u, opt_u, bucket_floats=200000, force_collectives=True)
+        assert dpu.stream is not None, "no compute stream on a HIP device"
+        assert dpu.stream.priority < 0, dpu.stream.priority
+        assert dpu.stream == dp0.stream, (dpu.stream, dp0.stream)
+        dpu.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(dpu.stream):
+            for _ in range(3):
+                dpu.train_step(x, t)
+        torch.cuda.synchronize()
+        assert torch.equal(net_u.engine.params, net.engine.params), "loop under dp.stream != hopping train_step"
+        # the library's side stream is one per device and process, whatever the number of contexts
+        assert net_u.engine.ctx.side_stream() == net.engine.ctx.side_stream() != 0
+
         # the whole data-parallel step as one hipGraph, RCCL all-reduces captured with it
         from bilinear_amd.dp import CapturedDataParallelStep
         net_c, opt_c = _make(dev, cfg)

@@ -1047,3 +1047,29 @@ def test_train_step_operator_under_torch_compile_fullgraph():
         outs.append((pred.clone(), loss.clone(), eng.params.clone(), opt._exp_avg_sq.clone()))
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+def test_contexts_of_one_device_share_the_side_stream_and_outlive_each_other():
+    """blh_context_create: the side stream is one lowest-priority stream per device and process,
+    reference-counted (include/bilinear_hip.h, "Context"); destroying one context must leave the
+    others usable."""
+    import bilinear_amd
+    from bilinear_amd import _native as N
+    dev = _dev()
+    a, b = N.Context(dev), N.Context(dev)
+    sa, sb = a.side_stream(), b.side_stream()
+    assert sa and sa == sb
+    del a
+    import gc
+    gc.collect()
+    torch.manual_seed(0)
+    net, opt, _, _ = bilinear_amd.load(dev, num_blocks=1, width=1024)
+    net.train()
+    x = torch.randn(2048, 32, device=dev)
+    t = torch.randn(2048, 48, device=dev)
+    net.engine.ensure(dev)
+    assert net.engine.ctx.side_stream() == sb
+    pred, loss = net.train_step(opt, x, t, max_norm=1.0)     # two-stream backward on the shared stream
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss).item() and torch.isfinite(net.engine.params).all().item()
+    assert b.side_stream() == sb
