@@ -286,6 +286,15 @@ int decode_fwd_rows_per_block(int64_t batch) {
   while (rt < 4 && ceil_div(batch, 16 * rt) > 1024) rt *= 2;
   return 16 * rt;
 }
+// bf16 operands: a block re-reads the whole decode weight (96 KB at W = 1024) for its rows, three
+// quarters of the kernel's load instructions at 16 rows per block; as many rows per block as still
+// leave one block per CU (measured, B = 16384: 23.3 / 21.7 / 19.0 us at 16 / 32 / 64 rows; B = 8192:
+// 13.8 / 12.8 / 16.2 us; the fp32 kernel at B = 4096 is fastest at 16 rows: 11.1 / 15.3 / 22.3 us)
+int decode_fwd_rows_per_block_h(int64_t batch) {
+  int rt = 1;
+  while (rt < 4 && (ceil_div(batch, 16 * rt) > 1024 || ceil_div(batch, 32 * rt) >= 256)) rt *= 2;
+  return 16 * rt;
+}
 
 bool decode_fwd_supported(int64_t batch, int W, int OF) {
   // (a wave's share of the reduction, W / 8, is walked in chunks of 32)
@@ -317,7 +326,7 @@ int launch_decode_fwd_mse_h(hipStream_t s, const uint16_t* A, const uint16_t* Wd
                             float* loss_part, float* dbias_part, int64_t batch, int W, int OF, float scale,
                             int* nparts) {
   if (!decode_fwd_supported(batch, W, OF) || W % 8 != 0 || OF % 4 != 0) return BLH_ERR_SHAPE;
-  const int rows = decode_fwd_rows_per_block(batch);
+  const int rows = decode_fwd_rows_per_block_h(batch);
   const int blocks = (int)ceil_div(batch, rows);
   if (rows == 16)
     hipLaunchKernelGGL(decode_fwd_mse_h_kernel<1>, dim3(blocks), dim3(64 * DEC_WAVES), 0, s, A, Wd, bd, target,
