@@ -107,6 +107,29 @@ def test_bucket_merging_single_process():
     assert red.launched == [(700, 1000), (200, 700), (0, 200)]
 
 
+def test_default_bucket_size_is_a_quarter_of_the_arena():
+    """Default plan: about four collectives per step, none under 1 Mi elements (dp.py:
+    GradBucketReducer) — the arena of BASELINE configs[2] (4 blocks x 1024) reported stage by stage
+    as blh_backward does it (decode first) gives four buckets, not nine."""
+    from bilinear_amd.dp import GradBucketReducer
+    W, stages = 1024, 9
+    sizes = [W * 32 + 3 * W] + [W * W + 3 * W] * (stages - 1) + [48 * W + 64]
+    total = sum(sizes)
+    flat = torch.zeros(total)
+    red = GradBucketReducer(flat)
+    assert red.bucket_floats == max(1 << 20, total // 4)
+    assert GradBucketReducer(torch.zeros(1000)).bucket_floats == 1 << 20
+    red.begin()
+    hi = total
+    for sz in reversed(sizes):
+        red.on_ready(hi - sz, sz)
+        hi -= sz
+    red.finish()
+    assert len(red.launched) == 4
+    assert red.launched[0][1] == total and red.launched[-1][0] == 0
+    assert all(a[0] == b[1] for a, b in zip(red.launched, red.launched[1:]))     # contiguous, descending
+
+
 def _worker_bf16(rank, world, port, result_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
