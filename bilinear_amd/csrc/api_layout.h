@@ -228,6 +228,7 @@ struct WorkspaceH {
   std::vector<uint32_t*> keep;      // per heavy stage: dropout keep bits [ceil(B/4)][W/8] (bn_bf16.hip)
   uint16_t* G0; uint16_t* G1;
   float* stat_part; float* bn_part; float* dz_colsum_part; float* slabs;
+  float* bslabs;                    // [hidden stages][slabs][W][W]: the batched weight gradient (null: not planned)
   float* dpred; uint16_t* dpredh;   // [B][out] fp32 and its bf16 image
   float* loss_part; double* sumsq_part; float* colsum_part;
   double* sync_buf;                 // [2][W] fp64 (SyncBN exchange; its first 2W floats in backward)
@@ -259,6 +260,23 @@ static Splits wgrad_plan_h(int64_t M, int64_t N, int64_t batch) {
   sp.k_per = (int)round_up(sp.k_per, 128);
   sp.splits = (int)ceil_div(batch, sp.k_per);
   return sp;
+}
+
+// Batched weight gradient (r03): the W x W stages whose single launch cannot fill the chip with 256 x 256
+// tiles (16 tiles at W = 1024) are computed by ONE launch over `items` stages (gemm_bf16s_256.h, grid z =
+// stage x slab) with as few batch slabs per stage as make about 256 workgroups: 8 stages x 2 slabs at
+// configs[2], each workgroup 8192 rows deep.  {0, 0}: not applicable (the per-stage plan above is used).
+static Splits wgrad_batched_plan_h(int64_t W, int64_t batch, int items) {
+  if (items < 2 || W % 256 != 0 || batch % 128 != 0 || std::getenv("BLH_NO_BATCHED_WGRAD")) return Splits{0, 0};
+  const int64_t tiles = (W / 256) * (W / 256);
+  if (tiles >= wgrad256_min_tiles()) return Splits{0, 0};      // one stage fills the chip by itself
+  int64_t s = 1;
+  while (s < 8 && tiles * items * (s * 2) <= 256) s *= 2;
+  while (s > 1 && batch % (s * 128) != 0) s >>= 1;
+  // (each workgroup at least 2048 rows deep: below that the per-stage plan measured as fast or faster,
+  //  0.434 against 0.441 ms per step at 2 x 1024, B = 4096)
+  if (tiles * items * s < 224 || batch / s < 2048) return Splits{0, 0};
+  return Splits{(int)s, (int)(batch / s)};
 }
 
 static int64_t slab_floats_h(const blh_model_desc* d, int64_t batch) {
@@ -295,6 +313,11 @@ static WorkspaceH carve_h(const blh_model_desc* d, int64_t batch, void* base) {
   ws.bn_part = (float*)take(chunks * 2 * W * sizeof(float));
   ws.dz_colsum_part = (float*)take((int64_t)nh * chunks * W * sizeof(float));
   ws.slabs = (float*)take(slab_floats_h(d, batch) * sizeof(float));
+  {
+    const int hidden = 2 * d->num_blocks;
+    const Splits bp = wgrad_batched_plan_h(W, batch, hidden);
+    ws.bslabs = bp.splits > 1 ? (float*)take((int64_t)hidden * bp.splits * W * W * sizeof(float)) : nullptr;
+  }
   ws.dpred = (float*)take(batch * d->out_features * sizeof(float));
   ws.dpredh = (uint16_t*)take(batch * d->out_features * 2);
   ws.loss_part = (float*)take(4096 * sizeof(float));

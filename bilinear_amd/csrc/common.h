@@ -163,6 +163,8 @@ int launch_bias_colreduce(hipStream_t s, const float* part, int64_t stage_stride
                           int64_t extra_off = 0);
 // out[i] = sum_s in[s][i]   (slabs of `count` floats)
 int launch_sum_slabs(hipStream_t s, const float* slabs, int64_t count, int splits, float* out);
+int launch_sum_slabs_batched(hipStream_t s, const float* slabs, int64_t count, int splits, int items,
+                             int64_t slab_item_stride, float* out, int64_t out_item_stride);
 int launch_sum_slabs_add(hipStream_t s, const float* slabs, int64_t count, int splits,
                          const float* addend, float* out);
 // small-batch forward: Z = sum(slabs) + bias; stat_part (may be null) receives the column

@@ -373,6 +373,34 @@ int launch_sum_slabs(hipStream_t s, const float* slabs, int64_t count, int split
   return launch_sum_slabs_add(s, slabs, count, splits, nullptr, out);
 }
 
+// The same for `items` independent outputs in one launch (the batched weight-gradient GEMM):
+// item b sums slabs + b * slab_item_stride into out + b * out_item_stride.
+__global__ __launch_bounds__(256) void sum_slabs_batched_kernel(const float* __restrict__ slabs, int64_t count,
+                                                                int splits, int64_t slab_item_stride,
+                                                                float* __restrict__ out, int64_t out_item_stride) {
+  const float* sl = slabs + (int64_t)blockIdx.y * slab_item_stride;
+  float* o = out + (int64_t)blockIdx.y * out_item_stride;
+  const int64_t n4 = count >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 a = ld4(sl + i * 4);
+    for (int s = 1; s < splits; ++s) {
+      const float4 b = ld4(sl + (int64_t)s * count + i * 4);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    st4(o + i * 4, a);
+  }
+}
+
+int launch_sum_slabs_batched(hipStream_t s, const float* slabs, int64_t count, int splits, int items,
+                             int64_t slab_item_stride, float* out, int64_t out_item_stride) {
+  if (count % 4 != 0 || slab_item_stride % 4 != 0 || out_item_stride % 4 != 0 || items < 1) return BLH_ERR_SHAPE;
+  const int64_t blocks = std::min<int64_t>(ceil_div(count / 4, 256), std::max<int64_t>(1, 4096 / items));
+  hipLaunchKernelGGL(sum_slabs_batched_kernel, dim3((unsigned)blocks, (unsigned)items), dim3(256), 0, s, slabs,
+                     count, splits, slab_item_stride, out, out_item_stride);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
 // ---------------------------------------------------------------------------
 // small-batch forward: Z = sum of split-K slabs + bias (streaming, fully parallel), then the
 // column (mean, M2) over all M rows as ONE statistics tile (Welford per thread, Chan merge

@@ -64,13 +64,16 @@ static int forced_tile() {
 
 int gemm_bf16s_pick_tile(int la, int lb, bool out_bf16, const GemmParamsH& p, int splits) {
   const int vec = out_bf16 ? 8 : 4;
-  const int64_t extent = (splits > 1) ? p.k_per_split : p.K;
+  const int slabs = p.batch_splits > 0 ? p.batch_splits : splits;     // per GEMM of a batched launch
+  const int64_t extent = (slabs > 1) ? p.k_per_split : p.K;
   const bool shape_ok = (p.N % 256 == 0) && extent >= 128 && (extent % 128 == 0) &&
-                        (splits == 1 || (int64_t)splits * p.k_per_split == p.K) &&
+                        (slabs == 1 || (int64_t)slabs * p.k_per_split == p.K) &&
+                        (p.batch_splits == 0 || splits % p.batch_splits == 0) &&
                         (p.ldc % vec == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
                         (!p.addend || ((p.ldadd % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.addend) & 15) == 0))) &&
-                        (!out_bf16 || splits == 1 || (p.c_split_stride % 8 == 0)) &&
-                        (out_bf16 || splits == 1 || (p.c_split_stride % 4 == 0)) &&
+                        (!out_bf16 || slabs == 1 || (p.c_split_stride % 8 == 0)) &&
+                        (out_bf16 || slabs == 1 || (p.c_split_stride % 4 == 0)) &&
+                        (p.batch_splits == 0 || p.c_batch_stride % 8 == 0) &&
                         ((int64_t)256 * std::max(p.lda, p.ldb) * 2 < (1ll << 31)) &&
                         (la == ROWK || p.M % 256 == 0);
   if (!shape_ok) return 128;
@@ -79,7 +82,7 @@ int gemm_bf16s_pick_tile(int la, int lb, bool out_bf16, const GemmParamsH& p, in
   const int64_t wgs = ceil_div(p.M, 256) * (p.N / 256) * splits;
   // fewer workgroups: the 128 x 128 grid fills the 256 CUs better.  Weight gradients (both
   // operands KROW, fp32 slabs): only with at most 4 slabs (api_layout.h: wgrad_plan_h)
-  if (la == KROW && splits > 4 && !getenv("BLH_WGRAD256_MIN_TILES")) return 128;
+  if (la == KROW && slabs > 4 && p.batch_splits == 0 && !getenv("BLH_WGRAD256_MIN_TILES")) return 128;
   return wgs >= 224 ? 256 : 128;
 }
 
@@ -99,6 +102,7 @@ int launch_gemm_bf16s(hipStream_t s, int la, int lb, int epi, bool out_bf16, con
   // 32-bit per-lane byte offsets inside one tile row panel
   if ((int64_t)128 * std::max(p.lda, p.ldb) * 2 >= (1ll << 31)) return BLH_ERR_SHAPE;
   const bool tile256 = gemm_bf16s_pick_tile(la, lb, out_bf16, p, splits) == 256;
+  if (p.batch_splits > 0 && !tile256) return BLH_ERR_SHAPE;   // (batched launches exist on the 256 x 256 kernel only)
   BLH_CASEH(ROWK, ROWK, EPI_BIAS_STATS, true)    // forward (train): Z bf16 + BatchNorm partials
   BLH_CASEH(ROWK, ROWK, EPI_BIAS, true)          // forward (eval)
   BLH_CASEH(ROWK, ROWK, EPI_BIAS, false)         // decode forward: fp32 prediction

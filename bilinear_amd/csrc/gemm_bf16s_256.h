@@ -317,16 +317,31 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16s_256_kernel(GemmParamsH p) {
   const int wr = wave >> 2, wc = wave & 3;
   const int tiles_n = p.N / BN;
   int tile = 0, slab = blockIdx.z;
-  if (!(gridDim.z > 1 && xcd_remap_split(blockIdx.x, blockIdx.z, gridDim.x, gridDim.z, (p.M + BM - 1) / BM,
-                                         tiles_n, &tile, &slab)))
+  if (p.batch_splits > 0) {
+    // batched launch: the (tile, z) space as one list, an XCD takes a contiguous piece of it — all tiles
+    // of one (item, slab) pair sit on one XCD, whose L2 then serves the operand panels they share
+    const int logical = xcd_remap(blockIdx.z * gridDim.x + blockIdx.x, gridDim.x * gridDim.z);
+    tile = logical % (int)gridDim.x;
+    slab = logical / (int)gridDim.x;
+  } else if (!(gridDim.z > 1 && xcd_remap_split(blockIdx.x, blockIdx.z, gridDim.x, gridDim.z, (p.M + BM - 1) / BM,
+                                                tiles_n, &tile, &slab)))
     tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  // batched launch: the z index carries (batch item, slab); the items are independent GEMMs of one shape
+  int item = 0;
+  if (p.batch_splits > 0) {
+    item = slab / p.batch_splits;
+    slab -= item * p.batch_splits;
+  }
+  const bf16_bits* Aop = p.A + (int64_t)item * p.a_batch_stride;
+  const bf16_bits* Bop = p.B + (int64_t)item * p.b_batch_stride;
   const int kz0 = slab * p.k_per_split;
   const int k_end = min(p.K, kz0 + p.k_per_split);
   const int nit = (k_end - kz0) >> 7;            // iterations of two K tiles (host: extent % 128 == 0, >= 128)
-  void* C = OUT_BF16 ? (void*)(reinterpret_cast<bf16_bits*>(p.C) + (int64_t)slab * p.c_split_stride)
-                     : (void*)(reinterpret_cast<float*>(p.C) + (int64_t)slab * p.c_split_stride);
+  const int64_t coff = (int64_t)item * p.c_batch_stride + (int64_t)slab * p.c_split_stride;
+  void* C = OUT_BF16 ? (void*)(reinterpret_cast<bf16_bits*>(p.C) + coff)
+                     : (void*)(reinterpret_cast<float*>(p.C) + coff);
 
   f32x4 acc[2][2][4][2];
 #pragma unroll
@@ -342,8 +357,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16s_256_kernel(GemmParamsH p) {
 
   PlanH256<LA> planA;
   PlanH256<LB> planB;
-  planA.init(p.A, p.lda, m0, p.M, kz0, tid);
-  planB.init(p.B, p.ldb, n0, p.N, kz0, tid);
+  planA.init(Aop, p.lda, m0, p.M, kz0, tid);
+  planB.init(Bop, p.ldb, n0, p.N, kz0, tid);
   const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) float*)smem);
   // LDS map: A halves of both buffers in the first 64 KiB, B halves in the second (every fragment
   // read of an operand is then base register + a 16-bit immediate): [EV.A0 EV.A1 OD.A0 OD.A1 | B likewise]

@@ -56,6 +56,11 @@ struct GemmParamsH {
   const bf16_bits* addend;   // [M][ldadd] bf16 (EPI_ADD)
   int64_t ldadd;
   float* stat_part;          // [tiles_m][2][N]
+  // batched launch (gemm_bf16s_256_kernel only): grid z = batch item * batch_splits + slab; item b reads
+  // A + b * a_batch_stride, B + b * b_batch_stride and writes C + b * c_batch_stride (elements).
+  // batch_splits == 0: an ordinary launch (grid z = slab).
+  int batch_splits;
+  int64_t a_batch_stride, b_batch_stride, c_batch_stride;
 };
 
 __device__ __forceinline__ float bf16_to_f32(bf16_bits v) { return __uint_as_float((uint32_t)v << 16); }
