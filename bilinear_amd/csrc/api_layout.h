@@ -262,14 +262,16 @@ static Splits wgrad_plan_h(int64_t M, int64_t N, int64_t batch) {
   return sp;
 }
 
-// Batched weight gradient (r03): the W x W stages whose single launch cannot fill the chip with 256 x 256
-// tiles (16 tiles at W = 1024) are computed by ONE launch over `items` stages (gemm_bf16s_256.h, grid z =
-// stage x slab) with as few batch slabs per stage as make about 256 workgroups: 8 stages x 2 slabs at
-// configs[2], each workgroup 8192 rows deep.  {0, 0}: not applicable (the per-stage plan above is used).
+// Batched weight gradient (r03): the weight gradients of all `items` hidden W x W stages in ONE launch of
+// the 256 x 256 kernel (gemm_bf16s_256.h, grid z = stage x slab) after the backward loop, with as few
+// batch slabs per stage as make about 256 workgroups: 8 stages x 2 slabs at configs[2] (each workgroup
+// 8192 rows deep: 25 us per stage against 42 alone / 60-100 in the step for the per-stage 128 x 128 plan),
+// 16 stages x 1 slab at configs[4] (no slabs at all, and no 256 x 256 weight gradient beside the
+// BatchNorm chain, which cannot run beside one: 7.73 -> 7.40 ms).  {0, 0}: not applicable (the per-stage
+// plan above is used; always under a bucket hook, which wants each range as early as possible).
 static Splits wgrad_batched_plan_h(int64_t W, int64_t batch, int items) {
   if (items < 2 || W % 256 != 0 || batch % 128 != 0 || std::getenv("BLH_NO_BATCHED_WGRAD")) return Splits{0, 0};
   const int64_t tiles = (W / 256) * (W / 256);
-  if (tiles >= wgrad256_min_tiles()) return Splits{0, 0};      // one stage fills the chip by itself
   int64_t s = 1;
   while (s < 8 && tiles * items * (s * 2) <= 256) s *= 2;
   while (s > 1 && batch % (s * 128) != 0) s >>= 1;
