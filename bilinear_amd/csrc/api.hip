@@ -621,16 +621,63 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
   if (dec_bias_S == 0) BLH_TRY(launch_colsum(on_ready ? s2 : s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
   else if (on_ready) BLH_TRY(launch_colreduce(s2, ws.dec_bias_part, dec_bias_S, OF, OF, grads + L.dec_b));
   BLH_TRY(ready(nh, L.dec_w, L.total - L.dec_w));
-  // Weight gradients of the hidden stages: without a bucket hook, ONE batched launch after the loop
-  // (api_layout.h: wgrad_batched_plan_h) instead of one launch per stage on the side stream.
-  const Splits bplan = on_ready == nullptr ? wgrad_batched_plan_h(W, batch, nh - 1) : Splits{0, 0};
-  const bool batched_w = bplan.splits > 0;
+  // Weight gradients of the hidden stages: batched launches of the 256 x 256 kernel (api_layout.h:
+  // wgrad_batched_plan_h) instead of one launch per stage.  Without a bucket hook: ONE group, all hidden
+  // stages, on the main stream after the loop.  With a hook (data parallel): groups of four stages from
+  // the top, each launched on the side stream when its lowest stage has its dZ, so that the first ranges
+  // are reported — and their all-reduce starts — after half of a four-block backward.
+  struct WGroup { int lo, hi; Splits plan; };
+  std::vector<WGroup> wgroups;
+  if (nh - 1 >= 2) {
+    if (on_ready == nullptr) {
+      wgroups.push_back(WGroup{1, nh - 1, wgrad_batched_plan_h(W, batch, nh - 1)});
+    } else {
+      for (int hi = nh - 1; hi >= 1; hi -= WGRAD_HOOK_GROUP) {
+        const int lo = std::max(1, hi - (WGRAD_HOOK_GROUP - 1));
+        wgroups.push_back(WGroup{lo, hi, wgrad_batched_plan_h(W, batch, hi - lo + 1)});
+      }
+    }
+  }
+  auto group_of = [&](int i) -> const WGroup* {
+    for (const WGroup& g : wgroups)
+      if (g.lo <= i && i <= g.hi && g.plan.splits > 0) return &g;
+    return nullptr;
+  };
+  // dW_k = dZ_k^T A_{k-1} for k = lo .. hi in one launch: the stages' dZ, A and gradient tensors lie one
+  // fixed stride apart (carve_h, make_layout)
+  auto launch_group = [&](const WGroup& grp, hipStream_t st) -> int {
+    const int items = grp.hi - grp.lo + 1;
+    if (nh < 3 || (ws.dZ[2] - ws.dZ[1]) != (ws.A[1] - ws.A[0])) return BLH_ERR_SHAPE;
+    const int64_t gstride = L.heavy[2].w - L.heavy[1].w;
+    for (int k = 2; k < nh; ++k)
+      if (L.heavy[k].w - L.heavy[k - 1].w != gstride) return BLH_ERR_SHAPE;
+    GemmParamsH g{};
+    g.A = ws.dZ[grp.lo]; g.lda = W; g.B = ws.A[grp.lo - 1]; g.ldb = W;
+    g.M = W; g.N = W; g.K = (int)batch; g.k_per_split = grp.plan.k_per; g.ldc = W;
+    g.batch_splits = grp.plan.splits;
+    g.a_batch_stride = ws.dZ[2] - ws.dZ[1];
+    g.b_batch_stride = ws.A[1] - ws.A[0];
+    float* out = grads + L.heavy[grp.lo].w;
+    if (grp.plan.splits == 1) {
+      g.C = out; g.c_batch_stride = gstride; g.c_split_stride = 0;
+      return launch_gemm_bf16s(st, KROW, KROW, EPI_STORE, false, g, items);
+    }
+    g.C = ws.bslabs; g.c_split_stride = (int64_t)W * W; g.c_batch_stride = (int64_t)grp.plan.splits * W * W;
+    BLH_TRY(launch_gemm_bf16s(st, KROW, KROW, EPI_STORE, false, g, items * grp.plan.splits));
+    return launch_sum_slabs_batched(st, ws.bslabs, (int64_t)W * W, grp.plan.splits, items, g.c_batch_stride, out,
+                                    gstride);
+  };
   for (int i = nh - 1; i >= 0; --i) {
     const HeavyOffsets& h = L.heavy[i];
     const bool first_of_block = (i >= 1) && (i % 2 == 1);
     const uint16_t* dA = first_of_block ? ws.G1 : ws.G0;
     const float* sv = ws.bn_saved[i];
-    const bool forks = two && !(batched_w && i > 0);   // (a hidden stage of the batched plan hands nothing over)
+    const WGroup* grp = i > 0 ? group_of(i) : nullptr;
+    const bool batched_w = grp != nullptr;
+    // (a hidden stage of a batched group hands nothing to the side stream, except the group's lowest
+    //  stage under a hook: the group's launch goes there, behind its bn_bwd_apply)
+    const bool group_fork = batched_w && on_ready != nullptr && i == grp->lo;
+    const bool forks = two && (!batched_w || group_fork);
     {   // dropout: the keep bits the forward wrote (bn_bf16.hip)
       BLH_TRY(launch_bn_bwd_reduce_h2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, ws.keep[i], ws.bn_part, batch, W));
       BLH_TRY(launch_bn_bwd_finalize_h2(s, ws.bn_part, chunks, W, sv, sv + W, grads + h.gamma, grads + h.beta));
@@ -650,8 +697,18 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
                                      ws.dZ[i], ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W,
                                      norm_batch));
     }
-    const bool late = forks && late_policy && i > 0;
+    const bool late = forks && late_policy && i > 0 && !group_fork;
     if (forks && !late) BLH_TRY(fork_wait(i, false));     // behind bn_bwd_apply (marker event)
+    if (group_fork) {
+      for (int k = grp->hi; k >= grp->lo; --k)
+        BLH_TRY(launch_colreduce(s2, ws.dz_colsum_part + (int64_t)k * chunks * W, chunks, W, W,
+                                 grads + L.heavy[k].b));
+      BLH_TRY(launch_group(*grp, s2));
+      for (int k = grp->hi; k >= grp->lo; --k) {
+        const int64_t end = (k + 1 < nh) ? L.heavy[k + 1].w : L.dec_w;
+        BLH_TRY(ready(k, L.heavy[k].w, end - L.heavy[k].w));
+      }
+    }
     // (data parallel: the bucket hook needs this stage's bias gradient now — on the side stream, in
     //  front of the stage's weight gradient: nothing on the main stream waits for it; otherwise all
     //  stages are reduced by one launch after the loop, as in backward_impl)
@@ -660,7 +717,7 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
                                          grads + h.b)
                       : BLH_OK;
     };
-    if (!late) BLH_TRY(bias_now());
+    if (!late && !batched_w) BLH_TRY(bias_now());
     if (i > 0) {
       GemmParamsH g{};
       g.A = ws.dZ[i]; g.lda = W;
@@ -683,35 +740,13 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
     } else {
       BLH_TRY(wgrad_h(s2, ws.dZ[0], W, W, ws.xh, IF, IF, batch, ws.slabs, grads + h.w));
     }
-    if (on_ready) {
+    if (on_ready && !batched_w) {
       const int64_t end = (i + 1 < nh) ? L.heavy[i + 1].w : L.dec_w;
       BLH_TRY(ready(i, h.w, end - h.w));
     }
   }
-  if (batched_w) {
-    // dW_i = dZ_i^T A_{i-1} for i = 1 .. nh-1 in one launch on the main stream: the stages' dZ, A and
-    // gradient tensors lie one fixed stride apart (carve_h, make_layout); the stage-0 and decode weight
-    // gradients (side stream) run beside it
-    const int items = nh - 1;
-    if (nh < 3 || (ws.dZ[2] - ws.dZ[1]) != (ws.A[1] - ws.A[0])) return BLH_ERR_SHAPE;
-    GemmParamsH g{};
-    g.A = ws.dZ[1]; g.lda = W; g.B = ws.A[0]; g.ldb = W;
-    g.M = W; g.N = W; g.K = (int)batch; g.k_per_split = bplan.k_per; g.ldc = W;
-    g.batch_splits = bplan.splits;
-    g.a_batch_stride = ws.dZ[2] - ws.dZ[1];
-    g.b_batch_stride = ws.A[1] - ws.A[0];
-    const int64_t gstride = L.heavy[2].w - L.heavy[1].w;
-    for (int i = 2; i < nh; ++i)
-      if (L.heavy[i].w - L.heavy[i - 1].w != gstride) return BLH_ERR_SHAPE;
-    if (bplan.splits == 1) {
-      g.C = grads + L.heavy[1].w; g.c_batch_stride = gstride; g.c_split_stride = 0;
-      BLH_TRY(launch_gemm_bf16s(s, KROW, KROW, EPI_STORE, false, g, items));
-    } else {
-      g.C = ws.bslabs; g.c_split_stride = (int64_t)W * W; g.c_batch_stride = (int64_t)bplan.splits * W * W;
-      BLH_TRY(launch_gemm_bf16s(s, KROW, KROW, EPI_STORE, false, g, items * bplan.splits));
-      BLH_TRY(launch_sum_slabs_batched(s, ws.bslabs, (int64_t)W * W, bplan.splits, items, g.c_batch_stride,
-                                       grads + L.heavy[1].w, gstride));
-    }
+  if (on_ready == nullptr && !wgroups.empty() && wgroups[0].plan.splits > 0) {
+    BLH_TRY(launch_group(wgroups[0], s));   // (the stage-0 and decode weight gradients, side stream, run beside it)
   }
   if (!on_ready) {
     int64_t offs[32];

@@ -269,15 +269,17 @@ static Splits wgrad_plan_h(int64_t M, int64_t N, int64_t batch) {
 // 16 stages x 1 slab at configs[4] (no slabs at all, and no 256 x 256 weight gradient beside the
 // BatchNorm chain, which cannot run beside one: 7.73 -> 7.40 ms).  {0, 0}: not applicable (the per-stage
 // plan above is used; always under a bucket hook, which wants each range as early as possible).
+static constexpr int WGRAD_HOOK_GROUP = 4;     // stages per batched launch under a bucket hook
 static Splits wgrad_batched_plan_h(int64_t W, int64_t batch, int items) {
   if (items < 2 || W % 256 != 0 || batch % 128 != 0 || std::getenv("BLH_NO_BATCHED_WGRAD")) return Splits{0, 0};
   const int64_t tiles = (W / 256) * (W / 256);
   int64_t s = 1;
   while (s < 8 && tiles * items * (s * 2) <= 256) s *= 2;
   while (s > 1 && batch % (s * 128) != 0) s >>= 1;
-  // (each workgroup at least 2048 rows deep: below that the per-stage plan measured as fast or faster,
-  //  0.434 against 0.441 ms per step at 2 x 1024, B = 4096)
-  if (tiles * items * s < 224 || batch / s < 2048) return Splits{0, 0};
+  // (each workgroup at least 4096 rows deep: below that the per-stage plan measured as fast or faster —
+  //  0.434 against 0.441 ms per step at 2 x 1024, B = 4096; 1.109 against 1.125 ms for the data-parallel
+  //  step at B = 8192 with groups of four stages x 4 slabs)
+  if (tiles * items * s < 224 || batch / s < 4096) return Splits{0, 0};
   return Splits{(int)s, (int)(batch / s)};
 }
 
@@ -315,10 +317,14 @@ static WorkspaceH carve_h(const blh_model_desc* d, int64_t batch, void* base) {
   ws.bn_part = (float*)take(chunks * 2 * W * sizeof(float));
   ws.dz_colsum_part = (float*)take((int64_t)nh * chunks * W * sizeof(float));
   ws.slabs = (float*)take(slab_floats_h(d, batch) * sizeof(float));
-  {
+  {   // slabs of the batched weight gradient: all hidden stages (no hook) or a group of up to four (hook)
     const int hidden = 2 * d->num_blocks;
-    const Splits bp = wgrad_batched_plan_h(W, batch, hidden);
-    ws.bslabs = bp.splits > 1 ? (float*)take((int64_t)hidden * bp.splits * W * W * sizeof(float)) : nullptr;
+    int64_t need = 0;
+    for (int items : {hidden, std::min(hidden, WGRAD_HOOK_GROUP), hidden % WGRAD_HOOK_GROUP}) {
+      const Splits bp = wgrad_batched_plan_h(W, batch, items);
+      if (bp.splits > 1) need = std::max(need, (int64_t)items * bp.splits * W * W);
+    }
+    ws.bslabs = need ? (float*)take(need * sizeof(float)) : nullptr;
   }
   ws.dpred = (float*)take(batch * d->out_features * sizeof(float));
   ws.dpredh = (uint16_t*)take(batch * d->out_features * 2);
