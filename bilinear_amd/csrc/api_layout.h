@@ -267,8 +267,8 @@ static Splits wgrad_plan_h(int64_t M, int64_t N, int64_t batch) {
 // batch slabs per stage as make about 256 workgroups: 8 stages x 2 slabs at configs[2] (each workgroup
 // 8192 rows deep: 25 us per stage against 42 alone / 60-100 in the step for the per-stage 128 x 128 plan),
 // 16 stages x 1 slab at configs[4] (no slabs at all, and no 256 x 256 weight gradient beside the
-// BatchNorm chain, which cannot run beside one: 7.73 -> 7.40 ms).  {0, 0}: not applicable (the per-stage
-// plan above is used; always under a bucket hook, which wants each range as early as possible).
+// BatchNorm chain, which cannot run beside one: 7.73 -> 7.40 ms).  Under a bucket hook `items` is a group of
+// WGRAD_HOOK_GROUP stages (api.hip: backward_h).  {0, 0}: not applicable (the per-stage plan above is used).
 static constexpr int WGRAD_HOOK_GROUP = 4;     // stages per batched launch under a bucket hook
 static Splits wgrad_batched_plan_h(int64_t W, int64_t batch, int items) {
   if (items < 2 || W % 256 != 0 || batch % 128 != 0 || std::getenv("BLH_NO_BATCHED_WGRAD")) return Splits{0, 0};
