@@ -62,7 +62,7 @@ def time_kernel(fn, reps, warm=50):
     return start.elapsed_time(stop) / reps
 
 
-def gemm_rooflines(batch, width, reps, dtype="fp32"):
+def gemm_rooflines(batch, width, reps, dtype="fp32", hidden=0):
     """Live timings of the three Linear contractions at the hidden-layer shape."""
     from bilinear_amd import _native as N
     lib = N.lib()
@@ -80,7 +80,7 @@ def gemm_rooflines(batch, width, reps, dtype="fp32"):
                 return rc
             return call
     if dtype == "bf16s":
-        return gemm_rooflines_bf16s(batch, width, reps)
+        return gemm_rooflines_bf16s(batch, width, reps, hidden)
     A = torch.randn(batch, width, device=dev)
     Wt = torch.randn(width, width, device=dev) * 0.03
     bias = torch.randn(width, device=dev)
@@ -137,8 +137,22 @@ def bf16s_kernel_name(batch, width):
     return "gemm_bf16s_kernel"
 
 
-def gemm_rooflines_bf16s(batch, width, reps):
-    """The three contractions of a hidden Linear in bf16 storage (gemm_bf16s_kernel.h)."""
+def batched_wgrad_plan(width, batch, items):
+    """Slabs per stage of the batched weight gradient (api_layout.h: wgrad_batched_plan_h), 0 = per-stage plan."""
+    if items < 2 or width % 256 or batch % 128:
+        return 0
+    tiles = (width // 256) ** 2
+    s = 1
+    while s < 8 and tiles * items * (s * 2) <= 256:
+        s *= 2
+    while s > 1 and batch % (s * 128):
+        s //= 2
+    return s if (tiles * items * s >= 224 and batch // s >= 4096) else 0
+
+
+def gemm_rooflines_bf16s(batch, width, reps, hidden=0):
+    """The three contractions of a hidden Linear in bf16 storage (gemm_bf16s_kernel.h); with `hidden` stages
+    also the batched weight gradient of all of them in one launch, as the fused step runs it (per stage)."""
     from bilinear_amd import _native as N
     lib = N.lib()
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -176,6 +190,20 @@ def gemm_rooflines_bf16s(batch, width, reps):
     for name, fn in (("linear_fwd", fwd), ("linear_dgrad", dgrad), ("linear_wgrad", wgrad)):
         ms = time_kernel(fn, reps)
         out[name] = {"ms": ms, "tflops": flop / ms / 1e9}
+    bs = batched_wgrad_plan(width, batch, hidden)
+    if bs:
+        del slabs
+        dz = torch.randn(hidden, batch, width, device=dev).to(torch.bfloat16)
+        act = torch.randn(hidden, batch, width, device=dev).to(torch.bfloat16)
+        outb = torch.empty(hidden, bs, width, width, device=dev)
+
+        def wgrad_batched():
+            N.check(lib.blh_gemm_bf16s_batched(st, dz.data_ptr(), width, 1, batch * width, act.data_ptr(), width, 1,
+                                               batch * width, outb.data_ptr(), width, bs * width * width,
+                                               width, width, batch, hidden, bs), "wgrad batched")
+        ms = time_kernel(wgrad_batched, max(20, reps // 8)) / hidden
+        out["linear_wgrad_batched"] = {"ms": ms, "tflops": flop / ms / 1e9, "stages": hidden, "slabs": bs,
+                                       "note": "per stage, all hidden stages in one launch (the fused step)"}
     return out
 
 
@@ -501,7 +529,7 @@ def config_block(idx, dev, steps, ramp_ms):
     final = float(loss.item())
     fwd, bwd = flops_per_pose(a.blocks, a.width)
     poses = a.batch * steps / el
-    kern = gemm_rooflines(a.batch, a.width, reps=200, dtype=a.dtype)
+    kern = gemm_rooflines(a.batch, a.width, reps=200, dtype=a.dtype, hidden=2 * a.blocks)
     out = {
         "workload": workload_label(a, 1) + "; x~N(0,1)[B,32], t~N(0,1)[B,48], Kaiming-normal init",
         "value": poses, "unit": "poses/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
@@ -749,7 +777,7 @@ def main():
         log("fwd+bwd only: %.3f ms" % fb_ms)
         # (long enough for the clocks to settle: the first ~50 ms after an idle period run at a
         #  lower DVFS state and read 10-15 % slow)
-        kern = gemm_rooflines(args.batch, args.width, reps=500, dtype=args.dtype)
+        kern = gemm_rooflines(args.batch, args.width, reps=500, dtype=args.dtype, hidden=2 * args.blocks)
         log("kernel timings: %s" % json.dumps(kern))
         dom = kern["linear_fwd"]
         result = {

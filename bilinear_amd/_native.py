@@ -136,6 +136,9 @@ _SIGNATURES = {
     "blh_gemm_bf16s": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
                                c_void_p, c_int64, c_int32, c_int64, c_int64, c_int64, c_int32,
                                c_void_p, c_void_p, c_int64, c_void_p]),
+    "blh_gemm_bf16s_batched": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_int64, c_int32,
+                                       c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int32,
+                                       c_int32]),
     "blh_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "blh_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "blh_linear_fwd_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

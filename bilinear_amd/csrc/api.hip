@@ -1521,6 +1521,24 @@ int blh_gemm_bf16s(void* stream, const uint16_t* A, int64_t lda, int32_t a_kmajo
                            out_bf16 != 0, g, splits);
 }
 
+int blh_gemm_bf16s_batched(void* stream, const uint16_t* A, int64_t lda, int32_t a_kmajor, int64_t a_item_stride,
+                           const uint16_t* B, int64_t ldb, int32_t b_kmajor, int64_t b_item_stride, float* C,
+                           int64_t ldc, int64_t c_item_stride, int64_t M, int64_t N, int64_t K, int32_t items,
+                           int32_t splits) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || items < 1 || splits < 1) return BLH_ERR_INVALID_ARGUMENT;
+  if (K % splits != 0 || a_item_stride % 8 != 0 || b_item_stride % 8 != 0) return BLH_ERR_SHAPE;
+  if (splits > 1 && c_item_stride < (int64_t)splits * M * ldc) return BLH_ERR_INVALID_ARGUMENT;
+  GemmParamsH g{};
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.M = (int)M; g.N = (int)N; g.K = (int)K;
+  g.k_per_split = (int)(K / splits);
+  g.c_split_stride = M * ldc;
+  g.batch_splits = splits;
+  g.a_batch_stride = a_item_stride; g.b_batch_stride = b_item_stride; g.c_batch_stride = c_item_stride;
+  return launch_gemm_bf16s((hipStream_t)stream, a_kmajor ? KROW : ROWK, b_kmajor ? KROW : ROWK, EPI_STORE, false, g,
+                           items * splits);
+}
+
 int32_t blh_gemm_bf16s_tile(int64_t M, int64_t N, int64_t K, int32_t a_kmajor, int32_t b_kmajor,
                             int32_t out_bf16, int32_t splits) {
   if (M <= 0 || N <= 0 || K <= 0 || splits < 1) return BLH_ERR_INVALID_ARGUMENT;

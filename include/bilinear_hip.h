@@ -435,6 +435,17 @@ int blh_gemm_bf16s(void* stream, const uint16_t* A, int64_t lda, int32_t a_kmajo
                    int64_t ldadd, float* stat_part);
 int32_t blh_gemm_bf16s_tile(int64_t M, int64_t N, int64_t K, int32_t a_kmajor, int32_t b_kmajor,
                             int32_t out_bf16, int32_t splits);
+/* `items` independent contractions of ONE shape in one launch of the 256 x 256 kernel: the weight
+ * gradients dW_l = dZ_l^T A_(l-1) of several hidden stages of the lifter at once
+ * (train_bilinear.py:79 through model/bilinear.py:25-26), which one stage alone cannot fill the
+ * chip with.  Item i reads A + i * a_item_stride and B + i * b_item_stride (elements) and writes
+ * fp32 slabs C + i * c_item_stride + s * M * ldc for s < splits (splits == 1: the result itself).
+ * Shapes: M, N % 256 == 0, K == splits * k with k % 128 == 0; BLH_ERR_SHAPE otherwise, and when
+ * items * splits * (M/256) * (N/256) < 224 workgroups (use blh_gemm_bf16s per item then).       */
+int blh_gemm_bf16s_batched(void* stream, const uint16_t* A, int64_t lda, int32_t a_kmajor, int64_t a_item_stride,
+                           const uint16_t* B, int64_t ldb, int32_t b_kmajor, int64_t b_item_stride, float* C,
+                           int64_t ldc, int64_t c_item_stride, int64_t M, int64_t N, int64_t K, int32_t items,
+                           int32_t splits);
 /* fp32 <-> bf16 (round to nearest even) over `count` elements (multiple of 4).              */
 int blh_cast_f32_to_bf16(void* stream, const float* src, uint16_t* dst, int64_t count);
 int blh_cast_bf16_to_f32(void* stream, const uint16_t* src, float* dst, int64_t count);

@@ -88,6 +88,47 @@ def test_gemm_bf16s_layouts(native, M, N, K, ak, bk, splits, out_bf16):
         assert err.max() <= 2e-5, err.max()
 
 
+@pytest.mark.parametrize("M,N,K,items,splits,pad", [
+    (1024, 1024, 8192, 4, 4, 0),     # a group of four W = 1024 stages (the data-parallel hook path)
+    (1024, 1024, 4096, 8, 2, 512),   # eight stages x two slabs, item strides larger than the tensors
+    (512, 768, 2048, 10, 4, 0),      # non-square output, items x slabs x tiles = 240 workgroups
+    (2048, 2048, 4096, 4, 1, 0),     # W = 2048: one slab, results written in place (no slabs)
+])
+def test_gemm_bf16s_batched_weight_gradients(native, M, N, K, items, splits, pad):
+    """blh_gemm_bf16s_batched: `items` weight gradients dW_i = dZ_i^T A_i (both operands with the
+    reduction index as the memory row) in ONE launch of the 256 x 256 kernel, item strides on every
+    operand, slabs over the reduction; each item against the exact product of its bf16 operands."""
+    dev = _dev()
+    rng = np.random.RandomState(items + splits)
+    sa, sb = K * M + pad, K * N + pad          # elements between items (the step: one [B, W] tensor apart)
+    A = rng.standard_normal((items, sa)).astype(np.float32)
+    B = rng.standard_normal((items, sb)).astype(np.float32)
+    Ab, Bb = _to_bf16_bits(A), _to_bf16_bits(B)
+    a = torch.from_numpy(Ab.view(np.int16)).to(dev)
+    b = torch.from_numpy(Bb.view(np.int16)).to(dev)
+    sc = splits * M * N + (64 if splits > 1 else 192)
+    c = torch.full((items, sc), float("nan"), device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = native.blh_gemm_bf16s_batched(st, a.data_ptr(), M, 1, sa, b.data_ptr(), N, 1, sb, c.data_ptr(), N, sc,
+                                       M, N, K, items, splits)
+    assert rc == 0, native.blh_status_string(rc)
+    torch.cuda.synchronize()
+    got_all = c.cpu().numpy().astype(np.float64)
+    for i in range(items):
+        A64 = _bits_to_f32(Ab[i, :K * M]).astype(np.float64).reshape(K, M)
+        B64 = _bits_to_f32(Bb[i, :K * N]).astype(np.float64).reshape(K, N)
+        ref = A64.T @ B64
+        mag = np.abs(A64).T @ np.abs(B64)
+        got = got_all[i, :splits * M * N].reshape(splits, M, N).sum(axis=0)
+        err = np.abs(got - ref) / mag
+        assert err.max() <= 2e-5, (i, err.max())
+        assert np.isnan(got_all[i, splits * M * N:]).all(), "wrote past the item's slabs"
+    # too few workgroups for the 256 x 256 kernel: refused, not silently run on another kernel
+    rc = native.blh_gemm_bf16s_batched(st, a.data_ptr(), M, 1, sa, b.data_ptr(), N, 1, sb, c.data_ptr(), N, sc,
+                                       256, 256, K, 2, 1)
+    assert rc != 0
+
+
 @pytest.mark.parametrize("M,N,K", [(392, 384, 192), (8392, 768, 256)])
 def test_gemm_bf16s_epilogues(native, M, N, K):
     """(392, 384, 192): the 128 x 128 kernel; (8392, 768, 256): the 256 x 256 kernel (33 x 3 tiles,
