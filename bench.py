@@ -130,24 +130,26 @@ def bf16s_kernel_name(batch, width):
     """Which bf16-storage GEMM the library picks for the forward contraction at this shape."""
     try:
         from bilinear_amd import _native as N
-        if N.lib().blh_gemm_bf16s_tile(batch, width, width, 0, 0, 1, 1) == 256:
+        rows = N.lib().blh_gemm_bf16s_tile(batch, width, width, 0, 0, 1, 1)
+        cols = N.lib().blh_gemm_bf16s_tile_cols(batch, width, width, 0, 0, 1, 1)
+        if rows == 256:
             return "gemm_bf16s_256_kernel"
+        if cols == 256:
+            return "gemm_bf16s_128x256_kernel"
     except Exception:   # noqa: BLE001  (naming only)
         pass
     return "gemm_bf16s_kernel"
 
 
-def batched_wgrad_plan(width, batch, items):
-    """Slabs per stage of the batched weight gradient (api_layout.h: wgrad_batched_plan_h), 0 = per-stage plan."""
-    if items < 2 or width % 256 or batch % 128:
-        return 0
-    tiles = (width // 256) ** 2
-    s = 1
-    while s < 8 and tiles * items * (s * 2) <= 256:
-        s *= 2
-    while s > 1 and batch % (s * 128):
-        s //= 2
-    return s if (tiles * items * s >= 224 and batch // s >= 4096) else 0
+def wgrad_plans(width, batch, stages):
+    """(slabs per stage of the batched weight gradient or 0, slabs of the per-stage plan): asked of the
+    library (blh_wgrad_plan_bf16s -> api_layout.h), so the timings below follow the step's own plan
+    under every tuning knob."""
+    from bilinear_amd import _native as N
+    batched, per_stage = ctypes.c_int32(0), ctypes.c_int32(1)
+    N.check(N.lib().blh_wgrad_plan_bf16s(width, batch, max(1, stages), ctypes.byref(batched),
+                                         ctypes.byref(per_stage)), "blh_wgrad_plan_bf16s")
+    return int(batched.value), int(per_stage.value)
 
 
 def gemm_rooflines_bf16s(batch, width, reps, hidden=0):
@@ -163,13 +165,7 @@ def gemm_rooflines_bf16s(batch, width, reps, hidden=0):
     Z = torch.empty(batch, width, dtype=torch.bfloat16, device=dev)
     stat = torch.empty((batch + 127) // 128, 2, width, device=dev)
     # batch slabs of the weight gradient as the step plans them (api_layout.h: wgrad_plan_h)
-    t256 = (width // 256) ** 2
-    if width % 256 == 0 and t256 >= 64:
-        splits = max(1, 256 // t256)
-        while splits > 1 and batch % (splits * 128) != 0:
-            splits //= 2
-    else:
-        splits = max(1, min((256 * 128 * 128) // (width * width), batch // 128))
+    bs, splits = wgrad_plans(width, batch, hidden)
     slabs = torch.empty(splits, width, width, device=dev)
     flop = 2.0 * batch * width * width
 
@@ -190,7 +186,6 @@ def gemm_rooflines_bf16s(batch, width, reps, hidden=0):
     for name, fn in (("linear_fwd", fwd), ("linear_dgrad", dgrad), ("linear_wgrad", wgrad)):
         ms = time_kernel(fn, reps)
         out[name] = {"ms": ms, "tflops": flop / ms / 1e9}
-    bs = batched_wgrad_plan(width, batch, hidden)
     if bs:
         del slabs
         dz = torch.randn(hidden, batch, width, device=dev).to(torch.bfloat16)
@@ -259,33 +254,49 @@ def skinny_rooflines(batch, width, reps):
     return out
 
 
+def _traffic_record(batch, width, kernel_substr):
+    """HBM traffic (bytes per launch) of a shipped GEMM from the newest committed rocprofv3 --pmc record that
+    has this shape (profiles/r04_traffic.json, this round's binary: tools_dev/pmc_r04.sh).  bench.py cannot
+    run the PMC passes itself (separate profiler runs); None for shapes that were not profiled."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r04_traffic.json")) as f:
+            shape = json.load(f)["shapes"].get("%dx%d" % (batch, width), {})
+        for kernel, rec in shape.items():
+            if kernel_substr in kernel:
+                return rec["traffic_bytes"], "profiles/r04_traffic.json"
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
+
+
 def recorded_traffic(batch, width):
-    """HBM traffic of the dominant kernel (bytes per launch).  bench.py cannot run the PMC
-    passes itself; the figure comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    runs of the same kernel (profiles/r02_traffic.json, gfx950 correction applied there) and
-    is only reported for the shape it was measured on."""
+    """fp32 ring GEMM forward (EPI 2 = bias + BatchNorm partials); falls back to the round-2 record."""
+    t, src = _traffic_record(batch, width, "gemm_f32_ring_kernel<128, 128, 4, 2, 0, 0, 2")
+    if t is not None:
+        return t, src
     if (batch, width) != (4096, 1024):
-        return None
+        return None, None
     try:
         with open(os.path.join(REPO, "profiles", "r02_traffic.json")) as f:
-            return json.load(f)["kernels"]["linear_fwd"]["traffic_bytes"]
+            return json.load(f)["kernels"]["linear_fwd"]["traffic_bytes"], "profiles/r02_traffic.json"
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
 def recorded_traffic_bf16s(batch, width):
-    """PMC traffic (bytes per launch) of the bf16-storage forward GEMM at (M = batch, N = K =
-    width), from the committed rocprofv3 --pmc runs (profiles/r03_bf16s_traffic.json; the newest
-    record wins).  None for shapes that were not profiled."""
-    for name in ("r03_bf16s_traffic.json",):
-        try:
-            with open(os.path.join(REPO, "profiles", name)) as f:
-                rec = json.load(f)["linear_fwd"].get("%dx%d" % (batch, width))
-            if rec:
-                return rec["traffic_bytes"]
-        except (OSError, KeyError, ValueError):
-            pass
-    return None
+    """bf16-storage forward GEMM (<ROWK, ROWK, bias + BatchNorm partials, bf16 out> of whichever kernel the
+    dispatcher picks at this shape); falls back to the round-3 record."""
+    t, src = _traffic_record(batch, width, "<0, 0, 2, true")
+    if t is not None:
+        return t, src
+    try:
+        with open(os.path.join(REPO, "profiles", "r03_bf16s_traffic.json")) as f:
+            rec = json.load(f)["linear_fwd"].get("%dx%d" % (batch, width))
+        if rec and (batch, width) != (8192, 1024):     # (that shape changed kernels in round 4)
+            return rec["traffic_bytes"], "profiles/r03_bf16s_traffic.json"
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
 
 
 def recorded_ceiling(batch, width):
@@ -302,26 +313,31 @@ def roofline_block(args, dom):
     """Roofline of the dominant kernel (the WxW Linear forward GEMM at M = batch)."""
     flop = 2.0 * args.batch * args.width * args.width
     if args.dtype == "fp32":
+        traffic, traffic_src = recorded_traffic(args.batch, args.width)
         return {
             "kernel": "gemm_f32_ring_kernel<128,128,4,2,ROWK,ROWK,BIAS_STATS> (Linear %dx%d forward, M=%d)" % (
                 args.width, args.width, args.batch),
             "bound": "mfma", "achieved": dom["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": dom["tflops"] / FP32_MFMA_PEAK_TFLOPS,
-            "traffic": recorded_traffic(args.batch, args.width),
-            "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r02_traffic.json)",
+            "traffic": traffic,
+            "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, %s)" % traffic_src,
             "avg_launch_ms": dom["ms"], "flop_per_launch": flop,
+            "avg_launch_ms_how": "HIP events around %d back-to-back launches on the launch stream; the rocprofv3 "
+                                 "--kernel-trace average of the same kernel inside the step is in "
+                                 "profiles/r04_final_kernel_stats.md" % 500,
             # what a kernel of this launch shape (one 128x128 tile per CU) can reach at all: the
             # same kernel with its loop reduced to the MFMAs, measured (profiles/r02_traffic.json)
             "shape_ceiling": recorded_ceiling(args.batch, args.width),
         }
     if args.dtype == "bf16s":
+        traffic, traffic_src = recorded_traffic_bf16s(args.batch, args.width)
         return {
             "kernel": "%s<ROWK,ROWK,BIAS_STATS,bf16 out> (Linear %dx%d forward, M=%d, bf16 storage)" % (
                 bf16s_kernel_name(args.batch, args.width), args.width, args.width, args.batch),
             "bound": "mfma", "achieved": dom["tflops"], "peak": BF16_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": dom["tflops"] / BF16_MFMA_PEAK_TFLOPS,
-            "traffic": recorded_traffic_bf16s(args.batch, args.width),
-            "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r03_bf16s_traffic.json)",
+            "traffic": traffic,
+            "traffic_unit": "bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, %s)" % traffic_src,
             "avg_launch_ms": dom["ms"], "flop_per_launch": flop,
             "algorithmic_bytes_per_launch": 2.0 * (2 * args.batch * args.width + args.width * args.width),
         }
@@ -461,7 +477,9 @@ def self_launch(n):
     has touched the GPU, let rank 0's JSON line through on stdout, and exit with the children's
     return code.  (Nothing is exec'ed: a process that has initialised HIP must never be replaced.)"""
     rehearse = os.environ.get("BLH_BENCH_REHEARSE") == "1"
-    have = torch.cuda.device_count()          # does not initialise the GPU
+    # (device_count() may call hipGetDeviceCount on builds without amdsmi, i.e. initialise the HIP
+    #  runtime in THIS process; harmless: the ranks are fresh children and nothing is exec'ed)
+    have = torch.cuda.device_count()
     if have < n and not rehearse:
         raise SystemExit("bench.py --gpus %d: this node exposes %d GPU%s (set BLH_BENCH_REHEARSE=1 to "
                          "rehearse the multi-rank control flow on one GPU over gloo)" % (n, have, "" if have == 1 else "s"))
@@ -794,6 +812,10 @@ def main():
             "dtype": DTYPE_TEXT[args.dtype],
             "pre_ramp_ms": ramp_ms,
             "pre_ramp_steps": ramp_steps,
+            "protocol": "untimed pre-ramp (%d steps, %.0f ms: DVFS ramp after idle) + --warmup steps, then --steps "
+                        "timed steps between barrier+synchronize pairs; rounds 1-2 had no pre-ramp (their "
+                        "20-step driver runs were timed inside the clock ramp): compare across rounds with "
+                        "--pre-ramp-ms 0" % (ramp_steps, ramp_ms),
             "data": "synthetic",
             "config": {
                 "workload": workload_label(args, world) + "; x~N(0,1)[B,32], t~N(0,1)[B,48], "
@@ -814,7 +836,9 @@ def main():
             "final_loss": final_loss,
             "fwd_bwd_only": {"ms_per_step": fb_ms, "poses_per_s": args.batch / (fb_ms / 1e3)},
             "step_tflops": poses * (fwd + bwd) / 1e12,
-            "step_frac_of_fp32_mfma_peak": poses * (fwd + bwd) / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
+            ("step_frac_of_bf16_mfma_peak" if args.dtype in ("bf16s", "bf16") else "step_frac_of_fp32_mfma_peak"):
+                poses * (fwd + bwd) / 1e12 / ((BF16_MFMA_PEAK_TFLOPS if args.dtype in ("bf16s", "bf16")
+                                               else FP32_MFMA_PEAK_TFLOPS) * world),
             "roofline": roofline_block(args, dom),
             "roofline_hbm": skinny_rooflines(args.batch, args.width, reps=300),
             "kernels": kern,
@@ -838,13 +862,27 @@ def main():
             cores = host_cores()
             log("cpu baseline on %d threads" % cores)
             cpu = TP.time_cpu_steps(args.blocks, args.width, args.batch, steps=args.cpu_steps,
-                                    warmup=2, threads=cores)
+                                    warmup=3, threads=cores)
+            # also forward + backward alone, and BASELINE configs[0]'s batch of 64
+            # (the reference's own batch size, /root/reference/util/config.py:15)
+            cpu_fb = TP.time_cpu_steps(args.blocks, args.width, args.batch, steps=max(10, args.cpu_steps),
+                                       warmup=3, threads=cores, fwd_bwd_only=True)
+            cpu64 = TP.time_cpu_steps(args.blocks, args.width, 64, steps=50, warmup=5, threads=cores)
+            cpu64_fb = TP.time_cpu_steps(args.blocks, args.width, 64, steps=50, warmup=5, threads=cores,
+                                         fwd_bwd_only=True)
             result["cpu_baseline"] = {
                 "value": cpu["poses_per_s"], "unit": "poses/s", "cores": cpu["threads"],
                 "kind": "port",
                 "sample": "%d full steps (fwd+MSE+bwd+clip+Adam) of oracle/torch_port.py, batch %d, "
-                          "fp32, after 2 warm-up steps" % (cpu["steps"], args.batch),
+                          "fp32, after 3 warm-up steps" % (cpu["steps"], args.batch),
                 "ms_per_step": cpu["ms_per_step"],
+                "fwd_bwd": {"value": cpu_fb["poses_per_s"], "unit": "poses/s", "ms_per_step": cpu_fb["ms_per_step"],
+                            "sample": "%d x (zero_grad + forward + MSE + backward), batch %d" % (
+                                cpu_fb["steps"], args.batch)},
+                "batch_64": {"value": cpu64["poses_per_s"], "unit": "poses/s", "ms_per_step": cpu64["ms_per_step"],
+                             "fwd_bwd_value": cpu64_fb["poses_per_s"], "fwd_bwd_ms_per_step": cpu64_fb["ms_per_step"],
+                             "sample": "50 full steps / 50 forward+backward passes at batch 64 "
+                                       "(BASELINE configs[0]), after 5 warm-up steps"},
             }
         print(json.dumps(result), flush=True)
     if multi:

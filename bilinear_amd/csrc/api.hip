@@ -490,7 +490,7 @@ static int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, c
     g.bias = params + h.b; g.stat_part = ws.stat_part;
     BLH_TRY(launch_gemm_bf16s(s, ROWK, ROWK, train ? EPI_BIAS_STATS : EPI_BIAS, true, g, 1));
     // (BatchNorm partials: one (mean, M2) pair per row tile of the kernel that ran, 128 or 256 rows)
-    const int st_rows = gemm_bf16s_pick_tile(ROWK, ROWK, true, g, 1);
+    const int st_rows = gemm_bf16s_tile_rows(gemm_bf16s_pick_tile(ROWK, ROWK, true, g, 1));
     const int st_tiles = (int)ceil_div(batch, st_rows);
     const uint16_t* skip = (i >= 2 && (i % 2) == 0) ? ws.A[i - 2] : nullptr;
     float* rm = bn_running + ((int64_t)i * 2 + 0) * W;
@@ -573,7 +573,9 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
     GemmParamsH gp{};
     gp.M = (int)batch; gp.N = W; gp.K = W; gp.k_per_split = W; gp.lda = gp.ldb = gp.ldc = W;
     const int tile = gemm_bf16s_pick_tile(ROWK, KROW, true, gp, 1);
-    late_policy = ceil_div(batch, tile) * ceil_div(W, tile) > (tile == 256 ? 256 : 512);
+    // (the big-tile kernels hold a CU alone; two workgroups of the 128 x 128 kernel share one)
+    late_policy = ceil_div(batch, gemm_bf16s_tile_rows(tile)) * ceil_div(W, gemm_bf16s_tile_cols(tile)) >
+                  (tile == H_TILE_128 ? 512 : 256);
   }
   // Two streams as in backward_impl: every weight-gradient GEMM (+ its slab sum) runs on the
   // context's side stream — in order there, so they share one slab buffer — forked behind the
@@ -1547,7 +1549,33 @@ int32_t blh_gemm_bf16s_tile(int64_t M, int64_t N, int64_t K, int32_t a_kmajor, i
   g.M = (int)M; g.N = (int)N; g.K = (int)K;
   g.k_per_split = (splits > 1) ? (int)round_up(ceil_div(K, splits), 128) : (int)K;
   g.c_split_stride = M * N;
-  return gemm_bf16s_pick_tile(a_kmajor ? KROW : ROWK, b_kmajor ? KROW : ROWK, out_bf16 != 0, g, splits);
+  return gemm_bf16s_tile_rows(gemm_bf16s_pick_tile(a_kmajor ? KROW : ROWK, b_kmajor ? KROW : ROWK, out_bf16 != 0, g, splits));
+}
+
+int32_t blh_gemm_bf16s_tile_cols(int64_t M, int64_t N, int64_t K, int32_t a_kmajor, int32_t b_kmajor,
+                                 int32_t out_bf16, int32_t splits) {
+  if (M <= 0 || N <= 0 || K <= 0 || splits < 1) return BLH_ERR_INVALID_ARGUMENT;
+  GemmParamsH g{};
+  g.lda = a_kmajor ? M : K; g.ldb = b_kmajor ? N : K; g.ldc = N;
+  g.M = (int)M; g.N = (int)N; g.K = (int)K;
+  g.k_per_split = (splits > 1) ? (int)round_up(ceil_div(K, splits), 128) : (int)K;
+  g.c_split_stride = M * N;
+  return gemm_bf16s_tile_cols(gemm_bf16s_pick_tile(a_kmajor ? KROW : ROWK, b_kmajor ? KROW : ROWK, out_bf16 != 0, g, splits));
+}
+
+int blh_wgrad_plan_bf16s(int64_t width, int64_t batch, int32_t stages, int32_t* batched_slabs,
+                         int32_t* stage_slabs) {
+  if (width <= 0 || batch <= 0 || stages < 1) return BLH_ERR_INVALID_ARGUMENT;
+  if (batched_slabs) *batched_slabs = wgrad_batched_plan_h(width, batch, stages).splits;
+  if (stage_slabs) *stage_slabs = wgrad_plan_h(width, width, batch).splits;
+  return BLH_OK;
+}
+
+int blh_gemm_bf16s_force_tile(int32_t tile) {
+  if (tile != 0 && tile != -1 && tile != H_TILE_128 && tile != H_TILE_256 && tile != H_TILE_128x256)
+    return BLH_ERR_INVALID_ARGUMENT;
+  gemm_bf16s_force_tile(tile);
+  return BLH_OK;
 }
 
 int blh_cast_f32_to_bf16(void* stream, const float* src, uint16_t* dst, int64_t count) {

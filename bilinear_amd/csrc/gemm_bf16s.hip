@@ -6,6 +6,7 @@
 
 #include "gemm_bf16s_kernel.h"
 #include "gemm_bf16s_256.h"
+#include "gemm_bf16s_128x256.h"
 
 namespace blh {
 
@@ -50,45 +51,78 @@ static int launch_h256(hipStream_t s, const GemmParamsH& p, int splits) {
   return BLH_OK;
 }
 
-// Which kernel serves a contraction: 256 (gemm_bf16s_256.h: 256 x 256 tiles, one workgroup per
-// CU, 8-phase schedule) when the launch has enough tiles to fill the chip and its shape meets that
-// kernel's restrictions, else 128 (gemm_bf16s_kernel.h).  BLH_BF16S_TILE = 128 | 256 forces one
-// (256 only where the shape allows it) for A/B measurements.
+template <int LA, int LB, int EPI, bool OUT_BF16>
+static int launch_h128x256(hipStream_t s, const GemmParamsH& p, int splits) {
+  static std::atomic<uint64_t> attr_done{0};
+  auto kern = gemm_bf16s_128x256_kernel<LA, LB, EPI, OUT_BF16>;
+  BLH_TRY(ensure_lds_attr_h(attr_done, reinterpret_cast<const void*>(kern), H128_LDS_BYTES));
+  const int tiles = (int)(ceil_div(p.M, 128) * (p.N / 256));
+  launch_kernel(kern, dim3(tiles, 1, splits), dim3(512), H128_LDS_BYTES, s, p);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+// Which kernel serves a contraction.  H_TILE_256 (gemm_bf16s_256.h: 256 x 256 tiles, one workgroup
+// per CU, 8-phase schedule) when the launch has enough such tiles to fill the chip and its shape meets
+// that kernel's restrictions; H_TILE_128x256 (gemm_bf16s_128x256.h: the same schedule on 128-row
+// tiles and a three-deep ring) when only the half-height tiles fill it (M = 8192 at W = 1024:
+// BASELINE configs[3] per GPU); else H_TILE_128 (gemm_bf16s_kernel.h).  BLH_BF16S_TILE = 128 | 256 |
+// 384 forces one (the big tiles only where the shape allows them) for A/B measurements.
+static std::atomic<int> g_forced_tile{-1};
 static int forced_tile() {
-  static const int v = [] {
+  int v = g_forced_tile.load(std::memory_order_relaxed);
+  if (v < 0) {
     const char* e = getenv("BLH_BF16S_TILE");
-    return e ? atoi(e) : 0;
-  }();
+    v = e ? atoi(e) : 0;
+    g_forced_tile.store(v, std::memory_order_relaxed);
+  }
   return v;
 }
+void gemm_bf16s_force_tile(int tile) { g_forced_tile.store(tile < 0 ? -1 : tile, std::memory_order_relaxed); }
 
 int gemm_bf16s_pick_tile(int la, int lb, bool out_bf16, const GemmParamsH& p, int splits) {
   const int vec = out_bf16 ? 8 : 4;
   const int slabs = p.batch_splits > 0 ? p.batch_splits : splits;     // per GEMM of a batched launch
   const int64_t extent = (slabs > 1) ? p.k_per_split : p.K;
-  const bool shape_ok = (p.N % 256 == 0) && extent >= 128 && (extent % 128 == 0) &&
-                        (slabs == 1 || (int64_t)slabs * p.k_per_split == p.K) &&
-                        (p.batch_splits == 0 || splits % p.batch_splits == 0) &&
-                        (p.ldc % vec == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
-                        (!p.addend || ((p.ldadd % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.addend) & 15) == 0))) &&
-                        (!out_bf16 || slabs == 1 || (p.c_split_stride % 8 == 0)) &&
-                        (out_bf16 || slabs == 1 || (p.c_split_stride % 4 == 0)) &&
-                        (p.batch_splits == 0 || p.c_batch_stride % 8 == 0) &&
-                        ((int64_t)256 * std::max(p.lda, p.ldb) * 2 < (1ll << 31)) &&
-                        (la == ROWK || p.M % 256 == 0);
-  if (!shape_ok) return 128;
+  // what both big-tile kernels need: whole 256-column tiles, 16-byte C rows / addend rows / slabs
+  const bool common_ok = (p.N % 256 == 0) && extent >= 128 &&
+                         (slabs == 1 || (int64_t)slabs * p.k_per_split == p.K) &&
+                         (p.batch_splits == 0 || splits % p.batch_splits == 0) &&
+                         (p.ldc % vec == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                         (!p.addend || ((p.ldadd % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.addend) & 15) == 0))) &&
+                         (!out_bf16 || slabs == 1 || (p.c_split_stride % 8 == 0)) &&
+                         (out_bf16 || slabs == 1 || (p.c_split_stride % 4 == 0)) &&
+                         (p.batch_splits == 0 || p.c_batch_stride % 8 == 0) &&
+                         ((int64_t)256 * std::max(p.lda, p.ldb) * 2 < (1ll << 31));
+  const bool ok256 = common_ok && (extent % 128 == 0) && (la == ROWK || p.M % 256 == 0);
+  const bool ok128x256 = common_ok && (extent % 64 == 0) && p.batch_splits == 0 && (la == ROWK || p.M % 128 == 0);
   const int force = forced_tile();
-  if (force == 128 || force == 256) return force;
-  const int64_t wgs = ceil_div(p.M, 256) * (p.N / 256) * splits;
-  // fewer workgroups: the 128 x 128 grid fills the 256 CUs better.  Weight gradients (both
-  // operands KROW, fp32 slabs): only with at most 4 slabs (api_layout.h: wgrad_plan_h)
-  if (la == KROW && slabs > 4 && p.batch_splits == 0 && !getenv("BLH_WGRAD256_MIN_TILES")) return 128;
-  return wgs >= 224 ? 256 : 128;
+  if (force == H_TILE_128) return H_TILE_128;
+  if (force == H_TILE_256 && ok256) return H_TILE_256;
+  if (force == H_TILE_128x256 && ok128x256) return H_TILE_128x256;
+  if (ok256) {
+    const int64_t wgs = ceil_div(p.M, 256) * (p.N / 256) * splits;
+    // Weight gradients (both operands KROW, fp32 slabs): only with at most 4 slabs (api_layout.h: wgrad_plan_h)
+    const bool wgrad_many_slabs = la == KROW && slabs > 4 && p.batch_splits == 0 && !getenv("BLH_WGRAD256_MIN_TILES");
+    if (!wgrad_many_slabs && wgs >= 224) return H_TILE_256;
+  }
+  if (ok128x256 && la == ROWK) {
+    // (forward / data gradient; the weight gradient keeps its measured plans)
+    const int64_t wgs = ceil_div(p.M, 128) * (p.N / 256) * splits;
+    if (wgs >= 224) return H_TILE_128x256;
+  }
+  // fewer workgroups: the 128 x 128 grid fills the 256 CUs better
+  return H_TILE_128;
 }
+
+int gemm_bf16s_tile_rows(int tile) { return tile == H_TILE_256 ? 256 : 128; }
+int gemm_bf16s_tile_cols(int tile) { return tile == H_TILE_128 ? 128 : 256; }
 
 #define BLH_CASEH(LA_, LB_, EPI_, OUT_)                                          \
   if (la == LA_ && lb == LB_ && epi == EPI_ && out_bf16 == OUT_)                 \
-    return tile256 ? launch_h256<LA_, LB_, EPI_, OUT_>(s, p, splits) : launch_h<LA_, LB_, EPI_, OUT_>(s, p, splits);
+    return tile == H_TILE_256      ? launch_h256<LA_, LB_, EPI_, OUT_>(s, p, splits)    \
+           : tile == H_TILE_128x256 ? launch_h128x256<LA_, LB_, EPI_, OUT_>(s, p, splits) \
+                                    : launch_h<LA_, LB_, EPI_, OUT_>(s, p, splits);
 
 int launch_gemm_bf16s(hipStream_t s, int la, int lb, int epi, bool out_bf16, const GemmParamsH& p,
                       int splits) {
@@ -101,8 +135,8 @@ int launch_gemm_bf16s(hipStream_t s, int la, int lb, int epi, bool out_bf16, con
   if (((uintptr_t)p.A | (uintptr_t)p.B) & 15) return BLH_ERR_INVALID_ARGUMENT;
   // 32-bit per-lane byte offsets inside one tile row panel
   if ((int64_t)128 * std::max(p.lda, p.ldb) * 2 >= (1ll << 31)) return BLH_ERR_SHAPE;
-  const bool tile256 = gemm_bf16s_pick_tile(la, lb, out_bf16, p, splits) == 256;
-  if (p.batch_splits > 0 && !tile256) return BLH_ERR_SHAPE;   // (batched launches exist on the 256 x 256 kernel only)
+  const int tile = gemm_bf16s_pick_tile(la, lb, out_bf16, p, splits);
+  if (p.batch_splits > 0 && tile != H_TILE_256) return BLH_ERR_SHAPE;   // (batched launches exist on the 256 x 256 kernel only)
   BLH_CASEH(ROWK, ROWK, EPI_BIAS_STATS, true)    // forward (train): Z bf16 + BatchNorm partials
   BLH_CASEH(ROWK, ROWK, EPI_BIAS, true)          // forward (eval)
   BLH_CASEH(ROWK, ROWK, EPI_BIAS, false)         // decode forward: fp32 prediction

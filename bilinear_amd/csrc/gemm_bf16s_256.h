@@ -140,8 +140,9 @@ __device__ __forceinline__ void read_frags_256(bf16x8_t (&frag)[T][2], const bf1
 // ---- epilogue ------------------------------------------------------------------------------------
 // acc[qm][qn][i][j][reg]: row m0 + qm*128 + wr*64 + i*16 + 4*(lane>>4) + reg,
 //                         column n0 + qn*128 + wc*32 + j*16 + (lane & 15)
-template <int EPI, bool OUT_BF16>
-__device__ inline void gemm_epilogue_256(f32x4 (&acc)[2][2][4][2], const GemmParamsH& p, void* Cv, float* smem,
+// NQM: quadrant rows of the tile (2: the 256 x 256 kernel, 1: the 128 x 256 kernel of gemm_bf16s_128x256.h)
+template <int EPI, bool OUT_BF16, int NQM = 2>
+__device__ inline void gemm_epilogue_256(f32x4 (&acc)[NQM][2][4][2], const GemmParamsH& p, void* Cv, float* smem,
                                          int m0, int n0, int tile_m) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
@@ -154,7 +155,7 @@ __device__ inline void gemm_epilogue_256(f32x4 (&acc)[2][2][4][2], const GemmPar
       for (int j = 0; j < 2; ++j) {
         const float bv = p.bias[n0 + qn * 128 + wc * 32 + j * 16 + c16];
 #pragma unroll
-        for (int qm = 0; qm < 2; ++qm)
+        for (int qm = 0; qm < NQM; ++qm)
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -174,10 +175,11 @@ __device__ inline void gemm_epilogue_256(f32x4 (&acc)[2][2][4][2], const GemmPar
   float* stg = smem;
   // skip-gradient addend: all 16 pieces of this thread (4 passes x 4) are requested here, in front of
   // the staging passes, so that their latency is paid once per tile and not once per pass
-  uint4 adv[(EPI == EPI_ADD && OUT_BF16) ? 4 : 1][(EPI == EPI_ADD && OUT_BF16) ? 4 : 1];
+  constexpr int NPS = 2 * NQM;        // staging passes of 64 rows
+  uint4 adv[(EPI == EPI_ADD && OUT_BF16) ? NPS : 1][(EPI == EPI_ADD && OUT_BF16) ? 4 : 1];
   if constexpr (EPI == EPI_ADD && OUT_BF16) {
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps)
+    for (int ps = 0; ps < NPS; ++ps)
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int q = it * 512 + tid;
@@ -187,7 +189,7 @@ __device__ inline void gemm_epilogue_256(f32x4 (&acc)[2][2][4][2], const GemmPar
       }
   }
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {
+  for (int ps = 0; ps < NPS; ++ps) {
     const int qm = ps >> 1, wrp = ps & 1;
     if (wr == wrp) {
 #pragma unroll
@@ -230,17 +232,17 @@ __device__ inline void gemm_epilogue_256(f32x4 (&acc)[2][2][4][2], const GemmPar
         }
       }
     }
-    if (ps < 3 || EPI == EPI_BIAS_STATS) __syncthreads();
+    if (ps < NPS - 1 || EPI == EPI_BIAS_STATS) __syncthreads();
   }
 
   if (EPI == EPI_BIAS_STATS) {
-    // per-tile column (mean, M2) over the tile's 256 rows, from the fp32 values (before rounding).
-    // Each wave row (128 of the rows) forms its own (n, mean, M2) in registers + two shuffles; one
+    // per-tile column (mean, M2) over the tile's 128 NQM rows, from the fp32 values (before rounding).
+    // Each wave row (half of the rows) forms its own (n, mean, M2) in registers + two shuffles; one
     // LDS exchange merges the two with Chan's formula.
     float* red = smem;                  // [2 wave rows][256 columns][mean, M2]
     int nrow = 0;                       // valid rows of this wave row (wave-uniform)
 #pragma unroll
-    for (int qm = 0; qm < 2; ++qm) nrow += max(0, min(64, p.M - (m0 + qm * 128 + wr * 64)));
+    for (int qm = 0; qm < NQM; ++qm) nrow += max(0, min(64, p.M - (m0 + qm * 128 + wr * 64)));
     const float inv_n = nrow > 0 ? 1.0f / (float)nrow : 0.f;
 #pragma unroll
     for (int qn = 0; qn < 2; ++qn)
@@ -248,7 +250,7 @@ __device__ inline void gemm_epilogue_256(f32x4 (&acc)[2][2][4][2], const GemmPar
       for (int j = 0; j < 2; ++j) {
         float s = 0.f;
 #pragma unroll
-        for (int qm = 0; qm < 2; ++qm)
+        for (int qm = 0; qm < NQM; ++qm)
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -261,7 +263,7 @@ __device__ inline void gemm_epilogue_256(f32x4 (&acc)[2][2][4][2], const GemmPar
         const float mean = s * inv_n;
         float q = 0.f;
 #pragma unroll
-        for (int qm = 0; qm < 2; ++qm)
+        for (int qm = 0; qm < NQM; ++qm)
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -283,7 +285,7 @@ __device__ inline void gemm_epilogue_256(f32x4 (&acc)[2][2][4][2], const GemmPar
       const int n0r = nrow;             // this wave row's count; the other one's:
       int n1r = 0;
 #pragma unroll
-      for (int qm = 0; qm < 2; ++qm) n1r += max(0, min(64, p.M - (m0 + qm * 128 + 64)));
+      for (int qm = 0; qm < NQM; ++qm) n1r += max(0, min(64, p.M - (m0 + qm * 128 + 64)));
 #pragma unroll
       for (int qn = 0; qn < 2; ++qn)
 #pragma unroll

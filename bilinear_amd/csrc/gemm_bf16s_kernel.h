@@ -174,8 +174,12 @@ __device__ inline void read_frags_h(bf16x8_t (&frag)[T], const bf16_bits* lds, i
 // host-side entry points (gemm_bf16s.hip)
 int launch_gemm_bf16s(hipStream_t s, int la, int lb, int epi, bool out_bf16, const GemmParamsH& p,
                       int splits);
-// 128 or 256: the tile (kernel) launch_gemm_bf16s uses for this contraction (gemm_bf16s.hip)
+// the tile (kernel) launch_gemm_bf16s uses for this contraction (gemm_bf16s.hip)
+enum HTile : int { H_TILE_128 = 128, H_TILE_256 = 256, H_TILE_128x256 = 384 };
 int gemm_bf16s_pick_tile(int la, int lb, bool out_bf16, const GemmParamsH& p, int splits);
+int gemm_bf16s_tile_rows(int tile);   // rows of one tile = rows per BatchNorm-partials record
+int gemm_bf16s_tile_cols(int tile);
+void gemm_bf16s_force_tile(int tile);  // 0: automatic; -1: re-read BLH_BF16S_TILE
 int launch_cast_f32_bf16(hipStream_t s, const float* src, uint16_t* dst, int64_t n);
 int launch_cast_bf16_f32(hipStream_t s, const uint16_t* src, float* dst, int64_t n);
 

@@ -7,6 +7,7 @@
 
 #include "../gemm_bf16s_kernel.h"
 #include "../gemm_bf16s_256.h"
+#include "../gemm_bf16s_128x256.h"
 
 using namespace blh;
 thread_local int blh::g_last_hip_error = 0;
@@ -43,6 +44,24 @@ float run256(const GemmParamsH& p, int splits, int reps) {
   for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(512), H256_LDS_BYTES, 0, p);
   CK(hipEventRecord(e0, 0));
   for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(512), H256_LDS_BYTES, 0, p);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  CK(hipGetLastError());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / reps;
+}
+
+template <int LA, int LB, int EPI, bool OB, int ABL = 0>
+float run128x256(const GemmParamsH& p, int splits, int reps) {
+  auto kern = gemm_bf16s_128x256_kernel<LA, LB, EPI, OB, ABL>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)H128_LDS_BYTES));
+  const int tiles = (int)(ceil_div(p.M, 128) * (p.N / 256));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(512), H128_LDS_BYTES, 0, p);
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(512), H128_LDS_BYTES, 0, p);
   CK(hipEventRecord(e1, 0));
   CK(hipEventSynchronize(e1));
   CK(hipGetLastError());
@@ -100,6 +119,51 @@ int main(int argc, char** argv) {
       }
     return 0;
   }
+  if (getenv("KSWEEP")) {   // forward at N = W, K = 128 .. W: fixed cost (intercept) and cost per K tile (slope)
+    for (int K = 128; K <= W; K *= 2) {
+      GemmParamsH fk = f;
+      fk.K = K; fk.k_per_split = K;
+      float a = run128x256<ROWK, ROWK, EPI_BIAS_STATS, true>(fk, 1, reps);
+      float b = run256<ROWK, ROWK, EPI_BIAS_STATS, true>(fk, 1, reps);
+      float c = run<ROWK, ROWK, EPI_BIAS_STATS, true, 64, 2>(fk, 1, reps);
+      printf("K %5d (%3d K tiles)  128x256 %6.1f us | 256x256 %6.1f us | 128x128 %6.1f us\n", K, K / 64, a * 1e3, b * 1e3, c * 1e3);
+    }
+    return 0;
+  }
+  if (getenv("STAMPS")) {   // where one launch of the 128 x 256 forward spends its time (wave 0 of every workgroup)
+    const int wgs = (M / 128) * (W / 256);
+    uint64_t* dbg; CK(hipMalloc(&dbg, (size_t)wgs * 64));
+    GemmParamsH fs = f;
+    fs.addend = reinterpret_cast<const bf16_bits*>(dbg);
+    for (int r = 0; r < 3; ++r) {
+      run128x256<ROWK, ROWK, EPI_BIAS_STATS, true, 4>(fs, 1, 20);
+      CK(hipDeviceSynchronize());
+      std::vector<uint64_t> hs((size_t)wgs * 8);
+      CK(hipMemcpy(hs.data(), dbg, hs.size() * 8, hipMemcpyDeviceToHost));
+      uint64_t t0 = ~0ull, t4 = 0;
+      for (int w = 0; w < wgs; ++w) { t0 = std::min(t0, hs[w * 8]); t4 = std::max(t4, hs[w * 8 + 4]); }
+      double seg[4] = {0, 0, 0, 0}, start = 0, end = 0;
+      for (int w = 0; w < wgs; ++w) {
+        for (int i = 0; i < 4; ++i) seg[i] += (double)(hs[w * 8 + i + 1] - hs[w * 8 + i]) * 0.01 / wgs;
+        start += (double)(hs[w * 8] - t0) * 0.01 / wgs;
+        end += (double)(t4 - hs[w * 8 + 4]) * 0.01 / wgs;
+      }
+      printf("first entry -> last drain %.2f us | mean per workgroup: entry skew %.2f, prologue %.2f, loop %.2f, epilogue (stores issued) %.2f, "
+             "store drain %.2f, idle until the last one ends %.2f us\n", (double)(t4 - t0) * 0.01, start, seg[0], seg[1], seg[2], seg[3], end);
+    }
+    return 0;
+  }
+  if (getenv("ABLATE")) {   // the 128 x 256 kernel's loop with one ingredient removed (timing only)
+    for (int round = 0; round < 2; ++round) {
+      float a0 = run128x256<ROWK, ROWK, EPI_BIAS_STATS, true, 0>(f, 1, reps);
+      float a1 = run128x256<ROWK, ROWK, EPI_BIAS_STATS, true, 1>(f, 1, reps);
+      float a2 = run128x256<ROWK, ROWK, EPI_BIAS_STATS, true, 2>(f, 1, reps);
+      float a3 = run128x256<ROWK, ROWK, EPI_BIAS_STATS, true, 3>(f, 1, reps);
+      printf("128x256 fwd: full %6.1f us | no DMA %6.1f | no fragment reads %6.1f | no MFMAs %6.1f\n", a0 * 1e3, a1 * 1e3,
+             a2 * 1e3, a3 * 1e3);
+    }
+    return 0;
+  }
   for (int round = 0; round < 3; ++round) {
     if (!only256) {
       ROW(64, 2)
@@ -110,6 +174,17 @@ int main(int argc, char** argv) {
     float t3 = run256<KROW, KROW, EPI_STORE, false>(w2, splits256, reps);
     printf("256x256 8-phase (128 KB LDS)  fwd %7.1f us %6.0f TF | dgrad %7.1f us %6.0f TF | wgrad(x%d) %7.1f us %6.0f TF\n",
            t1 * 1e3, flop / t1 / 1e9, t2 * 1e3, flop / t2 / 1e9, splits256, t3 * 1e3, flop / t3 / 1e9);
+    {
+      // the 128 x 256 kernel (three-deep ring): weight gradient with twice the slabs of the 256 x 256 plan
+      const int sp = std::min(8, splits256 * 2);
+      GemmParamsH w3 = w;
+      w3.k_per_split = (int)round_up(ceil_div(M, sp), 128);
+      float u1 = run128x256<ROWK, ROWK, EPI_BIAS_STATS, true>(f, 1, reps);
+      float u2 = run128x256<ROWK, KROW, EPI_STORE, true>(d, 1, reps);
+      float u3 = ((int64_t)w3.k_per_split * sp == M) ? run128x256<KROW, KROW, EPI_STORE, false>(w3, sp, reps) : 0.f;
+      printf("128x256 3-ring  (144 KB LDS)  fwd %7.1f us %6.0f TF | dgrad %7.1f us %6.0f TF | wgrad(x%d) %7.1f us %6.0f TF\n",
+             u1 * 1e3, flop / u1 / 1e9, u2 * 1e3, flop / u2 / 1e9, sp, u3 * 1e3, u3 > 0 ? flop / u3 / 1e9 : 0.0);
+    }
   }
   return 0;
 }

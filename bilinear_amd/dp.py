@@ -119,14 +119,18 @@ class GradBucketReducer:
             work = dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._works.append((work, tensor))
 
+    def flush(self):
+        """Launch the bucket still pending (the last ranges of backward)."""
+        if self._pending is not None:
+            self._launch(*self._pending)
+            self._pending = None
+
     def finish(self, cast_back=True):
         """Wait for every launched collective.  Compressed buckets: ``cast_back=True`` writes the
         averaged bf16 values back into the fp32 arena; ``cast_back=False`` leaves them in
         ``self._half`` for an optimiser that reads bf16 gradients (Engine.clip_adam_bf16) and
         returns the factor still to be applied (1 / world when the backend summed)."""
-        if self._pending is not None:
-            self._launch(*self._pending)
-            self._pending = None
+        self.flush()
         scale = 1.0
         for work, view in self._works:
             work.wait()
@@ -259,8 +263,12 @@ class DataParallel:
         pred, loss = eng.forward_train_loss(x, target, sync=sync, global_batch=gb)
         self._reducer.begin()
         eng.backward(x, None, on_ready=self._reducer.on_ready, sync=sync, global_batch=gb)
-        # bf16 buckets on a HIP device stay bf16: norm, clip and Adam read them directly
-        half_direct = self.compress == "bf16" and eng.grads.is_cuda and (self.world > 1 or self.force_collectives)
+        # bf16 buckets on a HIP device stay bf16: norm, clip and Adam read them directly — when the
+        # reducer really exchanged (its own state decides: ``force_collectives`` without a process
+        # group launches nothing and leaves no bf16 image to read)
+        self._reducer.flush()
+        exchanged = (self._reducer.world > 1 or self._reducer.force) and self._reducer._half is not None
+        half_direct = self.compress == "bf16" and eng.grads.is_cuda and exchanged
         gscale = self._reducer.finish(cast_back=not half_direct)
         # the reported loss is the GLOBAL batch's: mean of the per-rank means (equal shards; the
         # reference logs the loss of the whole batch, train_bilinear.py:86-88).  Its 1-float

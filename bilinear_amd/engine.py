@@ -349,6 +349,7 @@ class Engine:
             self._stream(), N.ptr(self.params), N.ptr(grads_bf16), float(grad_scale), N.ptr(self.grads),
             N.ptr(exp_avg), N.ptr(exp_avg_sq), self.layout.total, ctypes.byref(hyper), N.ptr(sc),
             sc.numel(), N.ptr(stats)), "blh_clip_adam_step_bf16")
+        self.invalidate_shadow()          # the parameters changed behind any persistent bf16 image
 
     def set_two_stream(self, enabled):
         """A/B switch of the two-stream backward (bit-identical results either way)."""

@@ -424,17 +424,30 @@ int blh_gemm_fp16x2(void* stream, const float* A, int64_t lda, int32_t a_kmajor,
  * with splits > 1); stat_part (optional, with bias, splits == 1): per-row-tile column (mean,
  * M2) of the fp32 values before rounding, [ceil(M/T)][2][N] with T = blh_gemm_bf16s_tile(...)
  * rows per tile.  splits > 1 writes slabs [splits][M][ldc].
- * Two kernels serve it: 128 x 128 tiles (any shape) and, for launches with enough tiles to fill
+ * Three kernels serve it: 128 x 128 tiles (any shape); for launches with enough tiles to fill
  * the chip (N % 256 == 0, reduction slabs % 128 == 0), 256 x 256 tiles with the 8-phase
- * schedule; blh_gemm_bf16s_tile says which one a contraction of contiguous operands takes
- * (128 or 256; the environment variable BLH_BF16S_TILE = 128 | 256 forces one where the shape
- * allows it, for A/B measurements).                                                          */
+ * schedule; and 128 x 256 tiles with the same schedule on a three-deep LDS ring where only
+ * half-height tiles fill the chip (M = 8192 at N = 1024).  blh_gemm_bf16s_tile /
+ * blh_gemm_bf16s_tile_cols say which rows x columns tile a contraction of contiguous operands
+ * takes (the environment variable BLH_BF16S_TILE = 128 | 256 | 384 (= 128 x 256) forces one
+ * where the shape allows it, for A/B measurements).                                          */
 int blh_gemm_bf16s(void* stream, const uint16_t* A, int64_t lda, int32_t a_kmajor, const uint16_t* B,
                    int64_t ldb, int32_t b_kmajor, void* C, int64_t ldc, int32_t out_bf16, int64_t M,
                    int64_t N, int64_t K, int32_t splits, const float* bias, const uint16_t* addend,
                    int64_t ldadd, float* stat_part);
 int32_t blh_gemm_bf16s_tile(int64_t M, int64_t N, int64_t K, int32_t a_kmajor, int32_t b_kmajor,
                             int32_t out_bf16, int32_t splits);
+int32_t blh_gemm_bf16s_tile_cols(int64_t M, int64_t N, int64_t K, int32_t a_kmajor, int32_t b_kmajor,
+                                 int32_t out_bf16, int32_t splits);
+/* How the bf16-storage backward plans the weight gradients dW = dZ^T A of its hidden width x width
+ * stages at this batch (api_layout.h): *batched_slabs = batch slabs per stage when `stages` of them
+ * run as ONE batched launch (0: they do not; each stage then runs alone with *stage_slabs slabs).
+ * For benchmarks and tools that time these contractions the way the step launches them.        */
+int blh_wgrad_plan_bf16s(int64_t width, int64_t batch, int32_t stages, int32_t* batched_slabs,
+                         int32_t* stage_slabs);
+/* Developer / test knob (process-wide): force the tile of every following bf16-storage GEMM where
+ * its shape allows it: 128, 256, 384 (= 128 x 256); 0 = automatic; -1 = re-read BLH_BF16S_TILE.  */
+int blh_gemm_bf16s_force_tile(int32_t tile);
 /* `items` independent contractions of ONE shape in one launch of the 256 x 256 kernel: the weight
  * gradients dW_l = dZ_l^T A_(l-1) of several hidden stages of the lifter at once
  * (train_bilinear.py:79 through model/bilinear.py:25-26), which one stage alone cannot fill the

@@ -50,14 +50,21 @@ CASES = [
     (8320, 1024, 1024, 0, 1, 1),      # dgrad, ragged last row tile (M % 256 = 128)
     (1024, 1024, 16384, 1, 1, 4),     # wgrad at B = 16384
     (2048, 2048, 16384, 1, 1, 1),     # wgrad, W = 2048, B = 16384, one slab
+    # the 128 x 256 kernel (gemm_bf16s_128x256.h) picks up M = 8192 at N = 1024 above; its ragged edges:
+    (8300, 1024, 320, 0, 0, 1),       # ragged last row tile (108 rows), 5 K tiles (K % 128 = 64)
+    (8250, 1024, 128, 0, 1, 1),       # dgrad, two K tiles: the loop body never runs
+    (7300, 1024, 192, 0, 0, 1),       # three K tiles: one trip through the loop
+    (3600, 2048, 448, 0, 1, 1),       # N = 2048: 29 x 8 tiles, ragged last row tile (16 rows)
 ]
 
 
 @pytest.mark.parametrize("out_bf16", [0, 1])
 @pytest.mark.parametrize("M,N,K,ak,bk,splits", CASES)
-def test_gemm_bf16s_layouts(native, M, N, K, ak, bk, splits, out_bf16):
+def test_gemm_bf16s_layouts(native, M, N, K, ak, bk, splits, out_bf16, force_tile=0):
     if out_bf16 and (splits > 1 or (ak and bk)):
         pytest.skip("weight-gradient outputs (slabs) are fp32")
+    if force_tile:
+        assert native.blh_gemm_bf16s_force_tile(force_tile) == 0
     dev = _dev()
     rng = np.random.RandomState(M + 3 * N + 7 * K)
     A = rng.standard_normal((K, M) if ak else (M, K)).astype(np.float32)
@@ -74,10 +81,14 @@ def test_gemm_bf16s_layouts(native, M, N, K, ak, bk, splits, out_bf16):
         c = torch.full((M, N), -1, dtype=torch.int16, device=dev)
     else:
         c = torch.full((splits, M, N), float("nan"), device=dev)
-    rc = native.blh_gemm_bf16s(st, a.data_ptr(), A.shape[1], ak, b.data_ptr(), B.shape[1], bk,
-                               c.data_ptr(), N, out_bf16, M, N, K, splits, None, None, 0, None)
+    try:
+        rc = native.blh_gemm_bf16s(st, a.data_ptr(), A.shape[1], ak, b.data_ptr(), B.shape[1], bk,
+                                   c.data_ptr(), N, out_bf16, M, N, K, splits, None, None, 0, None)
+        torch.cuda.synchronize()
+    finally:
+        if force_tile:
+            native.blh_gemm_bf16s_force_tile(-1)
     assert rc == 0, native.blh_status_string(rc)
-    torch.cuda.synchronize()
     if out_bf16:
         got = _bits_to_f32(c.cpu().numpy().view(np.uint16)).astype(np.float64)
         # one rounding to bf16 on top of the fp32 accumulation
@@ -86,6 +97,24 @@ def test_gemm_bf16s_layouts(native, M, N, K, ak, bk, splits, out_bf16):
         got = c.cpu().numpy().astype(np.float64).sum(axis=0)
         err = np.abs(got - ref) / mag
         assert err.max() <= 2e-5, err.max()
+
+
+@pytest.mark.parametrize("M,N,K,ak,bk,splits,out_bf16", [
+    (4096, 1024, 1024, 0, 0, 1, 1),   # shapes the dispatcher gives to other kernels, forced onto 128 x 256 tiles
+    (300, 512, 192, 0, 1, 1, 0),      # three row tiles (the last one 44 rows), fp32 out
+    (1024, 1024, 4096, 1, 1, 4, 0),   # weight gradient: both operands through the transposing read, 4 slabs
+    (384, 768, 1088, 1, 1, 1, 0),     # weight gradient, 17 K tiles, one slab
+    (1024, 1024, 8192, 1, 1, 8, 0),   # weight gradient, 8 slabs (the XCD-per-slab map)
+])
+def test_gemm_bf16s_128x256_forced(native, M, N, K, ak, bk, splits, out_bf16):
+    """Every operand layout of gemm_bf16s_128x256_kernel, including those the dispatcher does not route to it."""
+    assert native.blh_gemm_bf16s_force_tile(384) == 0
+    try:
+        assert native.blh_gemm_bf16s_tile(M, N, K, ak, bk, out_bf16, splits) == 128
+        assert native.blh_gemm_bf16s_tile_cols(M, N, K, ak, bk, out_bf16, splits) == 256
+    finally:
+        native.blh_gemm_bf16s_force_tile(-1)
+    test_gemm_bf16s_layouts(native, M, N, K, ak, bk, splits, out_bf16, force_tile=384)
 
 
 @pytest.mark.parametrize("M,N,K,items,splits,pad", [
@@ -129,10 +158,22 @@ def test_gemm_bf16s_batched_weight_gradients(native, M, N, K, items, splits, pad
     assert rc != 0
 
 
-@pytest.mark.parametrize("M,N,K", [(392, 384, 192), (8392, 768, 256)])
-def test_gemm_bf16s_epilogues(native, M, N, K):
-    """(392, 384, 192): the 128 x 128 kernel; (8392, 768, 256): the 256 x 256 kernel (33 x 3 tiles,
-    a ragged last row tile of 200 rows)."""
+@pytest.fixture
+def forced_tile(native, request):
+    tile = request.param
+    assert native.blh_gemm_bf16s_force_tile(tile) == 0
+    yield tile
+    native.blh_gemm_bf16s_force_tile(-1)
+
+
+@pytest.mark.parametrize("M,N,K,forced_tile,rows", [
+    (392, 384, 192, 0, 128),      # the 128 x 128 kernel
+    (8392, 768, 256, 256, 256),   # the 256 x 256 kernel: 33 x 3 tiles, a ragged last row tile of 200 rows
+    (8392, 768, 256, 384, 128),   # the 128 x 256 kernel: 66 x 3 tiles, the last one 72 rows
+    (9800, 768, 256, 0, 128),     # the shape the dispatcher itself gives to the 128 x 256 kernel (77 x 3 tiles)
+], indirect=["forced_tile"])
+def test_gemm_bf16s_epilogues(native, M, N, K, forced_tile, rows):
+    """Bias + BatchNorm tile partials and the skip-gradient addend on each of the three kernels."""
     dev = _dev()
     rng = np.random.RandomState(4)
     A = rng.standard_normal((M, K)).astype(np.float32)
@@ -148,6 +189,8 @@ def test_gemm_bf16s_epilogues(native, M, N, K):
     # forward: + bias, bf16 out, BatchNorm tile partials of the un-rounded values
     z = torch.empty(M, N, dtype=torch.int16, device=dev)
     T = native.blh_gemm_bf16s_tile(M, N, K, 0, 0, 1, 1)          # rows per statistics tile
+    assert T == rows
+    assert native.blh_gemm_bf16s_tile_cols(M, N, K, 0, 0, 1, 1) == (128 if (forced_tile == 0 and M < 1000) else 256)
     part = torch.empty((M + T - 1) // T, 2, N, device=dev)
     assert native.blh_gemm_bf16s(st, a.data_ptr(), K, 0, w.data_ptr(), K, 0, z.data_ptr(), N, 1, M, N, K,
                                  1, bt.data_ptr(), None, 0, part.data_ptr()) == 0
