@@ -656,10 +656,9 @@ def main():
     from bilinear_amd.dp import DataParallel
 
     # Order of set-up under RCCL: the process group first (eagerly: device_id), everything else after it.
-    # Round 2 built the model first, on a world-size-1 measurement that read 10 % slow the other way
-    # round; that was the side stream sharing a hardware queue with torch's default stream (api.hip,
-    # blh_context_create), not the allocation order.  With the model first this flow runs 2.3-3.0 ms
-    # per step instead of 1.14 (python bench.py --rehearse-rccl; profiles/r03_dp_overhead.md).
+    # The order no longer matters for speed (round 3: 2.3-3.0 ms per step with the model first; cause and
+    # repair in profiles/r04_dp_setup_order.md: the engine tunes its stream pair); BLH_BENCH_INIT_LAST=1
+    # runs the other order.
     init_first = os.environ.get("BLH_BENCH_INIT_LAST") != "1"
     if multi and init_first:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -110,6 +110,9 @@ _SIGNATURES = {
                                             c_void_p, c_void_p, c_int64, c_void_p]),
     "blh_gemm_bf16s_tile": (c_int32, [c_int64, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32]),
     "blh_gemm_bf16s_force_tile": (c_int, [c_int32]),
+    "blh_side_stream_renew": (c_int, []),
+    "blh_side_stream_generation": (c_int32, []),
+    "blh_tune_streams": (c_int, [c_void_p, c_int32, POINTER(c_float)]),
     "blh_wgrad_plan_bf16s": (c_int, [c_int64, c_int64, c_int32, POINTER(c_int32), POINTER(c_int32)]),
     "blh_gemm_bf16s_tile_cols": (c_int32, [c_int64, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32]),
     "blh_train_step_captured": (c_int, [c_void_p, POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,

@@ -60,12 +60,20 @@ static DropoutSrc layer_drop(const blh_context* ctx, const blh_dropout* drop, in
   return d;
 }
 
-// every network-level entry point: the context must belong to the device that is current
-static int check_ctx(const blh_context* ctx) {
+// the process-wide side stream table (streams.hip)
+hipStream_t side_stream_current(int device);
+hipError_t side_stream_acquire(int device, hipStream_t* out);
+void side_stream_release(int device);
+
+// every network-level entry point: the context must belong to the device that is current; it picks up
+// the device's current side stream (blh_side_stream_renew may have replaced it since the last call)
+static int check_ctx(blh_context* ctx) {
   if (!ctx) return BLH_ERR_INVALID_ARGUMENT;
   int dev = -1;
   BLH_HIP_TRY(hipGetDevice(&dev));
-  return dev == ctx->device ? BLH_OK : BLH_ERR_INVALID_ARGUMENT;
+  if (dev != ctx->device) return BLH_ERR_INVALID_ARGUMENT;
+  ctx->s2 = side_stream_current(dev);
+  return ctx->s2 ? BLH_OK : BLH_ERR_INVALID_ARGUMENT;
 }
 
 // ------------------------------------------------------------- forward -----
@@ -785,39 +793,6 @@ const char* blh_status_string(int status) {
 int blh_last_hip_error(void) { return g_last_hip_error; }
 int blh_abi_version(void) { return BLH_ABI_VERSION; }
 
-// The process-wide side streams (see blh_context_create).
-namespace {
-constexpr int kMaxDevices = 64;
-std::mutex g_side_mu;
-hipStream_t g_side_stream[kMaxDevices] = {};
-int g_side_refs[kMaxDevices] = {};
-
-hipError_t side_stream_acquire(int device, hipStream_t* out) {
-  if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
-  std::lock_guard<std::mutex> lk(g_side_mu);
-  if (g_side_refs[device] == 0) {
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    const char* pr = getenv("BLH_SIDE_PRIORITY");   // "normal": the round-2 behaviour (A/B knob)
-    const hipError_t e = (pr && !strcmp(pr, "normal"))
-                             ? hipStreamCreateWithFlags(&g_side_stream[device], hipStreamNonBlocking)
-                             : hipStreamCreateWithPriority(&g_side_stream[device], hipStreamNonBlocking, least);
-    if (e != hipSuccess) return e;
-  }
-  ++g_side_refs[device];
-  *out = g_side_stream[device];
-  return hipSuccess;
-}
-void side_stream_release(int device) {
-  std::lock_guard<std::mutex> lk(g_side_mu);
-  if (device < 0 || device >= kMaxDevices || g_side_refs[device] == 0) return;
-  if (--g_side_refs[device] == 0) {
-    (void)hipStreamDestroy(g_side_stream[device]);
-    g_side_stream[device] = nullptr;
-  }
-}
-}  // namespace
-
 int blh_context_create(blh_context** out) {
   if (!out) return BLH_ERR_INVALID_ARGUMENT;
   *out = nullptr;
@@ -902,7 +877,9 @@ int blh_context_get_option(const blh_context* c, int32_t option) {
 }
 
 void* blh_context_side_stream(blh_context* c) {
-  return (c && c->two_stream) ? (void*)c->s2 : nullptr;
+  if (!c || !c->two_stream) return nullptr;
+  c->s2 = blh::side_stream_current(c->device);
+  return (void*)c->s2;
 }
 
 int32_t blh_num_heavy(const blh_model_desc* d) { return d ? 1 + 2 * d->num_blocks : 0; }
@@ -942,7 +919,7 @@ int64_t blh_workspace_bytes(const blh_model_desc* d, int64_t batch) {
   return d->gemm_dtype == 4 ? carve_h(d, batch, nullptr).bytes : carve(d, batch, nullptr).bytes;
 }
 
-static int check_common(const blh_context* ctx, const blh_model_desc* d, const void* ws,
+static int check_common(blh_context* ctx, const blh_model_desc* d, const void* ws,
                         int64_t ws_bytes, int64_t batch) {
   BLH_TRY(check_ctx(ctx));
   BLH_TRY(check_desc(d));

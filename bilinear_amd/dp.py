@@ -177,11 +177,12 @@ class DataParallel:
     ``x_local`` is this rank's row slice of the global batch.  Dropout uses the
     global row index (rank * local_batch), so the Philox mask of a row does not
     depend on the number of GPUs.
-    Order of set-up on a HIP device: create the RCCL process group FIRST
-    (``init_process_group("nccl", device_id=...)``), then the module, its optimizer and this driver.
-    Measured at world size 1 with every collective issued (``bench.py --rehearse-rccl``,
-    profiles/r03_dp_overhead.md): 1.14-1.16 ms per configs[1] step in this order, 2.3-3.0 ms with the
-    module first.  See also ``stream``.
+    Order of set-up: any.  (Round 3 prescribed "process group first": with the module built before
+    ``init_process_group("nccl", ...)`` the step took 2.3-3.0 instead of 1.1 ms.  The cause was the pair
+    (compute stream, side stream) landing on hardware queues that do not run beside each other, which
+    every set-up order draws anew; the engine now measures the pair in front of the first two-stream
+    call on a compute stream and replaces the side stream of a bad pair — ``Engine._tune_streams``,
+    profiles/r04_dp_setup_order.md: 1.105-1.108 ms in every order.)  See also ``stream``.
     """
 
     def __init__(self, module, optimizer, group=None, bucket_floats=None, max_norm=1.0,

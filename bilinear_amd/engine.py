@@ -181,6 +181,30 @@ class Engine:
     def _stream():
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    _tuned = {}        # (device index, compute-stream handle) -> side-stream generation it was tuned against
+
+    def _tune_streams(self):
+        """Once per compute stream (and again whenever the library's side stream was replaced): let the
+        library check that this stream and its side stream run beside each other, and pick another side
+        stream if they do not (blh_tune_streams: a 2 ms probe).  On this stack a bad pair makes the
+        two-stream backward 2x slower, and which pairs are bad depends on what the process created in
+        which order — e.g. an RCCL communicator between the two streams (profiles/r04_dp_setup_order.md).
+        BLH_NO_STREAM_TUNE=1 switches it off."""
+        st = torch.cuda.current_stream()
+        key = (st.device.index, st.cuda_stream)
+        lib = N.lib()
+        gen = lib.blh_side_stream_generation()
+        if Engine._tuned.get(key) == gen:
+            return
+        import os
+        if os.environ.get("BLH_NO_STREAM_TUNE") == "1" or torch.cuda.is_current_stream_capturing() \
+                or not self.ctx.get_option(N.OPT_TWO_STREAM):
+            return
+        rep = (ctypes.c_float * 4)()
+        N.check(lib.blh_tune_streams(ctypes.c_void_p(st.cuda_stream), 3, rep), "blh_tune_streams")
+        self.stream_tune_report = tuple(rep)
+        Engine._tuned[key] = lib.blh_side_stream_generation()
+
     def _momentum(self):
         m = self.module.encode[1].momentum
         return -1.0 if m is None else float(m)
@@ -376,6 +400,7 @@ class Engine:
             if tuple(dpred.shape) != (batch, OUT_FEATURES) or dpred.dtype != torch.float32:
                 raise RuntimeError("bad output gradient: %s %s" % (tuple(dpred.shape), dpred.dtype))
         ws = self.workspace(batch)
+        self._tune_streams()
         errors = []
         if on_ready is not None:
             # a reported range is complete on the library's side stream (weight-gradient GEMMs):
@@ -456,6 +481,7 @@ class Engine:
             raise RuntimeError("bad target: %s %s" % (tuple(target.shape), target.dtype))
         ws = self.workspace(batch)
         self._drop_struct(batch)          # validates explicit masks (shape, device)
+        self._tune_streams()
         pred, loss = torch.ops.bilinear_hip.train_step(
             x, target, self.params, self.grads, exp_avg, exp_avg_sq, self.bn_running, self.bn_nbt,
             ws, stats, self.masks, *self._op_args(), self.seed, self.rng_step, self.row_offset,

@@ -102,6 +102,27 @@ int blh_context_get_option(const blh_context* ctx, int32_t option);
 /* The side stream (hipStream_t as void*) the weight-gradient GEMMs run on; NULL when
  * BLH_OPT_TWO_STREAM is 0.  See blh_backward.                                            */
 void* blh_context_side_stream(blh_context* ctx);
+/* Replace the current device's process-wide side stream by a freshly created one; every context of
+ * the device uses the new one from its next call on (the old one is drained and destroyed: call it
+ * between steps, never under stream capture).  Why it exists: on this stack the two streams of the
+ * backward (the caller's compute stream and the side stream) run at full speed only when their
+ * hardware queues were created on the same side of the last RCCL communicator creation — with one
+ * older and one younger every kernel of the step runs 1.5-5x longer (DESIGN.md section 4,
+ * profiles/r04_dp_setup_order.md).  blh_tune_streams is the measured form of the same repair. */
+int blh_side_stream_renew(void);
+/* Counts the replacements of side streams in this process (any device): a caller that caches the result
+ * of blh_tune_streams for a compute stream re-tunes when the number has changed.                     */
+int32_t blh_side_stream_generation(void);
+/* Measure whether kernels on `stream` (the compute stream the step will be enqueued on) and on the
+ * current device's side stream really run beside each other, and repair the pair if they do not: a
+ * short probe (12 short kernels on `stream` while 6 longer ones keep the side stream busy) is timed
+ * for the current side stream and, if they take more than 2.5x their solo time (measured: 1.6-1.8x
+ * for a good pair, 3.8x and more for a bad one), for up to `max_candidates` (0..7) freshly created
+ * side streams, stopping at the first good one; the best becomes the device's side stream, the
+ * others are destroyed.  Synchronises, allocates 32 MB for the duration of the call: call it once
+ * per compute stream at set-up, never under stream capture.  report (optional, 4 floats): ms of the
+ * short kernels alone, beside the side stream found, beside the one kept, number of candidates tried. */
+int blh_tune_streams(void* stream, int32_t max_candidates, float* report);
 
 /* ------------------------------------------------------------------------
  * Model description.  The reference hard-codes num_blocks=2, width=1024,
