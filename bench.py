@@ -66,7 +66,7 @@ def gemm_rooflines(batch, width, reps, dtype="fp32", hidden=0):
     """Live timings of the three Linear contractions at the hidden-layer shape."""
     from bilinear_amd import _native as N
     lib = N.lib()
-    gemm = {"bf16": lib.blh_gemm_bf16, "bf16x3": lib.blh_gemm_bf16x3}.get(dtype, lib.blh_gemm_f32)
+    gemm = {"bf16x3": lib.blh_gemm_bf16x3}.get(dtype, lib.blh_gemm_f32)
     dev = torch.device("cuda", torch.cuda.current_device())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     if dtype == "fp16x2":      # operand maxima once (inside the network the producers supply them)
@@ -363,18 +363,7 @@ def roofline_block(args, dom):
             "traffic": None, "avg_launch_ms": dom["ms"], "flop_per_launch": flop,
             "bf16_mfma_tflops_executed": 6.0 * dom["tflops"],
         }
-    # mixed mode keeps fp32 tensors in memory: the bf16 MFMA (2.5 PF) is fed at most at the
-    # memory rate, so the kernel is priced against HBM with its algorithmic bytes A + W + Z
-    alg = 4.0 * (args.batch * args.width * 2 + args.width * args.width)
-    gbs = alg / (dom["ms"] * 1e-3) / 1e9
-    return {
-        "kernel": "gemm_bf16_kernel<128,128,2,2,ROWK,ROWK,BIAS> (Linear %dx%d forward, M=%d, fp32 storage)" % (
-            args.width, args.width, args.batch),
-        "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": dom["ms"],
-        "algorithmic_bytes_per_launch": alg, "tflops": dom["tflops"],
-        "frac_of_bf16_mfma_peak": dom["tflops"] / BF16_MFMA_PEAK_TFLOPS,
-    }
+    raise ValueError("no roofline block for dtype %s" % args.dtype)
 
 
 def alt_mode_block(args, dev, x, t, alt):
@@ -567,8 +556,7 @@ def config_block(idx, dev, steps, ramp_ms):
 DTYPE_TEXT = {"fp32": "f32", "bf16x3": "f32 (operands split into 3 bf16 pieces, bf16 MFMA, fp32 accumulate)",
               "fp16x2": "f32 (operands split into 2 scaled fp16 pieces, f16 MFMA, fp32 accumulate)",
               "bf16s": "bf16 (activations / gradients / weight shadow stored in bf16, bf16 MFMA, fp32 "
-                       "accumulate, fp32 master weights + BatchNorm statistics + Adam)",
-              "bf16": "bf16 (MFMA inputs; fp32 accumulate and storage)"}
+                       "accumulate, fp32 master weights + BatchNorm statistics + Adam)"}
 
 
 def main():
@@ -583,9 +571,9 @@ def main():
     ap.add_argument("--blocks", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", choices=["fp32", "bf16s", "bf16", "bf16x3", "fp16x2"], default=None,
-                    help="GEMM arithmetic: fp32 MFMA (BASELINE configs[1], default) or bf16 MFMA "
-                         "inputs with fp32 accumulation and fp32 storage (configs 3-5)")
+    ap.add_argument("--dtype", choices=["fp32", "bf16s", "bf16x3", "fp16x2"], default=None,
+                    help="GEMM arithmetic: fp32 MFMA (BASELINE configs[1], default), bf16 storage with bf16 "
+                         "MFMA and fp32 accumulation (configs[2..4]), or the fp32-accurate split modes")
     ap.add_argument("--sync-bn", action="store_true",
                     help="N>1: BatchNorm statistics over the global batch (exact reference semantics)")
     ap.add_argument("--graph", action="store_true",
@@ -835,8 +823,8 @@ def main():
             "final_loss": final_loss,
             "fwd_bwd_only": {"ms_per_step": fb_ms, "poses_per_s": args.batch / (fb_ms / 1e3)},
             "step_tflops": poses * (fwd + bwd) / 1e12,
-            ("step_frac_of_bf16_mfma_peak" if args.dtype in ("bf16s", "bf16") else "step_frac_of_fp32_mfma_peak"):
-                poses * (fwd + bwd) / 1e12 / ((BF16_MFMA_PEAK_TFLOPS if args.dtype in ("bf16s", "bf16")
+            ("step_frac_of_bf16_mfma_peak" if args.dtype == "bf16s" else "step_frac_of_fp32_mfma_peak"):
+                poses * (fwd + bwd) / 1e12 / ((BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16s"
                                                else FP32_MFMA_PEAK_TFLOPS) * world),
             "roofline": roofline_block(args, dom),
             "roofline_hbm": skinny_rooflines(args.batch, args.width, reps=300),

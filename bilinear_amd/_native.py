@@ -122,9 +122,6 @@ _SIGNATURES = {
     "blh_gemm_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
                              c_void_p, c_int64, c_int64, c_int64, c_int64, c_int32, c_void_p,
                              c_void_p, c_int64]),
-    "blh_gemm_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
-                              c_void_p, c_int64, c_int64, c_int64, c_int64, c_int32, c_void_p,
-                              c_void_p, c_int64]),
     "blh_gemm_bf16x3": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
                                 c_void_p, c_int64, c_int64, c_int64, c_int64, c_int32, c_void_p,
                                 c_void_p, c_int64]),

@@ -104,7 +104,7 @@ static int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s
     g.bias = params + h.b;
     g.stat_part = ws.stat_part;
     const Splits fs = small_m_splits(batch, W, h.fan_in);
-    const bool enc64 = train && i == 0 && fs.splits == 1 && h.fan_in <= 32 && batch >= 2048 && d->gemm_dtype != 1;
+    const bool enc64 = train && i == 0 && fs.splits == 1 && h.fan_in <= 32 && batch >= 2048;
     if (fs.splits > 1) {
       // small batch: too few 128x128 output tiles to fill the chip and each would walk the
       // whole reduction alone (latency-bound), so cut the reduction across workgroups and
@@ -166,7 +166,7 @@ static int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s
   // over W is split across workgroups (slabs) and a small kernel adds the slabs, the bias and,
   // in the fused step, the MSE loss / gradient (train_bilinear.py:78).
   const int OF = d->out_features;
-  if (d->gemm_dtype != 1 && decode_fwd_supported(batch, W, OF)) {
+  if (decode_fwd_supported(batch, W, OF)) {
     // purpose-built kernel (skinny.hip): reads A once, no slabs, bias + MSE + dpred + the loss and
     // decode-bias partials in the same launch
     int np = 0;
@@ -195,7 +195,7 @@ static int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s
 static int wgrad(int dtype, hipStream_t s, GemmTile tile, const float* dZ, int64_t ld_dz, int M,
                  const float* act, int64_t ld_act, int N, int64_t batch, int64_t tiles,
                  float* slabs, float* out, GradRegion* region, const float* amax_dz = nullptr,
-                 const float* amax_act = nullptr, int amax_parts = 0) {
+                 const float* amax_act = nullptr, int amax_parts = 0, double* sq = nullptr, int sq_blocks = 0) {
   const Splits sp = pick_splits(batch, tiles);
   GemmParams g{};
   g.A = dZ; g.lda = ld_dz;
@@ -217,6 +217,7 @@ static int wgrad(int dtype, hipStream_t s, GemmTile tile, const float* dZ, int64
     region->slabs = slabs; region->splits = sp.splits;
     return BLH_OK;
   }
+  if (sq) return launch_sum_slabs_sq(s, slabs, (int64_t)M * N, sp.splits, out, sq, sq_blocks);
   return launch_sum_slabs(s, slabs, (int64_t)M * N, sp.splits, out);
 }
 
@@ -227,7 +228,8 @@ static int wgrad(int dtype, hipStream_t s, GemmTile tile, const float* dZ, int64
 // so that stage l-2 does not overwrite what wgrad(l) is still reading.
 // fused: the caller is the whole-step path: the decode-bias partials come from decode_finish
 // (dec_bias_S rows) and the sum-of-squares partials of the arena are returned for clip+Adam.
-struct FusedBackward { int dec_bias_S; double* sumsq_part; int* sumsq_nparts; };
+// sumsq_src[0]: where the partials really are when backward_impl returns (sumsq_part, or the producers' array)
+struct FusedBackward { int dec_bias_S; double* sumsq_part; int* sumsq_nparts; double** sumsq_src; };
 
 static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
                          const float* x, const blh_dropout* drop, const Workspace& ws,
@@ -247,6 +249,31 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
   tl_stop_event = nullptr;
   const bool defer = (on_ready == nullptr) && ctx->defer_slabs;
   std::vector<GradRegion> wreg(nh + 1);
+  // Fused step, gradient norm (clip_grad_norm_, train_bilinear.py:81): the kernels that WRITE the gradient ranges
+  // — slab sums of the weight gradients, the gamma / beta finalize, the bias reduction — also emit the
+  // sum-of-squares partials of what they write (ws.sumsq_fold: a dense array, every launch fills exactly its
+  // own slots, so the sum is deterministic), and no pass over the arena is left between the join and
+  // clip + Adam (grads_finish: 9 us + its launch gap at configs[1]).  Needs every weight gradient to come out
+  // of a slab sum, and the slots to fit.
+  struct Fold { bool on = false; int per_w = 0; std::vector<int> w_off; int gb0 = 0, bias0 = 0, total = 0; } fold;
+  if (fused && fused->sumsq_part && !on_ready && !defer && !getenv("BLH_NO_SUMSQ_FOLD") && W % 16 == 0 &&
+      fused->dec_bias_S > 0) {
+    const bool slabbed = pick_splits(batch, ceil_div(W, 128) * ceil_div(W, 128)).splits > 1 &&
+                         pick_splits(batch, ceil_div(W, 128) * ceil_div(d->in_features, 32)).splits > 1 &&
+                         pick_splits(batch, ceil_div(OF, 64) * ceil_div(W, 128)).splits > 1;
+    fold.per_w = (int)std::min<int64_t>(256, std::max<int64_t>(8, 2048 / (nh + 1)));
+    int off = 0;
+    for (int i = 0; i <= nh; ++i) {
+      fold.w_off.push_back(off);
+      const int64_t cnt = i == nh ? (int64_t)OF * W : (int64_t)W * L.heavy[i].fan_in;
+      off += sum_slabs_sq_blocks(cnt, fold.per_w);
+    }
+    fold.gb0 = off;
+    fold.bias0 = fold.gb0 + nh * bn_bwd_finalize_blocks(W);
+    fold.total = fold.bias0 + bias_colreduce_blocks(W, nh, true);
+    fold.on = slabbed && nh >= 2 && fold.total <= SUMSQ_FOLD_PARTS;
+  }
+  auto fold_w = [&](int i) -> double* { return fold.on ? ws.sumsq_fold + fold.w_off[i] : nullptr; };
   // two streams: on by default (-3 % step)
   const bool two = ctx->two_stream && !ctx->sync.fn && !defer && small_m_splits(batch, W, W).splits == 1;
   hipStream_t s2 = two ? ctx->s2 : s;
@@ -310,14 +337,14 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
     g.M = (int)batch; g.N = W; g.K = OF; g.k_per_split = OF;
     arm_fork(nh);
     // (K = 48: two K tiles and 16.8 MB of output; 64-row tiles = two workgroups per CU)
-    BLH_TRY(launch_gemm(s, (batch >= 2048 && d->gemm_dtype != 1) ? TILE_64x128 : TILE_128x128, ROWK, KROW, EPI_STORE, g, 1,
+    BLH_TRY(launch_gemm(s, batch >= 2048 ? TILE_64x128 : TILE_128x128, ROWK, KROW, EPI_STORE, g, 1,
                         d->gemm_dtype));
     tl_stop_event = nullptr;
   }
   BLH_TRY(fork_wait(nh));
   BLH_TRY(wgrad(d->gemm_dtype, s2, TILE_64x128, dpred, OF, OF, ws.A[nh - 1], W, W, batch,
                 ceil_div(OF, 64) * ceil_div(W, 128), defer ? ws.stage_slabs[nh] : ws.slabs,
-                grads + L.dec_w, defer ? &wreg[nh] : nullptr));
+                grads + L.dec_w, defer ? &wreg[nh] : nullptr, nullptr, nullptr, 0, fold_w(nh), fold.per_w));
   BLH_TRY(wdone(nh));
   // (decode bias: on the side stream under a hook — behind the fork, its inputs are older than that)
   if (!fused) BLH_TRY(launch_colsum(on_ready ? s2 : s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
@@ -334,7 +361,8 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
     const float* sv = ws.bn_saved[i];
     // (dropout: the keep bits the forward wrote, ws.keep[i])
     BLH_TRY(launch_bn_bwd_reduce_f2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, ws.keep[i], ws.bn_part, batch, W));
-    BLH_TRY(launch_bn_bwd_finalize_h2(s, ws.bn_part, chunks, W, sv, sv + W, grads + h.gamma, grads + h.beta));
+    BLH_TRY(launch_bn_bwd_finalize_h2(s, ws.bn_part, chunks, W, sv, sv + W, grads + h.gamma, grads + h.beta,
+                                      fold.on ? ws.sumsq_fold + fold.gb0 + i * bn_bwd_finalize_blocks(W) : nullptr));
     const float* dg = grads + h.gamma;
     const float* db = grads + h.beta;
     int64_t norm_batch = batch;
@@ -417,13 +445,13 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
       BLH_TRY(wgrad(d->gemm_dtype, sw, TILE_128x32, dzbuf, W, W, x, d->in_features,
                     d->in_features, batch, ceil_div(W, 128) * ceil_div(d->in_features, 32),
                     (defer || (two && !side)) ? ws.stage_slabs[0] : ws.slabs, grads + h.w,
-                    defer ? &wreg[0] : nullptr));
+                    defer ? &wreg[0] : nullptr, nullptr, nullptr, 0, fold_w(0), fold.per_w));
       if (side) BLH_TRY(wdone(0));
     } else {
       BLH_TRY(wgrad(d->gemm_dtype, sw, TILE_128x128, dzbuf, W, W, ws.A[i - 1], W, W, batch,
                     ceil_div(W, 128) * ceil_div(W, 128), defer ? ws.stage_slabs[i] : ws.slabs,
                     grads + h.w, defer ? &wreg[i] : nullptr, dz_amax, ws.amax_A[i - 1],
-                    ws.amax_parts));
+                    ws.amax_parts, fold_w(i), fold.per_w));
       BLH_TRY(wdone(i));
     }
     if (on_ready) {
@@ -440,10 +468,14 @@ static int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t 
     for (int i = 0; i < nh; ++i) offs[i] = L.heavy[i].b;
     BLH_TRY(launch_bias_colreduce(s, ws.dz_colsum_part, (int64_t)chunks * W, chunks, W, nh, offs,
                                   grads, fused ? ws.dec_bias_part : nullptr,
-                                  fused ? fused->dec_bias_S : 0, OF, L.dec_b));
+                                  fused ? fused->dec_bias_S : 0, OF, L.dec_b,
+                                  fold.on ? ws.sumsq_fold + fold.bias0 : nullptr));
   }
   if (two) BLH_HIP_TRY(hipStreamWaitEvent(s, g_side.ev_w[on_ready != nullptr ? 0 : 1], 0));
-  if (!on_ready) {   // (covers the no_defer A/B mode too: its regions are all plain)
+  if (fold.on) {     // the producers left the partials: hand them to clip + Adam
+    fused->sumsq_src[0] = ws.sumsq_fold;
+    *fused->sumsq_nparts = fold.total;
+  } else if (!on_ready) {   // (covers the no_defer A/B mode too: its regions are all plain)
     // regions in arena order: [weight (slabs or plain)] [bias, gamma, beta (plain)] per stage,
     // then decode weight and decode bias (+ tail padding)
     GradRegions R{};
@@ -677,20 +709,31 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
     return launch_sum_slabs_batched(st, ws.bslabs, (int64_t)W * W, grp.plan.splits, items, g.c_batch_stride, out,
                                     gstride);
   };
+  // a data-gradient GEMM whose output only feeds the BatchNorm backward of the stage below
+  // (the second stage of a block: its output is not a skip operand; and stage 1, whose block-input gradient
+  // nothing below needs) forms that stage's gated gradient dY' and the (dY' z, dY') column sums in its
+  // epilogue (EPI_BN_BWD, big-tile kernels only): the stage below then skips bn_bwd_reduce_h2 and its
+  // bn_bwd_apply_h2 reads no keep bits.  k9_chunks > 0: stage i's dA arrived that way, with that many partial rows.
+  const bool k9_enabled = getenv("BLH_NO_K9") == nullptr;
+  int k9_chunks = 0;
   for (int i = nh - 1; i >= 0; --i) {
     const HeavyOffsets& h = L.heavy[i];
     const bool first_of_block = (i >= 1) && (i % 2 == 1);
     const uint16_t* dA = first_of_block ? ws.G1 : ws.G0;
     const float* sv = ws.bn_saved[i];
     const WGroup* grp = i > 0 ? group_of(i) : nullptr;
+    const int k9_in = k9_chunks;      // how this stage's dA was produced
+    k9_chunks = 0;
     const bool batched_w = grp != nullptr;
     // (a hidden stage of a batched group hands nothing to the side stream, except the group's lowest
     //  stage under a hook: the group's launch goes there, behind its bn_bwd_apply)
     const bool group_fork = batched_w && on_ready != nullptr && i == grp->lo;
     const bool forks = two && (!batched_w || group_fork);
     {   // dropout: the keep bits the forward wrote (bn_bf16.hip)
-      BLH_TRY(launch_bn_bwd_reduce_h2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, ws.keep[i], ws.bn_part, batch, W));
-      BLH_TRY(launch_bn_bwd_finalize_h2(s, ws.bn_part, chunks, W, sv, sv + W, grads + h.gamma, grads + h.beta));
+      if (k9_in == 0)
+        BLH_TRY(launch_bn_bwd_reduce_h2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, ws.keep[i], ws.bn_part, batch, W));
+      BLH_TRY(launch_bn_bwd_finalize_h2(s, ws.bn_part, k9_in ? k9_in : chunks, W, sv, sv + W, grads + h.gamma,
+                                        grads + h.beta));
       const float* dg = grads + h.gamma;
       const float* db = grads + h.beta;
       int64_t norm_batch = batch;
@@ -705,7 +748,7 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
       }
       BLH_TRY(launch_bn_bwd_apply_h2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W, dg, db, ws.keep[i],
                                      ws.dZ[i], ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W,
-                                     norm_batch));
+                                     norm_batch, k9_in > 0));
     }
     const bool late = forks && late_policy && i > 0 && !group_fork;
     if (forks && !late) BLH_TRY(fork_wait(i, false));     // behind bn_bwd_apply (marker event)
@@ -734,12 +777,22 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
       g.B = ws.wsh + h.w; g.ldb = W;
       g.M = (int)batch; g.N = W; g.K = W; g.k_per_split = W; g.ldc = W;
       if (late) arm_fork(i);
+      // K9: this GEMM's output is only read by the BatchNorm backward of stage i - 1
+      const int tile = gemm_bf16s_pick_tile(ROWK, KROW, true, g, 1);
+      const int64_t k9_rows = ceil_div(batch, gemm_bf16s_tile_rows(tile));
+      const bool k9 = k9_enabled && tile != H_TILE_128 && (!first_of_block || i == 1) && k9_rows <= chunks;
+      if (k9) {
+        const float* svd = ws.bn_saved[i - 1];
+        g.bn_z = ws.Z[i - 1]; g.ldz = W; g.bn_keep = ws.keep[i - 1];
+        g.bn_scale = svd + 2 * W; g.bn_shift = svd + 3 * W; g.stat_part = ws.bn_part;
+        k9_chunks = (int)k9_rows;
+      }
       if (first_of_block) {   // d(block input) = dZ W + d(block output), in place in G0
         g.C = ws.G0; g.addend = ws.G0; g.ldadd = W;
-        BLH_TRY(launch_gemm_bf16s(s, ROWK, KROW, EPI_ADD, true, g, 1));
+        BLH_TRY(launch_gemm_bf16s(s, ROWK, KROW, k9 ? EPI_BN_BWD_ADD : EPI_ADD, true, g, 1));
       } else {
         g.C = ws.G1;
-        BLH_TRY(launch_gemm_bf16s(s, ROWK, KROW, EPI_STORE, true, g, 1));
+        BLH_TRY(launch_gemm_bf16s(s, ROWK, KROW, k9 ? EPI_BN_BWD : EPI_STORE, true, g, 1));
       }
       tl_stop_event = nullptr;
       if (late) {
@@ -1034,7 +1087,7 @@ int blh_backward(blh_context* ctx, const blh_model_desc* d, void* stream, const 
   }
   const Workspace ws = carve(d, batch, workspace);
   if (from_loss && loss_nparts > 0) {   // decode-bias partials of the fused decode kernel
-    const FusedBackward fb{loss_nparts, nullptr, nullptr};
+    const FusedBackward fb{loss_nparts, nullptr, nullptr, nullptr};
     return backward_impl(ctx, d, (hipStream_t)stream, params, x, drop, ws, ws.dpred, grads, batch,
                          on_ready, user, &fb);
   }
@@ -1128,10 +1181,11 @@ int blh_train_step(blh_context* ctx, const blh_model_desc* d, void* stream, floa
   BLH_TRY(forward_impl(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
                        target, (float)(2.0 / denom), ws.loss_part, &nparts));
   int np = 0;
-  const FusedBackward fb{nparts, ws.sumsq_part, &np};
+  double* sq_src = ws.sumsq_part;
+  const FusedBackward fb{nparts, ws.sumsq_part, &np, &sq_src};
   BLH_TRY(backward_impl(ctx, d, s, params, x, drop, ws, ws.dpred, grads, batch, nullptr, nullptr, &fb));
   const int64_t count = make_layout(d).total;
-  return launch_clip_adam(s, params, grads, exp_avg, exp_avg_sq, count, *hyper, ws.sumsq_part, np,
+  return launch_clip_adam(s, params, grads, exp_avg, exp_avg_sq, count, *hyper, sq_src, np,
                           stats_out, LossFinish{ws.loss_part, nparts, denom, loss_out});
 }
 
@@ -1369,11 +1423,12 @@ int blh_train_step_captured(blh_context* ctx, const blh_model_desc* d, void* str
   const Workspace ws = carve(d, batch, workspace);
   BLH_TRY(forward_impl(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
                        target, (float)(2.0 / denom), ws.loss_part, &nparts));
-  const FusedBackward fb{nparts, ws.sumsq_part, &np};
+  double* sq_src = ws.sumsq_part;
+  const FusedBackward fb{nparts, ws.sumsq_part, &np, &sq_src};
   BLH_TRY(backward_impl(ctx, d, s, params, x, drop, ws, ws.dpred, grads, batch, nullptr, nullptr, &fb));
   const int64_t count = make_layout(d).total;
   return launch_clip_adam_dev(s, params, grads, exp_avg, exp_avg_sq, count, dev_state,
-                              ws.sumsq_part, np, stats_out,
+                              sq_src, np, stats_out,
                               LossFinish{ws.loss_part, nparts, denom, loss_out});
 }
 
@@ -1395,7 +1450,7 @@ static int gemm_entry(int dtype, void* stream, const float* A, int64_t lda, int3
   GemmTile tile = TILE_128x128;
   if (N <= 32) tile = TILE_128x32;
   else if (N <= 64) tile = TILE_128x64;
-  else if (M <= 64 && (dtype != 1 || (a_kmajor && b_kmajor))) tile = TILE_64x128;
+  else if (M <= 64) tile = TILE_64x128;
   return launch_gemm((hipStream_t)stream, tile, a_kmajor ? KROW : ROWK, b_kmajor ? KROW : ROWK,
                      epi, g, splits, dtype);
 }
@@ -1405,14 +1460,6 @@ int blh_gemm_f32(void* stream, const float* A, int64_t lda, int32_t a_kmajor, co
                  int64_t K, int32_t splits, const float* bias, const float* addend,
                  int64_t ldadd) {
   return gemm_entry(0, stream, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, splits, bias,
-                    addend, ldadd);
-}
-
-int blh_gemm_bf16(void* stream, const float* A, int64_t lda, int32_t a_kmajor, const float* B,
-                  int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc, int64_t M, int64_t N,
-                  int64_t K, int32_t splits, const float* bias, const float* addend,
-                  int64_t ldadd) {
-  return gemm_entry(1, stream, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, splits, bias,
                     addend, ldadd);
 }
 

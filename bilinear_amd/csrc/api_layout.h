@@ -40,7 +40,8 @@ static int check_desc(const blh_model_desc* d) {
     return BLH_ERR_SHAPE;
   if (d->out_features > 64) return BLH_ERR_SHAPE;   // decode uses one 64-wide column tile
   if (1 + 2 * d->num_blocks > 32) return BLH_ERR_SHAPE;
-  if (d->gemm_dtype < 0 || d->gemm_dtype > 4) return BLH_ERR_INVALID_ARGUMENT;
+  // (1 was round 1's mixed mode — fp32 tensors, operands rounded to bf16 on load — superseded by 4 and removed)
+  if (d->gemm_dtype < 0 || d->gemm_dtype > 4 || d->gemm_dtype == 1) return BLH_ERR_INVALID_ARGUMENT;
   return BLH_OK;
 }
 
@@ -94,6 +95,7 @@ struct Workspace {
   float* dpred;                   // [B][out]
   float* loss_part;               // [4096]
   double* sumsq_part;             // [1024]
+  double* sumsq_fold;             // [SUMSQ_FOLD_PARTS]: partials written by the gradient producers (fused step)
   float* colsum_part;             // [ceil(B/256)][out]
   double* sync_buf;               // [2][W] fp64 (SyncBN exchange; also used as float [2][W])
   std::vector<float*> stage_slabs; // per stage (+ decode): split-K wgrad slabs kept until grads_finish
@@ -179,6 +181,7 @@ static Workspace carve(const blh_model_desc* d, int64_t batch, void* base) {
   ws.dpred = (float*)take(batch * d->out_features * sizeof(float));
   ws.loss_part = (float*)take(4096 * sizeof(float));
   ws.sumsq_part = (double*)take(SUMSQ_MAX_PARTS * sizeof(double));
+  ws.sumsq_fold = (double*)take(SUMSQ_FOLD_PARTS * sizeof(double));
   ws.colsum_part = (float*)take(ceil_div(batch, 256) * d->out_features * sizeof(float));
   ws.sync_buf = (double*)take(2 * W * sizeof(double));
   for (int i = 0; i <= nh; ++i) {

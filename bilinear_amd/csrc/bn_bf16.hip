@@ -228,7 +228,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_h2_kernel(const float* __
                                                                  const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd,
                                                                  float* __restrict__ dgamma,
-                                                                 float* __restrict__ dbeta) {
+                                                                 float* __restrict__ dbeta,
+                                                                 double* __restrict__ sq) {
   __shared__ double r1[16][16], r2[16][16];
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int col = blockIdx.x * 16 + cl;
@@ -252,12 +253,22 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_h2_kernel(const float* __
     double t1 = 0.0, t2 = 0.0;
 #pragma unroll
     for (int s = 0; s < 16; ++s) { t1 += r1[s][cl]; t2 += r2[s][cl]; }
-    dgamma[col] = (float)((double)invstd[col] * (t1 - (double)mean[col] * t2));
-    dbeta[col] = (float)t2;
+    const float dg = (float)((double)invstd[col] * (t1 - (double)mean[col] * t2)), db = (float)t2;
+    dgamma[col] = dg;
+    dbeta[col] = db;
+    if (sq) {   // sum of squares of the 32 gradients this block wrote (lanes 0-15 of wave 0 hold them)
+      double q = (double)dg * (double)dg + (double)db * (double)db;
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+      if (threadIdx.x == 0) sq[blockIdx.x] = q;
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
+// PREGATED: dA already is dY' = 2 keep [y > 0] dA (written by the data-gradient GEMM's EPI_BN_BWD epilogue,
+// gemm_bf16s_256.h): neither the keep bits nor the gate are needed
+template <bool PREGATED>
 __global__ __launch_bounds__(H2_THREADS, BLH_H2_WAVES) void bn_bwd_apply_h2_kernel(
     const bf16_bits* __restrict__ dA, const bf16_bits* __restrict__ Z, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -293,7 +304,7 @@ __global__ __launch_bounds__(H2_THREADS, BLH_H2_WAVES) void bn_bwd_apply_h2_kern
   if (ok)
     for (int64_t rg = r0 + 4 * w; rg < r1; rg += 16) {
       uint4 zq[4], gq[4];
-      const uint32_t kw = keepbits[(rg >> 2) * W8 + (col >> 3)];
+      const uint32_t kw = PREGATED ? 0u : keepbits[(rg >> 2) * W8 + (col >> 3)];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int64_t r = min(rg + j, batch - 1);
@@ -308,7 +319,8 @@ __global__ __launch_bounds__(H2_THREADS, BLH_H2_WAVES) void bn_bwd_apply_h2_kern
         const uint32_t bits = kw >> (8 * j);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          const float dy = (((bits >> c) & 1u) && (fmaf(z[c], sc[c], sh[c]) > 0.f)) ? g[c] * 2.f : 0.f;
+          const float dy = PREGATED ? g[c]
+                                    : ((((bits >> c) & 1u) && (fmaf(z[c], sc[c], sh[c]) > 0.f)) ? g[c] * 2.f : 0.f);
           o[c] = fmaf(sc[c], dy, fmaf(ca[c], z[c], cb[c]));
         }
         if (rg + j < batch) {
@@ -356,10 +368,13 @@ int launch_bn_bwd_reduce_h2(hipStream_t s, const uint16_t* dA, const uint16_t* Z
   return BLH_OK;
 }
 
+int bn_bwd_finalize_blocks(int W) { return (int)ceil_div(W, 16); }
+
 int launch_bn_bwd_finalize_h2(hipStream_t s, const float* part, int chunks, int W, const float* mean,
-                              const float* invstd, float* dgamma, float* dbeta) {
+                              const float* invstd, float* dgamma, float* dbeta, double* sq) {
+  if (sq && W % 16 != 0) return BLH_ERR_SHAPE;     // (a ragged last block would reduce over idle lanes)
   hipLaunchKernelGGL(bn_bwd_finalize_h2_kernel, dim3((unsigned)ceil_div(W, 16)), dim3(256), 0, s, part, chunks,
-                     W, mean, invstd, dgamma, dbeta);
+                     W, mean, invstd, dgamma, dbeta, sq);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
@@ -367,10 +382,14 @@ int launch_bn_bwd_finalize_h2(hipStream_t s, const float* part, int chunks, int 
 int launch_bn_bwd_apply_h2(hipStream_t s, const uint16_t* dA, const uint16_t* Z, const float* scale,
                            const float* shift, const float* mean, const float* invstd, const float* dgamma,
                            const float* dbeta, const uint32_t* keepbits, uint16_t* dZ, float* colsum_part,
-                           int64_t batch, int W, int64_t norm_batch) {
+                           int64_t batch, int W, int64_t norm_batch, bool pregated) {
   if (W % 8 != 0) return BLH_ERR_SHAPE;
-  launch_kernel(bn_bwd_apply_h2_kernel, h2_grid(batch, W), dim3(H2_THREADS), 0, s, dA, Z, scale, shift, mean,
-                invstd, dgamma, dbeta, keepbits, dZ, colsum_part, batch, W, ew_row_chunk_h(batch), norm_batch);
+  if (pregated)
+    launch_kernel(bn_bwd_apply_h2_kernel<true>, h2_grid(batch, W), dim3(H2_THREADS), 0, s, dA, Z, scale, shift, mean,
+                  invstd, dgamma, dbeta, keepbits, dZ, colsum_part, batch, W, ew_row_chunk_h(batch), norm_batch);
+  else
+    launch_kernel(bn_bwd_apply_h2_kernel<false>, h2_grid(batch, W), dim3(H2_THREADS), 0, s, dA, Z, scale, shift, mean,
+                  invstd, dgamma, dbeta, keepbits, dZ, colsum_part, batch, W, ew_row_chunk_h(batch), norm_batch);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }

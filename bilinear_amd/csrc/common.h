@@ -54,7 +54,10 @@ enum Epilogue : int {
   EPI_BIAS = 1,        // C = acc + bias[n]
   EPI_BIAS_STATS = 2,  // C = acc + bias[n]; per-tile column (mean, M2) partials
   EPI_ADD = 3,         // C = acc + addend[m][n]
-  EPI_BN_RELU = 4      // eval forward: C = relu(bn_eval(acc + bias[n])) (+ addend[m][n], the block skip)
+  EPI_BN_RELU = 4,     // eval forward: C = relu(bn_eval(acc + bias[n])) (+ addend[m][n], the block skip)
+  EPI_BN_BWD = 5,      // bf16-storage data gradient feeding a BatchNorm backward (gemm_bf16s_256.h): C = the gated
+                       // gradient dY' = 2 keep [y > 0] acc, per-row-tile column sums of dY' z and dY'
+  EPI_BN_BWD_ADD = 6   // the same with acc + addend[m][n] (the block-skip gradient)
 };
 
 struct GemmParams {
@@ -127,12 +130,14 @@ int launch_bn_apply_h2(hipStream_t s, bool train, const uint16_t* Z, const float
 // part [chunks][2][W]: sum dY z, sum dY (chunks = ew_num_row_chunks_h(batch))
 int launch_bn_bwd_reduce_h2(hipStream_t s, const uint16_t* dA, const uint16_t* Z, const float* scale,
                             const float* shift, const uint32_t* keepbits, float* part, int64_t batch, int W);
+// sq (optional): one sum-of-squares partial of (dgamma, dbeta) per block, bn_bwd_finalize_blocks(W) of them
 int launch_bn_bwd_finalize_h2(hipStream_t s, const float* part, int chunks, int W, const float* mean,
-                              const float* invstd, float* dgamma, float* dbeta);
+                              const float* invstd, float* dgamma, float* dbeta, double* sq = nullptr);
+int bn_bwd_finalize_blocks(int W);
 int launch_bn_bwd_apply_h2(hipStream_t s, const uint16_t* dA, const uint16_t* Z, const float* scale,
                            const float* shift, const float* mean, const float* invstd, const float* dgamma,
                            const float* dbeta, const uint32_t* keepbits, uint16_t* dZ, float* colsum_part,
-                           int64_t batch, int W, int64_t norm_batch);
+                           int64_t batch, int W, int64_t norm_batch, bool pregated = false);
 // fp32-storage path, second generation (bn_f32.hip): keepbits [ceil(B/8)][W/4] words
 int64_t bn_keepbits_words_f32(int64_t batch, int W);
 int launch_bn_apply_f2(hipStream_t s, bool train, const float* Z, const float* scale, const float* shift,
@@ -157,12 +162,18 @@ int launch_bn_fwd_finalize_sums(hipStream_t s, const double* sums, int64_t n_glo
 // out[c] = sum_s in[s][c] for c < ncols (rows of `ld` floats), fp64 accumulation
 int launch_colreduce(hipStream_t s, const float* in, int S, int64_t ld, int ncols, float* out);
 // Linear-bias gradients of all stages in one launch (partials [stage][S][W])
+// sq (optional): one sum-of-squares partial of the written gradients per block, bias_colreduce_blocks() of them
 int launch_bias_colreduce(hipStream_t s, const float* part, int64_t stage_stride, int S, int W,
                           int num_stages, const int64_t* out_offsets, float* grads,
                           const float* extra_part = nullptr, int extra_S = 0, int extra_cols = 0,
-                          int64_t extra_off = 0);
+                          int64_t extra_off = 0, double* sq = nullptr);
+int bias_colreduce_blocks(int W, int num_stages, bool extra);
 // out[i] = sum_s in[s][i]   (slabs of `count` floats)
 int launch_sum_slabs(hipStream_t s, const float* slabs, int64_t count, int splits, float* out);
+// the same with one sum-of-squares partial of `out` per block: sq[0 .. sum_slabs_sq_blocks(count, max_blocks))
+int launch_sum_slabs_sq(hipStream_t s, const float* slabs, int64_t count, int splits, float* out, double* sq,
+                        int max_blocks);
+int sum_slabs_sq_blocks(int64_t count, int max_blocks);
 int launch_sum_slabs_batched(hipStream_t s, const float* slabs, int64_t count, int splits, int items,
                              int64_t slab_item_stride, float* out, int64_t out_item_stride);
 int launch_sum_slabs_add(hipStream_t s, const float* slabs, int64_t count, int splits,

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void bias_colreduce_kernel(const float* __rest
                                                              int64_t stage_stride, int S, int W,
                                                              int num_stages,
                                                              float* __restrict__ grads,
-                                                             BiasOffsets offs) {
+                                                             BiasOffsets offs, double* __restrict__ sq) {
   __shared__ double red[8][32];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + cl;
@@ -303,25 +303,39 @@ __global__ __launch_bounds__(256) void bias_colreduce_kernel(const float* __rest
   const double acc = strided_colsum<8>(in, sl, 8, rows, cols, min(col, cols - 1));
   red[sl][cl] = acc;
   __syncthreads();
+  float written = 0.f;
   if (sl == 0 && col < cols) {
     double t = 0.0;
 #pragma unroll
     for (int s = 0; s < 8; ++s) t += red[s][cl];
-    grads[out + col] = (float)t;
+    written = (float)t;
+    grads[out + col] = written;
   }
+  if (sq) {   // sum of squares of the 32 gradients this block wrote (wave 0 holds them)
+    if (sl < 2) {
+      double q = (double)written * (double)written;
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+      if (threadIdx.x == 0) sq[blockIdx.y * gridDim.x + blockIdx.x] = q;
+    }
+  }
+}
+
+int bias_colreduce_blocks(int W, int num_stages, bool extra) {
+  return (int)ceil_div(W, 32) * (num_stages + (extra ? 1 : 0));
 }
 
 int launch_bias_colreduce(hipStream_t s, const float* part, int64_t stage_stride, int S, int W,
                           int num_stages, const int64_t* out_offsets, float* grads,
                           const float* extra_part, int extra_S, int extra_cols,
-                          int64_t extra_off) {
+                          int64_t extra_off, double* sq) {
   if (num_stages > 32) return BLH_ERR_SHAPE;
   BiasOffsets o{};
   for (int i = 0; i < num_stages; ++i) o.off[i] = out_offsets[i];
   o.extra_part = extra_part; o.extra_S = extra_S; o.extra_cols = extra_cols; o.extra_off = extra_off;
   hipLaunchKernelGGL(bias_colreduce_kernel,
                      dim3((unsigned)ceil_div(W, 32), num_stages + (extra_part ? 1 : 0)), dim3(256),
-                     0, s, part, stage_stride, S, W, num_stages, grads, o);
+                     0, s, part, stage_stride, S, W, num_stages, grads, o, sq);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
@@ -371,6 +385,58 @@ int launch_sum_slabs_add(hipStream_t s, const float* slabs, int64_t count, int s
 
 int launch_sum_slabs(hipStream_t s, const float* slabs, int64_t count, int splits, float* out) {
   return launch_sum_slabs_add(s, slabs, count, splits, nullptr, out);
+}
+
+// out = sum of the slabs, and one sum-of-squares partial of `out` per block (the fused fp32 step: the
+// gradient norm of clip_grad_norm_ is gathered by the kernels that write the gradients).  1024 threads per
+// block so that a few hundred partials cover a 1024 x 1024 weight gradient at full memory-level parallelism.
+__global__ __launch_bounds__(1024) void sum_slabs_sq_kernel(const float* __restrict__ slabs, int64_t count,
+                                                            int splits, float* __restrict__ out,
+                                                            double* __restrict__ sq) {
+  __shared__ double sh[16];
+  const int64_t n4 = count >> 2;
+  double acc = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 a = ld4(slabs + i * 4);
+    int s = 1;
+    for (; s + 3 <= splits; s += 3) {
+      const float4 b0 = ld4(slabs + (int64_t)(s + 0) * count + i * 4);
+      const float4 b1 = ld4(slabs + (int64_t)(s + 1) * count + i * 4);
+      const float4 b2 = ld4(slabs + (int64_t)(s + 2) * count + i * 4);
+      a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
+      a.x += b1.x; a.y += b1.y; a.z += b1.z; a.w += b1.w;
+      a.x += b2.x; a.y += b2.y; a.z += b2.z; a.w += b2.w;
+    }
+    for (; s < splits; ++s) {
+      const float4 b = ld4(slabs + (int64_t)s * count + i * 4);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    st4(out + i * 4, a);
+    acc += (double)((a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    sq[blockIdx.x] = t;
+  }
+}
+
+int sum_slabs_sq_blocks(int64_t count, int max_blocks) {
+  return (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(count / 4, 1024), max_blocks));
+}
+
+int launch_sum_slabs_sq(hipStream_t s, const float* slabs, int64_t count, int splits, float* out, double* sq,
+                        int max_blocks) {
+  if (count % 4 != 0 || !sq) return BLH_ERR_SHAPE;
+  hipLaunchKernelGGL(sum_slabs_sq_kernel, dim3((unsigned)sum_slabs_sq_blocks(count, max_blocks)), dim3(1024), 0, s,
+                     slabs, count, splits, out, sq);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
 }
 
 // The same for `items` independent outputs in one launch (the batched weight-gradient GEMM):

@@ -146,6 +146,16 @@ int launch_gemm_bf16s(hipStream_t s, int la, int lb, int epi, bool out_bf16, con
   BLH_CASEH(ROWK, KROW, EPI_ADD, true)           // dgrad + block-skip gradient
   BLH_CASEH(ROWK, KROW, EPI_STORE, false)
   BLH_CASEH(KROW, KROW, EPI_STORE, false)        // wgrad: fp32 slabs
+  if (epi == EPI_BN_BWD || epi == EPI_BN_BWD_ADD) {   // dgrad + the BatchNorm-backward reductions of the stage below
+    if (tile == H_TILE_128 || la != ROWK || lb != KROW || !out_bf16 || splits != 1 || !p.bn_z || !p.bn_keep ||
+        !p.bn_scale || !p.bn_shift || !p.stat_part || (p.ldz % 8) != 0 || (epi == EPI_BN_BWD_ADD && !p.addend))
+      return BLH_ERR_SHAPE;
+    if (tile == H_TILE_256)
+      return epi == EPI_BN_BWD ? launch_h256<ROWK, KROW, EPI_BN_BWD, true>(s, p, 1)
+                               : launch_h256<ROWK, KROW, EPI_BN_BWD_ADD, true>(s, p, 1);
+    return epi == EPI_BN_BWD ? launch_h128x256<ROWK, KROW, EPI_BN_BWD, true>(s, p, 1)
+                             : launch_h128x256<ROWK, KROW, EPI_BN_BWD_ADD, true>(s, p, 1);
+  }
   return BLH_ERR_INVALID_ARGUMENT;
 }
 #undef BLH_CASEH

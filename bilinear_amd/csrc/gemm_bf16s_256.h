@@ -304,6 +304,130 @@ __device__ inline void gemm_epilogue_256(f32x4 (&acc)[NQM][2][4][2], const GemmP
   }
 }
 
+// ---- epilogue of a data gradient that feeds a BatchNorm backward -------------------------
+// The GEMM dA = dZ W (+ skip gradient) produces the gradient with respect to the OUTPUT of the stage below;
+// that stage's BatchNorm backward starts with two column reductions over (dA, Z) — bn_bwd_reduce_h2, a
+// streaming kernel that re-reads dA and Z from memory — and only then forms dZ.  Here the tile is still in
+// the accumulators: the store phase reads the matching Z rows and the keep-bit word of each 4 x 8 patch,
+// forms dY' = 2 keep [z scale + shift > 0] bf16(dA) (exactly the value the streaming kernel would form from
+// the stored bf16 dA: doubling commutes with the rounding), stores dY' in dA's place (bn_bwd_apply_h2 then
+// needs neither the bits nor the gate) and adds dY' z and dY' into per-thread column sums, which one LDS
+// exchange per tile turns into the [tile row][2][N] partials bn_bwd_finalize_h2 consumes.
+// Store-phase mapping: 64 rows per pass = 16 groups of 4 rows x 32 chunks of 8 columns = one (group, chunk)
+// per thread: a thread owns exactly one keep-bit word per pass, a wave stores two whole 512-byte row
+// segments per instruction.
+template <int NQM, bool HAS_ADD>
+__device__ inline void gemm_epilogue_256_bnbwd(f32x4 (&acc)[NQM][2][4][2], const GemmParamsH& p, void* Cv,
+                                               float* smem, int m0, int n0, int tile_m) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int g = lane >> 4, c16 = lane & 15;
+  constexpr int SP = 260;
+  constexpr int NPS = 2 * NQM;
+  float* stg = smem;
+  const int rg = tid >> 5, ch = tid & 31;          // 4-row group of the pass, 8-column chunk
+  const int col = n0 + ch * 8;
+  const int W8 = p.N >> 3;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) s1[c] = s2[c] = 0.f;
+  bf16_bits* C = reinterpret_cast<bf16_bits*>(Cv);
+  // (register budget: the 256 x 256 kernel holds 128 accumulator registers through this phase, so the
+  //  operands of a pass — four Z rows, four addend rows, the keep word — are requested at the head of the
+  //  pass, in front of the staging writes and the barrier that hide most of their latency, not a pass ahead;
+  //  scale / shift are re-read per pass: 64 bytes from L1)
+#pragma unroll
+  for (int ps = 0; ps < NPS; ++ps) {
+    const int qm = ps >> 1, wrp = ps & 1;
+    uint4 zq[4], aq[HAS_ADD ? 4 : 1];
+    uint32_t kw;
+    {
+      const int row0 = m0 + qm * 128 + wrp * 64 + 4 * rg;
+      kw = row0 < p.M ? p.bn_keep[(int64_t)(row0 >> 2) * W8 + (col >> 3)] : 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t r = min(row0 + j, p.M - 1);
+        zq[j] = *reinterpret_cast<const uint4*>(p.bn_z + r * p.ldz + col);
+        if constexpr (HAS_ADD) aq[j] = *reinterpret_cast<const uint4*>(p.addend + r * p.ldadd + col);
+      }
+    }
+    if (wr == wrp) {
+#pragma unroll
+      for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              stg[(i * 16 + 4 * g + r) * SP + qn * 128 + wc * 32 + j * 16 + c16] = acc[qm][qn][i][j][r];
+    }
+    __syncthreads();
+    float sc[8], sh[8];
+    {
+      const float4 a0 = *reinterpret_cast<const float4*>(p.bn_scale + col), a1 = *reinterpret_cast<const float4*>(p.bn_scale + col + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bn_shift + col), b1 = *reinterpret_cast<const float4*>(p.bn_shift + col + 4);
+      sc[0] = a0.x; sc[1] = a0.y; sc[2] = a0.z; sc[3] = a0.w; sc[4] = a1.x; sc[5] = a1.y; sc[6] = a1.z; sc[7] = a1.w;
+      sh[0] = b0.x; sh[1] = b0.y; sh[2] = b0.z; sh[3] = b0.w; sh[4] = b1.x; sh[5] = b1.y; sh[6] = b1.z; sh[7] = b1.w;
+    }
+    const int row0 = m0 + qm * 128 + wrp * 64 + 4 * rg;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = row0 + j;
+      const float4 v0 = *reinterpret_cast<const float4*>(stg + (4 * rg + j) * SP + ch * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(stg + (4 * rg + j) * SP + ch * 8 + 4);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      if constexpr (HAS_ADD) {
+        const uint4 ad = aq[j];
+        v[0] += __uint_as_float(ad.x << 16); v[1] += __uint_as_float(ad.x & 0xffff0000u);
+        v[2] += __uint_as_float(ad.y << 16); v[3] += __uint_as_float(ad.y & 0xffff0000u);
+        v[4] += __uint_as_float(ad.z << 16); v[5] += __uint_as_float(ad.z & 0xffff0000u);
+        v[6] += __uint_as_float(ad.w << 16); v[7] += __uint_as_float(ad.w & 0xffff0000u);
+      }
+      const uint4 zz = zq[j];
+      const float z[8] = {__uint_as_float(zz.x << 16), __uint_as_float(zz.x & 0xffff0000u),
+                          __uint_as_float(zz.y << 16), __uint_as_float(zz.y & 0xffff0000u),
+                          __uint_as_float(zz.z << 16), __uint_as_float(zz.z & 0xffff0000u),
+                          __uint_as_float(zz.w << 16), __uint_as_float(zz.w & 0xffff0000u)};
+      const uint32_t bits = row < p.M ? (kw >> (8 * j)) : 0u;
+      float dy[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float gr = bf16_to_f32(f32_to_bf16(v[c]));          // the gradient as bf16 storage would hold it
+        dy[c] = (((bits >> c) & 1u) && (fmaf(z[c], sc[c], sh[c]) > 0.f)) ? gr * 2.f : 0.f;
+        s2[c] += dy[c];
+        s1[c] = fmaf(dy[c], z[c], s1[c]);
+      }
+      if (row < p.M) {
+        uint4 o;
+        o.x = (uint32_t)f32_to_bf16(dy[0]) | ((uint32_t)f32_to_bf16(dy[1]) << 16);
+        o.y = (uint32_t)f32_to_bf16(dy[2]) | ((uint32_t)f32_to_bf16(dy[3]) << 16);
+        o.z = (uint32_t)f32_to_bf16(dy[4]) | ((uint32_t)f32_to_bf16(dy[5]) << 16);
+        o.w = (uint32_t)f32_to_bf16(dy[6]) | ((uint32_t)f32_to_bf16(dy[7]) << 16);
+        *reinterpret_cast<uint4*>(C + (int64_t)row * p.ldc + col) = o;
+      }
+    }
+    __syncthreads();
+  }
+  // column sums of the tile: 16 row groups x 256 columns, one tensor at a time through LDS
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    float* red = smem;                       // [16][256]
+#pragma unroll
+    for (int c = 0; c < 8; c += 4)
+      *reinterpret_cast<float4*>(red + rg * 256 + ch * 8 + c) =
+          which == 0 ? make_float4(s1[c], s1[c + 1], s1[c + 2], s1[c + 3]) : make_float4(s2[c], s2[c + 1], s2[c + 2], s2[c + 3]);
+    __syncthreads();
+    if (tid < 256) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += red[r * 256 + tid];
+      p.stat_part[((int64_t)tile_m * 2 + which) * p.N + n0 + tid] = t;
+    }
+    __syncthreads();
+  }
+}
+
 // ---- kernel ----------------------------------------------------------------------------------------
 template <int LA, int LB, int EPI, bool OUT_BF16>
 __global__ __launch_bounds__(512, 2) void gemm_bf16s_256_kernel(GemmParamsH p) {
@@ -438,7 +562,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16s_256_kernel(GemmParamsH p) {
 #undef BLH_WAIT_LGKM
 #undef BLH_SB
   __syncthreads();
-  gemm_epilogue_256<EPI, OUT_BF16>(acc, p, C, smem, m0, n0, tile_m);
+  if constexpr (EPI == EPI_BN_BWD || EPI == EPI_BN_BWD_ADD)
+    gemm_epilogue_256_bnbwd<2, EPI == EPI_BN_BWD_ADD>(acc, p, C, smem, m0, n0, tile_m);
+  else gemm_epilogue_256<EPI, OUT_BF16>(acc, p, C, smem, m0, n0, tile_m);
 }
 
 }  // namespace blh

@@ -61,6 +61,14 @@ struct GemmParamsH {
   // batch_splits == 0: an ordinary launch (grid z = slab).
   int batch_splits;
   int64_t a_batch_stride, b_batch_stride, c_batch_stride;
+  // EPI_BN_BWD (big-tile kernels): the stage whose OUTPUT gradient this GEMM produces — its pre-BatchNorm
+  // tensor Z [M][ldz] (bf16), dropout keep bits ([ceil(M/4)][N/8] words, bn_bf16.hip), scale / shift [N];
+  // stat_part receives [tiles_m][2][N]: sum over the tile's rows of dY' z and of dY'
+  const bf16_bits* bn_z;
+  int64_t ldz;
+  const uint32_t* bn_keep;
+  const float* bn_scale;
+  const float* bn_shift;
 };
 
 __device__ __forceinline__ float bf16_to_f32(bf16_bits v) { return __uint_as_float((uint32_t)v << 16); }
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(GemmParamsH p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (p.N + BN - 1) / BN;
-  int tile = 0, slab = blockIdx.z;   // (split grids: slab-major XCD mapping, gemm_f32_kernel.h)
+  int tile = 0, slab = blockIdx.z;   // (split grids: slab-major XCD mapping, gemm_dma.h: xcd_remap_split)
   if (!(gridDim.z > 1 && xcd_remap_split(blockIdx.x, blockIdx.z, gridDim.x, gridDim.z, (p.M + BM - 1) / BM,
                                          tiles_n, &tile, &slab)))
     tile = xcd_remap(blockIdx.x, gridDim.x);

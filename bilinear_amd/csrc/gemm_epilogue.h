@@ -3,7 +3,7 @@
 //   EPI_STORE / EPI_BIAS / EPI_ADD, EPI_BIAS_STATS (per-128-row-tile BatchNorm partials),
 //   EPI_BN_RELU (eval-mode heavy_linear in one kernel: bias, BatchNorm with running statistics,
 //   ReLU, optional block skip).
-//   See gemm_f32_kernel.h for the contractions it serves.
+//   See gemm_f32_ring.h for the contractions it serves.
 #pragma once
 #include "common.h"
 

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (p.N + BN - 1) / BN;
-  int tile = 0, slab = blockIdx.z;   // (split grids: slab-major XCD mapping, gemm_f32_kernel.h)
+  int tile = 0, slab = blockIdx.z;   // (split grids: slab-major XCD mapping, gemm_dma.h: xcd_remap_split)
   if (!(gridDim.z > 1 && xcd_remap_split(blockIdx.x, blockIdx.z, gridDim.x, gridDim.z, (p.M + BM - 1) / BM,
                                          tiles_n, &tile, &slab)))
     tile = xcd_remap(blockIdx.x, gridDim.x);

@@ -2,7 +2,6 @@
 #include <atomic>
 #include <cstdlib>
 
-#include "gemm_bf16_kernel.h"
 #include "gemm_f32_ring.h"
 #include "gemm_split_kernel.h"
 #include "gemm_f16x2_kernel.h"
@@ -125,51 +124,6 @@ static int launch_128x32(hipStream_t s, int la, int lb, int epi, const GemmParam
 }
 #undef BLH_CASE
 
-// ---- bf16-MFMA instantiations (mixed mode: fp32 storage, bf16 MFMA inputs) ----------------
-template <int BM, int BN, int WM, int WN, int LA, int LB, int EPI>
-static int launch_cfg_bf16(hipStream_t s, const GemmParams& p, int splits) {
-  constexpr int NT = 64 * WM * WN;
-  constexpr size_t lds = gemm_bf16_lds_bytes<BM, BN>();
-  static std::atomic<uint64_t> attr_done{0};
-  auto kern = gemm_bf16_kernel<BM, BN, WM, WN, LA, LB, EPI>;
-  BLH_TRY(ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), lds));
-  const int tiles = (int)(ceil_div(p.M, BM) * ceil_div(p.N, BN));
-  launch_kernel(kern, dim3(tiles, 1, splits), dim3(NT), lds, s, p);
-  BLH_HIP_TRY(hipGetLastError());
-  return BLH_OK;
-}
-
-#define BLH_CASE16(BM_, BN_, WM_, WN_, LA_, LB_, EPI_) \
-  if (la == LA_ && lb == LB_ && epi == EPI_)           \
-    return launch_cfg_bf16<BM_, BN_, WM_, WN_, LA_, LB_, EPI_>(s, p, splits);
-
-static int launch_bf16(hipStream_t s, GemmTile tile, int la, int lb, int epi, const GemmParams& p,
-                       int splits) {
-  switch (tile) {
-    case TILE_128x128:
-      BLH_CASE16(128, 128, 4, 2, ROWK, ROWK, EPI_BIAS_STATS)
-      BLH_CASE16(128, 128, 4, 2, ROWK, ROWK, EPI_BIAS)
-      BLH_CASE16(128, 128, 4, 2, ROWK, ROWK, EPI_BN_RELU)
-      BLH_CASE16(128, 128, 4, 2, ROWK, ROWK, EPI_STORE)
-      BLH_CASE16(128, 128, 4, 2, ROWK, KROW, EPI_STORE)
-      BLH_CASE16(128, 128, 4, 2, ROWK, KROW, EPI_ADD)
-      BLH_CASE16(128, 128, 4, 2, KROW, KROW, EPI_STORE)
-      break;
-    case TILE_128x64:
-      BLH_CASE16(128, 64, 2, 2, ROWK, ROWK, EPI_STORE)
-      BLH_CASE16(128, 64, 2, 2, ROWK, ROWK, EPI_BIAS)
-      break;
-    case TILE_64x128:
-      BLH_CASE16(64, 128, 2, 2, KROW, KROW, EPI_STORE)
-      break;
-    case TILE_128x32:
-      BLH_CASE16(128, 32, 4, 1, KROW, KROW, EPI_STORE)
-      break;
-  }
-  return BLH_ERR_INVALID_ARGUMENT;
-}
-#undef BLH_CASE16
-
 // ---- bf16x3 split instantiations (gemm_dtype = 2: fp32 accuracy on the bf16 matrix cores) ---
 template <int LA, int LB, int EPI>
 static int launch_cfg_split(hipStream_t s, const GemmParams& p, int splits) {
@@ -248,7 +202,7 @@ int launch_gemm(hipStream_t s, GemmTile tile, int la, int lb, int epi, const Gem
   if (la == KROW && p.M % 4 != 0) return BLH_ERR_SHAPE;
   if (lb == KROW && p.N % 4 != 0) return BLH_ERR_SHAPE;
   if (splits > 1 && (p.k_per_split % 32 != 0)) return BLH_ERR_SHAPE;   // whole 32-deep K tiles per slab
-  if (dtype == 1) return launch_bf16(s, tile, la, lb, epi, p, splits);
+  if (dtype == 1) return BLH_ERR_INVALID_ARGUMENT;   // (round 1's mixed mode: removed, superseded by gemm_dtype 4)
   // the split kernels take reductions in whole K tiles of 32 (every slab); other shapes (the
   // K = 48 decode dgrad) run on the exact kernel
   const bool whole_tiles = (p.K % 32 == 0) && (p.k_per_split % 32 == 0) &&

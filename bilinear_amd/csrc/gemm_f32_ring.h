@@ -2,7 +2,7 @@
 //
 //   C[M,N] = A (M x K) * B (K x N) on v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD,
 //   157.3 TFLOP/s peak).  Contractions, operand layouts (ROWK / KROW) and epilogues are those of
-//   gemm_f32_kernel.h (the register-staged reference kernel kept for tools/gemm_bench); this
+//   tools/gemm_f32_kernel.h (the register-staged reference kernel kept for tools/gemm_bench); this
 //   file differs in how the operands reach the matrix cores:
 //
 //   * HBM/L2 -> LDS by LDS-DMA in its SCALAR-BASE form (`global_load_lds_dwordx4 voff, s[base]`):

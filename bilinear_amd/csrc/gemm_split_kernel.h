@@ -12,7 +12,7 @@
 //   Why: gfx950 multiplies fp32 on the matrix cores at 157 TFLOP/s (v_mfma_f32_32x32x2_f32) but
 //   bf16 at 2.5 PFLOP/s; six bf16 MFMAs per 16 k cost 6/16 of the fp32-MFMA cycles.
 //
-// Same contractions, operand layouts (ROWK / KROW) and epilogues as gemm_f32_kernel.h.
+// Same contractions, operand layouts (ROWK / KROW) and epilogues as gemm_f32_ring.h.
 // Workgroup = 256 threads = 4 waves (2 x 2), tile 128 x 128, K tile 32; each wave owns 64 x 64
 // (2 x 2 accumulators of 32 x 32), so a k-step of 16 is 12 fragment reads for 24 MFMAs.
 //
@@ -23,11 +23,15 @@
 // loads a 4(k) x 4(row) patch as four float4 and writes four 8-B rows per plane.
 #pragma once
 #include "common.h"
-#include "gemm_bf16_kernel.h"   // bf16x8_t
+#include "common.h"
+#include "gemm_epilogue.h"
+#include "gemm_dma.h"
 #include "gemm_epilogue.h"
 #include "gemm_dma.h"          // g_zero16, lds_dma16_asm, xcd_remap
 
 namespace blh {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 #ifndef BLH_SPLIT_ABLATE
 #define BLH_SPLIT_ABLATE 0   // tools only: 1 no in-loop loads, 2 no split/store, 4 no barrier (wrong results)
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_split_kernel(GemmParams p) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (p.N + BN - 1) / BN;
-  int tile = 0, slab = blockIdx.z;   // (split grids: slab-major XCD mapping, gemm_f32_kernel.h)
+  int tile = 0, slab = blockIdx.z;   // (split grids: slab-major XCD mapping, gemm_dma.h: xcd_remap_split)
   if (!(gridDim.z > 1 && xcd_remap_split(blockIdx.x, blockIdx.z, gridDim.x, gridDim.z, (p.M + BM - 1) / BM,
                                          tiles_n, &tile, &slab)))
     tile = xcd_remap(blockIdx.x, gridDim.x);

@@ -14,6 +14,9 @@ static constexpr int EW_COLS_PER_BLOCK = 256;    // 64 lanes x float4, 4 waves s
 static constexpr int EW_THREADS_HOST = 256;
 static constexpr int WAMAX_PARTS = 64;
 static constexpr int SUMSQ_MAX_PARTS = 1024;
+// sum-of-squares partials written by the kernels that PRODUCE the gradient ranges of the fp32 backward
+// (slab sums, bias reduction, gamma / beta finalize): the fused step then needs no pass over the arena
+static constexpr int SUMSQ_FOLD_PARTS = 4096;
 
 // rows handled by one block of the streaming BatchNorm kernels: whole 32-row Philox patches,
 // at most 128 row chunks (= partials of the column sums)

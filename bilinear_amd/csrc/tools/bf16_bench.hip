@@ -2,7 +2,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../gemm_bf16_kernel.h"
+#include "gemm_bf16_kernel.h"
 using namespace blh;
 thread_local int blh::g_last_hip_error = 0;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)

@@ -5,7 +5,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../gemm_f32_kernel.h"
+#include "gemm_f32_kernel.h"
 #include "../gemm_f32_ring.h"
 
 using namespace blh;

@@ -13,9 +13,9 @@
 // Fragment: lane (r = lane&31, h = lane>>5) of k-step kk reads the 8 bf16 at
 // [row r][16 kk + 8 h .. +7] — exactly the A / B operand of the 32x32x16 MFMA.
 #pragma once
-#include "common.h"
-#include "gemm_epilogue.h"
-#include "gemm_dma.h"          // g_zero16, lds_dma16_asm, xcd_remap
+#include "../common.h"
+#include "../gemm_epilogue.h"
+#include "../gemm_dma.h"          // g_zero16, lds_dma16_asm, xcd_remap
 
 namespace blh {
 

@@ -30,9 +30,9 @@
 // k = 8s+j (half 0) and 8s+4+j (half 1).  Both operands use the same map, so
 // the permutation of k inside a group is immaterial.
 #pragma once
-#include "common.h"
-#include "gemm_epilogue.h"
-#include "gemm_dma.h"
+#include "../common.h"
+#include "../gemm_epilogue.h"
+#include "../gemm_dma.h"
 
 namespace blh {
 

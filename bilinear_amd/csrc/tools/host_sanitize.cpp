@@ -38,6 +38,10 @@ int main() {
     for (int w : widths)
       for (int mode = 0; mode <= 4; ++mode) {
         blh_model_desc d{nb, w, 32, 48, mode};
+        if (mode == 1) {   // round 1's mixed mode: removed, refused
+          CHECK(check_desc(&d) == BLH_ERR_INVALID_ARGUMENT);
+          continue;
+        }
         CHECK(check_desc(&d) == BLH_OK);
         const ArenaLayout L = make_layout(&d);
         const int nh = 1 + 2 * nb;

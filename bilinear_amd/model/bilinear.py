@@ -22,7 +22,7 @@ from ..optim import Adam
 
 __all__ = ["heavy_linear", "BilinearUnit", "Bilinear", "load"]
 
-GEMM_DTYPES = {"fp32": 0, "bf16": 1, "bf16x3": 2, "fp16x2": 3, "bf16s": 4}
+GEMM_DTYPES = {"fp32": 0, "bf16x3": 2, "fp16x2": 3, "bf16s": 4}   # (1, round 1's mixed mode, is gone)
 
 
 class _HeavyStageFunction(torch.autograd.Function):
@@ -174,8 +174,7 @@ class BilinearUnit(nn.Module):
             raise ValueError("gemm_dtype must be one of %s" % sorted(GEMM_DTYPES))
         # "fp32": exact fp32 MFMA, the reference's arithmetic.  "bf16s": bf16 STORAGE — activations,
         # gradients and a weight shadow are bf16 in HBM, fp32 master weights / BatchNorm statistics
-        # / Adam (BASELINE configs 3-5).  "bf16": tensors stay fp32, GEMM operands are rounded to
-        # bf16 on load (the round-1 form of configs 3-5, kept for comparison)
+        # / Adam (BASELINE configs 3-5).  "bf16x3" / "fp16x2": fp32 accuracy on the 16-bit matrix cores
         self.gemm_dtype = gemm_dtype
         self.encode = heavy_linear(in_features=IN_FEATURES, out_features=self.width)
         self.bilinear = nn.ModuleList([

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define BLH_ABI_VERSION 3
+#define BLH_ABI_VERSION 4
 
 typedef enum {
   BLH_OK = 0,
@@ -69,6 +69,13 @@ int blh_abi_version(void);
  *     context first and returns BLH_ERR_INVALID_ARGUMENT when another device is current.
  *   - one context = one in-flight call: a context must not be used from two host threads
  *     at once (use one context per thread / per model replica; contexts are cheap).
+ *   - the contexts of one device share the side stream, so they take turns at it, and STREAM
+ *     CAPTURE EXCLUDES THEM ALL: while one context captures a two-stream step
+ *     (blh_train_step_captured / a captured blh_backward with BLH_OPT_TWO_STREAM = 1) the side
+ *     stream is in capture mode, and work another context (or thread) enqueues on it then is
+ *     recorded into — or invalidates — that capture.  Capture with no other context of the device
+ *     in use (the Python mirror captures the single-stream order by default: its graph does not
+ *     touch the side stream at all).
  *   - kernel attributes (dynamic LDS size) are set once per device, thread-safely.
  * The reference has no counterpart: it runs on PyTorch's per-process CUDA state
  * (/root/reference/util/config.py:17 picks the one device).                              */
@@ -135,9 +142,8 @@ typedef struct {
   int32_t in_features;  /* 2*16 = 32                                         */
   int32_t out_features; /* 3*16 = 48                                         */
   int32_t gemm_dtype;   /* 0: exact fp32 MFMA (the reference's arithmetic);
-                           1: "mixed" — every tensor stays fp32 in memory, GEMM operands are
-                              rounded to bf16 on load and multiplied on bf16 MFMA with fp32
-                              accumulation (BASELINE configs 3-5);
+                           1: (removed in ABI 4: round 1's mixed mode — fp32 tensors, operands
+                              rounded to bf16 on load; superseded by 4) -> BLH_ERR_INVALID_ARGUMENT;
                            2: "bf16x3" — fp32 accuracy on the bf16 matrix cores: every operand
                               value is split exactly into three bf16 pieces on load and the
                               product is accumulated in fp32 from six bf16 MFMAs (the dropped
@@ -413,12 +419,6 @@ int blh_gemm_f32(void* stream, const float* A, int64_t lda, int32_t a_kmajor, co
                  int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc, int64_t M, int64_t N,
                  int64_t K, int32_t splits, const float* bias, const float* addend,
                  int64_t ldadd);
-/* Same contraction with the operands rounded to bf16 on load (bf16 MFMA, fp32 accumulate):
- * the GEMM of gemm_dtype = 1.  Only the operand layouts the network uses are built.        */
-int blh_gemm_bf16(void* stream, const float* A, int64_t lda, int32_t a_kmajor, const float* B,
-                  int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc, int64_t M, int64_t N,
-                  int64_t K, int32_t splits, const float* bias, const float* addend,
-                  int64_t ldadd);
 /* Same contraction in gemm_dtype = 2 arithmetic (three-way bf16 split of both operands, six bf16
  * MFMAs per product, fp32 accumulate).  Shapes the 128x128 split kernel does not cover (N <= 64,
  * or M <= 64) run on the exact fp32 kernel.                                                    */

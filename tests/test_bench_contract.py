@@ -25,7 +25,7 @@ def test_flop_model_matches_survey():
 
 
 @pytest.mark.parametrize("dtype,bound,peak", [("fp32", "mfma", 157.3), ("bf16x3", "mfma", 2500.0 / 6),
-                                              ("fp16x2", "mfma", 2500.0 / 3), ("bf16", "hbm", 8000.0)])
+                                              ("fp16x2", "mfma", 2500.0 / 3), ("bf16s", "mfma", 2500.0)])
 def test_roofline_block_fields(dtype, bound, peak):
     b = _bench()
     args = argparse.Namespace(batch=4096, width=1024, dtype=dtype)
@@ -37,10 +37,11 @@ def test_roofline_block_fields(dtype, bound, peak):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     if dtype == "fp32":          # PMC traffic of the dominant kernel, recorded under profiles/
         import json, os
-        rec = json.load(open(os.path.join(os.path.dirname(__file__), "..", "profiles", "r02_traffic.json")))
-        k = rec["kernels"]["linear_fwd"]
+        rec = json.load(open(os.path.join(os.path.dirname(__file__), "..", "profiles", "r04_traffic.json")))
+        k = [v for n, v in rec["shapes"]["4096x1024"].items() if n.startswith("gemm_f32_ring_kernel<128, 128, 4, 2, 0, 0, 2")][0]
         assert k["traffic_bytes"] == 2 * 1024 * k["fetch_size_kb"] + 1024 * k["write_size_kb"]   # gfx950 x2 correction
         assert r["traffic"] == k["traffic_bytes"] and abs(r["achieved"] - 119.3) < 0.1
+        assert "r04_traffic.json" in r["traffic_unit"]          # this round's binary, not an older record
 
 
 def test_cpu_baseline_port_runs_the_whole_step():

@@ -403,6 +403,48 @@ def test_bf16s_backward_schedules_are_bit_identical():
     assert torch.isfinite(out[(True, 1)][3]).all()
 
 
+@pytest.mark.parametrize("nb,batch", [(2, 8192), (1, 16384)])
+def test_bn_backward_reductions_in_the_dgrad_epilogue_match_the_streaming_kernel(nb, batch):
+    """SURVEY K9 (round 4): the data-gradient GEMMs whose output only feeds the BatchNorm backward of the stage
+    below form that stage's gated gradient dY' and the (dY' z, dY') column sums in their epilogue
+    (EPI_BN_BWD, the 256 x 256 and 128 x 256 kernels), and the stage below skips bn_bwd_reduce_h2.  The
+    gated values are the same bf16 numbers the streaming kernel forms; only the order of the column sums
+    differs, so every gradient agrees with the BLH_NO_K9=1 run to summation rounding (plus the few bf16
+    roundings of dZ that a 1e-7 change of the column sums moves)."""
+    import os
+
+    import bilinear_amd
+    dev = _dev()
+    x, t = (torch.randn(batch, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(3)),
+            torch.randn(batch, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(4)))
+    out = {}
+    for k9 in (True, False):
+        if not k9:
+            os.environ["BLH_NO_K9"] = "1"
+        try:
+            torch.manual_seed(0)
+            net, opt, _, _ = bilinear_amd.load(dev, num_blocks=nb, width=1024, gemm_dtype="bf16s")
+            net.train()
+            net.engine.ensure(dev)
+            net.engine.seed = 11
+            opt.zero_grad()
+            pred = net(x)
+            torch.nn.functional.mse_loss(pred, t).backward()
+            torch.cuda.synchronize()
+            out[k9] = (pred.detach().clone(), net.engine.grads.clone(),
+                       {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+        finally:
+            os.environ.pop("BLH_NO_K9", None)
+    assert torch.equal(out[True][0], out[False][0])              # the forward is untouched
+    assert not torch.equal(out[True][1], out[False][1])          # ... and the backward really took another path
+    for k in out[True][2]:
+        a, b = out[True][2][k].double(), out[False][2][k].double()
+        if k.endswith(".0.bias") and not k.startswith("decode"):
+            continue                                             # pre-BatchNorm biases: rounding noise (SURVEY H2)
+        rel = float((a - b).norm() / b.norm())
+        assert rel <= 2e-3, (k, rel)
+
+
 def test_persistent_shadow_is_bit_identical_and_invalidated_by_parameter_writes():
     """BLH_OPT_PERSISTENT_SHADOW (fused Adam -> bf16 weight image): the same steps with
     and without it are bit-identical — through plain fused steps, a load_state_dict between two

@@ -125,6 +125,83 @@ def test_data_parallel_two_ranks_match_manual_average(tmp_path, cfg):
 
 
 # ----------------------------------------------------------------------------
+# bf16 storage + bf16-compressed buckets, per-rank BatchNorm statistics (BASELINE configs[3], [4]: the
+# step bench.py --gpus N times): two ranks over gloo on one GPU against the manual average
+# ----------------------------------------------------------------------------
+CFG_H = (1, 1024, 2048, "bf16s")
+
+
+def _worker_bf16s(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bilinear_amd.dp import DataParallel
+        dev = torch.device("cuda:0")
+        net, opt = _make(dev, CFG_H)
+        x, t = _data(dev, CFG_H)
+        dp = DataParallel(net, opt, bucket_floats=300000, compress="bf16")
+        sl = slice(rank * CFG_H[2], (rank + 1) * CFG_H[2])
+        pred, loss = dp.train_step(x[sl], t[sl])
+        torch.cuda.synchronize()
+        assert len(dp._reducer.launched) >= 2 and dp._reducer._half is not None
+        np.save(os.path.join(out_dir, "hparams%d.npy" % rank), net.engine.params.cpu().numpy())
+        np.save(os.path.join(out_dir, "hgrads%d.npy" % rank), net.engine.grads.cpu().numpy())
+        np.save(os.path.join(out_dir, "hstats%d.npy" % rank), opt._stats.cpu().numpy())
+        np.save(os.path.join(out_dir, "hloss%d.npy" % rank), np.array([float(loss.item())]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16s_two_ranks_with_bf16_buckets_match_manual_average(tmp_path):
+    """blh_clip_adam_step_bf16 reading the exchanged bf16 buckets directly: the clipped gradient it
+    leaves in the fp32 arena == clip(mean of the two shards' gradients, each rounded to bf16 for the
+    wire, summed in bf16), the total norm and the replicas' parameters likewise."""
+    port = _free_port()
+    mp.spawn(_worker_bf16s, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = np.load(tmp_path / "hparams0.npy"), np.load(tmp_path / "hparams1.npy")
+    g0, g1 = np.load(tmp_path / "hgrads0.npy"), np.load(tmp_path / "hgrads1.npy")
+    assert np.array_equal(p0, p1), "replicas diverged"
+    assert np.array_equal(g0, g1)
+    # the reported loss is the global batch's on both ranks
+    assert np.load(tmp_path / "hloss0.npy")[0] == np.load(tmp_path / "hloss1.npy")[0]
+
+    dev = torch.device("cuda:0")
+    net, opt = _make(dev, CFG_H)
+    x, t = _data(dev, CFG_H)
+    eng = net.engine
+    eng.ensure(dev)
+    B = CFG_H[2]
+    shards, losses = [], []
+    bn0, nbt0 = eng.bn_running.clone(), eng.bn_nbt.clone()
+    for r in range(2):
+        sl = slice(r * B, (r + 1) * B)
+        eng.row_offset = r * B
+        eng.rng_step = 0
+        eng.bn_running.copy_(bn0)
+        eng.bn_nbt.copy_(nbt0)
+        pred, loss = eng.forward_train_loss(x[sl].contiguous(), t[sl].contiguous())
+        eng.backward(x[sl].contiguous(), None)
+        shards.append(eng.grads.clone())
+        losses.append(float(loss.item()))
+    torch.cuda.synchronize()
+    wire = (shards[0].to(torch.bfloat16) + shards[1].to(torch.bfloat16)).float() * 0.5     # bf16 sum, exact halving
+    norm = float(wire.double().pow(2).sum().sqrt())
+    clipped = (wire * min(1.0, 1.0 / (norm + 1e-6))).cpu().numpy()
+    stats = np.load(tmp_path / "hstats0.npy")
+    assert abs(stats[0] - norm) <= 1e-4 * norm, (stats, norm)
+    rel = np.linalg.norm(g0 - clipped) / np.linalg.norm(clipped)
+    assert rel <= 1e-4, rel                       # same bf16 values in, fp32 arithmetic on both sides
+    assert abs(np.load(tmp_path / "hloss0.npy")[0] - 0.5 * (losses[0] + losses[1])) <= 1e-5 * losses[0]
+    # ... and against the uncompressed average: bf16 rounding of the wire only
+    plain = (0.5 * (shards[0] + shards[1]))
+    pn = float(plain.double().pow(2).sum().sqrt())
+    plain = (plain * min(1.0, 1.0 / (pn + 1e-6))).cpu().numpy()
+    rel = np.linalg.norm(g0 - plain) / np.linalg.norm(plain)
+    assert 0 < rel <= 6e-3, rel
+
+
+# ----------------------------------------------------------------------------
 # SyncBN: two ranks == one device on the concatenated batch (the reference's semantics)
 # ----------------------------------------------------------------------------
 def _worker_sync(rank, world, port, out_dir):

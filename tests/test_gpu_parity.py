@@ -675,114 +675,18 @@ def test_mpjpe_matches_oracle():
 
 
 # ----------------------------------------------------------------------------
-# gemm_dtype = "bf16" (BASELINE configs 3-5): fp32 tensors, GEMM operands rounded to bf16,
-# bf16 MFMA with fp32 accumulation.  Tolerances are bf16's (8-bit mantissa, eps = 2^-8):
-# a K-term dot product of rounded operands carries ~2^-9*sqrt(2) relative error per term,
-# i.e. ~4e-3 of the output RMS; the tests allow 2e-2 on outputs/gradients (north_star's 1e-3
-# is stated for fp32 only).
-# ----------------------------------------------------------------------------
-BF16_GEMM_CASES = [
-    (4096, 1024, 1024, 0, 0, 1),      # forward
-    (300, 1024, 64, 0, 0, 1),         # ragged M, one K tile
-    (4096, 48, 1024, 0, 0, 4),        # decode forward (split over W)
-    (200, 1024, 1024, 0, 1, 1),       # dgrad
-    (64, 1024, 48, 0, 1, 1),          # decode dgrad, ragged K
-    (1024, 1024, 4096, 1, 1, 4),      # wgrad
-    (1024, 32, 1000, 1, 1, 8),        # encode wgrad
-    (48, 1024, 777, 1, 1, 1),         # decode wgrad
-]
-
-
-def _to_bf16(a):
-    """Round-to-nearest-even fp32 -> bf16 -> fp32, as v_cvt_pk_bf16_f32 does."""
-    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
-    u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
-    return u.astype(np.uint32).view(np.float32)
-
-
-@pytest.mark.parametrize("M,N,K,ak,bk,splits", BF16_GEMM_CASES)
-def test_gemm_bf16_layouts(native, M, N, K, ak, bk, splits):
-    dev = _dev()
-    rng = np.random.RandomState(M + 3 * N + 7 * K)
-    A = rng.standard_normal((K, M) if ak else (M, K)).astype(np.float32)
-    B = rng.standard_normal((K, N) if bk else (N, K)).astype(np.float32)
-    Ar, Br = _to_bf16(A), _to_bf16(B)
-    # exact expectation: the product of the ROUNDED operands in high precision
-    ref = (Ar.T if ak else Ar).astype(np.float64) @ (Br if bk else Br.T).astype(np.float64)
-    a, b = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
-    c = torch.full((splits, M, N), float("nan"), device=dev)
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    rc = native.blh_gemm_bf16(st, a.data_ptr(), A.shape[1], ak, b.data_ptr(), B.shape[1], bk,
-                              c.data_ptr(), N, M, N, K, splits, None, None, 0)
-    assert rc == 0, native.blh_status_string(rc)
-    out = c.sum(dim=0) if splits > 1 else c[0]
-    torch.cuda.synchronize()
-    _close(out.cpu().numpy(), ref, 2e-5, "bf16 gemm vs rounded-operand product")
-
-
-@pytest.mark.parametrize("nb,width,batch", [(2, 1024, 512), (4, 1024, 256), (1, 256, 4096)])
-def test_bf16_mode_against_oracle(nb, width, batch):
-    """The bf16 mode must reproduce the oracle run with the SAME operand rounding (fp64
-    accumulation) to fp32 accuracy; the distance to the un-rounded oracle is reported (ReLU /
-    dropout gates of pre-activations within bf16 rounding of zero flip, which alone puts
-    ~5 % relative L2 error on hidden-layer weight gradients — a property of bf16, not of the
-    kernels)."""
-    dev = _dev()
-    st = O.init_state(200 + nb, nb, width)
+# (gemm_dtype = "bf16", round 1's mixed mode — fp32 tensors, operands rounded to bf16 on load — was
+#  removed in round 4 together with its tests: gemm_dtype "bf16s" superseded it; tests/test_gpu_bf16s.py,
+#  tests/test_gpu_timed_path.py.)  The model descriptor must refuse it:
+def test_removed_mixed_mode_is_refused(native):
+    from bilinear_amd import _native as N
+    d = N.ModelDesc(2, 1024, 32, 48, 1)
+    assert native.blh_param_arena_floats(ctypes.byref(d)) == -1          # BLH_ERR_INVALID_ARGUMENT
     import bilinear_amd
-    net = bilinear_amd.BilinearUnit(nb, width, gemm_dtype="bf16")
-    sd = net.state_dict()
-    net.load_state_dict({k: torch.from_numpy(np.array(st[k])).reshape(sd[k].shape) for k in sd})
-    net = net.to(dev).train()
-    x, t = O.synthetic_batch(5, batch)
-    masks = O.random_masks(9, batch, nb, width)
-    net.engine.set_dropout_masks(masks)
-    xt, tt = torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev)
-    pred = net(xt)
-    loss = torch.nn.functional.mse_loss(pred, tt)
-    loss.backward()
-
-    def oracle(rounding):
-        O.set_gemm_rounding(rounding)
-        try:
-            s2 = {k: v.copy() for k, v in st.items()}
-            rp, cache = O.forward(s2, x, masks, training=True, dtype=np.float64)
-            rl, dp = O.mse_loss(rp, t.astype(np.float64))
-            return rp, rl, O.backward(s2, cache, dp, dtype=np.float64)
-        finally:
-            O.set_gemm_rounding(None)
-
-    rp, rl, rg = oracle("bf16")
-    got_pred = pred.detach().cpu().numpy()
-    # (the bf16 MFMA's internal fp32 accumulation is not an exact fmaf chain like the f32
-    #  MFMA's: ~1e-5 per GEMM, a few 1e-4 after five BatchNorm'ed stages)
-    assert np.linalg.norm(got_pred - rp) / np.linalg.norm(rp) <= 2e-3
-    assert abs(loss.item() - rl) <= 2e-3 * rl
-    worst = 0.0
-    for k, p in net.named_parameters():
-        if is_prebn_bias(k):
-            continue
-        got = p.grad.cpu().numpy().astype(np.float64)
-        rel = np.linalg.norm(got - rg[k]) / np.linalg.norm(rg[k])
-        # Not tight by nature: a 1e-5 accumulation-order difference moves ~0.25 % of the next
-        # stage's operands across a bf16 rounding boundary (2^-8 each) and flips a few ReLU
-        # gates, so two correct bf16 runs drift apart by 1e-4..1e-3 per stage and by per-cent on
-        # the gradients of the early stages.  The bit-level check of the kernels is
-        # test_gemm_bf16_layouts (exact product of the rounded operands, 2e-5).
-        assert rel <= 0.1, (k, rel)
-        worst = max(worst, rel)
-    fp, fl, fg = oracle(None)
-    far = max(np.linalg.norm(p.grad.cpu().numpy() - fg[k]) / np.linalg.norm(fg[k])
-              for k, p in net.named_parameters() if not is_prebn_bias(k))
-    print("bf16 mode: vs same-rounding oracle %.2e; vs exact oracle pred %.2e, grads %.2e" % (
-        worst, np.linalg.norm(got_pred - fp) / np.linalg.norm(fp), far))
-    assert np.linalg.norm(got_pred - fp) / np.linalg.norm(fp) <= 2e-2
-    assert far <= 0.3
+    with pytest.raises(ValueError):
+        bilinear_amd.BilinearUnit(2, 1024, gemm_dtype="bf16")
 
 
-# ----------------------------------------------------------------------------
-# cold API rows of SURVEY.md §8(a): reset_statistics (a4), checkpoint restore (a5)
-# ----------------------------------------------------------------------------
 def test_reset_statistics_cumulative_average():
     """model/bilinear.py:43-55: momentum=None makes BatchNorm keep the cumulative average
     of the batch statistics (factor 1/num_batches_tracked)."""
@@ -973,6 +877,60 @@ def test_device_dataset_feeds_training_and_metric():
         assert abs(per_action[k] - ref_sum[k] / (ref_cnt[k] * 16)) <= 1e-4 * per_action[k] + 1e-3
     tot = sum(ref_sum.values()) / (sum(ref_cnt.values()) * 16)
     assert abs(avg - tot) <= 1e-4 * tot + 1e-3
+
+
+@pytest.mark.parametrize("protocol", ["SH", "SH+FT"])
+def test_detected_joint_protocols_through_the_device_path(tmp_path, protocol):
+    """SURVEY.md 8(f) rank 4 (/root/reference/H36M/protocol.py:1-4, H36M/data.py:31-34): the SH / SH+FT
+    protocols only select which ``{task}_{protocol}.bin`` pickles feed the SAME path.  On the device:
+    pickles of the reference's layout (python lists) -> DevicePoseDataset.from_pickles(protocol=...) ->
+    one fused step of the HIP path on the first batch == the oracle's step on the oracle's own
+    restatement of the loader (H36M/data.py:36-59,108-110), and the detected-joint inputs really are
+    the ones that were fed (they differ from the ground-truth protocol's)."""
+    import pickle
+
+    import bilinear_amd
+    from bilinear_amd.data import DevicePoseDataset, synthetic_raw
+    dev = _dev()
+    base_tr, base_va = synthetic_raw(1024, seed=21), synthetic_raw(128, seed=22)
+    rng = np.random.RandomState(23)
+    for proto, noise in (("GT", 0.0), ("SH", 6.0), ("SH+FT", 3.0)):
+        for task, raw in (("train", base_tr), ("valid", base_va)):
+            r = dict(raw)
+            r["part"] = (raw["part"] + noise * rng.standard_normal(raw["part"].shape)).astype(np.float32).tolist()
+            r["S"] = raw["S"].tolist()
+            with open(tmp_path / ("%s_%s.bin" % (task, proto)), "wb") as f:
+                pickle.dump(r, f)
+    train, valid = DevicePoseDataset.from_pickles(str(tmp_path), dev, protocol=protocol)
+    gt_train, _ = DevicePoseDataset.from_pickles(str(tmp_path), dev, protocol="GT")
+    assert train.x.is_cuda and not torch.allclose(train.x, gt_train.x) and torch.allclose(train.t, gt_train.t)
+    with open(tmp_path / ("train_%s.bin" % protocol), "rb") as f:
+        raw_tr = pickle.load(f)
+    ptr, str_ = O.h36m_flatten(np.asarray(raw_tr["part"], np.float32), np.asarray(raw_tr["S"], np.float32))
+    mx, sx = O.h36m_stats(ptr)
+    mt, st_ = O.h36m_stats(str_)
+    xo, to = O.h36m_normalise(ptr, mx, sx), O.h36m_normalise(str_, mt, st_)
+    batch, nb, width = 512, 1, 256
+    x, t = next(iter(train.epoch(0, batch, shuffle=False)))
+    _close(x.cpu().numpy(), xo[:batch], 2e-5, "SH batch x")
+    _close(t.cpu().numpy(), to[:batch], 2e-5, "SH batch t")
+    st = O.init_state(77, nb, width)
+    net = bilinear_amd.BilinearUnit(nb, width)
+    sd = net.state_dict()
+    net.load_state_dict({k: torch.from_numpy(np.array(st[k])).reshape(sd[k].shape) for k in sd})
+    net = net.to(dev).train()
+    opt = bilinear_amd.Adam(net.parameters(), lr=1e-3, module=net)
+    masks = O.random_masks(5, batch, nb, width)
+    net.engine.set_dropout_masks(masks)
+    pred, loss = net.train_step(opt, x, t)
+    torch.cuda.synchronize()
+    ost = {k: v.copy() for k, v in st.items()}
+    oopt = O.adam_init(ost, O.param_keys(nb))
+    r = O.train_step(ost, oopt, xo[:batch], to[:batch], masks, 1e-3)
+    _close(pred.cpu().numpy(), r["pred"], 1e-4, "%s step prediction" % protocol)
+    assert abs(loss.item() - r["loss"]) <= 1e-5 * r["loss"]
+    w = dict(net.named_parameters())["decode.weight"].detach().cpu().numpy()
+    assert np.abs(w - ost["decode.weight"]).max() <= 2e-5 + 1e-3 * 1e-3     # post-Adam: |update| <= lr
 
 
 @pytest.mark.parametrize("loss_scale,gamma_scale", [(1e-7, 1.0), (1e4, 1.0), (1.0, 300.0), (1e-5, 0.01)])
