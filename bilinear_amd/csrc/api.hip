@@ -780,7 +780,10 @@ static int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
       // K9: this GEMM's output is only read by the BatchNorm backward of stage i - 1
       const int tile = gemm_bf16s_pick_tile(ROWK, KROW, true, g, 1);
       const int64_t k9_rows = ceil_div(batch, gemm_bf16s_tile_rows(tile));
-      const bool k9 = k9_enabled && tile != H_TILE_128 && (!first_of_block || i == 1) && k9_rows <= chunks;
+      // (the addend form — stage 1 only — spills in the 256 x 256 kernel, which holds 128 accumulator registers
+      //  through its epilogue: there stage 0 keeps the streaming reduction)
+      const bool k9 = k9_enabled && tile != H_TILE_128 && k9_rows <= chunks &&
+                      (!first_of_block || (i == 1 && tile == H_TILE_128x256));
       if (k9) {
         const float* svd = ws.bn_saved[i - 1];
         g.bn_z = ws.Z[i - 1]; g.ldz = W; g.bn_keep = ws.keep[i - 1];

@@ -428,6 +428,144 @@ __device__ inline void gemm_epilogue_256_bnbwd(f32x4 (&acc)[NQM][2][4][2], const
   }
 }
 
+// The same without an addend, staged as PACKED bf16: the gated gradient only needs bf16(acc), so the 128 (64)
+// accumulator registers are first rounded and packed in pairs of rows (v_cvt_pk_bf16_f32: registers r, r + 1 of an
+// MFMA tile are rows 4 g + r, 4 g + r + 1 of one column), which (1) halves the LDS traffic of the staging,
+// (2) lets a whole 128-row half of the tile be staged at once (66 KB of 32-bit row-pair words: one barrier pair
+// per quadrant row instead of two), and (3) frees the accumulator registers, so that the Z rows and keep words
+// of the NEXT half are requested while this one is processed (the fp32-staged form above, with 128 accumulator
+// registers alive, has to request its operands at the head of every pass and waits for memory four times per tile:
+// 256 x 256 dgrad 30 -> 50 us at M = 16384, profiles/r04_k9.md).
+template <int NQM>
+__device__ inline void gemm_epilogue_256_bnbwd_packed(f32x4 (&acc)[NQM][2][4][2], const GemmParamsH& p, void* Cv,
+                                                      float* smem, int m0, int n0, int tile_m) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int g = lane >> 4, c16 = lane & 15;
+  constexpr int SPW = 260;                           // words per row pair
+  uint32_t* stg = reinterpret_cast<uint32_t*>(smem);
+  const int rg0 = tid >> 5, ch = tid & 31;           // 4-row group (of 16; + 16 for the second item), 8-column chunk
+  const int col = n0 + ch * 8;
+  const int W8 = p.N >> 3;
+  bf16_bits* C = reinterpret_cast<bf16_bits*>(Cv);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) s1[c] = s2[c] = 0.f;
+  // operands of one 128-row half: two (4-row group, chunk) items per thread
+  uint4 zq[2][2][4];       // [buffer][item][row]
+  uint32_t kw[2][2];
+  auto request = [&](int qm, int buf) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row0 = m0 + qm * 128 + 4 * (it * 16 + rg0);
+      kw[buf][it] = row0 < p.M ? p.bn_keep[(int64_t)(row0 >> 2) * W8 + (col >> 3)] : 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t r = min(row0 + j, p.M - 1);
+        zq[buf][it][j] = *reinterpret_cast<const uint4*>(p.bn_z + r * p.ldz + col);
+      }
+    }
+  };
+  request(0, 0);
+  // round + pack: pk[qm][qn][i][j][h] = rows (4 g + 2 h, 4 g + 2 h + 1) of the MFMA tile, one column
+  uint32_t pk[NQM][2][4][2][2];
+  {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int qm = 0; qm < NQM; ++qm)
+#pragma unroll
+      for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const bf2 b = {(__bf16)acc[qm][qn][i][j][2 * h], (__bf16)acc[qm][qn][i][j][2 * h + 1]};
+              pk[qm][qn][i][j][h] = *reinterpret_cast<const uint32_t*>(&b);
+            }
+  }
+  float sc[8], sh[8];
+  {
+    const float4 a0 = *reinterpret_cast<const float4*>(p.bn_scale + col), a1 = *reinterpret_cast<const float4*>(p.bn_scale + col + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bn_shift + col), b1 = *reinterpret_cast<const float4*>(p.bn_shift + col + 4);
+    sc[0] = a0.x; sc[1] = a0.y; sc[2] = a0.z; sc[3] = a0.w; sc[4] = a1.x; sc[5] = a1.y; sc[6] = a1.z; sc[7] = a1.w;
+    sh[0] = b0.x; sh[1] = b0.y; sh[2] = b0.z; sh[3] = b0.w; sh[4] = b1.x; sh[5] = b1.y; sh[6] = b1.z; sh[7] = b1.w;
+  }
+#pragma unroll
+  for (int qm = 0; qm < NQM; ++qm) {
+    const int buf = qm & 1;
+    // stage the 128 rows of this quadrant row: row pair (wr * 32 + i * 8 + 2 g + h), 256 columns
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            stg[(wr * 32 + i * 8 + 2 * g + h) * SPW + qn * 128 + wc * 32 + j * 16 + c16] = pk[qm][qn][i][j][h];
+    if (qm + 1 < NQM) request(qm + 1, buf ^ 1);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int rgi = it * 16 + rg0;                 // 4-row group of the half: rows 4 rgi .. 4 rgi + 3
+      const int row0 = m0 + qm * 128 + 4 * rgi;
+#pragma unroll
+      for (int hp = 0; hp < 2; ++hp) {               // row pair 2 rgi + hp = rows 4 rgi + 2 hp, + 1
+        const uint4 w0 = *reinterpret_cast<const uint4*>(stg + (2 * rgi + hp) * SPW + ch * 8);
+        const uint4 w1 = *reinterpret_cast<const uint4*>(stg + (2 * rgi + hp) * SPW + ch * 8 + 4);
+        const uint32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {                // even / odd row of the pair
+          const int j = 2 * hp + e;
+          const int row = row0 + j;
+          const uint4 zz = zq[buf][it][j];
+          const float z[8] = {__uint_as_float(zz.x << 16), __uint_as_float(zz.x & 0xffff0000u),
+                              __uint_as_float(zz.y << 16), __uint_as_float(zz.y & 0xffff0000u),
+                              __uint_as_float(zz.z << 16), __uint_as_float(zz.z & 0xffff0000u),
+                              __uint_as_float(zz.w << 16), __uint_as_float(zz.w & 0xffff0000u)};
+          const uint32_t bits = row < p.M ? (kw[buf][it] >> (8 * j)) : 0u;
+          float dy[8];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const float gr = e == 0 ? __uint_as_float(w[c] << 16) : __uint_as_float(w[c] & 0xffff0000u);
+            dy[c] = (((bits >> c) & 1u) && (fmaf(z[c], sc[c], sh[c]) > 0.f)) ? gr * 2.f : 0.f;
+            s2[c] += dy[c];
+            s1[c] = fmaf(dy[c], z[c], s1[c]);
+          }
+          if (row < p.M) {
+            uint4 o;
+            o.x = (uint32_t)f32_to_bf16(dy[0]) | ((uint32_t)f32_to_bf16(dy[1]) << 16);
+            o.y = (uint32_t)f32_to_bf16(dy[2]) | ((uint32_t)f32_to_bf16(dy[3]) << 16);
+            o.z = (uint32_t)f32_to_bf16(dy[4]) | ((uint32_t)f32_to_bf16(dy[5]) << 16);
+            o.w = (uint32_t)f32_to_bf16(dy[6]) | ((uint32_t)f32_to_bf16(dy[7]) << 16);
+            *reinterpret_cast<uint4*>(C + (int64_t)row * p.ldc + col) = o;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // column sums of the tile: 16 thread rows x 256 columns, one tensor at a time through LDS
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    float* red = smem;                       // [16][256]
+#pragma unroll
+    for (int c = 0; c < 8; c += 4)
+      *reinterpret_cast<float4*>(red + rg0 * 256 + ch * 8 + c) =
+          which == 0 ? make_float4(s1[c], s1[c + 1], s1[c + 2], s1[c + 3]) : make_float4(s2[c], s2[c + 1], s2[c + 2], s2[c + 3]);
+    __syncthreads();
+    if (tid < 256) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += red[r * 256 + tid];
+      p.stat_part[((int64_t)tile_m * 2 + which) * p.N + n0 + tid] = t;
+    }
+    __syncthreads();
+  }
+}
+
 // ---- kernel ----------------------------------------------------------------------------------------
 template <int LA, int LB, int EPI, bool OUT_BF16>
 __global__ __launch_bounds__(512, 2) void gemm_bf16s_256_kernel(GemmParamsH p) {
@@ -562,8 +700,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16s_256_kernel(GemmParamsH p) {
 #undef BLH_WAIT_LGKM
 #undef BLH_SB
   __syncthreads();
-  if constexpr (EPI == EPI_BN_BWD || EPI == EPI_BN_BWD_ADD)
-    gemm_epilogue_256_bnbwd<2, EPI == EPI_BN_BWD_ADD>(acc, p, C, smem, m0, n0, tile_m);
+  if constexpr (EPI == EPI_BN_BWD) gemm_epilogue_256_bnbwd_packed<2>(acc, p, C, smem, m0, n0, tile_m);
+  else if constexpr (EPI == EPI_BN_BWD_ADD) gemm_epilogue_256_bnbwd<2, true>(acc, p, C, smem, m0, n0, tile_m);
   else gemm_epilogue_256<EPI, OUT_BF16>(acc, p, C, smem, m0, n0, tile_m);
 }
 
