@@ -110,6 +110,7 @@ _SIGNATURES = {
                                             c_void_p, c_void_p, c_int64, c_void_p]),
     "blh_gemm_bf16s_tile": (c_int32, [c_int64, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32]),
     "blh_gemm_bf16s_force_tile": (c_int, [c_int32]),
+    "blh_context_grid_barrier_timeouts": (c_int64, [c_void_p]),
     "blh_side_stream_renew": (c_int, []),
     "blh_side_stream_generation": (c_int32, []),
     "blh_tune_streams": (c_int, [c_void_p, c_int32, POINTER(c_float)]),

@@ -46,6 +46,9 @@ struct blh_context {
   bool persistent_shadow = false;
   const void* shadow_params = nullptr;
   const void* shadow_ws = nullptr;
+  // grid barrier of the fused forward stage (gemm_bf16s_bnfwd.h): arrivals, generation, timeouts; device memory
+  // owned by the context, zeroed once here
+  uint32_t* grid_bar = nullptr;
 };
 
 namespace blh {
@@ -528,13 +531,33 @@ static int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, c
     g.C = ws.Z[i]; g.ldc = W;
     g.M = (int)batch; g.N = W; g.K = h.fan_in; g.k_per_split = h.fan_in;
     g.bias = params + h.b; g.stat_part = ws.stat_part;
-    BLH_TRY(launch_gemm_bf16s(s, ROWK, ROWK, train ? EPI_BIAS_STATS : EPI_BIAS, true, g, 1));
     // (BatchNorm partials: one (mean, M2) pair per row tile of the kernel that ran, 128 or 256 rows)
-    const int st_rows = gemm_bf16s_tile_rows(gemm_bf16s_pick_tile(ROWK, ROWK, true, g, 1));
+    const int tile = gemm_bf16s_pick_tile(ROWK, ROWK, true, g, 1);
+    const int st_rows = gemm_bf16s_tile_rows(tile);
     const int st_tiles = (int)ceil_div(batch, st_rows);
     const uint16_t* skip = (i >= 2 && (i % 2) == 0) ? ws.A[i - 2] : nullptr;
     float* rm = bn_running + ((int64_t)i * 2 + 0) * W;
     float* rv = bn_running + ((int64_t)i * 2 + 1) * W;
+    // The whole stage in ONE launch (gemm_bf16s_bnfwd.h: statistics merged behind a grid barrier, BatchNorm +
+    // ReLU + dropout + skip applied to the tile the workgroup still holds): big-tile kernels whose grid fits the
+    // chip one workgroup per CU (configs[2]: 256 tiles of 256 x 256; configs[3] per GPU: 256 of 128 x 256), per-rank
+    // statistics.  Bit-identical to the three-launch form and MEASURED SLOWER (configs[2] 1.59 against 1.47 ms,
+    // configs[3] per-GPU shape 1.10 against 0.95: profiles/r04_fused_forward.md), so it is opt-in: BLH_FWD_FUSE=1.
+    if (train && !ctx->sync.fn && tile != H_TILE_128 && ctx->grid_bar && getenv("BLH_FWD_FUSE") &&
+        (int64_t)st_tiles * (W / 256) <= gemm_bf16s_fused_forward_max_wgs() && st_tiles <= 128) {
+      g.fwd.gamma = params + h.gamma; g.fwd.beta = params + h.beta;
+      g.fwd.running_mean = rm; g.fwd.running_var = rv; g.fwd.nbt = nbt + i; g.fwd.momentum = momentum;
+      g.fwd.saved = ws.bn_saved[i];
+      g.fwd.skip = skip; g.fwd.ldskip = W;
+      g.fwd.A = ws.A[i]; g.fwd.lda_out = W;
+      g.fwd.keepbits = ws.keep[i];
+      g.fwd.drop = layer_drop(ctx, drop, i, batch, W);
+      g.fwd.bar = ctx->grid_bar;
+      g.fwd.tile_rows = st_rows;
+      BLH_TRY(launch_gemm_bf16s(s, ROWK, ROWK, EPI_BN_FWD, true, g, 1));
+      continue;
+    }
+    BLH_TRY(launch_gemm_bf16s(s, ROWK, ROWK, train ? EPI_BIAS_STATS : EPI_BIAS, true, g, 1));
     if (train) {
       float* sv = ws.bn_saved[i];
       if (ctx->sync.fn) {   // SyncBN: statistics over the global batch (fp64 sums exchanged by the host)
@@ -885,6 +908,8 @@ int blh_context_create(blh_context** out) {
     if ((e = hipEventCreateWithFlags(&c->ev_r[i], hipEventDisableTiming)) != hipSuccess) return fail(e);
   }
   // A/B switches for experiments (the documented way is blh_context_set_option)
+  if ((e = hipMalloc(reinterpret_cast<void**>(&c->grid_bar), 64)) != hipSuccess) return fail(e);
+  if ((e = hipMemset(c->grid_bar, 0, 64)) != hipSuccess) return fail(e);
   c->two_stream = getenv("BLH_ONE_STREAM") == nullptr;
   c->defer_slabs = getenv("BLH_DEFER_SLABS") != nullptr;
   c->late_fork = getenv("BLH_EARLY_FORK") ? 0 : (getenv("BLH_LATE_FORK") ? 1 : 2);
@@ -900,6 +925,7 @@ int blh_context_destroy(blh_context* c) {
     if (c->ev_r[i]) (void)hipEventDestroy(c->ev_r[i]);
   }
   if (c->s2) side_stream_release(c->device);
+  if (c->grid_bar) (void)hipFree(c->grid_bar);
   delete c;
   return BLH_OK;
 }
@@ -930,6 +956,13 @@ int blh_context_get_option(const blh_context* c, int32_t option) {
     case BLH_OPT_PERSISTENT_SHADOW: return c->persistent_shadow ? 1 : 0;
   }
   return BLH_ERR_INVALID_ARGUMENT;
+}
+
+int64_t blh_context_grid_barrier_timeouts(blh_context* c) {
+  if (!c || !c->grid_bar) return BLH_ERR_INVALID_ARGUMENT;
+  uint32_t words[3] = {0, 0, 0};
+  BLH_HIP_TRY(hipMemcpy(words, c->grid_bar, sizeof(words), hipMemcpyDeviceToHost));
+  return (int64_t)words[2];
 }
 
 void* blh_context_side_stream(blh_context* c) {

@@ -57,7 +57,9 @@ enum Epilogue : int {
   EPI_BN_RELU = 4,     // eval forward: C = relu(bn_eval(acc + bias[n])) (+ addend[m][n], the block skip)
   EPI_BN_BWD = 5,      // bf16-storage data gradient feeding a BatchNorm backward (gemm_bf16s_256.h): C = the gated
                        // gradient dY' = 2 keep [y > 0] acc, per-row-tile column sums of dY' z and dY'
-  EPI_BN_BWD_ADD = 6   // the same with acc + addend[m][n] (the block-skip gradient)
+  EPI_BN_BWD_ADD = 6,  // the same with acc + addend[m][n] (the block-skip gradient)
+  EPI_BN_FWD = 7       // bf16-storage forward stage in one launch (gemm_bf16s_bnfwd.h): Z = acc + bias, batch statistics
+                       // behind a grid barrier, A = 2 keep relu(bn(Z)) (+ skip), keep bits
 };
 
 struct GemmParams {

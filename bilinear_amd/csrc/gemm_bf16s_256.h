@@ -137,6 +137,81 @@ __device__ __forceinline__ void read_frags_256(bf16x8_t (&frag)[T][2], const bf1
   }
 }
 
+// per-tile column (mean, M2) over the tile's 128 NQM rows, from the fp32 accumulators (before rounding):
+// p.stat_part[tile_m][2][N].  Uses the first 4 KiB of smem; the caller separates it from other LDS use.
+template <int NQM>
+__device__ inline void tile_stats_256(f32x4 (&acc)[NQM][2][4][2], const GemmParamsH& p, float* smem, int m0, int n0,
+                                      int tile_m) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int g = lane >> 4, c16 = lane & 15;
+  // per-tile column (mean, M2) over the tile's 128 NQM rows, from the fp32 values (before rounding).
+  // Each wave row (half of the rows) forms its own (n, mean, M2) in registers + two shuffles; one
+  // LDS exchange merges the two with Chan's formula.
+  float* red = smem;                  // [2 wave rows][256 columns][mean, M2]
+  int nrow = 0;                       // valid rows of this wave row (wave-uniform)
+#pragma unroll
+  for (int qm = 0; qm < NQM; ++qm) nrow += max(0, min(64, p.M - (m0 + qm * 128 + wr * 64)));
+  const float inv_n = nrow > 0 ? 1.0f / (float)nrow : 0.f;
+#pragma unroll
+  for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int qm = 0; qm < NQM; ++qm)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = m0 + qm * 128 + wr * 64 + i * 16 + 4 * g + r;
+            if (row < p.M) s += acc[qm][qn][i][j][r];
+          }
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      const float mean = s * inv_n;
+      float q = 0.f;
+#pragma unroll
+      for (int qm = 0; qm < NQM; ++qm)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = m0 + qm * 128 + wr * 64 + i * 16 + 4 * g + r;
+            const float dlt = acc[qm][qn][i][j][r] - mean;
+            if (row < p.M) q += dlt * dlt;
+          }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      if (g == 0) {
+        const int lc = qn * 128 + wc * 32 + j * 16 + c16;
+        red[(wr * 256 + lc) * 2 + 0] = mean;
+        red[(wr * 256 + lc) * 2 + 1] = q;
+      }
+    }
+  lds_barrier();
+  if (wr == 0 && g == 0) {
+    const int n0r = nrow;             // this wave row's count; the other one's:
+    int n1r = 0;
+#pragma unroll
+    for (int qm = 0; qm < NQM; ++qm) n1r += max(0, min(64, p.M - (m0 + qm * 128 + 64)));
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int lc = qn * 128 + wc * 32 + j * 16 + c16;
+        const float ma = red[lc * 2], qa = red[lc * 2 + 1];
+        const float mb = red[(256 + lc) * 2], qb = red[(256 + lc) * 2 + 1];
+        const float na = (float)n0r, nb = (float)n1r, nt = na + nb;
+        const float d = mb - ma;
+        const float mean = ma + d * (nb / nt);
+        const float m2 = qa + qb + d * d * (na * nb / nt);
+        p.stat_part[((int64_t)tile_m * 2 + 0) * p.N + n0 + lc] = mean;
+        p.stat_part[((int64_t)tile_m * 2 + 1) * p.N + n0 + lc] = m2;
+      }
+  }
+}
+
 // ---- epilogue ------------------------------------------------------------------------------------
 // acc[qm][qn][i][j][reg]: row m0 + qm*128 + wr*64 + i*16 + 4*(lane>>4) + reg,
 //                         column n0 + qn*128 + wc*32 + j*16 + (lane & 15)
@@ -235,73 +310,7 @@ __device__ inline void gemm_epilogue_256(f32x4 (&acc)[NQM][2][4][2], const GemmP
     if (ps < NPS - 1 || EPI == EPI_BIAS_STATS) __syncthreads();
   }
 
-  if (EPI == EPI_BIAS_STATS) {
-    // per-tile column (mean, M2) over the tile's 128 NQM rows, from the fp32 values (before rounding).
-    // Each wave row (half of the rows) forms its own (n, mean, M2) in registers + two shuffles; one
-    // LDS exchange merges the two with Chan's formula.
-    float* red = smem;                  // [2 wave rows][256 columns][mean, M2]
-    int nrow = 0;                       // valid rows of this wave row (wave-uniform)
-#pragma unroll
-    for (int qm = 0; qm < NQM; ++qm) nrow += max(0, min(64, p.M - (m0 + qm * 128 + wr * 64)));
-    const float inv_n = nrow > 0 ? 1.0f / (float)nrow : 0.f;
-#pragma unroll
-    for (int qn = 0; qn < 2; ++qn)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float s = 0.f;
-#pragma unroll
-        for (int qm = 0; qm < NQM; ++qm)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int row = m0 + qm * 128 + wr * 64 + i * 16 + 4 * g + r;
-              if (row < p.M) s += acc[qm][qn][i][j][r];
-            }
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        const float mean = s * inv_n;
-        float q = 0.f;
-#pragma unroll
-        for (int qm = 0; qm < NQM; ++qm)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int row = m0 + qm * 128 + wr * 64 + i * 16 + 4 * g + r;
-              const float dlt = acc[qm][qn][i][j][r] - mean;
-              if (row < p.M) q += dlt * dlt;
-            }
-        q += __shfl_xor(q, 16);
-        q += __shfl_xor(q, 32);
-        if (g == 0) {
-          const int lc = qn * 128 + wc * 32 + j * 16 + c16;
-          red[(wr * 256 + lc) * 2 + 0] = mean;
-          red[(wr * 256 + lc) * 2 + 1] = q;
-        }
-      }
-    lds_barrier();
-    if (wr == 0 && g == 0) {
-      const int n0r = nrow;             // this wave row's count; the other one's:
-      int n1r = 0;
-#pragma unroll
-      for (int qm = 0; qm < NQM; ++qm) n1r += max(0, min(64, p.M - (m0 + qm * 128 + 64)));
-#pragma unroll
-      for (int qn = 0; qn < 2; ++qn)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int lc = qn * 128 + wc * 32 + j * 16 + c16;
-          const float ma = red[lc * 2], qa = red[lc * 2 + 1];
-          const float mb = red[(256 + lc) * 2], qb = red[(256 + lc) * 2 + 1];
-          const float na = (float)n0r, nb = (float)n1r, nt = na + nb;
-          const float d = mb - ma;
-          const float mean = ma + d * (nb / nt);
-          const float m2 = qa + qb + d * d * (na * nb / nt);
-          p.stat_part[((int64_t)tile_m * 2 + 0) * p.N + n0 + lc] = mean;
-          p.stat_part[((int64_t)tile_m * 2 + 1) * p.N + n0 + lc] = m2;
-        }
-    }
-  }
+  if (EPI == EPI_BIAS_STATS) tile_stats_256<NQM>(acc, p, smem, m0, n0, tile_m);
 }
 
 // ---- epilogue of a data gradient that feeds a BatchNorm backward -------------------------
@@ -566,6 +575,10 @@ __device__ inline void gemm_epilogue_256_bnbwd_packed(f32x4 (&acc)[NQM][2][4][2]
   }
 }
 
+}  // namespace blh
+#include "gemm_bf16s_bnfwd.h"
+namespace blh {
+
 // ---- kernel ----------------------------------------------------------------------------------------
 template <int LA, int LB, int EPI, bool OUT_BF16>
 __global__ __launch_bounds__(512, 2) void gemm_bf16s_256_kernel(GemmParamsH p) {
@@ -700,7 +713,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16s_256_kernel(GemmParamsH p) {
 #undef BLH_WAIT_LGKM
 #undef BLH_SB
   __syncthreads();
-  if constexpr (EPI == EPI_BN_BWD) gemm_epilogue_256_bnbwd_packed<2>(acc, p, C, smem, m0, n0, tile_m);
+  if constexpr (EPI == EPI_BN_FWD) gemm_epilogue_256_bnfwd<2>(acc, p, smem, m0, n0, tile_m, tile_n);
+  else if constexpr (EPI == EPI_BN_BWD) gemm_epilogue_256_bnbwd_packed<2>(acc, p, C, smem, m0, n0, tile_m);
   else if constexpr (EPI == EPI_BN_BWD_ADD) gemm_epilogue_256_bnbwd<2, true>(acc, p, C, smem, m0, n0, tile_m);
   else gemm_epilogue_256<EPI, OUT_BF16>(acc, p, C, smem, m0, n0, tile_m);
 }

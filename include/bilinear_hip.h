@@ -109,6 +109,14 @@ int blh_context_get_option(const blh_context* ctx, int32_t option);
 /* The side stream (hipStream_t as void*) the weight-gradient GEMMs run on; NULL when
  * BLH_OPT_TWO_STREAM is 0.  See blh_backward.                                            */
 void* blh_context_side_stream(blh_context* ctx);
+/* The fused forward stage of gemm_dtype 4 (Linear + BatchNorm + ReLU + Dropout in one launch, statistics merged
+ * behind a grid-wide barrier) needs every workgroup of its launch resident at once; the library only takes it
+ * when the grid has at most one workgroup per CU, and its barrier spin is bounded (0.3 s), so a launch that was
+ * denied the whole device (another training forward running beside it) ends with wrong results instead of
+ * hanging.  This returns how many workgroups ever gave up waiting on this context's barrier (0 = never;
+ * synchronous: one small device-to-host copy).  The fused stage is bit-identical to the three-launch form and
+ * measured slower (profiles/r04_fused_forward.md): it is opt-in, BLH_FWD_FUSE=1.                             */
+int64_t blh_context_grid_barrier_timeouts(blh_context* ctx);
 /* Replace the current device's process-wide side stream by a freshly created one; every context of
  * the device uses the new one from its next call on (the old one is drained and destroyed: call it
  * between steps, never under stream capture).  Why it exists: on this stack the two streams of the
