@@ -81,7 +81,11 @@ struct PlanH128 {
 // ABL (tools/bf16s_bench only): 1 no DMA in the loop, 2 no fragment reads, 3 no MFMAs (results are then wrong);
 // 4: correct results + 100 MHz real-time stamps of wave 0 {entry, loop start, loop end, stores issued, stores
 // drained} per workgroup into the buffer p.addend points to
-template <int LA, int LB, int EPI, bool OUT_BF16, int ABL = 0>
+// SYNC (experiment, tools/bf16s_bench): 0 = two barriers per phase, waves 4-7 one barrier behind (shipped);
+// 1 = ONE barrier per phase (in front of the MFMAs), no stagger — legal on the three-deep ring: a half-tile is
+// re-filled a whole K tile after its last read, and every wave has consumed those reads (its MFMAs waited for
+// them) before it arrives at the barrier the re-filling wave has passed
+template <int LA, int LB, int EPI, bool OUT_BF16, int ABL = 0, int SYNC = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16s_128x256_kernel(GemmParamsH p) {
   constexpr int BM = 128, BN = 256;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16s_128x256_kernel(GemmParamsH 
   BLH_STAGE_1((uint32_t)H128_BUF_BYTES) BLH_STAGE_2((uint32_t)H128_BUF_BYTES)
   BLH_WAIT_VM(6);
   BLH_BAR();
-  if (wr == 1) BLH_BAR();                        // waves 4-7 run one barrier behind waves 0-3
+  if (SYNC == 0 && wr == 1) BLH_BAR();           // waves 4-7 run one barrier behind waves 0-3
   if (ABL == 4) stamp[1] = __builtin_amdgcn_s_memrealtime();
 
   // K tile in the buffer at byte offset BOFF; STG: request tile + 2 into the buffer at ROFF
@@ -166,12 +170,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16s_128x256_kernel(GemmParamsH 
   /* phase 1: quadrant 0 */                                                                       \
   BLH_LOAD_B(0, BOFF); BLH_SB(); BLH_LOAD_A(BOFF); BLH_SB();                                      \
   if (STG) { BLH_STAGE_1(ROFF) }                                                                  \
-  BLH_BAR(); BLH_MFMA(0) BLH_BAR();                                                               \
+  BLH_BAR(); BLH_MFMA(0) if (SYNC == 0) BLH_BAR();                                                \
   /* phase 2: quadrant 1 */                                                                       \
   BLH_LOAD_B(1, BOFF); BLH_SB();                                                                  \
   if (STG) { BLH_STAGE_2(ROFF) }                                                                  \
   WAIT;                                                                                           \
-  BLH_BAR(); BLH_MFMA(1) BLH_BAR();
+  BLH_BAR(); BLH_MFMA(1) if (SYNC == 0) BLH_BAR();
 
   uint32_t boff = 0, roff = 2u * H128_BUF_BYTES;  // buffer of the current tile / of tile + 2
   if (ABL == 2) {   // (fragments that no read defines)
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16s_128x256_kernel(GemmParamsH 
   BLH_KTILE(boff, false, 0u, BLH_WAIT_VM(0))
   boff = (boff == 2u * H128_BUF_BYTES) ? 0u : boff + (uint32_t)H128_BUF_BYTES;
   BLH_KTILE(boff, false, 0u, (void)0)
-  if (wr == 0) BLH_BAR();                        // the barrier waves 4-7 took at the start
+  if (SYNC == 0 && wr == 0) BLH_BAR();           // the barrier waves 4-7 took at the start
 
 #undef BLH_KTILE
 #undef BLH_STAGE_1

@@ -52,9 +52,9 @@ float run256(const GemmParamsH& p, int splits, int reps) {
   return ms / reps;
 }
 
-template <int LA, int LB, int EPI, bool OB, int ABL = 0>
+template <int LA, int LB, int EPI, bool OB, int ABL = 0, int SYNC = 0>
 float run128x256(const GemmParamsH& p, int splits, int reps) {
-  auto kern = gemm_bf16s_128x256_kernel<LA, LB, EPI, OB, ABL>;
+  auto kern = gemm_bf16s_128x256_kernel<LA, LB, EPI, OB, ABL, SYNC>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)H128_LDS_BYTES));
   const int tiles = (int)(ceil_div(p.M, 128) * (p.N / 256));
   hipEvent_t e0, e1;
@@ -127,6 +127,20 @@ int main(int argc, char** argv) {
       float b = run256<ROWK, ROWK, EPI_BIAS_STATS, true>(fk, 1, reps);
       float c = run<ROWK, ROWK, EPI_BIAS_STATS, true, 64, 2>(fk, 1, reps);
       printf("K %5d (%3d K tiles)  128x256 %6.1f us | 256x256 %6.1f us | 128x128 %6.1f us\n", K, K / 64, a * 1e3, b * 1e3, c * 1e3);
+    }
+    return 0;
+  }
+  if (getenv("SYNCAB")) {   // barrier structure of the 128 x 256 kernel: shipped (0) against one barrier per phase (1)
+    std::vector<uint16_t> c0((size_t)M * W), c1((size_t)M * W);
+    for (int round = 0; round < 3; ++round) {
+      float a0 = run128x256<ROWK, ROWK, EPI_BIAS_STATS, true, 0, 0>(f, 1, reps);
+      CK(hipMemcpy(c0.data(), C, c0.size() * 2, hipMemcpyDeviceToHost));
+      float a1 = run128x256<ROWK, ROWK, EPI_BIAS_STATS, true, 0, 1>(f, 1, reps);
+      CK(hipMemcpy(c1.data(), C, c1.size() * 2, hipMemcpyDeviceToHost));
+      float d0 = run128x256<ROWK, KROW, EPI_STORE, true, 0, 0>(d, 1, reps);
+      float d1 = run128x256<ROWK, KROW, EPI_STORE, true, 0, 1>(d, 1, reps);
+      printf("128x256 fwd: two barriers + stagger %6.1f us | one barrier %6.1f us (outputs %s) || dgrad %6.1f | %6.1f us\n",
+             a0 * 1e3, a1 * 1e3, memcmp(c0.data(), c1.data(), c0.size() * 2) ? "DIFFER" : "identical", d0 * 1e3, d1 * 1e3);
     }
     return 0;
   }

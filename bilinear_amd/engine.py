@@ -295,6 +295,32 @@ class Engine:
             self.rng_step += 1
         return pred
 
+    def forward_train_autograd(self, x):
+        """Train-mode forward as the DIFFERENTIABLE custom operator ``torch.ops.bilinear_hip.lifter_train``
+        (torch.library.register_autograd, bilinear_amd/ops.py): ``loss.backward()`` of
+        /root/reference/train_bilinear.py:79 reaches blh_backward through the operator's registered backward,
+        and each Parameter's ``.grad`` becomes a view of its slot in the gradient arena."""
+        x = self._check_input(x)
+        self.ensure(x.device)
+        batch = x.shape[0]
+        if batch < 2:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s"
+                             % (tuple(x.shape),))
+        ws = self.workspace(batch)
+        drop = self._drop_struct(batch)
+        named = self._named_params()
+        _ops.ENGINES[int(self.ctx.handle.value)] = self
+        pred = torch.ops.bilinear_hip.lifter_train(
+            x, [p for _, p, _, _ in named], self.params, self.bn_running, self.bn_nbt, ws, self.grads, self.masks,
+            *self._op_args(), self.seed, self.rng_step, self.row_offset, self._momentum(),
+            [int(off) for _, _, off, _ in named])
+        self._saved_batch = batch
+        self._saved_drop = drop
+        self.generation += 1
+        if self.masks is None:
+            self.rng_step += 1
+        return pred
+
     def forward_train_loss(self, x, target, sync=None, global_batch=None):
         """Train-mode forward + nn.MSELoss (train_bilinear.py:76,78) in one enqueue, as the fused
         step runs them: returns (pred, loss); the loss gradient stays in the workspace and the

@@ -213,6 +213,11 @@ class BilinearUnit(nn.Module):
             return eng.forward_eval(in_tensor)
         if torch.is_grad_enabled():
             params = [p for _, p, _, _ in eng._named_params()]
+            # the differentiable custom operator (torch.library.register_autograd) — unless gradients are being
+            # accumulated into existing .grad tensors or a data-parallel bucket hook wants the ranges as they
+            # complete: those need Python between the kernels (_LifterFunction)
+            if eng.grad_ready_hook is None and all(p.grad is None for p in params):
+                return eng.forward_train_autograd(in_tensor)
             return _LifterFunction.apply(in_tensor, eng, *params)
         return eng.forward_train(in_tensor)
 

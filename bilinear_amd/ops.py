@@ -36,6 +36,18 @@ _LIB.define(
     "forward_train(Tensor x, Tensor params, Tensor(a!) bn_running, Tensor(b!) bn_nbt, "
     "Tensor(c!) workspace, Tensor? masks, int ctx, int num_blocks, int width, int gemm_dtype, "
     "int seed, int step, int row_offset, float momentum) -> Tensor")
+# The differentiable form of forward_train (torch.library.register_autograd below): ``param_views`` are the
+# module's nn.Parameters — views of ``params`` (the arena) at ``offsets`` — and exist in the schema only so that
+# autograd connects them to the output; the kernels read the arena.  Its backward is the ``backward`` operator.
+# torch.library registers autograd formulas for FUNCTIONAL schemas only, so the buffers the native call writes as
+# a side effect (BatchNorm running statistics and counter, the workspace with the saved activations, and — in
+# backward — the gradient arena) are declared as plain inputs here: nothing else in a traced graph reads them, the
+# returned prediction is a fresh tensor, and the mutable twin ``forward_train`` stays for callers that want the
+# aliasing spelled out.
+_LIB.define(
+    "lifter_train(Tensor x, Tensor[] param_views, Tensor params, Tensor bn_running, Tensor bn_nbt, "
+    "Tensor workspace, Tensor grads, Tensor? masks, int ctx, int num_blocks, int width, int gemm_dtype, "
+    "int seed, int step, int row_offset, float momentum, int[] offsets) -> Tensor")
 _LIB.define(
     "backward(Tensor x, Tensor dpred, Tensor params, Tensor(a!) workspace, Tensor(b!) grads, "
     "Tensor? masks, int ctx, int num_blocks, int width, int gemm_dtype, int seed, int step, "
@@ -85,6 +97,12 @@ def _forward_train(x, params, bn_running, bn_nbt, workspace, masks, ctx, num_blo
     return pred
 
 
+def _lifter_train(x, param_views, params, bn_running, bn_nbt, workspace, grads, masks, ctx, num_blocks, width,
+                  gemm_dtype, seed, step, row_offset, momentum, offsets):
+    return _forward_train(x, params, bn_running, bn_nbt, workspace, masks, ctx, num_blocks, width, gemm_dtype,
+                          seed, step, row_offset, momentum)
+
+
 def _backward(x, dpred, params, workspace, grads, masks, ctx, num_blocks, width, gemm_dtype, seed,
               step, row_offset):
     batch = x.shape[0]
@@ -116,6 +134,7 @@ def _train_step(x, target, params, grads, exp_avg, exp_avg_sq, bn_running, bn_nb
 # HIP device only ("CUDA" is PyTorch-ROCm's dispatch key for HIP tensors): no CPU kernels exist
 _LIB.impl("eval_fwd", _eval_fwd, "CUDA")
 _LIB.impl("forward_train", _forward_train, "CUDA")
+_LIB.impl("lifter_train", _lifter_train, "CUDA")
 _LIB.impl("backward", _backward, "CUDA")
 _LIB.impl("train_step", _train_step, "CUDA")
 
@@ -131,7 +150,43 @@ def _fake_step(x, *args, **kwargs):
 # shape functions (FakeTensor / torch.compile tracing; no arithmetic)
 torch.library.register_fake("bilinear_hip::eval_fwd", _fake_pred, lib=_LIB)
 torch.library.register_fake("bilinear_hip::forward_train", _fake_pred, lib=_LIB)
+torch.library.register_fake("bilinear_hip::lifter_train", _fake_pred, lib=_LIB)
 torch.library.register_fake("bilinear_hip::backward", lambda *a, **k: None, lib=_LIB)
 torch.library.register_fake("bilinear_hip::train_step", _fake_step, lib=_LIB)
 
-OPS = ("eval_fwd", "forward_train", "backward", "train_step")
+
+
+# ---- autograd of lifter_train: loss.backward() of /root/reference/train_bilinear.py:79 -----------------------
+# engines by context handle (eager mode: the engine's own bookkeeping — the saved-activation guard, the tuned
+# stream pair — stays in charge; under torch.compile the traced backward calls the raw operator)
+import weakref  # noqa: E402
+
+ENGINES = weakref.WeakValueDictionary()
+
+
+def _lifter_setup(ctx, inputs, output):
+    (x, param_views, params, bn_running, bn_nbt, workspace, grads, masks, c, nb, w, dt, seed, step, row_offset,
+     momentum, offsets) = inputs
+    ctx.save_for_backward(x, params, workspace, grads, masks)
+    ctx.ints = (c, nb, w, dt, seed, step, row_offset)
+    ctx.slots = [(int(o), tuple(p.shape), p.numel()) for o, p in zip(offsets, param_views)]
+    eng = ENGINES.get(int(c))
+    # (eager: the forward wrapper bumps engine.generation right after this call returns)
+    ctx.generation = None if eng is None else eng.generation + 1
+
+
+def _lifter_backward(ctx, dpred):
+    x, params, workspace, grads, masks = ctx.saved_tensors
+    c = ctx.ints[0]
+    eng = ENGINES.get(int(c))
+    if eng is not None and type(dpred) is torch.Tensor:          # eager
+        eng.backward(x, dpred, on_ready=None, generation=ctx.generation)
+    else:                                                        # traced (AOTAutograd): the operator itself
+        torch.ops.bilinear_hip.backward(x, dpred.contiguous(), params, workspace, grads, masks, *ctx.ints)
+    views = [grads[o:o + n].view(shape) for o, shape, n in ctx.slots]
+    return (None, views) + (None,) * 15
+
+
+torch.library.register_autograd("bilinear_hip::lifter_train", _lifter_backward, setup_context=_lifter_setup, lib=_LIB)
+
+OPS = ("eval_fwd", "forward_train", "lifter_train", "backward", "train_step")

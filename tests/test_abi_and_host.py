@@ -180,6 +180,14 @@ def test_custom_ops_trace_through_their_fake_implementations():
         pred = torch.ops.bilinear_hip.forward_train(x, params, running, nbt, ws, None, 0, 2, W, 0, 1, 0, 0, 0.1)
         assert tuple(pred.shape) == (B, 48)
         assert torch.ops.bilinear_hip.backward(x, pred, params, ws, grads, None, 0, 2, W, 0, 1, 0, 0) is None
+        # the differentiable operator: the parameter views carry requires_grad, and a traced backward (what
+        # AOTAutograd records) reaches the gradient arena through the registered formula
+        views = [params[:W * 32].view(W, 32).detach().requires_grad_(), params[W * 32:W * 33].detach().requires_grad_()]
+        pred = torch.ops.bilinear_hip.lifter_train(x, views, params, running, nbt, ws, grads, None, 0, 2, W, 0, 1, 0, 0,
+                                                   0.1, [0, W * 32])
+        assert tuple(pred.shape) == (B, 48) and pred.requires_grad
+        gv = torch.autograd.grad(pred.sum(), views)
+        assert [tuple(g.shape) for g in gv] == [(W, 32), (W,)]
         pred, loss = torch.ops.bilinear_hip.train_step(x, t, params, grads, m, v, running, nbt, ws, stats, None,
                                                        0, 2, W, 0, 1, 0, 0, 0.1, 1e-3, 0.9, 0.999, 1e-8, 1.0, 1)
         assert tuple(pred.shape) == (B, 48) and tuple(loss.shape) == ()

@@ -1007,6 +1007,82 @@ def test_train_step_operator_under_torch_compile_fullgraph():
         assert torch.equal(a, b)
 
 
+def test_drop_in_step_through_the_differentiable_operator():
+    """The five-call step of /root/reference/train_bilinear.py:75-83 (zero_grad, forward, MSELoss, backward,
+    clip_grad_norm_, Adam.step) with ``loss.backward()`` going through ``torch.ops.bilinear_hip.lifter_train``'s
+    registered autograd formula (torch.library.register_autograd): bit-identical to the autograd.Function bridge
+    it replaces, .grad tensors are views of the gradient arena, a second forward before backward still raises;
+    and the same forward + loss compiled with torch.compile(fullgraph=True) (AOTAutograd traces the formula
+    down to the ``backward`` operator) gives the same gradients."""
+    import bilinear_amd
+    from bilinear_amd.model.bilinear import _LifterFunction
+    dev = _dev()
+    x = torch.randn(512, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    t = torch.randn(512, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+
+    def make():
+        torch.manual_seed(3)
+        net, opt, _, _ = bilinear_amd.load(dev, num_blocks=1, width=256)
+        net.train()
+        net.engine.ensure(dev)
+        net.engine.seed = 11
+        return net, opt
+
+    outs = {}
+    for path in ("operator", "function"):
+        net, opt = make()
+        eng = net.engine
+        for _ in range(2):
+            opt.zero_grad()
+            if path == "operator":
+                pred = net(x)                      # BilinearUnit.forward -> lifter_train
+                assert type(pred.grad_fn).__name__ != "_LifterFunctionBackward"
+            else:
+                pred = _LifterFunction.apply(x, eng, *[p for _, p, _, _ in eng._named_params()])
+            loss = torch.nn.functional.mse_loss(pred, t)
+            loss.backward()
+            for _, p, off, shape in eng._named_params():
+                assert p.grad is not None and p.grad.data_ptr() == eng.grad_view(off, shape).data_ptr()
+            bilinear_amd.clip_grad_norm_(net.parameters(), 1.0, module=net)
+            opt.step()
+        torch.cuda.synchronize()
+        outs[path] = (pred.detach().clone(), eng.grads.clone(), eng.params.clone())
+    for a, b in zip(outs["operator"], outs["function"]):
+        assert torch.equal(a, b)
+    # the saved-activation guard survives the move
+    net, opt = make()
+    p1 = net(x)
+    net(x)
+    with pytest.raises(RuntimeError, match="overwritten"):
+        p1.sum().backward()
+    # torch.compile(fullgraph=True): forward + loss traced through the operator, backward through its formula
+    net, opt = make()
+    eng = net.engine
+    named = eng._named_params()
+    views = [p for _, p, _, _ in named]
+    offs = [int(off) for _, _, off, _ in named]
+    ws = eng.workspace(512)
+    args = eng._op_args() + (eng.seed, 0, 0, 0.1)
+
+    def fwd_loss(x, t, views, arena, running, nbt, ws, grads):
+        pred = torch.ops.bilinear_hip.lifter_train(x, views, arena, running, nbt, ws, grads, None, *args, offs)
+        return torch.nn.functional.mse_loss(pred, t)
+
+    compiled = torch.compile(fwd_loss, fullgraph=True, backend="aot_eager")
+    loss_c = compiled(x, t, views, eng.params, eng.bn_running, eng.bn_nbt, ws, eng.grads)
+    eng._saved_batch, eng._saved_drop = 512, eng._drop_struct(512)        # (what Engine.forward_train_autograd records)
+    eng.generation += 1
+    loss_c.backward()
+    torch.cuda.synchronize()
+    g_compiled = eng.grads.clone()
+    net2, _ = make()
+    opt2_pred = net2(x)
+    torch.nn.functional.mse_loss(opt2_pred, t).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(g_compiled, net2.engine.grads)
+    assert abs(float(loss_c) - float(torch.nn.functional.mse_loss(opt2_pred, t))) == 0.0
+
+
 def test_contexts_of_one_device_share_the_side_stream_and_outlive_each_other():
     """blh_context_create: the side stream is one lowest-priority stream per device and process,
     reference-counted (include/bilinear_hip.h, "Context"); destroying one context must leave the
