@@ -491,11 +491,16 @@ def self_launch(n):
     raise SystemExit(proc.wait())
 
 
-def pre_ramp(one_step, min_ms):
+def pre_ramp(one_step, min_ms, agree=None):
     """Un-timed steps until at least ``min_ms`` of wall time have passed with the GPU busy: the
     first ~50 ms after an idle period run at a lower DVFS state (10-15 % slow), and a driver run of
     20 steps after 5 warm-up steps (27 ms of GPU work) would otherwise be timed inside the ramp.
-    The driver's --warmup steps still follow; nothing is removed from the timed region."""
+    The driver's --warmup steps still follow; nothing is removed from the timed region.
+
+    ``agree`` (N > 1): maps this rank's elapsed time to one value every rank sees (the maximum over
+    ranks).  Every step holds collectives, so all ranks MUST leave the loop after the same number
+    of steps; each rank deciding on its own clock would let one rank run ten steps more than its
+    peers and wait in an all-reduce nobody answers."""
     if min_ms <= 0:
         return 0.0, 0
     torch.cuda.synchronize()
@@ -507,6 +512,8 @@ def pre_ramp(one_step, min_ms):
         n += 10
         torch.cuda.synchronize()
         el = 1e3 * (time.perf_counter() - t0)
+        if agree is not None:
+            el = agree(el)
         if el >= min_ms:
             return el, n
 
@@ -712,7 +719,11 @@ def main():
         dp.stream.wait_stream(torch.cuda.current_stream(dev))
         torch.cuda.set_stream(dp.stream)
     log("model built, pre-ramp + warm-up")
-    ramp_ms, ramp_steps = pre_ramp(one_step, args.pre_ramp_ms)
+    def slowest_rank(ms):
+        v = torch.tensor([ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return float(v.item())
+    ramp_ms, ramp_steps = pre_ramp(one_step, args.pre_ramp_ms, slowest_rank if multi else None)
     for _ in range(args.warmup):
         one_step()
     if multi:

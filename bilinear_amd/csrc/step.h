@@ -1,0 +1,88 @@
+// Internal interface between the C ABI (api.hip) and the two step implementations: step_f32.hip (fp32
+// storage: gemm_dtype 0, 2, 3) and step_bf16s.hip (bf16 storage: gemm_dtype 4).  Not installed.
+#pragma once
+#include <cstdlib>
+#include <vector>
+
+#include "common.h"
+#include "gemm_bf16s_kernel.h"
+#include "api_layout.h"
+
+namespace blh {
+// SyncBN plumbing of the current call (data parallel): statistics over `global_batch` rows,
+// exchanged by the host callback
+struct SyncCtx { blh_sync_fn fn; void* user; int64_t global_batch; };
+}  // namespace blh
+
+// Caller-owned context (include/bilinear_hip.h): the side stream of the two-stream backward with
+// its fork / join events, the option flags, and the per-call plumbing (SyncBN callback, device
+// address of the captured step's dropout counter).  Bound to one device; one call at a time.
+static constexpr int BLH_CTX_EVENTS = 34;      // 1 + 2*num_blocks <= 32 stages, + decode, + spare
+struct blh_context {
+  int device = -1;
+  hipStream_t s2 = nullptr;
+  hipEvent_t ev_dz[BLH_CTX_EVENTS], ev_w[BLH_CTX_EVENTS], ev_r[BLH_CTX_EVENTS];
+  bool two_stream = true;
+  bool defer_slabs = false;
+  int late_fork = 2;        // BLH_OPT_LATE_FORK: 0 early, 1 late, 2 auto
+  // per-call state (set by the entry point for the duration of the call)
+  blh::SyncCtx sync = {nullptr, nullptr, 0};
+  const uint64_t* step_dev = nullptr;
+  // left by blh_forward_train_loss for blh_backward(dpred == NULL): rows of that forward and the
+  // number of decode-bias / loss partial rows its decode kernel wrote (0: none)
+  int64_t loss_batch = 0;
+  int loss_nparts = 0;
+  // BLH_OPT_PERSISTENT_SHADOW: the (params, workspace) whose bf16 parameter image the last fused
+  // step's Adam kernel left up to date (nullptr: none)
+  bool persistent_shadow = false;
+  const void* shadow_params = nullptr;
+  const void* shadow_ws = nullptr;
+  // grid barrier of the fused forward stage (gemm_bf16s_bnfwd.h): arrivals, generation, timeouts; device memory
+  // owned by the context, zeroed once here
+  uint32_t* grid_bar = nullptr;
+};
+
+namespace blh {
+
+static inline DropoutSrc layer_drop(const blh_context* ctx, const blh_dropout* drop, int layer,
+                             int64_t batch, int W) {
+  DropoutSrc d;
+  d.step_dev = ctx->step_dev;
+  d.keep = drop->keep_mask ? drop->keep_mask + (int64_t)layer * batch * W : nullptr;
+  d.seed = drop->seed; d.step = drop->step; d.row_offset = drop->row_offset;
+  d.layer = drop->layer_base + layer;
+  return d;
+}
+
+// fused: the caller is the whole-step path: the decode-bias partials come from the fused decode kernel
+// (dec_bias_S rows) and the sum-of-squares partials of the arena are returned for clip + Adam;
+// sumsq_src[0]: where the partials really are when backward_impl returns (sumsq_part, or the producers' array)
+struct FusedBackward { int dec_bias_S; double* sumsq_part; int* sumsq_nparts; double** sumsq_src; };
+
+// ---- step_f32.hip
+int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
+                 float* bn_running, int64_t* nbt, const float* x, const blh_dropout* drop,
+                 float momentum, const Workspace& ws, float* pred, int64_t batch,
+                 bool train, const float* target, float mse_scale, float* loss_part,
+                 int* loss_nparts);
+int wgrad(int dtype, hipStream_t s, GemmTile tile, const float* dZ, int64_t ld_dz, int M,
+          const float* act, int64_t ld_act, int N, int64_t batch, int64_t tiles,
+          float* slabs, float* out, GradRegion* region, const float* amax_dz = nullptr,
+          const float* amax_act = nullptr, int amax_parts = 0, double* sq = nullptr, int sq_blocks = 0);
+int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
+                  const float* x, const blh_dropout* drop, const Workspace& ws,
+                  const float* dpred, float* grads, int64_t batch,
+                  blh_grad_ready_fn on_ready, void* user,
+                  const FusedBackward* fused = nullptr);
+// ---- step_bf16s.hip
+int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
+              float* bn_running, int64_t* nbt, const float* x, const blh_dropout* drop,
+              float momentum, const WorkspaceH& ws, float* pred, int64_t batch, bool train,
+              bool shadow_valid = false, const float* target = nullptr, float mse_scale = 0.f,
+              int* loss_nparts = nullptr);
+int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
+               const blh_dropout* drop, const WorkspaceH& ws, const float* dpred,
+               float* grads, int64_t batch, blh_grad_ready_fn on_ready, void* user,
+               int dec_bias_S = 0);
+
+}  // namespace blh

@@ -1,0 +1,354 @@
+// The bf16-storage step (gemm_dtype 4, BASELINE configs 3-5): forward and backward DAG.  Pure enqueue code.
+#include "step.h"
+
+namespace blh {
+
+// =================================================================================================
+// gemm_dtype 4 — "bf16s": bf16 storage (BASELINE configs 3-5).  Every [B,W] tensor (pre-BN output
+// Z, activation A, gradients G / dZ), the network input and a shadow of all parameters are bf16
+// in HBM; every contraction runs on gemm_bf16s_kernel.h (bf16 MFMA, fp32 accumulate, operands fed
+// by LDS-DMA without any conversion); BatchNorm statistics (from the fp32 accumulators, before
+// rounding), the parameters, their gradients (fp32 slabs of the weight-gradient GEMM), Adam and
+// the loss stay fp32.  Gradients need no loss scaling: bf16 keeps fp32's exponent range.
+// =================================================================================================
+int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
+                     float* bn_running, int64_t* nbt, const float* x, const blh_dropout* drop,
+                     float momentum, const WorkspaceH& ws, float* pred, int64_t batch, bool train,
+              bool shadow_valid, const float* target, float mse_scale, int* loss_nparts) {
+  const ArenaLayout L = make_layout(d);
+  const int nh = (int)L.heavy.size();
+  const int W = d->width, OF = d->out_features, IF = d->in_features;
+  // bf16 images of the parameters (the GEMMs read the weights from it) and of the input
+  // (shadow_valid: the previous fused step's Adam kernel wrote it, BLH_OPT_PERSISTENT_SHADOW)
+  ctx->shadow_params = ctx->shadow_ws = nullptr;
+  if (!shadow_valid) BLH_TRY(launch_cast_f32_bf16(s, params, ws.wsh, L.total));
+  BLH_TRY(launch_cast_f32_bf16(s, x, ws.xh, batch * IF));
+  for (int i = 0; i < nh; ++i) {
+    const HeavyOffsets& h = L.heavy[i];
+    GemmParamsH g{};
+    g.A = (i == 0) ? ws.xh : ws.A[i - 1]; g.lda = h.fan_in;
+    g.B = ws.wsh + h.w; g.ldb = h.fan_in;
+    g.C = ws.Z[i]; g.ldc = W;
+    g.M = (int)batch; g.N = W; g.K = h.fan_in; g.k_per_split = h.fan_in;
+    g.bias = params + h.b; g.stat_part = ws.stat_part;
+    // (BatchNorm partials: one (mean, M2) pair per row tile of the kernel that ran, 128 or 256 rows)
+    const int tile = gemm_bf16s_pick_tile(ROWK, ROWK, true, g, 1);
+    const int st_rows = gemm_bf16s_tile_rows(tile);
+    const int st_tiles = (int)ceil_div(batch, st_rows);
+    const uint16_t* skip = (i >= 2 && (i % 2) == 0) ? ws.A[i - 2] : nullptr;
+    float* rm = bn_running + ((int64_t)i * 2 + 0) * W;
+    float* rv = bn_running + ((int64_t)i * 2 + 1) * W;
+    // The whole stage in ONE launch (gemm_bf16s_bnfwd.h: statistics merged behind a grid barrier, BatchNorm +
+    // ReLU + dropout + skip applied to the tile the workgroup still holds): big-tile kernels whose grid fits the
+    // chip one workgroup per CU (configs[2]: 256 tiles of 256 x 256; configs[3] per GPU: 256 of 128 x 256), per-rank
+    // statistics.  Bit-identical to the three-launch form and MEASURED SLOWER (configs[2] 1.59 against 1.47 ms,
+    // configs[3] per-GPU shape 1.10 against 0.95: profiles/r04_fused_forward.md), so it is opt-in: BLH_FWD_FUSE=1.
+    if (train && !ctx->sync.fn && tile != H_TILE_128 && ctx->grid_bar && getenv("BLH_FWD_FUSE") &&
+        (int64_t)st_tiles * (W / 256) <= gemm_bf16s_fused_forward_max_wgs() && st_tiles <= 128) {
+      g.fwd.gamma = params + h.gamma; g.fwd.beta = params + h.beta;
+      g.fwd.running_mean = rm; g.fwd.running_var = rv; g.fwd.nbt = nbt + i; g.fwd.momentum = momentum;
+      g.fwd.saved = ws.bn_saved[i];
+      g.fwd.skip = skip; g.fwd.ldskip = W;
+      g.fwd.A = ws.A[i]; g.fwd.lda_out = W;
+      g.fwd.keepbits = ws.keep[i];
+      g.fwd.drop = layer_drop(ctx, drop, i, batch, W);
+      g.fwd.bar = ctx->grid_bar;
+      g.fwd.tile_rows = st_rows;
+      BLH_TRY(launch_gemm_bf16s(s, ROWK, ROWK, EPI_BN_FWD, true, g, 1));
+      continue;
+    }
+    BLH_TRY(launch_gemm_bf16s(s, ROWK, ROWK, train ? EPI_BIAS_STATS : EPI_BIAS, true, g, 1));
+    if (train) {
+      float* sv = ws.bn_saved[i];
+      if (ctx->sync.fn) {   // SyncBN: statistics over the global batch (fp64 sums exchanged by the host)
+        BLH_TRY(launch_bn_fwd_local_sums(s, ws.stat_part, st_tiles, st_rows, batch, W, ws.sync_buf));
+        ctx->sync.fn(ctx->sync.user, ws.sync_buf, 2 * (int64_t)W, 1);
+        BLH_TRY(launch_bn_fwd_finalize_sums(s, ws.sync_buf, ctx->sync.global_batch, W, params + h.gamma,
+                                            params + h.beta, rm, rv, nbt + i, momentum, sv, sv + W,
+                                            sv + 2 * W, sv + 3 * W));
+      } else {
+        BLH_TRY(launch_bn_fwd_finalize(s, ws.stat_part, st_tiles, st_rows, batch, W, params + h.gamma,
+                                       params + h.beta, rm, rv, nbt + i, momentum, sv, sv + W,
+                                       sv + 2 * W, sv + 3 * W));
+      }
+      BLH_TRY(launch_bn_apply_h2(s, true, ws.Z[i], sv + 2 * W, sv + 3 * W, nullptr, nullptr, nullptr,
+                                 nullptr, skip, ws.A[i], ws.keep[i], batch, W,
+                                 layer_drop(ctx, drop, i, batch, W), nbt + i));
+    } else {
+      DropoutSrc none{nullptr, 0, 0, 0, 0, nullptr};
+      BLH_TRY(launch_bn_apply_h2(s, false, ws.Z[i], nullptr, nullptr, params + h.gamma, params + h.beta,
+                                 rm, rv, skip, ws.A[i], nullptr, batch, W, none, nullptr));
+    }
+  }
+  // decode (model/bilinear.py:39) fused with nn.MSELoss (train_bilinear.py:78) when a target is given:
+  // skinny.hip's purpose-built kernel reads A once and writes pred, dpred (fp32 and bf16), the loss
+  // partials and the decode-bias partials; *loss_nparts = their row count (0: the generic path ran)
+  if (loss_nparts) *loss_nparts = 0;
+  if (decode_fwd_supported(batch, W, OF)) {
+    int np = 0;
+    BLH_TRY(launch_decode_fwd_mse_h(s, ws.A[nh - 1], ws.wsh + L.dec_w, params + L.dec_b, target, pred,
+                                    target ? ws.dpred : nullptr, target ? ws.dpredh : nullptr,
+                                    target ? ws.loss_part : nullptr, target ? ws.dec_bias_part : nullptr,
+                                    batch, W, OF, mse_scale, &np));
+    if (loss_nparts && target) *loss_nparts = np;
+    return BLH_OK;
+  }
+  GemmParamsH g{};   // (shapes the skinny kernel does not take: N = 48 as one ragged column tile)
+  g.A = ws.A[nh - 1]; g.lda = W;
+  g.B = ws.wsh + L.dec_w; g.ldb = W;
+  g.C = pred; g.ldc = OF;
+  g.M = (int)batch; g.N = OF; g.K = W; g.k_per_split = W;
+  g.bias = params + L.dec_b;
+  return launch_gemm_bf16s(s, ROWK, ROWK, EPI_BIAS, false, g, 1);
+}
+
+// dW = dZ^T act (both bf16, reduction over the batch split into fp32 slabs), summed into `out`
+static int wgrad_h(hipStream_t s, const uint16_t* dZ, int64_t ld_dz, int M, const uint16_t* act,
+                   int64_t ld_act, int N, int64_t batch, float* slabs, float* out) {
+  const Splits sp = wgrad_plan_h(M, N, batch);
+  GemmParamsH g{};
+  g.A = dZ; g.lda = ld_dz; g.B = act; g.ldb = ld_act;
+  g.M = M; g.N = N; g.K = (int)batch; g.k_per_split = sp.k_per; g.ldc = N;
+  if (sp.splits == 1) {
+    g.C = out;
+    return launch_gemm_bf16s(s, KROW, KROW, EPI_STORE, false, g, 1);
+  }
+  g.C = slabs; g.c_split_stride = (int64_t)M * N;
+  BLH_TRY(launch_gemm_bf16s(s, KROW, KROW, EPI_STORE, false, g, sp.splits));
+  return launch_sum_slabs(s, slabs, (int64_t)M * N, sp.splits, out);
+}
+
+// dec_bias_S > 0: the forward ran the fused decode + MSE kernel: ws.dpredh and the decode-bias
+// partials (dec_bias_S rows of ws.dec_bias_part) are already there
+int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
+                      const blh_dropout* drop, const WorkspaceH& ws, const float* dpred,
+                      float* grads, int64_t batch, blh_grad_ready_fn on_ready, void* user,
+                      int dec_bias_S) {
+  const ArenaLayout L = make_layout(d);
+  const int nh = (int)L.heavy.size();
+  const int W = d->width, OF = d->out_features, IF = d->in_features;
+  const int chunks = ew_num_row_chunks_h(batch);
+  // BLH_OPT_LATE_FORK auto, as in backward_impl: early when the data-gradient launch is one round of
+  // workgroups (256 of the 256x256 kernel, 512 of the 128x128 one; configs[2], configs[3] per GPU),
+  // late when it is several (configs[4]: 7.78 against 7.91 ms)
+  bool late_policy = ctx->late_fork != 0;
+  if (ctx->late_fork == 2) {
+    GemmParamsH gp{};
+    gp.M = (int)batch; gp.N = W; gp.K = W; gp.k_per_split = W; gp.lda = gp.ldb = gp.ldc = W;
+    const int tile = gemm_bf16s_pick_tile(ROWK, KROW, true, gp, 1);
+    // (the big-tile kernels hold a CU alone; two workgroups of the 128 x 128 kernel share one)
+    late_policy = ceil_div(batch, gemm_bf16s_tile_rows(tile)) * ceil_div(W, gemm_bf16s_tile_cols(tile)) >
+                  (tile == H_TILE_128 ? 512 : 256);
+  }
+  // Two streams as in backward_impl: every weight-gradient GEMM (+ its slab sum) runs on the
+  // context's side stream — in order there, so they share one slab buffer — forked behind the
+  // data-gradient GEMM of its stage (BLH_OPT_LATE_FORK) or behind bn_bwd_apply; one join at the end.
+  tl_stop_event = nullptr;
+  const bool two = ctx->two_stream && !ctx->sync.fn;   // (SyncBN: the exchanges are enqueued on `s`)
+  hipStream_t s2 = two ? ctx->s2 : s;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cap);
+  const bool attach = two && cap == hipStreamCaptureStatusNone;
+  auto arm_fork = [&](int idx) { if (attach) tl_stop_event = ctx->ev_dz[idx]; };
+  auto fork_wait = [&](int idx, bool attached) -> int {   // s2 continues behind the last kernel of s
+    if (!two) return BLH_OK;
+    if (!(attached && attach)) BLH_HIP_TRY(hipEventRecord(ctx->ev_dz[idx], s));
+    BLH_HIP_TRY(hipStreamWaitEvent(s2, ctx->ev_dz[idx], 0));
+    return BLH_OK;
+  };
+  // a reported range: weight gradient on the side stream, bias / gamma / beta on the main one;
+  // the side stream waits for the main one, so the range is complete ON THE SIDE STREAM
+  auto ready = [&](int idx, int64_t off, int64_t cnt) -> int {
+    if (!on_ready) return BLH_OK;
+    if (!two && ctx->two_stream) {   // (SyncBN call of a two-stream context: produced on `s`)
+      BLH_HIP_TRY(hipEventRecord(ctx->ev_r[idx], s));
+      BLH_HIP_TRY(hipStreamWaitEvent(ctx->s2, ctx->ev_r[idx], 0));
+    }
+    // two streams: every part of the range was produced on the side stream behind the stage's fork
+    // (weight gradient, bias reduction) or on the main stream in front of it (gamma / beta)
+    on_ready(user, off, cnt);
+    return BLH_OK;
+  };
+  // decode: dA_last = dP W_d (carries the first fork), dW = dP^T A_last, db = colsum(dP)
+  if (dec_bias_S == 0) BLH_TRY(launch_cast_f32_bf16(s, dpred, ws.dpredh, batch * OF));
+  {
+    GemmParamsH g{};
+    g.A = ws.dpredh; g.lda = OF;
+    g.B = ws.wsh + L.dec_w; g.ldb = W;
+    g.C = ws.G0; g.ldc = W;
+    g.M = (int)batch; g.N = W; g.K = OF; g.k_per_split = OF;
+    arm_fork(nh);
+    BLH_TRY(launch_gemm_bf16s(s, ROWK, KROW, EPI_STORE, true, g, 1));
+    tl_stop_event = nullptr;
+  }
+  BLH_TRY(fork_wait(nh, true));
+  BLH_TRY(wgrad_h(s2, ws.dpredh, OF, OF, ws.A[nh - 1], W, W, batch, ws.slabs, grads + L.dec_w));
+  if (dec_bias_S == 0) BLH_TRY(launch_colsum(on_ready ? s2 : s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
+  else if (on_ready) BLH_TRY(launch_colreduce(s2, ws.dec_bias_part, dec_bias_S, OF, OF, grads + L.dec_b));
+  BLH_TRY(ready(nh, L.dec_w, L.total - L.dec_w));
+  // Weight gradients of the hidden stages: batched launches of the 256 x 256 kernel (api_layout.h:
+  // wgrad_batched_plan_h) instead of one launch per stage.  Without a bucket hook: ONE group, all hidden
+  // stages, on the main stream after the loop.  With a hook (data parallel): groups of four stages from
+  // the top, each launched on the side stream when its lowest stage has its dZ, so that the first ranges
+  // are reported — and their all-reduce starts — after half of a four-block backward.
+  struct WGroup { int lo, hi; Splits plan; };
+  std::vector<WGroup> wgroups;
+  if (nh - 1 >= 2) {
+    if (on_ready == nullptr) {
+      wgroups.push_back(WGroup{1, nh - 1, wgrad_batched_plan_h(W, batch, nh - 1)});
+    } else {
+      for (int hi = nh - 1; hi >= 1; hi -= WGRAD_HOOK_GROUP) {
+        const int lo = std::max(1, hi - (WGRAD_HOOK_GROUP - 1));
+        wgroups.push_back(WGroup{lo, hi, wgrad_batched_plan_h(W, batch, hi - lo + 1)});
+      }
+    }
+  }
+  auto group_of = [&](int i) -> const WGroup* {
+    for (const WGroup& g : wgroups)
+      if (g.lo <= i && i <= g.hi && g.plan.splits > 0) return &g;
+    return nullptr;
+  };
+  // dW_k = dZ_k^T A_{k-1} for k = lo .. hi in one launch: the stages' dZ, A and gradient tensors lie one
+  // fixed stride apart (carve_h, make_layout)
+  auto launch_group = [&](const WGroup& grp, hipStream_t st) -> int {
+    const int items = grp.hi - grp.lo + 1;
+    if (nh < 3 || (ws.dZ[2] - ws.dZ[1]) != (ws.A[1] - ws.A[0])) return BLH_ERR_SHAPE;
+    const int64_t gstride = L.heavy[2].w - L.heavy[1].w;
+    for (int k = 2; k < nh; ++k)
+      if (L.heavy[k].w - L.heavy[k - 1].w != gstride) return BLH_ERR_SHAPE;
+    GemmParamsH g{};
+    g.A = ws.dZ[grp.lo]; g.lda = W; g.B = ws.A[grp.lo - 1]; g.ldb = W;
+    g.M = W; g.N = W; g.K = (int)batch; g.k_per_split = grp.plan.k_per; g.ldc = W;
+    g.batch_splits = grp.plan.splits;
+    g.a_batch_stride = ws.dZ[2] - ws.dZ[1];
+    g.b_batch_stride = ws.A[1] - ws.A[0];
+    float* out = grads + L.heavy[grp.lo].w;
+    if (grp.plan.splits == 1) {
+      g.C = out; g.c_batch_stride = gstride; g.c_split_stride = 0;
+      return launch_gemm_bf16s(st, KROW, KROW, EPI_STORE, false, g, items);
+    }
+    g.C = ws.bslabs; g.c_split_stride = (int64_t)W * W; g.c_batch_stride = (int64_t)grp.plan.splits * W * W;
+    BLH_TRY(launch_gemm_bf16s(st, KROW, KROW, EPI_STORE, false, g, items * grp.plan.splits));
+    return launch_sum_slabs_batched(st, ws.bslabs, (int64_t)W * W, grp.plan.splits, items, g.c_batch_stride, out,
+                                    gstride);
+  };
+  // a data-gradient GEMM whose output only feeds the BatchNorm backward of the stage below
+  // (the second stage of a block: its output is not a skip operand; and stage 1, whose block-input gradient
+  // nothing below needs) forms that stage's gated gradient dY' and the (dY' z, dY') column sums in its
+  // epilogue (EPI_BN_BWD, big-tile kernels only): the stage below then skips bn_bwd_reduce_h2 and its
+  // bn_bwd_apply_h2 reads no keep bits.  k9_chunks > 0: stage i's dA arrived that way, with that many partial rows.
+  const bool k9_enabled = getenv("BLH_NO_K9") == nullptr;
+  int k9_chunks = 0;
+  for (int i = nh - 1; i >= 0; --i) {
+    const HeavyOffsets& h = L.heavy[i];
+    const bool first_of_block = (i >= 1) && (i % 2 == 1);
+    const uint16_t* dA = first_of_block ? ws.G1 : ws.G0;
+    const float* sv = ws.bn_saved[i];
+    const WGroup* grp = i > 0 ? group_of(i) : nullptr;
+    const int k9_in = k9_chunks;      // how this stage's dA was produced
+    k9_chunks = 0;
+    const bool batched_w = grp != nullptr;
+    // (a hidden stage of a batched group hands nothing to the side stream, except the group's lowest
+    //  stage under a hook: the group's launch goes there, behind its bn_bwd_apply)
+    const bool group_fork = batched_w && on_ready != nullptr && i == grp->lo;
+    const bool forks = two && (!batched_w || group_fork);
+    {   // dropout: the keep bits the forward wrote (bn_bf16.hip)
+      if (k9_in == 0)
+        BLH_TRY(launch_bn_bwd_reduce_h2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, ws.keep[i], ws.bn_part, batch, W));
+      BLH_TRY(launch_bn_bwd_finalize_h2(s, ws.bn_part, k9_in ? k9_in : chunks, W, sv, sv + W, grads + h.gamma,
+                                        grads + h.beta));
+      const float* dg = grads + h.gamma;
+      const float* db = grads + h.beta;
+      int64_t norm_batch = batch;
+      if (ctx->sync.fn) {
+        // SyncBN: the parameter gradients keep the LOCAL sums (averaged later with the rest of the
+        // arena); the BatchNorm backward itself needs the sums over the global batch
+        float* sb = reinterpret_cast<float*>(ws.sync_buf);
+        BLH_HIP_TRY(hipMemcpyAsync(sb, grads + h.gamma, W * sizeof(float), hipMemcpyDeviceToDevice, s));
+        BLH_HIP_TRY(hipMemcpyAsync(sb + W, grads + h.beta, W * sizeof(float), hipMemcpyDeviceToDevice, s));
+        ctx->sync.fn(ctx->sync.user, sb, 2 * (int64_t)W, 0);
+        dg = sb; db = sb + W; norm_batch = ctx->sync.global_batch;
+      }
+      BLH_TRY(launch_bn_bwd_apply_h2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W, dg, db, ws.keep[i],
+                                     ws.dZ[i], ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W,
+                                     norm_batch, k9_in > 0));
+    }
+    const bool late = forks && late_policy && i > 0 && !group_fork;
+    if (forks && !late) BLH_TRY(fork_wait(i, false));     // behind bn_bwd_apply (marker event)
+    if (group_fork) {
+      for (int k = grp->hi; k >= grp->lo; --k)
+        BLH_TRY(launch_colreduce(s2, ws.dz_colsum_part + (int64_t)k * chunks * W, chunks, W, W,
+                                 grads + L.heavy[k].b));
+      BLH_TRY(launch_group(*grp, s2));
+      for (int k = grp->hi; k >= grp->lo; --k) {
+        const int64_t end = (k + 1 < nh) ? L.heavy[k + 1].w : L.dec_w;
+        BLH_TRY(ready(k, L.heavy[k].w, end - L.heavy[k].w));
+      }
+    }
+    // (data parallel: the bucket hook needs this stage's bias gradient now — on the side stream, in
+    //  front of the stage's weight gradient: nothing on the main stream waits for it; otherwise all
+    //  stages are reduced by one launch after the loop, as in backward_impl)
+    auto bias_now = [&]() -> int {
+      return on_ready ? launch_colreduce(s2, ws.dz_colsum_part + (int64_t)i * chunks * W, chunks, W, W,
+                                         grads + h.b)
+                      : BLH_OK;
+    };
+    if (!late && !batched_w) BLH_TRY(bias_now());
+    if (i > 0) {
+      GemmParamsH g{};
+      g.A = ws.dZ[i]; g.lda = W;
+      g.B = ws.wsh + h.w; g.ldb = W;
+      g.M = (int)batch; g.N = W; g.K = W; g.k_per_split = W; g.ldc = W;
+      if (late) arm_fork(i);
+      // K9: this GEMM's output is only read by the BatchNorm backward of stage i - 1
+      const int tile = gemm_bf16s_pick_tile(ROWK, KROW, true, g, 1);
+      const int64_t k9_rows = ceil_div(batch, gemm_bf16s_tile_rows(tile));
+      // (the addend form — stage 1 only — spills in the 256 x 256 kernel, which holds 128 accumulator registers
+      //  through its epilogue: there stage 0 keeps the streaming reduction)
+      const bool k9 = k9_enabled && tile != H_TILE_128 && k9_rows <= chunks &&
+                      (!first_of_block || (i == 1 && tile == H_TILE_128x256));
+      if (k9) {
+        const float* svd = ws.bn_saved[i - 1];
+        g.bn_z = ws.Z[i - 1]; g.ldz = W; g.bn_keep = ws.keep[i - 1];
+        g.bn_scale = svd + 2 * W; g.bn_shift = svd + 3 * W; g.stat_part = ws.bn_part;
+        k9_chunks = (int)k9_rows;
+      }
+      if (first_of_block) {   // d(block input) = dZ W + d(block output), in place in G0
+        g.C = ws.G0; g.addend = ws.G0; g.ldadd = W;
+        BLH_TRY(launch_gemm_bf16s(s, ROWK, KROW, k9 ? EPI_BN_BWD_ADD : EPI_ADD, true, g, 1));
+      } else {
+        g.C = ws.G1;
+        BLH_TRY(launch_gemm_bf16s(s, ROWK, KROW, k9 ? EPI_BN_BWD : EPI_STORE, true, g, 1));
+      }
+      tl_stop_event = nullptr;
+      if (late) {
+        BLH_TRY(fork_wait(i, true));
+        BLH_TRY(bias_now());
+      }
+      if (!batched_w) BLH_TRY(wgrad_h(s2, ws.dZ[i], W, W, ws.A[i - 1], W, W, batch, ws.slabs, grads + h.w));
+    } else {
+      BLH_TRY(wgrad_h(s2, ws.dZ[0], W, W, ws.xh, IF, IF, batch, ws.slabs, grads + h.w));
+    }
+    if (on_ready && !batched_w) {
+      const int64_t end = (i + 1 < nh) ? L.heavy[i + 1].w : L.dec_w;
+      BLH_TRY(ready(i, h.w, end - h.w));
+    }
+  }
+  if (on_ready == nullptr && !wgroups.empty() && wgroups[0].plan.splits > 0) {
+    BLH_TRY(launch_group(wgroups[0], s));   // (the stage-0 and decode weight gradients, side stream, run beside it)
+  }
+  if (!on_ready) {
+    int64_t offs[32];
+    if (nh > 32) return BLH_ERR_SHAPE;
+    for (int i = 0; i < nh; ++i) offs[i] = L.heavy[i].b;
+    BLH_TRY(launch_bias_colreduce(s, ws.dz_colsum_part, (int64_t)chunks * W, chunks, W, nh, offs, grads,
+                                  dec_bias_S > 0 ? ws.dec_bias_part : nullptr, dec_bias_S, OF, L.dec_b));
+  }
+  if (two) {   // join: the side stream is in order, its last kernel is stage 0's slab sum
+    BLH_HIP_TRY(hipEventRecord(ctx->ev_w[0], s2));
+    BLH_HIP_TRY(hipStreamWaitEvent(s, ctx->ev_w[0], 0));
+  }
+  return BLH_OK;
+}
+
+}  // namespace blh

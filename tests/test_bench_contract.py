@@ -49,3 +49,18 @@ def test_cpu_baseline_port_runs_the_whole_step():
     out = TP.time_cpu_steps(1, 64, 32, steps=2, warmup=1, threads=2)
     assert out["steps"] == 2 and out["threads"] == 2
     assert out["poses_per_s"] > 0 and abs(out["ms_per_step"] * out["poses_per_s"] / 1e3 - 32) < 1e-6 * 32
+
+
+def test_pre_ramp_leaves_on_the_agreed_clock(monkeypatch):
+    """N > 1: every rank must leave the pre-ramp after the same number of steps (each step holds collectives),
+    so the exit test uses the value `agree` returns (the maximum over ranks), never the local clock alone."""
+    import torch
+    b = _bench()
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    steps = []
+    answers = iter([0.0, 0.0, 1e9])          # the group says "not yet" twice, whatever this rank's clock shows
+    el, n = b.pre_ramp(lambda: steps.append(1), 1e-6, agree=lambda ms: next(answers))
+    assert n == 30 and len(steps) == 30 and el == 1e9
+    steps.clear()
+    el, n = b.pre_ramp(lambda: steps.append(1), 1e-6)       # one rank: its own clock
+    assert n == 10 and len(steps) == 10
