@@ -185,6 +185,7 @@ OPT_TWO_STREAM = 0
 OPT_DEFER_SLABS = 1
 OPT_LATE_FORK = 2
 OPT_PERSISTENT_SHADOW = 3
+OPT_SMALL_STEP = 4
 
 
 class Context:
@@ -207,6 +208,14 @@ class Context:
 
     def side_stream(self):
         return lib().blh_context_side_stream(self.handle)
+
+    def grid_barrier_timeouts(self):
+        """Grid barriers of this context's persistent launches that gave up waiting (0 unless a launch could not
+        be fully resident; its results are then wrong).  Synchronises."""
+        n = int(lib().blh_context_grid_barrier_timeouts(self.handle))
+        if n < 0:
+            check(n, "blh_context_grid_barrier_timeouts")
+        return n
 
     def __del__(self):
         try:

@@ -9,6 +9,7 @@
 
 #include <mutex>
 #include "step.h"
+#include "small_step.h"
 
 namespace blh {
 
@@ -119,6 +120,7 @@ int blh_context_set_option(blh_context* c, int32_t option, int32_t value) {
       if (value < 0 || value > 2) return BLH_ERR_INVALID_ARGUMENT;
       c->late_fork = value;
       return BLH_OK;
+    case BLH_OPT_SMALL_STEP: c->small_step = value != 0; return BLH_OK;
     case BLH_OPT_PERSISTENT_SHADOW:
       c->persistent_shadow = value != 0;
       c->shadow_params = c->shadow_ws = nullptr;
@@ -134,15 +136,16 @@ int blh_context_get_option(const blh_context* c, int32_t option) {
     case BLH_OPT_DEFER_SLABS: return c->defer_slabs ? 1 : 0;
     case BLH_OPT_LATE_FORK: return c->late_fork;
     case BLH_OPT_PERSISTENT_SHADOW: return c->persistent_shadow ? 1 : 0;
+    case BLH_OPT_SMALL_STEP: return c->small_step ? 1 : 0;
   }
   return BLH_ERR_INVALID_ARGUMENT;
 }
 
 int64_t blh_context_grid_barrier_timeouts(blh_context* c) {
   if (!c || !c->grid_bar) return BLH_ERR_INVALID_ARGUMENT;
-  uint32_t words[3] = {0, 0, 0};
+  uint32_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   BLH_HIP_TRY(hipMemcpy(words, c->grid_bar, sizeof(words), hipMemcpyDeviceToHost));
-  return (int64_t)words[2];
+  return (int64_t)words[2] + (int64_t)words[6];      // fused bf16 forward stage + one-launch small-batch step
 }
 
 void* blh_context_side_stream(blh_context* c) {
@@ -359,6 +362,46 @@ int blh_clip_grad_norm(void* stream, float* grads, int64_t count, float max_norm
                            stats_out);
 }
 
+// Batches of at most 64 rows in exact fp32 take the one-launch step (small_step.hip) when the device can hold
+// its grid; BLH_NO_SMALL_STEP=1 keeps the multi-launch path (A/B measurements, tests of that path).
+static bool small_step_applies(const blh_context* ctx, const blh_model_desc* d, int64_t batch) {
+  if (!ctx->small_step || d->gemm_dtype != 0 || batch > 64 || ctx->sync.fn || !ctx->grid_bar) return false;
+  static const bool off = getenv("BLH_NO_SMALL_STEP") != nullptr;
+  if (off) return false;
+  const int grid = small_step_max_grid(nullptr);
+  return grid > 0 && d->width / 4 <= grid && d->width <= 1024 && d->in_features <= 1024;
+}
+
+static int small_step(blh_context* ctx, const blh_model_desc* d, hipStream_t s, float* params, float* grads,
+                      float* exp_avg, float* exp_avg_sq, float* bn_running, int64_t* bn_nbt, const float* x,
+                      const float* target, const blh_dropout* drop, float momentum, const blh_adam_hyper* hyper,
+                      const blh_step_state* dev_state, const Workspace& ws, float* pred, float* loss_out,
+                      float* stats_out, int64_t batch) {
+  const ArenaLayout L = make_layout(d);
+  SmallStepParams p{};
+  p.nh = (int)L.heavy.size(); p.W = d->width; p.in_f = d->in_features; p.out_f = d->out_features;
+  p.batch = (int)batch;
+  for (int i = 0; i < p.nh; ++i) {
+    p.w_off[i] = L.heavy[i].w; p.b_off[i] = L.heavy[i].b; p.g_off[i] = L.heavy[i].gamma; p.be_off[i] = L.heavy[i].beta;
+    p.A[i] = ws.A[i]; p.dZ[i] = ws.dZ[i];
+  }
+  p.dec_w = L.dec_w; p.dec_b = L.dec_b; p.count = L.total;
+  p.params = params; p.grads = grads; p.m = exp_avg; p.v = exp_avg_sq;
+  p.bn_running = bn_running; p.nbt = bn_nbt; p.x = x; p.target = target;
+  p.dpred = ws.dpred; p.pred = pred; p.loss_out = loss_out; p.stats_out = stats_out;
+  p.loss_part = ws.loss_part; p.sumsq_part = ws.sumsq_part; p.bar = ctx->grid_bar + 4;      // (words 0-2: the bf16 fused forward stage's barrier)
+  p.drop = layer_drop(ctx, drop, 0, batch, d->width);
+  p.momentum = momentum;
+  p.denom = (double)batch * d->out_features;
+  p.mse_scale = (float)(2.0 / p.denom);
+  if (hyper) {
+    if (hyper->step < 1) return BLH_ERR_INVALID_ARGUMENT;
+    p.adam = adam_consts(*hyper);
+  }
+  p.st = dev_state;
+  return launch_small_step(s, p);
+}
+
 int blh_train_step(blh_context* ctx, const blh_model_desc* d, void* stream, float* params, float* grads,
                    float* exp_avg, float* exp_avg_sq, float* bn_running, int64_t* bn_nbt,
                    const float* x, const float* target, const blh_dropout* drop, float momentum,
@@ -394,6 +437,9 @@ int blh_train_step(blh_context* ctx, const blh_model_desc* d, void* stream, floa
     return BLH_OK;
   }
   const Workspace ws = carve(d, batch, workspace);
+  if (small_step_applies(ctx, d, batch))
+    return small_step(ctx, d, s, params, grads, exp_avg, exp_avg_sq, bn_running, bn_nbt, x, target, drop, momentum,
+                      hyper, nullptr, ws, pred, loss_out, stats_out, batch);
   BLH_TRY(forward_impl(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
                        target, (float)(2.0 / denom), ws.loss_part, &nparts));
   int np = 0;
@@ -637,6 +683,9 @@ int blh_train_step_captured(blh_context* ctx, const blh_model_desc* d, void* str
                                 LossFinish{wh.loss_part, nparts, denom, loss_out}, keep ? wh.wsh : nullptr);
   }
   const Workspace ws = carve(d, batch, workspace);
+  if (small_step_applies(ctx, d, batch))
+    return small_step(ctx, d, s, params, grads, exp_avg, exp_avg_sq, bn_running, bn_nbt, x, target, drop, momentum,
+                      nullptr, dev_state, ws, pred, loss_out, stats_out, batch);
   BLH_TRY(forward_impl(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
                        target, (float)(2.0 / denom), ws.loss_part, &nparts));
   double* sq_src = ws.sumsq_part;

@@ -195,6 +195,9 @@ int launch_mse(hipStream_t s, const float* pred, const float* target, int64_t n,
 // optimiser
 // loss = sum(part[0..n)) / denom, finished by block 0 of the optimiser kernel (part == nullptr: off)
 struct LossFinish { const float* part; int n; double denom; float* out; };
+// scalars of one Adam step (torch.optim.Adam forms them in double and rounds each once: adam_consts)
+struct AdamConsts { float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, max_norm; };
+AdamConsts adam_consts(const blh_adam_hyper& h);
 int launch_sumsq(hipStream_t s, const float* g, int64_t count, double* part, int* nparts);
 // shadow (optional): bf16 image of the updated parameters (the bf16-storage forward's weights)
 int launch_clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count,

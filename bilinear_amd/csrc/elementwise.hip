@@ -716,7 +716,6 @@ __device__ __forceinline__ void finish_loss(const LossFinish& lf, double* sh) {
 // of the compressed data-parallel exchange, times gscale); gout: the fp32 arena, which receives the
 // clipped gradient (the reference's .grad after clip_grad_norm_); shadow (optional): the bf16 image
 // of the updated parameters for the next bf16-storage forward.
-struct AdamConsts { float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, max_norm; };
 
 template <typename TG>
 __device__ __forceinline__ void clip_adam_body(float* __restrict__ p, const TG* gin, float* gout,
@@ -770,7 +769,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(
   clip_adam_body<TG>(p, gin, gout, m, v, count, c, gscale, sumsq_part, nparts, stats_out, lf, shadow, sh);
 }
 
-static AdamConsts adam_consts(const blh_adam_hyper& h) {
+AdamConsts adam_consts(const blh_adam_hyper& h) {
   // torch.optim.Adam forms these scalars in double (Python floats) and rounds each once
   const double bc1 = 1.0 - pow(h.beta1, (double)h.step);
   const double bc2 = 1.0 - pow(h.beta2, (double)h.step);

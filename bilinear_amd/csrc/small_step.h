@@ -1,0 +1,35 @@
+// The one-launch training step for batches of at most 64 rows (small_step.hip).
+#pragma once
+#include "common.h"
+
+namespace blh {
+
+constexpr int SS_MAX_STAGES = 33;        // 1 + 2 * num_blocks (api_layout.h: check_desc)
+
+struct SmallStepParams {
+  int nh, W, in_f, out_f, batch;
+  int64_t w_off[SS_MAX_STAGES], b_off[SS_MAX_STAGES], g_off[SS_MAX_STAGES], be_off[SS_MAX_STAGES];
+  int64_t dec_w, dec_b, count;
+  float* params; float* grads; float* m; float* v;
+  float* bn_running; int64_t* nbt;
+  const float* x; const float* target;
+  float* A[SS_MAX_STAGES];               // [batch][W] per stage (workspace)
+  float* dZ[SS_MAX_STAGES];
+  float* dpred;                          // [batch][out_f]
+  float* pred; float* loss_out; float* stats_out;
+  float* loss_part;                      // [out_f / 4]
+  double* sumsq_part;                    // [grid]
+  uint32_t* bar;                         // grid barrier words (context)
+  DropoutSrc drop;                       // of stage 0 (keep: base of the [nh][batch][W] masks)
+  float momentum, mse_scale;
+  double denom;
+  AdamConsts adam;
+  const blh_step_state* st;              // captured step: Adam scalars from device memory instead of `adam`
+  unsigned long long* stamps;            // developer tool only (tools/small_step_bench.hip): [grid][64] s_memrealtime
+};
+
+// number of workgroups of the launch (= CUs of the device) if all of them can be resident at once, else 0
+int small_step_max_grid(int* num_cus_out);
+int launch_small_step(hipStream_t s, const SmallStepParams& p);
+
+}  // namespace blh

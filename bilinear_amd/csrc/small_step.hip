@@ -1,0 +1,460 @@
+// The whole training step at the reference's own batch size (util/config.py:15: batch_size = 64) as ONE
+// persistent launch: zero_grad, forward (Linear -> BatchNorm1d -> ReLU -> Dropout stages with block skips,
+// /root/reference/model/bilinear.py:7-13,31-41), MSE, backward, clip_grad_norm_(1) and Adam
+// (/root/reference/train_bilinear.py:75-83).
+//
+// Why: at 64 rows the multi-launch step is ~50 kernels of 5 us each, every one of them nothing but launch latency
+// and a cold first read (0.32 ms per step at 2 x 1024, hipGraph replay no faster).  Here the batch is at most 64
+// rows, so a workgroup that owns FOUR columns of a stage owns them for all rows: BatchNorm statistics, the BatchNorm
+// backward sums, the weight gradient of its four weight rows and the dropout patch (32 rows x 4 columns per
+// Philox call, philox.h) are all local to it; only the activations (forward) and dZ (backward) of a stage cross
+// workgroups, through L2, behind one grid barrier per stage (grid_barrier.h).  2 nh + 1 barriers per step
+// (nh = 1 + 2 num_blocks stages).
+//
+// Work split: workgroup g owns column group cg(g) (XCD-aware: the 32 workgroups of one XCD own 128 adjacent
+// columns, so the strided weight columns the data gradient reads are fetched once per XCD L2).  256 threads =
+// 4 waves x 16 rows; the 64 lanes of a wave split the reduction index four elements each (float4, coalesced
+// rows of the activation), every lane accumulates a 16 x 4 block and a 63-shuffle butterfly leaves element
+// (row, column) = (tid / 4, tid % 4) in thread tid.  That mapping is the same in every stage, forward and backward,
+// so what backward needs of forward (x-hat, the ReLU/dropout gate, the BatchNorm scale) never leaves the
+// workgroup: it waits in LDS.  The weights of the next stage are requested BEFORE the barrier wait (they do not
+// depend on anyone), so their HBM latency hides behind the barrier; weight-gradient work sits between
+// arrive() and wait() for the same reason.
+//
+// Arithmetic is fp32 FMA on the vector ALU (0.5 MFLOP per workgroup and stage: the matrix cores have nothing to
+// win at 64 x 4 tiles); column statistics in fp32 over <= 64 rows, the norm of the gradient in fp64 partials, one
+// per workgroup, summed in a fixed order (deterministic).  Same Philox keep bits, same Adam arithmetic
+// (clip_adam_body, elementwise.hip) as the multi-launch path.
+#include "common.h"
+#include "philox.h"
+#include "grid_barrier.h"
+#include "small_step.h"
+
+namespace blh {
+
+namespace {
+
+constexpr int SS_THREADS = 256;
+constexpr int SS_MAX_ROWS = 64;
+constexpr int SS_PASSES = 4;            // reduction length <= 4 * 256
+constexpr int SS_RB = 8;                // rows per batch of loads in ss_gemm (x 4 passes = 16 loads in flight per wave)
+
+typedef float4 WBlock[SS_PASSES][4];
+
+__device__ __forceinline__ float4 ss_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// What other workgroups read behind the next barrier (activations, dZ, dpred) is stored write-through at agent
+// scope (global_store ... sc1): the barrier then needs no L2 write-back on the arriving side (1.9 us of 7.3,
+// tools/grid_barrier_bench.hip), only the drain of the stores that arrive_published() waits for.
+__device__ __forceinline__ void ss_publish(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// weights of one reduction pass, ROWS form (forward): wb[j][c] = Wrow[c][k .. k+3], k = 256 j + 4 lane
+__device__ __forceinline__ void ss_load_w_rows(WBlock& wb, const float* __restrict__ Wp, int K, int lane) {
+#pragma unroll
+  for (int j = 0; j < SS_PASSES; ++j) {
+    const int k = j * 256 + lane * 4;
+    const int kk = min(k, K - 4);          // (loads are unconditional: a load under a lane mask costs a branch and
+#pragma unroll                             //  a full wait each; out-of-range lanes get zero weights instead)
+    for (int c = 0; c < 4; ++c) {
+      const float4 w = ss_ld4(Wp + (int64_t)c * K + kk);
+      wb[j][c] = (k < K) ? w : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+}
+// COLUMNS form (data gradient): wb[j][q] = W[m + q][n0 .. n0+3], m = 256 j + 4 lane; ld = row length of W
+__device__ __forceinline__ void ss_load_w_cols(WBlock& wb, const float* __restrict__ Wp, int M, int ld, int lane) {
+#pragma unroll
+  for (int j = 0; j < SS_PASSES; ++j) {
+    const int m = j * 256 + lane * 4;
+    const int mm = min(m, M - 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 w = ss_ld4(Wp + (int64_t)(mm + q) * ld);
+      wb[j][q] = (m < M) ? w : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+}
+
+// out(row, c) = sum_k In[row][k] * w(k, c) for the wave's 16 rows; returns the element (16 wave + lane / 4, lane % 4).
+//  * Two halves of 8 rows: 32 accumulators next to the 64 weight registers.  Each half ends in a 32-value
+//    butterfly (31 shuffles + 1) that leaves the sum of value (lane % 32) in both half-waves; lanes 0-31 keep the
+//    first half's element, lanes 32-63 the second's, which is the (lane / 4, lane % 4) mapping.
+//  * A batch of loads is SS_RB WHOLE ROWS (x 4 passes of 1 KB): rows are exactly 4 KB apart, so a batch of one
+//    1 KB piece of many rows would sit on the same few L2 channels for every wave of every CU at once.
+//  * Loads are unconditional and all four passes always run (clamped index, zero weights past K): a load under a
+//    lane mask, or a pass under a uniform branch, costs a branch and a full wait each.  sched_barrier keeps the scheduler from hoisting every batch to the top (spills).
+template <bool COLS>
+__device__ __forceinline__ float ss_gemm(const WBlock& wb, const float* __restrict__ In, int ld, int K, int batch,
+                                         int wave, int lane) {
+  float out = 0.f;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    float acc[8][4];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
+#pragma unroll
+    for (int rp = 0; rp < 8 / SS_RB; ++rp) {
+      float4 a[SS_RB][SS_PASSES];
+#pragma unroll
+      for (int u = 0; u < SS_RB; ++u) {
+        const int row = min(wave * 16 + half * 8 + rp * SS_RB + u, batch - 1);
+#pragma unroll
+        for (int j = 0; j < SS_PASSES; ++j)
+          a[u][j] = ss_ld4(In + (int64_t)row * ld + min(j * 256 + lane * 4, K - 4));
+      }
+#pragma unroll
+      for (int u = 0; u < SS_RB; ++u) {
+        const int r = rp * SS_RB + u;
+#pragma unroll
+        for (int j = 0; j < SS_PASSES; ++j) {
+          {
+            const float4 av = a[u][j];
+            if (COLS) {
+              const float4 w0 = wb[j][0], w1 = wb[j][1], w2 = wb[j][2], w3 = wb[j][3];
+              acc[r][0] = fmaf(av.x, w0.x, fmaf(av.y, w1.x, fmaf(av.z, w2.x, fmaf(av.w, w3.x, acc[r][0]))));
+              acc[r][1] = fmaf(av.x, w0.y, fmaf(av.y, w1.y, fmaf(av.z, w2.y, fmaf(av.w, w3.y, acc[r][1]))));
+              acc[r][2] = fmaf(av.x, w0.z, fmaf(av.y, w1.z, fmaf(av.z, w2.z, fmaf(av.w, w3.z, acc[r][2]))));
+              acc[r][3] = fmaf(av.x, w0.w, fmaf(av.y, w1.w, fmaf(av.z, w2.w, fmaf(av.w, w3.w, acc[r][3]))));
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const float4 w = wb[j][c];
+                acc[r][c] = fmaf(av.x, w.x, fmaf(av.y, w.y, fmaf(av.z, w.z, fmaf(av.w, w.w, acc[r][c]))));
+              }
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = acc[i >> 2][i & 3];
+#pragma unroll
+    for (int h = 16; h >= 1; h >>= 1) {
+      const bool up = (lane & h) != 0;
+#pragma unroll
+      for (int i = 0; i < h; ++i) {
+        // (the empty asm keeps the two operands opaque: otherwise the select of two array elements is folded
+        //  into ONE dynamically indexed element, which is lowered to a compare/select chain over all 32)
+        float lo = v[i], hi = v[i + h];
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        const float keep = up ? hi : lo;
+        const float send = up ? lo : hi;
+        v[i] = keep + __shfl_xor(send, h);
+      }
+    }
+    const float tot = v[0] + __shfl_xor(v[0], 32);
+    if ((lane >> 5) == half) out = tot;
+  }
+  return out;
+}
+
+// sum over the rows of the workgroup's 64 x 4 tile: every thread gets the sum of its column
+__device__ __forceinline__ float ss_colsum(float v, float* sh, int wave, int lane) {
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  __syncthreads();
+  if (lane < 4) sh[wave * 4 + lane] = v;
+  __syncthreads();
+  const int c = lane & 3;
+  return (sh[c] + sh[4 + c]) + (sh[8 + c] + sh[12 + c]);
+}
+
+__device__ __forceinline__ bool ss_keep(const DropoutSrc& d, int layer_index, int64_t layer_elems, int row, int col,
+                                        int W) {
+  if (d.keep) return d.keep[(int64_t)layer_index * layer_elems + (int64_t)row * W + col] != 0;
+  const Philox128 p = dropout_patch(d.seed, dropout_step(d), d.layer + layer_index,
+                                    (int64_t)(row & ~31) + d.row_offset, col);
+  const int w = (row & 31) >> 3;
+  const uint32_t word = w == 0 ? p.w[0] : (w == 1 ? p.w[1] : (w == 2 ? p.w[2] : p.w[3]));
+  return ((word >> (4 * (row & 7) + (col & 3))) & 1u) != 0;
+}
+
+// dW rows of the workgroup: out[c][k] = sum_b dz[b][c] * In[b][k]; dz: LDS [64] float4 (4 columns of a row)
+__device__ __forceinline__ double ss_wgrad(const float4* __restrict__ sh_dz, const float* __restrict__ In, int K,
+                                           int batch, float* __restrict__ out) {
+  double sq = 0.0;
+  for (int kq = threadIdx.x; kq * 4 < K; kq += SS_THREADS) {
+    float4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = float4{0.f, 0.f, 0.f, 0.f};
+    for (int b0 = 0; b0 < batch; b0 += 16) {
+      float4 a[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a[u] = ss_ld4(In + (int64_t)min(b0 + u, batch - 1) * K + kq * 4);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const float4 dz = (b0 + u < batch) ? sh_dz[b0 + u] : float4{0.f, 0.f, 0.f, 0.f};
+        acc[0].x = fmaf(dz.x, a[u].x, acc[0].x); acc[0].y = fmaf(dz.x, a[u].y, acc[0].y);
+        acc[0].z = fmaf(dz.x, a[u].z, acc[0].z); acc[0].w = fmaf(dz.x, a[u].w, acc[0].w);
+        acc[1].x = fmaf(dz.y, a[u].x, acc[1].x); acc[1].y = fmaf(dz.y, a[u].y, acc[1].y);
+        acc[1].z = fmaf(dz.y, a[u].z, acc[1].z); acc[1].w = fmaf(dz.y, a[u].w, acc[1].w);
+        acc[2].x = fmaf(dz.z, a[u].x, acc[2].x); acc[2].y = fmaf(dz.z, a[u].y, acc[2].y);
+        acc[2].z = fmaf(dz.z, a[u].z, acc[2].z); acc[2].w = fmaf(dz.z, a[u].w, acc[2].w);
+        acc[3].x = fmaf(dz.w, a[u].x, acc[3].x); acc[3].y = fmaf(dz.w, a[u].y, acc[3].y);
+        acc[3].z = fmaf(dz.w, a[u].z, acc[3].z); acc[3].w = fmaf(dz.w, a[u].w, acc[3].w);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      *reinterpret_cast<float4*>(out + (int64_t)c * K + kq * 4) = acc[c];
+      sq += (double)acc[c].x * acc[c].x + (double)acc[c].y * acc[c].y + (double)acc[c].z * acc[c].z +
+            (double)acc[c].w * acc[c].w;
+    }
+  }
+  return sq;
+}
+
+__device__ __forceinline__ double ss_block_sum(double v, double* sh) {
+  __syncthreads();
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = SS_THREADS / 2; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  return sh[0];
+}
+
+}  // namespace
+
+// LDS: [0, 2 KB) scratch doubles for block sums | 64 float4 dz | 16 floats colsum | per stage: x-hat[256], gate[256], bn[8]
+__global__ __launch_bounds__(SS_THREADS) void small_step_kernel(const SmallStepParams p) {
+  extern __shared__ __align__(16) unsigned char ss_smem[];
+  double* sh_d = reinterpret_cast<double*>(ss_smem);                               // 256 doubles
+  float4* sh_dz = reinterpret_cast<float4*>(ss_smem + 2048);                       // 64 float4
+  float* sh_cs = reinterpret_cast<float*>(ss_smem + 2048 + 1024);                  // 16 floats
+  float* sh_save = reinterpret_cast<float*>(ss_smem + 2048 + 1024 + 64);           // nh x (256 + 256 + 8) floats
+  constexpr int SAVE_STRIDE = 256 + 256 + 8;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.x;
+  const int W = p.W, B = p.batch, nh = p.nh, OF = p.out_f;
+  const int ngroups = W >> 2;
+  const bool own = g < ngroups;                                     // owns a column group of the hidden width
+  const int cg = own ? (g & 7) * (ngroups >> 3) + (g >> 3) : 0;
+  const int n0 = cg * 4;
+  const bool own_dec = g < (OF >> 2);                               // owns 4 output columns of decode
+  const int o0 = g * 4;
+  const int row = tid >> 2, c = tid & 3;
+  const bool valid = row < B;
+  const int col = n0 + c;
+  const float inv_b = 1.0f / (float)B;
+  GridBarrier bar{p.bar, gridDim.x, 0u};
+  bar.init();
+  double sq = 0.0;                                                  // sum of squares of the gradients this thread wrote
+  int stamp_i = 0;
+  auto stamp = [&]() {
+    if (p.stamps && tid == 0) p.stamps[(int64_t)g * 64 + (stamp_i < 64 ? stamp_i : 63)] = __builtin_amdgcn_s_memrealtime();
+    ++stamp_i;
+  };
+  stamp();
+
+  WBlock wb;
+  if (own) ss_load_w_rows(wb, p.params + p.w_off[0] + (int64_t)n0 * p.in_f, p.in_f, lane);
+
+  // ------------------------------------------------------------------ forward ----
+  for (int i = 0; i < nh; ++i) {
+    const int K = (i == 0) ? p.in_f : W;
+    const float* in = (i == 0) ? p.x : p.A[i - 1];
+    if (own) {
+      // the stage's scalars first: their latency hides behind the GEMM
+      const float bias = p.params[p.b_off[i] + col], gamma = p.params[p.g_off[i] + col], beta = p.params[p.be_off[i] + col];
+      float* rm = p.bn_running + ((int64_t)i * 2 + 0) * W;
+      float* rv = p.bn_running + ((int64_t)i * 2 + 1) * W;
+      const float rm0 = rm[col], rv0 = rv[col];
+      const int64_t nbt0 = p.nbt[i];
+      const float skipv = (i >= 2 && (i & 1) == 0 && valid) ? p.A[i - 2][(int64_t)row * W + col] : 0.f;
+      const bool kept = valid && ss_keep(p.drop, i, (int64_t)B * W, row, col, W);
+      stamp();
+      float z = ss_gemm<false>(wb, in, K, K, B, wave, lane) + bias;
+      stamp();
+      if (!valid) z = 0.f;
+      const float mean = ss_colsum(z, sh_cs, wave, lane) * inv_b;
+      const float dlt = valid ? z - mean : 0.f;
+      const float m2 = ss_colsum(dlt * dlt, sh_cs, wave, lane);
+      const float invstd = (float)(1.0 / sqrt((double)m2 / (double)B + (double)1e-5f));
+      const float sc = gamma * invstd;
+      const float sh = beta - mean * sc;
+      if (row == 0) {            // running statistics (unbiased variance; momentum < 0: cumulative average)
+        const double f = (p.momentum >= 0.f) ? (double)p.momentum : 1.0 / (double)(nbt0 + 1);
+        const double unbiased = (double)m2 / (double)(B > 1 ? B - 1 : 1);
+        rm[col] = (float)((1.0 - f) * (double)rm0 + f * (double)mean);
+        rv[col] = (float)((1.0 - f) * (double)rv0 + f * unbiased);
+      }
+      const float y = fmaf(z, sc, sh);
+      const bool on = kept && y > 0.f;
+      const float a = (on ? y * 2.f : 0.f) + skipv;
+      if (valid) ss_publish(&p.A[i][(int64_t)row * W + col], a);
+      float* sv = sh_save + i * SAVE_STRIDE;
+      sv[tid] = dlt * invstd;                 // x-hat
+      sv[256 + tid] = on ? 2.f : 0.f;         // d a / d y
+      if (row == 0) { sv[512 + c] = sc; }
+    }
+    stamp();
+    // weights of the next stage (or of decode): nobody else writes them, so ask before waiting
+    if (i + 1 < nh) {
+      if (own) ss_load_w_rows(wb, p.params + p.w_off[i + 1] + (int64_t)n0 * W, W, lane);
+    } else if (own_dec) {
+      ss_load_w_rows(wb, p.params + p.dec_w + (int64_t)o0 * W, W, lane);
+    }
+    bar.arrive_published();
+    bar.wait();
+    stamp();
+  }
+
+  // ------------------------------------------------------------------ decode + MSE ----
+  float g_even = 0.f;      // gradient w.r.t. the output of the last even stage (the block skip source)
+  if (own_dec) {
+    const int oc = o0 + c;
+    const float pr = ss_gemm<false>(wb, p.A[nh - 1], W, W, B, wave, lane) + p.params[p.dec_b + oc];
+    float diff = 0.f;
+    if (valid) {
+      p.pred[(int64_t)row * OF + oc] = pr;
+      diff = pr - p.target[(int64_t)row * OF + oc];
+      ss_publish(&p.dpred[(int64_t)row * OF + oc], diff * p.mse_scale);
+    }
+    const float l4 = ss_colsum(diff * diff, sh_cs, wave, lane);
+    // the four column sums -> one partial per workgroup
+    if (tid == 0) p.loss_part[g] = (sh_cs[0] + sh_cs[4] + sh_cs[8] + sh_cs[12]) + (sh_cs[1] + sh_cs[5] + sh_cs[9] + sh_cs[13]) +
+                                   (sh_cs[2] + sh_cs[6] + sh_cs[10] + sh_cs[14]) + (sh_cs[3] + sh_cs[7] + sh_cs[11] + sh_cs[15]);
+    (void)l4;
+    const float dp = diff * p.mse_scale;
+    const float db = ss_colsum(dp, sh_cs, wave, lane);
+    if (row == 0) { p.grads[p.dec_b + oc] = db; sq += (double)db * db; }
+    __syncthreads();
+    reinterpret_cast<float*>(sh_dz)[tid] = dp;          // [row][c]
+  }
+  stamp();
+  bar.arrive_published();
+  if (own_dec) {
+    __syncthreads();
+    sq += ss_wgrad(sh_dz, p.A[nh - 1], W, B, p.grads + p.dec_w + (int64_t)o0 * W);
+  }
+  // decode weights, COLUMNS form: [OF][W], reduction over the OF outputs
+  if (own) ss_load_w_cols(wb, p.params + p.dec_w + n0, OF, W, lane);
+  bar.wait();
+  stamp();
+
+  // ------------------------------------------------------------------ backward ----
+  for (int i = nh - 1; i >= 0; --i) {
+    if (own) {
+      const bool top = (i == nh - 1);
+      float ga = top ? ss_gemm<true>(wb, p.dpred, OF, OF, B, wave, lane)
+                     : ss_gemm<true>(wb, p.dZ[i + 1], W, W, B, wave, lane);
+      stamp();
+      if ((i & 1) == 0) {
+        if (!top) ga += g_even;
+        g_even = ga;
+      }
+      const float* sv = sh_save + i * SAVE_STRIDE;
+      const float xhat = sv[tid], gate = sv[256 + tid], sc = sv[512 + c];
+      const float dy = valid ? ga * gate : 0.f;
+      const float s_b = ss_colsum(dy, sh_cs, wave, lane);             // d beta
+      const float s_g = ss_colsum(dy * xhat, sh_cs, wave, lane);      // d gamma
+      const float dz = valid ? sc * (dy - (s_b + xhat * s_g) * inv_b) : 0.f;
+      const float dbias = ss_colsum(dz, sh_cs, wave, lane);
+      if (row == 0) {
+        p.grads[p.g_off[i] + col] = s_g;
+        p.grads[p.be_off[i] + col] = s_b;
+        p.grads[p.b_off[i] + col] = dbias;
+        sq += (double)s_g * s_g + (double)s_b * s_b + (double)dbias * dbias;
+      }
+      if (i >= 1 && valid) ss_publish(&p.dZ[i][(int64_t)row * W + col], dz);
+      __syncthreads();
+      reinterpret_cast<float*>(sh_dz)[tid] = dz;
+    }
+    stamp();
+    if (i >= 1) bar.arrive_published();
+    if (own) {
+      __syncthreads();
+      const int K = (i == 0) ? p.in_f : W;
+      sq += ss_wgrad(sh_dz, (i == 0) ? p.x : p.A[i - 1], K, B, p.grads + p.w_off[i] + (int64_t)n0 * K);
+      if (i >= 1) ss_load_w_cols(wb, p.params + p.w_off[i] + n0, W, W, lane);
+    }
+    stamp();
+    if (i >= 1) bar.wait();
+    stamp();
+  }
+
+  // ------------------------------------------------------------------ clip + Adam ----
+  const double wg_sq = ss_block_sum(sq, sh_d);
+  if (tid == 0) p.sumsq_part[g] = wg_sq;
+  bar.sync();
+  stamp();
+  double a = 0.0;
+  for (int k = tid; k < (int)gridDim.x; k += SS_THREADS) a += p.sumsq_part[k];
+  const double total_sq = ss_block_sum(a, sh_d);
+  AdamConsts ac = p.adam;
+  if (p.st) ac = AdamConsts{(float)(1.0 - p.st->beta1), (float)p.st->beta2, (float)(1.0 - p.st->beta2),
+                            p.st->step_size, p.st->bc2_sqrt, (float)p.st->eps, (float)p.st->max_norm};
+  const float total_norm = (float)sqrt(total_sq);
+  float coef = 1.0f;
+  if (ac.max_norm > 0.f) coef = fminf(ac.max_norm / (total_norm + 1e-6f), 1.0f);
+  if (g == 0 && tid == 0) {
+    if (p.stats_out) { p.stats_out[0] = total_norm; p.stats_out[1] = coef; }
+    double l = 0.0;
+    for (int k = 0; k < (OF >> 2); ++k) l += (double)p.loss_part[k];
+    p.loss_out[0] = (float)(l / p.denom);
+    for (int i = 0; i < nh; ++i) p.nbt[i] += 1;
+  }
+  if (g == 0) bar.finish();
+  const int64_t n4 = p.count >> 2;
+  for (int64_t i = (int64_t)g * SS_THREADS + tid; i < n4; i += (int64_t)gridDim.x * SS_THREADS) {
+    float4 gv = ss_ld4(p.grads + i * 4), mv = ss_ld4(p.m + i * 4), vv = ss_ld4(p.v + i * 4), pv = ss_ld4(p.params + i * 4);
+    float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x; float* pp = &pv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gg = gp[k] * coef;
+      gp[k] = gg;
+      mp[k] = mp[k] + (gg - mp[k]) * ac.one_minus_b1;
+      vp[k] = vp[k] * ac.b2 + (ac.one_minus_b2 * gg) * gg;
+      const float denom = sqrtf(vp[k]) / ac.bc2_sqrt + ac.eps;
+      pp[k] = pp[k] - ac.step_size * (mp[k] / denom);
+    }
+    *reinterpret_cast<float4*>(p.grads + i * 4) = gv;
+    *reinterpret_cast<float4*>(p.m + i * 4) = mv;
+    *reinterpret_cast<float4*>(p.v + i * 4) = vv;
+    *reinterpret_cast<float4*>(p.params + i * 4) = pv;
+  }
+  stamp();
+}
+
+size_t small_step_lds_bytes(int nh) { return 2048 + 1024 + 64 + (size_t)nh * (256 + 256 + 8) * sizeof(float); }
+
+int small_step_max_grid(int* num_cus_out) {
+  static int cus = -1, fits = 0;
+  if (cus < 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    const size_t lds = small_step_lds_bytes(SS_MAX_STAGES);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(small_step_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, small_step_kernel, SS_THREADS, lds) != hipSuccess)
+      return 0;
+    fits = per_cu >= 1 ? n : 0;
+    cus = n;
+  }
+  if (num_cus_out) *num_cus_out = cus;
+  return fits;
+}
+
+int launch_small_step(hipStream_t s, const SmallStepParams& p) {
+  const int grid = small_step_max_grid(nullptr);
+  if (grid <= 0 || p.W / 4 > grid || p.batch > SS_MAX_ROWS || p.nh > SS_MAX_STAGES || p.W > 256 * SS_PASSES ||
+      p.in_f > 256 * SS_PASSES || p.out_f > 256 * SS_PASSES)
+    return BLH_ERR_SHAPE;
+  hipLaunchKernelGGL(small_step_kernel, dim3((unsigned)grid), dim3(SS_THREADS), small_step_lds_bytes(p.nh), s, p);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+}  // namespace blh

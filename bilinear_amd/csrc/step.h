@@ -35,6 +35,7 @@ struct blh_context {
   // BLH_OPT_PERSISTENT_SHADOW: the (params, workspace) whose bf16 parameter image the last fused
   // step's Adam kernel left up to date (nullptr: none)
   bool persistent_shadow = false;
+  bool small_step = true;
   const void* shadow_params = nullptr;
   const void* shadow_ws = nullptr;
   // grid barrier of the fused forward stage (gemm_bf16s_bnfwd.h): arrivals, generation, timeouts; device memory

@@ -146,7 +146,8 @@ class Engine:
             old = self.ctx
             self.ctx = N.Context(device)
             if old is not None:    # keep the options across a device move
-                for opt in (N.OPT_TWO_STREAM, N.OPT_DEFER_SLABS, N.OPT_LATE_FORK, N.OPT_PERSISTENT_SHADOW):
+                for opt in (N.OPT_TWO_STREAM, N.OPT_DEFER_SLABS, N.OPT_LATE_FORK, N.OPT_PERSISTENT_SHADOW,
+                            N.OPT_SMALL_STEP):
                     self.ctx.set_option(opt, old.get_option(opt))
         self.device = device
         self._workspace = None
@@ -406,6 +407,13 @@ class Engine:
         if self.ctx is None:
             raise RuntimeError("the engine is not on a device yet")
         self.ctx.set_option(N.OPT_TWO_STREAM, 1 if enabled else 0)
+
+    def set_small_step(self, enabled):
+        """A/B switch of the one-launch step for batches of at most 64 rows (BLH_OPT_SMALL_STEP, fp32 only; default
+        on): off = the multi-launch path every other batch size takes."""
+        if self.ctx is None:
+            raise RuntimeError("the engine is not on a device yet")
+        self.ctx.set_option(N.OPT_SMALL_STEP, 1 if enabled else 0)
 
     def backward(self, x, dpred, on_ready=None, sync=None, global_batch=None, generation=None):
         """Gradients of every parameter into the grad arena (overwritten).  ``generation`` (the

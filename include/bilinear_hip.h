@@ -94,6 +94,11 @@ typedef enum {
                              at most one 128 KB-LDS workgroup per CU — the dispatcher then runs
                              them one after the other without a cross-queue latency — else 1.
                              Scheduling only: results are bit-identical.                     */
+  BLH_OPT_SMALL_STEP = 4, /* default 1: blh_train_step / blh_train_step_captured with gemm_dtype 0, at most 64 rows
+                             and width <= 1024 run as ONE persistent launch (small_step.hip: grid barriers between
+                             the stages, every workgroup resident) instead of ~50 launches — the reference's own
+                             batch size, /root/reference/util/config.py:15.  0: the multi-launch path.  Same
+                             arithmetic up to the order of fp32 sums (both within the fp32 parity tolerance). */
   BLH_OPT_PERSISTENT_SHADOW = 3
                           /* gemm_dtype 4 only, default 0.  1: the Adam kernel of blh_train_step /
                              blh_train_step_captured also writes the bf16 image of the updated

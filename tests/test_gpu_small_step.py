@@ -1,0 +1,116 @@
+"""The one-launch training step for batches of at most 64 rows (csrc/small_step.hip, BLH_OPT_SMALL_STEP): the
+reference's own batch size (/root/reference/util/config.py:15).  The golden-vector tests of test_gpu_parity.py
+(reference fixtures at B = 8 and 64) run through it by default; here it is compared with the multi-launch path
+on the same inputs — every tensor the step writes — over ragged batches, widths and depths, with Philox and with
+explicit dropout masks, and against the fp64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda", 0)
+
+
+def _rel(a, b):
+    a = a.double().flatten(); b = b.double().flatten()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def _pair(dev, nb, width, seed=11):
+    import bilinear_amd
+    nets = []
+    for small in (True, False):
+        torch.manual_seed(seed)
+        net, opt, _, _ = bilinear_amd.load(dev, num_blocks=nb, width=width, gemm_dtype="fp32")
+        net.train()
+        net.engine.ensure(dev)
+        net.engine.seed = 4242
+        net.engine.set_small_step(small)
+        nets.append((net, opt))
+    return nets
+
+
+@pytest.mark.parametrize("nb,width,batch", [(2, 1024, 64), (2, 1024, 8), (2, 1024, 33), (1, 256, 2), (0, 64, 17),
+                                            (4, 512, 64), (3, 1024, 50)])
+def test_small_step_equals_the_multi_launch_step(nb, width, batch):
+    dev = _dev()
+    (na, oa), (nb_, ob) = _pair(dev, nb, width)
+    assert na.engine.ctx.get_option(4) == 1 and nb_.engine.ctx.get_option(4) == 0
+    g = torch.Generator().manual_seed(batch)
+    # (at B = 2 BatchNorm leaves gradients that are rounding noise, which Adam's sign-like update amplifies into
+    #  the parameters: one step there, three elsewhere)
+    steps = 1 if batch < 8 else 3
+    for s in range(steps):
+        x = torch.randn(batch, 32, generator=g).to(dev)
+        t = torch.randn(batch, 48, generator=g).to(dev)
+        pa, la = na.train_step(oa, x, t, max_norm=1.0)
+        pb, lb = nb_.train_step(ob, x, t, max_norm=1.0)
+        torch.cuda.synchronize()
+        assert na.engine.ctx.grid_barrier_timeouts() == 0
+        # a ReLU gate within rounding of zero may open on one path and not on the other: whole-tensor norms
+        tol = 2e-5 * (s + 1)
+        assert _rel(pa, pb) <= tol, ("pred", s, _rel(pa, pb))
+        assert abs(la.item() - lb.item()) <= tol * abs(lb.item())
+        assert _rel(na.engine.grads, nb_.engine.grads) <= 10 * tol, ("grads", s, _rel(na.engine.grads, nb_.engine.grads))
+        assert _rel(oa._exp_avg, ob._exp_avg) <= 10 * tol
+        assert _rel(oa._exp_avg_sq, ob._exp_avg_sq) <= 20 * tol
+        # (Adam's update is sign-like where the gradient is rounding noise — at B = 2 BatchNorm leaves nothing
+        #  else — so the parameters get the bound of one update per step next to the norm)
+        assert float((na.engine.params - nb_.engine.params).abs().max()) <= 2.1e-3 * (s + 1)
+        assert _rel(na.engine.params, nb_.engine.params) <= (tol if batch * width >= 64 * 512 else 1e-3)
+        assert _rel(na.engine.bn_running, nb_.engine.bn_running) <= tol
+        sa, sb = oa.last_grad_norm_stats.cpu(), ob.last_grad_norm_stats.cpu()
+        assert abs(sa[0] - sb[0]) <= 10 * tol * abs(sb[0]) and abs(sa[1] - sb[1]) <= 10 * tol
+    assert int(na.encode[1].num_batches_tracked) == steps == int(nb_.encode[1].num_batches_tracked)
+
+
+def test_small_step_is_deterministic():
+    """Two runs of the same steps are bit-identical (every sum has a fixed order)."""
+    dev = _dev()
+    (na, oa), _ = _pair(dev, 2, 1024)
+    (nc, oc), _ = _pair(dev, 2, 1024)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(64, 32, generator=g).to(dev); t = torch.randn(64, 48, generator=g).to(dev)
+    for _ in range(3):
+        pa, la = na.train_step(oa, x, t)
+        pc, lc = nc.train_step(oc, x, t)
+        assert torch.equal(pa, pc) and la.item() == lc.item()
+    assert torch.equal(na.engine.params, nc.engine.params) and torch.equal(oa._exp_avg_sq, oc._exp_avg_sq)
+    assert torch.equal(na.engine.grads, nc.engine.grads) and torch.equal(na.engine.bn_running, nc.engine.bn_running)
+
+
+@pytest.mark.parametrize("batch", [64, 24])
+def test_small_step_against_the_fp64_oracle_and_philox_replay(batch):
+    """(a) explicit gate-safe masks: every observable of the step against oracle/numpy_oracle.py at the tight fp32
+    tolerance of the timed-path tests; (b) the Philox step is bit-identical to the explicit-mask step fed the
+    materialised Philox masks (same keep bits as the multi-launch kernels, philox.h)."""
+    import test_gpu_timed_path as T
+    dev = _dev()
+    nb, width = 2, 1024
+    entry = T._entry_with_masks(nb, width, batch, dev)
+    xt, tt = torch.from_numpy(entry["x"]).to(dev), torch.from_numpy(entry["t"]).to(dev)
+    r = T._run_oracle(entry, entry["safe"])
+    net, opt = T._build(entry["st0"], dev, nb, width, "fp32")
+    assert net.engine.ctx.get_option(4) == 1
+    net.engine.set_dropout_masks(entry["safe"])
+    pred, loss = net.train_step(opt, xt, tt, max_norm=1.0)
+    torch.cuda.synchronize()
+    assert net.engine.ctx.grid_barrier_timeouts() == 0
+    T._compare_fused_step(net, opt, pred, loss.item(), r, T.TIGHT)
+    out = []
+    for explicit in (False, True):
+        net, opt = T._build(entry["st0"], dev, nb, width, "fp32")
+        if explicit:
+            net.engine.set_dropout_masks(entry["philox"])
+        pred, loss = net.train_step(opt, xt, tt, max_norm=1.0)
+        torch.cuda.synchronize()
+        out.append((pred.clone(), net.engine.grads.clone(), net.engine.params.clone(), opt._exp_avg.clone(),
+                    net.engine.bn_running.clone(), loss.item()))
+    for a, b, what in zip(out[0][:5], out[1][:5], ("pred", "grads", "params", "exp_avg", "running")):
+        assert torch.equal(a, b), what
+    assert out[0][5] == out[1][5]
