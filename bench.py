@@ -560,6 +560,43 @@ def config_block(idx, dev, steps, ramp_ms):
     return out
 
 
+def batch64_block(dev, steps, ramp_ms):
+    """The reference's own batch size (util/config.py:15: 64 poses; BASELINE configs[0]'s shape) on the GPU, fp32,
+    2 blocks x 1024: the whole step as ONE persistent launch (csrc/small_step.hip, the default at <= 64 rows) and,
+    beside it, the multi-launch path every larger batch takes."""
+    import bilinear_amd
+    torch.manual_seed(1)
+    net, opt, _, _ = bilinear_amd.load(dev, num_blocks=2, width=1024, gemm_dtype="fp32")
+    net.train()
+    net.engine.ensure(dev)
+    g = torch.Generator(device=dev).manual_seed(1000)
+    x = torch.randn(64, 32, device=dev, generator=g)
+    t = torch.randn(64, 48, device=dev, generator=g)
+
+    def one_step():
+        return net.train_step(opt, x, t, max_norm=1.0)
+    out = {}
+    for name, small in (("one_launch", True), ("multi_launch", False)):
+        net.engine.set_small_step(small)
+        pre_ramp(one_step, ramp_ms)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            _, loss = one_step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out[name] = {"ms_per_step": 1e3 * el / steps, "poses_per_s": 64 * steps / el, "final_loss": float(loss.item())}
+    timeouts = net.engine.ctx.grid_barrier_timeouts()
+    del net, opt
+    torch.cuda.empty_cache()
+    return {"workload": "2 blocks x 1024, batch 64 (the reference's batch_size), fp32, whole training step",
+            "value": out["one_launch"]["poses_per_s"], "unit": "poses/s",
+            "ms_per_step": out["one_launch"]["ms_per_step"], "steps": steps,
+            "launch": "one persistent launch per step (small_step.hip: a grid barrier per stage)",
+            "grid_barrier_timeouts": timeouts,
+            "multi_launch": out["multi_launch"], "final_loss": out["one_launch"]["final_loss"]}
+
+
 DTYPE_TEXT = {"fp32": "f32", "bf16x3": "f32 (operands split into 3 bf16 pieces, bf16 MFMA, fp32 accumulate)",
               "fp16x2": "f32 (operands split into 2 scaled fp16 pieces, f16 MFMA, fp32 accumulate)",
               "bf16s": "bf16 (activations / gradients / weight shadow stored in bf16, bf16 MFMA, fp32 "
@@ -855,6 +892,9 @@ def main():
                 log("configs[%d]: %.3f ms/step, %.3g poses/s, fwd GEMM %.0f TFLOP/s" % (
                     idx, b["ms_per_step"], b["value"], b["roofline"]["achieved"]))
             result["configs"] = blocks
+            result["batch_64"] = batch64_block(dev, 10 * args.config_steps, args.pre_ramp_ms)
+            log("batch 64: %.3f ms/step in one launch, %.3f multi-launch" % (
+                result["batch_64"]["ms_per_step"], result["batch_64"]["multi_launch"]["ms_per_step"]))
         if world == 1 and not args.no_cpu_baseline:
             from oracle import torch_port as TP
             cores = host_cores()

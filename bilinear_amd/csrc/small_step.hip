@@ -48,6 +48,12 @@ __device__ __forceinline__ float4 ss_ld4(const float* p) { return *reinterpret_c
 __device__ __forceinline__ void ss_publish(float* p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// (the gradients too: every workgroup reads the whole gradient arena behind the last barrier)
+__device__ __forceinline__ void ss_publish4(float* p, float4 v) {
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  const f32x4_t q = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
+}
 
 // weights of one reduction pass, ROWS form (forward): wb[j][c] = Wrow[c][k .. k+3], k = 256 j + 4 lane
 __device__ __forceinline__ void ss_load_w_rows(WBlock& wb, const float* __restrict__ Wp, int K, int lane) {
@@ -203,7 +209,7 @@ __device__ __forceinline__ double ss_wgrad(const float4* __restrict__ sh_dz, con
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      *reinterpret_cast<float4*>(out + (int64_t)c * K + kq * 4) = acc[c];
+      ss_publish4(out + (int64_t)c * K + kq * 4, acc[c]);
       sq += (double)acc[c].x * acc[c].x + (double)acc[c].y * acc[c].y + (double)acc[c].z * acc[c].z +
             (double)acc[c].w * acc[c].w;
     }
@@ -322,12 +328,13 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(const SmallStepP
     }
     const float l4 = ss_colsum(diff * diff, sh_cs, wave, lane);
     // the four column sums -> one partial per workgroup
-    if (tid == 0) p.loss_part[g] = (sh_cs[0] + sh_cs[4] + sh_cs[8] + sh_cs[12]) + (sh_cs[1] + sh_cs[5] + sh_cs[9] + sh_cs[13]) +
-                                   (sh_cs[2] + sh_cs[6] + sh_cs[10] + sh_cs[14]) + (sh_cs[3] + sh_cs[7] + sh_cs[11] + sh_cs[15]);
+    if (tid == 0)
+      ss_publish(&p.loss_part[g], (sh_cs[0] + sh_cs[4] + sh_cs[8] + sh_cs[12]) + (sh_cs[1] + sh_cs[5] + sh_cs[9] + sh_cs[13]) +
+                                      (sh_cs[2] + sh_cs[6] + sh_cs[10] + sh_cs[14]) + (sh_cs[3] + sh_cs[7] + sh_cs[11] + sh_cs[15]));
     (void)l4;
     const float dp = diff * p.mse_scale;
     const float db = ss_colsum(dp, sh_cs, wave, lane);
-    if (row == 0) { p.grads[p.dec_b + oc] = db; sq += (double)db * db; }
+    if (row == 0) { ss_publish(&p.grads[p.dec_b + oc], db); sq += (double)db * db; }
     __syncthreads();
     reinterpret_cast<float*>(sh_dz)[tid] = dp;          // [row][c]
   }
@@ -361,9 +368,9 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(const SmallStepP
       const float dz = valid ? sc * (dy - (s_b + xhat * s_g) * inv_b) : 0.f;
       const float dbias = ss_colsum(dz, sh_cs, wave, lane);
       if (row == 0) {
-        p.grads[p.g_off[i] + col] = s_g;
-        p.grads[p.be_off[i] + col] = s_b;
-        p.grads[p.b_off[i] + col] = dbias;
+        ss_publish(&p.grads[p.g_off[i] + col], s_g);
+        ss_publish(&p.grads[p.be_off[i] + col], s_b);
+        ss_publish(&p.grads[p.b_off[i] + col], dbias);
         sq += (double)s_g * s_g + (double)s_b * s_b + (double)dbias * dbias;
       }
       if (i >= 1 && valid) ss_publish(&p.dZ[i][(int64_t)row * W + col], dz);
@@ -385,8 +392,9 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(const SmallStepP
 
   // ------------------------------------------------------------------ clip + Adam ----
   const double wg_sq = ss_block_sum(sq, sh_d);
-  if (tid == 0) p.sumsq_part[g] = wg_sq;
-  bar.sync();
+  if (tid == 0) __hip_atomic_store(&p.sumsq_part[g], wg_sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bar.arrive_published();          // (gradients, loss and norm partials all went out write-through)
+  bar.wait();
   stamp();
   double a = 0.0;
   for (int k = tid; k < (int)gridDim.x; k += SS_THREADS) a += p.sumsq_part[k];

@@ -8,7 +8,7 @@
 using namespace blh;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-template <int MODE>   // 0: full barrier; 1: no fences (atomics only); 2: full + each workgroup dirties `kb` KB before
+template <int MODE, int SLEEP = 1>   // 0: full barrier; 1: no fences (atomics only); 2: full + each workgroup dirties `kb` KB before
 __global__ __launch_bounds__(256) void bench(uint32_t* bar, int n, float* buf, int kb, unsigned long long* out) {
   GridBarrier b{bar, gridDim.x, 0u};
   b.init();
@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void bench(uint32_t* bar, int n, float* buf, i
         if (MODE == 3 || MODE == 5) asm volatile("buffer_wbl2 sc1\n s_waitcnt vmcnt(0)" ::: "memory");
         (void)__hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while ((int32_t)(__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - b.target) < 0)
-          __builtin_amdgcn_s_sleep(1);
+          if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
         if (MODE == 4 || MODE == 5) asm volatile("buffer_inv sc1\n s_waitcnt vmcnt(0)" ::: "memory");
         b.target += b.nwg;
       }
@@ -51,6 +51,10 @@ int main() {
   for (int rep = 0; rep < 2; ++rep) {
     hipLaunchKernelGGL(bench<0>, dim3(256), dim3(256), 0, 0, bar, n, buf, 0, out); report("release + add + poll + acquire");
     hipLaunchKernelGGL(bench<1>, dim3(256), dim3(256), 0, 0, bar, n, buf, 0, out); report("add + poll only (no fences)");
+    hipLaunchKernelGGL((bench<1, 0>), dim3(256), dim3(256), 0, 0, bar, n, buf, 0, out); report("add + poll, no sleep");
+    hipLaunchKernelGGL((bench<1, 4>), dim3(256), dim3(256), 0, 0, bar, n, buf, 0, out); report("add + poll, s_sleep 4");
+    hipLaunchKernelGGL((bench<1, 16>), dim3(256), dim3(256), 0, 0, bar, n, buf, 0, out); report("add + poll, s_sleep 16");
+    hipLaunchKernelGGL((bench<1, 64>), dim3(256), dim3(256), 0, 0, bar, n, buf, 0, out); report("add + poll, s_sleep 64");
     hipLaunchKernelGGL(bench<3>, dim3(256), dim3(256), 0, 0, bar, n, buf, 0, out); report("wbl2 + add + poll");
     hipLaunchKernelGGL(bench<4>, dim3(256), dim3(256), 0, 0, bar, n, buf, 0, out); report("add + poll + inv");
     hipLaunchKernelGGL(bench<5>, dim3(256), dim3(256), 0, 0, bar, n, buf, 0, out); report("wbl2 + add + poll + inv");
