@@ -37,7 +37,8 @@ namespace {
 constexpr int SS_THREADS = 256;
 constexpr int SS_MAX_ROWS = 64;
 constexpr int SS_PASSES = 4;            // reduction length <= 4 * 256
-constexpr int SS_RB = 8;                // rows per batch of loads in ss_gemm (x 4 passes = 16 loads in flight per wave)
+constexpr int SS_RB = 8;                // rows per batch of loads in ss_gemm (x 4 passes = 32 loads in flight per wave;
+                                        // all 64 at once was tried: the allocator spills)
 
 typedef float4 WBlock[SS_PASSES][4];
 
@@ -94,6 +95,11 @@ template <bool COLS>
 __device__ __forceinline__ float ss_gemm(const WBlock& wb, const float* __restrict__ In, int ld, int K, int batch,
                                          int wave, int lane) {
   float out = 0.f;
+  // (addresses as uniform row base + unsigned 32-bit lane offset: the saddr form of global_load, one VGPR per
+  //  pass instead of a 64-bit address pair per load)
+  uint32_t koff[SS_PASSES];
+#pragma unroll
+  for (int j = 0; j < SS_PASSES; ++j) koff[j] = (uint32_t)min(j * 256 + lane * 4, K - 4) * 4u;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     float acc[8][4];
@@ -107,9 +113,9 @@ __device__ __forceinline__ float ss_gemm(const WBlock& wb, const float* __restri
 #pragma unroll
       for (int u = 0; u < SS_RB; ++u) {
         const int row = min(wave * 16 + half * 8 + rp * SS_RB + u, batch - 1);
+        const char* base = reinterpret_cast<const char*>(In + (int64_t)row * ld);
 #pragma unroll
-        for (int j = 0; j < SS_PASSES; ++j)
-          a[u][j] = ss_ld4(In + (int64_t)row * ld + min(j * 256 + lane * 4, K - 4));
+        for (int j = 0; j < SS_PASSES; ++j) a[u][j] = *reinterpret_cast<const float4*>(base + koff[j]);
       }
 #pragma unroll
       for (int u = 0; u < SS_RB; ++u) {
@@ -190,7 +196,7 @@ __device__ __forceinline__ double ss_wgrad(const float4* __restrict__ sh_dz, con
     float4 acc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = float4{0.f, 0.f, 0.f, 0.f};
-    for (int b0 = 0; b0 < batch; b0 += 16) {
+    for (int b0 = 0; b0 < batch; b0 += 16) {      // (32 rows per batch: the allocator spills, 213 us instead of 200)
       float4 a[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) a[u] = ss_ld4(In + (int64_t)min(b0 + u, batch - 1) * K + kq * 4);
@@ -239,7 +245,8 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(const SmallStepP
   float* sh_save = reinterpret_cast<float*>(ss_smem + 2048 + 1024 + 64);           // nh x (256 + 256 + 8) floats
   constexpr int SAVE_STRIDE = 256 + 256 + 8;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = tid >> 6;
   const int g = blockIdx.x;
   const int W = p.W, B = p.batch, nh = p.nh, OF = p.out_f;
   const int ngroups = W >> 2;
