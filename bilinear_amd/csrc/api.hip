@@ -210,6 +210,46 @@ static int check_drop(const blh_dropout* drop) {
   return BLH_OK;
 }
 
+// Batches of at most 64 rows in exact fp32 take the one-launch step (small_step.hip) when the device can hold
+// its grid; BLH_NO_SMALL_STEP=1 keeps the multi-launch path (A/B measurements, tests of that path).
+static bool small_step_applies(const blh_context* ctx, const blh_model_desc* d, int64_t batch) {
+  if (!ctx->small_step || d->gemm_dtype != 0 || batch > 64 || ctx->sync.fn || !ctx->grid_bar) return false;
+  static const bool off = getenv("BLH_NO_SMALL_STEP") != nullptr;
+  if (off) return false;
+  const int grid = small_step_max_grid(nullptr);
+  return grid > 0 && d->width / 4 <= grid && d->width <= 1024 && d->in_features <= 1024;
+}
+
+static int small_step(blh_context* ctx, const blh_model_desc* d, hipStream_t s, float* params, float* grads,
+                      float* exp_avg, float* exp_avg_sq, float* bn_running, int64_t* bn_nbt, const float* x,
+                      const float* target, const blh_dropout* drop, float momentum, const blh_adam_hyper* hyper,
+                      const blh_step_state* dev_state, const Workspace& ws, float* pred, float* loss_out,
+                      float* stats_out, int64_t batch, int phase = SS_ALL, const float* dpred = nullptr) {
+  const ArenaLayout L = make_layout(d);
+  SmallStepParams p{};
+  p.nh = (int)L.heavy.size(); p.W = d->width; p.in_f = d->in_features; p.out_f = d->out_features;
+  p.batch = (int)batch;
+  for (int i = 0; i < p.nh; ++i) {
+    p.w_off[i] = L.heavy[i].w; p.b_off[i] = L.heavy[i].b; p.g_off[i] = L.heavy[i].gamma; p.be_off[i] = L.heavy[i].beta;
+    p.A[i] = ws.A[i]; p.dZ[i] = ws.dZ[i]; p.Z[i] = ws.Z[i]; p.bn_saved[i] = ws.bn_saved[i];
+  }
+  p.dec_w = L.dec_w; p.dec_b = L.dec_b; p.count = L.total;
+  p.params = params; p.grads = grads; p.m = exp_avg; p.v = exp_avg_sq;
+  p.bn_running = bn_running; p.nbt = bn_nbt; p.x = x; p.target = target;
+  p.dpred = dpred ? const_cast<float*>(dpred) : ws.dpred; p.pred = pred; p.loss_out = loss_out; p.stats_out = stats_out;
+  p.loss_part = ws.loss_part; p.sumsq_part = ws.sumsq_part; p.bar = ctx->grid_bar + 4;      // (words 0-2: the bf16 fused forward stage's barrier)
+  p.drop = layer_drop(ctx, drop, 0, batch, d->width);
+  p.momentum = momentum;
+  p.denom = (double)batch * d->out_features;
+  p.mse_scale = (float)(2.0 / p.denom);
+  if (hyper) {
+    if (hyper->step < 1) return BLH_ERR_INVALID_ARGUMENT;
+    p.adam = adam_consts(*hyper);
+  }
+  p.st = dev_state;
+  return launch_small_step(s, p, phase);
+}
+
 int blh_forward_train(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params,
                       float* bn_running, int64_t* bn_nbt, const float* x,
                       const blh_dropout* drop, float momentum, void* workspace,
@@ -222,6 +262,13 @@ int blh_forward_train(blh_context* ctx, const blh_model_desc* d, void* stream, c
     return forward_h(ctx, d, (hipStream_t)stream, params, bn_running, bn_nbt, x, drop, momentum,
                      carve_h(d, batch, workspace), pred, batch, true);
   const Workspace ws = carve(d, batch, workspace);
+  if (small_step_applies(ctx, d, batch)) {
+    // the drop-in forward at <= 64 rows: one launch; what it saves for backward is in the one-launch format
+    BLH_TRY(small_step(ctx, d, (hipStream_t)stream, const_cast<float*>(params), nullptr, nullptr, nullptr, bn_running,
+                       bn_nbt, x, nullptr, drop, momentum, nullptr, nullptr, ws, pred, nullptr, nullptr, batch, SS_FWD));
+    ctx->saved_small_ws = workspace; ctx->saved_small_batch = batch;
+    return BLH_OK;
+  }
   return forward_impl(ctx, d, (hipStream_t)stream, params, bn_running, bn_nbt, x, drop, momentum, ws,
                       pred, batch, true, nullptr, 0.f, nullptr, nullptr);
 }
@@ -305,6 +352,14 @@ int blh_backward(blh_context* ctx, const blh_model_desc* d, void* stream, const 
                       batch, on_ready, user, from_loss ? loss_nparts : 0);
   }
   const Workspace ws = carve(d, batch, workspace);
+  if (ctx->saved_small_ws == workspace && workspace) {
+    // the activations in this workspace were saved by the one-launch forward: only its backward can read them
+    if (from_loss || ctx->saved_small_batch != batch || ctx->sync.fn) return BLH_ERR_INVALID_ARGUMENT;
+    BLH_TRY(small_step(ctx, d, (hipStream_t)stream, const_cast<float*>(params), grads, nullptr, nullptr, nullptr, nullptr,
+                       x, nullptr, drop, 0.f, nullptr, nullptr, ws, nullptr, nullptr, nullptr, batch, SS_BWD, dpred));
+    if (on_ready) on_ready(user, 0, make_layout(d).total);     // every range at once
+    return BLH_OK;
+  }
   if (from_loss && loss_nparts > 0) {   // decode-bias partials of the fused decode kernel
     const FusedBackward fb{loss_nparts, nullptr, nullptr, nullptr};
     return backward_impl(ctx, d, (hipStream_t)stream, params, x, drop, ws, ws.dpred, grads, batch,
@@ -360,46 +415,6 @@ int blh_clip_grad_norm(void* stream, float* grads, int64_t count, float max_norm
   BLH_TRY(launch_sumsq((hipStream_t)stream, grads, count, sc.sumsq_part, &nparts));
   return launch_clip_scale((hipStream_t)stream, grads, count, max_norm, sc.sumsq_part, nparts,
                            stats_out);
-}
-
-// Batches of at most 64 rows in exact fp32 take the one-launch step (small_step.hip) when the device can hold
-// its grid; BLH_NO_SMALL_STEP=1 keeps the multi-launch path (A/B measurements, tests of that path).
-static bool small_step_applies(const blh_context* ctx, const blh_model_desc* d, int64_t batch) {
-  if (!ctx->small_step || d->gemm_dtype != 0 || batch > 64 || ctx->sync.fn || !ctx->grid_bar) return false;
-  static const bool off = getenv("BLH_NO_SMALL_STEP") != nullptr;
-  if (off) return false;
-  const int grid = small_step_max_grid(nullptr);
-  return grid > 0 && d->width / 4 <= grid && d->width <= 1024 && d->in_features <= 1024;
-}
-
-static int small_step(blh_context* ctx, const blh_model_desc* d, hipStream_t s, float* params, float* grads,
-                      float* exp_avg, float* exp_avg_sq, float* bn_running, int64_t* bn_nbt, const float* x,
-                      const float* target, const blh_dropout* drop, float momentum, const blh_adam_hyper* hyper,
-                      const blh_step_state* dev_state, const Workspace& ws, float* pred, float* loss_out,
-                      float* stats_out, int64_t batch) {
-  const ArenaLayout L = make_layout(d);
-  SmallStepParams p{};
-  p.nh = (int)L.heavy.size(); p.W = d->width; p.in_f = d->in_features; p.out_f = d->out_features;
-  p.batch = (int)batch;
-  for (int i = 0; i < p.nh; ++i) {
-    p.w_off[i] = L.heavy[i].w; p.b_off[i] = L.heavy[i].b; p.g_off[i] = L.heavy[i].gamma; p.be_off[i] = L.heavy[i].beta;
-    p.A[i] = ws.A[i]; p.dZ[i] = ws.dZ[i];
-  }
-  p.dec_w = L.dec_w; p.dec_b = L.dec_b; p.count = L.total;
-  p.params = params; p.grads = grads; p.m = exp_avg; p.v = exp_avg_sq;
-  p.bn_running = bn_running; p.nbt = bn_nbt; p.x = x; p.target = target;
-  p.dpred = ws.dpred; p.pred = pred; p.loss_out = loss_out; p.stats_out = stats_out;
-  p.loss_part = ws.loss_part; p.sumsq_part = ws.sumsq_part; p.bar = ctx->grid_bar + 4;      // (words 0-2: the bf16 fused forward stage's barrier)
-  p.drop = layer_drop(ctx, drop, 0, batch, d->width);
-  p.momentum = momentum;
-  p.denom = (double)batch * d->out_features;
-  p.mse_scale = (float)(2.0 / p.denom);
-  if (hyper) {
-    if (hyper->step < 1) return BLH_ERR_INVALID_ARGUMENT;
-    p.adam = adam_consts(*hyper);
-  }
-  p.st = dev_state;
-  return launch_small_step(s, p);
 }
 
 int blh_train_step(blh_context* ctx, const blh_model_desc* d, void* stream, float* params, float* grads,

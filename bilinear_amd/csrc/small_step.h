@@ -5,6 +5,7 @@
 namespace blh {
 
 constexpr int SS_MAX_STAGES = 33;        // 1 + 2 * num_blocks (api_layout.h: check_desc)
+enum SmallStepPhase { SS_ALL = 0, SS_FWD = 1, SS_BWD = 2 };
 
 struct SmallStepParams {
   int nh, W, in_f, out_f, batch;
@@ -15,6 +16,8 @@ struct SmallStepParams {
   const float* x; const float* target;
   float* A[SS_MAX_STAGES];               // [batch][W] per stage (workspace)
   float* dZ[SS_MAX_STAGES];
+  float* Z[SS_MAX_STAGES];               // SS_FWD / SS_BWD: x-hat crosses the two launches here (the gate in dZ)
+  float* bn_saved[SS_MAX_STAGES];        // [4][W] mean, invstd, scale, shift
   float* dpred;                          // [batch][out_f]
   float* pred; float* loss_out; float* stats_out;
   float* loss_part;                      // [out_f / 4]
@@ -30,6 +33,6 @@ struct SmallStepParams {
 
 // number of workgroups of the launch (= CUs of the device) if all of them can be resident at once, else 0
 int small_step_max_grid(int* num_cus_out);
-int launch_small_step(hipStream_t s, const SmallStepParams& p);
+int launch_small_step(hipStream_t s, const SmallStepParams& p, int phase = SS_ALL);
 
 }  // namespace blh

@@ -53,7 +53,10 @@ __device__ __forceinline__ void ss_publish(float* p, float v) {
 __device__ __forceinline__ void ss_publish4(float* p, float4 v) {
   typedef float f32x4_t __attribute__((ext_vector_type(4)));
   const f32x4_t q = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
+  // (s_nop: a VMEM store of more than 64 bits must not be followed at once by a VALU write of the VGPRs that hold
+  //  its data — the compiler inserts that wait state for its own stores, it cannot for inline asm; without it the
+  //  split kernels stored 20 % wrong weight gradients, tools_dev/small_dropin_debug.py)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(q) : "memory");
 }
 
 // weights of one reduction pass, ROWS form (forward): wb[j][c] = Wrow[c][k .. k+3], k = 256 j + 4 lane
@@ -236,7 +239,12 @@ __device__ __forceinline__ double ss_block_sum(double v, double* sh) {
 
 }  // namespace
 
+// PHASE SS_ALL: the whole step.  SS_FWD / SS_BWD: the two halves the drop-in surface calls separately
+// (blh_forward_train, blh_backward: /root/reference/train_bilinear.py:76,79 with nn.MSELoss, clip_grad_norm_ and
+// Adam.step as their own calls between / behind them); what backward needs of forward then crosses the two launches
+// in the workspace (x-hat in Z, the gate in dZ, gamma * invstd in the saved-statistics rows) instead of in LDS.
 // LDS: [0, 2 KB) scratch doubles for block sums | 64 float4 dz | 16 floats colsum | per stage: x-hat[256], gate[256], bn[8]
+template <int PHASE>
 __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(const SmallStepParams p) {
   extern __shared__ __align__(16) unsigned char ss_smem[];
   double* sh_d = reinterpret_cast<double*>(ss_smem);                               // 256 doubles
@@ -270,10 +278,10 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(const SmallStepP
   stamp();
 
   WBlock wb;
-  if (own) ss_load_w_rows(wb, p.params + p.w_off[0] + (int64_t)n0 * p.in_f, p.in_f, lane);
+  if (PHASE != SS_BWD && own) ss_load_w_rows(wb, p.params + p.w_off[0] + (int64_t)n0 * p.in_f, p.in_f, lane);
 
   // ------------------------------------------------------------------ forward ----
-  for (int i = 0; i < nh; ++i) {
+  for (int i = 0; PHASE != SS_BWD && i < nh; ++i) {
     const int K = (i == 0) ? p.in_f : W;
     const float* in = (i == 0) ? p.x : p.A[i - 1];
     if (own) {
@@ -305,10 +313,21 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(const SmallStepP
       const bool on = kept && y > 0.f;
       const float a = (on ? y * 2.f : 0.f) + skipv;
       if (valid) ss_publish(&p.A[i][(int64_t)row * W + col], a);
-      float* sv = sh_save + i * SAVE_STRIDE;
-      sv[tid] = dlt * invstd;                 // x-hat
-      sv[256 + tid] = on ? 2.f : 0.f;         // d a / d y
-      if (row == 0) { sv[512 + c] = sc; }
+      if (PHASE == SS_ALL) {
+        float* sv = sh_save + i * SAVE_STRIDE;
+        sv[tid] = dlt * invstd;                 // x-hat
+        sv[256 + tid] = on ? 2.f : 0.f;         // d a / d y
+        if (row == 0) { sv[512 + c] = sc; }
+      } else {
+        if (valid) {
+          p.Z[i][(int64_t)row * W + col] = dlt * invstd;
+          p.dZ[i][(int64_t)row * W + col] = on ? 2.f : 0.f;
+        }
+        if (row == 0) {
+          float* st = p.bn_saved[i];
+          st[col] = mean; st[W + col] = invstd; st[2 * W + col] = sc; st[3 * W + col] = sh;
+        }
+      }
     }
     stamp();
     // weights of the next stage (or of decode): nobody else writes them, so ask before waiting
@@ -322,44 +341,67 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(const SmallStepP
     stamp();
   }
 
-  // ------------------------------------------------------------------ decode + MSE ----
+  // ------------------------------------------------------------------ decode (+ MSE) ----
   float g_even = 0.f;      // gradient w.r.t. the output of the last even stage (the block skip source)
+  if (PHASE == SS_FWD) {   // forward only: the prediction, and the BatchNorm counters once everybody has read them
+    if (own_dec) {
+      const int oc = o0 + c;
+      const float pr = ss_gemm<false>(wb, p.A[nh - 1], W, W, B, wave, lane) + p.params[p.dec_b + oc];
+      if (valid) p.pred[(int64_t)row * OF + oc] = pr;
+    }
+    if (g == 0) {
+      if (tid == 0) for (int i = 0; i < nh; ++i) p.nbt[i] += 1;
+      bar.finish();
+    }
+    stamp();
+    return;
+  }
   if (own_dec) {
     const int oc = o0 + c;
-    const float pr = ss_gemm<false>(wb, p.A[nh - 1], W, W, B, wave, lane) + p.params[p.dec_b + oc];
-    float diff = 0.f;
-    if (valid) {
-      p.pred[(int64_t)row * OF + oc] = pr;
-      diff = pr - p.target[(int64_t)row * OF + oc];
-      ss_publish(&p.dpred[(int64_t)row * OF + oc], diff * p.mse_scale);
+    float dp = 0.f;
+    if (PHASE == SS_ALL) {
+      const float pr = ss_gemm<false>(wb, p.A[nh - 1], W, W, B, wave, lane) + p.params[p.dec_b + oc];
+      float diff = 0.f;
+      if (valid) {
+        p.pred[(int64_t)row * OF + oc] = pr;
+        diff = pr - p.target[(int64_t)row * OF + oc];
+        ss_publish(&p.dpred[(int64_t)row * OF + oc], diff * p.mse_scale);
+      }
+      (void)ss_colsum(diff * diff, sh_cs, wave, lane);
+      // the four column sums -> one partial per workgroup
+      if (tid == 0)
+        ss_publish(&p.loss_part[g], (sh_cs[0] + sh_cs[4] + sh_cs[8] + sh_cs[12]) + (sh_cs[1] + sh_cs[5] + sh_cs[9] + sh_cs[13]) +
+                                        (sh_cs[2] + sh_cs[6] + sh_cs[10] + sh_cs[14]) + (sh_cs[3] + sh_cs[7] + sh_cs[11] + sh_cs[15]));
+      dp = diff * p.mse_scale;
+    } else {               // backward only: d loss / d prediction comes from the caller
+      dp = valid ? p.dpred[(int64_t)row * OF + oc] : 0.f;
     }
-    const float l4 = ss_colsum(diff * diff, sh_cs, wave, lane);
-    // the four column sums -> one partial per workgroup
-    if (tid == 0)
-      ss_publish(&p.loss_part[g], (sh_cs[0] + sh_cs[4] + sh_cs[8] + sh_cs[12]) + (sh_cs[1] + sh_cs[5] + sh_cs[9] + sh_cs[13]) +
-                                      (sh_cs[2] + sh_cs[6] + sh_cs[10] + sh_cs[14]) + (sh_cs[3] + sh_cs[7] + sh_cs[11] + sh_cs[15]));
-    (void)l4;
-    const float dp = diff * p.mse_scale;
     const float db = ss_colsum(dp, sh_cs, wave, lane);
     if (row == 0) { ss_publish(&p.grads[p.dec_b + oc], db); sq += (double)db * db; }
     __syncthreads();
     reinterpret_cast<float*>(sh_dz)[tid] = dp;          // [row][c]
   }
   stamp();
-  bar.arrive_published();
+  if (PHASE == SS_ALL) bar.arrive_published();          // (backward only: dpred is an input of the launch)
   if (own_dec) {
     __syncthreads();
     sq += ss_wgrad(sh_dz, p.A[nh - 1], W, B, p.grads + p.dec_w + (int64_t)o0 * W);
   }
   // decode weights, COLUMNS form: [OF][W], reduction over the OF outputs
   if (own) ss_load_w_cols(wb, p.params + p.dec_w + n0, OF, W, lane);
-  bar.wait();
+  if (PHASE == SS_ALL) bar.wait();
   stamp();
 
   // ------------------------------------------------------------------ backward ----
   for (int i = nh - 1; i >= 0; --i) {
     if (own) {
       const bool top = (i == nh - 1);
+      // (backward only: what forward left in the workspace, requested before the GEMM)
+      float sx = 0.f, sg = 0.f, ss = 0.f;
+      if (PHASE == SS_BWD) {
+        if (valid) { sx = p.Z[i][(int64_t)row * W + col]; sg = p.dZ[i][(int64_t)row * W + col]; }
+        ss = p.bn_saved[i][2 * W + col];
+      }
       float ga = top ? ss_gemm<true>(wb, p.dpred, OF, OF, B, wave, lane)
                      : ss_gemm<true>(wb, p.dZ[i + 1], W, W, B, wave, lane);
       stamp();
@@ -367,8 +409,13 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(const SmallStepP
         if (!top) ga += g_even;
         g_even = ga;
       }
-      const float* sv = sh_save + i * SAVE_STRIDE;
-      const float xhat = sv[tid], gate = sv[256 + tid], sc = sv[512 + c];
+      float xhat, gate, sc;
+      if (PHASE == SS_ALL) {
+        const float* sv = sh_save + i * SAVE_STRIDE;
+        xhat = sv[tid]; gate = sv[256 + tid]; sc = sv[512 + c];
+      } else {
+        xhat = sx; gate = sg; sc = ss;
+      }
       const float dy = valid ? ga * gate : 0.f;
       const float s_b = ss_colsum(dy, sh_cs, wave, lane);             // d beta
       const float s_g = ss_colsum(dy * xhat, sh_cs, wave, lane);      // d gamma
@@ -397,6 +444,11 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(const SmallStepP
     stamp();
   }
 
+  if (PHASE == SS_BWD) {           // the gradient arena is complete (clip_grad_norm_ and Adam.step are the caller's next calls)
+    if (g == 0) bar.finish();
+    stamp();
+    return;
+  }
   // ------------------------------------------------------------------ clip + Adam ----
   const double wg_sq = ss_block_sum(sq, sh_d);
   if (tid == 0) __hip_atomic_store(&p.sumsq_part[g], wg_sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -450,24 +502,35 @@ int small_step_max_grid(int* num_cus_out) {
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     const size_t lds = small_step_lds_bytes(SS_MAX_STAGES);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(small_step_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, small_step_kernel, SS_THREADS, lds) != hipSuccess)
-      return 0;
-    fits = per_cu >= 1 ? n : 0;
+    int worst = 1 << 30;
+    auto probe = [&](auto kern) {
+      int per_cu = 0;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SS_THREADS, lds) != hipSuccess)
+        per_cu = 0;
+      worst = per_cu < worst ? per_cu : worst;
+    };
+    probe(small_step_kernel<SS_ALL>);
+    probe(small_step_kernel<SS_FWD>);
+    probe(small_step_kernel<SS_BWD>);
+    fits = worst >= 1 ? n : 0;
     cus = n;
   }
   if (num_cus_out) *num_cus_out = cus;
   return fits;
 }
 
-int launch_small_step(hipStream_t s, const SmallStepParams& p) {
+int launch_small_step(hipStream_t s, const SmallStepParams& p, int phase) {
   const int grid = small_step_max_grid(nullptr);
   if (grid <= 0 || p.W / 4 > grid || p.batch > SS_MAX_ROWS || p.nh > SS_MAX_STAGES || p.W > 256 * SS_PASSES ||
       p.in_f > 256 * SS_PASSES || p.out_f > 256 * SS_PASSES)
     return BLH_ERR_SHAPE;
-  hipLaunchKernelGGL(small_step_kernel, dim3((unsigned)grid), dim3(SS_THREADS), small_step_lds_bytes(p.nh), s, p);
+  const size_t lds = small_step_lds_bytes(p.nh);
+  if (phase == SS_ALL) hipLaunchKernelGGL(small_step_kernel<SS_ALL>, dim3((unsigned)grid), dim3(SS_THREADS), lds, s, p);
+  else if (phase == SS_FWD) hipLaunchKernelGGL(small_step_kernel<SS_FWD>, dim3((unsigned)grid), dim3(SS_THREADS), lds, s, p);
+  else if (phase == SS_BWD) hipLaunchKernelGGL(small_step_kernel<SS_BWD>, dim3((unsigned)grid), dim3(SS_THREADS), lds, s, p);
+  else return BLH_ERR_INVALID_ARGUMENT;
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }

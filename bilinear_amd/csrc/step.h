@@ -36,6 +36,10 @@ struct blh_context {
   // step's Adam kernel left up to date (nullptr: none)
   bool persistent_shadow = false;
   bool small_step = true;
+  // the workspace whose saved activations are in the one-launch forward's format (small_step.hip, SS_FWD), and
+  // their batch; any multi-launch train-mode forward on the context clears it (forward_impl)
+  const void* saved_small_ws = nullptr;
+  int64_t saved_small_batch = 0;
   const void* shadow_params = nullptr;
   const void* shadow_ws = nullptr;
   // grid barrier of the fused forward stage (gemm_bf16s_bnfwd.h): arrivals, generation, timeouts; device memory

@@ -15,6 +15,7 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
   const int nh = (int)L.heavy.size();
   const int W = d->width;
   const int tiles_m = (int)ceil_div(batch, 128);
+  if (train) ctx->saved_small_ws = nullptr;     // (the saved activations are in this path's format from here on)
   if (ws.amax_W)   // gemm_dtype 3: max |w| of every hidden Linear weight, once per forward
     for (int i = 1; i < nh; ++i)
       BLH_TRY(launch_wamax(s, params + L.heavy[i].w, 0, 1, (int64_t)W * W, ws.amax_W + (int64_t)i * WAMAX_PARTS));

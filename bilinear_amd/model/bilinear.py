@@ -131,6 +131,13 @@ def heavy_linear(in_features, out_features, bias=True):
     )
 
 
+# Which autograd bridge the eager drop-in forward takes: "op" = the differentiable custom operator
+# (torch.ops.bilinear_hip.lifter_train, the only form torch.compile can trace — it is always used while compiling),
+# "function" (default) = the plain autograd.Function below: same kernels, bit-identical results, 70 us less host
+# time per step (tools_dev/dropin_b64.py: the five-call step at batch 64 is host-bound).
+EAGER_AUTOGRAD = "function"
+
+
 class _LifterFunction(torch.autograd.Function):
     """Autograd bridge for the drop-in surface: ``loss.backward()``
     (train_bilinear.py:79) lands in Engine.backward, which fills the flat gradient
@@ -216,7 +223,8 @@ class BilinearUnit(nn.Module):
             # the differentiable custom operator (torch.library.register_autograd) — unless gradients are being
             # accumulated into existing .grad tensors or a data-parallel bucket hook wants the ranges as they
             # complete: those need Python between the kernels (_LifterFunction)
-            if eng.grad_ready_hook is None and all(p.grad is None for p in params):
+            if eng.grad_ready_hook is None and all(p.grad is None for p in params) and (
+                    EAGER_AUTOGRAD == "op" or torch.compiler.is_compiling()):
                 return eng.forward_train_autograd(in_tensor)
             return _LifterFunction.apply(in_tensor, eng, *params)
         return eng.forward_train(in_tensor)

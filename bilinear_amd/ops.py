@@ -183,7 +183,7 @@ def _lifter_backward(ctx, dpred):
         eng.backward(x, dpred, on_ready=None, generation=ctx.generation)
     else:                                                        # traced (AOTAutograd): the operator itself
         torch.ops.bilinear_hip.backward(x, dpred.contiguous(), params, workspace, grads, masks, *ctx.ints)
-    views = [grads[o:o + n].view(shape) for o, shape, n in ctx.slots]
+    views = [grads.as_strided(shape, (shape[1], 1) if len(shape) == 2 else (1,), o) for o, shape, n in ctx.slots]
     return (None, views) + (None,) * 15
 
 

@@ -39,6 +39,7 @@ class Adam(torch.optim.Optimizer):
         self._t = 0
         self._stats = None
         self._step_tensor = None
+        self._state_for = None          # the engine's parameter list the state views were built for
 
     # ---------------------------------------------------------------- moments --
     def _ensure_moments(self, engine):
@@ -57,7 +58,10 @@ class Adam(torch.optim.Optimizer):
                     self._t = max(self._t, int(float(st["step"])))
             self._exp_avg, self._exp_avg_sq = m, v
             self._stats = torch.zeros(2, dtype=torch.float32, device=dev)
-        if fresh or any(p not in self.state for _, p, _, _ in engine._named_params()):
+        named = engine._named_params()
+        if not fresh and self._state_for is named and len(self.state) == len(named):
+            return                       # (same Parameter objects as when the state views were made)
+        if fresh or any(p not in self.state for _, p, _, _ in named):
             # one shared host scalar: torch.optim.Adam keeps a per-parameter `step`
             # tensor; they are always equal, so every entry aliases this one
             self._step_tensor = torch.tensor(float(self._t))
@@ -67,6 +71,7 @@ class Adam(torch.optim.Optimizer):
                     "exp_avg": self._exp_avg[off:off + p.numel()].view(shape),
                     "exp_avg_sq": self._exp_avg_sq[off:off + p.numel()].view(shape),
                 }
+        self._state_for = named
 
     def _sync_step_state(self, engine):
         self._step_tensor.fill_(float(self._t))
@@ -84,13 +89,12 @@ class Adam(torch.optim.Optimizer):
     def _gather_grads(self, engine):
         """Make sure every parameter's gradient sits in the arena slot."""
         missing = 0
-        for _, p, off, shape in engine._named_params():
-            if p.grad is None:
+        for (_, p, off, shape), ptr in zip(engine._named_params(), engine.grad_ptrs()):
+            g = p.grad
+            if g is None:
                 missing += 1
-                continue
-            view = engine.grad_view(off, shape)
-            if p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad)
+            elif g.data_ptr() != ptr:
+                engine.grad_view(off, shape).copy_(g)
         return missing
 
     @torch.no_grad()
@@ -152,12 +156,13 @@ def clip_grad_norm_(module_or_parameters, max_norm, module=None):
     engine = _engine_of(module)
     if engine.params is None:
         raise RuntimeError("no gradients: run a forward/backward first")
-    for _, p, off, shape in engine._named_params():
-        if p.grad is None:
+    for (_, p, off, shape), ptr in zip(engine._named_params(), engine.grad_ptrs()):
+        g = p.grad
+        if g is None:
             raise RuntimeError("clip_grad_norm_: a parameter has no gradient")
-        view = engine.grad_view(off, shape)
-        if p.grad.data_ptr() != view.data_ptr():
-            view.copy_(p.grad)
+        if g.data_ptr() != ptr:
+            view = engine.grad_view(off, shape)
+            view.copy_(g)
             p.grad = view
     stats = torch.empty(2, dtype=torch.float32, device=engine.device)
     sc = engine.scratch()

@@ -1007,7 +1007,7 @@ def test_train_step_operator_under_torch_compile_fullgraph():
         assert torch.equal(a, b)
 
 
-def test_drop_in_step_through_the_differentiable_operator():
+def test_drop_in_step_through_the_differentiable_operator(monkeypatch):
     """The five-call step of /root/reference/train_bilinear.py:75-83 (zero_grad, forward, MSELoss, backward,
     clip_grad_norm_, Adam.step) with ``loss.backward()`` going through ``torch.ops.bilinear_hip.lifter_train``'s
     registered autograd formula (torch.library.register_autograd): bit-identical to the autograd.Function bridge
@@ -1028,6 +1028,10 @@ def test_drop_in_step_through_the_differentiable_operator():
         net.engine.seed = 11
         return net, opt
 
+    import bilinear_amd.model.bilinear as MB
+    assert MB.EAGER_AUTOGRAD == "function"         # eager default: the lean bridge (the operator costs 70 us more per
+    monkeypatch.setattr(MB, "EAGER_AUTOGRAD", "op")   # step on the host); this test drives the operator in eager mode
+    request_default = lambda: monkeypatch.setattr(MB, "EAGER_AUTOGRAD", "function")
     outs = {}
     for path in ("operator", "function"):
         net, opt = make()
@@ -1081,6 +1085,9 @@ def test_drop_in_step_through_the_differentiable_operator():
     torch.cuda.synchronize()
     assert torch.equal(g_compiled, net2.engine.grads)
     assert abs(float(loss_c) - float(torch.nn.functional.mse_loss(opt2_pred, t))) == 0.0
+    request_default()
+    pred = net2(x)
+    assert type(pred.grad_fn).__name__ == "_LifterFunctionBackward"
 
 
 def test_contexts_of_one_device_share_the_side_stream_and_outlive_each_other():

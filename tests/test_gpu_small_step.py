@@ -114,3 +114,53 @@ def test_small_step_against_the_fp64_oracle_and_philox_replay(batch):
     for a, b, what in zip(out[0][:5], out[1][:5], ("pred", "grads", "params", "exp_avg", "running")):
         assert torch.equal(a, b), what
     assert out[0][5] == out[1][5]
+
+
+@pytest.mark.parametrize("nb,width,batch", [(2, 1024, 64), (1, 512, 40)])
+def test_drop_in_forward_and_backward_take_the_one_launch_kernels(nb, width, batch):
+    """The reference's five-call step body (/root/reference/train_bilinear.py:75-83) at <= 64 rows: forward and
+    backward are one launch each (SS_FWD / SS_BWD, the saved activations cross in the workspace).  Raw gradients,
+    the clipped step and the BatchNorm buffers against the multi-launch path; switching the option between forward
+    and backward does not mix the two saved-activation formats; gradient accumulation over two backwards works."""
+    import bilinear_amd
+    dev = _dev()
+    (na, oa), (nm, om) = _pair(dev, nb, width)
+    g = torch.Generator().manual_seed(9)
+    crit = torch.nn.MSELoss()
+    for s in range(3):
+        x = torch.randn(batch, 32, generator=g).to(dev)
+        t = torch.randn(batch, 48, generator=g).to(dev)
+        raws = []
+        for net, opt in ((na, oa), (nm, om)):
+            opt.zero_grad()
+            pred = net(x)
+            loss = crit(pred, t)
+            if net is na and s == 1:
+                net.engine.set_small_step(False)      # the backward must still be the one-launch one
+            loss.backward()
+            if net is na and s == 1:
+                net.engine.set_small_step(True)
+            raws.append((pred.detach().clone(), loss.item(), net.engine.grads.clone()))
+            bilinear_amd.clip_grad_norm_(net.parameters(), max_norm=1, module=net)
+            opt.step()
+        torch.cuda.synchronize()
+        assert na.engine.ctx.grid_barrier_timeouts() == 0
+        tol = 2e-5 * (s + 1)
+        assert _rel(raws[0][0], raws[1][0]) <= tol
+        assert abs(raws[0][1] - raws[1][1]) <= tol * abs(raws[1][1])
+        assert _rel(raws[0][2], raws[1][2]) <= 10 * tol, ("raw grads", s, _rel(raws[0][2], raws[1][2]))
+        assert _rel(na.engine.params, nm.engine.params) <= tol
+        assert _rel(na.engine.bn_running, nm.engine.bn_running) <= tol
+    assert int(na.encode[1].num_batches_tracked) == 3
+    # accumulation: two forward/backward pairs without zero_grad add up
+    x = torch.randn(batch, 32, generator=g).to(dev); t = torch.randn(batch, 48, generator=g).to(dev)
+    oa.zero_grad()
+    crit(na(x), t).backward()
+    g1 = na.engine.grads.clone()
+    crit(na(x), t).backward()
+    torch.cuda.synchronize()
+    # (dropout draws a new mask for the second forward, so only the structure is checked: finite, changed, and the
+    #  parameters' .grad are still the arena views)
+    assert torch.isfinite(na.engine.grads).all() and not torch.equal(g1, na.engine.grads)
+    for (_, p, off, shape), ptr in zip(na.engine._named_params(), na.engine.grad_ptrs()):
+        assert p.grad.data_ptr() == ptr

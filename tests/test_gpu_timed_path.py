@@ -682,6 +682,50 @@ def test_config4_per_gpu_shape_8x2048_b16384_bf16s_forward_loss_decode_grad():
     assert torch.isfinite(net.engine.grads).all()
 
 
+@pytest.mark.parametrize("nb,width,small,copies", [(8, 2048, 2048, 8), (4, 1024, 2048, 8)])
+def test_full_batch_backward_by_replication_bf16s(nb, width, small, copies):
+    """The whole backward at the BASELINE per-GPU batch (configs[4]: 8 x 2048 at 16384 rows; configs[2]: 4 x 1024
+    at 16384) through a size-independent property, since an fp64 oracle backward of 16 stages at that size is
+    minutes of CPU: a batch made of ``copies`` repetitions of a ``small``-row batch (inputs, targets and dropout masks
+    repeated) has the same BatchNorm statistics, the same mean-reduced loss and therefore the same parameter
+    gradients as the small batch — whose backward IS compared with the oracle
+    (test_config4_network_8x2048_bf16s_against_oracle, B = 2048).  d loss / d prediction is smaller by exactly
+    1/copies (a power of two: every bf16 rounding scales with it), so the two gradient arenas differ only by the
+    order of fp32 sums over the batch."""
+    dev = _dev()
+    st0 = _state(nb, width, 300 + nb)
+    g = torch.Generator(device=dev).manual_seed(77)
+    x = torch.randn(small, 32, device=dev, generator=g)
+    t = torch.randn(small, 48, device=dev, generator=g)
+    nh = 1 + 2 * nb
+    masks = [(torch.rand(small, width, device=dev, generator=g) < 0.5).to(torch.uint8) for _ in range(nh)]
+    out = []
+    for rep in (1, copies):
+        net, opt = _build(st0, dev, nb, width, "bf16s")
+        net.engine.set_dropout_masks([m.repeat(rep, 1) for m in masks])
+        opt.zero_grad()
+        pred = net(x.repeat(rep, 1))
+        loss = torch.nn.functional.mse_loss(pred, t.repeat(rep, 1))
+        loss.backward()
+        torch.cuda.synchronize()
+        out.append((pred.detach()[:small].clone(), loss.item(), net.engine.grads.clone(),
+                    {k: p.grad.detach().clone() for k, p in net.named_parameters()}))
+        del net, opt
+        torch.cuda.empty_cache()
+    (p1, l1, g1, n1), (p8, l8, g8, n8) = out
+    assert _rel_l2(p8.cpu().numpy(), p1.cpu().numpy()) <= 2e-3        # (batch statistics: other summation order)
+    assert abs(l8 - l1) <= 1e-3 * abs(l1)
+    worst = ("", 0.0)
+    for k in n1:
+        if is_prebn_bias(k):
+            continue
+        e = _rel_l2(n8[k].cpu().numpy(), n1[k].cpu().numpy())
+        worst = max(worst, (k, e), key=lambda kv: kv[1])
+        assert e <= 5e-3, (k, e)
+    print("%d x %d, %d rows = %d copies of %d: worst gradient rel-L2 %.2e (%s)" % (
+        nb, width, small * copies, copies, small, worst[1], worst[0]))
+
+
 def test_config3_shape_4x1024_b16384_fp32_against_oracle():
     _forward_backward_check(4, 1024, 16384, "fp32", None, 1e-4, 1e-3, 3e-4)
 
