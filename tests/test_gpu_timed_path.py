@@ -462,7 +462,42 @@ def _oracle_first_step(entry, rounding, dtype):
     return entry[key]
 
 
-def _bf16s_forward_backward_check(nb, width, batch, thr=2e-2):
+def _replicated_batch_check(entry, net1, pred1, loss1, nb, width, small, copies):
+    """The whole backward at ``small * copies`` rows (the BASELINE per-GPU batches: an fp64 oracle backward of 16
+    stages at 16384 rows is minutes of CPU) through a size-independent property: a batch made of ``copies``
+    repetitions of the ``small``-row batch (inputs, targets, gate-safe dropout masks repeated) has the same BatchNorm
+    statistics, the same mean-reduced loss and therefore the same parameter gradients as the small batch, whose
+    gradients have just been compared with the oracle.  d loss / d prediction is smaller by exactly 1 / copies (a
+    power of two: every bf16 rounding scales with it).  Where both batches take the same kernels the two arenas
+    agree to 1e-7 (tools_dev/replication_probe.py); from 8192 rows on the big-tile kernels round at other points, so
+    the bound is the bf16-storage cap of this file.  (With masks that are NOT gate-safe the same comparison shows
+    3-7 %: ReLU gates within bf16 noise of zero open differently on the two kernel paths.)"""
+    dev = pred1.device
+    g1 = {k: p.grad.detach().clone() for k, p in net1.named_parameters()}
+    x = torch.from_numpy(entry["x"]).to(dev).repeat(copies, 1)
+    t = torch.from_numpy(entry["t"]).to(dev).repeat(copies, 1)
+    net, opt = _build(entry["st0"], dev, nb, width, "bf16s")
+    net.engine.set_dropout_masks([torch.from_numpy(np.asarray(m)).to(dev).repeat(copies, 1) for m in entry["safe"]])
+    opt.zero_grad()
+    pred = net(x)
+    loss = torch.nn.functional.mse_loss(pred, t)
+    loss.backward()
+    torch.cuda.synchronize()
+    e_pred = _rel_l2(pred.detach()[:small].cpu().numpy(), pred1.detach().cpu().numpy())
+    errs = {k: _rel_l2(p.grad.cpu().numpy(), g1[k].cpu().numpy()) for k, p in net.named_parameters()
+            if not is_prebn_bias(k)}
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    print("replicated batch %d x %d, %d rows = %d copies of %d: pred rel-L2 %.2e, loss rel %.2e, worst gradient "
+          "rel-L2 %.2e (%s)" % (nb, width, small * copies, copies, small, e_pred, abs(loss.item() - loss1) / abs(loss1),
+                                worst[1], worst[0]))
+    assert e_pred <= BF16S_CAP["pred"] and abs(loss.item() - loss1) <= BF16S_CAP["loss"] * abs(loss1)
+    for k, e in errs.items():
+        assert e <= BF16S_CAP["grad"], (k, e)
+    del net, opt
+    torch.cuda.empty_cache()
+
+
+def _bf16s_forward_backward_check(nb, width, batch, thr=2e-2, replicate=0):
     """Drop-in forward + loss + backward (raw gradients, running statistics) in bf16 storage
     against the same-rounding fp64 oracle, at a BASELINE shape; then the size-independent
     properties (pre-BN bias gradients vanish; Philox == replayed masks, bit for bit)."""
@@ -498,6 +533,8 @@ def _bf16s_forward_backward_check(nb, width, batch, thr=2e-2):
             rows.append((k, "stat", _rel_l2(sd[k].cpu().numpy(), r64["state"][k]), sfloor))
     _bf16s_assert_rows("bf16s %dx%d B=%d: rel L2 vs same-rounding fp64 oracle (noise floor = the fp32-accumulating oracle)" % (
         nb, width, batch), rows)
+    if replicate:
+        _replicated_batch_check(entry, net, pred, loss.item(), nb, width, batch, replicate)
     outs = []
     for explicit in (False, True):
         n2, o2 = _build(entry["st0"], dev, nb, width, "bf16s")
@@ -639,7 +676,7 @@ def test_config3_per_gpu_shape_4x1024_b8192_bf16s_against_oracle():
 def test_config4_network_8x2048_bf16s_against_oracle():
     """BASELINE configs[4] network (8 blocks x 2048) at B = 2048: 256 output tiles per GEMM,
     every width-2048 kernel path (16 hidden stages, 8 skip gradients) against the oracle."""
-    _bf16s_forward_backward_check(8, 2048, 2048)
+    _bf16s_forward_backward_check(8, 2048, 2048, replicate=8)     # + the full backward at configs[4]'s 16384 rows
 
 
 def test_config4_per_gpu_shape_8x2048_b16384_bf16s_forward_loss_decode_grad():
@@ -680,50 +717,6 @@ def test_config4_per_gpu_shape_8x2048_b16384_bf16s_forward_loss_decode_grad():
              _rel_l2(r32["db"], r64["db"]), "grad")]
     _bf16s_assert_rows("bf16s 8x2048 B=16384:", [(k, kind, e, f) for k, e, f, kind in rows])
     assert torch.isfinite(net.engine.grads).all()
-
-
-@pytest.mark.parametrize("nb,width,small,copies", [(8, 2048, 2048, 8), (4, 1024, 2048, 8)])
-def test_full_batch_backward_by_replication_bf16s(nb, width, small, copies):
-    """The whole backward at the BASELINE per-GPU batch (configs[4]: 8 x 2048 at 16384 rows; configs[2]: 4 x 1024
-    at 16384) through a size-independent property, since an fp64 oracle backward of 16 stages at that size is
-    minutes of CPU: a batch made of ``copies`` repetitions of a ``small``-row batch (inputs, targets and dropout masks
-    repeated) has the same BatchNorm statistics, the same mean-reduced loss and therefore the same parameter
-    gradients as the small batch — whose backward IS compared with the oracle
-    (test_config4_network_8x2048_bf16s_against_oracle, B = 2048).  d loss / d prediction is smaller by exactly
-    1/copies (a power of two: every bf16 rounding scales with it), so the two gradient arenas differ only by the
-    order of fp32 sums over the batch."""
-    dev = _dev()
-    st0 = _state(nb, width, 300 + nb)
-    g = torch.Generator(device=dev).manual_seed(77)
-    x = torch.randn(small, 32, device=dev, generator=g)
-    t = torch.randn(small, 48, device=dev, generator=g)
-    nh = 1 + 2 * nb
-    masks = [(torch.rand(small, width, device=dev, generator=g) < 0.5).to(torch.uint8) for _ in range(nh)]
-    out = []
-    for rep in (1, copies):
-        net, opt = _build(st0, dev, nb, width, "bf16s")
-        net.engine.set_dropout_masks([m.repeat(rep, 1) for m in masks])
-        opt.zero_grad()
-        pred = net(x.repeat(rep, 1))
-        loss = torch.nn.functional.mse_loss(pred, t.repeat(rep, 1))
-        loss.backward()
-        torch.cuda.synchronize()
-        out.append((pred.detach()[:small].clone(), loss.item(), net.engine.grads.clone(),
-                    {k: p.grad.detach().clone() for k, p in net.named_parameters()}))
-        del net, opt
-        torch.cuda.empty_cache()
-    (p1, l1, g1, n1), (p8, l8, g8, n8) = out
-    assert _rel_l2(p8.cpu().numpy(), p1.cpu().numpy()) <= 2e-3        # (batch statistics: other summation order)
-    assert abs(l8 - l1) <= 1e-3 * abs(l1)
-    worst = ("", 0.0)
-    for k in n1:
-        if is_prebn_bias(k):
-            continue
-        e = _rel_l2(n8[k].cpu().numpy(), n1[k].cpu().numpy())
-        worst = max(worst, (k, e), key=lambda kv: kv[1])
-        assert e <= 5e-3, (k, e)
-    print("%d x %d, %d rows = %d copies of %d: worst gradient rel-L2 %.2e (%s)" % (
-        nb, width, small * copies, copies, small, worst[1], worst[0]))
 
 
 def test_config3_shape_4x1024_b16384_fp32_against_oracle():
