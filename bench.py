@@ -586,6 +586,26 @@ def batch64_block(dev, steps, ramp_ms):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         out[name] = {"ms_per_step": 1e3 * el / steps, "poses_per_s": 64 * steps / el, "final_loss": float(loss.item())}
+    # the reference's five-call step body on the drop-in surface (train_bilinear.py:75-83): one-launch forward and
+    # backward kernels, torch's MSELoss, clip and Adam as their own calls — host-bound at this size
+    import bilinear_amd as _B
+    net.engine.set_small_step(True)
+    crit = torch.nn.MSELoss()
+
+    def five_calls():
+        opt.zero_grad()
+        loss = crit(net(x), t)
+        loss.backward()
+        _B.clip_grad_norm_(net.parameters(), max_norm=1, module=net)
+        opt.step()
+    for _ in range(50):
+        five_calls()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        five_calls()
+    torch.cuda.synchronize()
+    five_ms = 1e3 * (time.perf_counter() - t0) / steps
     timeouts = net.engine.ctx.grid_barrier_timeouts()
     del net, opt
     torch.cuda.empty_cache()
@@ -594,7 +614,10 @@ def batch64_block(dev, steps, ramp_ms):
             "ms_per_step": out["one_launch"]["ms_per_step"], "steps": steps,
             "launch": "one persistent launch per step (small_step.hip: a grid barrier per stage)",
             "grid_barrier_timeouts": timeouts,
-            "multi_launch": out["multi_launch"], "final_loss": out["one_launch"]["final_loss"]}
+            "multi_launch": out["multi_launch"], "final_loss": out["one_launch"]["final_loss"],
+            "five_call_drop_in": {"ms_per_step": five_ms, "poses_per_s": 64e3 / five_ms,
+                                  "step": "zero_grad, forward, nn.MSELoss, backward, clip_grad_norm_, Adam.step as "
+                                          "separate calls (the reference's loop); host-bound"}}
 
 
 DTYPE_TEXT = {"fp32": "f32", "bf16x3": "f32 (operands split into 3 bf16 pieces, bf16 MFMA, fp32 accumulate)",
