@@ -98,7 +98,13 @@ typedef enum {
                              and width <= 1024 run as ONE persistent launch (small_step.hip: grid barriers between
                              the stages, every workgroup resident) instead of ~50 launches — the reference's own
                              batch size, /root/reference/util/config.py:15.  0: the multi-launch path.  Same
-                             arithmetic up to the order of fp32 sums (both within the fp32 parity tolerance). */
+                             arithmetic up to the order of fp32 sums (both within the fp32 parity tolerance).
+                             blh_forward_train / blh_backward take the same kernel in two halves (the saved
+                             activations are then in its format: the context pairs them).  The launch fills the
+                             device (one workgroup per CU, all resident, grid barriers between the stages): do
+                             not run two of them at the same time on one device (two contexts on two streams) —
+                             neither could become resident, their barriers would give up after ~0.3 s each and
+                             the results would be wrong (blh_context_grid_barrier_timeouts() counts that).   */
   BLH_OPT_PERSISTENT_SHADOW = 3
                           /* gemm_dtype 4 only, default 0.  1: the Adam kernel of blh_train_step /
                              blh_train_step_captured also writes the bf16 image of the updated
