@@ -191,3 +191,34 @@ def test_custom_ops_trace_through_their_fake_implementations():
         pred, loss = torch.ops.bilinear_hip.train_step(x, t, params, grads, m, v, running, nbt, ws, stats, None,
                                                        0, 2, W, 0, 1, 0, 0, 0.1, 1e-3, 0.9, 0.999, 1e-8, 1.0, 1)
         assert tuple(pred.shape) == (B, 48) and tuple(loss.shape) == ()
+
+
+def test_cached_parameter_list_follows_module_surgery():
+    """Engine._named_params() is cached (the drop-in step asks for it seven times per step and walking
+    named_parameters() was half of the host time at batch 64); the cache is re-validated through the module-tree
+    links it was resolved through, so replacing a submodule or a Parameter object is seen at the next call."""
+    import torch
+    import bilinear_amd
+    net = bilinear_amd.BilinearUnit(num_blocks=1, width=64)
+    eng = net.engine
+    a = eng._named_params()
+    assert eng._named_params() is a                                   # cached
+    assert [n for n, _, _, _ in a] == [n for n, _ in net.named_parameters()]
+    assert all(p is q for (_, p, _, _), (_, q) in zip(a, net.named_parameters()))
+    bns = eng._bn_modules()
+    assert bns[0] is net.encode[1] and bns[2] is net.bilinear[0][1][1]
+    # a new Parameter object in place of an old one
+    net.decode.bias = torch.nn.Parameter(torch.zeros(48))
+    b = eng._named_params()
+    assert b is not a and b[-1][1] is net.decode.bias
+    # a replaced submodule (its parameters are new objects)
+    net.encode[0] = torch.nn.Linear(32, 64)
+    c = eng._named_params()
+    assert c is not b and c[0][1] is net.encode[0].weight and c[1][1] is net.encode[0].bias
+    net.bilinear[0][0][1] = torch.nn.BatchNorm1d(64)
+    assert eng._bn_modules()[1] is net.bilinear[0][0][1]
+    # in-place data changes keep the cache (same objects)
+    d = eng._named_params()
+    with torch.no_grad():
+        net.decode.weight.mul_(2.0)
+    assert eng._named_params() is d
