@@ -120,7 +120,10 @@ int blh_context_set_option(blh_context* c, int32_t option, int32_t value) {
       if (value < 0 || value > 2) return BLH_ERR_INVALID_ARGUMENT;
       c->late_fork = value;
       return BLH_OK;
-    case BLH_OPT_SMALL_STEP: c->small_step = value != 0; return BLH_OK;
+    case BLH_OPT_SMALL_STEP:
+      if (value < 0 || value > 2) return BLH_ERR_INVALID_ARGUMENT;
+      c->small_step = value;
+      return BLH_OK;
     case BLH_OPT_PERSISTENT_SHADOW:
       c->persistent_shadow = value != 0;
       c->shadow_params = c->shadow_ws = nullptr;
@@ -136,7 +139,7 @@ int blh_context_get_option(const blh_context* c, int32_t option) {
     case BLH_OPT_DEFER_SLABS: return c->defer_slabs ? 1 : 0;
     case BLH_OPT_LATE_FORK: return c->late_fork;
     case BLH_OPT_PERSISTENT_SHADOW: return c->persistent_shadow ? 1 : 0;
-    case BLH_OPT_SMALL_STEP: return c->small_step ? 1 : 0;
+    case BLH_OPT_SMALL_STEP: return c->small_step;
   }
   return BLH_ERR_INVALID_ARGUMENT;
 }
@@ -210,34 +213,40 @@ static int check_drop(const blh_dropout* drop) {
   return BLH_OK;
 }
 
-// Batches of at most 64 rows in exact fp32 take the one-launch step (small_step.hip) when the device can hold
-// its grid; BLH_NO_SMALL_STEP=1 keeps the multi-launch path (A/B measurements, tests of that path).
-static bool small_step_applies(const blh_context* ctx, const blh_model_desc* d, int64_t batch) {
-  if (!ctx->small_step || d->gemm_dtype != 0 || batch > 64 || ctx->sync.fn || !ctx->grid_bar) return false;
+// Batches of at most 64 rows in exact fp32 take the small-batch step (small_step.hip): BLH_OPT_SMALL_STEP 1 (default)
+// = one launch per stage, 2 = one persistent launch with grid barriers (needs the whole grid resident: falls back to
+// 1 when the device cannot hold it), 0 or BLH_NO_SMALL_STEP=1 = the multi-launch path of every other batch size.
+static int small_step_mode(const blh_context* ctx, const blh_model_desc* d, int64_t batch) {
+  if (!ctx->small_step || d->gemm_dtype != 0 || batch > 64 || ctx->sync.fn) return 0;
   static const bool off = getenv("BLH_NO_SMALL_STEP") != nullptr;
-  if (off) return false;
-  const int grid = small_step_max_grid(nullptr);
-  return grid > 0 && d->width / 4 <= grid && d->width <= 1024 && d->in_features <= 1024;
+  if (off || d->width > 1024 || d->in_features > 1024) return 0;
+  if (ctx->small_step == 2 && ctx->grid_bar) {
+    const int grid = small_step_max_grid(nullptr);
+    if (grid > 0 && d->width / 4 <= grid) return 2;
+  }
+  return 1;
 }
 
-static int small_step(blh_context* ctx, const blh_model_desc* d, hipStream_t s, float* params, float* grads,
-                      float* exp_avg, float* exp_avg_sq, float* bn_running, int64_t* bn_nbt, const float* x,
-                      const float* target, const blh_dropout* drop, float momentum, const blh_adam_hyper* hyper,
-                      const blh_step_state* dev_state, const Workspace& ws, float* pred, float* loss_out,
-                      float* stats_out, int64_t batch, int phase = SS_ALL, const float* dpred = nullptr) {
+static int small_params(SmallStepParams& p, blh_context* ctx, const blh_model_desc* d, float* params, float* grads,
+                        float* exp_avg, float* exp_avg_sq, float* bn_running, int64_t* bn_nbt, const float* x,
+                        const float* target, const blh_dropout* drop, float momentum, const blh_adam_hyper* hyper,
+                        const blh_step_state* dev_state, const Workspace& ws, float* pred, float* loss_out,
+                        float* stats_out, int64_t batch, const float* dpred) {
   const ArenaLayout L = make_layout(d);
-  SmallStepParams p{};
+  p = SmallStepParams{};
   p.nh = (int)L.heavy.size(); p.W = d->width; p.in_f = d->in_features; p.out_f = d->out_features;
   p.batch = (int)batch;
   for (int i = 0; i < p.nh; ++i) {
     p.w_off[i] = L.heavy[i].w; p.b_off[i] = L.heavy[i].b; p.g_off[i] = L.heavy[i].gamma; p.be_off[i] = L.heavy[i].beta;
     p.A[i] = ws.A[i]; p.dZ[i] = ws.dZ[i]; p.Z[i] = ws.Z[i]; p.bn_saved[i] = ws.bn_saved[i];
   }
+  p.gskip[0] = ws.G0; p.gskip[1] = ws.G1;
   p.dec_w = L.dec_w; p.dec_b = L.dec_b; p.count = L.total;
   p.params = params; p.grads = grads; p.m = exp_avg; p.v = exp_avg_sq;
   p.bn_running = bn_running; p.nbt = bn_nbt; p.x = x; p.target = target;
   p.dpred = dpred ? const_cast<float*>(dpred) : ws.dpred; p.pred = pred; p.loss_out = loss_out; p.stats_out = stats_out;
-  p.loss_part = ws.loss_part; p.sumsq_part = ws.sumsq_part; p.bar = ctx->grid_bar + 4;      // (words 0-2: the bf16 fused forward stage's barrier)
+  p.loss_part = ws.loss_part; p.sumsq_part = ws.sumsq_part;
+  p.bar = ctx->grid_bar ? ctx->grid_bar + 4 : nullptr;      // (words 0-2: the bf16 fused forward stage's barrier)
   p.drop = layer_drop(ctx, drop, 0, batch, d->width);
   p.momentum = momentum;
   p.denom = (double)batch * d->out_features;
@@ -247,7 +256,61 @@ static int small_step(blh_context* ctx, const blh_model_desc* d, hipStream_t s, 
     p.adam = adam_consts(*hyper);
   }
   p.st = dev_state;
-  return launch_small_step(s, p, phase);
+  return BLH_OK;
+}
+
+// The weight gradients of all hidden stages of the staged small-batch backward as ONE GEMM launch: the dZ buffers of
+// stages 1 .. nh-1 are consecutive in the workspace, and so are the activations A[0 .. nh-2] and the weight slots of
+// the gradient arena (equal strides), so dW_i = dZ_i^T A_{i-1} for all i is the "split-K" form of the ring GEMM
+// with one slab per stage, each slab stored to its own output.  Needs whole 32-deep K tiles per stage.
+static bool small_wgrad_batched_ok(const blh_model_desc* d, const ArenaLayout& L, const Workspace& ws, int64_t batch) {
+  const int nh = (int)L.heavy.size();
+  if (nh < 2 || batch % 32 != 0) return false;
+  const int64_t act = batch * (int64_t)d->width;
+  for (int i = 1; i + 1 < nh; ++i) {
+    if (ws.dZ[i + 1] - ws.dZ[i] != act || ws.A[i] - ws.A[i - 1] != act) return false;
+    if (L.heavy[i + 1].w - L.heavy[i].w != L.heavy[2].w - L.heavy[1].w) return false;
+  }
+  return true;
+}
+static int small_wgrad_batched(hipStream_t s, const blh_model_desc* d, const ArenaLayout& L, const Workspace& ws,
+                               float* grads, int64_t batch) {
+  const int nh = (int)L.heavy.size(), W = d->width;
+  GemmParams g{};
+  g.A = ws.dZ[1]; g.lda = W;
+  g.B = ws.A[0]; g.ldb = W;
+  g.C = grads + L.heavy[1].w; g.ldc = W;
+  g.M = W; g.N = W; g.K = (int)((nh - 1) * batch); g.k_per_split = (int)batch;
+  g.c_split_stride = nh > 2 ? L.heavy[2].w - L.heavy[1].w : 0;
+  return launch_gemm(s, TILE_128x128, KROW, KROW, EPI_STORE, g, nh - 1, 0);
+}
+
+// the whole step (blh_train_step / blh_train_step_captured)
+static int small_train_step(int mode, blh_context* ctx, const blh_model_desc* d, hipStream_t s, float* params,
+                            float* grads, float* exp_avg, float* exp_avg_sq, float* bn_running, int64_t* bn_nbt,
+                            const float* x, const float* target, const blh_dropout* drop, float momentum,
+                            const blh_adam_hyper* hyper, const blh_step_state* dev_state, const Workspace& ws,
+                            float* pred, float* loss_out, float* stats_out, int64_t batch) {
+  SmallStepParams p;
+  BLH_TRY(small_params(p, ctx, d, params, grads, exp_avg, exp_avg_sq, bn_running, bn_nbt, x, target, drop, momentum,
+                       hyper, dev_state, ws, pred, loss_out, stats_out, batch, nullptr));
+  ctx->saved_small_ws = nullptr;
+  if (mode == 2) return launch_small_step(s, p, SS_ALL);
+  BLH_TRY(launch_small_forward_staged(s, p, true));
+  const ArenaLayout L = make_layout(d);
+  int nparts = d->width / 4 + d->out_features / 4;
+  if (small_wgrad_batched_ok(d, L, ws, batch)) {
+    BLH_TRY(launch_small_backward_staged(s, p, false, false));
+    BLH_TRY(small_wgrad_batched(s, d, L, ws, grads, batch));
+    BLH_TRY(launch_sumsq(s, grads, p.count, ws.sumsq_part, &nparts));      // (one pass over the 17 MB arena)
+  } else {
+    BLH_TRY(launch_small_backward_staged(s, p, false, true));
+  }
+  const LossFinish lf{ws.loss_part, d->out_features / 4, p.denom, loss_out};
+  if (dev_state)
+    return launch_clip_adam_dev(s, params, grads, exp_avg, exp_avg_sq, p.count, dev_state, ws.sumsq_part, nparts,
+                                stats_out, lf);
+  return launch_clip_adam(s, params, grads, exp_avg, exp_avg_sq, p.count, *hyper, ws.sumsq_part, nparts, stats_out, lf);
 }
 
 int blh_forward_train(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params,
@@ -262,11 +325,14 @@ int blh_forward_train(blh_context* ctx, const blh_model_desc* d, void* stream, c
     return forward_h(ctx, d, (hipStream_t)stream, params, bn_running, bn_nbt, x, drop, momentum,
                      carve_h(d, batch, workspace), pred, batch, true);
   const Workspace ws = carve(d, batch, workspace);
-  if (small_step_applies(ctx, d, batch)) {
-    // the drop-in forward at <= 64 rows: one launch; what it saves for backward is in the one-launch format
-    BLH_TRY(small_step(ctx, d, (hipStream_t)stream, const_cast<float*>(params), nullptr, nullptr, nullptr, bn_running,
-                       bn_nbt, x, nullptr, drop, momentum, nullptr, nullptr, ws, pred, nullptr, nullptr, batch, SS_FWD));
-    ctx->saved_small_ws = workspace; ctx->saved_small_batch = batch;
+  if (const int mode = small_step_mode(ctx, d, batch)) {
+    // the drop-in forward at <= 64 rows; what it saves for backward is in the small-batch format
+    SmallStepParams p;
+    BLH_TRY(small_params(p, ctx, d, const_cast<float*>(params), nullptr, nullptr, nullptr, bn_running, bn_nbt, x, nullptr,
+                         drop, momentum, nullptr, nullptr, ws, pred, nullptr, nullptr, batch, nullptr));
+    if (mode == 2) BLH_TRY(launch_small_step((hipStream_t)stream, p, SS_FWD));
+    else BLH_TRY(launch_small_forward_staged((hipStream_t)stream, p, false));
+    ctx->saved_small_ws = workspace; ctx->saved_small_batch = batch; ctx->saved_small_mode = mode;
     return BLH_OK;
   }
   return forward_impl(ctx, d, (hipStream_t)stream, params, bn_running, bn_nbt, x, drop, momentum, ws,
@@ -355,8 +421,16 @@ int blh_backward(blh_context* ctx, const blh_model_desc* d, void* stream, const 
   if (ctx->saved_small_ws == workspace && workspace) {
     // the activations in this workspace were saved by the one-launch forward: only its backward can read them
     if (from_loss || ctx->saved_small_batch != batch || ctx->sync.fn) return BLH_ERR_INVALID_ARGUMENT;
-    BLH_TRY(small_step(ctx, d, (hipStream_t)stream, const_cast<float*>(params), grads, nullptr, nullptr, nullptr, nullptr,
-                       x, nullptr, drop, 0.f, nullptr, nullptr, ws, nullptr, nullptr, nullptr, batch, SS_BWD, dpred));
+    SmallStepParams p;
+    BLH_TRY(small_params(p, ctx, d, const_cast<float*>(params), grads, nullptr, nullptr, nullptr, nullptr, x, nullptr, drop,
+                         0.f, nullptr, nullptr, ws, nullptr, nullptr, nullptr, batch, dpred));
+    if (ctx->saved_small_mode == 2) BLH_TRY(launch_small_step((hipStream_t)stream, p, SS_BWD));
+    else {
+      const ArenaLayout L = make_layout(d);
+      const bool batched = small_wgrad_batched_ok(d, L, ws, batch);
+      BLH_TRY(launch_small_backward_staged((hipStream_t)stream, p, true, !batched));
+      if (batched) BLH_TRY(small_wgrad_batched((hipStream_t)stream, d, L, ws, grads, batch));
+    }
     if (on_ready) on_ready(user, 0, make_layout(d).total);     // every range at once
     return BLH_OK;
   }
@@ -452,9 +526,9 @@ int blh_train_step(blh_context* ctx, const blh_model_desc* d, void* stream, floa
     return BLH_OK;
   }
   const Workspace ws = carve(d, batch, workspace);
-  if (small_step_applies(ctx, d, batch))
-    return small_step(ctx, d, s, params, grads, exp_avg, exp_avg_sq, bn_running, bn_nbt, x, target, drop, momentum,
-                      hyper, nullptr, ws, pred, loss_out, stats_out, batch);
+  if (const int mode = small_step_mode(ctx, d, batch))
+    return small_train_step(mode, ctx, d, s, params, grads, exp_avg, exp_avg_sq, bn_running, bn_nbt, x, target, drop,
+                            momentum, hyper, nullptr, ws, pred, loss_out, stats_out, batch);
   BLH_TRY(forward_impl(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
                        target, (float)(2.0 / denom), ws.loss_part, &nparts));
   int np = 0;
@@ -698,9 +772,9 @@ int blh_train_step_captured(blh_context* ctx, const blh_model_desc* d, void* str
                                 LossFinish{wh.loss_part, nparts, denom, loss_out}, keep ? wh.wsh : nullptr);
   }
   const Workspace ws = carve(d, batch, workspace);
-  if (small_step_applies(ctx, d, batch))
-    return small_step(ctx, d, s, params, grads, exp_avg, exp_avg_sq, bn_running, bn_nbt, x, target, drop, momentum,
-                      nullptr, dev_state, ws, pred, loss_out, stats_out, batch);
+  if (const int mode = small_step_mode(ctx, d, batch))
+    return small_train_step(mode, ctx, d, s, params, grads, exp_avg, exp_avg_sq, bn_running, bn_nbt, x, target, drop,
+                            momentum, nullptr, dev_state, ws, pred, loss_out, stats_out, batch);
   BLH_TRY(forward_impl(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
                        target, (float)(2.0 / denom), ws.loss_part, &nparts));
   double* sq_src = ws.sumsq_part;

@@ -18,6 +18,7 @@ struct SmallStepParams {
   float* dZ[SS_MAX_STAGES];
   float* Z[SS_MAX_STAGES];               // SS_FWD / SS_BWD: x-hat crosses the two launches here (the gate in dZ)
   float* bn_saved[SS_MAX_STAGES];        // [4][W] mean, invstd, scale, shift
+  float* gskip[2];                       // staged launches: gradient w.r.t. the output of an even stage, for stage i - 2
   float* dpred;                          // [batch][out_f]
   float* pred; float* loss_out; float* stats_out;
   float* loss_part;                      // [out_f / 4]
@@ -34,5 +35,11 @@ struct SmallStepParams {
 // number of workgroups of the launch (= CUs of the device) if all of them can be resident at once, else 0
 int small_step_max_grid(int* num_cus_out);
 int launch_small_step(hipStream_t s, const SmallStepParams& p, int phase = SS_ALL);
+// one launch per stage (no grid barrier, no residency requirement): forward stages + decode (mse: + MSE, dpred,
+// decode gradients, loss / norm partials), backward stages (dec_here: decode gradients from the caller's dpred);
+// the gradient-norm partials are sumsq_part[0 .. W / 4 + out_f / 4)
+int launch_small_forward_staged(hipStream_t s, const SmallStepParams& p, bool mse);
+// wgrad_here = false: the hidden stages' weight gradients are left to the caller (one batched GEMM launch)
+int launch_small_backward_staged(hipStream_t s, const SmallStepParams& p, bool dec_here, bool wgrad_here);
 
 }  // namespace blh

@@ -37,6 +37,7 @@ namespace {
 constexpr int SS_THREADS = 256;
 constexpr int SS_MAX_ROWS = 64;
 constexpr int SS_PASSES = 4;            // reduction length <= 4 * 256
+constexpr int SS_SMALLK = 64;           // encode fan-in up to which the staged stage-0 kernel keeps x in LDS
 constexpr int SS_RB = 8;                // rows per batch of loads in ss_gemm (x 4 passes = 32 loads in flight per wave;
                                         // all 64 at once was tried: the allocator spills)
 
@@ -192,6 +193,7 @@ __device__ __forceinline__ bool ss_keep(const DropoutSrc& d, int layer_index, in
 }
 
 // dW rows of the workgroup: out[c][k] = sum_b dz[b][c] * In[b][k]; dz: LDS [64] float4 (4 columns of a row)
+template <bool PUBLISH = true>
 __device__ __forceinline__ double ss_wgrad(const float4* __restrict__ sh_dz, const float* __restrict__ In, int K,
                                            int batch, float* __restrict__ out) {
   double sq = 0.0;
@@ -218,7 +220,8 @@ __device__ __forceinline__ double ss_wgrad(const float4* __restrict__ sh_dz, con
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      ss_publish4(out + (int64_t)c * K + kq * 4, acc[c]);
+      if (PUBLISH) ss_publish4(out + (int64_t)c * K + kq * 4, acc[c]);
+      else *reinterpret_cast<float4*>(out + (int64_t)c * K + kq * 4) = acc[c];
       sq += (double)acc[c].x * acc[c].x + (double)acc[c].y * acc[c].y + (double)acc[c].z * acc[c].z +
             (double)acc[c].w * acc[c].w;
     }
@@ -493,6 +496,200 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(const SmallStepP
   stamp();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same stage bodies, ONE LAUNCH PER STAGE (no grid barrier, no residency requirement): forward stages,
+// decode (+ MSE), backward stages, then the library's clip + Adam kernel — 2 nh + 2 launches instead of ~52.
+// A kernel boundary costs the next kernel's launch latency and a cold L2, about what a grid barrier's poll +
+// invalidate costs (5.5 us) — but back-to-back launches overlap their launch latencies, the hardware's cache
+// maintenance is cheaper than 256 workgroups' fences, and everything is stored with ordinary (write-back) stores.
+// What backward needs of forward crosses in the workspace exactly as for SS_FWD / SS_BWD (x-hat in Z, the gate in dZ,
+// gamma * invstd in the saved-statistics rows); the skip gradient of an even stage waits for stage i - 2 in G0 / G1.
+struct SsIdx {
+  int tid, lane, wave, g, n0, row, c, col;
+  bool valid;
+};
+__device__ __forceinline__ SsIdx ss_idx(int W, int B) {
+  SsIdx x;
+  x.tid = threadIdx.x; x.lane = x.tid & 63; x.wave = x.tid >> 6; x.g = blockIdx.x;
+  const int ngroups = W >> 2;
+  x.n0 = ((x.g & 7) * (ngroups >> 3) + (x.g >> 3)) * 4;       // XCD-aware, as in the persistent kernel
+  x.row = x.tid >> 2; x.c = x.tid & 3; x.col = x.n0 + x.c;
+  x.valid = x.row < B;
+  return x;
+}
+
+// grid: W / 4 workgroups
+__global__ __launch_bounds__(SS_THREADS) void small_fwd_stage_kernel(const SmallStepParams p, const int i) {
+  __shared__ float sh_cs[16];
+  const int W = p.W, B = p.batch;
+  const SsIdx x = ss_idx(W, B);
+  const int K = (i == 0) ? p.in_f : W;
+  const float* in = (i == 0) ? p.x : p.A[i - 1];
+  const float inv_b = 1.0f / (float)B;
+  WBlock wb;
+  ss_load_w_rows(wb, p.params + p.w_off[i] + (int64_t)x.n0 * K, K, x.lane);
+  const float bias = p.params[p.b_off[i] + x.col], gamma = p.params[p.g_off[i] + x.col], beta = p.params[p.be_off[i] + x.col];
+  float* rm = p.bn_running + ((int64_t)i * 2 + 0) * W;
+  float* rv = p.bn_running + ((int64_t)i * 2 + 1) * W;
+  const float rm0 = rm[x.col], rv0 = rv[x.col];
+  const int64_t nbt0 = p.nbt[i];
+  const int64_t e = (int64_t)x.row * W + x.col;
+  const float skipv = (i >= 2 && (i & 1) == 0 && x.valid) ? p.A[i - 2][e] : 0.f;
+  const bool kept = x.valid && ss_keep(p.drop, i, (int64_t)B * W, x.row, x.col, W);
+  float z = ss_gemm<false>(wb, in, K, K, B, x.wave, x.lane) + bias;
+  if (!x.valid) z = 0.f;
+  const float mean = ss_colsum(z, sh_cs, x.wave, x.lane) * inv_b;
+  const float dlt = x.valid ? z - mean : 0.f;
+  const float m2 = ss_colsum(dlt * dlt, sh_cs, x.wave, x.lane);
+  const float invstd = (float)(1.0 / sqrt((double)m2 / (double)B + (double)1e-5f));
+  const float sc = gamma * invstd;
+  const float sh = beta - mean * sc;
+  if (x.row == 0) {
+    const double f = (p.momentum >= 0.f) ? (double)p.momentum : 1.0 / (double)(nbt0 + 1);
+    const double unbiased = (double)m2 / (double)(B > 1 ? B - 1 : 1);
+    rm[x.col] = (float)((1.0 - f) * (double)rm0 + f * (double)mean);
+    rv[x.col] = (float)((1.0 - f) * (double)rv0 + f * unbiased);
+    float* st = p.bn_saved[i];
+    st[x.col] = mean; st[W + x.col] = invstd; st[2 * W + x.col] = sc; st[3 * W + x.col] = sh;
+  }
+  const float y = fmaf(z, sc, sh);
+  const bool on = kept && y > 0.f;
+  if (x.valid) {
+    p.A[i][e] = (on ? y * 2.f : 0.f) + skipv;
+    p.Z[i][e] = dlt * invstd;
+    p.dZ[i][e] = on ? 2.f : 0.f;
+  }
+}
+
+// grid: out_f / 4 workgroups.  MSE: + loss partials, d loss / d prediction, the decode gradients and their norm
+// partials (slots [W / 4, W / 4 + out_f / 4) of sumsq_part); either way the BatchNorm counters (every forward stage
+// has read them: the stage kernels are complete).
+template <bool MSE>
+__global__ __launch_bounds__(SS_THREADS) void small_decode_kernel(const SmallStepParams p) {
+  __shared__ float sh_cs[16];
+  __shared__ double sh_d[SS_THREADS];
+  const int W = p.W, B = p.batch, OF = p.out_f, nh = p.nh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x;
+  const int o0 = g * 4, row = tid >> 2, c = tid & 3, oc = o0 + c;
+  const bool valid = row < B;
+  WBlock wb;
+  ss_load_w_rows(wb, p.params + p.dec_w + (int64_t)o0 * W, W, lane);
+  const float bd = p.params[p.dec_b + oc];
+  const float tg = (MSE && valid) ? p.target[(int64_t)row * OF + oc] : 0.f;
+  const float pr = ss_gemm<false>(wb, p.A[nh - 1], W, W, B, wave, lane) + bd;
+  if (valid) p.pred[(int64_t)row * OF + oc] = pr;
+  if (g == 0 && tid == 0) for (int i = 0; i < nh; ++i) p.nbt[i] += 1;
+  if (!MSE) return;
+  const float diff = valid ? pr - tg : 0.f;
+  const float dp = diff * p.mse_scale;
+  if (valid) p.dpred[(int64_t)row * OF + oc] = dp;
+  (void)ss_colsum(diff * diff, sh_cs, wave, lane);
+  if (tid == 0)
+    p.loss_part[g] = (sh_cs[0] + sh_cs[4] + sh_cs[8] + sh_cs[12]) + (sh_cs[1] + sh_cs[5] + sh_cs[9] + sh_cs[13]) +
+                     (sh_cs[2] + sh_cs[6] + sh_cs[10] + sh_cs[14]) + (sh_cs[3] + sh_cs[7] + sh_cs[11] + sh_cs[15]);
+  // (the decode WEIGHT gradient is formed by the top backward stage kernel, four columns per workgroup, from the
+  //  activations its threads own: here 12 workgroups would each read the whole activation for it, 8 us)
+  double sq = 0.0;
+  const float db = ss_colsum(dp, sh_cs, wave, lane);
+  if (row == 0) { p.grads[p.dec_b + oc] = db; sq += (double)db * db; }
+  const double wg_sq = ss_block_sum(sq, sh_d);
+  if (tid == 0) p.sumsq_part[(W >> 2) + g] = wg_sq;
+}
+
+// grid: W / 4 workgroups.  dec_here (top stage of the drop-in backward): d loss / d prediction comes from the
+// caller and the decode gradients are formed here by the workgroups g < out_f / 4.  wgrad_here = 0: the weight
+// gradients of the hidden stages come from ONE batched MFMA GEMM launch behind the stage kernels (the host's
+// launch_gemm over the consecutive dZ / A buffers: 64 tiles of 128 x 128 per stage read 4 MB where the four-column
+// ownership of this kernel reads the whole activation in every workgroup — 8 us per stage).
+__global__ __launch_bounds__(SS_THREADS) void small_bwd_stage_kernel(const SmallStepParams p, const int i,
+                                                                      const int dec_here, const int wgrad_here) {
+  __shared__ float sh_cs[16];
+  __shared__ float4 sh_dz[SS_MAX_ROWS];
+  __shared__ double sh_d[SS_THREADS];
+  __shared__ __align__(16) float sh_big[SS_MAX_ROWS * 64];      // dpred [B][out_f] (top stage)
+  __shared__ __align__(16) float sh_x[SS_MAX_ROWS * SS_SMALLK]; // x [B][in_f] (stage 0)
+  const int W = p.W, B = p.batch, OF = p.out_f, nh = p.nh;
+  const SsIdx x = ss_idx(W, B);
+  const bool top = (i == nh - 1);
+  const float inv_b = 1.0f / (float)B;
+  const int64_t e = (int64_t)x.row * W + x.col;
+  double sq = 0.0;
+  WBlock wb;
+  if (top) ss_load_w_cols(wb, p.params + p.dec_w + x.n0, OF, W, x.lane);
+  else ss_load_w_cols(wb, p.params + p.w_off[i + 1] + x.n0, W, W, x.lane);
+  // what forward left in the workspace, and the skip gradient of stage i + 2
+  float xhat = 0.f, gate = 0.f, gin = 0.f;
+  if (x.valid) { xhat = p.Z[i][e]; gate = p.dZ[i][e]; }
+  const float sc = p.bn_saved[i][2 * W + x.col];
+  const bool even = (i & 1) == 0;
+  if (even && !top && x.valid) gin = p.gskip[((i >> 1) + 1) & 1][e];
+  if (top) {
+    // decode weight gradient, the four columns of this workgroup: dWd[o][col] = sum_b dpred[b][o] * A[b][col]
+    // (dec_here, workgroup 0: + the decode bias gradient — the drop-in backward has no decode kernel before it)
+    for (int k = x.tid; k < B * OF; k += SS_THREADS) sh_big[k] = p.dpred[k];
+    reinterpret_cast<float*>(sh_dz)[x.tid] = x.valid ? p.A[nh - 1][e] : 0.f;
+    __syncthreads();
+    if (x.tid < OF * 4) {
+      const int o = x.tid >> 2, cc = x.tid & 3;
+      float acc = 0.f;
+      for (int b = 0; b < B; ++b) acc = fmaf(sh_big[b * OF + o], reinterpret_cast<const float*>(sh_dz)[b * 4 + cc], acc);
+      p.grads[p.dec_w + (int64_t)o * W + x.n0 + cc] = acc;
+      sq += (double)acc * acc;
+    }
+    if (dec_here && x.g == 0 && x.tid < OF) {
+      float db = 0.f;
+      for (int b = 0; b < B; ++b) db += sh_big[b * OF + x.tid];
+      p.grads[p.dec_b + x.tid] = db;
+      sq += (double)db * db;
+    }
+    __syncthreads();
+  }
+  if (i == 0 && p.in_f <= SS_SMALLK) {
+    // encode: the input rows, for the weight gradient at the end (requested now)
+    for (int k = x.tid * 4; k < B * p.in_f; k += SS_THREADS * 4)
+      *reinterpret_cast<float4*>(sh_x + k) = ss_ld4(p.x + k);
+  }
+  float ga = top ? ss_gemm<true>(wb, p.dpred, OF, OF, B, x.wave, x.lane)
+                 : ss_gemm<true>(wb, p.dZ[i + 1], W, W, B, x.wave, x.lane);
+  if (even) {
+    ga += gin;
+    if (i >= 2 && x.valid) p.gskip[(i >> 1) & 1][e] = ga;
+  }
+  const float dy = x.valid ? ga * gate : 0.f;
+  const float s_b = ss_colsum(dy, sh_cs, x.wave, x.lane);
+  const float s_g = ss_colsum(dy * xhat, sh_cs, x.wave, x.lane);
+  const float dz = x.valid ? sc * (dy - (s_b + xhat * s_g) * inv_b) : 0.f;
+  const float dbias = ss_colsum(dz, sh_cs, x.wave, x.lane);
+  if (x.row == 0) {
+    p.grads[p.g_off[i] + x.col] = s_g;
+    p.grads[p.be_off[i] + x.col] = s_b;
+    p.grads[p.b_off[i] + x.col] = dbias;
+    sq += (double)s_g * s_g + (double)s_b * s_b + (double)dbias * dbias;
+  }
+  if (i >= 1 && x.valid) p.dZ[i][e] = dz;
+  if (i == 0 || wgrad_here) {
+    __syncthreads();
+    reinterpret_cast<float*>(sh_dz)[x.tid] = dz;
+    __syncthreads();
+    const int K = (i == 0) ? p.in_f : W;
+    if (i == 0 && K <= SS_SMALLK) {
+      // dW0[col][k] = sum_b dz[b][c] * x[b][k]: one (c, k) pair per thread, both operands in LDS
+      for (int t = x.tid; t < 4 * K; t += SS_THREADS) {
+        const int cc = t / K, k = t - cc * K;
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc = fmaf(reinterpret_cast<const float*>(sh_dz)[b * 4 + cc], sh_x[b * K + k], acc);
+        p.grads[p.w_off[0] + (int64_t)(x.n0 + cc) * K + k] = acc;
+        sq += (double)acc * acc;
+      }
+    } else {
+      sq += ss_wgrad<false>(sh_dz, (i == 0) ? p.x : p.A[i - 1], K, B, p.grads + p.w_off[i] + (int64_t)x.n0 * K);
+    }
+  }
+  // one norm partial per workgroup, accumulated over the stage launches in a fixed order (deterministic)
+  const double wg_sq = ss_block_sum(sq, sh_d);
+  if (x.tid == 0) p.sumsq_part[x.g] = (top ? 0.0 : p.sumsq_part[x.g]) + wg_sq;
+}
+
 size_t small_step_lds_bytes(int nh) { return 2048 + 1024 + 64 + (size_t)nh * (256 + 256 + 8) * sizeof(float); }
 
 int small_step_max_grid(int* num_cus_out) {
@@ -531,6 +728,30 @@ int launch_small_step(hipStream_t s, const SmallStepParams& p, int phase) {
   else if (phase == SS_FWD) hipLaunchKernelGGL(small_step_kernel<SS_FWD>, dim3((unsigned)grid), dim3(SS_THREADS), lds, s, p);
   else if (phase == SS_BWD) hipLaunchKernelGGL(small_step_kernel<SS_BWD>, dim3((unsigned)grid), dim3(SS_THREADS), lds, s, p);
   else return BLH_ERR_INVALID_ARGUMENT;
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+bool small_staged_shape_ok(const SmallStepParams& p) {
+  return p.batch <= SS_MAX_ROWS && p.nh <= SS_MAX_STAGES && p.W <= 256 * SS_PASSES && p.W % 32 == 0 &&
+         p.in_f <= 256 * SS_PASSES && p.in_f % 4 == 0 && p.out_f <= 256 * SS_PASSES && p.out_f % 4 == 0;
+}
+
+int launch_small_forward_staged(hipStream_t s, const SmallStepParams& p, bool mse) {
+  if (!small_staged_shape_ok(p)) return BLH_ERR_SHAPE;
+  const dim3 grid((unsigned)(p.W / 4)), block(SS_THREADS);
+  for (int i = 0; i < p.nh; ++i) hipLaunchKernelGGL(small_fwd_stage_kernel, grid, block, 0, s, p, i);
+  if (mse) hipLaunchKernelGGL(small_decode_kernel<true>, dim3((unsigned)(p.out_f / 4)), block, 0, s, p);
+  else hipLaunchKernelGGL(small_decode_kernel<false>, dim3((unsigned)(p.out_f / 4)), block, 0, s, p);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+int launch_small_backward_staged(hipStream_t s, const SmallStepParams& p, bool dec_here, bool wgrad_here) {
+  if (!small_staged_shape_ok(p)) return BLH_ERR_SHAPE;
+  const dim3 grid((unsigned)(p.W / 4)), block(SS_THREADS);
+  for (int i = p.nh - 1; i >= 0; --i)
+    hipLaunchKernelGGL(small_bwd_stage_kernel, grid, block, 0, s, p, i, dec_here ? 1 : 0, wgrad_here ? 1 : 0);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }

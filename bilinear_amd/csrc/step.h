@@ -35,11 +35,12 @@ struct blh_context {
   // BLH_OPT_PERSISTENT_SHADOW: the (params, workspace) whose bf16 parameter image the last fused
   // step's Adam kernel left up to date (nullptr: none)
   bool persistent_shadow = false;
-  bool small_step = true;
+  int small_step = 1;                 // BLH_OPT_SMALL_STEP: 0 off, 1 one launch per stage, 2 one persistent launch
   // the workspace whose saved activations are in the one-launch forward's format (small_step.hip, SS_FWD), and
   // their batch; any multi-launch train-mode forward on the context clears it (forward_impl)
   const void* saved_small_ws = nullptr;
   int64_t saved_small_batch = 0;
+  int saved_small_mode = 0;
   const void* shadow_params = nullptr;
   const void* shadow_ws = nullptr;
   // grid barrier of the fused forward stage (gemm_bf16s_bnfwd.h): arrivals, generation, timeouts; device memory

@@ -451,12 +451,14 @@ class Engine:
             raise RuntimeError("the engine is not on a device yet")
         self.ctx.set_option(N.OPT_TWO_STREAM, 1 if enabled else 0)
 
-    def set_small_step(self, enabled):
-        """A/B switch of the one-launch step for batches of at most 64 rows (BLH_OPT_SMALL_STEP, fp32 only; default
-        on): off = the multi-launch path every other batch size takes."""
+    def set_small_step(self, mode):
+        """The small-batch step (at most 64 rows, fp32, BLH_OPT_SMALL_STEP): True / 1 / "staged" (default) = one
+        launch per stage; 2 / "persistent" = one persistent launch with grid barriers between the stages; False / 0 =
+        the multi-launch path every other batch size takes."""
         if self.ctx is None:
             raise RuntimeError("the engine is not on a device yet")
-        self.ctx.set_option(N.OPT_SMALL_STEP, 1 if enabled else 0)
+        value = {"staged": 1, "persistent": 2, "off": 0}.get(mode, mode)
+        self.ctx.set_option(N.OPT_SMALL_STEP, int(value))
 
     def backward(self, x, dpred, on_ready=None, sync=None, global_batch=None, generation=None):
         """Gradients of every parameter into the grad arena (overwritten).  ``generation`` (the

@@ -21,10 +21,10 @@ def _rel(a, b):
     return float((a - b).norm() / max(float(b.norm()), 1e-30))
 
 
-def _pair(dev, nb, width, seed=11):
+def _pair(dev, nb, width, seed=11, mode=1):
     import bilinear_amd
     nets = []
-    for small in (True, False):
+    for small in (mode, 0):
         torch.manual_seed(seed)
         net, opt, _, _ = bilinear_amd.load(dev, num_blocks=nb, width=width, gemm_dtype="fp32")
         net.train()
@@ -35,12 +35,13 @@ def _pair(dev, nb, width, seed=11):
     return nets
 
 
+@pytest.mark.parametrize("mode", [1, 2])        # one launch per stage (default) / one persistent launch
 @pytest.mark.parametrize("nb,width,batch", [(2, 1024, 64), (2, 1024, 8), (2, 1024, 33), (1, 256, 2), (0, 64, 17),
                                             (4, 512, 64), (3, 1024, 50)])
-def test_small_step_equals_the_multi_launch_step(nb, width, batch):
+def test_small_step_equals_the_multi_launch_step(nb, width, batch, mode):
     dev = _dev()
-    (na, oa), (nb_, ob) = _pair(dev, nb, width)
-    assert na.engine.ctx.get_option(4) == 1 and nb_.engine.ctx.get_option(4) == 0
+    (na, oa), (nb_, ob) = _pair(dev, nb, width, mode=mode)
+    assert na.engine.ctx.get_option(4) == mode and nb_.engine.ctx.get_option(4) == 0
     g = torch.Generator().manual_seed(batch)
     # (at B = 2 BatchNorm leaves gradients that are rounding noise, which Adam's sign-like update amplifies into
     #  the parameters: one step there, three elsewhere)
@@ -69,11 +70,12 @@ def test_small_step_equals_the_multi_launch_step(nb, width, batch):
     assert int(na.encode[1].num_batches_tracked) == steps == int(nb_.encode[1].num_batches_tracked)
 
 
-def test_small_step_is_deterministic():
+@pytest.mark.parametrize("mode", [1, 2])
+def test_small_step_is_deterministic(mode):
     """Two runs of the same steps are bit-identical (every sum has a fixed order)."""
     dev = _dev()
-    (na, oa), _ = _pair(dev, 2, 1024)
-    (nc, oc), _ = _pair(dev, 2, 1024)
+    (na, oa), _ = _pair(dev, 2, 1024, mode=mode)
+    (nc, oc), _ = _pair(dev, 2, 1024, mode=mode)
     g = torch.Generator().manual_seed(0)
     x = torch.randn(64, 32, generator=g).to(dev); t = torch.randn(64, 48, generator=g).to(dev)
     for _ in range(3):
@@ -84,8 +86,9 @@ def test_small_step_is_deterministic():
     assert torch.equal(na.engine.grads, nc.engine.grads) and torch.equal(na.engine.bn_running, nc.engine.bn_running)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("batch", [64, 24])
-def test_small_step_against_the_fp64_oracle_and_philox_replay(batch):
+def test_small_step_against_the_fp64_oracle_and_philox_replay(batch, mode):
     """(a) explicit gate-safe masks: every observable of the step against oracle/numpy_oracle.py at the tight fp32
     tolerance of the timed-path tests; (b) the Philox step is bit-identical to the explicit-mask step fed the
     materialised Philox masks (same keep bits as the multi-launch kernels, philox.h)."""
@@ -96,7 +99,8 @@ def test_small_step_against_the_fp64_oracle_and_philox_replay(batch):
     xt, tt = torch.from_numpy(entry["x"]).to(dev), torch.from_numpy(entry["t"]).to(dev)
     r = T._run_oracle(entry, entry["safe"])
     net, opt = T._build(entry["st0"], dev, nb, width, "fp32")
-    assert net.engine.ctx.get_option(4) == 1
+    assert net.engine.ctx.get_option(4) == 1                   # default: one launch per stage
+    net.engine.set_small_step(mode)
     net.engine.set_dropout_masks(entry["safe"])
     pred, loss = net.train_step(opt, xt, tt, max_norm=1.0)
     torch.cuda.synchronize()
@@ -105,6 +109,7 @@ def test_small_step_against_the_fp64_oracle_and_philox_replay(batch):
     out = []
     for explicit in (False, True):
         net, opt = T._build(entry["st0"], dev, nb, width, "fp32")
+        net.engine.set_small_step(mode)
         if explicit:
             net.engine.set_dropout_masks(entry["philox"])
         pred, loss = net.train_step(opt, xt, tt, max_norm=1.0)
@@ -116,15 +121,16 @@ def test_small_step_against_the_fp64_oracle_and_philox_replay(batch):
     assert out[0][5] == out[1][5]
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("nb,width,batch", [(2, 1024, 64), (1, 512, 40)])
-def test_drop_in_forward_and_backward_take_the_one_launch_kernels(nb, width, batch):
+def test_drop_in_forward_and_backward_take_the_one_launch_kernels(nb, width, batch, mode):
     """The reference's five-call step body (/root/reference/train_bilinear.py:75-83) at <= 64 rows: forward and
     backward are one launch each (SS_FWD / SS_BWD, the saved activations cross in the workspace).  Raw gradients,
     the clipped step and the BatchNorm buffers against the multi-launch path; switching the option between forward
     and backward does not mix the two saved-activation formats; gradient accumulation over two backwards works."""
     import bilinear_amd
     dev = _dev()
-    (na, oa), (nm, om) = _pair(dev, nb, width)
+    (na, oa), (nm, om) = _pair(dev, nb, width, mode=mode)
     g = torch.Generator().manual_seed(9)
     crit = torch.nn.MSELoss()
     for s in range(3):
@@ -136,10 +142,10 @@ def test_drop_in_forward_and_backward_take_the_one_launch_kernels(nb, width, bat
             pred = net(x)
             loss = crit(pred, t)
             if net is na and s == 1:
-                net.engine.set_small_step(False)      # the backward must still be the one-launch one
+                net.engine.set_small_step(False)      # the backward must still be the small-batch one
             loss.backward()
             if net is na and s == 1:
-                net.engine.set_small_step(True)
+                net.engine.set_small_step(mode)
             raws.append((pred.detach().clone(), loss.item(), net.engine.grads.clone()))
             bilinear_amd.clip_grad_norm_(net.parameters(), max_norm=1, module=net)
             opt.step()
