@@ -121,7 +121,7 @@ int blh_context_set_option(blh_context* c, int32_t option, int32_t value) {
       c->late_fork = value;
       return BLH_OK;
     case BLH_OPT_SMALL_STEP:
-      if (value < 0 || value > 2) return BLH_ERR_INVALID_ARGUMENT;
+      if (value < 0 || value > 3) return BLH_ERR_INVALID_ARGUMENT;
       c->small_step = value;
       return BLH_OK;
     case BLH_OPT_PERSISTENT_SHADOW:
@@ -213,14 +213,19 @@ static int check_drop(const blh_dropout* drop) {
   return BLH_OK;
 }
 
-// Batches of at most 64 rows in exact fp32 take the small-batch step (small_step.hip): BLH_OPT_SMALL_STEP 1 (default)
-// = one launch per stage, 2 = one persistent launch with grid barriers (needs the whole grid resident: falls back to
-// 1 when the device cannot hold it), 0 or BLH_NO_SMALL_STEP=1 = the multi-launch path of every other batch size.
-static int small_step_mode(const blh_context* ctx, const blh_model_desc* d, int64_t batch) {
+// Batches of at most 64 rows in exact fp32 take the small-batch step (small_step.hip).  BLH_OPT_SMALL_STEP: 1 (default)
+// = automatic: the fused step (blh_train_step) as one launch per stage — GPU-bound, 0.154 ms against 0.200 for the
+// persistent form — and the drop-in halves (blh_forward_train, blh_backward) as one persistent launch each — that loop
+// is host-bound, 2 launches cost the host less than 11; 2 = persistent everywhere; 3 = one launch per stage
+// everywhere; 0 or BLH_NO_SMALL_STEP=1 = the multi-launch path of every other batch size.  The persistent form needs
+// the whole grid resident: where the device cannot hold it, the staged form is taken.
+// Returns 0 (not applicable), 1 (staged) or 2 (persistent).
+static int small_step_mode(const blh_context* ctx, const blh_model_desc* d, int64_t batch, bool drop_in) {
   if (!ctx->small_step || d->gemm_dtype != 0 || batch > 64 || ctx->sync.fn) return 0;
   static const bool off = getenv("BLH_NO_SMALL_STEP") != nullptr;
   if (off || d->width > 1024 || d->in_features > 1024) return 0;
-  if (ctx->small_step == 2 && ctx->grid_bar) {
+  const bool want_persistent = ctx->small_step == 2 || (ctx->small_step == 1 && drop_in);
+  if (want_persistent && ctx->grid_bar) {
     const int grid = small_step_max_grid(nullptr);
     if (grid > 0 && d->width / 4 <= grid) return 2;
   }
@@ -245,7 +250,7 @@ static int small_params(SmallStepParams& p, blh_context* ctx, const blh_model_de
   p.params = params; p.grads = grads; p.m = exp_avg; p.v = exp_avg_sq;
   p.bn_running = bn_running; p.nbt = bn_nbt; p.x = x; p.target = target;
   p.dpred = dpred ? const_cast<float*>(dpred) : ws.dpred; p.pred = pred; p.loss_out = loss_out; p.stats_out = stats_out;
-  p.loss_part = ws.loss_part; p.sumsq_part = ws.sumsq_part;
+  p.loss_part = ws.loss_part; p.sumsq_part = ws.sumsq_fold;      // (SUMSQ_FOLD_PARTS slots)
   p.bar = ctx->grid_bar ? ctx->grid_bar + 4 : nullptr;      // (words 0-2: the bf16 fused forward stage's barrier)
   p.drop = layer_drop(ctx, drop, 0, batch, d->width);
   p.momentum = momentum;
@@ -273,8 +278,9 @@ static bool small_wgrad_batched_ok(const blh_model_desc* d, const ArenaLayout& L
   }
   return true;
 }
+// sq (optional): one norm partial per workgroup of the launch, (nh - 1) * (W / 128)^2 of them
 static int small_wgrad_batched(hipStream_t s, const blh_model_desc* d, const ArenaLayout& L, const Workspace& ws,
-                               float* grads, int64_t batch) {
+                               float* grads, int64_t batch, double* sq = nullptr) {
   const int nh = (int)L.heavy.size(), W = d->width;
   GemmParams g{};
   g.A = ws.dZ[1]; g.lda = W;
@@ -282,7 +288,8 @@ static int small_wgrad_batched(hipStream_t s, const blh_model_desc* d, const Are
   g.C = grads + L.heavy[1].w; g.ldc = W;
   g.M = W; g.N = W; g.K = (int)((nh - 1) * batch); g.k_per_split = (int)batch;
   g.c_split_stride = nh > 2 ? L.heavy[2].w - L.heavy[1].w : 0;
-  return launch_gemm(s, TILE_128x128, KROW, KROW, EPI_STORE, g, nh - 1, 0);
+  g.sq_part = sq;
+  return launch_gemm(s, TILE_128x128, KROW, KROW, sq ? EPI_STORE_SQ : EPI_STORE, g, nh - 1, 0);
 }
 
 // the whole step (blh_train_step / blh_train_step_captured)
@@ -298,19 +305,22 @@ static int small_train_step(int mode, blh_context* ctx, const blh_model_desc* d,
   if (mode == 2) return launch_small_step(s, p, SS_ALL);
   BLH_TRY(launch_small_forward_staged(s, p, true));
   const ArenaLayout L = make_layout(d);
+  // gradient-norm partials: [0, W/4) the stage kernels (accumulated over the stages), [W/4, W/4 + out/4) decode, then
+  // one per workgroup of the batched weight-gradient GEMM
   int nparts = d->width / 4 + d->out_features / 4;
-  if (small_wgrad_batched_ok(d, L, ws, batch)) {
+  const int tiles = (int)(ceil_div(d->width, 128) * ceil_div(d->width, 128));
+  if (small_wgrad_batched_ok(d, L, ws, batch) && nparts + (p.nh - 1) * tiles <= SUMSQ_FOLD_PARTS) {
     BLH_TRY(launch_small_backward_staged(s, p, false, false));
-    BLH_TRY(small_wgrad_batched(s, d, L, ws, grads, batch));
-    BLH_TRY(launch_sumsq(s, grads, p.count, ws.sumsq_part, &nparts));      // (one pass over the 17 MB arena)
+    BLH_TRY(small_wgrad_batched(s, d, L, ws, grads, batch, p.sumsq_part + nparts));
+    nparts += (p.nh - 1) * tiles;
   } else {
     BLH_TRY(launch_small_backward_staged(s, p, false, true));
   }
   const LossFinish lf{ws.loss_part, d->out_features / 4, p.denom, loss_out};
   if (dev_state)
-    return launch_clip_adam_dev(s, params, grads, exp_avg, exp_avg_sq, p.count, dev_state, ws.sumsq_part, nparts,
+    return launch_clip_adam_dev(s, params, grads, exp_avg, exp_avg_sq, p.count, dev_state, p.sumsq_part, nparts,
                                 stats_out, lf);
-  return launch_clip_adam(s, params, grads, exp_avg, exp_avg_sq, p.count, *hyper, ws.sumsq_part, nparts, stats_out, lf);
+  return launch_clip_adam(s, params, grads, exp_avg, exp_avg_sq, p.count, *hyper, p.sumsq_part, nparts, stats_out, lf);
 }
 
 int blh_forward_train(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params,
@@ -325,7 +335,7 @@ int blh_forward_train(blh_context* ctx, const blh_model_desc* d, void* stream, c
     return forward_h(ctx, d, (hipStream_t)stream, params, bn_running, bn_nbt, x, drop, momentum,
                      carve_h(d, batch, workspace), pred, batch, true);
   const Workspace ws = carve(d, batch, workspace);
-  if (const int mode = small_step_mode(ctx, d, batch)) {
+  if (const int mode = small_step_mode(ctx, d, batch, true)) {
     // the drop-in forward at <= 64 rows; what it saves for backward is in the small-batch format
     SmallStepParams p;
     BLH_TRY(small_params(p, ctx, d, const_cast<float*>(params), nullptr, nullptr, nullptr, bn_running, bn_nbt, x, nullptr,
@@ -526,7 +536,7 @@ int blh_train_step(blh_context* ctx, const blh_model_desc* d, void* stream, floa
     return BLH_OK;
   }
   const Workspace ws = carve(d, batch, workspace);
-  if (const int mode = small_step_mode(ctx, d, batch))
+  if (const int mode = small_step_mode(ctx, d, batch, false))
     return small_train_step(mode, ctx, d, s, params, grads, exp_avg, exp_avg_sq, bn_running, bn_nbt, x, target, drop,
                             momentum, hyper, nullptr, ws, pred, loss_out, stats_out, batch);
   BLH_TRY(forward_impl(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
@@ -772,7 +782,7 @@ int blh_train_step_captured(blh_context* ctx, const blh_model_desc* d, void* str
                                 LossFinish{wh.loss_part, nparts, denom, loss_out}, keep ? wh.wsh : nullptr);
   }
   const Workspace ws = carve(d, batch, workspace);
-  if (const int mode = small_step_mode(ctx, d, batch))
+  if (const int mode = small_step_mode(ctx, d, batch, false))
     return small_train_step(mode, ctx, d, s, params, grads, exp_avg, exp_avg_sq, bn_running, bn_nbt, x, target, drop,
                             momentum, nullptr, dev_state, ws, pred, loss_out, stats_out, batch);
   BLH_TRY(forward_impl(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,

@@ -58,8 +58,10 @@ enum Epilogue : int {
   EPI_BN_BWD = 5,      // bf16-storage data gradient feeding a BatchNorm backward (gemm_bf16s_256.h): C = the gated
                        // gradient dY' = 2 keep [y > 0] acc, per-row-tile column sums of dY' z and dY'
   EPI_BN_BWD_ADD = 6,  // the same with acc + addend[m][n] (the block-skip gradient)
-  EPI_BN_FWD = 7       // bf16-storage forward stage in one launch (gemm_bf16s_bnfwd.h): Z = acc + bias, batch statistics
+  EPI_BN_FWD = 7,      // bf16-storage forward stage in one launch (gemm_bf16s_bnfwd.h): Z = acc + bias, batch statistics
                        // behind a grid barrier, A = 2 keep relu(bn(Z)) (+ skip), keep bits
+  EPI_STORE_SQ = 8     // C = acc, and one fp64 sum of squares of the stored tile per workgroup (sq_part[z * tiles + x]):
+                       // the gradient-norm partials of a weight gradient without another pass over it
 };
 
 struct GemmParams {
@@ -80,6 +82,7 @@ struct GemmParams {
   // gemm_dtype 3 (fp16 two-piece split): max |value| partials of each operand tensor
   const float* a_amax; int a_namax;
   const float* b_amax; int b_namax;
+  double* sq_part;          // EPI_STORE_SQ: [splits][tiles]
 };
 
 enum GemmTile : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_128x32 = 3 };

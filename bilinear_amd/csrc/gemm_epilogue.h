@@ -93,6 +93,31 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], 
       }
     }
 
+  if (EPI == EPI_STORE_SQ) {
+    // one sum of squares of the tile per workgroup (fixed order: lanes, then waves)
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+          const int col = col_w + jn * 32;
+          if (row < p.M && col < p.N && is_cons) s += (double)acc[i][jn][r] * (double)acc[i][jn][r];
+        }
+      }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    double* red = reinterpret_cast<double*>(smem);   // (stage buffers are dead: the barrier closed the main loop)
+    if (lane == 0) red[wave] = s;
+    lds_barrier();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+      p.sq_part[(int64_t)blockIdx.z * gridDim.x + blockIdx.x] = t;
+    }
+  }
   if (EPI == EPI_BIAS_STATS) {
     // Per-tile column statistics in the shifted (Welford/Chan) form: tile mean and
     // M2 = sum (z - tile_mean)^2, merged across tiles by bn_fwd_finalize.  Avoids the

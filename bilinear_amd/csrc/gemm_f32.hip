@@ -97,6 +97,7 @@ static int launch_128x128(hipStream_t s, int la, int lb, int epi, const GemmPara
   BLH_CASE(128, 128, 4, 2, ROWK, KROW, EPI_STORE)        // dgrad
   BLH_CASE(128, 128, 4, 2, ROWK, KROW, EPI_ADD)          // dgrad + residual gradient
   BLH_CASE(128, 128, 4, 2, KROW, KROW, EPI_STORE)        // wgrad (split over the batch)
+  BLH_CASE(128, 128, 4, 2, KROW, KROW, EPI_STORE_SQ)     // batched small-batch wgrad + its norm partials
   BLH_CASE(128, 128, 4, 2, KROW, ROWK, EPI_STORE)
   return BLH_ERR_INVALID_ARGUMENT;
 }
