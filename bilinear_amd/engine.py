@@ -289,6 +289,20 @@ class Engine:
             raise RuntimeError("expected a float32 input, got %s" % x.dtype)
         return x.contiguous()
 
+    def _native(self, name, *args):
+        """One native entry point: the registered operator while torch.compile traces (that is what it can trace),
+        the operator's implementation directly in eager mode (less host time per call).  Every tensor argument
+        must be on this engine's device: a host pointer handed to the library would fault, so they are checked here
+        (the operator dispatch would have refused them by itself)."""
+        if torch.compiler.is_compiling():
+            return getattr(torch.ops.bilinear_hip, name)(*args)
+        dev = self.params.device          # (a tensor's device always carries its index)
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.device != dev:
+                raise RuntimeError("bilinear_hip::%s: a tensor on '%s' where '%s' is expected (there is no CPU "
+                                   "implementation)" % (name, a.device, dev))
+        return _ops.IMPLS[name](*args)
+
     def _sync_callback(self, ws, all_reduce_sum, errors):
         """ctypes callback for the SyncBN variants: wraps the exchange buffer (which lives in
         the workspace) as a tensor and hands it to ``all_reduce_sum`` (stream-ordered)."""
@@ -318,8 +332,8 @@ class Engine:
         ws = self.workspace(batch)
         drop = self._drop_struct(batch)
         if sync is None:
-            pred = torch.ops.bilinear_hip.forward_train(
-                x, self.params, self.bn_running, self.bn_nbt, ws, self.masks, *self._op_args(),
+            pred = self._native(
+                "forward_train", x, self.params, self.bn_running, self.bn_nbt, ws, self.masks, *self._op_args(),
                 self.seed, self.rng_step, self.row_offset, self._momentum())
         else:
             pred = torch.empty(batch, OUT_FEATURES, dtype=torch.float32, device=x.device)
@@ -412,7 +426,7 @@ class Engine:
         batch = x.shape[0]
         ws = self.workspace(batch)
         self._saved_batch = None       # eval overwrites the saved activations
-        return torch.ops.bilinear_hip.eval_fwd(x, self.params, self.bn_running, ws, *self._op_args())
+        return self._native("eval_fwd", x, self.params, self.bn_running, ws, *self._op_args())
 
     def set_persistent_shadow(self, enabled):
         """gemm_dtype "bf16s" only (BLH_OPT_PERSISTENT_SHADOW; default off): the fused train step's
@@ -507,8 +521,8 @@ class Engine:
         self._grad_ready_cb = cb       # keep alive during the call
         if sync is None and on_ready is None and dpred is not None:
             d = self._saved_drop
-            torch.ops.bilinear_hip.backward(
-                x, dpred, self.params, ws, self.grads, self.masks if d.keep_mask else None,
+            self._native(
+                "backward", x, dpred, self.params, ws, self.grads, self.masks if d.keep_mask else None,
                 *self._op_args(), int(d.seed), int(d.step), int(d.row_offset))
         elif sync is None:
             N.check(N.lib().blh_backward(
@@ -562,8 +576,8 @@ class Engine:
         ws = self.workspace(batch)
         self._drop_struct(batch)          # validates explicit masks (shape, device)
         self._tune_streams()
-        pred, loss = torch.ops.bilinear_hip.train_step(
-            x, target, self.params, self.grads, exp_avg, exp_avg_sq, self.bn_running, self.bn_nbt,
+        pred, loss = self._native(
+            "train_step", x, target, self.params, self.grads, exp_avg, exp_avg_sq, self.bn_running, self.bn_nbt,
             ws, stats, self.masks, *self._op_args(), self.seed, self.rng_step, self.row_offset,
             self._momentum(), float(lr), float(betas[0]), float(betas[1]), float(eps),
             0.0 if max_norm is None else float(max_norm), int(step))
