@@ -221,7 +221,9 @@ static int check_drop(const blh_dropout* drop) {
 // the whole grid resident: where the device cannot hold it, the staged form is taken.
 // Returns 0 (not applicable), 1 (staged) or 2 (persistent).
 static int small_step_mode(const blh_context* ctx, const blh_model_desc* d, int64_t batch, bool drop_in) {
-  if (!ctx->small_step || d->gemm_dtype != 0 || batch > 64 || ctx->sync.fn) return 0;
+  // (gemm_dtype 2 / 3 — fp32 accuracy on the 16-bit matrix cores — take the same exact-fp32 kernels here: at 64
+  //  rows there is nothing for a matrix core to win, and exact fp32 is what those modes approximate)
+  if (!ctx->small_step || d->gemm_dtype == 4 || batch > 64 || ctx->sync.fn) return 0;
   static const bool off = getenv("BLH_NO_SMALL_STEP") != nullptr;
   if (off || d->width > 1024 || d->in_features > 1024) return 0;
   const bool want_persistent = ctx->small_step == 2 || (ctx->small_step == 1 && drop_in);

@@ -94,7 +94,7 @@ typedef enum {
                              at most one 128 KB-LDS workgroup per CU — the dispatcher then runs
                              them one after the other without a cross-queue latency — else 1.
                              Scheduling only: results are bit-identical.                     */
-  BLH_OPT_SMALL_STEP = 4, /* gemm_dtype 0, at most 64 rows, width <= 1024 — the reference's own batch size,
+  BLH_OPT_SMALL_STEP = 4, /* gemm_dtype 0 (and 2 / 3, which approximate it), at most 64 rows, width <= 1024 — the reference's own batch size,
                              /root/reference/util/config.py:15 — run on purpose-built kernels (small_step.hip) in
                              which a workgroup owns four columns of a stage for all rows, so BatchNorm, dropout
                              and the BatchNorm backward are local to it, instead of ~50 launch-bound launches:
