@@ -393,6 +393,14 @@ int blh_forward_eval(blh_context* ctx, const blh_model_desc* d, void* stream, co
     return forward_h(ctx, d, (hipStream_t)stream, params, const_cast<float*>(bn_running), nullptr, x,
                      &none, 0.f, carve_h(d, batch, workspace), pred, batch, false);
   const Workspace ws = carve(d, batch, workspace);
+  if (small_step_mode(ctx, d, batch, false)) {
+    // serving-sized batches: one launch per stage (7 launches instead of ~17)
+    SmallStepParams p;
+    BLH_TRY(small_params(p, ctx, d, const_cast<float*>(params), nullptr, nullptr, nullptr, const_cast<float*>(bn_running),
+                         nullptr, x, nullptr, &none, 0.f, nullptr, nullptr, ws, pred, nullptr, nullptr, batch, nullptr));
+    ctx->saved_small_ws = nullptr;          // (the activation buffers are overwritten)
+    return launch_small_eval_staged((hipStream_t)stream, p);
+  }
   return forward_impl(ctx, d, (hipStream_t)stream, params, const_cast<float*>(bn_running), nullptr, x,
                       &none, 0.f, ws, pred, batch, false, nullptr, 0.f, nullptr, nullptr);
 }

@@ -39,6 +39,8 @@ int launch_small_step(hipStream_t s, const SmallStepParams& p, int phase = SS_AL
 // decode gradients, loss / norm partials), backward stages (dec_here: decode gradients from the caller's dpred);
 // the gradient-norm partials are sumsq_part[0 .. W / 4 + out_f / 4)
 int launch_small_forward_staged(hipStream_t s, const SmallStepParams& p, bool mse);
+// eval-mode forward (running statistics, no dropout, nothing saved; p.nbt must be null): nh + 1 launches
+int launch_small_eval_staged(hipStream_t s, const SmallStepParams& p);
 // wgrad_here = false: the hidden stages' weight gradients are left to the caller (one batched GEMM launch)
 int launch_small_backward_staged(hipStream_t s, const SmallStepParams& p, bool dec_here, bool wgrad_here);
 

@@ -561,6 +561,26 @@ __global__ __launch_bounds__(SS_THREADS) void small_fwd_stage_kernel(const Small
   }
 }
 
+// Eval mode (/root/reference/valid_bilinear.py:31,52): Linear + BatchNorm with the running statistics + ReLU (+ skip),
+// no dropout, nothing saved.  Same operations in the same order as the eval epilogue of the big-batch path
+// (gemm_epilogue.h, EPI_BN_RELU): sc = gamma / sqrt(var + eps), sh = beta - mean * sc, a = max(fma(z, sc, sh), 0).
+__global__ __launch_bounds__(SS_THREADS) void small_eval_stage_kernel(const SmallStepParams p, const int i) {
+  const int W = p.W, B = p.batch;
+  const SsIdx x = ss_idx(W, B);
+  const int K = (i == 0) ? p.in_f : W;
+  const float* in = (i == 0) ? p.x : p.A[i - 1];
+  WBlock wb;
+  ss_load_w_rows(wb, p.params + p.w_off[i] + (int64_t)x.n0 * K, K, x.lane);
+  const float bias = p.params[p.b_off[i] + x.col], gamma = p.params[p.g_off[i] + x.col], beta = p.params[p.be_off[i] + x.col];
+  const float rm = p.bn_running[((int64_t)i * 2 + 0) * W + x.col], rv = p.bn_running[((int64_t)i * 2 + 1) * W + x.col];
+  const int64_t e = (int64_t)x.row * W + x.col;
+  const float skipv = (i >= 2 && (i & 1) == 0 && x.valid) ? p.A[i - 2][e] : 0.f;
+  const float z = ss_gemm<false>(wb, in, K, K, B, x.wave, x.lane) + bias;
+  const float sc = gamma * (1.0f / sqrtf(rv + 1e-5f));
+  const float sh = beta - rm * sc;
+  if (x.valid) p.A[i][e] = fmaxf(fmaf(z, sc, sh), 0.f) + skipv;
+}
+
 // grid: out_f / 4 workgroups.  MSE: + loss partials, d loss / d prediction, the decode gradients and their norm
 // partials (slots [W / 4, W / 4 + out_f / 4) of sumsq_part); either way the BatchNorm counters (every forward stage
 // has read them: the stage kernels are complete).
@@ -578,7 +598,7 @@ __global__ __launch_bounds__(SS_THREADS) void small_decode_kernel(const SmallSte
   const float tg = (MSE && valid) ? p.target[(int64_t)row * OF + oc] : 0.f;
   const float pr = ss_gemm<false>(wb, p.A[nh - 1], W, W, B, wave, lane) + bd;
   if (valid) p.pred[(int64_t)row * OF + oc] = pr;
-  if (g == 0 && tid == 0) for (int i = 0; i < nh; ++i) p.nbt[i] += 1;
+  if (p.nbt && g == 0 && tid == 0) for (int i = 0; i < nh; ++i) p.nbt[i] += 1;      // (eval: nbt == nullptr)
   if (!MSE) return;
   const float diff = valid ? pr - tg : 0.f;
   const float dp = diff * p.mse_scale;
@@ -743,6 +763,15 @@ int launch_small_forward_staged(hipStream_t s, const SmallStepParams& p, bool ms
   for (int i = 0; i < p.nh; ++i) hipLaunchKernelGGL(small_fwd_stage_kernel, grid, block, 0, s, p, i);
   if (mse) hipLaunchKernelGGL(small_decode_kernel<true>, dim3((unsigned)(p.out_f / 4)), block, 0, s, p);
   else hipLaunchKernelGGL(small_decode_kernel<false>, dim3((unsigned)(p.out_f / 4)), block, 0, s, p);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+int launch_small_eval_staged(hipStream_t s, const SmallStepParams& p) {
+  if (!small_staged_shape_ok(p) || p.nbt != nullptr) return BLH_ERR_INVALID_ARGUMENT;
+  const dim3 grid((unsigned)(p.W / 4)), block(SS_THREADS);
+  for (int i = 0; i < p.nh; ++i) hipLaunchKernelGGL(small_eval_stage_kernel, grid, block, 0, s, p, i);
+  hipLaunchKernelGGL(small_decode_kernel<false>, dim3((unsigned)(p.out_f / 4)), block, 0, s, p);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }

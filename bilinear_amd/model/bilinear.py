@@ -215,7 +215,7 @@ class BilinearUnit(nn.Module):
             raise RuntimeError(
                 "bilinear_amd.BilinearUnit runs only on a HIP device (MI355X); input is on '%s' "
                 "and there is no CPU fallback." % in_tensor.device)
-        eng.ensure(in_tensor.device)
+        # (the engine's forward_* methods re-check that the parameters still live in the arenas: eng.ensure)
         if not self.training:
             return eng.forward_eval(in_tensor)
         if torch.is_grad_enabled():

@@ -124,7 +124,8 @@ class Adam(torch.optim.Optimizer):
         """zero_grad + forward + MSELoss + backward + clip_grad_norm_ + step
         (train_bilinear.py:75-83) as one native enqueue; see BilinearUnit.train_step."""
         engine = _engine_of(module)
-        engine.ensure(x.device)
+        if engine.params is None or engine.device != x.device:
+            engine.ensure(x.device)          # (first use / device move; engine.train_step runs the full check)
         self._ensure_moments(engine)
         g = self.param_groups[0]
         self._t += 1
