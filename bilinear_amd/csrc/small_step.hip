@@ -25,6 +25,8 @@
 // win at 64 x 4 tiles); column statistics in fp32 over <= 64 rows, the norm of the gradient in fp64 partials, one
 // per workgroup, summed in a fixed order (deterministic).  Same Philox keep bits, same Adam arithmetic
 // (clip_adam_body, elementwise.hip) as the multi-launch path.
+#include <atomic>
+
 #include "common.h"
 #include "philox.h"
 #include "grid_barrier.h"
@@ -713,11 +715,16 @@ __global__ __launch_bounds__(SS_THREADS) void small_bwd_stage_kernel(const Small
 size_t small_step_lds_bytes(int nh) { return 2048 + 1024 + 64 + (size_t)nh * (256 + 256 + 8) * sizeof(float); }
 
 int small_step_max_grid(int* num_cus_out) {
-  static int cus = -1, fits = 0;
-  if (cus < 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  // per device (one entry per ordinal; a process normally drives one GPU): the dynamic-LDS attribute of the three
+  // persistent kernels is a per-device setting, and so is what fits
+  constexpr int MAX_DEV = 64;
+  static std::atomic<int> cache[MAX_DEV];          // 0 = not probed, -1 = does not fit, n = CUs
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return 0;
+  int v = cache[dev].load(std::memory_order_acquire);
+  if (v == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 0;
     const size_t lds = small_step_lds_bytes(SS_MAX_STAGES);
     int worst = 1 << 30;
     auto probe = [&](auto kern) {
@@ -731,11 +738,11 @@ int small_step_max_grid(int* num_cus_out) {
     probe(small_step_kernel<SS_ALL>);
     probe(small_step_kernel<SS_FWD>);
     probe(small_step_kernel<SS_BWD>);
-    fits = worst >= 1 ? n : 0;
-    cus = n;
+    v = worst >= 1 ? n : -1;
+    cache[dev].store(v, std::memory_order_release);      // (two threads racing here compute the same value)
   }
-  if (num_cus_out) *num_cus_out = cus;
-  return fits;
+  if (num_cus_out) *num_cus_out = v > 0 ? v : 0;
+  return v > 0 ? v : 0;
 }
 
 int launch_small_step(hipStream_t s, const SmallStepParams& p, int phase) {
