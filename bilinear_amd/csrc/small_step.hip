@@ -1,30 +1,34 @@
-// The whole training step at the reference's own batch size (util/config.py:15: batch_size = 64) as ONE
-// persistent launch: zero_grad, forward (Linear -> BatchNorm1d -> ReLU -> Dropout stages with block skips,
-// /root/reference/model/bilinear.py:7-13,31-41), MSE, backward, clip_grad_norm_(1) and Adam
-// (/root/reference/train_bilinear.py:75-83).
+// The training step, the drop-in forward / backward and the eval forward at the reference's own batch size
+// (util/config.py:15: batch_size = 64; anything up to 64 rows) on purpose-built kernels: zero_grad, forward
+// (Linear -> BatchNorm1d -> ReLU -> Dropout stages with block skips, /root/reference/model/bilinear.py:7-13,31-41),
+// MSE, backward, clip_grad_norm_(1) and Adam (/root/reference/train_bilinear.py:75-83).
 //
 // Why: at 64 rows the multi-launch step is ~50 kernels of 5 us each, every one of them nothing but launch latency
 // and a cold first read (0.32 ms per step at 2 x 1024, hipGraph replay no faster).  Here the batch is at most 64
 // rows, so a workgroup that owns FOUR columns of a stage owns them for all rows: BatchNorm statistics, the BatchNorm
-// backward sums, the weight gradient of its four weight rows and the dropout patch (32 rows x 4 columns per
-// Philox call, philox.h) are all local to it; only the activations (forward) and dZ (backward) of a stage cross
-// workgroups, through L2, behind one grid barrier per stage (grid_barrier.h).  2 nh + 1 barriers per step
-// (nh = 1 + 2 num_blocks stages).
+// backward sums, the bias / gamma / beta gradients and the dropout patch (32 rows x 4 columns per Philox call,
+// philox.h) are all local to it; only the activations (forward) and dZ (backward) of a stage cross workgroups.
+//
+// Two forms of the same stage bodies (BLH_OPT_SMALL_STEP picks):
+//   * ONE LAUNCH PER STAGE (second half of this file; the fused step's default, 0.153 ms): stage kernels, a decode
+//     kernel, one batched GEMM launch for the hidden weight gradients, the library's clip + Adam kernel;
+//   * ONE PERSISTENT LAUNCH (small_step_kernel, first half; 0.200 ms; its forward / backward halves serve the
+//     host-bound drop-in loop): a grid barrier per stage (grid_barrier.h), 2 nh + 1 per step (nh = 1 + 2 num_blocks).
 //
 // Work split: workgroup g owns column group cg(g) (XCD-aware: the 32 workgroups of one XCD own 128 adjacent
 // columns, so the strided weight columns the data gradient reads are fetched once per XCD L2).  256 threads =
 // 4 waves x 16 rows; the 64 lanes of a wave split the reduction index four elements each (float4, coalesced
-// rows of the activation), every lane accumulates a 16 x 4 block and a 63-shuffle butterfly leaves element
+// rows of the activation), every lane accumulates 8 x 4 blocks and a shuffle butterfly leaves element
 // (row, column) = (tid / 4, tid % 4) in thread tid.  That mapping is the same in every stage, forward and backward,
-// so what backward needs of forward (x-hat, the ReLU/dropout gate, the BatchNorm scale) never leaves the
-// workgroup: it waits in LDS.  The weights of the next stage are requested BEFORE the barrier wait (they do not
-// depend on anyone), so their HBM latency hides behind the barrier; weight-gradient work sits between
-// arrive() and wait() for the same reason.
+// so what backward needs of forward (x-hat, the ReLU/dropout gate, the BatchNorm scale) belongs to the same thread:
+// in the persistent kernel it waits in LDS, between stage launches in the workspace.  In the persistent kernel the
+// weights of the next stage are requested BEFORE the barrier wait (they do not depend on anyone), and
+// weight-gradient work sits between arrive() and wait().
 //
 // Arithmetic is fp32 FMA on the vector ALU (0.5 MFLOP per workgroup and stage: the matrix cores have nothing to
-// win at 64 x 4 tiles); column statistics in fp32 over <= 64 rows, the norm of the gradient in fp64 partials, one
-// per workgroup, summed in a fixed order (deterministic).  Same Philox keep bits, same Adam arithmetic
-// (clip_adam_body, elementwise.hip) as the multi-launch path.
+// win at 64 x 4 tiles); column statistics in fp32 over <= 64 rows, the norm of the gradient in fp64 partials
+// summed in a fixed order (deterministic).  Same Philox keep bits, same Adam arithmetic (clip_adam_body,
+// elementwise.hip) as the multi-launch path.
 #include <atomic>
 
 #include "common.h"
