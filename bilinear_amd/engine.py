@@ -87,6 +87,7 @@ class Engine:
         self.generation = 0            # counts train-mode forwards (guards backward, see _LifterFunction)
         self.shadow_epoch = 0          # counts invalidations of the persistent bf16 weight image
         self._grad_ptr_cache = None
+        self._grad_view_cache = None
         self._np_cache = None          # (_named_params list, module links, parameter links, BatchNorm modules)
 
     # ---------------------------------------------------------------- arenas --
@@ -198,6 +199,15 @@ class Engine:
         if len(shape) == 2:
             return self.grads.as_strided(shape, (shape[1], 1), off)
         return self.grads.as_strided(shape, (1,), off)
+
+    def grad_views(self):
+        """The arena slots as tensors, in _named_params() order — cached per gradient arena, so that handing a
+        Parameter its ``.grad`` costs an attribute store instead of a new view (22 of them per backward)."""
+        c = self._grad_view_cache
+        if c is None or c[0] != self.grads.data_ptr():
+            c = (self.grads.data_ptr(), [self.grad_view(off, shape) for _, off, shape in self.layout.entries])
+            self._grad_view_cache = c
+        return c[1]
 
     def grad_ptrs(self):
         """Device addresses of the arena slots, in _named_params() order (cached per gradient arena)."""

@@ -159,8 +159,7 @@ class _LifterFunction(torch.autograd.Function):
         old = engine.grads.clone() if accumulate else None
         hook = engine.grad_ready_hook
         engine.backward(ctx.x, dpred, on_ready=hook, generation=ctx.generation)
-        for (_, p, off, shape) in engine._named_params():
-            view = engine.grad_view(off, shape)
+        for (_, p, off, shape), view in zip(engine._named_params(), engine.grad_views()):
             if p.grad is None:
                 p.grad = view
             elif p.grad.data_ptr() == view.data_ptr():

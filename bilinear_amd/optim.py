@@ -132,9 +132,9 @@ class Adam(torch.optim.Optimizer):
         pred, loss = engine.train_step(x, target, self._exp_avg, self._exp_avg_sq, float(g["lr"]),
                                        g["betas"], g["eps"], max_norm, self._t, self._stats)
         self._sync_step_state(engine)
-        for _, p, off, shape in engine._named_params():
+        for (_, p, _, _), view in zip(engine._named_params(), engine.grad_views()):
             if p.grad is None:
-                p.grad = engine.grad_view(off, shape)
+                p.grad = view
         return pred, loss
 
     @property
