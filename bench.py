@@ -576,7 +576,7 @@ def batch64_block(dev, steps, ramp_ms):
     def one_step():
         return net.train_step(opt, x, t, max_norm=1.0)
     out = {}
-    for name, small in (("staged", 3), ("one_launch", 2), ("multi_launch", 0)):
+    for name, small in (("staged", 1), ("one_launch", 2), ("multi_launch", 0)):
         net.engine.set_small_step(small)
         pre_ramp(one_step, ramp_ms)
         torch.cuda.synchronize()

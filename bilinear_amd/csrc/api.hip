@@ -121,7 +121,7 @@ int blh_context_set_option(blh_context* c, int32_t option, int32_t value) {
       c->late_fork = value;
       return BLH_OK;
     case BLH_OPT_SMALL_STEP:
-      if (value < 0 || value > 3) return BLH_ERR_INVALID_ARGUMENT;
+      if (value < 0 || value > 2) return BLH_ERR_INVALID_ARGUMENT;
       c->small_step = value;
       return BLH_OK;
     case BLH_OPT_PERSISTENT_SHADOW:
@@ -213,12 +213,12 @@ static int check_drop(const blh_dropout* drop) {
   return BLH_OK;
 }
 
-// Batches of at most 64 rows in exact fp32 take the small-batch step (small_step.hip).  BLH_OPT_SMALL_STEP: 1 (default)
-// = automatic: the fused step (blh_train_step) as one launch per stage — GPU-bound, 0.154 ms against 0.200 for the
-// persistent form — and the drop-in halves (blh_forward_train, blh_backward) as one persistent launch each — that loop
-// is host-bound, 2 launches cost the host less than 11; 2 = persistent everywhere; 3 = one launch per stage
-// everywhere; 0 or BLH_NO_SMALL_STEP=1 = the multi-launch path of every other batch size.  The persistent form needs
-// the whole grid resident: where the device cannot hold it, the staged form is taken.
+// Batches of at most 64 rows in exact fp32 take the small-batch kernels (small_step.hip).  BLH_OPT_SMALL_STEP: 1 (default)
+// = one launch per stage (the fused step 0.153 ms against 0.200 for the persistent form; the host-bound drop-in loop
+// the same within its noise, tools_dev/dropin_b64_ab.py: medians 0.31 / 0.36 ms) — no grid barrier, no residency
+// requirement; 2 = persistent launches (one for the fused step, one each for the drop-in forward and backward);
+// 0 or BLH_NO_SMALL_STEP=1 = the multi-launch path of every other batch size.  The persistent form needs the whole
+// grid resident: where the device cannot hold it, the staged form is taken.
 // Returns 0 (not applicable), 1 (staged) or 2 (persistent).
 static int small_step_mode(const blh_context* ctx, const blh_model_desc* d, int64_t batch, bool drop_in) {
   // (gemm_dtype 2 / 3 — fp32 accuracy on the 16-bit matrix cores — take the same exact-fp32 kernels here: at 64
@@ -226,7 +226,8 @@ static int small_step_mode(const blh_context* ctx, const blh_model_desc* d, int6
   if (!ctx->small_step || d->gemm_dtype == 4 || batch > 64 || ctx->sync.fn) return 0;
   static const bool off = getenv("BLH_NO_SMALL_STEP") != nullptr;
   if (off || d->width > 1024 || d->in_features > 1024) return 0;
-  const bool want_persistent = ctx->small_step == 2 || (ctx->small_step == 1 && drop_in);
+  (void)drop_in;
+  const bool want_persistent = ctx->small_step == 2;
   if (want_persistent && ctx->grid_bar) {
     const int grid = small_step_max_grid(nullptr);
     if (grid > 0 && d->width / 4 <= grid) return 2;

@@ -35,7 +35,7 @@ struct blh_context {
   // BLH_OPT_PERSISTENT_SHADOW: the (params, workspace) whose bf16 parameter image the last fused
   // step's Adam kernel left up to date (nullptr: none)
   bool persistent_shadow = false;
-  int small_step = 1;                 // BLH_OPT_SMALL_STEP: 0 off, 1 automatic, 2 persistent launches, 3 one launch per stage
+  int small_step = 1;                 // BLH_OPT_SMALL_STEP: 0 off, 1 one launch per stage, 2 persistent launches
   // the workspace whose saved activations are in the one-launch forward's format (small_step.hip, SS_FWD), and
   // their batch; any multi-launch train-mode forward on the context clears it (forward_impl)
   const void* saved_small_ws = nullptr;

@@ -476,13 +476,12 @@ class Engine:
         self.ctx.set_option(N.OPT_TWO_STREAM, 1 if enabled else 0)
 
     def set_small_step(self, mode):
-        """The small-batch kernels (at most 64 rows, fp32, BLH_OPT_SMALL_STEP): True / 1 / "auto" (default) = the fused
-        step as one launch per stage, the drop-in forward / backward as one persistent launch each; 2 / "persistent" =
-        persistent launches everywhere; 3 / "staged" = one launch per stage everywhere; False / 0 = the multi-launch
-        path every other batch size takes."""
+        """The small-batch kernels (at most 64 rows, fp32, BLH_OPT_SMALL_STEP): True / 1 / "staged" (default) = one
+        launch per stage; 2 / "persistent" = persistent launches with grid barriers; False / 0 = the multi-launch path
+        every other batch size takes."""
         if self.ctx is None:
             raise RuntimeError("the engine is not on a device yet")
-        value = {"auto": 1, "persistent": 2, "staged": 3, "off": 0}.get(mode, mode)
+        value = {"staged": 1, "persistent": 2, "off": 0}.get(mode, mode)
         self.ctx.set_option(N.OPT_SMALL_STEP, int(value))
 
     def backward(self, x, dpred, on_ready=None, sync=None, global_batch=None, generation=None):

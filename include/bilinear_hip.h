@@ -94,23 +94,24 @@ typedef enum {
                              at most one 128 KB-LDS workgroup per CU — the dispatcher then runs
                              them one after the other without a cross-queue latency — else 1.
                              Scheduling only: results are bit-identical.                     */
-  BLH_OPT_SMALL_STEP = 4, /* gemm_dtype 0 (and 2 / 3, which approximate it), at most 64 rows, width <= 1024 — the reference's own batch size,
-                             /root/reference/util/config.py:15 — run on purpose-built kernels (small_step.hip) in
-                             which a workgroup owns four columns of a stage for all rows, so BatchNorm, dropout
-                             and the BatchNorm backward are local to it, instead of ~50 launch-bound launches:
-                               1 (default) automatic: blh_train_step / blh_train_step_captured as one launch per
-                                 stage (2 stages + 3 launches: 0.154 ms per step at 2 x 1024 against 0.316);
-                                 blh_forward_train / blh_backward (the drop-in loop, host-bound) as ONE persistent
-                                 launch each, with grid barriers between the stages;
-                               2 persistent launches everywhere (the fused step: one launch, 0.200 ms);
-                               3 one launch per stage everywhere;   0 the multi-launch path.
+  BLH_OPT_SMALL_STEP = 4, /* gemm_dtype 0 (and 2 / 3, which approximate it), at most 64 rows, width <= 1024 — the
+                             reference's own batch size, /root/reference/util/config.py:15 — run on purpose-built
+                             kernels (small_step.hip) in which a workgroup owns four columns of a stage for all
+                             rows, so BatchNorm, dropout and the BatchNorm backward are local to it, instead of
+                             ~50 launch-bound launches.  Applies to blh_train_step(_captured), blh_forward_train,
+                             blh_backward and blh_forward_eval:
+                               1 (default) one launch per stage (the fused step: 2 stages + 3 launches, 0.153 ms
+                                 at 2 x 1024 against 0.316; no residency requirement);
+                               2 persistent launches with grid barriers between the stages (the fused step: one
+                                 launch, 0.200 ms; forward / backward: one each);   0 the multi-launch path.
                              Same arithmetic up to the order of fp32 sums (all within the fp32 parity tolerance).
                              The saved activations of such a forward are in the small-batch format: the context
-                             pairs blh_backward with them.  A persistent launch fills the device (one workgroup per
-                             CU, all resident): do not run two of them at the same time on one device (two contexts
-                             on two streams) — neither could become resident, their barriers would give up after
-                             ~0.3 s each and the results would be wrong (blh_context_grid_barrier_timeouts() counts
-                             that); where the device cannot hold the grid at all the staged form is taken.        */
+                             pairs blh_backward with them.  A persistent launch (2) fills the device (one
+                             workgroup per CU, all resident): do not run two of them at the same time on one
+                             device (two contexts on two streams) — neither could become resident, their barriers
+                             would give up after ~0.3 s each and the results would be wrong
+                             (blh_context_grid_barrier_timeouts() counts that); where the device cannot hold the
+                             grid at all the staged form is taken.                                          */
   BLH_OPT_PERSISTENT_SHADOW = 3
                           /* gemm_dtype 4 only, default 0.  1: the Adam kernel of blh_train_step /
                              blh_train_step_captured also writes the bf16 image of the updated

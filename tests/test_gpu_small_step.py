@@ -35,7 +35,7 @@ def _pair(dev, nb, width, seed=11, mode=1):
     return nets
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])     # automatic (default) / persistent launches / one launch per stage
+@pytest.mark.parametrize("mode", [1, 2])        # one launch per stage (default) / persistent launches
 @pytest.mark.parametrize("nb,width,batch", [(2, 1024, 64), (2, 1024, 8), (2, 1024, 33), (1, 256, 2), (0, 64, 17),
                                             (4, 512, 64), (3, 1024, 50)])
 def test_small_step_equals_the_multi_launch_step(nb, width, batch, mode):
@@ -70,7 +70,7 @@ def test_small_step_equals_the_multi_launch_step(nb, width, batch, mode):
     assert int(na.encode[1].num_batches_tracked) == steps == int(nb_.encode[1].num_batches_tracked)
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 2])
 def test_small_step_is_deterministic(mode):
     """Two runs of the same steps are bit-identical (every sum has a fixed order)."""
     dev = _dev()
@@ -86,7 +86,7 @@ def test_small_step_is_deterministic(mode):
     assert torch.equal(na.engine.grads, nc.engine.grads) and torch.equal(na.engine.bn_running, nc.engine.bn_running)
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("batch", [64, 24])
 def test_small_step_against_the_fp64_oracle_and_philox_replay(batch, mode):
     """(a) explicit gate-safe masks: every observable of the step against oracle/numpy_oracle.py at the tight fp32
@@ -99,7 +99,7 @@ def test_small_step_against_the_fp64_oracle_and_philox_replay(batch, mode):
     xt, tt = torch.from_numpy(entry["x"]).to(dev), torch.from_numpy(entry["t"]).to(dev)
     r = T._run_oracle(entry, entry["safe"])
     net, opt = T._build(entry["st0"], dev, nb, width, "fp32")
-    assert net.engine.ctx.get_option(4) == 1                   # default: automatic
+    assert net.engine.ctx.get_option(4) == 1                   # default: one launch per stage
     net.engine.set_small_step(mode)
     net.engine.set_dropout_masks(entry["safe"])
     pred, loss = net.train_step(opt, xt, tt, max_norm=1.0)
@@ -121,7 +121,7 @@ def test_small_step_against_the_fp64_oracle_and_philox_replay(batch, mode):
     assert out[0][5] == out[1][5]
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("nb,width,batch", [(2, 1024, 64), (1, 512, 40)])
 def test_drop_in_forward_and_backward_take_the_one_launch_kernels(nb, width, batch, mode):
     """The reference's five-call step body (/root/reference/train_bilinear.py:75-83) at <= 64 rows: forward and

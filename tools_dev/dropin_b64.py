@@ -30,6 +30,10 @@ import bilinear_amd.model.bilinear as MB
 if len(sys.argv) > 1:
     MB.EAGER_AUTOGRAD = sys.argv[1]
 print("eager autograd bridge:", MB.EAGER_AUTOGRAD)
+net.engine.ensure(dev)
+if len(sys.argv) > 2:
+    net.engine.set_small_step(int(sys.argv[2]))
+print("small-step option:", net.engine.ctx.get_option(4))
 for name, fn in (("five-call drop-in", five), ("train_step", one)):
     for _ in range(300):
         fn()
