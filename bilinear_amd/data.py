@@ -88,18 +88,20 @@ class DevicePoseDataset:
         """Batches of one pass over the split (DataLoader(shuffle=..., drop_last=False) semantics,
         train_bilinear.py:33-43).  The permutation is drawn on the device from (seed, epoch)."""
         n = len(self)
+        xs, ts, acts = self.x, self.t, self.action_ids
         if shuffle:
+            # the whole epoch is gathered ONCE (two launches, 0.2 ms for Human3.6M's 1.56 M poses) and the batches are
+            # views of it: at the reference's batch of 64 the step takes 0.15 ms, and a per-batch index_select pair
+            # (two launches + 40 us of host time) would cost more than the step it feeds
             g = torch.Generator(device=self.device).manual_seed(self.seed * 1000003 + int(epoch))
             perm = torch.randperm(n, device=self.device, generator=g)
+            xs, ts = xs.index_select(0, perm), ts.index_select(0, perm)
+            if with_actions and acts is not None:
+                acts = acts.index_select(0, perm)
         for b in range(self.num_batches(batch_size, drop_last)):
             lo, hi = b * batch_size, min(n, (b + 1) * batch_size)
-            if shuffle:
-                sel = perm[lo:hi]
-                x, t = self.x.index_select(0, sel), self.t.index_select(0, sel)
-                a = self.action_ids.index_select(0, sel) if (with_actions and self.action_ids is not None) else None
-            else:
-                x, t = self.x[lo:hi], self.t[lo:hi]
-                a = self.action_ids[lo:hi] if (with_actions and self.action_ids is not None) else None
+            x, t = xs[lo:hi], ts[lo:hi]
+            a = acts[lo:hi] if (with_actions and acts is not None) else None
             yield (x, t, a) if with_actions else (x, t)
 
     @staticmethod
