@@ -170,3 +170,41 @@ def test_drop_in_forward_and_backward_take_the_one_launch_kernels(nb, width, bat
     assert torch.isfinite(na.engine.grads).all() and not torch.equal(g1, na.engine.grads)
     for (_, p, off, shape), ptr in zip(na.engine._named_params(), na.engine.grad_ptrs()):
         assert p.grad.data_ptr() == ptr
+
+
+def test_small_step_shape_sweep():
+    """Seeded sweep over depths, widths (every multiple of 64 up to 1024 is a legal width: the XCD-aware column-group
+    map, the batched weight-gradient GEMM and the ragged tiles all depend on it) and batches 2 .. 64 (batches that are
+    not multiples of 32 take the in-kernel weight gradients): one fused step and one five-call step against the
+    multi-launch path."""
+    import bilinear_amd
+    dev = _dev()
+    rng = np.random.default_rng(20260)
+    crit = torch.nn.MSELoss()
+    combos = [(int(rng.integers(0, 6)), int(64 * rng.integers(1, 17)), int(rng.integers(2, 65))) for _ in range(10)]
+    combos += [(2, 960, 64), (1, 192, 32), (5, 448, 63)]
+    for nb, width, batch in combos:
+        (na, oa), (nm, om) = _pair(dev, nb, width, seed=nb * 1000 + width + batch)
+        g = torch.Generator().manual_seed(width + batch)
+        x = torch.randn(batch, 32, generator=g).to(dev)
+        t = torch.randn(batch, 48, generator=g).to(dev)
+        pa, la = na.train_step(oa, x, t, max_norm=1.0)
+        pm, lm = nm.train_step(om, x, t, max_norm=1.0)
+        torch.cuda.synchronize()
+        what = (nb, width, batch)
+        assert _rel(pa, pm) <= 2e-5, (what, "pred", _rel(pa, pm))
+        assert abs(la.item() - lm.item()) <= 2e-5 * abs(lm.item()), what
+        if batch >= 8:           # (below that BatchNorm leaves gradients that are rounding noise)
+            assert _rel(na.engine.grads, nm.engine.grads) <= 2e-4, (what, "grads", _rel(na.engine.grads, nm.engine.grads))
+            assert _rel(oa._exp_avg_sq, om._exp_avg_sq) <= 4e-4, what
+        assert _rel(na.engine.bn_running, nm.engine.bn_running) <= 2e-5, what
+        raws = []
+        for net, opt in ((na, oa), (nm, om)):
+            opt.zero_grad()
+            loss = crit(net(x), t)
+            loss.backward()
+            raws.append(net.engine.grads.clone())
+        torch.cuda.synchronize()
+        if batch >= 8:
+            assert _rel(raws[0], raws[1]) <= 1e-3, (what, "drop-in raw grads", _rel(raws[0], raws[1]))
+        assert torch.isfinite(raws[0]).all(), what
