@@ -208,3 +208,35 @@ def test_small_step_shape_sweep():
         if batch >= 8:
             assert _rel(raws[0], raws[1]) <= 1e-3, (what, "drop-in raw grads", _rel(raws[0], raws[1]))
         assert torch.isfinite(raws[0]).all(), what
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_captured_small_step_replays_like_eager(mode):
+    """hipGraph replay of the small-batch step (blh_train_step_captured: Adam scalars and the dropout step from device
+    memory; persistent form: the barrier's base survives from replay to replay) is bit-identical to the eager step."""
+    import bilinear_amd
+    dev = _dev()
+
+    def make():
+        torch.manual_seed(5)
+        net, opt, _, _ = bilinear_amd.load(dev, num_blocks=2, gemm_dtype="fp32")
+        net.train()
+        net.engine.ensure(dev)
+        net.engine.seed = 99
+        net.engine.set_small_step(mode)
+        return net, opt
+
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(64, 32, generator=g).to(dev) for _ in range(4)]
+    ts = [torch.randn(64, 48, generator=g).to(dev) for _ in range(4)]
+    net_a, opt_a = make()
+    net_b, opt_b = make()
+    step = bilinear_amd.CapturedTrainStep(net_b, opt_b, 64)
+    for i in range(4):
+        pa, la = net_a.train_step(opt_a, xs[i], ts[i])
+        pb, lb = step(xs[i], ts[i])
+        assert torch.equal(pa, pb) and la.item() == lb.item(), i
+    torch.cuda.synchronize()
+    assert torch.equal(net_a.engine.params, net_b.engine.params)
+    assert torch.equal(opt_a._exp_avg_sq, opt_b._exp_avg_sq)
+    assert net_b.engine.ctx.grid_barrier_timeouts() == 0
