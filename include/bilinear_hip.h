@@ -133,7 +133,8 @@ void* blh_context_side_stream(blh_context* ctx);
  * denied the whole device (another training forward running beside it) ends with wrong results instead of
  * hanging.  This returns how many workgroups ever gave up waiting on this context's barrier (0 = never;
  * synchronous: one small device-to-host copy).  The fused stage is bit-identical to the three-launch form and
- * measured slower (profiles/r04_fused_forward.md): it is opt-in, BLH_FWD_FUSE=1.                             */
+ * measured slower (profiles/r04_fused_forward.md): it is opt-in, BLH_FWD_FUSE=1.  The persistent small-batch
+ * launches (BLH_OPT_SMALL_STEP = 2) use barriers of the same kind and are counted here too.                  */
 int64_t blh_context_grid_barrier_timeouts(blh_context* ctx);
 /* Replace the current device's process-wide side stream by a freshly created one; every context of
  * the device uses the new one from its next call on (the old one is drained and destroyed: call it
