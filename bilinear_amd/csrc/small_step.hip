@@ -41,7 +41,8 @@ namespace blh {
 namespace {
 
 constexpr int SS_THREADS = 256;
-constexpr int SS_MAX_ROWS = 64;
+constexpr int SS_MAX_ROWS = 64;          // the persistent kernel
+constexpr int SS_STAGED_MAX_ROWS = 128;  // the stage kernels (8 waves per workgroup above 64 rows)
 constexpr int SS_PASSES = 4;            // reduction length <= 4 * 256
 constexpr int SS_SMALLK = 64;           // encode fan-in up to which the staged stage-0 kernel keeps x in LDS
 constexpr int SS_RB = 8;                // rows per batch of loads in ss_gemm (x 4 passes = 32 loads in flight per wave;
@@ -176,6 +177,7 @@ __device__ __forceinline__ float ss_gemm(const WBlock& wb, const float* __restri
 }
 
 // sum over the rows of the workgroup's 64 x 4 tile: every thread gets the sum of its column
+template <int NW = 4>
 __device__ __forceinline__ float ss_colsum(float v, float* sh, int wave, int lane) {
   v += __shfl_xor(v, 4);
   v += __shfl_xor(v, 8);
@@ -185,7 +187,9 @@ __device__ __forceinline__ float ss_colsum(float v, float* sh, int wave, int lan
   if (lane < 4) sh[wave * 4 + lane] = v;
   __syncthreads();
   const int c = lane & 3;
-  return (sh[c] + sh[4 + c]) + (sh[8 + c] + sh[12 + c]);
+  float t = (sh[c] + sh[4 + c]) + (sh[8 + c] + sh[12 + c]);
+  if (NW == 8) t += (sh[16 + c] + sh[20 + c]) + (sh[24 + c] + sh[28 + c]);
+  return t;
 }
 
 __device__ __forceinline__ bool ss_keep(const DropoutSrc& d, int layer_index, int64_t layer_elems, int row, int col,
@@ -199,11 +203,11 @@ __device__ __forceinline__ bool ss_keep(const DropoutSrc& d, int layer_index, in
 }
 
 // dW rows of the workgroup: out[c][k] = sum_b dz[b][c] * In[b][k]; dz: LDS [64] float4 (4 columns of a row)
-template <bool PUBLISH = true>
+template <bool PUBLISH = true, int NT = SS_THREADS>
 __device__ __forceinline__ double ss_wgrad(const float4* __restrict__ sh_dz, const float* __restrict__ In, int K,
                                            int batch, float* __restrict__ out) {
   double sq = 0.0;
-  for (int kq = threadIdx.x; kq * 4 < K; kq += SS_THREADS) {
+  for (int kq = threadIdx.x; kq * 4 < K; kq += NT) {
     float4 acc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = float4{0.f, 0.f, 0.f, 0.f};
@@ -235,11 +239,12 @@ __device__ __forceinline__ double ss_wgrad(const float4* __restrict__ sh_dz, con
   return sq;
 }
 
+template <int NT = SS_THREADS>
 __device__ __forceinline__ double ss_block_sum(double v, double* sh) {
   __syncthreads();
   sh[threadIdx.x] = v;
   __syncthreads();
-  for (int o = SS_THREADS / 2; o >= 1; o >>= 1) {
+  for (int o = NT / 2; o >= 1; o >>= 1) {
     if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
     __syncthreads();
   }
@@ -524,9 +529,10 @@ __device__ __forceinline__ SsIdx ss_idx(int W, int B) {
   return x;
 }
 
-// grid: W / 4 workgroups
-__global__ __launch_bounds__(SS_THREADS) void small_fwd_stage_kernel(const SmallStepParams p, const int i) {
-  __shared__ float sh_cs[16];
+// grid: W / 4 workgroups of NW waves: NW = 4 serves up to 64 rows, NW = 8 up to 128 (wave w takes rows 16 w .. 16 w + 15)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void small_fwd_stage_kernel(const SmallStepParams p, const int i) {
+  __shared__ float sh_cs[4 * NW];
   const int W = p.W, B = p.batch;
   const SsIdx x = ss_idx(W, B);
   const int K = (i == 0) ? p.in_f : W;
@@ -544,9 +550,9 @@ __global__ __launch_bounds__(SS_THREADS) void small_fwd_stage_kernel(const Small
   const bool kept = x.valid && ss_keep(p.drop, i, (int64_t)B * W, x.row, x.col, W);
   float z = ss_gemm<false>(wb, in, K, K, B, x.wave, x.lane) + bias;
   if (!x.valid) z = 0.f;
-  const float mean = ss_colsum(z, sh_cs, x.wave, x.lane) * inv_b;
+  const float mean = ss_colsum<NW>(z, sh_cs, x.wave, x.lane) * inv_b;
   const float dlt = x.valid ? z - mean : 0.f;
-  const float m2 = ss_colsum(dlt * dlt, sh_cs, x.wave, x.lane);
+  const float m2 = ss_colsum<NW>(dlt * dlt, sh_cs, x.wave, x.lane);
   const float invstd = (float)(1.0 / sqrt((double)m2 / (double)B + (double)1e-5f));
   const float sc = gamma * invstd;
   const float sh = beta - mean * sc;
@@ -570,7 +576,8 @@ __global__ __launch_bounds__(SS_THREADS) void small_fwd_stage_kernel(const Small
 // Eval mode (/root/reference/valid_bilinear.py:31,52): Linear + BatchNorm with the running statistics + ReLU (+ skip),
 // no dropout, nothing saved.  Same operations in the same order as the eval epilogue of the big-batch path
 // (gemm_epilogue.h, EPI_BN_RELU): sc = gamma / sqrt(var + eps), sh = beta - mean * sc, a = max(fma(z, sc, sh), 0).
-__global__ __launch_bounds__(SS_THREADS) void small_eval_stage_kernel(const SmallStepParams p, const int i) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void small_eval_stage_kernel(const SmallStepParams p, const int i) {
   const int W = p.W, B = p.batch;
   const SsIdx x = ss_idx(W, B);
   const int K = (i == 0) ? p.in_f : W;
@@ -590,10 +597,10 @@ __global__ __launch_bounds__(SS_THREADS) void small_eval_stage_kernel(const Smal
 // grid: out_f / 4 workgroups.  MSE: + loss partials, d loss / d prediction, the decode gradients and their norm
 // partials (slots [W / 4, W / 4 + out_f / 4) of sumsq_part); either way the BatchNorm counters (every forward stage
 // has read them: the stage kernels are complete).
-template <bool MSE>
-__global__ __launch_bounds__(SS_THREADS) void small_decode_kernel(const SmallStepParams p) {
-  __shared__ float sh_cs[16];
-  __shared__ double sh_d[SS_THREADS];
+template <bool MSE, int NW>
+__global__ __launch_bounds__(64 * NW) void small_decode_kernel(const SmallStepParams p) {
+  __shared__ float sh_cs[4 * NW];
+  __shared__ double sh_d[64 * NW];
   const int W = p.W, B = p.batch, OF = p.out_f, nh = p.nh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x;
   const int o0 = g * 4, row = tid >> 2, c = tid & 3, oc = o0 + c;
@@ -609,16 +616,18 @@ __global__ __launch_bounds__(SS_THREADS) void small_decode_kernel(const SmallSte
   const float diff = valid ? pr - tg : 0.f;
   const float dp = diff * p.mse_scale;
   if (valid) p.dpred[(int64_t)row * OF + oc] = dp;
-  (void)ss_colsum(diff * diff, sh_cs, wave, lane);
-  if (tid == 0)
-    p.loss_part[g] = (sh_cs[0] + sh_cs[4] + sh_cs[8] + sh_cs[12]) + (sh_cs[1] + sh_cs[5] + sh_cs[9] + sh_cs[13]) +
-                     (sh_cs[2] + sh_cs[6] + sh_cs[10] + sh_cs[14]) + (sh_cs[3] + sh_cs[7] + sh_cs[11] + sh_cs[15]);
+  (void)ss_colsum<NW>(diff * diff, sh_cs, wave, lane);
+  if (tid == 0) {       // the per-wave column sums -> one partial per workgroup (fixed order)
+    float l = 0.f;
+    for (int k = 0; k < 4 * NW; ++k) l += sh_cs[k];
+    p.loss_part[g] = l;
+  }
   // (the decode WEIGHT gradient is formed by the top backward stage kernel, four columns per workgroup, from the
   //  activations its threads own: here 12 workgroups would each read the whole activation for it, 8 us)
   double sq = 0.0;
-  const float db = ss_colsum(dp, sh_cs, wave, lane);
+  const float db = ss_colsum<NW>(dp, sh_cs, wave, lane);
   if (row == 0) { p.grads[p.dec_b + oc] = db; sq += (double)db * db; }
-  const double wg_sq = ss_block_sum(sq, sh_d);
+  const double wg_sq = ss_block_sum<64 * NW>(sq, sh_d);
   if (tid == 0) p.sumsq_part[(W >> 2) + g] = wg_sq;
 }
 
@@ -627,13 +636,15 @@ __global__ __launch_bounds__(SS_THREADS) void small_decode_kernel(const SmallSte
 // gradients of the hidden stages come from ONE batched MFMA GEMM launch behind the stage kernels (the host's
 // launch_gemm over the consecutive dZ / A buffers: 64 tiles of 128 x 128 per stage read 4 MB where the four-column
 // ownership of this kernel reads the whole activation in every workgroup — 8 us per stage).
-__global__ __launch_bounds__(SS_THREADS) void small_bwd_stage_kernel(const SmallStepParams p, const int i,
-                                                                      const int dec_here, const int wgrad_here) {
-  __shared__ float sh_cs[16];
-  __shared__ float4 sh_dz[SS_MAX_ROWS];
-  __shared__ double sh_d[SS_THREADS];
-  __shared__ __align__(16) float sh_big[SS_MAX_ROWS * 64];      // dpred [B][out_f] (top stage)
-  __shared__ __align__(16) float sh_x[SS_MAX_ROWS * SS_SMALLK]; // x [B][in_f] (stage 0)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void small_bwd_stage_kernel(const SmallStepParams p, const int i,
+                                                                   const int dec_here, const int wgrad_here) {
+  constexpr int NT = 64 * NW, ROWS = 16 * NW;
+  __shared__ float sh_cs[4 * NW];
+  __shared__ float4 sh_dz[ROWS];
+  __shared__ double sh_d[NT];
+  // dpred [B][out_f] (top stage), then x [B][in_f] (stage 0): one buffer, used one after the other
+  __shared__ __align__(16) float sh_big[ROWS * 64];
   const int W = p.W, B = p.batch, OF = p.out_f, nh = p.nh;
   const SsIdx x = ss_idx(W, B);
   const bool top = (i == nh - 1);
@@ -652,7 +663,7 @@ __global__ __launch_bounds__(SS_THREADS) void small_bwd_stage_kernel(const Small
   if (top) {
     // decode weight gradient, the four columns of this workgroup: dWd[o][col] = sum_b dpred[b][o] * A[b][col]
     // (dec_here, workgroup 0: + the decode bias gradient — the drop-in backward has no decode kernel before it)
-    for (int k = x.tid; k < B * OF; k += SS_THREADS) sh_big[k] = p.dpred[k];
+    for (int k = x.tid; k < B * OF; k += NT) sh_big[k] = p.dpred[k];
     reinterpret_cast<float*>(sh_dz)[x.tid] = x.valid ? p.A[nh - 1][e] : 0.f;
     __syncthreads();
     if (x.tid < OF * 4) {
@@ -671,9 +682,10 @@ __global__ __launch_bounds__(SS_THREADS) void small_bwd_stage_kernel(const Small
     __syncthreads();
   }
   if (i == 0 && p.in_f <= SS_SMALLK) {
-    // encode: the input rows, for the weight gradient at the end (requested now)
-    for (int k = x.tid * 4; k < B * p.in_f; k += SS_THREADS * 4)
-      *reinterpret_cast<float4*>(sh_x + k) = ss_ld4(p.x + k);
+    // encode: the input rows, for the weight gradient at the end (requested now; the top-stage use of the buffer is
+    // over: the barrier above)
+    for (int k = x.tid * 4; k < B * p.in_f; k += NT * 4)
+      *reinterpret_cast<float4*>(sh_big + k) = ss_ld4(p.x + k);
   }
   float ga = top ? ss_gemm<true>(wb, p.dpred, OF, OF, B, x.wave, x.lane)
                  : ss_gemm<true>(wb, p.dZ[i + 1], W, W, B, x.wave, x.lane);
@@ -682,10 +694,10 @@ __global__ __launch_bounds__(SS_THREADS) void small_bwd_stage_kernel(const Small
     if (i >= 2 && x.valid) p.gskip[(i >> 1) & 1][e] = ga;
   }
   const float dy = x.valid ? ga * gate : 0.f;
-  const float s_b = ss_colsum(dy, sh_cs, x.wave, x.lane);
-  const float s_g = ss_colsum(dy * xhat, sh_cs, x.wave, x.lane);
+  const float s_b = ss_colsum<NW>(dy, sh_cs, x.wave, x.lane);
+  const float s_g = ss_colsum<NW>(dy * xhat, sh_cs, x.wave, x.lane);
   const float dz = x.valid ? sc * (dy - (s_b + xhat * s_g) * inv_b) : 0.f;
-  const float dbias = ss_colsum(dz, sh_cs, x.wave, x.lane);
+  const float dbias = ss_colsum<NW>(dz, sh_cs, x.wave, x.lane);
   if (x.row == 0) {
     p.grads[p.g_off[i] + x.col] = s_g;
     p.grads[p.be_off[i] + x.col] = s_b;
@@ -700,19 +712,19 @@ __global__ __launch_bounds__(SS_THREADS) void small_bwd_stage_kernel(const Small
     const int K = (i == 0) ? p.in_f : W;
     if (i == 0 && K <= SS_SMALLK) {
       // dW0[col][k] = sum_b dz[b][c] * x[b][k]: one (c, k) pair per thread, both operands in LDS
-      for (int t = x.tid; t < 4 * K; t += SS_THREADS) {
+      for (int t = x.tid; t < 4 * K; t += NT) {
         const int cc = t / K, k = t - cc * K;
         float acc = 0.f;
-        for (int b = 0; b < B; ++b) acc = fmaf(reinterpret_cast<const float*>(sh_dz)[b * 4 + cc], sh_x[b * K + k], acc);
+        for (int b = 0; b < B; ++b) acc = fmaf(reinterpret_cast<const float*>(sh_dz)[b * 4 + cc], sh_big[b * K + k], acc);
         p.grads[p.w_off[0] + (int64_t)(x.n0 + cc) * K + k] = acc;
         sq += (double)acc * acc;
       }
     } else {
-      sq += ss_wgrad<false>(sh_dz, (i == 0) ? p.x : p.A[i - 1], K, B, p.grads + p.w_off[i] + (int64_t)x.n0 * K);
+      sq += ss_wgrad<false, 64 * NW>(sh_dz, (i == 0) ? p.x : p.A[i - 1], K, B, p.grads + p.w_off[i] + (int64_t)x.n0 * K);
     }
   }
   // one norm partial per workgroup, accumulated over the stage launches in a fixed order (deterministic)
-  const double wg_sq = ss_block_sum(sq, sh_d);
+  const double wg_sq = ss_block_sum<64 * NW>(sq, sh_d);
   if (x.tid == 0) p.sumsq_part[x.g] = (top ? 0.0 : p.sumsq_part[x.g]) + wg_sq;
 }
 
@@ -764,34 +776,48 @@ int launch_small_step(hipStream_t s, const SmallStepParams& p, int phase) {
 }
 
 bool small_staged_shape_ok(const SmallStepParams& p) {
-  return p.batch <= SS_MAX_ROWS && p.nh <= SS_MAX_STAGES && p.W <= 256 * SS_PASSES && p.W % 32 == 0 &&
-         p.in_f <= 256 * SS_PASSES && p.in_f % 4 == 0 && p.out_f <= 256 * SS_PASSES && p.out_f % 4 == 0;
+  return p.batch <= SS_STAGED_MAX_ROWS && p.nh <= SS_MAX_STAGES && p.W <= 256 * SS_PASSES && p.W % 32 == 0 &&
+         p.in_f <= 256 * SS_PASSES && p.in_f % 4 == 0 && p.out_f <= 64 && p.out_f % 4 == 0;
 }
 
+// (up to 64 rows: 4 waves per workgroup; 65 .. 128 rows: 8)
+template <int NW>
+static void small_forward_staged(hipStream_t s, const SmallStepParams& p, bool mse) {
+  const dim3 grid((unsigned)(p.W / 4)), block(64 * NW), dgrid((unsigned)(p.out_f / 4));
+  for (int i = 0; i < p.nh; ++i) hipLaunchKernelGGL(small_fwd_stage_kernel<NW>, grid, block, 0, s, p, i);
+  if (mse) hipLaunchKernelGGL((small_decode_kernel<true, NW>), dgrid, block, 0, s, p);
+  else hipLaunchKernelGGL((small_decode_kernel<false, NW>), dgrid, block, 0, s, p);
+}
 int launch_small_forward_staged(hipStream_t s, const SmallStepParams& p, bool mse) {
   if (!small_staged_shape_ok(p)) return BLH_ERR_SHAPE;
-  const dim3 grid((unsigned)(p.W / 4)), block(SS_THREADS);
-  for (int i = 0; i < p.nh; ++i) hipLaunchKernelGGL(small_fwd_stage_kernel, grid, block, 0, s, p, i);
-  if (mse) hipLaunchKernelGGL(small_decode_kernel<true>, dim3((unsigned)(p.out_f / 4)), block, 0, s, p);
-  else hipLaunchKernelGGL(small_decode_kernel<false>, dim3((unsigned)(p.out_f / 4)), block, 0, s, p);
+  if (p.batch <= 64) small_forward_staged<4>(s, p, mse); else small_forward_staged<8>(s, p, mse);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
 
+template <int NW>
+static void small_eval_staged(hipStream_t s, const SmallStepParams& p) {
+  const dim3 grid((unsigned)(p.W / 4)), block(64 * NW);
+  for (int i = 0; i < p.nh; ++i) hipLaunchKernelGGL(small_eval_stage_kernel<NW>, grid, block, 0, s, p, i);
+  hipLaunchKernelGGL((small_decode_kernel<false, NW>), dim3((unsigned)(p.out_f / 4)), block, 0, s, p);
+}
 int launch_small_eval_staged(hipStream_t s, const SmallStepParams& p) {
   if (!small_staged_shape_ok(p) || p.nbt != nullptr) return BLH_ERR_INVALID_ARGUMENT;
-  const dim3 grid((unsigned)(p.W / 4)), block(SS_THREADS);
-  for (int i = 0; i < p.nh; ++i) hipLaunchKernelGGL(small_eval_stage_kernel, grid, block, 0, s, p, i);
-  hipLaunchKernelGGL(small_decode_kernel<false>, dim3((unsigned)(p.out_f / 4)), block, 0, s, p);
+  if (p.batch <= 64) small_eval_staged<4>(s, p); else small_eval_staged<8>(s, p);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
 
+template <int NW>
+static void small_backward_staged(hipStream_t s, const SmallStepParams& p, bool dec_here, bool wgrad_here) {
+  const dim3 grid((unsigned)(p.W / 4)), block(64 * NW);
+  for (int i = p.nh - 1; i >= 0; --i)
+    hipLaunchKernelGGL(small_bwd_stage_kernel<NW>, grid, block, 0, s, p, i, dec_here ? 1 : 0, wgrad_here ? 1 : 0);
+}
 int launch_small_backward_staged(hipStream_t s, const SmallStepParams& p, bool dec_here, bool wgrad_here) {
   if (!small_staged_shape_ok(p)) return BLH_ERR_SHAPE;
-  const dim3 grid((unsigned)(p.W / 4)), block(SS_THREADS);
-  for (int i = p.nh - 1; i >= 0; --i)
-    hipLaunchKernelGGL(small_bwd_stage_kernel, grid, block, 0, s, p, i, dec_here ? 1 : 0, wgrad_here ? 1 : 0);
+  if (p.batch <= 64) small_backward_staged<4>(s, p, dec_here, wgrad_here);
+  else small_backward_staged<8>(s, p, dec_here, wgrad_here);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
