@@ -42,7 +42,7 @@ namespace {
 
 constexpr int SS_THREADS = 256;
 constexpr int SS_MAX_ROWS = 64;          // the persistent kernel
-constexpr int SS_STAGED_MAX_ROWS = 128;  // the stage kernels (8 waves per workgroup above 64 rows)
+constexpr int SS_STAGED_MAX_ROWS = 512;  // the stage kernels (8 waves per workgroup above 64 rows, row blocks of 128)
 constexpr int SS_PASSES = 4;            // reduction length <= 4 * 256
 constexpr int SS_SMALLK = 64;           // encode fan-in up to which the staged stage-0 kernel keeps x in LDS
 constexpr int SS_RB = 8;                // rows per batch of loads in ss_gemm (x 4 passes = 32 loads in flight per wave;
@@ -517,24 +517,28 @@ __global__ __launch_bounds__(SS_THREADS) void small_step_kernel(const SmallStepP
 // gamma * invstd in the saved-statistics rows); the skip gradient of an even stage waits for stage i - 2 in G0 / G1.
 struct SsIdx {
   int tid, lane, wave, g, n0, row, c, col;
-  bool valid;
 };
-__device__ __forceinline__ SsIdx ss_idx(int W, int B) {
+__device__ __forceinline__ SsIdx ss_idx(int W) {
   SsIdx x;
   x.tid = threadIdx.x; x.lane = x.tid & 63; x.wave = x.tid >> 6; x.g = blockIdx.x;
   const int ngroups = W >> 2;
   x.n0 = ((x.g & 7) * (ngroups >> 3) + (x.g >> 3)) * 4;       // XCD-aware, as in the persistent kernel
-  x.row = x.tid >> 2; x.c = x.tid & 3; x.col = x.n0 + x.c;
-  x.valid = x.row < B;
+  x.row = x.tid >> 2; x.c = x.tid & 3; x.col = x.n0 + x.c;    // (row within a row block)
   return x;
 }
 
-// grid: W / 4 workgroups of NW waves: NW = 4 serves up to 64 rows, NW = 8 up to 128 (wave w takes rows 16 w .. 16 w + 15)
-template <int NW>
+// Workgroups of NW waves walk RB row blocks of 16 NW rows (wave w takes rows 16 w .. 16 w + 15 of a block): NW = 4,
+// RB = 1 serves up to 64 rows, NW = 8 up to 128 RB rows.  A thread holds element (row block r, row tid / 4, column
+// tid % 4) for every r; the column sums run over all blocks (the per-thread sum over r goes into ONE ss_colsum).
+// The GEMM core costs one pass over the whole activation per row block, so the form stops paying at ~512 rows.
+
+// grid: W / 4 workgroups
+template <int NW, int RB>
 __global__ __launch_bounds__(64 * NW) void small_fwd_stage_kernel(const SmallStepParams p, const int i) {
+  constexpr int RPB = 16 * NW;
   __shared__ float sh_cs[4 * NW];
   const int W = p.W, B = p.batch;
-  const SsIdx x = ss_idx(W, B);
+  const SsIdx x = ss_idx(W);
   const int K = (i == 0) ? p.in_f : W;
   const float* in = (i == 0) ? p.x : p.A[i - 1];
   const float inv_b = 1.0f / (float)B;
@@ -545,14 +549,28 @@ __global__ __launch_bounds__(64 * NW) void small_fwd_stage_kernel(const SmallSte
   float* rv = p.bn_running + ((int64_t)i * 2 + 1) * W;
   const float rm0 = rm[x.col], rv0 = rv[x.col];
   const int64_t nbt0 = p.nbt[i];
-  const int64_t e = (int64_t)x.row * W + x.col;
-  const float skipv = (i >= 2 && (i & 1) == 0 && x.valid) ? p.A[i - 2][e] : 0.f;
-  const bool kept = x.valid && ss_keep(p.drop, i, (int64_t)B * W, x.row, x.col, W);
-  float z = ss_gemm<false>(wb, in, K, K, B, x.wave, x.lane) + bias;
-  if (!x.valid) z = 0.f;
-  const float mean = ss_colsum<NW>(z, sh_cs, x.wave, x.lane) * inv_b;
-  const float dlt = x.valid ? z - mean : 0.f;
-  const float m2 = ss_colsum<NW>(dlt * dlt, sh_cs, x.wave, x.lane);
+  const bool has_skip = i >= 2 && (i & 1) == 0;
+  float z[RB], skipv[RB];
+  bool valid[RB], kept[RB];
+  float zs = 0.f;
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int row = r * RPB + x.row;
+    valid[r] = row < B;
+    skipv[r] = (has_skip && valid[r]) ? p.A[i - 2][(int64_t)row * W + x.col] : 0.f;
+    kept[r] = valid[r] && ss_keep(p.drop, i, (int64_t)B * W, row, x.col, W);
+    z[r] = ss_gemm<false>(wb, in, K, K, B, r * NW + x.wave, x.lane) + bias;
+    if (!valid[r]) z[r] = 0.f;
+    zs += z[r];
+  }
+  const float mean = ss_colsum<NW>(zs, sh_cs, x.wave, x.lane) * inv_b;
+  float dlt[RB], d2 = 0.f;
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    dlt[r] = valid[r] ? z[r] - mean : 0.f;
+    d2 = fmaf(dlt[r], dlt[r], d2);
+  }
+  const float m2 = ss_colsum<NW>(d2, sh_cs, x.wave, x.lane);
   const float invstd = (float)(1.0 / sqrt((double)m2 / (double)B + (double)1e-5f));
   const float sc = gamma * invstd;
   const float sh = beta - mean * sc;
@@ -564,167 +582,235 @@ __global__ __launch_bounds__(64 * NW) void small_fwd_stage_kernel(const SmallSte
     float* st = p.bn_saved[i];
     st[x.col] = mean; st[W + x.col] = invstd; st[2 * W + x.col] = sc; st[3 * W + x.col] = sh;
   }
-  const float y = fmaf(z, sc, sh);
-  const bool on = kept && y > 0.f;
-  if (x.valid) {
-    p.A[i][e] = (on ? y * 2.f : 0.f) + skipv;
-    p.Z[i][e] = dlt * invstd;
-    p.dZ[i][e] = on ? 2.f : 0.f;
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const float y = fmaf(z[r], sc, sh);
+    const bool on = kept[r] && y > 0.f;
+    if (valid[r]) {
+      const int64_t e = (int64_t)(r * RPB + x.row) * W + x.col;
+      p.A[i][e] = (on ? y * 2.f : 0.f) + skipv[r];
+      p.Z[i][e] = dlt[r] * invstd;
+      p.dZ[i][e] = on ? 2.f : 0.f;
+    }
   }
 }
 
 // Eval mode (/root/reference/valid_bilinear.py:31,52): Linear + BatchNorm with the running statistics + ReLU (+ skip),
 // no dropout, nothing saved.  Same operations in the same order as the eval epilogue of the big-batch path
 // (gemm_epilogue.h, EPI_BN_RELU): sc = gamma / sqrt(var + eps), sh = beta - mean * sc, a = max(fma(z, sc, sh), 0).
-template <int NW>
+template <int NW, int RB>
 __global__ __launch_bounds__(64 * NW) void small_eval_stage_kernel(const SmallStepParams p, const int i) {
+  constexpr int RPB = 16 * NW;
   const int W = p.W, B = p.batch;
-  const SsIdx x = ss_idx(W, B);
+  const SsIdx x = ss_idx(W);
   const int K = (i == 0) ? p.in_f : W;
   const float* in = (i == 0) ? p.x : p.A[i - 1];
   WBlock wb;
   ss_load_w_rows(wb, p.params + p.w_off[i] + (int64_t)x.n0 * K, K, x.lane);
   const float bias = p.params[p.b_off[i] + x.col], gamma = p.params[p.g_off[i] + x.col], beta = p.params[p.be_off[i] + x.col];
   const float rm = p.bn_running[((int64_t)i * 2 + 0) * W + x.col], rv = p.bn_running[((int64_t)i * 2 + 1) * W + x.col];
-  const int64_t e = (int64_t)x.row * W + x.col;
-  const float skipv = (i >= 2 && (i & 1) == 0 && x.valid) ? p.A[i - 2][e] : 0.f;
-  const float z = ss_gemm<false>(wb, in, K, K, B, x.wave, x.lane) + bias;
   const float sc = gamma * (1.0f / sqrtf(rv + 1e-5f));
   const float sh = beta - rm * sc;
-  if (x.valid) p.A[i][e] = fmaxf(fmaf(z, sc, sh), 0.f) + skipv;
+  const bool has_skip = i >= 2 && (i & 1) == 0;
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int row = r * RPB + x.row;
+    const bool valid = row < B;
+    const int64_t e = (int64_t)row * W + x.col;
+    const float skipv = (has_skip && valid) ? p.A[i - 2][e] : 0.f;
+    const float z = ss_gemm<false>(wb, in, K, K, B, r * NW + x.wave, x.lane) + bias;
+    if (valid) p.A[i][e] = fmaxf(fmaf(z, sc, sh), 0.f) + skipv;
+  }
 }
 
-// grid: out_f / 4 workgroups.  MSE: + loss partials, d loss / d prediction, the decode gradients and their norm
-// partials (slots [W / 4, W / 4 + out_f / 4) of sumsq_part); either way the BatchNorm counters (every forward stage
-// has read them: the stage kernels are complete).
-template <bool MSE, int NW>
+// grid: out_f / 4 workgroups.  MSE: + loss partials, d loss / d prediction, the decode bias gradient and its norm
+// partial (slots [W / 4, W / 4 + out_f / 4) of sumsq_part); either way the BatchNorm counters (every forward stage has
+// read them: the stage kernels are complete; eval: nbt == nullptr).  The decode WEIGHT gradient is formed by the top
+// backward stage kernel, four columns per workgroup, from the activations its threads own: here 12 workgroups would
+// each read the whole activation for it.
+template <bool MSE, int NW, int RB>
 __global__ __launch_bounds__(64 * NW) void small_decode_kernel(const SmallStepParams p) {
+  constexpr int RPB = 16 * NW;
   __shared__ float sh_cs[4 * NW];
   __shared__ double sh_d[64 * NW];
   const int W = p.W, B = p.batch, OF = p.out_f, nh = p.nh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x;
-  const int o0 = g * 4, row = tid >> 2, c = tid & 3, oc = o0 + c;
-  const bool valid = row < B;
+  const int o0 = g * 4, c = tid & 3, oc = o0 + c;
   WBlock wb;
   ss_load_w_rows(wb, p.params + p.dec_w + (int64_t)o0 * W, W, lane);
   const float bd = p.params[p.dec_b + oc];
-  const float tg = (MSE && valid) ? p.target[(int64_t)row * OF + oc] : 0.f;
-  const float pr = ss_gemm<false>(wb, p.A[nh - 1], W, W, B, wave, lane) + bd;
-  if (valid) p.pred[(int64_t)row * OF + oc] = pr;
-  if (p.nbt && g == 0 && tid == 0) for (int i = 0; i < nh; ++i) p.nbt[i] += 1;      // (eval: nbt == nullptr)
+  float d2 = 0.f, dps = 0.f;
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int row = r * RPB + (tid >> 2);
+    const bool valid = row < B;
+    const float tg = (MSE && valid) ? p.target[(int64_t)row * OF + oc] : 0.f;
+    const float pr = ss_gemm<false>(wb, p.A[nh - 1], W, W, B, r * NW + wave, lane) + bd;
+    if (valid) p.pred[(int64_t)row * OF + oc] = pr;
+    if (MSE) {
+      const float diff = valid ? pr - tg : 0.f;
+      const float dp = diff * p.mse_scale;
+      if (valid) p.dpred[(int64_t)row * OF + oc] = dp;
+      d2 = fmaf(diff, diff, d2);
+      dps += dp;
+    }
+  }
+  if (p.nbt && g == 0 && tid == 0) for (int i = 0; i < nh; ++i) p.nbt[i] += 1;
   if (!MSE) return;
-  const float diff = valid ? pr - tg : 0.f;
-  const float dp = diff * p.mse_scale;
-  if (valid) p.dpred[(int64_t)row * OF + oc] = dp;
-  (void)ss_colsum<NW>(diff * diff, sh_cs, wave, lane);
+  (void)ss_colsum<NW>(d2, sh_cs, wave, lane);
   if (tid == 0) {       // the per-wave column sums -> one partial per workgroup (fixed order)
     float l = 0.f;
     for (int k = 0; k < 4 * NW; ++k) l += sh_cs[k];
     p.loss_part[g] = l;
   }
-  // (the decode WEIGHT gradient is formed by the top backward stage kernel, four columns per workgroup, from the
-  //  activations its threads own: here 12 workgroups would each read the whole activation for it, 8 us)
   double sq = 0.0;
-  const float db = ss_colsum<NW>(dp, sh_cs, wave, lane);
-  if (row == 0) { p.grads[p.dec_b + oc] = db; sq += (double)db * db; }
+  const float db = ss_colsum<NW>(dps, sh_cs, wave, lane);
+  if ((tid >> 2) == 0) { p.grads[p.dec_b + oc] = db; sq += (double)db * db; }
   const double wg_sq = ss_block_sum<64 * NW>(sq, sh_d);
   if (tid == 0) p.sumsq_part[(W >> 2) + g] = wg_sq;
 }
 
 // grid: W / 4 workgroups.  dec_here (top stage of the drop-in backward): d loss / d prediction comes from the
-// caller and the decode gradients are formed here by the workgroups g < out_f / 4.  wgrad_here = 0: the weight
-// gradients of the hidden stages come from ONE batched MFMA GEMM launch behind the stage kernels (the host's
-// launch_gemm over the consecutive dZ / A buffers: 64 tiles of 128 x 128 per stage read 4 MB where the four-column
-// ownership of this kernel reads the whole activation in every workgroup — 8 us per stage).
-template <int NW>
+// caller and the decode bias gradient is formed here too (workgroup 0).  wgrad_here = 0: the weight gradients of
+// the hidden stages come from ONE batched MFMA GEMM launch behind the stage kernels (the host's launch_gemm over
+// the consecutive dZ / A buffers: 64 tiles of 128 x 128 per stage read 4 MB where the four-column ownership of this
+// kernel reads the whole activation in every workgroup — 8 us per stage).
+template <int NW, int RB>
 __global__ __launch_bounds__(64 * NW) void small_bwd_stage_kernel(const SmallStepParams p, const int i,
                                                                    const int dec_here, const int wgrad_here) {
-  constexpr int NT = 64 * NW, ROWS = 16 * NW;
+  constexpr int NT = 64 * NW, RPB = 16 * NW;
   __shared__ float sh_cs[4 * NW];
-  __shared__ float4 sh_dz[ROWS];
+  __shared__ float4 sh_dz[RPB * RB];                           // dz of every row (the in-kernel weight gradient)
   __shared__ double sh_d[NT];
-  // dpred [B][out_f] (top stage), then x [B][in_f] (stage 0): one buffer, used one after the other
-  __shared__ __align__(16) float sh_big[ROWS * 64];
+  __shared__ __align__(16) float sh_big[RPB * 64];             // one row block of dpred [.][out_f] or of x [.][in_f]
   const int W = p.W, B = p.batch, OF = p.out_f, nh = p.nh;
-  const SsIdx x = ss_idx(W, B);
+  const SsIdx x = ss_idx(W);
   const bool top = (i == nh - 1);
   const float inv_b = 1.0f / (float)B;
-  const int64_t e = (int64_t)x.row * W + x.col;
   double sq = 0.0;
   WBlock wb;
   if (top) ss_load_w_cols(wb, p.params + p.dec_w + x.n0, OF, W, x.lane);
   else ss_load_w_cols(wb, p.params + p.w_off[i + 1] + x.n0, W, W, x.lane);
   // what forward left in the workspace, and the skip gradient of stage i + 2
-  float xhat = 0.f, gate = 0.f, gin = 0.f;
-  if (x.valid) { xhat = p.Z[i][e]; gate = p.dZ[i][e]; }
-  const float sc = p.bn_saved[i][2 * W + x.col];
   const bool even = (i & 1) == 0;
-  if (even && !top && x.valid) gin = p.gskip[((i >> 1) + 1) & 1][e];
+  const float sc = p.bn_saved[i][2 * W + x.col];
+  float xhat[RB], gate[RB], gin[RB];
+  bool valid[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int row = r * RPB + x.row;
+    valid[r] = row < B;
+    const int64_t e = (int64_t)row * W + x.col;
+    xhat[r] = valid[r] ? p.Z[i][e] : 0.f;
+    gate[r] = valid[r] ? p.dZ[i][e] : 0.f;
+    gin[r] = (even && !top && valid[r]) ? p.gskip[((i >> 1) + 1) & 1][e] : 0.f;
+  }
   if (top) {
-    // decode weight gradient, the four columns of this workgroup: dWd[o][col] = sum_b dpred[b][o] * A[b][col]
-    // (dec_here, workgroup 0: + the decode bias gradient — the drop-in backward has no decode kernel before it)
-    for (int k = x.tid; k < B * OF; k += NT) sh_big[k] = p.dpred[k];
-    reinterpret_cast<float*>(sh_dz)[x.tid] = x.valid ? p.A[nh - 1][e] : 0.f;
-    __syncthreads();
+    // decode weight gradient, the four columns of this workgroup: dWd[o][col] = sum_b dpred[b][o] * A[b][col], one
+    // row block at a time through LDS (dec_here, workgroup 0: + the decode bias gradient — the drop-in backward has
+    // no decode kernel before it)
+    float acc = 0.f, db = 0.f;
+    const int o = x.tid >> 2, cc = x.tid & 3;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int r0 = r * RPB, nrow = min(RPB, B - r0);
+      if (nrow > 0) {                                            // (uniform)
+        for (int k = x.tid; k < nrow * OF; k += NT) sh_big[k] = p.dpred[(int64_t)r0 * OF + k];
+        reinterpret_cast<float*>(sh_dz)[x.tid] = valid[r] ? p.A[nh - 1][(int64_t)(r0 + x.row) * W + x.col] : 0.f;
+        __syncthreads();
+        if (x.tid < OF * 4)
+          for (int b = 0; b < nrow; ++b) acc = fmaf(sh_big[b * OF + o], reinterpret_cast<const float*>(sh_dz)[b * 4 + cc], acc);
+        if (dec_here && x.g == 0 && x.tid < OF)
+          for (int b = 0; b < nrow; ++b) db += sh_big[b * OF + x.tid];
+        __syncthreads();
+      }
+    }
     if (x.tid < OF * 4) {
-      const int o = x.tid >> 2, cc = x.tid & 3;
-      float acc = 0.f;
-      for (int b = 0; b < B; ++b) acc = fmaf(sh_big[b * OF + o], reinterpret_cast<const float*>(sh_dz)[b * 4 + cc], acc);
       p.grads[p.dec_w + (int64_t)o * W + x.n0 + cc] = acc;
       sq += (double)acc * acc;
     }
     if (dec_here && x.g == 0 && x.tid < OF) {
-      float db = 0.f;
-      for (int b = 0; b < B; ++b) db += sh_big[b * OF + x.tid];
       p.grads[p.dec_b + x.tid] = db;
       sq += (double)db * db;
     }
-    __syncthreads();
   }
-  if (i == 0 && p.in_f <= SS_SMALLK) {
-    // encode: the input rows, for the weight gradient at the end (requested now; the top-stage use of the buffer is
-    // over: the barrier above)
-    for (int k = x.tid * 4; k < B * p.in_f; k += NT * 4)
-      *reinterpret_cast<float4*>(sh_big + k) = ss_ld4(p.x + k);
+  float ga[RB], dy[RB], dz[RB];
+  float sb = 0.f, sg = 0.f;
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    ga[r] = top ? ss_gemm<true>(wb, p.dpred, OF, OF, B, r * NW + x.wave, x.lane)
+                : ss_gemm<true>(wb, p.dZ[i + 1], W, W, B, r * NW + x.wave, x.lane);
+    if (even) {
+      ga[r] += gin[r];
+      if (i >= 2 && valid[r]) p.gskip[(i >> 1) & 1][(int64_t)(r * RPB + x.row) * W + x.col] = ga[r];
+    }
+    dy[r] = valid[r] ? ga[r] * gate[r] : 0.f;
+    sb += dy[r];
+    sg = fmaf(dy[r], xhat[r], sg);
   }
-  float ga = top ? ss_gemm<true>(wb, p.dpred, OF, OF, B, x.wave, x.lane)
-                 : ss_gemm<true>(wb, p.dZ[i + 1], W, W, B, x.wave, x.lane);
-  if (even) {
-    ga += gin;
-    if (i >= 2 && x.valid) p.gskip[(i >> 1) & 1][e] = ga;
+  const float s_b = ss_colsum<NW>(sb, sh_cs, x.wave, x.lane);
+  const float s_g = ss_colsum<NW>(sg, sh_cs, x.wave, x.lane);
+  float dzs = 0.f;
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    dz[r] = valid[r] ? sc * (dy[r] - (s_b + xhat[r] * s_g) * inv_b) : 0.f;
+    dzs += dz[r];
+    if (i >= 1 && valid[r]) p.dZ[i][(int64_t)(r * RPB + x.row) * W + x.col] = dz[r];
   }
-  const float dy = x.valid ? ga * gate : 0.f;
-  const float s_b = ss_colsum<NW>(dy, sh_cs, x.wave, x.lane);
-  const float s_g = ss_colsum<NW>(dy * xhat, sh_cs, x.wave, x.lane);
-  const float dz = x.valid ? sc * (dy - (s_b + xhat * s_g) * inv_b) : 0.f;
-  const float dbias = ss_colsum<NW>(dz, sh_cs, x.wave, x.lane);
+  const float dbias = ss_colsum<NW>(dzs, sh_cs, x.wave, x.lane);
   if (x.row == 0) {
     p.grads[p.g_off[i] + x.col] = s_g;
     p.grads[p.be_off[i] + x.col] = s_b;
     p.grads[p.b_off[i] + x.col] = dbias;
     sq += (double)s_g * s_g + (double)s_b * s_b + (double)dbias * dbias;
   }
-  if (i >= 1 && x.valid) p.dZ[i][e] = dz;
   if (i == 0 || wgrad_here) {
     __syncthreads();
-    reinterpret_cast<float*>(sh_dz)[x.tid] = dz;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) reinterpret_cast<float*>(sh_dz)[r * NT + x.tid] = dz[r];      // [row][c], all rows
     __syncthreads();
     const int K = (i == 0) ? p.in_f : W;
     if (i == 0 && K <= SS_SMALLK) {
-      // dW0[col][k] = sum_b dz[b][c] * x[b][k]: one (c, k) pair per thread, both operands in LDS
-      for (int t = x.tid; t < 4 * K; t += NT) {
-        const int cc = t / K, k = t - cc * K;
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b) acc = fmaf(reinterpret_cast<const float*>(sh_dz)[b * 4 + cc], sh_big[b * K + k], acc);
-        p.grads[p.w_off[0] + (int64_t)(x.n0 + cc) * K + k] = acc;
-        sq += (double)acc * acc;
+      // dW0[col][k] = sum_b dz[b][c] * x[b][k]: one (c, k) pair per thread, x one row block at a time through LDS
+      float acc[(4 * SS_SMALLK + NT - 1) / NT];
+#pragma unroll
+      for (int u = 0; u < (4 * SS_SMALLK + NT - 1) / NT; ++u) acc[u] = 0.f;
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int r0 = r * RPB, nrow = min(RPB, B - r0);
+        if (nrow > 0) {
+          for (int k = x.tid * 4; k < nrow * K; k += NT * 4)
+            *reinterpret_cast<float4*>(sh_big + k) = ss_ld4(p.x + (int64_t)r0 * K + k);
+          __syncthreads();
+#pragma unroll
+          for (int u = 0; u < (4 * SS_SMALLK + NT - 1) / NT; ++u) {
+            const int t = u * NT + x.tid;
+            if (t < 4 * K) {
+              const int cc = t / K, k = t - cc * K;
+              float a = acc[u];
+              for (int b = 0; b < nrow; ++b)
+                a = fmaf(reinterpret_cast<const float*>(sh_dz)[(r0 + b) * 4 + cc], sh_big[b * K + k], a);
+              acc[u] = a;
+            }
+          }
+          __syncthreads();
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < (4 * SS_SMALLK + NT - 1) / NT; ++u) {
+        const int t = u * NT + x.tid;
+        if (t < 4 * K) {
+          const int cc = t / K, k = t - cc * K;
+          p.grads[p.w_off[0] + (int64_t)(x.n0 + cc) * K + k] = acc[u];
+          sq += (double)acc[u] * acc[u];
+        }
       }
     } else {
-      sq += ss_wgrad<false, 64 * NW>(sh_dz, (i == 0) ? p.x : p.A[i - 1], K, B, p.grads + p.w_off[i] + (int64_t)x.n0 * K);
+      sq += ss_wgrad<false, NT>(sh_dz, (i == 0) ? p.x : p.A[i - 1], K, B, p.grads + p.w_off[i] + (int64_t)x.n0 * K);
     }
   }
   // one norm partial per workgroup, accumulated over the stage launches in a fixed order (deterministic)
-  const double wg_sq = ss_block_sum<64 * NW>(sq, sh_d);
+  const double wg_sq = ss_block_sum<NT>(sq, sh_d);
   if (x.tid == 0) p.sumsq_part[x.g] = (top ? 0.0 : p.sumsq_part[x.g]) + wg_sq;
 }
 
@@ -780,46 +866,55 @@ bool small_staged_shape_ok(const SmallStepParams& p) {
          p.in_f <= 256 * SS_PASSES && p.in_f % 4 == 0 && p.out_f <= 64 && p.out_f % 4 == 0;
 }
 
-// (up to 64 rows: 4 waves per workgroup; 65 .. 128 rows: 8)
-template <int NW>
+// (up to 64 rows: 4 waves per workgroup, one row block; above: 8 waves and ceil(batch / 128) row blocks)
+#define SS_DISPATCH(FN, ...)                                   \
+  do {                                                         \
+    if (p.batch <= 64) FN<4, 1>(__VA_ARGS__);                  \
+    else if (p.batch <= 128) FN<8, 1>(__VA_ARGS__);            \
+    else if (p.batch <= 256) FN<8, 2>(__VA_ARGS__);            \
+    else if (p.batch <= 384) FN<8, 3>(__VA_ARGS__);            \
+    else FN<8, 4>(__VA_ARGS__);                                \
+  } while (0)
+
+template <int NW, int RB>
 static void small_forward_staged(hipStream_t s, const SmallStepParams& p, bool mse) {
   const dim3 grid((unsigned)(p.W / 4)), block(64 * NW), dgrid((unsigned)(p.out_f / 4));
-  for (int i = 0; i < p.nh; ++i) hipLaunchKernelGGL(small_fwd_stage_kernel<NW>, grid, block, 0, s, p, i);
-  if (mse) hipLaunchKernelGGL((small_decode_kernel<true, NW>), dgrid, block, 0, s, p);
-  else hipLaunchKernelGGL((small_decode_kernel<false, NW>), dgrid, block, 0, s, p);
+  for (int i = 0; i < p.nh; ++i) hipLaunchKernelGGL((small_fwd_stage_kernel<NW, RB>), grid, block, 0, s, p, i);
+  if (mse) hipLaunchKernelGGL((small_decode_kernel<true, NW, RB>), dgrid, block, 0, s, p);
+  else hipLaunchKernelGGL((small_decode_kernel<false, NW, RB>), dgrid, block, 0, s, p);
 }
 int launch_small_forward_staged(hipStream_t s, const SmallStepParams& p, bool mse) {
   if (!small_staged_shape_ok(p)) return BLH_ERR_SHAPE;
-  if (p.batch <= 64) small_forward_staged<4>(s, p, mse); else small_forward_staged<8>(s, p, mse);
+  SS_DISPATCH(small_forward_staged, s, p, mse);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
 
-template <int NW>
+template <int NW, int RB>
 static void small_eval_staged(hipStream_t s, const SmallStepParams& p) {
   const dim3 grid((unsigned)(p.W / 4)), block(64 * NW);
-  for (int i = 0; i < p.nh; ++i) hipLaunchKernelGGL(small_eval_stage_kernel<NW>, grid, block, 0, s, p, i);
-  hipLaunchKernelGGL((small_decode_kernel<false, NW>), dim3((unsigned)(p.out_f / 4)), block, 0, s, p);
+  for (int i = 0; i < p.nh; ++i) hipLaunchKernelGGL((small_eval_stage_kernel<NW, RB>), grid, block, 0, s, p, i);
+  hipLaunchKernelGGL((small_decode_kernel<false, NW, RB>), dim3((unsigned)(p.out_f / 4)), block, 0, s, p);
 }
 int launch_small_eval_staged(hipStream_t s, const SmallStepParams& p) {
   if (!small_staged_shape_ok(p) || p.nbt != nullptr) return BLH_ERR_INVALID_ARGUMENT;
-  if (p.batch <= 64) small_eval_staged<4>(s, p); else small_eval_staged<8>(s, p);
+  SS_DISPATCH(small_eval_staged, s, p);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
 
-template <int NW>
+template <int NW, int RB>
 static void small_backward_staged(hipStream_t s, const SmallStepParams& p, bool dec_here, bool wgrad_here) {
   const dim3 grid((unsigned)(p.W / 4)), block(64 * NW);
   for (int i = p.nh - 1; i >= 0; --i)
-    hipLaunchKernelGGL(small_bwd_stage_kernel<NW>, grid, block, 0, s, p, i, dec_here ? 1 : 0, wgrad_here ? 1 : 0);
+    hipLaunchKernelGGL((small_bwd_stage_kernel<NW, RB>), grid, block, 0, s, p, i, dec_here ? 1 : 0, wgrad_here ? 1 : 0);
 }
 int launch_small_backward_staged(hipStream_t s, const SmallStepParams& p, bool dec_here, bool wgrad_here) {
   if (!small_staged_shape_ok(p)) return BLH_ERR_SHAPE;
-  if (p.batch <= 64) small_backward_staged<4>(s, p, dec_here, wgrad_here);
-  else small_backward_staged<8>(s, p, dec_here, wgrad_here);
+  SS_DISPATCH(small_backward_staged, s, p, dec_here, wgrad_here);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
+#undef SS_DISPATCH
 
 }  // namespace blh

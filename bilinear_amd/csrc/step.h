@@ -36,8 +36,8 @@ struct blh_context {
   // step's Adam kernel left up to date (nullptr: none)
   bool persistent_shadow = false;
   int small_step = 1;                 // BLH_OPT_SMALL_STEP: 0 off, 1 one launch per stage, 2 persistent launches
-  // the workspace whose saved activations are in the one-launch forward's format (small_step.hip, SS_FWD), and
-  // their batch; any multi-launch train-mode forward on the context clears it (forward_impl)
+  // non-null: the saved activations of the context's last train-mode forward are in the small-batch format
+  // (small_step.hip), and their batch; any multi-launch train-mode forward on the context clears it (forward_impl)
   const void* saved_small_ws = nullptr;
   int64_t saved_small_batch = 0;
   int saved_small_mode = 0;
