@@ -339,7 +339,7 @@ int blh_forward_train(blh_context* ctx, const blh_model_desc* d, void* stream, c
                      carve_h(d, batch, workspace), pred, batch, true);
   const Workspace ws = carve(d, batch, workspace);
   if (const int mode = small_step_mode(ctx, d, batch, true)) {
-    // the drop-in forward at <= 64 rows; what it saves for backward is in the small-batch format
+    // the drop-in forward at small batch; what it saves for backward is in the small-batch format
     SmallStepParams p;
     BLH_TRY(small_params(p, ctx, d, const_cast<float*>(params), nullptr, nullptr, nullptr, bn_running, bn_nbt, x, nullptr,
                          drop, momentum, nullptr, nullptr, ws, pred, nullptr, nullptr, batch, nullptr));

@@ -1,4 +1,4 @@
-// The one-launch training step for batches of at most 64 rows (small_step.hip).
+// The small-batch kernels (small_step.hip): one launch per stage (up to 512 rows), one persistent launch (up to 64).
 #pragma once
 #include "common.h"
 

@@ -1,11 +1,11 @@
 // The training step, the drop-in forward / backward and the eval forward at the reference's own batch size
-// (util/config.py:15: batch_size = 64; anything up to 64 rows) on purpose-built kernels: zero_grad, forward
+// (util/config.py:15: batch_size = 64; the stage kernels take up to 512 rows, the persistent one 64): zero_grad, forward
 // (Linear -> BatchNorm1d -> ReLU -> Dropout stages with block skips, /root/reference/model/bilinear.py:7-13,31-41),
 // MSE, backward, clip_grad_norm_(1) and Adam (/root/reference/train_bilinear.py:75-83).
 //
 // Why: at 64 rows the multi-launch step is ~50 kernels of 5 us each, every one of them nothing but launch latency
-// and a cold first read (0.32 ms per step at 2 x 1024, hipGraph replay no faster).  Here the batch is at most 64
-// rows, so a workgroup that owns FOUR columns of a stage owns them for all rows: BatchNorm statistics, the BatchNorm
+// and a cold first read (0.32 ms per step at 2 x 1024, hipGraph replay no faster).  Here the batch is small enough
+// for a workgroup that owns FOUR columns of a stage to own them for all rows: BatchNorm statistics, the BatchNorm
 // backward sums, the bias / gamma / beta gradients and the dropout patch (32 rows x 4 columns per Philox call,
 // philox.h) are all local to it; only the activations (forward) and dZ (backward) of a stage cross workgroups.
 //
@@ -26,7 +26,7 @@
 // weight-gradient work sits between arrive() and wait().
 //
 // Arithmetic is fp32 FMA on the vector ALU (0.5 MFLOP per workgroup and stage: the matrix cores have nothing to
-// win at 64 x 4 tiles); column statistics in fp32 over <= 64 rows, the norm of the gradient in fp64 partials
+// win at 64 x 4 tiles); column statistics in fp32 over <= 512 rows, the norm of the gradient in fp64 partials
 // summed in a fixed order (deterministic).  Same Philox keep bits, same Adam arithmetic (clip_adam_body,
 // elementwise.hip) as the multi-launch path.
 #include <atomic>
