@@ -888,7 +888,7 @@ def main():
                 "batchnorm": ("sync (global batch)" if args.sync_bn else "per-rank statistics") if world > 1 else "single device",
                 "launch": ("hipGraph replay (1 launch/step)" if (use_graph or dp_captured is not None)
                            else ("eager, small-batch kernels (one launch per stage: 2 stages + 3 launches/step)"
-                                 if (args.batch <= 512 and args.dtype == "fp32" and not multi)
+                                 if (args.batch <= 384 and args.dtype == "fp32" and not multi)
                                  else "eager (~55 launches/step, weight-gradient GEMMs on a side stream)")) + (
                                "; Adam writes the bf16 weight image (persistent shadow)"
                                if args.persistent_shadow and args.dtype == "bf16s" else ""),

@@ -213,7 +213,7 @@ static int check_drop(const blh_dropout* drop) {
   return BLH_OK;
 }
 
-// Batches of at most 512 rows in exact fp32 take the small-batch kernels (small_step.hip).  BLH_OPT_SMALL_STEP: 1 (default)
+// Batches of at most 384 rows in exact fp32 take the small-batch kernels (small_step.hip).  BLH_OPT_SMALL_STEP: 1 (default)
 // = one launch per stage (the fused step 0.153 ms against 0.200 for the persistent form; the host-bound drop-in loop
 // the same within its noise, tools_dev/dropin_b64_ab.py: medians 0.31 / 0.36 ms) — no grid barrier, no residency
 // requirement; 2 = persistent launches (one for the fused step, one each for the drop-in forward and backward);
@@ -223,7 +223,7 @@ static int check_drop(const blh_dropout* drop) {
 static int small_step_mode(const blh_context* ctx, const blh_model_desc* d, int64_t batch, bool drop_in) {
   // (gemm_dtype 2 / 3 — fp32 accuracy on the 16-bit matrix cores — take the same exact-fp32 kernels here: at 64
   //  rows there is nothing for a matrix core to win, and exact fp32 is what those modes approximate)
-  if (!ctx->small_step || d->gemm_dtype == 4 || batch > 512 || ctx->sync.fn) return 0;
+  if (!ctx->small_step || d->gemm_dtype == 4 || batch > 384 || ctx->sync.fn) return 0;
   static const bool off = getenv("BLH_NO_SMALL_STEP") != nullptr;
   if (off || d->width > 1024 || d->in_features > 1024) return 0;
   (void)drop_in;

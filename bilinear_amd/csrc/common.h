@@ -183,8 +183,9 @@ int launch_sum_slabs_batched(hipStream_t s, const float* slabs, int64_t count, i
                              int64_t slab_item_stride, float* out, int64_t out_item_stride);
 int launch_sum_slabs_add(hipStream_t s, const float* slabs, int64_t count, int splits,
                          const float* addend, float* out);
-// small-batch forward: Z = sum(slabs) + bias; stat_part (may be null) receives the column
-// (mean, M2) over ALL M rows as a single statistics tile: [2][N]
+// small-batch forward: Z = sum(slabs) + bias; stat_part (may be null) receives the column (mean, M2) of every
+// fwd_finish_stat_rows()-row chunk: [ceil(M / rows)][2][N] (the tile form bn_fwd_finalize merges)
+int fwd_finish_stat_rows();
 int launch_fwd_finish(hipStream_t s, const float* slabs, int splits, int64_t M, int N,
                       const float* bias, float* Z, float* stat_part);
 // out[c] = sum over rows of X[rows][ld] columns [0,cols)

@@ -497,39 +497,51 @@ __global__ __launch_bounds__(256) void sum_slabs_bias_kernel(const float* __rest
   }
 }
 
-__global__ __launch_bounds__(256) void col_stats_direct_kernel(const float* __restrict__ Z,
-                                                               int64_t M, int N,
-                                                               float* __restrict__ stat_part) {
-  __shared__ float s_n[8][32], s_mean[8][32], s_m2[8][32];
+// Column statistics of Z in 64-row chunks (the tile form bn_fwd_finalize merges): block = 32 columns x 8 row
+// lanes of 8 rows; grid (N / 32, chunks).  (Round 1's form was ONE block per 32 columns walking all rows with a
+// division per element: 44 us at M = 1024, a quarter of that step.)
+constexpr int FWD_FINISH_ROWS = 64;
+__global__ __launch_bounds__(256) void col_stats_chunk_kernel(const float* __restrict__ Z, int64_t M, int N,
+                                                              float* __restrict__ stat_part) {
+  __shared__ float red[8][32];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + cl;
-  float n = 0.f, mean = 0.f, m2 = 0.f;
-  if (col < N)
-    for (int64_t r = rl; r < M; r += 8) {
-      const float x = Z[r * N + col];
-      n += 1.f;
-      const float d = x - mean;
-      mean += d / n;
-      m2 += d * (x - mean);
-    }
-  s_n[rl][cl] = n; s_mean[rl][cl] = mean; s_m2[rl][cl] = m2;
-  __syncthreads();
-  if (rl == 0 && col < N) {
-    float tn = 0.f, tm = 0.f, tm2 = 0.f;
+  const int64_t r0 = (int64_t)blockIdx.y * FWD_FINISH_ROWS;
+  const int cnt = (int)min<int64_t>(FWD_FINISH_ROWS, M - r0);
+  const bool okc = col < N;
+  float x[8];
+  float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) {
-      const float bn = s_n[w][cl];
-      if (bn > 0.f) {
-        const float d = s_mean[w][cl] - tm, nn = tn + bn;
-        tm += d * (bn / nn);
-        tm2 += s_m2[w][cl] + d * d * (tn * bn / nn);
-        tn = nn;
-      }
-    }
-    stat_part[col] = tm;
-    stat_part[N + col] = tm2;
+  for (int j = 0; j < 8; ++j) {
+    const int r = rl * 8 + j;
+    x[j] = (okc && r < cnt) ? Z[(r0 + r) * N + col] : 0.f;
+    s += x[j];
+  }
+  red[rl][cl] = s;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) t += red[w][cl];
+  const float mean = t / (float)cnt;
+  __syncthreads();
+  float d2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float d = x[j] - mean;
+    if (rl * 8 + j < cnt) d2 = fmaf(d, d, d2);
+  }
+  red[rl][cl] = d2;
+  __syncthreads();
+  if (rl == 0 && okc) {
+    float m2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) m2 += red[w][cl];
+    stat_part[((int64_t)blockIdx.y * 2 + 0) * N + col] = mean;
+    stat_part[((int64_t)blockIdx.y * 2 + 1) * N + col] = m2;
   }
 }
+
+int fwd_finish_stat_rows() { return FWD_FINISH_ROWS; }
 
 int launch_fwd_finish(hipStream_t s, const float* slabs, int splits, int64_t M, int N,
                       const float* bias, float* Z, float* stat_part) {
@@ -540,8 +552,8 @@ int launch_fwd_finish(hipStream_t s, const float* slabs, int splits, int64_t M, 
                      splits, N, bias, Z);
   BLH_HIP_TRY(hipGetLastError());
   if (stat_part) {
-    hipLaunchKernelGGL(col_stats_direct_kernel, dim3((unsigned)ceil_div(N, 32)), dim3(256), 0, s, Z,
-                       M, N, stat_part);
+    hipLaunchKernelGGL(col_stats_chunk_kernel, dim3((unsigned)ceil_div(N, 32), (unsigned)ceil_div(M, FWD_FINISH_ROWS)),
+                       dim3(256), 0, s, Z, M, N, stat_part);
     BLH_HIP_TRY(hipGetLastError());
   }
   return BLH_OK;

@@ -1,4 +1,4 @@
-// The small-batch kernels (small_step.hip): one launch per stage (up to 512 rows), one persistent launch (up to 64).
+// The small-batch kernels (small_step.hip): one launch per stage (up to 384 rows), one persistent launch (up to 64).
 #pragma once
 #include "common.h"
 

@@ -1,5 +1,5 @@
 // The training step, the drop-in forward / backward and the eval forward at the reference's own batch size
-// (util/config.py:15: batch_size = 64; the stage kernels take up to 512 rows, the persistent one 64): zero_grad, forward
+// (util/config.py:15: batch_size = 64; the stage kernels take up to 384 rows, the persistent one 64): zero_grad, forward
 // (Linear -> BatchNorm1d -> ReLU -> Dropout stages with block skips, /root/reference/model/bilinear.py:7-13,31-41),
 // MSE, backward, clip_grad_norm_(1) and Adam (/root/reference/train_bilinear.py:75-83).
 //
@@ -26,7 +26,7 @@
 // weight-gradient work sits between arrive() and wait().
 //
 // Arithmetic is fp32 FMA on the vector ALU (0.5 MFLOP per workgroup and stage: the matrix cores have nothing to
-// win at 64 x 4 tiles); column statistics in fp32 over <= 512 rows, the norm of the gradient in fp64 partials
+// win at 64 x 4 tiles); column statistics in fp32 over <= 384 rows, the norm of the gradient in fp64 partials
 // summed in a fixed order (deterministic).  Same Philox keep bits, same Adam arithmetic (clip_adam_body,
 // elementwise.hip) as the multi-launch path.
 #include <atomic>
@@ -42,7 +42,8 @@ namespace {
 
 constexpr int SS_THREADS = 256;
 constexpr int SS_MAX_ROWS = 64;          // the persistent kernel
-constexpr int SS_STAGED_MAX_ROWS = 512;  // the stage kernels (8 waves per workgroup above 64 rows, row blocks of 128)
+constexpr int SS_STAGED_MAX_ROWS = 384;  // the stage kernels (8 waves per workgroup above 64 rows, row blocks of 128;
+                                         // at 512 rows the multi-launch path is as fast: 0.466 against 0.477 ms)
 constexpr int SS_PASSES = 4;            // reduction length <= 4 * 256
 constexpr int SS_SMALLK = 64;           // encode fan-in up to which the staged stage-0 kernel keeps x in LDS
 constexpr int SS_RB = 8;                // rows per batch of loads in ss_gemm (x 4 passes = 32 loads in flight per wave;
@@ -530,7 +531,7 @@ __device__ __forceinline__ SsIdx ss_idx(int W) {
 // Workgroups of NW waves walk RB row blocks of 16 NW rows (wave w takes rows 16 w .. 16 w + 15 of a block): NW = 4,
 // RB = 1 serves up to 64 rows, NW = 8 up to 128 RB rows.  A thread holds element (row block r, row tid / 4, column
 // tid % 4) for every r; the column sums run over all blocks (the per-thread sum over r goes into ONE ss_colsum).
-// The GEMM core costs one pass over the whole activation per row block, so the form stops paying at ~512 rows.
+// The GEMM core costs one pass over the whole activation per row block, so the form stops paying at ~400 rows.
 
 // grid: W / 4 workgroups
 template <int NW, int RB>
@@ -872,8 +873,7 @@ bool small_staged_shape_ok(const SmallStepParams& p) {
     if (p.batch <= 64) FN<4, 1>(__VA_ARGS__);                  \
     else if (p.batch <= 128) FN<8, 1>(__VA_ARGS__);            \
     else if (p.batch <= 256) FN<8, 2>(__VA_ARGS__);            \
-    else if (p.batch <= 384) FN<8, 3>(__VA_ARGS__);            \
-    else FN<8, 4>(__VA_ARGS__);                                \
+    else FN<8, 3>(__VA_ARGS__);                                \
   } while (0)
 
 template <int NW, int RB>

@@ -14,7 +14,6 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
   const ArenaLayout L = make_layout(d);
   const int nh = (int)L.heavy.size();
   const int W = d->width;
-  const int tiles_m = (int)ceil_div(batch, 128);
   if (train) ctx->saved_small_ws = nullptr;     // (the saved activations are in this path's format from here on)
   if (ws.amax_W)   // gemm_dtype 3: max |w| of every hidden Linear weight, once per forward
     for (int i = 1; i < nh; ++i)
@@ -69,9 +68,9 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
     float* rv = bn_running + ((int64_t)i * 2 + 1) * W;
     if (train) {
       float* sv = ws.bn_saved[i];
-      // (the small-batch path produced one statistics tile covering all rows)
-      const int st_tiles = fs.splits > 1 ? 1 : (enc64 ? (int)ceil_div(batch, 64) : tiles_m);
-      const int st_rows = fs.splits > 1 ? (int)batch : (enc64 ? 64 : 128);
+      // (the small-batch path produced statistics tiles of fwd_finish_stat_rows() rows)
+      const int st_rows = fs.splits > 1 ? fwd_finish_stat_rows() : (enc64 ? 64 : 128);
+      const int st_tiles = (int)ceil_div(batch, st_rows);
       if (ctx->sync.fn) {
         BLH_TRY(launch_bn_fwd_local_sums(s, ws.stat_part, st_tiles, st_rows, batch, W, ws.sync_buf));
         ctx->sync.fn(ctx->sync.user, ws.sync_buf, 2 * (int64_t)W, 1);

@@ -476,7 +476,7 @@ class Engine:
         self.ctx.set_option(N.OPT_TWO_STREAM, 1 if enabled else 0)
 
     def set_small_step(self, mode):
-        """The small-batch kernels (at most 512 rows, fp32, BLH_OPT_SMALL_STEP): True / 1 / "staged" (default) = one
+        """The small-batch kernels (at most 384 rows, fp32, BLH_OPT_SMALL_STEP): True / 1 / "staged" (default) = one
         launch per stage; 2 / "persistent" = persistent launches with grid barriers; False / 0 = the multi-launch path
         every other batch size takes."""
         if self.ctx is None:

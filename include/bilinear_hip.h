@@ -94,7 +94,7 @@ typedef enum {
                              at most one 128 KB-LDS workgroup per CU — the dispatcher then runs
                              them one after the other without a cross-queue latency — else 1.
                              Scheduling only: results are bit-identical.                     */
-  BLH_OPT_SMALL_STEP = 4, /* gemm_dtype 0 (and 2 / 3, which approximate it), at most 512 rows (the persistent form:
+  BLH_OPT_SMALL_STEP = 4, /* gemm_dtype 0 (and 2 / 3, which approximate it), at most 384 rows (the persistent form:
                              64), width <= 1024 — the reference's own batch size is 64,
                              /root/reference/util/config.py:15 — run on purpose-built
                              kernels (small_step.hip) in which a workgroup owns four columns of a stage for all
