@@ -123,9 +123,17 @@ static Splits pick_splits(int64_t batch, int64_t tiles) {
 // Small-batch Linear forward / dgrad (M = batch rows, N = W columns, reduction K): when the
 // 128x128 output tiles cover less than half of the 256 CUs, split the reduction so that about
 // one workgroup per CU is in flight.  Returns splits == 1 for the ordinary path.
-static Splits small_m_splits(int64_t batch, int W, int K) {
+// Half-chip batches (more than 128 and at most 256 tiles of 64 x 128: 1024 < batch <= 2048 at W = 1024) run the hidden
+// Linears and their data gradients on 64-row tiles, one per CU, instead of 128-row tiles on half of the CUs (the
+// forward GEMM took the same 66 us at 2048 rows as at 4096) or a split reduction with its finishing kernels: batch
+// 2048 0.797 -> 0.67 ms per step.  Exact fp32 only (the 64 x 128 kernel has no split-precision form).
+static bool mid_tile64(int64_t batch, int W, int dtype) {
+  const int64_t tiles64 = ceil_div(batch, 64) * ceil_div(W, 128);
+  return dtype == 0 && tiles64 > 128 && tiles64 <= 256;      // (272 tiles = two rounds on 256 CUs: 0.87 ms at 2176 rows)
+}
+static Splits small_m_splits(int64_t batch, int W, int K, int dtype = -1) {
   const int64_t tiles = ceil_div(batch, 128) * ceil_div(W, 128);
-  if (tiles >= 128 || K < 64) return Splits{1, K};
+  if (tiles >= 128 || K < 64 || mid_tile64(batch, W, dtype)) return Splits{1, K};
   int64_t s = std::min<int64_t>(ceil_div(256, tiles), K / SPLIT_GRAIN);
   int64_t k_per = round_up(ceil_div(K, s), SPLIT_GRAIN);
   s = ceil_div(K, k_per);

@@ -113,7 +113,8 @@ static int launch_64x128(hipStream_t s, int la, int lb, int epi, const GemmParam
   BLH_CASE(64, 128, 2, 2, KROW, KROW, EPI_STORE)         // decode wgrad (M = 48)
   BLH_CASE(64, 128, 2, 2, ROWK, ROWK, EPI_STORE)
   BLH_CASE(64, 128, 2, 2, ROWK, ROWK, EPI_BIAS)
-  BLH_CASE(64, 128, 2, 2, ROWK, KROW, EPI_STORE)
+  BLH_CASE(64, 128, 2, 2, ROWK, KROW, EPI_STORE)         // data gradient of a half-chip batch (step_f32.hip: mid64)
+  BLH_CASE(64, 128, 2, 2, ROWK, KROW, EPI_ADD)
   return BLH_ERR_INVALID_ARGUMENT;
 }
 static int launch_128x32(hipStream_t s, int la, int lb, int epi, const GemmParams& p, int splits) {

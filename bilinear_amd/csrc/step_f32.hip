@@ -32,8 +32,11 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
     g.M = (int)batch; g.N = W; g.K = h.fan_in; g.k_per_split = h.fan_in;
     g.bias = params + h.b;
     g.stat_part = ws.stat_part;
-    const Splits fs = small_m_splits(batch, W, h.fan_in);
-    const bool enc64 = train && i == 0 && fs.splits == 1 && h.fan_in <= 32 && batch >= 2048;
+    const Splits fs = small_m_splits(batch, W, h.fan_in, train ? d->gemm_dtype : -1);      // (eval keeps its forms)
+    // 64-row tiles: the encode Linear at large batch (below), and the hidden Linears of a half-chip batch
+    // (api_layout.h: mid_tile64)
+    const bool mid64 = train && i >= 1 && fs.splits == 1 && mid_tile64(batch, W, d->gemm_dtype);
+    const bool enc64 = (train && i == 0 && fs.splits == 1 && h.fan_in <= 32 && batch >= 2048) || mid64;
     if (fs.splits > 1) {
       // small batch: too few 128x128 output tiles to fill the chip and each would walk the
       // whole reduction alone (latency-bound), so cut the reduction across workgroups and
@@ -200,7 +203,7 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
   }
   auto fold_w = [&](int i) -> double* { return fold.on ? ws.sumsq_fold + fold.w_off[i] : nullptr; };
   // two streams: on by default (-3 % step)
-  const bool two = ctx->two_stream && !ctx->sync.fn && !defer && small_m_splits(batch, W, W).splits == 1;
+  const bool two = ctx->two_stream && !ctx->sync.fn && !defer && small_m_splits(batch, W, W, d->gemm_dtype).splits == 1;
   hipStream_t s2 = two ? ctx->s2 : s;
   // auto (fp32 kernels): early.  The data-gradient launch fills the chip's LDS — 256 workgroups of the
   // 128 KB form (gemm_f32_backward_exclusive) or >= 512 of the 64 KB form — so the weight gradient
@@ -318,7 +321,7 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
     // there only adds two cross-queue latencies at the very end of backward) unless the
     // data-parallel hook wants every range complete on the side stream.
     const bool side = two && (i > 0 || on_ready != nullptr);
-    const bool fork_late = side && late_policy && i > 0 && small_m_splits(batch, W, W).splits == 1;
+    const bool fork_late = side && late_policy && i > 0 && small_m_splits(batch, W, W, d->gemm_dtype).splits == 1;
     hipStream_t sw = side ? s2 : s;
     if (side && !fork_late) arm_fork(i);
     BLH_TRY(launch_bn_bwd_apply_f2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W, dg, db, ws.keep[i],
@@ -338,7 +341,7 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
         g.a_amax = dz_amax; g.a_namax = ws.amax_parts;
         g.b_amax = ws.amax_W + (int64_t)i * WAMAX_PARTS; g.b_namax = WAMAX_PARTS;
       }
-      const Splits ds2 = small_m_splits(batch, W, W);
+      const Splits ds2 = small_m_splits(batch, W, W, d->gemm_dtype);
       float* dst = first_of_block ? ws.G0 : ws.G1;
       if (ds2.splits > 1) {
         g.C = ws.slabs; g.c_split_stride = batch * (int64_t)W; g.k_per_split = ds2.k_per;
@@ -346,13 +349,14 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
         BLH_TRY(launch_sum_slabs_add(s, ws.slabs, batch * (int64_t)W, ds2.splits,
                                      first_of_block ? ws.G0 : nullptr, dst));
       } else {
+        const GemmTile dtile = mid_tile64(batch, W, d->gemm_dtype) ? TILE_64x128 : TILE_128x128;
         if (first_of_block) {
           // d(block input) = dZ W + d(block output)   (skip path), in place in G0
           g.C = ws.G0; g.addend = ws.G0; g.ldadd = W;
-          BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_ADD, g, 1, d->gemm_dtype));
+          BLH_TRY(launch_gemm(s, dtile, ROWK, KROW, EPI_ADD, g, 1, d->gemm_dtype));
         } else {
           g.C = ws.G1;
-          BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, 1, d->gemm_dtype));
+          BLH_TRY(launch_gemm(s, dtile, ROWK, KROW, EPI_STORE, g, 1, d->gemm_dtype));
         }
       }
     }

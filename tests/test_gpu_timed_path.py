@@ -196,7 +196,7 @@ def _entry_with_masks(nb, width, batch, dev, rounding=None, thr=1e-4, safe=True)
 
 
 @pytest.mark.parametrize("mode", FP32_MODES)
-@pytest.mark.parametrize("batch", [2048, 4096, 4100])
+@pytest.mark.parametrize("batch", [1536, 2048, 4096, 4100])      # (1536, 2048: fp32 runs 64-row GEMM tiles, mid_tile64)
 def test_timed_path_step_matches_oracle(batch, mode):
     """blh_train_step exactly as bench.py runs it (non-split-K forward, two-stream backward)
     against the fp64 oracle; then the drop-in forward / backward (raw gradients) from the same

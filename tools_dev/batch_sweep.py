@@ -1,7 +1,7 @@
 """Fused train step (fp32, 2 x 1024) across batch sizes: ms per step and poses/s."""
 import time, torch, bilinear_amd
 dev = torch.device("cuda", 0)
-for B in (16, 64, 96, 128, 256, 512, 1024, 2048, 4096):
+for B in (16, 64, 128, 256, 384, 512, 768, 1024, 1280, 1536, 1792, 2048, 2176, 2304, 3072, 4096):
     torch.manual_seed(0)
     net, opt, _, _ = bilinear_amd.load(dev); net.train()
     x = torch.randn(B, 32, device=dev); t = torch.randn(B, 48, device=dev)
