@@ -4,6 +4,7 @@
 // tools/host_sanitize.cpp in the CPU test job.
 #pragma once
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -129,7 +130,9 @@ static Splits pick_splits(int64_t batch, int64_t tiles) {
 // 2048 0.797 -> 0.67 ms per step.  Exact fp32 only (the 64 x 128 kernel has no split-precision form).
 static bool mid_tile64(int64_t batch, int W, int dtype) {
   const int64_t tiles64 = ceil_div(batch, 64) * ceil_div(W, 128);
-  return dtype == 0 && tiles64 > 128 && tiles64 <= 256;      // (272 tiles = two rounds on 256 CUs: 0.87 ms at 2176 rows)
+  // (more tiles than CUs lose: 272 tiles at 2176 rows 0.87 ms; 384 / 512 tiles at 3072 / 4096 rows 0.964 / 1.042 ms
+  //  against 0.955 / 1.029 on 128-row tiles)
+  return dtype == 0 && tiles64 > 128 && tiles64 <= 256;
 }
 static Splits small_m_splits(int64_t batch, int W, int K, int dtype = -1) {
   const int64_t tiles = ceil_div(batch, 128) * ceil_div(W, 128);
