@@ -105,11 +105,17 @@ int gemm_bf16s_pick_tile(int la, int lb, bool out_bf16, const GemmParamsH& p, in
     // Weight gradients (both operands KROW, fp32 slabs): only with at most 4 slabs (api_layout.h: wgrad_plan_h)
     const bool wgrad_many_slabs = la == KROW && slabs > 4 && p.batch_splits == 0 && !getenv("BLH_WGRAD256_MIN_TILES");
     if (!wgrad_many_slabs && wgs >= 224) return H_TILE_256;
+    // forward / data gradient with 129 .. 223 tiles of 256 x 256 (batch 8448 .. 14080 at W = 1024): one round of
+    // 256 x 256 tiles on part of the chip (34 us at K = 1024) still beats TWO rounds of 128 x 256 tiles (2 x 22 us):
+    // batch 12288 1.349 -> 1.277 ms per step, 10240 1.279 -> 1.195 (tools_dev/batch_sweep_bf16s.py)
+    if (la == ROWK && splits == 1 && wgs > 128) return H_TILE_256;
   }
   if (ok128x256 && la == ROWK) {
     // (forward / data gradient; the weight gradient keeps its measured plans)
     const int64_t wgs = ceil_div(p.M, 128) * (p.N / 256) * splits;
-    if (wgs >= 224) return H_TILE_128x256;
+    // (from half a chip of them on: batch 4096 / 6144 at W = 1024 0.768 / 0.861 ms per step against 0.792 / 0.885 on
+    //  128 x 128 tiles)
+    if (wgs >= 128) return H_TILE_128x256;
   }
   // fewer workgroups: the 128 x 128 grid fills the 256 CUs better
   return H_TILE_128;

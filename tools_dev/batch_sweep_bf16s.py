@@ -1,7 +1,7 @@
 """Fused train step (bf16 storage, 4 x 1024) across batch sizes: ms per step and poses/s."""
 import time, torch, bilinear_amd
 dev = torch.device("cuda", 0)
-for B in (64, 256, 1024, 2048, 4096, 6144, 8192, 12288, 16384):
+for B in (1024, 2048, 3072, 4096, 6144, 8192, 10240, 12288, 16384):
     torch.manual_seed(0)
     net, opt, _, _ = bilinear_amd.load(dev, num_blocks=4, gemm_dtype="bf16s"); net.train()
     x = torch.randn(B, 32, device=dev); t = torch.randn(B, 48, device=dev)
