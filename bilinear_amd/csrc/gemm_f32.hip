@@ -110,6 +110,7 @@ static int launch_128x64(hipStream_t s, int la, int lb, int epi, const GemmParam
 }
 static int launch_64x128(hipStream_t s, int la, int lb, int epi, const GemmParams& p, int splits) {
   BLH_CASE(64, 128, 2, 2, ROWK, ROWK, EPI_BIAS_STATS)    // encode forward (K = 32): 2 workgroups per CU
+  BLH_CASE(64, 128, 2, 2, ROWK, ROWK, EPI_BN_RELU)       // eval forward of a half-chip batch (mid_tile64)
   BLH_CASE(64, 128, 2, 2, KROW, KROW, EPI_STORE)         // decode wgrad (M = 48)
   BLH_CASE(64, 128, 2, 2, ROWK, ROWK, EPI_STORE)
   BLH_CASE(64, 128, 2, 2, ROWK, ROWK, EPI_BIAS)

@@ -32,7 +32,7 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
     g.M = (int)batch; g.N = W; g.K = h.fan_in; g.k_per_split = h.fan_in;
     g.bias = params + h.b;
     g.stat_part = ws.stat_part;
-    const Splits fs = small_m_splits(batch, W, h.fan_in, train ? d->gemm_dtype : -1);      // (eval keeps its forms)
+    const Splits fs = small_m_splits(batch, W, h.fan_in, d->gemm_dtype);
     // 64-row tiles: the encode Linear at large batch (below), and the hidden Linears of a half-chip batch
     // (api_layout.h: mid_tile64)
     const bool mid64 = train && i >= 1 && fs.splits == 1 && mid_tile64(batch, W, d->gemm_dtype);
@@ -55,7 +55,8 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
       g.bn_mean = bn_running + ((int64_t)i * 2 + 0) * W;
       g.bn_var = bn_running + ((int64_t)i * 2 + 1) * W;
       g.addend = (i >= 2 && (i % 2) == 0) ? ws.A[i - 2] : nullptr; g.ldadd = W;
-      BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, EPI_BN_RELU, g, 1, d->gemm_dtype));
+      const bool ev64 = i >= 1 && mid_tile64(batch, W, d->gemm_dtype);      // (half-chip batch: 64-row tiles)
+      BLH_TRY(launch_gemm(s, ev64 ? TILE_64x128 : TILE_128x128, ROWK, ROWK, EPI_BN_RELU, g, 1, d->gemm_dtype));
       continue;
     } else if (enc64) {
       // encode (K = 32): one K tile, the kernel is all prologue + 16.8 MB of output; 64-row tiles

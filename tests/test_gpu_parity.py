@@ -430,7 +430,7 @@ def test_fused_train_step_matches_reference(fname, mode):
 
 
 @pytest.mark.parametrize("mode", FP32_MODES)
-@pytest.mark.parametrize("batch", [1, 37, 64, 100, 128, 333, 2048])
+@pytest.mark.parametrize("batch", [1, 37, 64, 100, 128, 333, 1500, 2048])
 def test_eval_forward_matches_oracle(mode, batch):
     """valid_bilinear.py:31,52 — eval mode uses running statistics, no dropout.  (At the larger
     batch every heavy_linear is ONE kernel: bias + BatchNorm + ReLU + skip in the GEMM epilogue; at serving

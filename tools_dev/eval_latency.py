@@ -2,7 +2,7 @@ import time, torch, bilinear_amd
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 net, opt, _, _ = bilinear_amd.load(dev); net.eval()
-for B in (1, 8, 64, 256, 1024):
+for B in (1, 64, 256, 384, 512, 1024, 1536, 2048, 4096, 16384):
     x = torch.randn(B, 32, device=dev)
     with torch.no_grad():
         for _ in range(200): net(x)
