@@ -304,7 +304,7 @@ static int small_train_step(int mode, blh_context* ctx, const blh_model_desc* d,
   SmallStepParams p;
   BLH_TRY(small_params(p, ctx, d, params, grads, exp_avg, exp_avg_sq, bn_running, bn_nbt, x, target, drop, momentum,
                        hyper, dev_state, ws, pred, loss_out, stats_out, batch, nullptr));
-  ctx->saved_small_ws = nullptr;
+  ctx->note_saved(ws.Z[0], batch, 0);     // (nothing a later blh_backward could use)
   if (mode == 2) return launch_small_step(s, p, SS_ALL);
   BLH_TRY(launch_small_forward_staged(s, p, true));
   const ArenaLayout L = make_layout(d);
@@ -345,7 +345,7 @@ int blh_forward_train(blh_context* ctx, const blh_model_desc* d, void* stream, c
                          drop, momentum, nullptr, nullptr, ws, pred, nullptr, nullptr, batch, nullptr));
     if (mode == 2) BLH_TRY(launch_small_step((hipStream_t)stream, p, SS_FWD));
     else BLH_TRY(launch_small_forward_staged((hipStream_t)stream, p, false));
-    ctx->saved_small_ws = workspace; ctx->saved_small_batch = batch; ctx->saved_small_mode = mode;
+    ctx->note_saved(workspace, batch, mode);
     return BLH_OK;
   }
   return forward_impl(ctx, d, (hipStream_t)stream, params, bn_running, bn_nbt, x, drop, momentum, ws,
@@ -399,7 +399,7 @@ int blh_forward_eval(blh_context* ctx, const blh_model_desc* d, void* stream, co
     SmallStepParams p;
     BLH_TRY(small_params(p, ctx, d, const_cast<float*>(params), nullptr, nullptr, nullptr, const_cast<float*>(bn_running),
                          nullptr, x, nullptr, &none, 0.f, nullptr, nullptr, ws, pred, nullptr, nullptr, batch, nullptr));
-    ctx->saved_small_ws = nullptr;          // (the activation buffers are overwritten)
+    ctx->note_saved(workspace, batch, 0);          // (the activation buffers are overwritten)
     return launch_small_eval_staged((hipStream_t)stream, p);
   }
   return forward_impl(ctx, d, (hipStream_t)stream, params, const_cast<float*>(bn_running), nullptr, x,
@@ -439,15 +439,15 @@ int blh_backward(blh_context* ctx, const blh_model_desc* d, void* stream, const 
                       batch, on_ready, user, from_loss ? loss_nparts : 0);
   }
   const Workspace ws = carve(d, batch, workspace);
-  // (paired through the context, not through the workspace address: a traced program may hand the backward a
-  //  functionalised copy of the workspace tensor — same contents, another pointer)
-  if (ctx->saved_small_ws != nullptr) {
-    // the activations in this workspace were saved by the one-launch forward: only its backward can read them
-    if (from_loss || ctx->saved_small_batch != batch || ctx->sync.fn) return BLH_ERR_INVALID_ARGUMENT;
+  // which forward saved what is in this workspace (step.h: by workspace address, else the context's last forward)
+  const blh_context::SavedFormat* saved = ctx->find_saved(workspace);
+  if (saved && saved->mode != 0) {
+    // the activations in this workspace were saved by the small-batch forward: only its backward can read them
+    if (from_loss || saved->batch != batch || ctx->sync.fn) return BLH_ERR_INVALID_ARGUMENT;
     SmallStepParams p;
     BLH_TRY(small_params(p, ctx, d, const_cast<float*>(params), grads, nullptr, nullptr, nullptr, nullptr, x, nullptr, drop,
                          0.f, nullptr, nullptr, ws, nullptr, nullptr, nullptr, batch, dpred));
-    if (ctx->saved_small_mode == 2) BLH_TRY(launch_small_step((hipStream_t)stream, p, SS_BWD));
+    if (saved->mode == 2) BLH_TRY(launch_small_step((hipStream_t)stream, p, SS_BWD));
     else {
       const ArenaLayout L = make_layout(d);
       const bool batched = small_wgrad_batched_ok(d, L, ws, batch);

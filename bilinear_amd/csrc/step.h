@@ -36,11 +36,24 @@ struct blh_context {
   // step's Adam kernel left up to date (nullptr: none)
   bool persistent_shadow = false;
   int small_step = 1;                 // BLH_OPT_SMALL_STEP: 0 off, 1 one launch per stage, 2 persistent launches
-  // non-null: the saved activations of the context's last train-mode forward are in the small-batch format
-  // (small_step.hip), and their batch; any multi-launch train-mode forward on the context clears it (forward_impl)
-  const void* saved_small_ws = nullptr;
-  int64_t saved_small_batch = 0;
-  int saved_small_mode = 0;
+  // Format of the activations each recent train-mode forward saved, by workspace: mode 0 the multi-launch layout
+  // (step_f32.hip), 1 / 2 the small-batch layout (small_step.hip; staged / persistent).  blh_backward looks its
+  // workspace up here; a workspace it does not find (a traced program may hand it a functionalised copy — same
+  // contents, another address) takes the record of the context's LAST forward.
+  struct SavedFormat { const void* ws; int64_t batch; int mode; };
+  SavedFormat saved[4] = {};
+  int saved_last = -1;
+  void note_saved(const void* ws, int64_t batch, int mode) {
+    int slot = -1;
+    for (int i = 0; i < 4; ++i) if (saved[i].ws == ws) slot = i;
+    if (slot < 0) slot = (saved_last + 1) & 3;
+    saved[slot] = {ws, batch, mode};
+    saved_last = slot;
+  }
+  const SavedFormat* find_saved(const void* ws) const {
+    for (int i = 0; i < 4; ++i) if (saved[i].ws == ws && ws) return &saved[i];
+    return saved_last >= 0 ? &saved[saved_last] : nullptr;
+  }
   const void* shadow_params = nullptr;
   const void* shadow_ws = nullptr;
   // grid barrier of the fused forward stage (gemm_bf16s_bnfwd.h): arrivals, generation, timeouts; device memory

@@ -14,7 +14,7 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
   const ArenaLayout L = make_layout(d);
   const int nh = (int)L.heavy.size();
   const int W = d->width;
-  if (train) ctx->saved_small_ws = nullptr;     // (the saved activations are in this path's format from here on)
+  if (train) ctx->note_saved(ws.Z[0], batch, 0);     // (ws.Z[0] is the workspace base, api_layout.h carve)
   if (ws.amax_W)   // gemm_dtype 3: max |w| of every hidden Linear weight, once per forward
     for (int i = 1; i < nh; ++i)
       BLH_TRY(launch_wamax(s, params + L.heavy[i].w, 0, 1, (int64_t)W * W, ws.amax_W + (int64_t)i * WAMAX_PARTS));

@@ -69,6 +69,10 @@ int blh_abi_version(void);
  *     context first and returns BLH_ERR_INVALID_ARGUMENT when another device is current.
  *   - one context = one in-flight call: a context must not be used from two host threads
  *     at once (use one context per thread / per model replica; contexts are cheap).
+ *     Several models may take turns on one context: it remembers per workspace (the last four)
+ *     which forward saved the activations there, so each blh_backward reads them with the kernels
+ *     that wrote them; the loss gradient of blh_forward_train_loss is remembered for the LAST
+ *     such forward only.
  *   - the contexts of one device share the side stream, so they take turns at it, and STREAM
  *     CAPTURE EXCLUDES THEM ALL: while one context captures a two-stream step
  *     (blh_train_step_captured / a captured blh_backward with BLH_OPT_TWO_STREAM = 1) the side

@@ -249,3 +249,42 @@ def test_captured_small_step_replays_like_eager(mode):
     assert torch.equal(net_a.engine.params, net_b.engine.params)
     assert torch.equal(opt_a._exp_avg_sq, opt_b._exp_avg_sq)
     assert net_b.engine.ctx.grid_barrier_timeouts() == 0
+
+
+def test_two_models_interleaved_on_one_context_keep_their_saved_formats():
+    """A C-ABI user may drive several models through ONE context (include/bilinear_hip.h: one in-flight call per
+    context).  The context remembers, per workspace, which forward saved the activations there: a small-batch
+    forward of model A followed by a multi-launch forward of model B (and the other way round) must send each
+    backward to the kernels that can read its workspace.  Against the same two models on contexts of their own."""
+    import bilinear_amd
+    dev = _dev()
+    crit = torch.nn.MSELoss()
+    g = torch.Generator().manual_seed(21)
+    xs = torch.randn(64, 32, generator=g).to(dev); ts = torch.randn(64, 48, generator=g).to(dev)
+    xl = torch.randn(640, 32, generator=g).to(dev); tl = torch.randn(640, 48, generator=g).to(dev)
+
+    def build():
+        nets = []
+        for seed in (3, 4):
+            torch.manual_seed(seed)
+            net, _, _, _ = bilinear_amd.load(dev, num_blocks=1, width=256, gemm_dtype="fp32")
+            net.train(); net.engine.ensure(dev); net.engine.seed = 77
+            nets.append(net)
+        return nets
+
+    ref_a, ref_b = build()
+    crit(ref_a(xs), ts).backward()
+    crit(ref_b(xl), tl).backward()
+    torch.cuda.synchronize()
+    for order in ("small_first", "large_first"):
+        a, b = build()
+        b.engine.ctx = a.engine.ctx                  # both models on A's context
+        if order == "small_first":
+            la = crit(a(xs), ts); lb = crit(b(xl), tl)
+            la.backward(); lb.backward()
+        else:
+            lb = crit(b(xl), tl); la = crit(a(xs), ts)
+            lb.backward(); la.backward()
+        torch.cuda.synchronize()
+        assert torch.equal(a.engine.grads, ref_a.engine.grads), order
+        assert torch.equal(b.engine.grads, ref_b.engine.grads), order
