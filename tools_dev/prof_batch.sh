@@ -1,11 +1,13 @@
-# kernel timeline of one fused step at a given batch (fp32, 2 x 1024)
+# kernel timeline of one fused step at a given batch (fp32, 2 x 1024; further bench.py flags after the batch)
 set -e
 B=${1:-1024}
+shift || true
+EXTRA="$@"
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_b$B
 mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/p -o f -- python3 $R/bench.py --batch $B --no-configs --no-cpu-baseline --no-alt --steps 100 --warmup 30 > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/p -o f -- python3 $R/bench.py --batch $B $EXTRA --no-configs --no-cpu-baseline --no-alt --steps 100 --warmup 30 > $O/bench.json 2> $O/bench.err
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("$O/p/f_kernel_trace.csv")))
