@@ -233,8 +233,12 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
     BLH_HIP_TRY(hipStreamWaitEvent(s2, g_side.ev_dz[idx], 0));
     return BLH_OK;
   };
+  // (recorded only where something waits for it — the join at the end, and gemm_dtype 3's amax buffers: every
+  //  record is a marker packet in the side stream's queue; no measurable step time either way, profiles/r04_batch_sweeps.md)
+  const int join_idx = on_ready != nullptr ? 0 : 1;
   auto wdone = [&](int idx) -> int {
     if (!two) return BLH_OK;
+    if (idx != join_idx && !ws.amax_W) return BLH_OK;
     BLH_HIP_TRY(hipEventRecord(g_side.ev_w[idx], s2));
     return BLH_OK;
   };
@@ -401,7 +405,7 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
                                   fused ? fused->dec_bias_S : 0, OF, L.dec_b,
                                   fold.on ? ws.sumsq_fold + fold.bias0 : nullptr));
   }
-  if (two) BLH_HIP_TRY(hipStreamWaitEvent(s, g_side.ev_w[on_ready != nullptr ? 0 : 1], 0));
+  if (two) BLH_HIP_TRY(hipStreamWaitEvent(s, g_side.ev_w[join_idx], 0));
   if (fold.on) {     // the producers left the partials: hand them to clip + Adam
     fused->sumsq_src[0] = ws.sumsq_fold;
     *fused->sumsq_nparts = fold.total;
