@@ -55,7 +55,7 @@ enum Epilogue : int {
   EPI_BIAS_STATS = 2,  // C = acc + bias[n]; per-tile column (mean, M2) partials
   EPI_ADD = 3,         // C = acc + addend[m][n]
   EPI_BN_RELU = 4,     // eval forward: C = relu(bn_eval(acc + bias[n])) (+ addend[m][n], the block skip)
-  EPI_BN_BWD = 5,      // bf16-storage data gradient feeding a BatchNorm backward (gemm_bf16s_256.h): C = the gated
+  EPI_BN_BWD = 5,      // data gradient feeding a BatchNorm backward (gemm_bf16s_256.h; fp32: gemm_epilogue.h): C = the gated
                        // gradient dY' = 2 keep [y > 0] acc, per-row-tile column sums of dY' z and dY'
   EPI_BN_BWD_ADD = 6,  // the same with acc + addend[m][n] (the block-skip gradient)
   EPI_BN_FWD = 7,      // bf16-storage forward stage in one launch (gemm_bf16s_bnfwd.h): Z = acc + bias, batch statistics
@@ -83,6 +83,13 @@ struct GemmParams {
   const float* a_amax; int a_namax;
   const float* b_amax; int b_namax;
   double* sq_part;          // EPI_STORE_SQ: [splits][tiles]
+  // EPI_BN_BWD (fp32 data gradient feeding only the BatchNorm backward of the stage below, gemm_epilogue.h):
+  // that stage's pre-BN output [M][ldc-shaped, leading dimension bnb_ldz], its keep bits (bn_f32.hip layout),
+  // scale / shift [N], and the per-row-tile column sums it leaves: [tiles_m][2][N] (S1 = sum dY' z, S2 = sum dY')
+  const float* bnb_z; int64_t bnb_ldz;
+  const uint32_t* bnb_keep;
+  const float* bnb_scale; const float* bnb_shift;
+  float* bnb_part;
 };
 
 enum GemmTile : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_128x32 = 3 };
@@ -155,7 +162,8 @@ int launch_bn_bwd_reduce_f2(hipStream_t s, const float* dA, const float* Z, cons
 int launch_bn_bwd_apply_f2(hipStream_t s, const float* dA, const float* Z, const float* scale,
                            const float* shift, const float* mean, const float* invstd, const float* dgamma,
                            const float* dbeta, const uint32_t* keepbits, float* dZ, float* colsum_part,
-                           int64_t batch, int W, int64_t norm_batch, float* amax_part = nullptr);
+                           int64_t batch, int W, int64_t norm_batch, float* amax_part = nullptr,
+                           bool pregated = false);   // pregated: dA is dY' already (EPI_BN_BWD), no bits read
 // SyncBN: local fp64 column sums [sum z | sum z^2] -> (host all-reduce) -> finalize
 int launch_bn_fwd_local_sums(hipStream_t s, const float* stat_part, int tiles, int tile_rows,
                              int64_t batch, int W, double* sums);

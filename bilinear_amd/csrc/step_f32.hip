@@ -285,6 +285,16 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
     BLH_TRY(launch_colreduce(s2, ws.dec_bias_part, fused->dec_bias_S, OF, OF, grads + L.dec_b));
   BLH_TRY(ready(nh, L.dec_w, L.total - L.dec_w));
 
+  // SURVEY K9 on the exact-fp32 path — OPT-IN (BLH_K9_F32=1), measured slower than the streaming reduce kernel it
+  // replaces (profiles/r04_k9_f32.md: headline 1.029 against 1.020 ms; the reduce kernel runs beside the weight
+  // gradient of the side stream, the epilogue's read of Z is on the data gradient's critical path).  The data gradient
+  // of a block's SECOND stage is read by nothing but the BatchNorm backward of the block's first stage: its GEMM
+  // epilogue (EPI_BN_BWD, gemm_epilogue.h) leaves the gated gradient dY' and the column sums per row tile, and the
+  // stage below skips bn_bwd_reduce_f2.  (The first stage's data gradient is the block-input gradient, a skip
+  // operand: the raw value has to be stored.)  Exact-fp32 GEMMs, one launch per tile.
+  const bool k9 = getenv("BLH_K9_F32") != nullptr && d->gemm_dtype == 0 &&
+                  small_m_splits(batch, W, W, d->gemm_dtype).splits == 1;
+  int pregated_tiles = 0;     // > 0: this stage's dA is dY' and ws.stat_part holds that many rows of partials
   for (int i = nh - 1; i >= 0; --i) {
     const HeavyOffsets& h = L.heavy[i];
     // gradient w.r.t. this stage's output: block boundaries live in G0, the middle of a
@@ -293,9 +303,13 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
     const float* dA = first_of_block ? ws.G1 : ws.G0;
     const float* sv = ws.bn_saved[i];
     // (dropout: the keep bits the forward wrote, ws.keep[i])
-    BLH_TRY(launch_bn_bwd_reduce_f2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, ws.keep[i], ws.bn_part, batch, W));
-    BLH_TRY(launch_bn_bwd_finalize_h2(s, ws.bn_part, chunks, W, sv, sv + W, grads + h.gamma, grads + h.beta,
+    const bool pregated = pregated_tiles > 0;
+    if (!pregated)
+      BLH_TRY(launch_bn_bwd_reduce_f2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, ws.keep[i], ws.bn_part, batch, W));
+    BLH_TRY(launch_bn_bwd_finalize_h2(s, pregated ? ws.stat_part : ws.bn_part, pregated ? pregated_tiles : chunks, W,
+                                      sv, sv + W, grads + h.gamma, grads + h.beta,
                                       fold.on ? ws.sumsq_fold + fold.gb0 + i * bn_bwd_finalize_blocks(W) : nullptr));
+    pregated_tiles = 0;
     const float* dg = grads + h.gamma;
     const float* db = grads + h.beta;
     int64_t norm_batch = batch;
@@ -331,7 +345,7 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
     if (side && !fork_late) arm_fork(i);
     BLH_TRY(launch_bn_bwd_apply_f2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W, dg, db, ws.keep[i],
                                    dzbuf, ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W,
-                                   norm_batch, dz_amax));
+                                   norm_batch, dz_amax, pregated));
     tl_stop_event = nullptr;
     if (side && !fork_late) BLH_TRY(fork_wait(i));
     if (fork_late) arm_fork(i);
@@ -359,6 +373,14 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
           // d(block input) = dZ W + d(block output)   (skip path), in place in G0
           g.C = ws.G0; g.addend = ws.G0; g.ldadd = W;
           BLH_TRY(launch_gemm(s, dtile, ROWK, KROW, EPI_ADD, g, 1, d->gemm_dtype));
+        } else if (k9) {
+          // (the forward's statistics partials are dead by now: ws.stat_part holds ceil(batch / 64) rows)
+          const float* svb = ws.bn_saved[i - 1];
+          g.C = ws.G1;
+          g.bnb_z = ws.Z[i - 1]; g.bnb_ldz = W; g.bnb_keep = ws.keep[i - 1];
+          g.bnb_scale = svb + 2 * W; g.bnb_shift = svb + 3 * W; g.bnb_part = ws.stat_part;
+          BLH_TRY(launch_gemm(s, dtile, ROWK, KROW, EPI_BN_BWD, g, 1, d->gemm_dtype));
+          pregated_tiles = (int)ceil_div(batch, gemm_stat_tile_rows(dtile));
         } else {
           g.C = ws.G1;
           BLH_TRY(launch_gemm(s, dtile, ROWK, KROW, EPI_STORE, g, 1, d->gemm_dtype));

@@ -755,3 +755,47 @@ def test_standalone_stages_draw_different_masks():
     assert (za != zb).float().mean().item() > 0.2
     both = ~za & ~zb
     assert torch.equal(ya[both], yb[both])
+
+
+@pytest.mark.parametrize("nb,width,batch", [(2, 1024, 4096), (2, 1024, 4100), (1, 1024, 1500), (3, 512, 2500),
+                                            (2, 1024, 16384)])
+def test_fp32_bn_backward_reductions_in_the_dgrad_epilogue_match_the_streaming_kernel(nb, width, batch):
+    """SURVEY K9 on the exact-fp32 path (round 4, gemm_epilogue.h EPI_BN_BWD): the data gradient of a block's second
+    stage is read by nothing but the BatchNorm backward of the block's first stage, so its GEMM epilogue forms that
+    stage's gated gradient dY' = 2 keep [y > 0] dA — the same expression on the same operands as bn_bwd_reduce_f2 —
+    and the per-row-tile column sums (dY' z, dY'); the stage below skips the reduce kernel and reads no keep bits.
+    Only the order of the column sums differs from the default run: every gradient agrees to summation rounding.
+    128-row tiles with a ragged last tile (4100), 64-row tiles (1500, 2500: mid_tile64).  Opt-in (BLH_K9_F32=1):
+    correct, but slower than the streaming reduce kernel it replaces (profiles/r04_k9_f32.md)."""
+    import os
+
+    import bilinear_amd
+    dev = _dev()
+    x = torch.randn(batch, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    t = torch.randn(batch, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    out = {}
+    for k9 in (True, False):
+        if k9:
+            os.environ["BLH_K9_F32"] = "1"
+        try:
+            torch.manual_seed(0)
+            net, opt, _, _ = bilinear_amd.load(dev, num_blocks=nb, width=width, gemm_dtype="fp32")
+            net.train()
+            net.engine.ensure(dev)
+            net.engine.seed = 11
+            opt.zero_grad()
+            pred = net(x)
+            torch.nn.functional.mse_loss(pred, t).backward()
+            torch.cuda.synchronize()
+            out[k9] = (pred.detach().clone(), net.engine.grads.clone(),
+                       {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+        finally:
+            os.environ.pop("BLH_K9_F32", None)
+    assert torch.equal(out[True][0], out[False][0])              # the forward is untouched
+    assert not torch.equal(out[True][1], out[False][1])          # ... and the backward really took another path
+    for k in out[True][2]:
+        a, b = out[True][2][k].double(), out[False][2][k].double()
+        if k.endswith(".0.bias") and not k.startswith("decode"):
+            continue                                             # pre-BatchNorm biases: rounding noise (SURVEY H2)
+        rel = float((a - b).norm() / b.norm())
+        assert rel <= 2e-5, (k, rel)
