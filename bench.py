@@ -598,14 +598,21 @@ def batch64_block(dev, steps, ramp_ms):
         loss.backward()
         _B.clip_grad_norm_(net.parameters(), max_norm=1, module=net)
         opt.step()
-    for _ in range(50):
-        five_calls()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        five_calls()
-    torch.cuda.synchronize()
-    five_ms = 1e3 * (time.perf_counter() - t0) / steps
+
+    def time_five():
+        for _ in range(50):
+            five_calls()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            five_calls()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / steps
+    five_ms = time_five()
+    # the same loop with torch's backward run on the calling thread (no hand-off to the autograd engine's device
+    # thread): a setting of the caller's, not of this package — reported beside the default
+    with torch.autograd.set_multithreading_enabled(False):
+        five_st_ms = time_five()
     timeouts = net.engine.ctx.grid_barrier_timeouts()
     del net, opt
     torch.cuda.empty_cache()
@@ -617,7 +624,10 @@ def batch64_block(dev, steps, ramp_ms):
             "multi_launch": out["multi_launch"], "final_loss": out["staged"]["final_loss"],
             "five_call_drop_in": {"ms_per_step": five_ms, "poses_per_s": 64e3 / five_ms,
                                   "step": "zero_grad, forward, nn.MSELoss, backward, clip_grad_norm_, Adam.step as "
-                                          "separate calls (the reference's loop); host-bound"}}
+                                          "separate calls (the reference's loop); host-bound",
+                                  "single_threaded_backward_ms_per_step": five_st_ms,
+                                  "single_threaded_backward": "the same loop under "
+                                                              "torch.autograd.set_multithreading_enabled(False)"}}
 
 
 DTYPE_TEXT = {"fp32": "f32", "bf16x3": "f32 (operands split into 3 bf16 pieces, bf16 MFMA, fp32 accumulate)",

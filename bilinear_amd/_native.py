@@ -254,6 +254,17 @@ def check(status, what):
         raise RuntimeError("bilinear_amd: %s failed: %s" % (what, msg))
 
 
+def current_stream():
+    """hipStream_t of torch's current stream on the current device, as a c_void_p.  Through the raw accessor
+    (no torch.cuda.Stream object, no device-index parsing: ~1 us instead of ~5 us per call — the drop-in step at
+    the reference's batch of 64 is host-bound and asks three times per step)."""
+    import torch
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is None:
+        return c_void_p(torch.cuda.current_stream().cuda_stream)
+    return c_void_p(raw(torch._C._cuda_getDevice()))
+
+
 def ptr(t):
     """Device pointer of a torch tensor (None -> NULL)."""
     return None if t is None else c_void_p(t.data_ptr())

@@ -233,7 +233,7 @@ class Engine:
 
     @staticmethod
     def _stream():
-        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return N.current_stream()
 
     _tuned = {}        # (device index, compute-stream handle) -> side-stream generation it was tuned against
 

@@ -61,7 +61,7 @@ _LIB.define(
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return N.current_stream()
 
 
 def _desc(num_blocks, width, gemm_dtype):

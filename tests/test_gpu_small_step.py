@@ -288,3 +288,16 @@ def test_two_models_interleaved_on_one_context_keep_their_saved_formats():
         torch.cuda.synchronize()
         assert torch.equal(a.engine.grads, ref_a.engine.grads), order
         assert torch.equal(b.engine.grads, ref_b.engine.grads), order
+
+
+def test_raw_current_stream_accessor_follows_torch_stream_contexts():
+    """bilinear_amd._native.current_stream() (the raw accessor the host-bound drop-in step uses) returns the handle of
+    torch's current stream — the default stream, and a side stream inside ``torch.cuda.stream(...)``."""
+    from bilinear_amd import _native as N
+    dev = _dev()
+    with torch.cuda.device(dev):
+        assert (N.current_stream().value or 0) == torch.cuda.current_stream().cuda_stream
+        side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side):
+            assert (N.current_stream().value or 0) == side.cuda_stream
+        assert (N.current_stream().value or 0) == torch.cuda.current_stream().cuda_stream

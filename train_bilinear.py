@@ -74,6 +74,11 @@ def main():
         device=device, parameter_dir=parameter_dir if os.path.exists(parameter_dir) else None)
     criterion = nn.MSELoss()
     bilinear.train()
+    # The five-call step is host-bound at the reference's batch of 64 (GPU: 0.15 ms of kernels per step).  torch's
+    # backward normally hands the graph to the autograd engine's device thread and waits for it; one operator deep,
+    # that hand-off is the largest single host cost of the step and the noisiest (0.30-0.56 ms per step measured on
+    # different boxes against a steady 0.28 on the calling thread, bench.py batch_64.five_call_drop_in).
+    torch.autograd.set_multithreading_enabled(False)
 
     for epoch in range(train_epoch + 1, train_epoch + args.epochs + 1):
         loss = None
