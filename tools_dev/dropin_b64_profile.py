@@ -39,6 +39,9 @@ def five(n):
         opt.step()
 
 
+import sys
+if len(sys.argv) > 1 and sys.argv[1] == "st":
+    torch.autograd.set_multithreading_enabled(False)
 five(200)
 torch.cuda.synchronize()
 parts()
@@ -47,4 +50,4 @@ pr.enable()
 five(300)
 pr.disable()
 torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(70)
