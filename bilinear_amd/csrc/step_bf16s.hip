@@ -144,7 +144,15 @@ int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const f
   // context's side stream — in order there, so they share one slab buffer — forked behind the
   // data-gradient GEMM of its stage (BLH_OPT_LATE_FORK) or behind bn_bwd_apply; one join at the end.
   tl_stop_event = nullptr;
-  const bool two = ctx->two_stream && !ctx->sync.fn;   // (SyncBN: the exchanges are enqueued on `s`)
+  // One stream when the hidden weight gradients go out as ONE batched launch after the chain (no bucket hook): the
+  // side stream would then carry only the decode and stage-0 weight gradients (22 + 17 us of work at configs[3]'s
+  // shape) for two forks and a join (5 + 7 + 12 us of cross-queue latency), and the stage-0 one starves behind the
+  // batched GEMM, which holds every CU's LDS.  Measured (profiles/r04_batch_sweeps.md): configs[2] 1.440 against
+  // 1.458 ms, configs[3] shape 0.925 against 0.943, configs[4] shape 7.38 against 7.44.  Per-stage weight gradients
+  // (smaller batches) keep the side stream: 0.755 against 0.830 ms at 4 x 1024, B = 4096.
+  const bool batched_main = on_ready == nullptr && nh - 1 >= 2 && wgrad_batched_plan_h(W, batch, nh - 1).splits > 0 &&
+                            getenv("BLH_BF16_FORCE_TWO_STREAM") == nullptr;
+  const bool two = ctx->two_stream && !ctx->sync.fn && !batched_main;   // (SyncBN: the exchanges are enqueued on `s`)
   hipStream_t s2 = two ? ctx->s2 : s;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &cap);
@@ -335,7 +343,7 @@ int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const f
     }
   }
   if (on_ready == nullptr && !wgroups.empty() && wgroups[0].plan.splits > 0) {
-    BLH_TRY(launch_group(wgroups[0], s));   // (the stage-0 and decode weight gradients, side stream, run beside it)
+    BLH_TRY(launch_group(wgroups[0], s));   // (everything is on `s` in this plan: batched_main above)
   }
   if (!on_ready) {
     int64_t offs[32];
