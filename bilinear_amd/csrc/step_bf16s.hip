@@ -21,8 +21,8 @@ int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const fl
   // bf16 images of the parameters (the GEMMs read the weights from it) and of the input
   // (shadow_valid: the previous fused step's Adam kernel wrote it, BLH_OPT_PERSISTENT_SHADOW)
   ctx->shadow_params = ctx->shadow_ws = nullptr;
-  if (!shadow_valid) BLH_TRY(launch_cast_f32_bf16(s, params, ws.wsh, L.total));
-  BLH_TRY(launch_cast_f32_bf16(s, x, ws.xh, batch * IF));
+  if (!shadow_valid) BLH_TRY(launch_cast2_f32_bf16(s, params, ws.wsh, L.total, x, ws.xh, batch * IF));
+  else BLH_TRY(launch_cast_f32_bf16(s, x, ws.xh, batch * IF));
   for (int i = 0; i < nh; ++i) {
     const HeavyOffsets& h = L.heavy[i];
     GemmParamsH g{};
