@@ -94,6 +94,7 @@ int blh_context_create(blh_context** out) {
   c->two_stream = getenv("BLH_ONE_STREAM") == nullptr;
   c->defer_slabs = getenv("BLH_DEFER_SLABS") != nullptr;
   c->late_fork = getenv("BLH_EARLY_FORK") ? 0 : (getenv("BLH_LATE_FORK") ? 1 : 2);
+  c->knobs = blh::dev_knobs_from_env();
   *out = c;
   return BLH_OK;
 }
@@ -128,6 +129,10 @@ int blh_context_set_option(blh_context* c, int32_t option, int32_t value) {
       c->persistent_shadow = value != 0;
       c->shadow_params = c->shadow_ws = nullptr;
       return BLH_OK;
+    case BLH_OPT_DEV_KNOBS:
+      if (value < 0 || value > blh::KNOB_ALL) return BLH_ERR_INVALID_ARGUMENT;
+      c->knobs = value;
+      return BLH_OK;
   }
   return BLH_ERR_INVALID_ARGUMENT;
 }
@@ -140,6 +145,7 @@ int blh_context_get_option(const blh_context* c, int32_t option) {
     case BLH_OPT_LATE_FORK: return c->late_fork;
     case BLH_OPT_PERSISTENT_SHADOW: return c->persistent_shadow ? 1 : 0;
     case BLH_OPT_SMALL_STEP: return c->small_step;
+    case BLH_OPT_DEV_KNOBS: return c->knobs;
   }
   return BLH_ERR_INVALID_ARGUMENT;
 }
@@ -224,8 +230,7 @@ static int small_step_mode(const blh_context* ctx, const blh_model_desc* d, int6
   // (gemm_dtype 2 / 3 — fp32 accuracy on the 16-bit matrix cores — take the same exact-fp32 kernels here: at 64
   //  rows there is nothing for a matrix core to win, and exact fp32 is what those modes approximate)
   if (!ctx->small_step || d->gemm_dtype == 4 || batch > 384 || ctx->sync.fn) return 0;
-  static const bool off = getenv("BLH_NO_SMALL_STEP") != nullptr;
-  if (off || d->width > 1024 || d->in_features > 1024) return 0;
+  if (ctx->knob(blh::KNOB_NO_SMALL_STEP) || d->width > 1024 || d->in_features > 1024) return 0;
   (void)drop_in;
   const bool want_persistent = ctx->small_step == 2 && batch <= 64;     // (the persistent kernel holds 64 rows)
   if (want_persistent && ctx->grid_bar) {

@@ -285,7 +285,8 @@ static Splits wgrad_plan_h(int64_t M, int64_t N, int64_t batch) {
 // WGRAD_HOOK_GROUP stages (api.hip: backward_h).  {0, 0}: not applicable (the per-stage plan above is used).
 static constexpr int WGRAD_HOOK_GROUP = 4;     // stages per batched launch under a bucket hook
 static Splits wgrad_batched_plan_h(int64_t W, int64_t batch, int items) {
-  if (items < 2 || W % 256 != 0 || batch % 128 != 0 || std::getenv("BLH_NO_BATCHED_WGRAD")) return Splits{0, 0};
+  static const bool off = std::getenv("BLH_NO_BATCHED_WGRAD") != nullptr;     // (developer knob, read once)
+  if (items < 2 || W % 256 != 0 || batch % 128 != 0 || off) return Splits{0, 0};
   const int64_t tiles = (W / 256) * (W / 256);
   int64_t s = 1;
   while (s < 8 && tiles * items * (s * 2) <= 256) s *= 2;

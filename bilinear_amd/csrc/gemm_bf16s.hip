@@ -103,7 +103,8 @@ int gemm_bf16s_pick_tile(int la, int lb, bool out_bf16, const GemmParamsH& p, in
   if (ok256) {
     const int64_t wgs = ceil_div(p.M, 256) * (p.N / 256) * splits;
     // Weight gradients (both operands KROW, fp32 slabs): only with at most 4 slabs (api_layout.h: wgrad_plan_h)
-    const bool wgrad_many_slabs = la == KROW && slabs > 4 && p.batch_splits == 0 && !getenv("BLH_WGRAD256_MIN_TILES");
+    static const bool min_tiles_forced = getenv("BLH_WGRAD256_MIN_TILES") != nullptr;   // (developer knob, read once)
+    const bool wgrad_many_slabs = la == KROW && slabs > 4 && p.batch_splits == 0 && !min_tiles_forced;
     if (!wgrad_many_slabs && wgs >= 224) return H_TILE_256;
     // forward / data gradient with 129 .. 223 tiles of 256 x 256 (batch 8448 .. 14080 at W = 1024): one round of
     // 256 x 256 tiles on part of the chip (34 us at K = 1024) still beats TWO rounds of 128 x 256 tiles (2 x 22 us):

@@ -12,6 +12,35 @@ namespace blh {
 // SyncBN plumbing of the current call (data parallel): statistics over `global_batch` rows,
 // exchanged by the host callback
 struct SyncCtx { blh_sync_fn fn; void* user; int64_t global_batch; };
+
+// Developer A/B switches ("Developer switches"): read from the environment ONCE, when the context is
+// created (blh_context_create), or set through blh_context_set_option(BLH_OPT_DEV_KNOBS, mask).  Nothing on the
+// per-step host path calls getenv.
+enum : int32_t {
+  KNOB_NO_SUMSQ_FOLD = 1,          // BLH_NO_SUMSQ_FOLD: fp32 fused step, separate gradient-norm pass
+  KNOB_K9_F32 = 2,                 // BLH_K9_F32: BatchNorm-backward sums in the fp32 data-gradient epilogue (slower)
+  KNOB_FWD_FUSE = 4,               // BLH_FWD_FUSE: bf16 forward stage in one launch behind a grid barrier (slower)
+  KNOB_BF16_FORCE_TWO_STREAM = 8,  // BLH_BF16_FORCE_TWO_STREAM: bf16 batched plan on two streams (the r04 order)
+  KNOB_NO_K9 = 16,                 // BLH_NO_K9: bf16, streaming reduce kernel instead of the epilogue
+  KNOB_NO_SMALL_STEP = 32,         // BLH_NO_SMALL_STEP: the <= 384-row kernels off
+  KNOB_NO_DECODE_FUSE = 64,        // BLH_NO_DECODE_FUSE: decode forward and backward as separate launches
+  KNOB_NO_ENCODE_FUSE = 128,       // BLH_NO_ENCODE_FUSE: encode stage through the materialised Z0
+  KNOB_NO_MID_FUSE = 256,          // BLH_NO_MID_FUSE: 385..2048-row stages on the multi-launch split-K form
+  KNOB_ALL = 511
+};
+static inline int32_t dev_knobs_from_env() {
+  int32_t m = 0;
+  if (std::getenv("BLH_NO_SUMSQ_FOLD")) m |= KNOB_NO_SUMSQ_FOLD;
+  if (std::getenv("BLH_K9_F32")) m |= KNOB_K9_F32;
+  if (std::getenv("BLH_FWD_FUSE")) m |= KNOB_FWD_FUSE;
+  if (std::getenv("BLH_BF16_FORCE_TWO_STREAM")) m |= KNOB_BF16_FORCE_TWO_STREAM;
+  if (std::getenv("BLH_NO_K9")) m |= KNOB_NO_K9;
+  if (std::getenv("BLH_NO_SMALL_STEP")) m |= KNOB_NO_SMALL_STEP;
+  if (std::getenv("BLH_NO_DECODE_FUSE")) m |= KNOB_NO_DECODE_FUSE;
+  if (std::getenv("BLH_NO_ENCODE_FUSE")) m |= KNOB_NO_ENCODE_FUSE;
+  if (std::getenv("BLH_NO_MID_FUSE")) m |= KNOB_NO_MID_FUSE;
+  return m;
+}
 }  // namespace blh
 
 // Caller-owned context (include/bilinear_hip.h): the side stream of the two-stream backward with
@@ -25,6 +54,8 @@ struct blh_context {
   bool two_stream = true;
   bool defer_slabs = false;
   int late_fork = 2;        // BLH_OPT_LATE_FORK: 0 early, 1 late, 2 auto
+  int32_t knobs = 0;        // BLH_OPT_DEV_KNOBS: blh::KNOB_* mask, latched from the environment at creation
+  bool knob(int32_t k) const { return (knobs & k) != 0; }
   // per-call state (set by the entry point for the duration of the call)
   blh::SyncCtx sync = {nullptr, nullptr, 0};
   const uint64_t* step_dev = nullptr;

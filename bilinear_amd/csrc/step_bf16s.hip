@@ -43,7 +43,7 @@ int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const fl
     // chip one workgroup per CU (configs[2]: 256 tiles of 256 x 256; configs[3] per GPU: 256 of 128 x 256), per-rank
     // statistics.  Bit-identical to the three-launch form and MEASURED SLOWER (configs[2] 1.59 against 1.47 ms,
     // configs[3] per-GPU shape 1.10 against 0.95: profiles/r04_fused_forward.md), so it is opt-in: BLH_FWD_FUSE=1.
-    if (train && !ctx->sync.fn && tile != H_TILE_128 && ctx->grid_bar && getenv("BLH_FWD_FUSE") &&
+    if (train && !ctx->sync.fn && tile != H_TILE_128 && ctx->grid_bar && ctx->knob(KNOB_FWD_FUSE) &&
         (int64_t)st_tiles * (W / 256) <= gemm_bf16s_fused_forward_max_wgs() && st_tiles <= 128) {
       g.fwd.gamma = params + h.gamma; g.fwd.beta = params + h.beta;
       g.fwd.running_mean = rm; g.fwd.running_var = rv; g.fwd.nbt = nbt + i; g.fwd.momentum = momentum;
@@ -151,7 +151,7 @@ int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const f
   // 1.458 ms, configs[3] shape 0.925 against 0.943, configs[4] shape 7.38 against 7.44.  Per-stage weight gradients
   // (smaller batches) keep the side stream: 0.755 against 0.830 ms at 4 x 1024, B = 4096.
   const bool batched_main = on_ready == nullptr && nh - 1 >= 2 && wgrad_batched_plan_h(W, batch, nh - 1).splits > 0 &&
-                            getenv("BLH_BF16_FORCE_TWO_STREAM") == nullptr;
+                            !ctx->knob(KNOB_BF16_FORCE_TWO_STREAM);
   const bool two = ctx->two_stream && !ctx->sync.fn && !batched_main;   // (SyncBN: the exchanges are enqueued on `s`)
   hipStream_t s2 = two ? ctx->s2 : s;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -245,7 +245,7 @@ int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const f
   // nothing below needs) forms that stage's gated gradient dY' and the (dY' z, dY') column sums in its
   // epilogue (EPI_BN_BWD, big-tile kernels only): the stage below then skips bn_bwd_reduce_h2 and its
   // bn_bwd_apply_h2 reads no keep bits.  k9_chunks > 0: stage i's dA arrived that way, with that many partial rows.
-  const bool k9_enabled = getenv("BLH_NO_K9") == nullptr;
+  const bool k9_enabled = !ctx->knob(KNOB_NO_K9);
   int k9_chunks = 0;
   for (int i = nh - 1; i >= 0; --i) {
     const HeavyOffsets& h = L.heavy[i];

@@ -185,7 +185,7 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
   // clip + Adam (grads_finish: 9 us + its launch gap at configs[1]).  Needs every weight gradient to come out
   // of a slab sum, and the slots to fit.
   struct Fold { bool on = false; int per_w = 0; std::vector<int> w_off; int gb0 = 0, bias0 = 0, total = 0; } fold;
-  if (fused && fused->sumsq_part && !on_ready && !defer && !getenv("BLH_NO_SUMSQ_FOLD") && W % 16 == 0 &&
+  if (fused && fused->sumsq_part && !on_ready && !defer && !ctx->knob(KNOB_NO_SUMSQ_FOLD) && W % 16 == 0 &&
       fused->dec_bias_S > 0) {
     const bool slabbed = pick_splits(batch, ceil_div(W, 128) * ceil_div(W, 128)).splits > 1 &&
                          pick_splits(batch, ceil_div(W, 128) * ceil_div(d->in_features, 32)).splits > 1 &&
@@ -292,7 +292,7 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
   // epilogue (EPI_BN_BWD, gemm_epilogue.h) leaves the gated gradient dY' and the column sums per row tile, and the
   // stage below skips bn_bwd_reduce_f2.  (The first stage's data gradient is the block-input gradient, a skip
   // operand: the raw value has to be stored.)  Exact-fp32 GEMMs, one launch per tile.
-  const bool k9 = getenv("BLH_K9_F32") != nullptr && d->gemm_dtype == 0 &&
+  const bool k9 = ctx->knob(KNOB_K9_F32) && d->gemm_dtype == 0 &&
                   small_m_splits(batch, W, W, d->gemm_dtype).splits == 1;
   int pregated_tiles = 0;     // > 0: this stage's dA is dY' and ws.stat_part holds that many rows of partials
   for (int i = nh - 1; i >= 0; --i) {

@@ -117,6 +117,10 @@ typedef enum {
                              would give up after ~0.3 s each and the results would be wrong
                              (blh_context_grid_barrier_timeouts() counts that); where the device cannot hold the
                              grid at all the staged form is taken.                                          */
+  BLH_OPT_DEV_KNOBS = 5,  /* developer A/B switches as one bit mask (csrc/step.h: blh::KNOB_*; DESIGN.md lists
+                             them).  The initial value is read from the BLH_* environment variables ONCE, in
+                             blh_context_create; no entry point reads the environment afterwards.  Measurement
+                             knobs, not API: every combination computes the same step.                       */
   BLH_OPT_PERSISTENT_SHADOW = 3
                           /* gemm_dtype 4 only, default 0.  1: the Adam kernel of blh_train_step /
                              blh_train_step_captured also writes the bf16 image of the updated
@@ -194,7 +198,8 @@ typedef struct {
                               workspace); all contractions run on bf16 MFMA with fp32 accumulation,
                               operands fed by LDS-DMA without conversion; BatchNorm statistics
                               (taken from the fp32 accumulators), parameters, their gradients,
-                              Adam and the loss stay fp32.  width % 128 == 0.  No SyncBN.      */
+                              Adam and the loss stay fp32.  width % 128 == 0.  SyncBN (blh_sync_fn)
+                              is supported in this mode as in mode 0.                          */
 } blh_model_desc;
 
 /* Number of heavy_linear stages = 1 + 2*num_blocks (encode + hidden). */

@@ -15,7 +15,7 @@ def main():
             n = r["Kernel_Name"]
             if pats and not any(p in n for p in pats):
                 continue
-            n = n.replace("void blh::", "").split("(")[0][:70]
+            n = n.replace("void ", "").replace("(anonymous namespace)::", "").replace("blh::", "").split("(")[0][:90]
             acc[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for n in sorted(acc):
         print(n)
