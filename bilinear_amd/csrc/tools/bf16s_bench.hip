@@ -8,6 +8,7 @@
 #include "../gemm_bf16s_kernel.h"
 #include "../gemm_bf16s_256.h"
 #include "../gemm_bf16s_128x256.h"
+#include "gemm_bf16s_p128x256.h"
 
 using namespace blh;
 thread_local int blh::g_last_hip_error = 0;
@@ -62,6 +63,25 @@ float run128x256(const GemmParamsH& p, int splits, int reps) {
   for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(512), H128_LDS_BYTES, 0, p);
   CK(hipEventRecord(e0, 0));
   for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(512), H128_LDS_BYTES, 0, p);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  CK(hipGetLastError());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / reps;
+}
+
+template <int LB, int EPI, int DBG = 0>
+float runp128x256(const GemmParamsH& p, int reps, int grid_cap = 256) {
+  auto kern = gemm_bf16s_p128x256_kernel<LB, EPI, DBG>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HP128_LDS_BYTES));
+  const int tiles = (int)((p.M / 128) * (p.N / 256));
+  const int grid = std::min(tiles, grid_cap);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), HP128_LDS_BYTES, 0, p, tiles);
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), HP128_LDS_BYTES, 0, p, tiles);
   CK(hipEventRecord(e1, 0));
   CK(hipEventSynchronize(e1));
   CK(hipGetLastError());
@@ -127,6 +147,46 @@ int main(int argc, char** argv) {
       float b = run256<ROWK, ROWK, EPI_BIAS_STATS, true>(fk, 1, reps);
       float c = run<ROWK, ROWK, EPI_BIAS_STATS, true, 64, 2>(fk, 1, reps);
       printf("K %5d (%3d K tiles)  128x256 %6.1f us | 256x256 %6.1f us | 128x128 %6.1f us\n", K, K / 64, a * 1e3, b * 1e3, c * 1e3);
+    }
+    return 0;
+  }
+  if (getenv("PERSIST")) {   // persistent 128 x 256 tiles (gemm_bf16s_p128x256.h) against the one-tile-per-workgroup kernels
+    const size_t nstat = (size_t)(M / 64 + 1) * 2 * W;
+    std::vector<uint16_t> c0((size_t)M * W), c1((size_t)M * W);
+    std::vector<float> s0(nstat), s1(nstat);
+    std::vector<float> hb(W);
+    for (auto& v : hb) v = (float)rand() / RAND_MAX - 0.5f;
+    CK(hipMemcpy(bias, hb.data(), W * 4, hipMemcpyHostToDevice));
+    for (int round = 0; round < 3; ++round) {
+      CK(hipMemset(C, 0, c0.size() * 2)); CK(hipMemset(stat, 0, nstat * 4));
+      float a0 = run128x256<ROWK, ROWK, EPI_BIAS_STATS, true>(f, 1, reps);
+      CK(hipMemcpy(c0.data(), C, c0.size() * 2, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(s0.data(), stat, nstat * 4, hipMemcpyDeviceToHost));
+      CK(hipMemset(C, 0, c0.size() * 2)); CK(hipMemset(stat, 0, nstat * 4));
+      float a1 = runp128x256<ROWK, EPI_BIAS_STATS>(f, reps);
+      CK(hipMemcpy(c1.data(), C, c1.size() * 2, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(s1.data(), stat, nstat * 4, hipMemcpyDeviceToHost));
+      const bool same_c = !memcmp(c0.data(), c1.data(), c0.size() * 2);
+      const bool same_s = !memcmp(s0.data(), s1.data(), (size_t)(M / 128) * 2 * W * 4);
+      float a2 = run256<ROWK, ROWK, EPI_BIAS_STATS, true>(f, 1, reps);
+      CK(hipMemset(C, 0, c0.size() * 2));
+      float d0 = run128x256<ROWK, KROW, EPI_STORE, true>(d, 1, reps);
+      CK(hipMemcpy(c0.data(), C, c0.size() * 2, hipMemcpyDeviceToHost));
+      CK(hipMemset(C, 0, c0.size() * 2));
+      float d1 = runp128x256<KROW, EPI_STORE>(d, reps);
+      CK(hipMemcpy(c1.data(), C, c1.size() * 2, hipMemcpyDeviceToHost));
+      const bool same_d = !memcmp(c0.data(), c1.data(), c0.size() * 2);
+      float d2 = run256<ROWK, KROW, EPI_STORE, true>(d, 1, reps);
+      if (round == 0) {
+        float x1 = runp128x256<ROWK, EPI_BIAS_STATS, 1>(f, reps), x2 = runp128x256<ROWK, EPI_BIAS_STATS, 2>(f, reps);
+        float x3 = runp128x256<ROWK, EPI_BIAS_STATS, 3>(f, reps);
+        printf("persistent fwd, ablations: staged, not stored %6.1f us | no window traffic %6.1f us | stored, not staged %6.1f us\n",
+               x1 * 1e3, x2 * 1e3, x3 * 1e3);
+      }
+      printf("fwd: 128x256 %6.1f us | persistent %6.1f us %5.0f TF (C %s, stats %s) | 256x256 %6.1f us || "
+             "dgrad: 128x256 %6.1f | persistent %6.1f us %5.0f TF (C %s) | 256x256 %6.1f us\n",
+             a0 * 1e3, a1 * 1e3, flop / a1 / 1e9, same_c ? "identical" : "DIFFER", same_s ? "identical" : "DIFFER",
+             a2 * 1e3, d0 * 1e3, d1 * 1e3, flop / d1 / 1e9, same_d ? "identical" : "DIFFER", d2 * 1e3);
     }
     return 0;
   }
