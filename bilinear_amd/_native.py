@@ -135,6 +135,7 @@ _SIGNATURES = {
     "blh_skinny_encode_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       POINTER(c_int32), c_int64, c_int32, c_int32]),
     "blh_skinny_decode_fwd_mse": (c_int, [c_void_p] * 9 + [c_int64, c_int64, c_int32, c_int32]),
+    "blh_skinny_decode_fused": (c_int, [c_void_p] * 10 + [c_int64, c_int64, c_int32, c_int32]),
     "blh_skinny_decode_bwd": (c_int, [c_void_p] * 7 + [c_int64, c_int64, c_int32, c_int32]),
     "blh_skinny_encode_wgrad": (c_int, [c_void_p] * 5 + [c_int64, c_int64, c_int32, c_int32]),
     "blh_gemm_bf16s": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
@@ -186,6 +187,7 @@ OPT_DEFER_SLABS = 1
 OPT_LATE_FORK = 2
 OPT_PERSISTENT_SHADOW = 3
 OPT_SMALL_STEP = 4
+OPT_DEV_KNOBS = 5         # bit mask of developer A/B switches (csrc/step.h: blh::KNOB_*), latched from BLH_* at context creation
 
 
 class Context:

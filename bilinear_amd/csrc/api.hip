@@ -446,7 +446,7 @@ int blh_backward(blh_context* ctx, const blh_model_desc* d, void* stream, const 
   const Workspace ws = carve(d, batch, workspace);
   // which forward saved what is in this workspace (step.h: by workspace address, else the context's last forward)
   const blh_context::SavedFormat* saved = ctx->find_saved(workspace);
-  if (saved && saved->mode != 0) {
+  if (saved && (saved->mode == 1 || saved->mode == 2)) {
     // the activations in this workspace were saved by the small-batch forward: only its backward can read them
     if (from_loss || saved->batch != batch || ctx->sync.fn) return BLH_ERR_INVALID_ARGUMENT;
     SmallStepParams p;
@@ -1038,6 +1038,23 @@ int blh_skinny_decode_fwd_mse(void* stream, const float* A, const float* Wd, con
   BLH_TRY(launch_decode_fwd_mse((hipStream_t)stream, A, Wd, bd, target, pred, dpred, loss_part, part,
                                 batch, width, out_features, (float)(2.0 / denom), &np));
   // (the training step folds this tiny reduction into the optimiser kernel; NULL skips it)
+  return loss_out ? launch_loss_finalize((hipStream_t)stream, loss_part, np, denom, loss_out) : BLH_OK;
+}
+
+int blh_skinny_decode_fused(void* stream, const float* A, const float* Wd, const float* bd,
+                            const float* target, float* pred, float* dpred, float* dA, float* loss_out,
+                            void* workspace, int64_t workspace_bytes, int64_t batch, int32_t width,
+                            int32_t out_features) {
+  if (!A || !Wd || !bd || !target || !pred || !dpred || !dA || !workspace || batch <= 0)
+    return BLH_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < blh_skinny_workspace_bytes(batch, width, 32, out_features)) return BLH_ERR_WORKSPACE;
+  if (!decode_fused_supported(batch, width, out_features)) return BLH_ERR_SHAPE;
+  float* part = (float*)workspace;              // [1026*OF] bias partials, then loss partials
+  float* loss_part = part + 1026 * (int64_t)out_features;
+  const double denom = (double)batch * out_features;
+  int np = 0;
+  BLH_TRY(launch_decode_fused((hipStream_t)stream, A, Wd, bd, target, pred, dpred, dA, loss_part, part, batch, width,
+                              out_features, (float)(2.0 / denom), &np));
   return loss_out ? launch_loss_finalize((hipStream_t)stream, loss_part, np, denom, loss_out) : BLH_OK;
 }
 

@@ -19,6 +19,7 @@
 // 3x slower beside a GEMM than alone).
 #include "common.h"
 #include "philox.h"
+#include "bn_f32_dev.h"
 
 namespace blh {
 
@@ -47,25 +48,6 @@ __device__ __forceinline__ void f2_block_colsum(float4 v, float* red, float* out
   __syncthreads();
   const int t = threadIdx.x;
   if (col0 + t < W) out[col0 + t] = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
-}
-
-// keep word of rows base + 8w .. base + 8w + 7, columns col .. col + 3
-__device__ __forceinline__ uint32_t f2_keep_word(const DropoutSrc& d, int64_t base, int w, int col, int W,
-                                                 int64_t batch) {
-  if (d.keep) {                      // explicit masks (parity tests): [B][W] bytes
-    uint32_t word = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int64_t r = base + 8 * w + j;
-      if (r < batch) {
-        const uchar4 k = *reinterpret_cast<const uchar4*>(d.keep + r * (int64_t)W + col);
-        word |= ((k.x ? 1u : 0u) | (k.y ? 2u : 0u) | (k.z ? 4u : 0u) | (k.w ? 8u : 0u)) << (4 * j);
-      }
-    }
-    return word;
-  }
-  const Philox128 p = dropout_patch(d.seed, dropout_step(d), d.layer, base + d.row_offset, col);
-  return w == 0 ? p.w[0] : (w == 1 ? p.w[1] : (w == 2 ? p.w[2] : p.w[3]));
 }
 
 template <bool TRAIN>

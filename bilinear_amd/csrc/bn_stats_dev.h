@@ -1,0 +1,30 @@
+// The store step of BatchNorm's forward statistics, shared by bn_fwd_finalize (elementwise.hip: per-tile partials)
+// and enc_bn_finalize (encode_f32.hip: statistics derived from the 33 x 32 sums of x).
+#pragma once
+#include "common.h"
+
+namespace blh {
+
+static constexpr float BN_EPS = 1e-5f;
+
+// batch mean / M2 of one column -> saved statistics, scale / shift, running statistics
+__device__ __forceinline__ void bn_finalize_store(double mean, double m2, int64_t batch, int col,
+                                                  const float* gamma, const float* beta,
+                                                  float* running_mean, float* running_var,
+                                                  const int64_t* nbt, float momentum, float* saved_mean,
+                                                  float* saved_invstd, float* scale, float* shift) {
+  const double var = m2 / (double)batch;
+  const float invstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
+  const float mu = (float)mean;
+  const float sc = gamma[col] * invstd;
+  saved_mean[col] = mu;
+  saved_invstd[col] = invstd;
+  scale[col] = sc;
+  shift[col] = beta[col] - mu * sc;
+  const double f = (momentum >= 0.f) ? (double)momentum : 1.0 / (double)(nbt[0] + 1);
+  const double unbiased = m2 / (double)(batch > 1 ? batch - 1 : 1);
+  running_mean[col] = (float)((1.0 - f) * (double)running_mean[col] + f * mean);
+  running_var[col] = (float)((1.0 - f) * (double)running_var[col] + f * unbiased);
+}
+
+}  // namespace blh

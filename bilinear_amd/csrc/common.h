@@ -244,6 +244,22 @@ int launch_decode_finish(hipStream_t s, const float* slabs, int splits, int64_t 
                          float* dbias_part = nullptr);
 // skinny.hip: decode forward fused with the MSE loss (pred, dpred, loss / decode-bias partials)
 bool decode_fwd_supported(int64_t batch, int W, int OF);
+// ---- encode stage without its pre-BatchNorm tensor (encode_f32.hip) ----
+bool enc_fused_supported(int64_t batch, int W, int in_features);
+int enc_bwd_finish_blocks(int W);
+int launch_enc_forward(hipStream_t s, const float* x, const float* W0, const float* b0, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, int64_t* nbt, float momentum,
+                       float* saved, float* z0_scratch, float* A, uint32_t* keepbits, int64_t batch, int W,
+                       const DropoutSrc& drop);
+// one pass over dA0 + the finish kernel: dW0, dgamma, dbeta, the bias column-sum rows, sums of squares (optional)
+int launch_enc_backward(hipStream_t s, const float* dA, const float* x, const float* W0, const float* b0,
+                        const float* saved, const uint32_t* gatebits, float* z0_scratch, int64_t batch, int W,
+                        float* dW0, float* dgamma, float* dbeta, float* db_rows, int db_nrows, double* sq_w,
+                        double* sq_gb);
+bool decode_fused_supported(int64_t batch, int W, int OF);
+int launch_decode_fused(hipStream_t s, const float* A, const float* Wd, const float* bd, const float* target,
+                        float* pred, float* dpred, float* dA, float* loss_part, float* dbias_part, int64_t batch,
+                        int W, int OF, float scale, int* nparts);
 int launch_decode_fwd_mse(hipStream_t s, const float* A, const float* Wd, const float* bd,
                           const float* target, float* pred, float* dpred, float* loss_part,
                           float* dbias_part, int64_t batch, int W, int OF, float scale, int* nparts);

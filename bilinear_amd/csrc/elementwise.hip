@@ -10,6 +10,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "bn_stats_dev.h"
 #include "philox.h"
 
 namespace blh {
@@ -22,7 +23,6 @@ namespace blh {
 #define BLH_EW_PRIO() __builtin_amdgcn_s_setprio(3)
 
 static constexpr int EW_THREADS = 256;
-static constexpr float BN_EPS = 1e-5f;
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -104,26 +104,6 @@ __device__ __forceinline__ double strided_colsum(const float* __restrict__ in, i
     for (int u = 0; u < U; ++u) acc += (s0 + u * stride < S) ? (double)v[u] : 0.0;
   }
   return acc;
-}
-
-// batch mean / M2 of one column -> saved statistics, scale / shift, running statistics
-__device__ __forceinline__ void bn_finalize_store(double mean, double m2, int64_t batch, int col,
-                                                  const float* gamma, const float* beta,
-                                                  float* running_mean, float* running_var,
-                                                  const int64_t* nbt, float momentum, float* saved_mean,
-                                                  float* saved_invstd, float* scale, float* shift) {
-  const double var = m2 / (double)batch;
-  const float invstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
-  const float mu = (float)mean;
-  const float sc = gamma[col] * invstd;
-  saved_mean[col] = mu;
-  saved_invstd[col] = invstd;
-  scale[col] = sc;
-  shift[col] = beta[col] - mu * sc;
-  const double f = (momentum >= 0.f) ? (double)momentum : 1.0 / (double)(nbt[0] + 1);
-  const double unbiased = m2 / (double)(batch > 1 ? batch - 1 : 1);
-  running_mean[col] = (float)((1.0 - f) * (double)running_mean[col] + f * mean);
-  running_var[col] = (float)((1.0 - f) * (double)running_var[col] + f * unbiased);
 }
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,458 @@
+// The encode stage of the lifter without its pre-BatchNorm tensor (fp32 storage, exact fp32 arithmetic).
+// (/root/reference/model/bilinear.py:22 `heavy_linear(16 * 2, 1024)`, :34)
+//
+// z = x W0^T + b0 has only 32 inputs, so everything BatchNorm needs from Z0 [B][W] follows from quantities of x:
+//   forward   the batch mean and variance of column j are  w_j . xbar + b_j  and  w_j^T Cov(x) w_j  (fp64 from the
+//             33 x 32 sums of x: enc_xstats, on the matrix cores, + enc_bn_finalize), so ONE kernel maps x -> A0 = 2 keep relu(z scale + shift)
+//             and the keep bits (enc_fwd): no 16.8 MB Z0 write, no re-read by a bn_apply pass.
+//   backward  the encode Linear has no data gradient; what is wanted are dgamma, dbeta, db0 and
+//             dW0 = dZ0^T X with dZ0 = scale dY' + a z + b' (bn_f32.hip).  The forward leaves keep AND [y > 0] as the
+//             stage's "keep" bits, so dY' = 2 dA0 keep' needs no z; P = dY'^T X is a contraction over the batch
+//             (enc_bwd: partials per row block, with S2 = sum dY'), and the rest is analytic again (enc_bwd_finish):
+//                 S1 = sum dY' z = W0 . P + b0 S2            (row-wise dot of W0 and P)
+//                 z^T X = W0 (X^T X) + b0 xs^T,             sum z = W0 xs + B b0
+//                 dW0 = diag(scale) P + diag(a) (z^T X) + b' xs^T,     db0 = scale S2 + a sum(z) + b' B.
+//             The stage reads dA0 once and nothing else of size [B][W] — the streaming path read dA0 and Z0 twice
+//             each, wrote dZ0 and read it again for the weight-gradient GEMM — and issues 32 MFMAs per 16 x 64
+//             tile (it runs beside the side stream's weight-gradient GEMM, which owns the matrix pipes: the first
+//             form re-computed z with 32 more and took 59 us there).
+//
+// MFMA layouts (v_mfma_f32_16x16x4_f32; lane l: n = l & 15, q = l >> 4).  A wave owns 64 columns c0 .. c0 + 63:
+//   z tile [16 rows][64 cols]: A operand = x (lane: row n, float4 of k = 16 h + 4 q .. + 3: component j feeds MFMA j,
+//     a permutation of the contraction index used on both operands), B operand = W0 (lane: float4 of row
+//     c0 + 4 n + jj, same k): MFMA group jj produces columns c0 + 4 n + jj, so acc[jj][reg] of a lane are rows
+//     4 q + reg x FOUR CONSECUTIVE columns c0 + 4 n .. + 3 — one 16-byte access per row for A0 / dA0 / keep bits.
+//   dY'^T X: the z tile's layout (column on the lane, rows in q and the registers) — in which the backward kernel
+//     loads dA0 and forms dY' — is exactly a B operand whose
+//     contraction index is the row (cdna_hip_programming.md 3, "An accumulator tile as the next MFMA's operand"):
+//     step reg contracts rows 4 q + reg; A operand = x^T (lane: feature 16 h + n, row 4 q + reg).  The result holds
+//     features 16 h + 4 q + reg' of column c0 + 4 n + jj: 16-byte stores into the [col][32] partial.
+#include "common.h"
+#include "philox.h"
+#include "bn_f32_dev.h"
+#include "bn_stats_dev.h"
+
+namespace blh {
+
+typedef float encf4 __attribute__((ext_vector_type(4)));
+
+static constexpr int ENC_IF = 32;                        // input features (16 joints x 2)
+static constexpr int ENC_XN = ENC_IF + ENC_IF * ENC_IF;  // colsum(x) | X^T X
+static constexpr int ENC_XBLOCKS = 64;                   // at most this many row blocks of enc_xstats
+static constexpr int ENC_XROWS = 256;                    // rows per block of enc_xstats (a multiple of 128)
+
+// ---- x statistics -------------------------------------------------------------------------------------------
+// xpart[b][0 .. 31] = sum_r x[r][f], xpart[b][32 + a * 32 + c] = sum_r x[r][a] x[r][c] over the block's rows (fp32
+// sums of exact products over at most a few hundred rows; the partials are added in fp64).  X^T X on the matrix
+// cores: per 4 rows both operands are the same registers — A = x^T (lane: feature n + 16 h, row 4 s + q), B = x
+// (lane: row 4 s + q, feature n + 16 h') — 4 MFMAs per 4 rows.  (The first form used fp64 vector FMAs from an LDS
+// copy, four dependent staging rounds per block: 21-28 us.)
+__global__ __launch_bounds__(256) void enc_xstats_kernel(const float* __restrict__ x, int64_t batch, int rows_per_block,
+                                                         float* __restrict__ xpart) {
+  __shared__ float red[4][ENC_XN];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(batch, r0 + rows_per_block);
+  encf4 acc[2][2];
+  acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = encf4{0.f, 0.f, 0.f, 0.f};
+  float cs0 = 0.f, cs1 = 0.f;
+  for (int64_t base = r0 + 32 * wave; base < r1; base += 128) {      // 8 steps of 4 rows per round, all loads first
+    float xv[8][2];
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const int64_t row = base + 4 * st + q;
+      const float* xr = x + min(row, batch - 1) * ENC_IF + n;
+      const bool ok = row < r1;
+      xv[st][0] = ok ? xr[0] : 0.f;
+      xv[st][1] = ok ? xr[16] : 0.f;
+    }
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      cs0 += xv[st][0]; cs1 += xv[st][1];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+          acc[h][h2] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[st][h], xv[st][h2], acc[h][h2], 0, 0, 0);
+    }
+  }
+  cs0 += __shfl_xor(cs0, 16); cs0 += __shfl_xor(cs0, 32);
+  cs1 += __shfl_xor(cs1, 16); cs1 += __shfl_xor(cs1, 32);
+  if (q == 0) { red[wave][n] = cs0; red[wave][16 + n] = cs1; }
+  // acc[h][h2][reg] = XtX[a = 16 h + 4 q + reg][c = 16 h2 + n]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) red[wave][ENC_IF + (16 * h + 4 * q + reg) * ENC_IF + 16 * h2 + n] = acc[h][h2][reg];
+  __syncthreads();
+  float* out = xpart + (int64_t)blockIdx.x * ENC_XN;
+  for (int e = threadIdx.x; e < ENC_XN; e += 256) out[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
+// Sums the partials and finishes BatchNorm's forward statistics of 16 columns per block (thread = column t >> 4,
+// features g = t & 15 and g + 16); leaves for the backward, per column, T[col][f] = (z^T X)[col][f] =
+// sum_k W0[col][k] XtX[k][f] + b0[col] xs[f] and zs[col] = sum of z over the batch, and xs[32] (block 0).
+__global__ __launch_bounds__(256) void enc_bn_finalize_kernel(
+    const float* __restrict__ xpart, int nparts, float* __restrict__ xs_out, float* __restrict__ ttab,
+    float* __restrict__ zs_out, const float* __restrict__ W0, const float* __restrict__ b0, int64_t batch, int W,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean, float* running_var,
+    const int64_t* nbt, float momentum, float* saved_mean, float* saved_invstd, float* scale, float* shift) {
+  __shared__ double xs[ENC_XN];
+  const int t = threadIdx.x;
+  {
+    // (the loads of 16 partials of all of the thread's entries are requested together: nparts / 16 round trips)
+    constexpr int NE = (ENC_XN + 255) / 256;
+    double tot[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) tot[i] = 0.0;
+    for (int p0 = 0; p0 < nparts; p0 += 16) {
+      float v[NE][16];
+#pragma unroll
+      for (int i = 0; i < NE; ++i)
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+          v[i][p] = xpart[(int64_t)min(p0 + p, nparts - 1) * ENC_XN + min(t + 256 * i, ENC_XN - 1)];
+#pragma unroll
+      for (int i = 0; i < NE; ++i)
+#pragma unroll
+        for (int p = 0; p < 16; ++p) tot[i] += p0 + p < nparts ? (double)v[i][p] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = t + 256 * i;
+      if (e < ENC_XN) xs[e] = tot[i];
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && t < ENC_IF) xs_out[t] = (float)xs[t];
+  const int col = blockIdx.x * 16 + (t >> 4), g = t & 15;
+  const bool ok = col < W;
+  const float* w = W0 + (int64_t)(ok ? col : 0) * ENC_IF;
+  float wr[ENC_IF];
+#pragma unroll
+  for (int k = 0; k < ENC_IF; k += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(w + k);
+    wr[k] = v.x; wr[k + 1] = v.y; wr[k + 2] = v.z; wr[k + 3] = v.w;
+  }
+  const double b = ok ? (double)b0[col] : 0.0, B = (double)batch;
+  // u[f] = sum_k w[k] XtX[k][f] for f = g, g + 16;   w^T XtX w = sum_f w[f] u[f];   w . xs
+  double u0 = 0.0, u1 = 0.0;
+#pragma unroll
+  for (int k = 0; k < ENC_IF; ++k) {
+    u0 = fma((double)wr[k], xs[ENC_IF + k * ENC_IF + g], u0);
+    u1 = fma((double)wr[k], xs[ENC_IF + k * ENC_IF + g + 16], u1);
+  }
+  const double wf0 = ok ? (double)w[g] : 0.0, wf1 = ok ? (double)w[g + 16] : 0.0;     // this thread's features
+  double quad = wf0 * u0 + wf1 * u1, dot = wf0 * xs[g] + wf1 * xs[g + 16];
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) { quad += __shfl_xor(quad, o); dot += __shfl_xor(dot, o); }
+  if (ok) {
+    ttab[(int64_t)col * ENC_IF + g] = (float)(u0 + b * xs[g]);
+    ttab[(int64_t)col * ENC_IF + g + 16] = (float)(u1 + b * xs[g + 16]);
+    if (g == 0) {
+      zs_out[col] = (float)(dot + B * b);
+      const double mean_wx = dot / B;                       // mean of w . x
+      const double m2 = quad - B * mean_wx * mean_wx;       // sum (z - mean)^2: the bias drops out
+      bn_finalize_store(mean_wx + b, m2 > 0.0 ? m2 : 0.0, batch, col, gamma, beta, running_mean, running_var, nbt,
+                        momentum, saved_mean, saved_invstd, scale, shift);
+    }
+  }
+}
+
+// ---- operands shared by the forward and the backward kernel ---------------------------------------------------
+struct EncCols {
+  float4 wb[4][2];     // W0 rows c0 + 4 n + jj, k = 16 h + 4 q .. + 3
+  float4 bias, sc, sh; // columns c0 + 4 n .. + 3
+};
+__device__ __forceinline__ void enc_load_cols(EncCols& c, const float* __restrict__ W0, const float* __restrict__ b0,
+                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                              int col, int q) {
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      c.wb[jj][h] = *reinterpret_cast<const float4*>(W0 + (int64_t)(col + jj) * ENC_IF + 16 * h + 4 * q);
+  c.bias = *reinterpret_cast<const float4*>(b0 + col);
+  c.sc = *reinterpret_cast<const float4*>(scale + col);
+  c.sh = *reinterpret_cast<const float4*>(shift + col);
+}
+// z of the 16-row tile at `base`: zt[jj][reg] = row base + 4 q + reg, column col + jj (without the bias)
+__device__ __forceinline__ void enc_z_tile(encf4 (&zt)[4], const EncCols& c, const float* __restrict__ x, int64_t base,
+                                           int64_t batch, int n, int q) {
+  const float* xr = x + min(base + n, batch - 1) * ENC_IF + 4 * q;
+  const float4 xa0 = *reinterpret_cast<const float4*>(xr), xa1 = *reinterpret_cast<const float4*>(xr + 16);
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    encf4 a = encf4{0.f, 0.f, 0.f, 0.f};
+    a = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0.x, c.wb[jj][0].x, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0.y, c.wb[jj][0].y, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0.z, c.wb[jj][0].z, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0.w, c.wb[jj][0].w, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x4f32(xa1.x, c.wb[jj][1].x, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x4f32(xa1.y, c.wb[jj][1].y, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x4f32(xa1.z, c.wb[jj][1].z, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x4f32(xa1.w, c.wb[jj][1].w, a, 0, 0, 0);
+    zt[jj] = a;
+  }
+}
+
+// ---- forward: x -> A0 (+ keep bits) ----------------------------------------------------------------------------
+// block = 4 waves x 64 columns = 256 columns; the block's rows [blockIdx.y * rows_per_block, ...) in 16-row tiles
+__global__ __launch_bounds__(256) void enc_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W0,
+                                                      const float* __restrict__ b0, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, float* __restrict__ A,
+                                                      uint32_t* __restrict__ keepbits, int64_t batch, int W,
+                                                      int rows_per_block, DropoutSrc drop, int64_t* nbt) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int col = blockIdx.x * 256 + wave * 64 + 4 * n;
+  if (nbt && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) nbt[0] += 1;
+  EncCols c;
+  enc_load_cols(c, W0, b0, scale, shift, col, q);
+  const int W4 = W >> 2;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;      // a multiple of 32
+  const int64_t r1 = min(batch, r0 + rows_per_block);
+  for (int64_t base = r0; base < r1; base += 16) {
+    encf4 zt[4];
+    enc_z_tile(zt, c, x, base, batch, n, q);
+    // keep word of the 8-row group of this lane's rows (rows base + 4 q .. + 3 are its low or high half)
+    const int64_t rg = base + 8 * (q >> 1);
+    const uint32_t kw = f2_keep_word(drop, base & ~(int64_t)31, (int)((rg >> 3) & 3), col, W, batch);
+    uint32_t gate = 0;                               // [y > 0] of this lane's 4 rows x 4 columns, at their bits of the word
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int64_t row = base + 4 * q + reg;
+      const int sh4 = 4 * (4 * (q & 1) + reg);
+      const uint32_t nib = kw >> sh4;
+      float4 a;
+      a.x = fmaxf(fmaf(zt[0][reg] + c.bias.x, c.sc.x, c.sh.x), 0.f);
+      a.y = fmaxf(fmaf(zt[1][reg] + c.bias.y, c.sc.y, c.sh.y), 0.f);
+      a.z = fmaxf(fmaf(zt[2][reg] + c.bias.z, c.sc.z, c.sh.z), 0.f);
+      a.w = fmaxf(fmaf(zt[3][reg] + c.bias.w, c.sc.w, c.sh.w), 0.f);
+      gate |= ((a.x > 0.f ? 1u : 0u) | (a.y > 0.f ? 2u : 0u) | (a.z > 0.f ? 4u : 0u) | (a.w > 0.f ? 8u : 0u)) << sh4;
+      a.x = (nib & 1u) ? a.x * 2.f : 0.f; a.y = (nib & 2u) ? a.y * 2.f : 0.f;
+      a.z = (nib & 4u) ? a.z * 2.f : 0.f; a.w = (nib & 8u) ? a.w * 2.f : 0.f;
+      if (row < batch) *reinterpret_cast<float4*>(A + row * W + col) = a;
+    }
+    // the stage's "keep" bits for the backward: keep AND [y > 0] (the other half of the word: lane l ^ 16)
+    gate |= __shfl_xor(gate, 16);
+    if ((q & 1) == 0 && rg < batch) keepbits[(rg >> 3) * W4 + (col >> 2)] = kw & gate;
+  }
+}
+
+// ---- backward: dA0 -> S2 = sum dY' and P = dY'^T X, partials per row block ------------------------------------------
+// block = 4 waves on the SAME 64 columns, wave w takes the 16-row tiles w, w + 4, ... of the block's rows
+__global__ __launch_bounds__(256) void enc_bwd_kernel(const float* __restrict__ dA, const float* __restrict__ x,
+                                                      const uint32_t* __restrict__ gatebits, float* __restrict__ s2part,
+                                                      float* __restrict__ ppart, int64_t batch, int W,
+                                                      int rows_per_block) {
+  __builtin_amdgcn_s_setprio(3);
+  // 9 KiB of LDS: the kernel has to fit BESIDE a workgroup of the side stream's weight-gradient GEMM (128 KiB of the
+  // CU's 160) — with a 32 KiB buffer per block its workgroups waited for the GEMM's to retire: 75 us
+  __shared__ __attribute__((aligned(16))) float red[64 * ENC_IF];        // [64 columns][32 features], waves add in turn
+  __shared__ float sred[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int c0 = blockIdx.x * 64;
+  const int col = c0 + 4 * n;
+  const int W4 = W >> 2;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = min(batch, r0 + rows_per_block);
+  encf4 pacc[4][2];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) pacc[jj][0] = pacc[jj][1] = encf4{0.f, 0.f, 0.f, 0.f};
+  float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t base = r0 + 16 * wave; base < r1; base += 64) {
+    float4 g[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+      g[reg] = *reinterpret_cast<const float4*>(dA + min(base + 4 * q + reg, batch - 1) * W + col);
+    const int64_t rg = base + 8 * (q >> 1);
+    const uint32_t kw = rg < batch ? gatebits[(rg >> 3) * W4 + (col >> 2)] : 0u;
+    // x^T operand: feature 16 h + n of row base + 4 q + reg
+    float xt[4][2];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const float* xr = x + min(base + 4 * q + reg, batch - 1) * ENC_IF + n;
+      xt[reg][0] = xr[0]; xt[reg][1] = xr[16];
+    }
+    encf4 dy[4];                                   // dy[jj][reg]: row base + 4 q + reg, column col + jj
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const uint32_t nib = (base + 4 * q + reg < batch) ? (kw >> (4 * (4 * (q & 1) + reg))) : 0u;
+      const float dx = (nib & 1u) ? g[reg].x * 2.f : 0.f, dyv = (nib & 2u) ? g[reg].y * 2.f : 0.f;
+      const float dz = (nib & 4u) ? g[reg].z * 2.f : 0.f, dw = (nib & 8u) ? g[reg].w * 2.f : 0.f;
+      s2.x += dx; s2.y += dyv; s2.z += dz; s2.w += dw;
+      dy[0][reg] = dx; dy[1][reg] = dyv; dy[2][reg] = dz; dy[3][reg] = dw;
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        pacc[jj][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[reg][0], dy[jj][reg], pacc[jj][0], 0, 0, 0);
+        pacc[jj][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[reg][1], dy[jj][reg], pacc[jj][1], 0, 0, 0);
+      }
+  }
+  // column sums over the lane groups q (rows), then over the four waves
+  s2.x += __shfl_xor(s2.x, 16); s2.y += __shfl_xor(s2.y, 16); s2.z += __shfl_xor(s2.z, 16); s2.w += __shfl_xor(s2.w, 16);
+  s2.x += __shfl_xor(s2.x, 32); s2.y += __shfl_xor(s2.y, 32); s2.z += __shfl_xor(s2.z, 32); s2.w += __shfl_xor(s2.w, 32);
+  if (q == 0) *reinterpret_cast<float4*>(&sred[wave][4 * n]) = s2;
+  // pacc[jj][h][reg'] = (dY'^T X)[column c0 + 4 n + jj][feature 16 h + 4 q + reg']: the four waves add their tiles
+  // into one LDS image in a fixed order (every lane owns the same 8 float4 of it in each wave)
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float4* dst = reinterpret_cast<float4*>(&red[(4 * n + jj) * ENC_IF + 16 * h + 4 * q]);
+          float4 v = make_float4(pacc[jj][h][0], pacc[jj][h][1], pacc[jj][h][2], pacc[jj][h][3]);
+          if (w > 0) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+          *dst = v;
+        }
+    }
+    __syncthreads();
+  }
+  const int t = threadIdx.x;
+  if (t < 64) s2part[(int64_t)blockIdx.y * W + c0 + t] = (sred[0][t] + sred[1][t]) + (sred[2][t] + sred[3][t]);
+  float* pp = ppart + ((int64_t)blockIdx.y * W + c0) * ENC_IF;
+  for (int e = t; e < 64 * ENC_IF / 4; e += 256)
+    *reinterpret_cast<float4*>(pp + 4 * e) = *reinterpret_cast<const float4*>(&red[4 * e]);
+}
+
+// ---- backward finish: dgamma, dbeta, dW0, db0 (+ the sums of squares of what it writes) ---------------------------
+// block = 16 columns x 32 features.  It runs beside the side stream's weight-gradient GEMM, where every vector
+// instruction waits for an issue slot the GEMM leaves: everything that does not depend on the gradient — z^T X, the
+// sum of z — was left by the forward (enc_bn_finalize); the first form computed it here and took 50 us.
+__global__ __launch_bounds__(512) void enc_bwd_finish_kernel(
+    const float* __restrict__ ppart, const float* __restrict__ s2part, int nrb, const float* __restrict__ xs,
+    const float* __restrict__ ttab, const float* __restrict__ zs, const float* __restrict__ W0,
+    const float* __restrict__ b0, const float* __restrict__ saved, int64_t batch, int W, float* __restrict__ dW0,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ db_rows, int db_nrows,
+    double* __restrict__ sq_w, double* __restrict__ sq_gb) {
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ double sqred[2][8];
+  const int t = threadIdx.x;
+  const int col = blockIdx.x * 16 + (t >> 5), f = t & 31;
+  double q2w = 0.0, q2g = 0.0;
+  if (col < W) {        // (whole 32-lane groups: the shuffles below stay inside a column)
+    const float wf = W0[(int64_t)col * ENC_IF + f], tf = ttab[(int64_t)col * ENC_IF + f], xf = xs[f];
+    const float bcol = b0[col], zsc = zs[col];
+    const float mean_f = saved[col], invstd_f = saved[W + col], scale_f = saved[2 * W + col];
+    double P = 0.0, S2 = 0.0;
+    for (int rb0 = 0; rb0 < nrb; rb0 += 16) {             // 2 x 16 loads in flight per round trip
+      float v[16], u2[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int64_t rb = min(rb0 + u, nrb - 1);
+        v[u] = ppart[(rb * W + col) * ENC_IF + f];
+        u2[u] = s2part[rb * W + col];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (rb0 + u < nrb) { P += (double)v[u]; S2 += (double)u2[u]; }
+    }
+    const double B = (double)batch, b = (double)bcol;
+    double s1 = (double)wf * P;                           // S1 = sum dY' z = W0[col] . P[col] + b0 S2
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o);
+    s1 += b * S2;
+    const double mean = (double)mean_f, invstd = (double)invstd_f, scale = (double)scale_f;
+    const double dg = invstd * (s1 - mean * S2), db = S2;
+    const double c1 = db / B, c2 = dg / B;
+    const double a = -scale * c2 * invstd, bp = scale * (c2 * invstd * mean - c1);
+    const float g = (float)(scale * P + a * (double)tf + bp * (double)xf);
+    dW0[(int64_t)col * ENC_IF + f] = g;
+    q2w = (double)g * (double)g;
+    if (f == 0) {
+      const float dgf = (float)dg, dbf = (float)db;
+      dgamma[col] = dgf; dbeta[col] = dbf;
+      q2g = (double)dgf * (double)dgf + (double)dbf * (double)dbf;
+      db_rows[col] = (float)(scale * S2 + a * (double)zsc + bp * B);
+    }
+  }
+  // (db_rows: the stage's slot of the bias column-sum partials, [db_nrows][W]: row 0 carries db0, the others zero)
+  for (int r = 1 + (t >> 4); r < db_nrows; r += 32) {
+    const int cc = blockIdx.x * 16 + (t & 15);
+    if (cc < W) db_rows[(int64_t)r * W + cc] = 0.f;
+  }
+  if (sq_w) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { q2w += __shfl_xor(q2w, o); q2g += __shfl_xor(q2g, o); }
+    if ((t & 63) == 0) { sqred[0][t >> 6] = q2w; sqred[1][t >> 6] = q2g; }
+    __syncthreads();
+    if (t < 2) {
+      double tt = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tt += sqred[t][k];
+      (t == 0 ? sq_w : sq_gb)[blockIdx.x] = tt;
+    }
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------
+// rows per block of enc_fwd / enc_bwd: whole 32-row Philox patches, at most 128 row blocks (the partials of
+// enc_bwd go where bn_bwd_reduce_f2's go: [ew_num_row_chunks][2][W])
+static int enc_fwd_rows(int64_t batch) { return (int)(32 * std::max<int64_t>(1, ceil_div(batch, 32 * 128))); }
+static int enc_bwd_rows(int64_t batch) { return (int)(128 * std::max<int64_t>(1, ceil_div(batch, 128 * 128))); }
+int enc_bwd_row_blocks(int64_t batch) { return (int)ceil_div(batch, enc_bwd_rows(batch)); }
+int enc_bwd_finish_blocks(int W) { return (int)ceil_div(W, 16); }      // = bn_bwd_finalize_blocks(W)
+
+// scratch inside the (unused) Z0 buffer of the stage, floats: [xs 32 | zs W | T W x 32 | xpart | ppart | s2part]
+struct EncScratch { float *xs, *zs, *ttab, *xpart, *ppart, *s2part; int64_t floats; };
+static EncScratch enc_scratch(float* z0, int64_t batch, int W) {
+  EncScratch e;
+  int64_t off = 0;
+  auto take = [&](int64_t n) { float* p = z0 ? z0 + off : nullptr; off += (n + 63) / 64 * 64; return p; };
+  e.xs = take(ENC_IF);
+  e.zs = take(W);
+  e.ttab = take((int64_t)W * ENC_IF);
+  e.xpart = take((int64_t)ENC_XBLOCKS * ENC_XN);
+  e.ppart = take((int64_t)enc_bwd_row_blocks(batch) * W * ENC_IF);
+  e.s2part = take((int64_t)enc_bwd_row_blocks(batch) * W);
+  e.floats = off;
+  return e;
+}
+bool enc_fused_supported(int64_t batch, int W, int in_features) {
+  return in_features == ENC_IF && W % 256 == 0 && batch >= 64 && enc_scratch(nullptr, batch, W).floats <= batch * (int64_t)W;
+}
+
+int launch_enc_forward(hipStream_t s, const float* x, const float* W0, const float* b0, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, int64_t* nbt, float momentum,
+                       float* saved, float* z0_scratch, float* A, uint32_t* keepbits, int64_t batch, int W,
+                       const DropoutSrc& drop) {
+  if (!enc_fused_supported(batch, W, ENC_IF)) return BLH_ERR_SHAPE;
+  const EncScratch e = enc_scratch(z0_scratch, batch, W);
+  const int xrows = (int)(ENC_XROWS * ceil_div(batch, (int64_t)ENC_XROWS * ENC_XBLOCKS));
+  const int xblocks = (int)ceil_div(batch, xrows);
+  hipLaunchKernelGGL(enc_xstats_kernel, dim3(xblocks), dim3(256), 0, s, x, batch, xrows, e.xpart);
+  hipLaunchKernelGGL(enc_bn_finalize_kernel, dim3((unsigned)ceil_div(W, 16)), dim3(256), 0, s, e.xpart, xblocks, e.xs,
+                     e.ttab, e.zs, W0, b0, batch, W, gamma, beta, running_mean, running_var, nbt, momentum, saved,
+                     saved + W, saved + 2 * W, saved + 3 * W);
+  const int rows = enc_fwd_rows(batch);
+  hipLaunchKernelGGL(enc_fwd_kernel, dim3(W / 256, (unsigned)ceil_div(batch, rows)), dim3(256), 0, s, x, W0, b0,
+                     saved + 2 * W, saved + 3 * W, A, keepbits, batch, W, rows, drop, nbt);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+int launch_enc_backward(hipStream_t s, const float* dA, const float* x, const float* W0, const float* b0,
+                        const float* saved, const uint32_t* gatebits, float* z0_scratch, int64_t batch, int W,
+                        float* dW0, float* dgamma, float* dbeta, float* db_rows, int db_nrows, double* sq_w,
+                        double* sq_gb) {
+  const EncScratch e = enc_scratch(z0_scratch, batch, W);
+  const int rows = enc_bwd_rows(batch);
+  hipLaunchKernelGGL(enc_bwd_kernel, dim3(W / 64, (unsigned)ceil_div(batch, rows)), dim3(256), 0, s, dA, x, gatebits,
+                     e.s2part, e.ppart, batch, W, rows);
+  hipLaunchKernelGGL(enc_bwd_finish_kernel, dim3((unsigned)enc_bwd_finish_blocks(W)), dim3(512), 0, s, e.ppart, e.s2part,
+                     enc_bwd_row_blocks(batch), e.xs, e.ttab, e.zs, W0, b0, saved, batch, W, dW0, dgamma, dbeta, db_rows,
+                     db_nrows, sq_w, sq_gb);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+}  // namespace blh

@@ -87,6 +87,10 @@ struct blh_context {
   }
   const void* shadow_params = nullptr;
   const void* shadow_ws = nullptr;
+  // one-pass decode (skinny.hip: decode_fused_kernel): the forward with a target also left the decode data gradient
+  // dA = dP Wd in this workspace's G0 for this batch; the backward that consumes that forward skips the GEMM
+  const void* dec_da_ws = nullptr;
+  int64_t dec_da_batch = 0;
   // grid barrier of the fused forward stage (gemm_bf16s_bnfwd.h): arrivals, generation, timeouts; device memory
   // owned by the context, zeroed once here
   uint32_t* grid_bar = nullptr;

@@ -6,6 +6,14 @@
 namespace blh {
 
 // ------------------------------------------------------------- forward -----
+// The encode stage without its pre-BatchNorm tensor (encode_f32.hip): exact-fp32 mode, per-rank statistics (SyncBN
+// exchanges tile sums of Z), the multi-launch path's batch sizes.  A train-mode forward that takes it records saved
+// format 3 for the workspace; the backward that consumes that forward reads the record.
+static bool enc_fused_ok(const blh_context* ctx, const blh_model_desc* d, int64_t batch) {
+  return d->gemm_dtype == 0 && !ctx->sync.fn && !ctx->knob(KNOB_NO_ENCODE_FUSE) && batch > 384 &&
+         enc_fused_supported(batch, d->width, d->in_features);
+}
+
 int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
                         float* bn_running, int64_t* nbt, const float* x, const blh_dropout* drop,
                         float momentum, const Workspace& ws, float* pred, int64_t batch,
@@ -14,13 +22,21 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
   const ArenaLayout L = make_layout(d);
   const int nh = (int)L.heavy.size();
   const int W = d->width;
-  if (train) ctx->note_saved(ws.Z[0], batch, 0);     // (ws.Z[0] is the workspace base, api_layout.h carve)
+  const bool enc_fused = train && enc_fused_ok(ctx, d, batch);
+  if (train) ctx->note_saved(ws.Z[0], batch, enc_fused ? 3 : 0);     // (ws.Z[0] is the workspace base, api_layout.h carve)
   if (ws.amax_W)   // gemm_dtype 3: max |w| of every hidden Linear weight, once per forward
     for (int i = 1; i < nh; ++i)
       BLH_TRY(launch_wamax(s, params + L.heavy[i].w, 0, 1, (int64_t)W * W, ws.amax_W + (int64_t)i * WAMAX_PARTS));
   for (int i = 0; i < nh; ++i) {
     const HeavyOffsets& h = L.heavy[i];
     const float* in = (i == 0) ? x : ws.A[i - 1];
+    if (i == 0 && enc_fused) {
+      // x statistics -> BatchNorm statistics -> A0 and the keep bits; Z0's buffer serves as scratch
+      BLH_TRY(launch_enc_forward(s, x, params + h.w, params + h.b, params + h.gamma, params + h.beta, bn_running,
+                                 bn_running + W, nbt, momentum, ws.bn_saved[0], ws.Z[0], ws.A[0], ws.keep[0], batch, W,
+                                 layer_drop(ctx, drop, 0, batch, W)));
+      continue;
+    }
     GemmParams g{};
     g.A = in; g.lda = h.fan_in;
     g.B = params + h.w; g.ldb = h.fan_in;
@@ -99,6 +115,17 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
   // over W is split across workgroups (slabs) and a small kernel adds the slabs, the bias and,
   // in the fused step, the MSE loss / gradient (train_bilinear.py:78).
   const int OF = d->out_features;
+  ctx->dec_da_ws = nullptr;
+  if (train && target && d->gemm_dtype == 0 && !ctx->knob(KNOB_NO_DECODE_FUSE) && decode_fused_supported(batch, W, OF)) {
+    // one pass over the last activation: prediction, MSE, dpred, the loss / decode-bias partials AND the decode data
+    // gradient dA = dP Wd (into G0, where backward expects the gradient of the last stage's output)
+    int np = 0;
+    BLH_TRY(launch_decode_fused(s, ws.A[nh - 1], params + L.dec_w, params + L.dec_b, target, pred, ws.dpred, ws.G0,
+                                loss_part, ws.dec_bias_part, batch, W, OF, mse_scale, &np));
+    if (loss_nparts) *loss_nparts = np;
+    ctx->dec_da_ws = ws.Z[0]; ctx->dec_da_batch = batch;
+    return BLH_OK;
+  }
   if (decode_fwd_supported(batch, W, OF)) {
     // purpose-built kernel (skinny.hip): reads A once, no slabs, bias + MSE + dpred + the loss and
     // decode-bias partials in the same launch
@@ -192,10 +219,12 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
                          pick_splits(batch, ceil_div(OF, 64) * ceil_div(W, 128)).splits > 1;
     fold.per_w = (int)std::min<int64_t>(256, std::max<int64_t>(8, 2048 / (nh + 1)));
     int off = 0;
+    const blh_context::SavedFormat* sf = ctx->find_saved(ws.Z[0]);
+    const bool enc0 = sf && sf->mode == 3 && sf->batch == batch;      // (stage 0: enc_wgrad_finish writes dW0)
     for (int i = 0; i <= nh; ++i) {
       fold.w_off.push_back(off);
       const int64_t cnt = i == nh ? (int64_t)OF * W : (int64_t)W * L.heavy[i].fan_in;
-      off += sum_slabs_sq_blocks(cnt, fold.per_w);
+      off += (i == 0 && enc0) ? enc_bwd_finish_blocks(W) : sum_slabs_sq_blocks(cnt, fold.per_w);
     }
     fold.gb0 = off;
     fold.bias0 = fold.gb0 + nh * bn_bwd_finalize_blocks(W);
@@ -262,7 +291,11 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
   // decode: dA_last = dP W_d on the main stream first (it carries the fork event: the decode
   // weight gradient then starts when it completes, next to the first BatchNorm-backward kernels),
   // dW = dP^T A_last on the side stream, db = colsum(dP)
-  {
+  // (one-pass decode: the forward that produced this dpred already left dA in G0 — the side stream forks at once,
+  //  behind the forward's last kernel, and the main stream goes straight to the first BatchNorm backward)
+  const bool have_da = fused && dpred == ws.dpred && ctx->dec_da_ws == ws.Z[0] && ctx->dec_da_batch == batch;
+  ctx->dec_da_ws = nullptr;
+  if (!have_da) {
     GemmParams g{};
     g.A = dpred; g.lda = OF;
     g.B = params + L.dec_w; g.ldb = W;
@@ -274,7 +307,12 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
                         d->gemm_dtype));
     tl_stop_event = nullptr;
   }
-  BLH_TRY(fork_wait(nh));
+  if (have_da && two) {
+    BLH_HIP_TRY(hipEventRecord(g_side.ev_dz[nh], s));
+    BLH_HIP_TRY(hipStreamWaitEvent(s2, g_side.ev_dz[nh], 0));
+  } else {
+    BLH_TRY(fork_wait(nh));
+  }
   BLH_TRY(wgrad(d->gemm_dtype, s2, TILE_64x128, dpred, OF, OF, ws.A[nh - 1], W, W, batch,
                 ceil_div(OF, 64) * ceil_div(W, 128), defer ? ws.stage_slabs[nh] : ws.slabs,
                 grads + L.dec_w, defer ? &wreg[nh] : nullptr, nullptr, nullptr, 0, fold_w(nh), fold.per_w));
@@ -295,8 +333,29 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
   const bool k9 = ctx->knob(KNOB_K9_F32) && d->gemm_dtype == 0 &&
                   small_m_splits(batch, W, W, d->gemm_dtype).splits == 1;
   int pregated_tiles = 0;     // > 0: this stage's dA is dY' and ws.stat_part holds that many rows of partials
+  const blh_context::SavedFormat* saved_fmt = ctx->find_saved(ws.Z[0]);
+  const bool enc_fused = saved_fmt && saved_fmt->mode == 3 && saved_fmt->batch == batch;
   for (int i = nh - 1; i >= 0; --i) {
     const HeavyOffsets& h = L.heavy[i];
+    if (i == 0 && enc_fused) {
+      // Encode stage without Z0 (encode_f32.hip): one pass over dA0 leaves sum dY' and dY'^T X per row block, the
+      // finish kernel forms dgamma, dbeta, dW0 and db0 from them and the forward's sums of x.  Main stream; under
+      // the bucket hook the side stream is made to wait for it (the range has to be complete there).
+      BLH_TRY(launch_enc_backward(s, ws.G0, x, params + h.w, params + h.b, ws.bn_saved[0], ws.keep[0], ws.Z[0], batch, W,
+                                  grads + h.w, grads + h.gamma, grads + h.beta,
+                                  on_ready ? grads + h.b : ws.dz_colsum_part, on_ready ? 1 : chunks, fold_w(0),
+                                  fold.on ? ws.sumsq_fold + fold.gb0 : nullptr));
+      wreg[0].slabs = nullptr; wreg[0].splits = 0;
+      if (on_ready) {
+        if (ctx->two_stream) {
+          BLH_HIP_TRY(hipEventRecord(g_side.ev_r[0], s));
+          BLH_HIP_TRY(hipStreamWaitEvent(g_side.s2, g_side.ev_r[0], 0));
+        }
+        if (two) BLH_TRY(wdone(0));
+        on_ready(user, h.w, ((1 < nh) ? L.heavy[1].w : L.dec_w) - h.w);
+      }
+      continue;
+    }
     // gradient w.r.t. this stage's output: block boundaries live in G0, the middle of a
     // block in G1 (stage i odd = first of a block: its output feeds only stage i+1)
     const bool first_of_block = (i >= 1) && (i % 2 == 1);

@@ -163,6 +163,56 @@ int blh_side_stream_renew(void) {
 
 int32_t blh_side_stream_generation(void) { return g_side_generation.load(); }
 
+// How often a device's side stream may be replaced by the tuner in one process: a caller that alternates two
+// compute streams (the default stream for the fused step, DataParallel.stream for the data-parallel one) could
+// otherwise make each tuning undo the other's choice for ever.
+static constexpr int kMaxTunerReplacements = 4;
+static int g_tuner_replacements[kMaxDevices] = {};
+
+// The probe proper.  Every failure inside it (no memory for the probe buffers beside a full caching allocator, a
+// stream that cannot be created, ...) leaves the pair as it was: tuning is an optimisation and never fails a step.
+static void tune_locked(hipStream_t main, int dev, int max_candidates, float* report) {
+  hipStream_t cand[8] = {};
+  int tried = 0;
+  hipStream_t best_stream = nullptr;                // nullptr: keep the current one
+  float alone = 0.f, cur = 0.f, best = 0.f;
+  bool ok = false;
+  {
+    Probe pr;
+    do {
+      if (pr.init() != BLH_OK) break;
+      if (pr.measure(main, nullptr, &alone) != BLH_OK) break;
+      if (pr.measure(main, g_side_stream[dev], &cur) != BLH_OK) break;
+      best = cur;
+      ok = true;
+      // (a pair is good when the short kernels take at most kGood x their solo time beside the busy side
+      //  stream — 1.58-1.76x measured for good pairs, 3.8-3.9x for bad ones; candidates are created only
+      //  when the current pair is bad, and the search stops at the first good one)
+      constexpr float kGood = 2.5f;
+      if (cur <= kGood * alone || g_tuner_replacements[dev] >= kMaxTunerReplacements) break;
+      while (tried < max_candidates) {
+        if (side_stream_create(&cand[tried]) != hipSuccess) break;
+        float v = 0.f;
+        const int rc = pr.measure(main, cand[tried], &v);
+        ++tried;
+        if (rc != BLH_OK) break;
+        if (v < best) { best = v; best_stream = cand[tried - 1]; }
+        if (v <= kGood * alone) break;
+      }
+    } while (false);
+  }
+  (void)hipGetLastError();                          // (a failed probe must not poison the caller's next check)
+  for (int i = 0; i < 8; ++i)
+    if (cand[i] && cand[i] != best_stream) (void)hipStreamDestroy(cand[i]);
+  if (best_stream) {
+    if (side_stream_replace(dev, best_stream) == hipSuccess) ++g_tuner_replacements[dev];
+  }
+  if (report) {
+    report[0] = ok ? alone : 0.f; report[1] = ok ? cur : 0.f; report[2] = ok ? best : 0.f;
+    report[3] = ok ? (float)tried : -1.f;
+  }
+}
+
 int blh_tune_streams(void* stream, int32_t max_candidates, float* report) {
   hipStream_t main = (hipStream_t)stream;
   int dev = -1;
@@ -173,35 +223,7 @@ int blh_tune_streams(void* stream, int32_t max_candidates, float* report) {
   if (cap != hipStreamCaptureStatusNone) return BLH_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> lk(g_side_mu);
   if (g_side_refs[dev] == 0) return BLH_ERR_INVALID_ARGUMENT;     // no context on this device yet
-  Probe pr;
-  BLH_TRY(pr.init());
-  float alone = 0.f, cur = 0.f;
-  BLH_TRY(pr.measure(main, nullptr, &alone));
-  BLH_TRY(pr.measure(main, g_side_stream[dev], &cur));
-  float best = cur;
-  hipStream_t best_stream = nullptr;                // nullptr: keep the current one
-  int tried = 0;
-  // (a pair is good when the short kernels take at most kGood x their solo time beside the busy side
-  //  stream — 1.58-1.76x measured for good pairs, 3.8-3.9x for bad ones; candidates are created only
-  //  when the current pair is bad, and the search stops at the first good one)
-  constexpr float kGood = 2.5f;
-  hipStream_t cand[8] = {};
-  if (cur > kGood * alone) {
-    while (tried < max_candidates) {
-      if (side_stream_create(&cand[tried]) != hipSuccess) break;
-      float v = 0.f;
-      BLH_TRY(pr.measure(main, cand[tried], &v));
-      ++tried;
-      if (v < best) { best = v; best_stream = cand[tried - 1]; }
-      if (v <= kGood * alone) break;
-    }
-  }
-  for (int i = 0; i < tried; ++i)
-    if (cand[i] && cand[i] != best_stream) (void)hipStreamDestroy(cand[i]);
-  if (best_stream) BLH_HIP_TRY(side_stream_replace(dev, best_stream));
-  if (report) {
-    report[0] = alone; report[1] = cur; report[2] = best; report[3] = (float)tried;
-  }
+  tune_locked(main, dev, max_candidates, report);
   return BLH_OK;
 }
 

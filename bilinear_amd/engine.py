@@ -258,6 +258,23 @@ class Engine:
         N.check(lib.blh_tune_streams(ctypes.c_void_p(st.cuda_stream), 3, rep), "blh_tune_streams")
         self.stream_tune_report = tuple(rep)
         Engine._tuned[key] = lib.blh_side_stream_generation()
+        alone, _, kept, tried = self.stream_tune_report
+        if tried >= 0 and alone > 0 and kept > 2.5 * alone and not Engine._tune_warned:
+            import warnings
+            Engine._tune_warned = True
+            warnings.warn("bilinear_amd: the compute stream and the library's side stream do not run beside each other "
+                          "(probe %.2fx its solo time after %d replacement candidates; a good pair is ~1.7x): the "
+                          "two-stream backward will be up to 2x slower.  Engine.set_two_stream(False), or create the "
+                          "model after the process group / on another stream and call Engine.retune_streams()."
+                          % (kept / alone, int(tried)), RuntimeWarning, stacklevel=3)
+
+    _tune_warned = False
+
+    @staticmethod
+    def retune_streams():
+        """Forget which compute streams were probed (the cache is keyed by the raw stream handle, which a destroyed
+        and re-created stream can reuse): the next two-stream call of every engine probes again."""
+        Engine._tuned.clear()
 
     def _momentum(self):
         m = self.module.encode[1].momentum
@@ -366,24 +383,25 @@ class Engine:
     def forward_train_autograd(self, x):
         """Train-mode forward as the DIFFERENTIABLE custom operator ``torch.ops.bilinear_hip.lifter_train``
         (torch.library.register_autograd, bilinear_amd/ops.py): ``loss.backward()`` of
-        /root/reference/train_bilinear.py:79 reaches blh_backward through the operator's registered backward,
-        and each Parameter's ``.grad`` becomes a view of its slot in the gradient arena."""
+        /root/reference/train_bilinear.py:79 reaches blh_backward through the operator's registered formula.  The
+        operator is functional — it returns the activations it saved and the updated BatchNorm statistics instead
+        of writing them behind the schema's back — so the two copy_ calls below ARE the buffer updates, visible to a
+        tracing compiler; each Parameter's ``.grad`` becomes a view of the one gradient tensor the formula returns
+        (arena layout: Adam.step / clip_grad_norm_ move it into the arena)."""
         x = self._check_input(x)
         self.ensure(x.device)
         batch = x.shape[0]
         if batch < 2:
             raise ValueError("Expected more than 1 value per channel when training, got input size %s"
                              % (tuple(x.shape),))
-        ws = self.workspace(batch)
-        drop = self._drop_struct(batch)
         named = self._named_params()
         _ops.ENGINES[int(self.ctx.handle.value)] = self
-        pred = torch.ops.bilinear_hip.lifter_train(
-            x, [p for _, p, _, _ in named], self.params, self.bn_running, self.bn_nbt, ws, self.grads, self.masks,
+        pred, _saved, new_running, new_nbt = torch.ops.bilinear_hip.lifter_train(
+            x, [p for _, p, _, _ in named], self.params, self.bn_running, self.bn_nbt, self.masks,
             *self._op_args(), self.seed, self.rng_step, self.row_offset, self._momentum(),
-            [int(off) for _, _, off, _ in named])
-        self._saved_batch = batch
-        self._saved_drop = drop
+            [int(off) for _, _, off, _ in named], self.layout.workspace_bytes(batch))
+        self.bn_running.copy_(new_running)
+        self.bn_nbt.copy_(new_nbt)
         self.generation += 1
         if self.masks is None:
             self.rng_step += 1

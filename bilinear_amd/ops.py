@@ -8,6 +8,7 @@ the C ABI directly, since a callback has no operator-schema type.
 
     pred = torch.ops.bilinear_hip.eval_fwd(x, params, bn_running, workspace, ctx, nb, W, dtype)
     pred = torch.ops.bilinear_hip.forward_train(x, params, bn_running, bn_nbt, workspace, masks, ...)
+    pred, saved, running, nbt = torch.ops.bilinear_hip.lifter_train(x, param_views, params, ...)   # differentiable
     torch.ops.bilinear_hip.backward(x, dpred, params, workspace, grads, masks, ...)
     pred, loss = torch.ops.bilinear_hip.train_step(x, target, params, grads, exp_avg, ...)
 
@@ -36,18 +37,24 @@ _LIB.define(
     "forward_train(Tensor x, Tensor params, Tensor(a!) bn_running, Tensor(b!) bn_nbt, "
     "Tensor(c!) workspace, Tensor? masks, int ctx, int num_blocks, int width, int gemm_dtype, "
     "int seed, int step, int row_offset, float momentum) -> Tensor")
-# The differentiable form of forward_train (torch.library.register_autograd below): ``param_views`` are the
-# module's nn.Parameters — views of ``params`` (the arena) at ``offsets`` — and exist in the schema only so that
-# autograd connects them to the output; the kernels read the arena.  Its backward is the ``backward`` operator.
-# torch.library registers autograd formulas for FUNCTIONAL schemas only, so the buffers the native call writes as
-# a side effect (BatchNorm running statistics and counter, the workspace with the saved activations, and — in
-# backward — the gradient arena) are declared as plain inputs here: nothing else in a traced graph reads them, the
-# returned prediction is a fresh tensor, and the mutable twin ``forward_train`` stays for callers that want the
-# aliasing spelled out.
+# The differentiable form of forward_train (torch.library.register_autograd below).  torch.library registers autograd
+# formulas for FUNCTIONAL schemas only, and a functional schema is a promise the compiler stack acts on (dead-code
+# elimination, re-ordering, static-input copies under CUDA-graph modes), so this operator really is functional
+# (round 5; round 4 declared the buffers the native call writes as plain inputs): it mutates NONE of its inputs.
+# The native forward runs on a clone of the BatchNorm running statistics / counter and on a workspace the operator
+# allocates, and all three are RETURNED — (pred, saved, new_running, new_nbt); the caller copies the statistics
+# back into the module's buffers with ordinary copy_ calls (Engine.forward_train_autograd), which a traced graph
+# sees as what they are.  ``param_views`` are the module's nn.Parameters — views of ``params`` (the arena) at
+# ``offsets`` — and exist in the schema only so that autograd connects them to the output; the kernels read the
+# arena.  The formula calls ``lifter_backward``: gradients come back as ONE fresh tensor in the arena's layout
+# (the .grad of each Parameter is a view of it); it uses the saved workspace as scratch and says so (Tensor(a!)).
 _LIB.define(
     "lifter_train(Tensor x, Tensor[] param_views, Tensor params, Tensor bn_running, Tensor bn_nbt, "
-    "Tensor workspace, Tensor grads, Tensor? masks, int ctx, int num_blocks, int width, int gemm_dtype, "
-    "int seed, int step, int row_offset, float momentum, int[] offsets) -> Tensor")
+    "Tensor? masks, int ctx, int num_blocks, int width, int gemm_dtype, int seed, int step, int row_offset, "
+    "float momentum, int[] offsets, int workspace_bytes) -> (Tensor, Tensor, Tensor, Tensor)")
+_LIB.define(
+    "lifter_backward(Tensor x, Tensor dpred, Tensor params, Tensor(a!) saved, Tensor? masks, int ctx, "
+    "int num_blocks, int width, int gemm_dtype, int seed, int step, int row_offset) -> Tensor")
 _LIB.define(
     "backward(Tensor x, Tensor dpred, Tensor params, Tensor(a!) workspace, Tensor(b!) grads, "
     "Tensor? masks, int ctx, int num_blocks, int width, int gemm_dtype, int seed, int step, "
@@ -97,10 +104,20 @@ def _forward_train(x, params, bn_running, bn_nbt, workspace, masks, ctx, num_blo
     return pred
 
 
-def _lifter_train(x, param_views, params, bn_running, bn_nbt, workspace, grads, masks, ctx, num_blocks, width,
-                  gemm_dtype, seed, step, row_offset, momentum, offsets):
-    return _forward_train(x, params, bn_running, bn_nbt, workspace, masks, ctx, num_blocks, width, gemm_dtype,
+def _lifter_train(x, param_views, params, bn_running, bn_nbt, masks, ctx, num_blocks, width, gemm_dtype, seed, step,
+                  row_offset, momentum, offsets, workspace_bytes):
+    new_running, new_nbt = bn_running.clone(), bn_nbt.clone()
+    saved = torch.empty(int(workspace_bytes), dtype=torch.uint8, device=x.device)
+    pred = _forward_train(x, params, new_running, new_nbt, saved, masks, ctx, num_blocks, width, gemm_dtype,
                           seed, step, row_offset, momentum)
+    return pred, saved, new_running, new_nbt
+
+
+def _lifter_backward(x, dpred, params, saved, masks, ctx, num_blocks, width, gemm_dtype, seed, step, row_offset):
+    grads = torch.empty_like(params)
+    _backward(x, dpred.contiguous(), params, saved, grads, masks, ctx, num_blocks, width, gemm_dtype, seed, step,
+              row_offset)
+    return grads
 
 
 def _backward(x, dpred, params, workspace, grads, masks, ctx, num_blocks, width, gemm_dtype, seed,
@@ -135,6 +152,7 @@ def _train_step(x, target, params, grads, exp_avg, exp_avg_sq, bn_running, bn_nb
 _LIB.impl("eval_fwd", _eval_fwd, "CUDA")
 _LIB.impl("forward_train", _forward_train, "CUDA")
 _LIB.impl("lifter_train", _lifter_train, "CUDA")
+_LIB.impl("lifter_backward", _lifter_backward, "CUDA")
 _LIB.impl("backward", _backward, "CUDA")
 _LIB.impl("train_step", _train_step, "CUDA")
 
@@ -150,46 +168,47 @@ def _fake_step(x, *args, **kwargs):
 # shape functions (FakeTensor / torch.compile tracing; no arithmetic)
 torch.library.register_fake("bilinear_hip::eval_fwd", _fake_pred, lib=_LIB)
 torch.library.register_fake("bilinear_hip::forward_train", _fake_pred, lib=_LIB)
-torch.library.register_fake("bilinear_hip::lifter_train", _fake_pred, lib=_LIB)
+
+
+def _fake_lifter(x, param_views, params, bn_running, bn_nbt, masks, ctx, num_blocks, width, gemm_dtype, seed, step,
+                 row_offset, momentum, offsets, workspace_bytes):
+    return (x.new_empty((x.shape[0], OUT_FEATURES)), x.new_empty((workspace_bytes,), dtype=torch.uint8),
+            torch.empty_like(bn_running), torch.empty_like(bn_nbt))
+
+
+torch.library.register_fake("bilinear_hip::lifter_train", _fake_lifter, lib=_LIB)
+torch.library.register_fake("bilinear_hip::lifter_backward", lambda x, dpred, params, *a, **k: torch.empty_like(params),
+                            lib=_LIB)
 torch.library.register_fake("bilinear_hip::backward", lambda *a, **k: None, lib=_LIB)
 torch.library.register_fake("bilinear_hip::train_step", _fake_step, lib=_LIB)
 
 
 
 # ---- autograd of lifter_train: loss.backward() of /root/reference/train_bilinear.py:79 -----------------------
-# engines by context handle (eager mode: the engine's own bookkeeping — the saved-activation guard, the tuned
-# stream pair — stays in charge; under torch.compile the traced backward calls the raw operator)
 import weakref  # noqa: E402
 
-ENGINES = weakref.WeakValueDictionary()
+ENGINES = weakref.WeakValueDictionary()      # engines by context handle (Engine.forward_train_autograd registers)
 
 
 def _lifter_setup(ctx, inputs, output):
-    (x, param_views, params, bn_running, bn_nbt, workspace, grads, masks, c, nb, w, dt, seed, step, row_offset,
-     momentum, offsets) = inputs
-    ctx.save_for_backward(x, params, workspace, grads, masks)
+    (x, param_views, params, bn_running, bn_nbt, masks, c, nb, w, dt, seed, step, row_offset, momentum, offsets,
+     workspace_bytes) = inputs
+    saved = output[1]
+    ctx.save_for_backward(x, params, saved, masks)
     ctx.ints = (c, nb, w, dt, seed, step, row_offset)
-    ctx.slots = [(int(o), tuple(p.shape), p.numel()) for o, p in zip(offsets, param_views)]
-    eng = ENGINES.get(int(c))
-    # (eager: the forward wrapper bumps engine.generation right after this call returns)
-    ctx.generation = None if eng is None else eng.generation + 1
+    ctx.slots = [(int(o), tuple(p.shape)) for o, p in zip(offsets, param_views)]
 
 
-def _lifter_backward(ctx, dpred):
-    x, params, workspace, grads, masks = ctx.saved_tensors
-    c = ctx.ints[0]
-    eng = ENGINES.get(int(c))
-    if eng is not None and type(dpred) is torch.Tensor:          # eager
-        eng.backward(x, dpred, on_ready=None, generation=ctx.generation)
-    else:                                                        # traced (AOTAutograd): the operator itself
-        torch.ops.bilinear_hip.backward(x, dpred.contiguous(), params, workspace, grads, masks, *ctx.ints)
-    views = [grads.as_strided(shape, (shape[1], 1) if len(shape) == 2 else (1,), o) for o, shape, n in ctx.slots]
-    return (None, views) + (None,) * 15
+def _lifter_formula(ctx, dpred, dsaved, drunning, dnbt):
+    x, params, saved, masks = ctx.saved_tensors
+    grads = torch.ops.bilinear_hip.lifter_backward(x, dpred, params, saved, masks, *ctx.ints)
+    views = [grads.as_strided(shape, (shape[1], 1) if len(shape) == 2 else (1,), o) for o, shape in ctx.slots]
+    return (None, views) + (None,) * 14
 
 
-torch.library.register_autograd("bilinear_hip::lifter_train", _lifter_backward, setup_context=_lifter_setup, lib=_LIB)
+torch.library.register_autograd("bilinear_hip::lifter_train", _lifter_formula, setup_context=_lifter_setup, lib=_LIB)
 
-OPS = ("eval_fwd", "forward_train", "lifter_train", "backward", "train_step")
+OPS = ("eval_fwd", "forward_train", "lifter_train", "lifter_backward", "backward", "train_step")
 
 # the same entry points without the operator dispatch (~20 us of host time per call): what the engine calls in eager
 # mode once IT has checked that every tensor is on the HIP device (a host pointer handed to the library would fault)

@@ -164,7 +164,11 @@ int32_t blh_side_stream_generation(void);
  * side streams, stopping at the first good one; the best becomes the device's side stream, the
  * others are destroyed.  Synchronises, allocates 32 MB for the duration of the call: call it once
  * per compute stream at set-up, never under stream capture.  report (optional, 4 floats): ms of the
- * short kernels alone, beside the side stream found, beside the one kept, number of candidates tried. */
+ * short kernels alone, beside the side stream found, beside the one kept, number of candidates tried.
+ * Tuning never fails a step: when the probe itself cannot run (no memory for its buffers, a stream that
+ * cannot be created) the pair stays as it was, the call returns BLH_OK and report[3] is -1; a device's side
+ * stream is replaced at most 4 times per process (two compute streams must not undo each other's choice
+ * for ever).  The caller judges the result: report[2] > 2.5 * report[0] means the pair kept is still bad. */
 int blh_tune_streams(void* stream, int32_t max_candidates, float* report);
 
 /* ------------------------------------------------------------------------
@@ -538,6 +542,13 @@ int blh_skinny_decode_fwd_mse(void* stream, const float* A, const float* Wd, con
                               const float* target, float* pred, float* dpred, float* loss_out,
                               void* workspace, int64_t workspace_bytes, int64_t batch, int32_t width,
                               int32_t out_features);
+/* One-pass decode (r05): blh_skinny_decode_fwd_mse AND the data gradient dA[B,W] = dpred Wd from one read of A
+ * (/root/reference/model/bilinear.py:29,39; train_bilinear.py:78-79: the loss is row-local).  What the fused
+ * training step launches at out_features == 48, width 512 / 1024, batch <= 16384; BLH_ERR_SHAPE otherwise.      */
+int blh_skinny_decode_fused(void* stream, const float* A, const float* Wd, const float* bd,
+                            const float* target, float* pred, float* dpred, float* dA, float* loss_out,
+                            void* workspace, int64_t workspace_bytes, int64_t batch, int32_t width,
+                            int32_t out_features);
 int blh_skinny_decode_bwd(void* stream, const float* dpred, const float* A, const float* Wd,
                           float* dWd, float* dA, void* workspace, int64_t workspace_bytes,
                           int64_t batch, int32_t width, int32_t out_features);

@@ -1,5 +1,5 @@
 """Worker of tests/test_gpu_dp.py::test_set_up_order_does_not_change_the_step_time (one process per
-set-up order): prints ``RESULT <order> <fused ms> <dp ms>`` for a world-1 RCCL group with every
+set-up order): prints ``RESULT <order> <fused ms> <dp ms> <probe alone ms> <probe beside the kept side stream ms>`` for a world-1 RCCL group with every
 collective issued.  Orders: group_first | model_first | tensors_first (see the test)."""
 import os
 import sys
@@ -67,7 +67,8 @@ def main():
     dp.stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(dp.stream):
         dpt = timeit(lambda: dp.train_step(x, t))
-    print("RESULT %s %.4f %.4f" % (order, fused, dpt), flush=True)
+    rep = getattr(net.engine, "stream_tune_report", None) or (0.0, 0.0, 0.0, -1.0)
+    print("RESULT %s %.4f %.4f %.4f %.4f" % (order, fused, dpt, rep[0], rep[2]), flush=True)
     dist.destroy_process_group()
 
 

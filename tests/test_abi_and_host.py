@@ -183,11 +183,19 @@ def test_custom_ops_trace_through_their_fake_implementations():
         # the differentiable operator: the parameter views carry requires_grad, and a traced backward (what
         # AOTAutograd records) reaches the gradient arena through the registered formula
         views = [params[:W * 32].view(W, 32).detach().requires_grad_(), params[W * 32:W * 33].detach().requires_grad_()]
-        pred = torch.ops.bilinear_hip.lifter_train(x, views, params, running, nbt, ws, grads, None, 0, 2, W, 0, 1, 0, 0,
-                                                   0.1, [0, W * 32])
+        pred, saved, new_running, new_nbt = torch.ops.bilinear_hip.lifter_train(
+            x, views, params, running, nbt, None, 0, 2, W, 0, 1, 0, 0, 0.1, [0, W * 32], 1 << 20)
         assert tuple(pred.shape) == (B, 48) and pred.requires_grad
+        # functional: what the native call writes comes back as outputs, no input is mutated
+        assert saved.dtype == torch.uint8 and saved.numel() == 1 << 20
+        assert new_running.shape == running.shape and new_nbt.dtype == torch.int64
         gv = torch.autograd.grad(pred.sum(), views)
         assert [tuple(g.shape) for g in gv] == [(W, 32), (W,)]
+        g = torch.ops.bilinear_hip.lifter_backward(x, pred.detach(), params, saved, None, 0, 2, W, 0, 1, 0, 0)
+        assert g.shape == params.shape
+        schema = str(torch.ops.bilinear_hip.lifter_train.default._schema)
+        assert "!" not in schema, schema                     # no mutable annotation: and none is needed
+        assert "(a!) saved" in str(torch.ops.bilinear_hip.lifter_backward.default._schema)
         pred, loss = torch.ops.bilinear_hip.train_step(x, t, params, grads, m, v, running, nbt, ws, stats, None,
                                                        0, 2, W, 0, 1, 0, 0, 0.1, 1e-3, 0.9, 0.999, 1e-8, 1.0, 1)
         assert tuple(pred.shape) == (B, 48) and tuple(loss.shape) == ()

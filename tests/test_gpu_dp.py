@@ -489,8 +489,10 @@ def test_set_up_order_does_not_change_the_step_time():
     the RCCL process group; round 4 found the cause (the compute stream and the library's side stream
     landing on hardware queues that do not run beside each other: profiles/r04_dp_setup_order.md) and the
     repair (the engine measures the pair once per compute stream and replaces the side stream of a bad
-    pair: blh_tune_streams).  Three set-up orders, one process each: the fused step and the data-parallel
-    step (world-1 RCCL, every collective issued) must take the same time in all of them."""
+    pair: blh_tune_streams).  Three set-up orders, one process each.  What is asserted is the mechanism — in every
+    order the probe of the pair the engine kept is a good one (at most 2.5x its solo time; a bad pair is 3.8x) —
+    and that no order is 1.3x slower than the fastest (a bad pair is 2x; the timings of three separate processes
+    on a shared box differ by a few per cent on their own: profiles/r04_dp_setup_order.md has the figures)."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -500,9 +502,10 @@ def test_set_up_order_does_not_change_the_step_time():
                              capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1].split()
-        res[order] = (float(line[2]), float(line[3]))
+        res[order] = tuple(float(v) for v in line[2:6])
+        alone, kept = res[order][2], res[order][3]
+        assert alone > 0 and kept <= 2.5 * alone, (order, res[order])
     fused = [v[0] for v in res.values()]
     dpt = [v[1] for v in res.values()]
-    # (same box, minutes apart: the spread of the good pairs is ~1 %; a bad pair is 2x)
-    assert max(fused) <= 1.05 * min(fused), res
-    assert max(dpt) <= 1.05 * min(dpt), res
+    assert max(fused) <= 1.3 * min(fused), res
+    assert max(dpt) <= 1.3 * min(dpt), res

@@ -1011,10 +1011,11 @@ def test_train_step_operator_under_torch_compile_fullgraph():
 def test_drop_in_step_through_the_differentiable_operator(monkeypatch):
     """The five-call step of /root/reference/train_bilinear.py:75-83 (zero_grad, forward, MSELoss, backward,
     clip_grad_norm_, Adam.step) with ``loss.backward()`` going through ``torch.ops.bilinear_hip.lifter_train``'s
-    registered autograd formula (torch.library.register_autograd): bit-identical to the autograd.Function bridge
-    it replaces, .grad tensors are views of the gradient arena, a second forward before backward still raises;
-    and the same forward + loss compiled with torch.compile(fullgraph=True) (AOTAutograd traces the formula
-    down to the ``backward`` operator) gives the same gradients."""
+    registered autograd formula (torch.library.register_autograd): bit-identical to the autograd.Function bridge;
+    the operator is FUNCTIONAL (round 5: it returns the saved activations and the updated BatchNorm statistics, the
+    module's buffers advance through ordinary copy_ calls) — so two forwards may be outstanding at once, each
+    backward reading its own saved activations; the same forward + loss under torch.compile(fullgraph=True)
+    (AOTAutograd traces the formula down to ``lifter_backward``) gives the same gradients."""
     import bilinear_amd
     from bilinear_amd.model.bilinear import _LifterFunction
     dev = _dev()
@@ -1030,8 +1031,8 @@ def test_drop_in_step_through_the_differentiable_operator(monkeypatch):
         return net, opt
 
     import bilinear_amd.model.bilinear as MB
-    assert MB.EAGER_AUTOGRAD == "function"         # eager default: the lean bridge (the operator costs 70 us more per
-    monkeypatch.setattr(MB, "EAGER_AUTOGRAD", "op")   # step on the host); this test drives the operator in eager mode
+    assert MB.EAGER_AUTOGRAD == "function"         # eager default: the lean bridge (the operator costs host time);
+    monkeypatch.setattr(MB, "EAGER_AUTOGRAD", "op")   # this test drives the operator in eager mode
     request_default = lambda: monkeypatch.setattr(MB, "EAGER_AUTOGRAD", "function")
     outs = {}
     for path in ("operator", "function"):
@@ -1046,49 +1047,102 @@ def test_drop_in_step_through_the_differentiable_operator(monkeypatch):
                 pred = _LifterFunction.apply(x, eng, *[p for _, p, _, _ in eng._named_params()])
             loss = torch.nn.functional.mse_loss(pred, t)
             loss.backward()
-            for _, p, off, shape in eng._named_params():
-                assert p.grad is not None and p.grad.data_ptr() == eng.grad_view(off, shape).data_ptr()
+            grads = torch.cat([p.grad.reshape(-1) for _, p, _, _ in eng._named_params()])
             bilinear_amd.clip_grad_norm_(net.parameters(), 1.0, module=net)
             opt.step()
         torch.cuda.synchronize()
-        outs[path] = (pred.detach().clone(), eng.grads.clone(), eng.params.clone())
+        outs[path] = (pred.detach().clone(), grads.clone(), eng.params.clone(), eng.bn_running.clone(), eng.bn_nbt.clone())
     for a, b in zip(outs["operator"], outs["function"]):
         assert torch.equal(a, b)
-    # the saved-activation guard survives the move
+    assert int(outs["operator"][4][0]) == 2
+    # two outstanding forwards: each backward reads the activations ITS forward returned
     net, opt = make()
     p1 = net(x)
-    net(x)
-    with pytest.raises(RuntimeError, match="overwritten"):
-        p1.sum().backward()
+    p2 = net(x)                                    # (another dropout step: other masks)
+    g1 = torch.autograd.grad(p1.sum(), [p for _, p, _, _ in net.engine._named_params()])
+    net_b, _ = make()
+    q1 = net_b(x)
+    h1 = torch.autograd.grad(q1.sum(), [p for _, p, _, _ in net_b.engine._named_params()])
+    assert all(torch.equal(a, b) for a, b in zip(g1, h1))
+    del p2
     # torch.compile(fullgraph=True): forward + loss traced through the operator, backward through its formula
     net, opt = make()
     eng = net.engine
     named = eng._named_params()
     views = [p for _, p, _, _ in named]
     offs = [int(off) for _, _, off, _ in named]
-    ws = eng.workspace(512)
     args = eng._op_args() + (eng.seed, 0, 0, 0.1)
+    wsb = eng.layout.workspace_bytes(512)
 
-    def fwd_loss(x, t, views, arena, running, nbt, ws, grads):
-        pred = torch.ops.bilinear_hip.lifter_train(x, views, arena, running, nbt, ws, grads, None, *args, offs)
-        return torch.nn.functional.mse_loss(pred, t)
+    def fwd_loss(x, t, views, arena, running, nbt):
+        pred, _, new_running, new_nbt = torch.ops.bilinear_hip.lifter_train(x, views, arena, running, nbt, None, *args,
+                                                                            offs, wsb)
+        return torch.nn.functional.mse_loss(pred, t), new_running, new_nbt
 
     compiled = torch.compile(fwd_loss, fullgraph=True, backend="aot_eager")
-    loss_c = compiled(x, t, views, eng.params, eng.bn_running, eng.bn_nbt, ws, eng.grads)
-    eng._saved_batch, eng._saved_drop = 512, eng._drop_struct(512)        # (what Engine.forward_train_autograd records)
-    eng.generation += 1
+    run0, nbt0 = eng.bn_running.clone(), eng.bn_nbt.clone()
+    loss_c, new_running, new_nbt = compiled(x, t, views, eng.params, eng.bn_running, eng.bn_nbt)
+    assert torch.equal(eng.bn_running, run0) and torch.equal(eng.bn_nbt, nbt0)      # inputs untouched
     loss_c.backward()
     torch.cuda.synchronize()
-    g_compiled = eng.grads.clone()
+    g_compiled = torch.cat([p.grad.reshape(-1) for p in views])
     net2, _ = make()
     opt2_pred = net2(x)
     torch.nn.functional.mse_loss(opt2_pred, t).backward()
     torch.cuda.synchronize()
-    assert torch.equal(g_compiled, net2.engine.grads)
+    g_eager = torch.cat([p.grad.reshape(-1) for _, p, _, _ in net2.engine._named_params()])
+    assert torch.equal(g_compiled, g_eager)
+    assert torch.equal(new_running, net2.engine.bn_running) and torch.equal(new_nbt, net2.engine.bn_nbt)
     assert abs(float(loss_c) - float(torch.nn.functional.mse_loss(opt2_pred, t))) == 0.0
     request_default()
     pred = net2(x)
     assert type(pred.grad_fn).__name__ == "_LifterFunctionBackward"
+
+
+def test_compiled_module_advances_batchnorm_statistics_under_cudagraph_mode(monkeypatch):
+    """with a functional schema that hid its writes, torch.compile was free to drop or re-order
+    the operator, and under CUDA-graph modes (mode="reduce-overhead": static-input copies) BatchNorm's running
+    statistics could stop advancing.  The module compiled with mode="reduce-overhead" (explicit dropout masks, so
+    that no integer argument changes between calls): running statistics and num_batches_tracked advance on every
+    call exactly as in eager mode, and the gradients equal the eager ones."""
+    import bilinear_amd
+    dev = _dev()
+    batch, width, nb = 512, 256, 1
+    x = torch.randn(batch, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    t = torch.randn(batch, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    g = torch.Generator(device=dev).manual_seed(9)
+    masks = [(torch.rand(batch, width, device=dev, generator=g) < 0.5).to(torch.uint8) for _ in range(1 + 2 * nb)]
+
+    def make():
+        torch.manual_seed(3)
+        net, opt, _, _ = bilinear_amd.load(dev, num_blocks=nb, width=width)
+        net.train()
+        net.engine.ensure(dev)
+        net.engine.set_dropout_masks(masks)
+        return net
+
+    def run(net, fn, steps):
+        out = []
+        for _ in range(steps):
+            for p in net.parameters():
+                p.grad = None
+            loss = torch.nn.functional.mse_loss(fn(x), t)
+            loss.backward()
+            torch.cuda.synchronize()
+            out.append((loss.detach().clone(), torch.cat([p.grad.reshape(-1) for _, p, _, _ in net.engine._named_params()]),
+                        net.engine.bn_running.clone(), net.engine.bn_nbt.clone()))
+        return out
+
+    eager_net = make()
+    eager = run(eager_net, eager_net, 3)
+    comp_net = make()
+    compiled = torch.compile(comp_net, mode="reduce-overhead")
+    comp = run(comp_net, compiled, 3)
+    for i, (e, c) in enumerate(zip(eager, comp)):
+        assert int(c[3][0]) == i + 1, ("num_batches_tracked", i, c[3])
+        for a, b, what in zip(e, c, ("loss", "gradients", "running statistics", "num_batches_tracked")):
+            assert torch.equal(a, b), (what, i)
+    assert not torch.equal(comp[0][2], comp[2][2])           # the statistics really moved
 
 
 def test_contexts_of_one_device_share_the_side_stream_and_outlive_each_other():

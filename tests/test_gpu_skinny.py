@@ -100,3 +100,43 @@ def test_decode_backward_and_encode_kernels(native, batch):
                                           batch, W, IF) == 0
     torch.cuda.synchronize()
     _close(dW0.cpu().numpy(), dZ.T.astype(np.float64) @ x.astype(np.float64), 3e-5, "dW0")
+
+
+@pytest.mark.parametrize("batch,width", [(4096, 1024), (4100, 1024), (16384, 1024), (37, 512), (2048, 512)])
+def test_decode_one_pass_forward_mse_and_data_gradient(native, batch, width):
+    """decode_fused_kernel (round 5): prediction, MSE, dpred, the loss AND the decode data gradient dA = dP Wd from
+    one read of the last activation — what the fused fp32 step launches (/root/reference/model/bilinear.py:29,39;
+    train_bilinear.py:78-79).  Against fp64 NumPy; ragged last row block (4100, 37); rows beyond the batch untouched."""
+    dev = _dev()
+    rng = np.random.RandomState(batch + width + 5)
+    OF = 48
+    A = rng.standard_normal((batch, width)).astype(np.float32)
+    A[:, 0] += 2.0
+    Wd = (rng.standard_normal((OF, width)) * 0.05).astype(np.float32)
+    bd = rng.standard_normal(OF).astype(np.float32)
+    t = rng.standard_normal((batch, OF)).astype(np.float32)
+    a, w, b, tt = (torch.from_numpy(v).to(dev) for v in (A, Wd, bd, t))
+    pred = torch.full((batch + 3, OF), float("nan"), device=dev)
+    dpred = torch.full((batch + 3, OF), float("nan"), device=dev)
+    dA = torch.full((batch + 3, width), float("nan"), device=dev)
+    loss = torch.zeros((), device=dev)
+    wsb = native.blh_skinny_workspace_bytes(batch, width, 32, OF)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = native.blh_skinny_decode_fused(st, a.data_ptr(), w.data_ptr(), b.data_ptr(), tt.data_ptr(), pred.data_ptr(),
+                                        dpred.data_ptr(), dA.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsb, batch,
+                                        width, OF)
+    assert rc == 0, native.blh_status_string(rc)
+    torch.cuda.synchronize()
+    ref = A.astype(np.float64) @ Wd.T.astype(np.float64) + bd
+    _close(pred[:batch].cpu().numpy(), ref, 2e-5, "pred")
+    d = ref - t
+    dp = 2 * d / d.size
+    _close(dpred[:batch].cpu().numpy(), dp, 1e-4, "dpred")
+    assert abs(loss.item() - (d ** 2).mean()) <= 1e-5 * (d ** 2).mean()
+    _close(dA[:batch].cpu().numpy(), dp @ Wd.astype(np.float64), 1e-4, "dA")
+    assert torch.isnan(pred[batch:]).all() and torch.isnan(dpred[batch:]).all() and torch.isnan(dA[batch:]).all()
+    # shapes the one-pass kernel does not serve are refused (the step then takes the two-kernel path)
+    assert native.blh_skinny_decode_fused(st, a.data_ptr(), w.data_ptr(), b.data_ptr(), tt.data_ptr(), pred.data_ptr(),
+                                          dpred.data_ptr(), dA.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsb, batch,
+                                          width, 32) != 0
