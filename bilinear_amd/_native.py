@@ -187,6 +187,7 @@ OPT_DEFER_SLABS = 1
 OPT_LATE_FORK = 2
 OPT_PERSISTENT_SHADOW = 3
 OPT_SMALL_STEP = 4
+OPT_BUCKET_FLOATS = 6     # blh_backward merges ready ranges into buckets of at least this many elements
 OPT_DEV_KNOBS = 5         # bit mask of developer A/B switches (csrc/step.h: blh::KNOB_*), latched from BLH_* at context creation
 
 

@@ -133,6 +133,10 @@ int blh_context_set_option(blh_context* c, int32_t option, int32_t value) {
       if (value < 0 || value > blh::KNOB_ALL) return BLH_ERR_INVALID_ARGUMENT;
       c->knobs = value;
       return BLH_OK;
+    case BLH_OPT_BUCKET_FLOATS:
+      if (value < 0) return BLH_ERR_INVALID_ARGUMENT;
+      c->bucket_floats = value;
+      return BLH_OK;
   }
   return BLH_ERR_INVALID_ARGUMENT;
 }
@@ -146,6 +150,7 @@ int blh_context_get_option(const blh_context* c, int32_t option) {
     case BLH_OPT_PERSISTENT_SHADOW: return c->persistent_shadow ? 1 : 0;
     case BLH_OPT_SMALL_STEP: return c->small_step;
     case BLH_OPT_DEV_KNOBS: return c->knobs;
+    case BLH_OPT_BUCKET_FLOATS: return c->bucket_floats;
   }
   return BLH_ERR_INVALID_ARGUMENT;
 }
@@ -426,10 +431,48 @@ int blh_mse_loss_grad(void* stream, const float* pred, const float* target, int6
                               loss_out);
 }
 
+// BLH_OPT_BUCKET_FLOATS: adjacent ready ranges (backward walks the arena downwards) are merged until a bucket holds at
+// least `want` elements; what is pending when backward returns is reported then.
+namespace {
+struct BucketMerger {
+  blh_grad_ready_fn fn; void* user; int64_t want; int64_t lo = 0, hi = 0; bool pending = false;
+  void flush() { if (pending) { fn(user, lo, hi - lo); pending = false; } }
+  static void thunk(void* self, int64_t off, int64_t cnt) {
+    BucketMerger* m = static_cast<BucketMerger*>(self);
+    const int64_t lo = off, hi = off + cnt;
+    if (!m->pending) { m->lo = lo; m->hi = hi; m->pending = true; }
+    else if (hi == m->lo) m->lo = lo;
+    else if (lo == m->hi) m->hi = hi;
+    else { m->flush(); m->lo = lo; m->hi = hi; m->pending = true; }
+    if (m->hi - m->lo >= m->want) m->flush();
+  }
+};
+}  // namespace
+
+static int backward_unmerged(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params, const float* x,
+                             const blh_dropout* drop, void* workspace, int64_t workspace_bytes,
+                             const float* dpred, float* grads, int64_t batch, blh_grad_ready_fn on_ready,
+                             void* user);
+
 int blh_backward(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params, const float* x,
                  const blh_dropout* drop, void* workspace, int64_t workspace_bytes,
                  const float* dpred, float* grads, int64_t batch, blh_grad_ready_fn on_ready,
                  void* user) {
+  if (ctx && on_ready && ctx->bucket_floats > 0) {
+    BucketMerger m{on_ready, user, ctx->bucket_floats};
+    const int rc = backward_unmerged(ctx, d, stream, params, x, drop, workspace, workspace_bytes, dpred, grads, batch,
+                                     &BucketMerger::thunk, &m);
+    if (rc == BLH_OK) m.flush();
+    return rc;
+  }
+  return backward_unmerged(ctx, d, stream, params, x, drop, workspace, workspace_bytes, dpred, grads, batch, on_ready,
+                           user);
+}
+
+static int backward_unmerged(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params, const float* x,
+                             const blh_dropout* drop, void* workspace, int64_t workspace_bytes,
+                             const float* dpred, float* grads, int64_t batch, blh_grad_ready_fn on_ready,
+                             void* user) {
   BLH_TRY(check_common(ctx, d, workspace, workspace_bytes, batch));
   BLH_TRY(check_drop(drop));
   if (!params || !x || !grads) return BLH_ERR_INVALID_ARGUMENT;

@@ -55,6 +55,8 @@ struct blh_context {
   bool defer_slabs = false;
   int late_fork = 2;        // BLH_OPT_LATE_FORK: 0 early, 1 late, 2 auto
   int32_t knobs = 0;        // BLH_OPT_DEV_KNOBS: blh::KNOB_* mask, latched from the environment at creation
+  int32_t bucket_floats = 0;   // BLH_OPT_BUCKET_FLOATS: > 0: blh_backward merges adjacent ready ranges into buckets of
+                               // at least this many elements before it calls the hook
   bool knob(int32_t k) const { return (knobs & k) != 0; }
   // per-call state (set by the entry point for the duration of the call)
   blh::SyncCtx sync = {nullptr, nullptr, 0};

@@ -255,6 +255,12 @@ class DataParallel:
             self._reducer = GradBucketReducer(eng.grads, self.group, self.bucket_floats,
                                               force_collectives=self.force_collectives,
                                               compress=self.compress)
+        # the library merges the ranges it reports into the reducer's buckets: the hook is entered once per bucket,
+        # not once per stage (blh_context_set_option(BLH_OPT_BUCKET_FLOATS))
+        from . import _native as N
+        if getattr(eng, "_bucket_floats_set", None) != self._reducer.bucket_floats:
+            eng.ctx.set_option(N.OPT_BUCKET_FLOATS, min(self._reducer.bucket_floats, (1 << 31) - 1))
+            eng._bucket_floats_set = self._reducer.bucket_floats
         batch = x.shape[0]
         eng.row_offset = self.rank * batch
         sync = self._all_reduce_sum if (self.sync_bn and (self.world > 1 or self.force_collectives)) else None

@@ -400,8 +400,8 @@ class Engine:
             x, [p for _, p, _, _ in named], self.params, self.bn_running, self.bn_nbt, self.masks,
             *self._op_args(), self.seed, self.rng_step, self.row_offset, self._momentum(),
             [int(off) for _, _, off, _ in named], self.layout.workspace_bytes(batch))
-        self.bn_running.copy_(new_running)
-        self.bn_nbt.copy_(new_nbt)
+        self.bn_running.copy_(new_running.detach())
+        self.bn_nbt.copy_(new_nbt.detach())
         self.generation += 1
         if self.masks is None:
             self.rng_step += 1

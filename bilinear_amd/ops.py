@@ -194,6 +194,9 @@ def _lifter_setup(ctx, inputs, output):
     (x, param_views, params, bn_running, bn_nbt, masks, c, nb, w, dt, seed, step, row_offset, momentum, offsets,
      workspace_bytes) = inputs
     saved = output[1]
+    # (only the prediction is differentiable: without this the statistics copied back into the module's buffers
+    #  would chain every step's graph to the previous one)
+    ctx.mark_non_differentiable(output[1], output[2], output[3])
     ctx.save_for_backward(x, params, saved, masks)
     ctx.ints = (c, nb, w, dt, seed, step, row_offset)
     ctx.slots = [(int(o), tuple(p.shape)) for o, p in zip(offsets, param_views)]

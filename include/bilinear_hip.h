@@ -117,6 +117,12 @@ typedef enum {
                              would give up after ~0.3 s each and the results would be wrong
                              (blh_context_grid_barrier_timeouts() counts that); where the device cannot hold the
                              grid at all the staged form is taken.                                          */
+  BLH_OPT_BUCKET_FLOATS = 6, /* default 0.  > 0: blh_backward / blh_backward_sync merge the contiguous gradient ranges
+                             they would report (one per stage, decode first) and call the hook once per BUCKET of at
+                             least this many elements, plus once for what is left at the end — the merging the
+                             data-parallel driver used to do in its Python callback, one return to the interpreter
+                             per stage.  A range is reported when its last part is ready, so
+                             a bucket is complete on the side stream exactly when its last range is.            */
   BLH_OPT_DEV_KNOBS = 5,  /* developer A/B switches as one bit mask (csrc/step.h: blh::KNOB_*; DESIGN.md lists
                              them).  The initial value is read from the BLH_* environment variables ONCE, in
                              blh_context_create; no entry point reads the environment afterwards.  Measurement

@@ -509,3 +509,40 @@ def test_set_up_order_does_not_change_the_step_time():
     dpt = [v[1] for v in res.values()]
     assert max(fused) <= 1.3 * min(fused), res
     assert max(dpt) <= 1.3 * min(dpt), res
+
+
+def test_library_merges_ready_ranges_into_buckets():
+    """BLH_OPT_BUCKET_FLOATS (round 5): blh_backward merges the per-stage ranges it reports into buckets of at least
+    the requested size, so the data-parallel hook returns to Python once per bucket instead of once per stage: the
+    merged ranges are unions of the unmerged ones, cover the arena exactly once from the top down, every one but the
+    last holds at least the bucket size, and the gradients are the same bits."""
+    import bilinear_amd
+    from bilinear_amd import _native as N
+    dev = torch.device("cuda:0")
+    x = torch.randn(2048, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    t = torch.randn(2048, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    out = {}
+    for bucket in (0, 1 << 20):
+        torch.manual_seed(0)
+        net, opt, _, _ = bilinear_amd.load(dev, num_blocks=2, width=1024)
+        net.train()
+        eng = net.engine
+        eng.ensure(dev)
+        eng.seed = 5
+        eng.ctx.set_option(N.OPT_BUCKET_FLOATS, bucket)
+        assert eng.ctx.get_option(N.OPT_BUCKET_FLOATS) == bucket
+        ranges = []
+        pred, loss = eng.forward_train_loss(x, t)
+        eng.backward(x, None, on_ready=lambda off, cnt: ranges.append((off, off + cnt)))
+        torch.cuda.synchronize()
+        out[bucket] = (ranges, eng.grads.clone())
+    plain, merged = out[0][0], out[1 << 20][0]
+    total = net.engine.layout.total
+    for rs in (plain, merged):
+        assert rs[0][1] == total and rs[-1][0] == 0
+        assert all(a[0] == b[1] for a, b in zip(rs, rs[1:]))            # contiguous, top down
+    assert len(plain) == 6 and len(merged) < len(plain)
+    assert all(hi - lo >= (1 << 20) for lo, hi in merged[:-1])
+    bounds = {lo for lo, _ in plain} | {total}
+    assert all(lo in bounds and hi in bounds for lo, hi in merged)
+    assert torch.equal(out[0][1], out[1 << 20][1])
