@@ -244,6 +244,15 @@ int launch_decode_finish(hipStream_t s, const float* slabs, int splits, int64_t 
                          float* dbias_part = nullptr);
 // skinny.hip: decode forward fused with the MSE loss (pred, dpred, loss / decode-bias partials)
 bool decode_fwd_supported(int64_t batch, int W, int OF);
+// ---- column-owner BatchNorm kernels, 385 .. 1024 rows (colowner_f32.hip) ----
+bool colowner_supported(int64_t batch, int W);
+int launch_colowner_fwd(hipStream_t s, const float* slabs, int splits, int64_t slab_stride, const float* bias,
+                        const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t* nbt,
+                        uint32_t* ticket, float momentum, float* saved, const float* skip, float* Z, float* A,
+                        uint32_t* keepbits, int64_t batch, int W, const DropoutSrc& drop);
+int launch_colowner_bwd(hipStream_t s, const float* dA_src, int splits, int64_t slab_stride, const float* addend,
+                        float* dA_out, const float* Z, const float* saved, const uint32_t* keepbits, float* dZ,
+                        float* dgamma, float* dbeta, float* db_rows, int db_nrows, double* sq_gb, int64_t batch, int W);
 // ---- encode stage without its pre-BatchNorm tensor (encode_f32.hip) ----
 bool enc_fused_supported(int64_t batch, int W, int in_features);
 int enc_bwd_finish_blocks(int W);

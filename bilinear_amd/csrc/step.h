@@ -25,7 +25,7 @@ enum : int32_t {
   KNOB_NO_SMALL_STEP = 32,         // BLH_NO_SMALL_STEP: the <= 384-row kernels off
   KNOB_NO_DECODE_FUSE = 64,        // BLH_NO_DECODE_FUSE: decode forward and backward as separate launches
   KNOB_NO_ENCODE_FUSE = 128,       // BLH_NO_ENCODE_FUSE: encode stage through the materialised Z0
-  KNOB_NO_MID_FUSE = 256,          // BLH_NO_MID_FUSE: 385..2048-row stages on the multi-launch split-K form
+  KNOB_MID_FUSE = 256,             // BLH_MID_FUSE: opt-in, 385..1024-row stages on the column-owner kernels (slower)
   KNOB_ALL = 511
 };
 static inline int32_t dev_knobs_from_env() {
@@ -38,7 +38,7 @@ static inline int32_t dev_knobs_from_env() {
   if (std::getenv("BLH_NO_SMALL_STEP")) m |= KNOB_NO_SMALL_STEP;
   if (std::getenv("BLH_NO_DECODE_FUSE")) m |= KNOB_NO_DECODE_FUSE;
   if (std::getenv("BLH_NO_ENCODE_FUSE")) m |= KNOB_NO_ENCODE_FUSE;
-  if (std::getenv("BLH_NO_MID_FUSE")) m |= KNOB_NO_MID_FUSE;
+  if (std::getenv("BLH_MID_FUSE")) m |= KNOB_MID_FUSE;
   return m;
 }
 }  // namespace blh

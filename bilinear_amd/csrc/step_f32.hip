@@ -14,6 +14,17 @@ static bool enc_fused_ok(const blh_context* ctx, const blh_model_desc* d, int64_
          enc_fused_supported(batch, d->width, d->in_features);
 }
 
+// Column-owner BatchNorm kernels (colowner_f32.hip) for the hidden stages at 385 .. 1024 rows: exact-fp32 mode,
+// per-rank statistics.  Same results as the multi-launch form up to the order of fp32 sums; nothing about the saved
+// activations changes (Z, A, keep bits, saved statistics), so forward and backward decide independently.
+// OPT-IN (BLH_MID_FUSE=1): built, verified and MEASURED SLOWER than the launches they replace — 32 workgroups cannot
+// stream the 16.8 MB of split-K slabs of a stage as fast as four full-chip launches pay their launch latency
+// (profiles/r05_colowner.md: 512 rows 0.554 against 0.485 ms per step, 1024 rows 0.636 against 0.616).
+static bool colowner_ok(const blh_context* ctx, const blh_model_desc* d, int64_t batch) {
+  return d->gemm_dtype == 0 && !ctx->sync.fn && ctx->knob(KNOB_MID_FUSE) && ctx->grid_bar != nullptr &&
+         colowner_supported(batch, d->width);
+}
+
 int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
                         float* bn_running, int64_t* nbt, const float* x, const blh_dropout* drop,
                         float momentum, const Workspace& ws, float* pred, int64_t batch,
@@ -23,6 +34,7 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
   const int nh = (int)L.heavy.size();
   const int W = d->width;
   const bool enc_fused = train && enc_fused_ok(ctx, d, batch);
+  const bool colown = colowner_ok(ctx, d, batch);
   if (train) ctx->note_saved(ws.Z[0], batch, enc_fused ? 3 : 0);     // (ws.Z[0] is the workspace base, api_layout.h carve)
   if (ws.amax_W)   // gemm_dtype 3: max |w| of every hidden Linear weight, once per forward
     for (int i = 1; i < nh; ++i)
@@ -59,6 +71,17 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
       // finish (slab sum + bias + BN tile statistics) in a streaming kernel
       g.C = ws.slabs; g.c_split_stride = batch * (int64_t)W; g.k_per_split = fs.k_per;
       BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, EPI_STORE, g, fs.splits, d->gemm_dtype));
+      if (train && colown) {
+        // 385 .. 1024 rows: ONE finishing launch — a workgroup owns 32 columns for all rows (colowner_f32.hip):
+        // slab sum + bias, batch statistics, running statistics, BatchNorm + ReLU + dropout (+ skip), keep bits
+        const float* skip_c = (i >= 2 && (i % 2) == 0) ? ws.A[i - 2] : nullptr;
+        BLH_TRY(launch_colowner_fwd(s, ws.slabs, fs.splits, batch * (int64_t)W, params + h.b, params + h.gamma,
+                                    params + h.beta, bn_running + ((int64_t)i * 2 + 0) * W,
+                                    bn_running + ((int64_t)i * 2 + 1) * W, nbt + i, ctx->grid_bar + 8, momentum,
+                                    ws.bn_saved[i], skip_c, ws.Z[i], ws.A[i], ws.keep[i], batch, W,
+                                    layer_drop(ctx, drop, i, batch, W)));
+        continue;
+      }
       BLH_TRY(launch_fwd_finish(s, ws.slabs, fs.splits, batch, W, params + h.b, ws.Z[i],
                                 train ? ws.stat_part : nullptr));
     } else if (!train && d->gemm_dtype != 3) {
@@ -335,6 +358,9 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
   int pregated_tiles = 0;     // > 0: this stage's dA is dY' and ws.stat_part holds that many rows of partials
   const blh_context::SavedFormat* saved_fmt = ctx->find_saved(ws.Z[0]);
   const bool enc_fused = saved_fmt && saved_fmt->mode == 3 && saved_fmt->batch == batch;
+  const bool colown_b = colowner_ok(ctx, d, batch) && !k9 && !defer;
+  struct PendingDA { const float* src = nullptr; int splits = 1; int64_t stride = 0; const float* addend = nullptr;
+                     float* out = nullptr; } pend;
   for (int i = nh - 1; i >= 0; --i) {
     const HeavyOffsets& h = L.heavy[i];
     if (i == 0 && enc_fused) {
@@ -363,11 +389,23 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
     const float* sv = ws.bn_saved[i];
     // (dropout: the keep bits the forward wrote, ws.keep[i])
     const bool pregated = pregated_tiles > 0;
+    // 385 .. 1024 rows: the whole BatchNorm backward of the stage in one launch (colowner_f32.hip); its input is the
+    // gradient tensor, or — when the stage above left its data gradient as split-K slabs — the slabs themselves
+    // (+ the block-skip gradient; the sum is written out where it is an operand again: `pend.out`)
+    const bool co_stage = colown_b && !pregated;
+    if (co_stage) {
+      BLH_TRY(launch_colowner_bwd(s, pend.src ? pend.src : dA, pend.src ? pend.splits : 1, pend.stride, pend.addend,
+                                  pend.out, ws.Z[i], sv, ws.keep[i], ws.dZ[i], grads + h.gamma, grads + h.beta,
+                                  ws.dz_colsum_part + (int64_t)i * chunks * W, chunks,
+                                  fold.on ? ws.sumsq_fold + fold.gb0 + i * bn_bwd_finalize_blocks(W) : nullptr, batch, W));
+      pend = PendingDA{};
+    } else {
     if (!pregated)
       BLH_TRY(launch_bn_bwd_reduce_f2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, ws.keep[i], ws.bn_part, batch, W));
     BLH_TRY(launch_bn_bwd_finalize_h2(s, pregated ? ws.stat_part : ws.bn_part, pregated ? pregated_tiles : chunks, W,
                                       sv, sv + W, grads + h.gamma, grads + h.beta,
                                       fold.on ? ws.sumsq_fold + fold.gb0 + i * bn_bwd_finalize_blocks(W) : nullptr));
+    }
     pregated_tiles = 0;
     const float* dg = grads + h.gamma;
     const float* db = grads + h.beta;
@@ -402,6 +440,7 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
     const bool fork_late = side && late_policy && i > 0 && small_m_splits(batch, W, W, d->gemm_dtype).splits == 1;
     hipStream_t sw = side ? s2 : s;
     if (side && !fork_late) arm_fork(i);
+    if (!co_stage)
     BLH_TRY(launch_bn_bwd_apply_f2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W, dg, db, ws.keep[i],
                                    dzbuf, ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W,
                                    norm_batch, dz_amax, pregated));
@@ -424,6 +463,13 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
       if (ds2.splits > 1) {
         g.C = ws.slabs; g.c_split_stride = batch * (int64_t)W; g.k_per_split = ds2.k_per;
         BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, ds2.splits, d->gemm_dtype));
+        // (the stage below is a column-owner stage: it sums the slabs itself — and the weight gradient of THIS stage,
+        //  next on the stream, takes its own slab buffer)
+        const bool consumer_co = colown_b && ws.stage_slabs[i] != nullptr && (i - 1 >= 1 || !enc_fused);
+        if (consumer_co)
+          pend = PendingDA{ws.slabs, ds2.splits, batch * (int64_t)W, first_of_block ? ws.G0 : nullptr,
+                           first_of_block ? ws.G0 : nullptr};
+        else
         BLH_TRY(launch_sum_slabs_add(s, ws.slabs, batch * (int64_t)W, ds2.splits,
                                      first_of_block ? ws.G0 : nullptr, dst));
       } else {
@@ -464,7 +510,7 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
       if (side) BLH_TRY(wdone(0));
     } else {
       BLH_TRY(wgrad(d->gemm_dtype, sw, TILE_128x128, dzbuf, W, W, ws.A[i - 1], W, W, batch,
-                    ceil_div(W, 128) * ceil_div(W, 128), defer ? ws.stage_slabs[i] : ws.slabs,
+                    ceil_div(W, 128) * ceil_div(W, 128), (defer || pend.src) ? ws.stage_slabs[i] : ws.slabs,
                     grads + h.w, defer ? &wreg[i] : nullptr, dz_amax, ws.amax_A[i - 1],
                     ws.amax_parts, fold_w(i), fold.per_w));
       BLH_TRY(wdone(i));

@@ -891,3 +891,53 @@ def test_encode_stage_without_z0_other_shapes(nb, width, batch):
         assert _rel(a[1][k], b[1][k]) <= 2e-2, (k, _rel(a[1][k], b[1][k]))
     assert _rel(a[2], b[2]) <= 1e-5 and torch.equal(a[3], b[3])
     assert abs(float(a[5]) - float(b[5])) <= 1e-3 * abs(float(b[5]))
+
+
+@pytest.mark.parametrize("nb,width,batch", [(2, 1024, 512), (2, 1024, 1024), (2, 1024, 777), (1, 512, 400), (3, 256, 640)])
+def test_column_owner_stages_match_the_multi_launch_path(nb, width, batch):
+    """Round 5, 385 .. 1024 rows (the per-GPU shapes of the headline batch split over 4 / 8 GPUs): the hidden stages
+    run their BatchNorm forward (slab sum + bias, statistics, apply, dropout, skip) and backward (reductions, dgamma /
+    dbeta, dZ, bias sums — reading the data-gradient slabs of the stage above directly) in ONE launch each
+    (colowner_f32.hip: a workgroup owns 32 columns for all rows; opt-in, BLH_MID_FUSE=1: correct, and slower than the
+    launches it replaces — profiles/r05_colowner.md).  Against the default multi-launch form (4-5 launches per stage)
+    on the same explicit masks: running statistics, counters, the drop-in step's gradients and
+    two fused steps agree to fp32 summation rounding (ragged batch 777: a partial last pass and 8-row group)."""
+    import os
+
+    import bilinear_amd
+    dev = _dev()
+    x = torch.randn(batch, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    t = torch.randn(batch, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    g = torch.Generator(device=dev).manual_seed(9)
+    masks = [(torch.rand(batch, width, device=dev, generator=g) < 0.5).to(torch.uint8) for _ in range(1 + 2 * nb)]
+    out = {}
+    for fused in (True, False):
+        if fused:
+            os.environ["BLH_MID_FUSE"] = "1"
+        try:
+            torch.manual_seed(0)
+            net, opt, _, _ = bilinear_amd.load(dev, num_blocks=nb, width=width, gemm_dtype="fp32")
+            net.train()
+            net.engine.ensure(dev)
+            net.engine.set_dropout_masks(masks)
+            opt.zero_grad()
+            pred = net(x)
+            torch.nn.functional.mse_loss(pred, t).backward()
+            torch.cuda.synchronize()
+            first = (pred.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()},
+                     net.engine.bn_running.clone(), net.engine.bn_nbt.clone())
+            for _ in range(2):
+                p2, loss = net.train_step(opt, x, t, max_norm=1.0)
+            torch.cuda.synchronize()
+            out[fused] = first + (p2.clone(), loss.clone(), net.engine.bn_running.clone(), net.engine.bn_nbt.clone())
+        finally:
+            os.environ.pop("BLH_MID_FUSE", None)
+    a, b = out[True], out[False]
+    assert _rel(a[0], b[0]) <= 1e-5, ("pred", _rel(a[0], b[0]))
+    for k in a[1]:
+        if k.endswith(".0.bias") and not k.startswith("decode"):
+            continue                              # pre-BatchNorm biases: rounding noise around zero (SURVEY H2)
+        assert _rel(a[1][k], b[1][k]) <= 2e-2, (k, _rel(a[1][k], b[1][k]))      # (a ReLU gate that opened differently: ~1e-3)
+    assert _rel(a[2], b[2]) <= 1e-5 and torch.equal(a[3], b[3]) and int(a[3][1]) == 1
+    assert abs(float(a[5]) - float(b[5])) <= 1e-3 * abs(float(b[5]))
+    assert _rel(a[6], b[6]) <= 1e-4 and torch.equal(a[7], b[7]) and int(a[7][1]) == 3

@@ -3,7 +3,7 @@ cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_dp
 mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/p -o f -- python3 $R/bench.py --gpus 1 --rehearse-rccl --no-configs --no-cpu-baseline --no-alt --steps 60 --warmup 20 > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/p -o f -- python3 $R/bench.py --gpus 1 --rehearse-rccl ${DP_EXTRA:-} --no-configs --no-cpu-baseline --no-alt --steps 60 --warmup 20 > $O/bench.json 2> $O/bench.err
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("$O/p/f_kernel_trace.csv")))
