@@ -122,7 +122,7 @@ def gemm_rooflines(batch, width, reps, dtype="fp32", hidden=0):
     time_kernel(fwd, 3 * reps)     # clock ramp: the first ~50 ms after idle run 10-15 % slow
     for name, fn in (("linear_fwd", fwd), ("linear_dgrad", dgrad), ("linear_wgrad", wgrad)):
         ms = time_kernel(fn, reps)
-        out[name] = {"ms": ms, "tflops": flop / ms / 1e9}
+        out[name] = {"ms": ms, "tflops": flop / ms / 1e9, "reps": reps}
     return out
 
 
@@ -185,7 +185,7 @@ def gemm_rooflines_bf16s(batch, width, reps, hidden=0):
     time_kernel(fwd, 3 * reps)
     for name, fn in (("linear_fwd", fwd), ("linear_dgrad", dgrad), ("linear_wgrad", wgrad)):
         ms = time_kernel(fn, reps)
-        out[name] = {"ms": ms, "tflops": flop / ms / 1e9}
+        out[name] = {"ms": ms, "tflops": flop / ms / 1e9, "reps": reps}
     if bs:
         del slabs
         dz = torch.randn(hidden, batch, width, device=dev).to(torch.bfloat16)
@@ -229,7 +229,29 @@ def skinny_rooflines(batch, width, reps):
     wsb = lib.blh_skinny_workspace_bytes(B, W, IF, OF)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     rows = ctypes.c_int32(0)
+    # the encode stage as the fp32 step launches it (encode_f32.hip): statistics from the sums of x, no Z0
+    from bilinear_amd import _native as N2
+    gam, bet = torch.ones(W, device=dev), torch.zeros(W, device=dev)
+    rmean, rvar = torch.zeros(W, device=dev), torch.ones(W, device=dev)
+    nbt1 = torch.zeros(1, dtype=torch.int64, device=dev)
+    saved = torch.empty(4, W, device=dev)
+    scratch = torch.empty(B * W, device=dev)
+    A0 = torch.empty(B, W, device=dev)
+    bits = torch.zeros(((B + 7) // 8) * (W // 4), dtype=torch.int32, device=dev)
+    dropd = N2.Dropout(None, 1, 0, 0, 0, 0)
+    db0, dg0, dbe0 = (torch.empty(W, device=dev) for _ in range(3))
     ops = [
+        ("encode_fused_fwd (x -> A0 + keep bits, BatchNorm statistics from the sums of x: 3 launches, no Z0: the "
+         "fp32 step's encode forward)", 4.0 * B * (IF + W) + B * W / 8.0,
+         lambda: lib.blh_skinny_encode_fused_fwd(st, x.data_ptr(), W0.data_ptr(), b0.data_ptr(), gam.data_ptr(),
+                                                 bet.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), nbt1.data_ptr(), 0.1,
+                                                 saved.data_ptr(), scratch.data_ptr(), A0.data_ptr(), bits.data_ptr(),
+                                                 ctypes.byref(dropd), B, W, IF)),
+        ("encode_fused_bwd (dA0 -> dW0, db0, dgamma, dbeta from dA0, the bits and x: 2 launches: the fp32 step's "
+         "encode backward)", 4.0 * B * (W + IF) + B * W / 8.0,
+         lambda: lib.blh_skinny_encode_fused_bwd(st, A.data_ptr(), x.data_ptr(), W0.data_ptr(), b0.data_ptr(),
+                                                 saved.data_ptr(), bits.data_ptr(), scratch.data_ptr(), dW0.data_ptr(),
+                                                 db0.data_ptr(), dg0.data_ptr(), dbe0.data_ptr(), B, W, IF)),
         ("encode_fwd (Linear 32->%d + BatchNorm partials)" % W, 4.0 * B * (IF + W),
          lambda: lib.blh_skinny_encode_fwd(st, x.data_ptr(), W0.data_ptr(), b0.data_ptr(), Z.data_ptr(),
                                            part.data_ptr(), ctypes.byref(rows), B, W, IF)),
@@ -249,6 +271,36 @@ def skinny_rooflines(batch, width, reps):
          lambda: lib.blh_skinny_encode_wgrad(st, Z.data_ptr(), x.data_ptr(), dW0.data_ptr(), ws.data_ptr(),
                                              wsb, B, W, IF)),
     ]
+    # HBM-side traffic of the kernels behind each entry point, from the committed rocprofv3 --pmc record of THIS
+    # shape (tools_dev/pmc_hbm.sh -> profiles/r05_hbm_traffic.json: 2 * FETCH_SIZE + WRITE_SIZE per launch; slab sums
+    # are shared between entry points and not attributed); None where no record covers the shape
+    kernels_of = {
+        "encode_fused_fwd": ["enc_xstats_kernel", "enc_bn_finalize_kernel", "enc_fwd_kernel"],
+        "encode_fused_bwd": ["enc_bwd_kernel", "enc_bwd_finish_kernel"],
+        "encode_fwd": ["gemm_f32_ring_kernel<64, 128, 2, 2, 0, 0, 2, 32, 3"],
+        "decode_fwd_mse": ["decode_fwd_mse_kernel"],
+        "decode_fused": ["decode_fused_kernel"],
+        "decode_bwd": ["gemm_f32_ring_kernel<64, 128, 2, 2, 0, 1, 0, 32, 3", "gemm_f32_ring_kernel<64, 128, 2, 2, 1, 1, 0, 32, 3"],
+        "encode_wgrad": ["gemm_f32_ring_kernel<128, 32, 4, 1, 1, 1, 0, 32, 3"],
+    }
+    rec = {}
+    try:
+        with open(os.path.join(REPO, "profiles", "r05_hbm_traffic.json")) as f:
+            cfg = json.load(f)["configs"]["configs[1]"]
+        if cfg["shape"]["B"] == B and cfg["shape"]["W"] == W:
+            rec = cfg["kernels"]
+    except (OSError, KeyError, ValueError):
+        pass
+
+    def traffic_of(opname):
+        total = 0
+        for sub in kernels_of.get(opname.split(" ")[0], []):
+            hit = [v["traffic_bytes"] for k, v in rec.items() if k.startswith(sub)]
+            if not hit:
+                return None
+            total += hit[0]
+        return total or None
+
     out = []
     for name, nbytes, fn in ops:
         if fn() != 0:          # (a shape this entry point does not serve: the step takes the other path there)
@@ -256,7 +308,8 @@ def skinny_rooflines(batch, width, reps):
         ms = time_kernel(fn, reps)
         gbs = nbytes / (ms * 1e-3) / 1e9
         out.append({"op": name, "algorithmic_bytes": nbytes, "avg_us": 1e3 * ms, "achieved": gbs,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bound": "hbm"})
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bound": "hbm",
+                    "traffic": traffic_of(name)})
     return out
 
 
@@ -315,6 +368,9 @@ def recorded_ceiling(batch, width):
         return None
 
 
+GEMM_REPS = 500       # launches per HIP-event timing of the dominant kernel (gemm_rooflines)
+
+
 def roofline_block(args, dom):
     """Roofline of the dominant kernel (the WxW Linear forward GEMM at M = batch)."""
     flop = 2.0 * args.batch * args.width * args.width
@@ -330,7 +386,7 @@ def roofline_block(args, dom):
             "avg_launch_ms": dom["ms"], "flop_per_launch": flop,
             "avg_launch_ms_how": "HIP events around %d back-to-back launches on the launch stream; the rocprofv3 "
                                  "--kernel-trace average of the same kernel inside the step is in "
-                                 "profiles/r04_final_kernel_stats.md" % 500,
+                                 "profiles/r05_final_kernel_stats.md" % dom.get("reps", GEMM_REPS),
             # what a kernel of this launch shape (one 128x128 tile per CU) can reach at all: the
             # same kernel with its loop reduced to the MFMAs, measured (profiles/r02_traffic.json)
             "shape_ceiling": recorded_ceiling(args.batch, args.width),
@@ -404,7 +460,7 @@ def alt_mode_block(args, dev, x, t, alt):
     out["ms_per_step"] = 1e3 * el / args.steps
     out["poses_per_s"] = args.batch * args.steps / el
     out["final_loss"] = float(loss.item())
-    kern = gemm_rooflines(args.batch, args.width, reps=500, dtype=alt)
+    kern = gemm_rooflines(args.batch, args.width, reps=GEMM_REPS, dtype=alt)
     out["kernels"] = kern
     out["arithmetic"] = {
         "bf16x3": "x = h + m + l exactly (3 bf16 pieces); a*b from 6 bf16 MFMAs, fp32 accumulate; "
@@ -568,8 +624,9 @@ def config_block(idx, dev, steps, ramp_ms):
 
 def batch64_block(dev, steps, ramp_ms):
     """The reference's own batch size (util/config.py:15: 64 poses; BASELINE configs[0]'s shape) on the GPU, fp32,
-    2 blocks x 1024: the whole step as ONE persistent launch (csrc/small_step.hip, the default at <= 64 rows) and,
-    beside it, the multi-launch path every larger batch takes."""
+    2 blocks x 1024, three forms of the same step: one launch per stage (csrc/small_step.hip, "staged": the DEFAULT at
+    <= 384 rows), the whole step as ONE persistent launch with grid barriers ("one_launch", option 2) and the
+    multi-launch path every larger batch takes; then the reference's five-call loop on the drop-in surface."""
     import bilinear_amd
     torch.manual_seed(1)
     net, opt, _, _ = bilinear_amd.load(dev, num_blocks=2, width=1024, gemm_dtype="fp32")
@@ -869,7 +926,7 @@ def main():
         log("fwd+bwd only: %.3f ms" % fb_ms)
         # (long enough for the clocks to settle: the first ~50 ms after an idle period run at a
         #  lower DVFS state and read 10-15 % slow)
-        kern = gemm_rooflines(args.batch, args.width, reps=500, dtype=args.dtype, hidden=2 * args.blocks)
+        kern = gemm_rooflines(args.batch, args.width, reps=GEMM_REPS, dtype=args.dtype, hidden=2 * args.blocks)
         log("kernel timings: %s" % json.dumps(kern))
         dom = kern["linear_fwd"]
         result = {
@@ -903,7 +960,8 @@ def main():
                 "dropout": "philox",
                 "batchnorm": ("sync (global batch)" if args.sync_bn else "per-rank statistics") if world > 1 else "single device",
                 "launch": ("hipGraph replay (1 launch/step)" if (use_graph or dp_captured is not None)
-                           else ("eager, small-batch kernels (one launch per stage: 2 stages + 3 launches/step)"
+                           else ("eager, small-batch kernels (one launch per stage: %d stage launches + 3 = %d launches/step)" % (
+                                     2 * (1 + 2 * args.blocks), 2 * (1 + 2 * args.blocks) + 3)
                                  if (args.batch <= 384 and args.dtype == "fp32" and not multi)
                                  else "eager (~55 launches/step, weight-gradient GEMMs on a side stream)")) + (
                                "; Adam writes the bf16 weight image (persistent shadow)"

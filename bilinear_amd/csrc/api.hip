@@ -1084,6 +1084,33 @@ int blh_skinny_decode_fwd_mse(void* stream, const float* A, const float* Wd, con
   return loss_out ? launch_loss_finalize((hipStream_t)stream, loss_part, np, denom, loss_out) : BLH_OK;
 }
 
+// The encode stage as the exact-fp32 step runs it at more than 384 rows (encode_f32.hip): forward x -> A0 + the
+// stage's keep AND gate bits + saved statistics, backward dA0 -> dW0, db0, dgamma, dbeta.  `scratch`: batch * width floats.
+int blh_skinny_encode_fused_fwd(void* stream, const float* x, const float* W0, const float* b0, const float* gamma,
+                                const float* beta, float* running_mean, float* running_var, int64_t* nbt,
+                                float momentum, float* saved, float* scratch, float* A, uint32_t* keepbits,
+                                const blh_dropout* drop, int64_t batch, int32_t width, int32_t in_features) {
+  if (!x || !W0 || !b0 || !gamma || !beta || !running_mean || !running_var || !nbt || !saved || !scratch || !A ||
+      !keepbits || !drop || batch < 2)
+    return BLH_ERR_INVALID_ARGUMENT;
+  if (!enc_fused_supported(batch, width, in_features)) return BLH_ERR_SHAPE;
+  DropoutSrc d;
+  d.step_dev = nullptr; d.keep = drop->keep_mask; d.seed = drop->seed; d.step = drop->step;
+  d.row_offset = drop->row_offset; d.layer = drop->layer_base;
+  return launch_enc_forward((hipStream_t)stream, x, W0, b0, gamma, beta, running_mean, running_var, nbt, momentum, saved,
+                            scratch, A, keepbits, batch, width, d);
+}
+
+int blh_skinny_encode_fused_bwd(void* stream, const float* dA, const float* x, const float* W0, const float* b0,
+                                const float* saved, const uint32_t* keepbits, float* scratch, float* dW0, float* db0,
+                                float* dgamma, float* dbeta, int64_t batch, int32_t width, int32_t in_features) {
+  if (!dA || !x || !W0 || !b0 || !saved || !keepbits || !scratch || !dW0 || !db0 || !dgamma || !dbeta || batch < 2)
+    return BLH_ERR_INVALID_ARGUMENT;
+  if (!enc_fused_supported(batch, width, in_features)) return BLH_ERR_SHAPE;
+  return launch_enc_backward((hipStream_t)stream, dA, x, W0, b0, saved, keepbits, scratch, batch, width, dW0, dgamma,
+                             dbeta, db0, 1, nullptr, nullptr);
+}
+
 int blh_skinny_decode_fused(void* stream, const float* A, const float* Wd, const float* bd,
                             const float* target, float* pred, float* dpred, float* dA, float* loss_out,
                             void* workspace, int64_t workspace_bytes, int64_t batch, int32_t width,

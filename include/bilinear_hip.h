@@ -548,6 +548,20 @@ int blh_skinny_decode_fwd_mse(void* stream, const float* A, const float* Wd, con
                               const float* target, float* pred, float* dpred, float* loss_out,
                               void* workspace, int64_t workspace_bytes, int64_t batch, int32_t width,
                               int32_t out_features);
+/* The encode stage without its pre-BatchNorm tensor (r05; /root/reference/model/bilinear.py:22,34): what the exact-fp32
+ * step launches at more than 384 rows.  Forward: the batch statistics of z = x W0^T + b0 follow from the 33 x 32 sums
+ * of x (mean_j = w_j . xbar + b_j, var_j = w_j^T Cov(x) w_j), so x -> A0 = 2 keep relu(BN(z)) is computed without
+ * writing Z0; `keepbits` ([ceil(B/8)][W/4] words) receives keep AND [y > 0], `saved` ([4][W]) mean, invstd, scale,
+ * shift; running statistics and the counter are updated (momentum < 0: cumulative average).  Backward: from dA0, the
+ * bits and x alone — dW0 [W][32], db0 [W], dgamma, dbeta.  `scratch`: batch * width floats, kept between the two
+ * calls (the forward leaves the sums of x there).  width % 256 == 0, in_features == 32; BLH_ERR_SHAPE otherwise.   */
+int blh_skinny_encode_fused_fwd(void* stream, const float* x, const float* W0, const float* b0, const float* gamma,
+                                const float* beta, float* running_mean, float* running_var, int64_t* nbt,
+                                float momentum, float* saved, float* scratch, float* A, uint32_t* keepbits,
+                                const blh_dropout* drop, int64_t batch, int32_t width, int32_t in_features);
+int blh_skinny_encode_fused_bwd(void* stream, const float* dA, const float* x, const float* W0, const float* b0,
+                                const float* saved, const uint32_t* keepbits, float* scratch, float* dW0, float* db0,
+                                float* dgamma, float* dbeta, int64_t batch, int32_t width, int32_t in_features);
 /* One-pass decode (r05): blh_skinny_decode_fwd_mse AND the data gradient dA[B,W] = dpred Wd from one read of A
  * (/root/reference/model/bilinear.py:29,39; train_bilinear.py:78-79: the loss is row-local).  What the fused
  * training step launches at out_features == 48, width 512 / 1024, batch <= 16384; BLH_ERR_SHAPE otherwise.      */

@@ -140,3 +140,75 @@ def test_decode_one_pass_forward_mse_and_data_gradient(native, batch, width):
     assert native.blh_skinny_decode_fused(st, a.data_ptr(), w.data_ptr(), b.data_ptr(), tt.data_ptr(), pred.data_ptr(),
                                           dpred.data_ptr(), dA.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsb, batch,
                                           width, 32) != 0
+
+
+@pytest.mark.parametrize("batch,width", [(4096, 1024), (4100, 1024), (900, 256), (16384, 1024)])
+def test_encode_stage_without_its_pre_batchnorm_tensor(native, batch, width):
+    """encode_f32.hip (round 5) through its C entry points against fp64 NumPy: forward x -> A0 = 2 keep relu(BN(x W0^T +
+    b0)) with the batch statistics derived from the sums of x (saved mean / invstd / scale / shift, running statistics
+    with momentum 0.1 and the unbiased variance, counter), backward dA0 -> dW0, db0, dgamma, dbeta from dA0, the
+    keep-AND-gate bits and x alone.  Explicit masks; elements whose pre-activation is within 1e-4 of the ReLU kink are
+    masked out (the gate of such an element is decided by rounding).  /root/reference/model/bilinear.py:7-13,22,34."""
+    from bilinear_amd import _native as N
+    dev = _dev()
+    rng = np.random.RandomState(batch + width)
+    IF = 32
+    x = rng.standard_normal((batch, IF)).astype(np.float32)
+    x[:, 3] += 0.5
+    W0 = (rng.standard_normal((width, IF)) * 0.25).astype(np.float32)
+    b0 = (rng.standard_normal(width) * 0.1).astype(np.float32)
+    gamma = (1.0 + 0.1 * rng.standard_normal(width)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(width)).astype(np.float32)
+    dA = (rng.standard_normal((batch, width)) * 1e-3).astype(np.float32)
+    z = x.astype(np.float64) @ W0.T.astype(np.float64) + b0
+    mean, var = z.mean(0), z.var(0)
+    invstd = 1.0 / np.sqrt(var + 1e-5)
+    y = (z - mean) * invstd * gamma + beta
+    keep = (rng.random_sample((batch, width)) < 0.5)
+    keep &= np.abs(y) > 1e-4
+    A_ref = 2.0 * keep * np.maximum(y, 0.0)
+    xt, w0, bt, gt, bet, dat = (torch.from_numpy(v).to(dev) for v in (x, W0, b0, gamma, beta, dA))
+    km = torch.from_numpy(keep.astype(np.uint8)).to(dev)
+    rm, rv = torch.zeros(width, device=dev), torch.ones(width, device=dev)
+    nbt = torch.zeros(1, dtype=torch.int64, device=dev)
+    saved = torch.full((4, width), float("nan"), device=dev)
+    scratch = torch.empty(batch * width, device=dev)
+    A = torch.full((batch + 1, width), float("nan"), device=dev)
+    bits = torch.zeros(((batch + 7) // 8) * (width // 4), dtype=torch.int32, device=dev)
+    drop = N.Dropout(km.data_ptr(), 0, 0, 0, 0, 0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = native.blh_skinny_encode_fused_fwd(st, xt.data_ptr(), w0.data_ptr(), bt.data_ptr(), gt.data_ptr(), bet.data_ptr(),
+                                            rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), 0.1, saved.data_ptr(),
+                                            scratch.data_ptr(), A.data_ptr(), bits.data_ptr(), ctypes.byref(drop), batch,
+                                            width, IF)
+    assert rc == 0, native.blh_status_string(rc)
+    torch.cuda.synchronize()
+    _close(A[:batch].cpu().numpy(), A_ref, 2e-5, "A0")
+    assert torch.isnan(A[batch:]).all() and int(nbt) == 1
+    sv = saved.cpu().numpy().astype(np.float64)
+    _close(sv[0], mean, 1e-6, "saved mean")
+    _close(sv[1], invstd, 1e-6, "saved invstd")
+    _close(sv[2], gamma * invstd, 1e-6, "scale")
+    _close(rm.cpu().numpy(), 0.1 * mean, 1e-6, "running mean")
+    _close(rv.cpu().numpy(), 0.9 + 0.1 * var * batch / (batch - 1), 1e-6, "running var")
+    # backward (BatchNorm1d backward with batch statistics, /root/reference/model/bilinear.py:10)
+    dY = 2.0 * keep * (y > 0) * dA.astype(np.float64)
+    zhat = (z - mean) * invstd
+    dgamma_ref, dbeta_ref = (dY * zhat).sum(0), dY.sum(0)
+    dZ = gamma * invstd * (dY - dbeta_ref / batch - zhat * dgamma_ref / batch)
+    dW0 = torch.full((width, IF), float("nan"), device=dev)
+    db0, dg, db = (torch.full((width,), float("nan"), device=dev) for _ in range(3))
+    rc = native.blh_skinny_encode_fused_bwd(st, dat.data_ptr(), xt.data_ptr(), w0.data_ptr(), bt.data_ptr(),
+                                            saved.data_ptr(), bits.data_ptr(), scratch.data_ptr(), dW0.data_ptr(),
+                                            db0.data_ptr(), dg.data_ptr(), db.data_ptr(), batch, width, IF)
+    assert rc == 0, native.blh_status_string(rc)
+    torch.cuda.synchronize()
+    _close(dg.cpu().numpy(), dgamma_ref, 1e-4, "dgamma")
+    _close(db.cpu().numpy(), dbeta_ref, 1e-4, "dbeta")
+    _close(dW0.cpu().numpy(), dZ.T @ x.astype(np.float64), 1e-4, "dW0")
+    assert np.abs(db0.cpu().numpy()).max() <= 1e-5 * max(1.0, np.abs(dZ).sum(0).max())      # sum of dZ: zero up to rounding
+    # shapes the kernels do not serve are refused
+    assert native.blh_skinny_encode_fused_fwd(st, xt.data_ptr(), w0.data_ptr(), bt.data_ptr(), gt.data_ptr(),
+                                              bet.data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), 0.1,
+                                              saved.data_ptr(), scratch.data_ptr(), A.data_ptr(), bits.data_ptr(),
+                                              ctypes.byref(drop), batch, width, 48) != 0

@@ -27,6 +27,12 @@ def algorithmic(kernel, cfg):
         return 3 * bw + bits, "dA, Z, keep bits read, dZ written"
     if k.startswith("clip_adam_kernel"):
         return 28 * cfg["P"], "g, p, m, v read; p, m, v written (28 B per parameter)"
+    if k.startswith("decode_fused_kernel"):
+        return 4 * B * (2 * W + 3 * 48), "A, target read; pred, dpred, dA written (fp32)"
+    if k.startswith("enc_fwd_kernel"):
+        return 4 * B * (32 + W) + bits, "x read; A0 + keep-and-gate bits written"
+    if k.startswith("enc_bwd_kernel"):
+        return 4 * B * (W + 32) + bits, "dA0, bits, x read (+ 4.3 MB of row-block partials written)"
     if k.startswith("decode_fwd_mse_kernel"):
         return 4 * B * (W + 3 * 48), "A, target read; pred, dpred written (fp32)"
     if k.startswith("decode_fwd_mse_h_kernel"):
