@@ -265,6 +265,14 @@ int launch_enc_backward(hipStream_t s, const float* dA, const float* x, const fl
                         const float* saved, const uint32_t* gatebits, float* z0_scratch, int64_t batch, int W,
                         float* dW0, float* dgamma, float* dbeta, float* db_rows, int db_nrows, double* sq_w,
                         double* sq_gb);
+bool enc_fused_supported_h(int64_t batch, int W, int in_features);
+int launch_enc_forward_h(hipStream_t s, const uint16_t* xh, const uint16_t* W0h, const float* b0, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, int64_t* nbt, float momentum,
+                         float* saved, uint16_t* z0_scratch, uint16_t* A, uint32_t* keepbits, int64_t batch, int W,
+                         const DropoutSrc& drop);
+int launch_enc_backward_h(hipStream_t s, const uint16_t* dA, const uint16_t* xh, const uint16_t* W0h, const float* b0,
+                          const float* saved, const uint32_t* gatebits, uint16_t* z0_scratch, int64_t batch, int W,
+                          float* dW0, float* dgamma, float* dbeta, float* db_rows, int db_nrows);
 bool decode_fused_supported(int64_t batch, int W, int OF);
 int launch_decode_fused(hipStream_t s, const float* A, const float* Wd, const float* bd, const float* target,
                         float* pred, float* dpred, float* dA, float* loss_part, float* dbias_part, int64_t batch,

@@ -35,6 +35,34 @@
 namespace blh {
 
 typedef float encf4 __attribute__((ext_vector_type(4)));
+typedef uint16_t enc_bf16;
+
+// H = bf16 storage (gemm_dtype 4): x (the cast input xh), W0 (the parameter shadow), A0 and dA0 are bf16 in memory;
+// the arithmetic is the fp32 path's on the exactly-converted values (products of two bf16 numbers are exact in
+// fp32: the contraction is what the bf16 MFMA path computes, up to the order of the fp32 sums), z is rounded to
+// bf16 before BatchNorm normalises it — the stored Z of the GEMM path is what bn_apply_h2 reads.
+template <bool H> struct EncT { typedef float T; };
+template <> struct EncT<true> { typedef enc_bf16 T; };
+__device__ __forceinline__ float enc_ld1(const float* p) { return *p; }
+__device__ __forceinline__ float enc_ld1(const enc_bf16* p) { return __uint_as_float((uint32_t)*p << 16); }
+__device__ __forceinline__ float4 enc_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 enc_ld4(const enc_bf16* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                     __uint_as_float(v.y & 0xffff0000u));
+}
+__device__ __forceinline__ float enc_round_bf16(float v) {
+  const __bf16 b = (__bf16)v;
+  return __uint_as_float((uint32_t)(*reinterpret_cast<const uint16_t*>(&b)) << 16);
+}
+__device__ __forceinline__ void enc_st4(float* p, const float4& a) { *reinterpret_cast<float4*>(p) = a; }
+__device__ __forceinline__ void enc_st4(enc_bf16* p, const float4& a) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  const bf2 lo = {(__bf16)a.x, (__bf16)a.y}, hi = {(__bf16)a.z, (__bf16)a.w};
+  uint2 o;
+  o.x = *reinterpret_cast<const uint32_t*>(&lo); o.y = *reinterpret_cast<const uint32_t*>(&hi);
+  *reinterpret_cast<uint2*>(p) = o;
+}
 
 static constexpr int ENC_IF = 32;                        // input features (16 joints x 2)
 static constexpr int ENC_XN = ENC_IF + ENC_IF * ENC_IF;  // colsum(x) | X^T X
@@ -47,7 +75,8 @@ static constexpr int ENC_XROWS = 256;                    // rows per block of en
 // cores: per 4 rows both operands are the same registers — A = x^T (lane: feature n + 16 h, row 4 s + q), B = x
 // (lane: row 4 s + q, feature n + 16 h') — 4 MFMAs per 4 rows.  (The first form used fp64 vector FMAs from an LDS
 // copy, four dependent staging rounds per block: 21-28 us.)
-__global__ __launch_bounds__(256) void enc_xstats_kernel(const float* __restrict__ x, int64_t batch, int rows_per_block,
+template <typename TX>
+__global__ __launch_bounds__(256) void enc_xstats_kernel(const TX* __restrict__ x, int64_t batch, int rows_per_block,
                                                          float* __restrict__ xpart) {
   __shared__ float red[4][ENC_XN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -62,10 +91,10 @@ __global__ __launch_bounds__(256) void enc_xstats_kernel(const float* __restrict
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
       const int64_t row = base + 4 * st + q;
-      const float* xr = x + min(row, batch - 1) * ENC_IF + n;
+      const TX* xr = x + min(row, batch - 1) * ENC_IF + n;
       const bool ok = row < r1;
-      xv[st][0] = ok ? xr[0] : 0.f;
-      xv[st][1] = ok ? xr[16] : 0.f;
+      xv[st][0] = ok ? enc_ld1(xr) : 0.f;
+      xv[st][1] = ok ? enc_ld1(xr + 16) : 0.f;
     }
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
@@ -95,9 +124,10 @@ __global__ __launch_bounds__(256) void enc_xstats_kernel(const float* __restrict
 // Sums the partials and finishes BatchNorm's forward statistics of 16 columns per block (thread = column t >> 4,
 // features g = t & 15 and g + 16); leaves for the backward, per column, T[col][f] = (z^T X)[col][f] =
 // sum_k W0[col][k] XtX[k][f] + b0[col] xs[f] and zs[col] = sum of z over the batch, and xs[32] (block 0).
+template <typename TW>
 __global__ __launch_bounds__(256) void enc_bn_finalize_kernel(
     const float* __restrict__ xpart, int nparts, float* __restrict__ xs_out, float* __restrict__ ttab,
-    float* __restrict__ zs_out, const float* __restrict__ W0, const float* __restrict__ b0, int64_t batch, int W,
+    float* __restrict__ zs_out, const TW* __restrict__ W0, const float* __restrict__ b0, int64_t batch, int W,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean, float* running_var,
     const int64_t* nbt, float momentum, float* saved_mean, float* saved_invstd, float* scale, float* shift) {
   __shared__ double xs[ENC_XN];
@@ -130,11 +160,11 @@ __global__ __launch_bounds__(256) void enc_bn_finalize_kernel(
   if (blockIdx.x == 0 && t < ENC_IF) xs_out[t] = (float)xs[t];
   const int col = blockIdx.x * 16 + (t >> 4), g = t & 15;
   const bool ok = col < W;
-  const float* w = W0 + (int64_t)(ok ? col : 0) * ENC_IF;
+  const TW* w = W0 + (int64_t)(ok ? col : 0) * ENC_IF;
   float wr[ENC_IF];
 #pragma unroll
   for (int k = 0; k < ENC_IF; k += 4) {
-    const float4 v = *reinterpret_cast<const float4*>(w + k);
+    const float4 v = enc_ld4(w + k);
     wr[k] = v.x; wr[k + 1] = v.y; wr[k + 2] = v.z; wr[k + 3] = v.w;
   }
   const double b = ok ? (double)b0[col] : 0.0, B = (double)batch;
@@ -145,7 +175,7 @@ __global__ __launch_bounds__(256) void enc_bn_finalize_kernel(
     u0 = fma((double)wr[k], xs[ENC_IF + k * ENC_IF + g], u0);
     u1 = fma((double)wr[k], xs[ENC_IF + k * ENC_IF + g + 16], u1);
   }
-  const double wf0 = ok ? (double)w[g] : 0.0, wf1 = ok ? (double)w[g + 16] : 0.0;     // this thread's features
+  const double wf0 = ok ? (double)enc_ld1(w + g) : 0.0, wf1 = ok ? (double)enc_ld1(w + g + 16) : 0.0;     // this thread's features
   double quad = wf0 * u0 + wf1 * u1, dot = wf0 * xs[g] + wf1 * xs[g + 16];
 #pragma unroll
   for (int o = 8; o >= 1; o >>= 1) { quad += __shfl_xor(quad, o); dot += __shfl_xor(dot, o); }
@@ -163,29 +193,39 @@ __global__ __launch_bounds__(256) void enc_bn_finalize_kernel(
 }
 
 // ---- operands shared by the forward and the backward kernel ---------------------------------------------------
+// A lane owns CPL consecutive columns: 4 with fp32 storage (one float4 per row), 8 with bf16 storage (16 bytes per
+// row as well — with 4 columns a bf16 lane moved 8 bytes per access and the forward took 26 us for 33.5 MB).
+template <int CPL>
 struct EncCols {
-  float4 wb[4][2];     // W0 rows c0 + 4 n + jj, k = 16 h + 4 q .. + 3
-  float4 bias, sc, sh; // columns c0 + 4 n .. + 3
+  float4 wb[CPL][2];                 // W0 rows col + jj, k = 16 h + 4 q .. + 3
+  float bias[CPL], sc[CPL], sh[CPL]; // columns col .. col + CPL - 1
 };
-__device__ __forceinline__ void enc_load_cols(EncCols& c, const float* __restrict__ W0, const float* __restrict__ b0,
+template <int CPL, typename TW>
+__device__ __forceinline__ void enc_load_cols(EncCols<CPL>& c, const TW* __restrict__ W0, const float* __restrict__ b0,
                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                               int col, int q) {
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj)
+  for (int jj = 0; jj < CPL; ++jj)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
-      c.wb[jj][h] = *reinterpret_cast<const float4*>(W0 + (int64_t)(col + jj) * ENC_IF + 16 * h + 4 * q);
-  c.bias = *reinterpret_cast<const float4*>(b0 + col);
-  c.sc = *reinterpret_cast<const float4*>(scale + col);
-  c.sh = *reinterpret_cast<const float4*>(shift + col);
+      c.wb[jj][h] = enc_ld4(W0 + (int64_t)(col + jj) * ENC_IF + 16 * h + 4 * q);
+#pragma unroll
+  for (int jj = 0; jj < CPL; jj += 4) {
+    const float4 bv = *reinterpret_cast<const float4*>(b0 + col + jj), sv = *reinterpret_cast<const float4*>(scale + col + jj),
+                 hv = *reinterpret_cast<const float4*>(shift + col + jj);
+    c.bias[jj] = bv.x; c.bias[jj + 1] = bv.y; c.bias[jj + 2] = bv.z; c.bias[jj + 3] = bv.w;
+    c.sc[jj] = sv.x; c.sc[jj + 1] = sv.y; c.sc[jj + 2] = sv.z; c.sc[jj + 3] = sv.w;
+    c.sh[jj] = hv.x; c.sh[jj + 1] = hv.y; c.sh[jj + 2] = hv.z; c.sh[jj + 3] = hv.w;
+  }
 }
 // z of the 16-row tile at `base`: zt[jj][reg] = row base + 4 q + reg, column col + jj (without the bias)
-__device__ __forceinline__ void enc_z_tile(encf4 (&zt)[4], const EncCols& c, const float* __restrict__ x, int64_t base,
-                                           int64_t batch, int n, int q) {
-  const float* xr = x + min(base + n, batch - 1) * ENC_IF + 4 * q;
-  const float4 xa0 = *reinterpret_cast<const float4*>(xr), xa1 = *reinterpret_cast<const float4*>(xr + 16);
+template <int CPL, typename TX>
+__device__ __forceinline__ void enc_z_tile(encf4 (&zt)[CPL], const EncCols<CPL>& c, const TX* __restrict__ x,
+                                           int64_t base, int64_t batch, int n, int q) {
+  const TX* xr = x + min(base + n, batch - 1) * ENC_IF + 4 * q;
+  const float4 xa0 = enc_ld4(xr), xa1 = enc_ld4(xr + 16);
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
+  for (int jj = 0; jj < CPL; ++jj) {
     encf4 a = encf4{0.f, 0.f, 0.f, 0.f};
     a = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0.x, c.wb[jj][0].x, a, 0, 0, 0);
     a = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0.y, c.wb[jj][0].y, a, 0, 0, 0);
@@ -198,118 +238,174 @@ __device__ __forceinline__ void enc_z_tile(encf4 (&zt)[4], const EncCols& c, con
     zt[jj] = a;
   }
 }
+// CPL values of one row, 16 bytes: a float4 (fp32 storage) or 8 bf16 (bf16 storage)
+__device__ __forceinline__ void enc_st_row(float* p, const float (&a)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(a[0], a[1], a[2], a[3]);
+}
+__device__ __forceinline__ void enc_st_row(enc_bf16* p, const float (&a)[8]) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  uint4 o;
+  const bf2 v0 = {(__bf16)a[0], (__bf16)a[1]}, v1 = {(__bf16)a[2], (__bf16)a[3]}, v2 = {(__bf16)a[4], (__bf16)a[5]},
+            v3 = {(__bf16)a[6], (__bf16)a[7]};
+  o.x = *reinterpret_cast<const uint32_t*>(&v0); o.y = *reinterpret_cast<const uint32_t*>(&v1);
+  o.z = *reinterpret_cast<const uint32_t*>(&v2); o.w = *reinterpret_cast<const uint32_t*>(&v3);
+  *reinterpret_cast<uint4*>(p) = o;
+}
+__device__ __forceinline__ void enc_ld_row(const float* p, float (&a)[4]) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+}
+__device__ __forceinline__ void enc_ld_row(const enc_bf16* p, float (&a)[8]) {
+  const uint4 v = *reinterpret_cast<const uint4*>(p);
+  a[0] = __uint_as_float(v.x << 16); a[1] = __uint_as_float(v.x & 0xffff0000u);
+  a[2] = __uint_as_float(v.y << 16); a[3] = __uint_as_float(v.y & 0xffff0000u);
+  a[4] = __uint_as_float(v.z << 16); a[5] = __uint_as_float(v.z & 0xffff0000u);
+  a[6] = __uint_as_float(v.w << 16); a[7] = __uint_as_float(v.w & 0xffff0000u);
+}
 
 // ---- forward: x -> A0 (+ keep bits) ----------------------------------------------------------------------------
-// block = 4 waves x 64 columns = 256 columns; the block's rows [blockIdx.y * rows_per_block, ...) in 16-row tiles
-__global__ __launch_bounds__(256) void enc_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W0,
+// block = 4 waves x 16 CPL columns; the block's rows [blockIdx.y * rows_per_block, ...) in 16-row tiles.
+// Keep-bit words: fp32 storage [B/8][W/4] (nibble j = row 8 g + j, bit c = column 4 (col/4) + c: bn_f32.hip) — a lane's
+// 4 rows x 4 columns are half a word, the other half is lane l ^ 16; bf16 storage [B/4][W/8] (byte j = row 4 g + j,
+// bit c = column 8 (col/8) + c: bn_bf16.hip) — a lane's 4 rows x 8 columns are exactly one word.
+template <bool H>
+__global__ __launch_bounds__(256) void enc_fwd_kernel(const typename EncT<H>::T* __restrict__ x,
+                                                      const typename EncT<H>::T* __restrict__ W0,
                                                       const float* __restrict__ b0, const float* __restrict__ scale,
-                                                      const float* __restrict__ shift, float* __restrict__ A,
+                                                      const float* __restrict__ shift,
+                                                      typename EncT<H>::T* __restrict__ A,
                                                       uint32_t* __restrict__ keepbits, int64_t batch, int W,
                                                       int rows_per_block, DropoutSrc drop, int64_t* nbt) {
+  constexpr int CPL = H ? 8 : 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
-  const int col = blockIdx.x * 256 + wave * 64 + 4 * n;
+  const int col = (blockIdx.x * 4 + wave) * (16 * CPL) + CPL * n;
   if (nbt && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) nbt[0] += 1;
-  EncCols c;
-  enc_load_cols(c, W0, b0, scale, shift, col, q);
-  const int W4 = W >> 2;
+  EncCols<CPL> c;
+  enc_load_cols<CPL>(c, W0, b0, scale, shift, col, q);
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;      // a multiple of 32
   const int64_t r1 = min(batch, r0 + rows_per_block);
   for (int64_t base = r0; base < r1; base += 16) {
-    encf4 zt[4];
-    enc_z_tile(zt, c, x, base, batch, n, q);
-    // keep word of the 8-row group of this lane's rows (rows base + 4 q .. + 3 are its low or high half)
+    encf4 zt[CPL];
+    enc_z_tile<CPL>(zt, c, x, base, batch, n, q);
+    // Philox / mask bits of the 8-row group this lane's rows belong to (nibble 4 (q & 1) + reg = row base + 4 q + reg),
+    // one word per 4 columns
     const int64_t rg = base + 8 * (q >> 1);
-    const uint32_t kw = f2_keep_word(drop, base & ~(int64_t)31, (int)((rg >> 3) & 3), col, W, batch);
-    uint32_t gate = 0;                               // [y > 0] of this lane's 4 rows x 4 columns, at their bits of the word
+    uint32_t kw[CPL / 4];
+#pragma unroll
+    for (int w4 = 0; w4 < CPL / 4; ++w4)
+      kw[w4] = f2_keep_word(drop, base & ~(int64_t)31, (int)((rg >> 3) & 3), col + 4 * w4, W, batch);
+    uint32_t word = 0;            // keep AND [y > 0]: fp32: nibble reg of this lane's half word; bf16: byte reg
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int64_t row = base + 4 * q + reg;
-      const int sh4 = 4 * (4 * (q & 1) + reg);
-      const uint32_t nib = kw >> sh4;
-      float4 a;
-      a.x = fmaxf(fmaf(zt[0][reg] + c.bias.x, c.sc.x, c.sh.x), 0.f);
-      a.y = fmaxf(fmaf(zt[1][reg] + c.bias.y, c.sc.y, c.sh.y), 0.f);
-      a.z = fmaxf(fmaf(zt[2][reg] + c.bias.z, c.sc.z, c.sh.z), 0.f);
-      a.w = fmaxf(fmaf(zt[3][reg] + c.bias.w, c.sc.w, c.sh.w), 0.f);
-      gate |= ((a.x > 0.f ? 1u : 0u) | (a.y > 0.f ? 2u : 0u) | (a.z > 0.f ? 4u : 0u) | (a.w > 0.f ? 8u : 0u)) << sh4;
-      a.x = (nib & 1u) ? a.x * 2.f : 0.f; a.y = (nib & 2u) ? a.y * 2.f : 0.f;
-      a.z = (nib & 4u) ? a.z * 2.f : 0.f; a.w = (nib & 8u) ? a.w * 2.f : 0.f;
-      if (row < batch) *reinterpret_cast<float4*>(A + row * W + col) = a;
+      uint32_t keep = 0, gate = 0;
+      float a[CPL];
+#pragma unroll
+      for (int jj = 0; jj < CPL; ++jj) {
+        float z = zt[jj][reg] + c.bias[jj];
+        if (H) z = enc_round_bf16(z);
+        const float y = fmaxf(fmaf(z, c.sc[jj], c.sh[jj]), 0.f);
+        const uint32_t k = (kw[jj >> 2] >> (4 * (4 * (q & 1) + reg) + (jj & 3))) & 1u;
+        keep |= k << jj;
+        gate |= (y > 0.f ? 1u : 0u) << jj;
+        a[jj] = k ? y * 2.f : 0.f;
+      }
+      word |= (keep & gate) << (CPL * reg);
+      if (row < batch) enc_st_row(A + row * W + col, a);
     }
-    // the stage's "keep" bits for the backward: keep AND [y > 0] (the other half of the word: lane l ^ 16)
-    gate |= __shfl_xor(gate, 16);
-    if ((q & 1) == 0 && rg < batch) keepbits[(rg >> 3) * W4 + (col >> 2)] = kw & gate;
+    if (!H) {
+      const uint32_t full = (word << (16 * (q & 1))) | (__shfl_xor(word, 16) << (16 * ((q & 1) ^ 1)));
+      if ((q & 1) == 0 && rg < batch) keepbits[(rg >> 3) * (W >> 2) + (col >> 2)] = full;
+    } else {
+      const int64_t rg4 = base + 4 * q;
+      if (rg4 < batch) keepbits[(rg4 >> 2) * (W >> 3) + (col >> 3)] = word;
+    }
   }
 }
 
 // ---- backward: dA0 -> S2 = sum dY' and P = dY'^T X, partials per row block ------------------------------------------
-// block = 4 waves on the SAME 64 columns, wave w takes the 16-row tiles w, w + 4, ... of the block's rows
-__global__ __launch_bounds__(256) void enc_bwd_kernel(const float* __restrict__ dA, const float* __restrict__ x,
+// block = 4 waves on the SAME 16 CPL columns, wave w takes the 16-row tiles w, w + 4, ... of the block's rows
+template <bool H>
+__global__ __launch_bounds__(256) void enc_bwd_kernel(const typename EncT<H>::T* __restrict__ dA,
+                                                      const typename EncT<H>::T* __restrict__ x,
                                                       const uint32_t* __restrict__ gatebits, float* __restrict__ s2part,
                                                       float* __restrict__ ppart, int64_t batch, int W,
                                                       int rows_per_block) {
+  constexpr int CPL = H ? 8 : 4, BC = 16 * CPL;
   __builtin_amdgcn_s_setprio(3);
-  // 9 KiB of LDS: the kernel has to fit BESIDE a workgroup of the side stream's weight-gradient GEMM (128 KiB of the
-  // CU's 160) — with a 32 KiB buffer per block its workgroups waited for the GEMM's to retire: 75 us
-  __shared__ __attribute__((aligned(16))) float red[64 * ENC_IF];        // [64 columns][32 features], waves add in turn
-  __shared__ float sred[4][64];
+  // 9 KiB of LDS (fp32 storage): the kernel has to fit BESIDE a workgroup of the side stream's weight-gradient GEMM
+  // (128 KiB of the CU's 160) — with a 32 KiB buffer per block its workgroups waited for the GEMM's to retire: 75 us
+  __shared__ __attribute__((aligned(16))) float red[BC * ENC_IF];        // [columns][32 features], waves add in turn
+  __shared__ float sred[4][BC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
-  const int c0 = blockIdx.x * 64;
-  const int col = c0 + 4 * n;
-  const int W4 = W >> 2;
+  const int c0 = blockIdx.x * BC;
+  const int col = c0 + CPL * n;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = min(batch, r0 + rows_per_block);
-  encf4 pacc[4][2];
+  encf4 pacc[CPL][2];
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) pacc[jj][0] = pacc[jj][1] = encf4{0.f, 0.f, 0.f, 0.f};
-  float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int jj = 0; jj < CPL; ++jj) pacc[jj][0] = pacc[jj][1] = encf4{0.f, 0.f, 0.f, 0.f};
+  float s2[CPL];
+#pragma unroll
+  for (int jj = 0; jj < CPL; ++jj) s2[jj] = 0.f;
   for (int64_t base = r0 + 16 * wave; base < r1; base += 64) {
-    float4 g[4];
+    float g[4][CPL];
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg)
-      g[reg] = *reinterpret_cast<const float4*>(dA + min(base + 4 * q + reg, batch - 1) * W + col);
-    const int64_t rg = base + 8 * (q >> 1);
-    const uint32_t kw = rg < batch ? gatebits[(rg >> 3) * W4 + (col >> 2)] : 0u;
+    for (int reg = 0; reg < 4; ++reg) enc_ld_row(dA + min(base + 4 * q + reg, batch - 1) * W + col, g[reg]);
+    // this lane's keep-and-gate bits: CPL bits per row at bit CPL * reg
+    uint32_t bits = 0;
+    if (!H) {
+      const int64_t rg = base + 8 * (q >> 1);
+      const uint32_t kw = rg < batch ? gatebits[(rg >> 3) * (W >> 2) + (col >> 2)] : 0u;
+      bits = (kw >> (16 * (q & 1))) & 0xFFFFu;
+    } else {
+      const int64_t rg4 = base + 4 * q;
+      bits = rg4 < batch ? gatebits[(rg4 >> 2) * (W >> 3) + (col >> 3)] : 0u;
+    }
     // x^T operand: feature 16 h + n of row base + 4 q + reg
     float xt[4][2];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const float* xr = x + min(base + 4 * q + reg, batch - 1) * ENC_IF + n;
-      xt[reg][0] = xr[0]; xt[reg][1] = xr[16];
+      const typename EncT<H>::T* xr = x + min(base + 4 * q + reg, batch - 1) * ENC_IF + n;
+      xt[reg][0] = enc_ld1(xr); xt[reg][1] = enc_ld1(xr + 16);
     }
-    encf4 dy[4];                                   // dy[jj][reg]: row base + 4 q + reg, column col + jj
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const uint32_t nib = (base + 4 * q + reg < batch) ? (kw >> (4 * (4 * (q & 1) + reg))) : 0u;
-      const float dx = (nib & 1u) ? g[reg].x * 2.f : 0.f, dyv = (nib & 2u) ? g[reg].y * 2.f : 0.f;
-      const float dz = (nib & 4u) ? g[reg].z * 2.f : 0.f, dw = (nib & 8u) ? g[reg].w * 2.f : 0.f;
-      s2.x += dx; s2.y += dyv; s2.z += dz; s2.w += dw;
-      dy[0][reg] = dx; dy[1][reg] = dyv; dy[2][reg] = dz; dy[3][reg] = dw;
+      const uint32_t rb = (base + 4 * q + reg < batch) ? (bits >> (CPL * reg)) : 0u;
+#pragma unroll
+      for (int jj = 0; jj < CPL; ++jj) {
+        const float dy = ((rb >> jj) & 1u) ? g[reg][jj] * 2.f : 0.f;     // dY' = 2 keep [y > 0] dA
+        s2[jj] += dy;
+        g[reg][jj] = dy;
+      }
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        pacc[jj][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[reg][0], dy[jj][reg], pacc[jj][0], 0, 0, 0);
-        pacc[jj][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[reg][1], dy[jj][reg], pacc[jj][1], 0, 0, 0);
+      for (int jj = 0; jj < CPL; ++jj) {
+        pacc[jj][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[reg][0], g[reg][jj], pacc[jj][0], 0, 0, 0);
+        pacc[jj][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[reg][1], g[reg][jj], pacc[jj][1], 0, 0, 0);
       }
   }
   // column sums over the lane groups q (rows), then over the four waves
-  s2.x += __shfl_xor(s2.x, 16); s2.y += __shfl_xor(s2.y, 16); s2.z += __shfl_xor(s2.z, 16); s2.w += __shfl_xor(s2.w, 16);
-  s2.x += __shfl_xor(s2.x, 32); s2.y += __shfl_xor(s2.y, 32); s2.z += __shfl_xor(s2.z, 32); s2.w += __shfl_xor(s2.w, 32);
-  if (q == 0) *reinterpret_cast<float4*>(&sred[wave][4 * n]) = s2;
-  // pacc[jj][h][reg'] = (dY'^T X)[column c0 + 4 n + jj][feature 16 h + 4 q + reg']: the four waves add their tiles
-  // into one LDS image in a fixed order (every lane owns the same 8 float4 of it in each wave)
+#pragma unroll
+  for (int jj = 0; jj < CPL; ++jj) {
+    s2[jj] += __shfl_xor(s2[jj], 16);
+    s2[jj] += __shfl_xor(s2[jj], 32);
+    if (q == 0) sred[wave][CPL * n + jj] = s2[jj];
+  }
+  // pacc[jj][h][reg'] = (dY'^T X)[column col + jj][feature 16 h + 4 q + reg']: the four waves add their tiles
+  // into one LDS image in a fixed order (every lane owns the same float4s of it in each wave)
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
+      for (int jj = 0; jj < CPL; ++jj)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          float4* dst = reinterpret_cast<float4*>(&red[(4 * n + jj) * ENC_IF + 16 * h + 4 * q]);
+          float4* dst = reinterpret_cast<float4*>(&red[(CPL * n + jj) * ENC_IF + 16 * h + 4 * q]);
           float4 v = make_float4(pacc[jj][h][0], pacc[jj][h][1], pacc[jj][h][2], pacc[jj][h][3]);
           if (w > 0) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
           *dst = v;
@@ -318,9 +414,9 @@ __global__ __launch_bounds__(256) void enc_bwd_kernel(const float* __restrict__ 
     __syncthreads();
   }
   const int t = threadIdx.x;
-  if (t < 64) s2part[(int64_t)blockIdx.y * W + c0 + t] = (sred[0][t] + sred[1][t]) + (sred[2][t] + sred[3][t]);
+  if (t < BC) s2part[(int64_t)blockIdx.y * W + c0 + t] = (sred[0][t] + sred[1][t]) + (sred[2][t] + sred[3][t]);
   float* pp = ppart + ((int64_t)blockIdx.y * W + c0) * ENC_IF;
-  for (int e = t; e < 64 * ENC_IF / 4; e += 256)
+  for (int e = t; e < BC * ENC_IF / 4; e += 256)
     *reinterpret_cast<float4*>(pp + 4 * e) = *reinterpret_cast<const float4*>(&red[4 * e]);
 }
 
@@ -328,9 +424,10 @@ __global__ __launch_bounds__(256) void enc_bwd_kernel(const float* __restrict__ 
 // block = 16 columns x 32 features.  It runs beside the side stream's weight-gradient GEMM, where every vector
 // instruction waits for an issue slot the GEMM leaves: everything that does not depend on the gradient — z^T X, the
 // sum of z — was left by the forward (enc_bn_finalize); the first form computed it here and took 50 us.
+template <typename TW>
 __global__ __launch_bounds__(512) void enc_bwd_finish_kernel(
     const float* __restrict__ ppart, const float* __restrict__ s2part, int nrb, const float* __restrict__ xs,
-    const float* __restrict__ ttab, const float* __restrict__ zs, const float* __restrict__ W0,
+    const float* __restrict__ ttab, const float* __restrict__ zs, const TW* __restrict__ W0,
     const float* __restrict__ b0, const float* __restrict__ saved, int64_t batch, int W, float* __restrict__ dW0,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ db_rows, int db_nrows,
     double* __restrict__ sq_w, double* __restrict__ sq_gb) {
@@ -340,7 +437,7 @@ __global__ __launch_bounds__(512) void enc_bwd_finish_kernel(
   const int col = blockIdx.x * 16 + (t >> 5), f = t & 31;
   double q2w = 0.0, q2g = 0.0;
   if (col < W) {        // (whole 32-lane groups: the shuffles below stay inside a column)
-    const float wf = W0[(int64_t)col * ENC_IF + f], tf = ttab[(int64_t)col * ENC_IF + f], xf = xs[f];
+    const float wf = enc_ld1(W0 + (int64_t)col * ENC_IF + f), tf = ttab[(int64_t)col * ENC_IF + f], xf = xs[f];
     const float bcol = b0[col], zsc = zs[col];
     const float mean_f = saved[col], invstd_f = saved[W + col], scale_f = saved[2 * W + col];
     double P = 0.0, S2 = 0.0;
@@ -421,38 +518,77 @@ bool enc_fused_supported(int64_t batch, int W, int in_features) {
   return in_features == ENC_IF && W % 256 == 0 && batch >= 64 && enc_scratch(nullptr, batch, W).floats <= batch * (int64_t)W;
 }
 
-int launch_enc_forward(hipStream_t s, const float* x, const float* W0, const float* b0, const float* gamma,
-                       const float* beta, float* running_mean, float* running_var, int64_t* nbt, float momentum,
-                       float* saved, float* z0_scratch, float* A, uint32_t* keepbits, int64_t batch, int W,
-                       const DropoutSrc& drop) {
-  if (!enc_fused_supported(batch, W, ENC_IF)) return BLH_ERR_SHAPE;
-  const EncScratch e = enc_scratch(z0_scratch, batch, W);
+template <bool H>
+static int enc_forward_t(hipStream_t s, const typename EncT<H>::T* x, const typename EncT<H>::T* W0, const float* b0,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t* nbt,
+                         float momentum, float* saved, float* scratch, typename EncT<H>::T* A, uint32_t* keepbits,
+                         int64_t batch, int W, const DropoutSrc& drop) {
+  typedef typename EncT<H>::T T;
+  const EncScratch e = enc_scratch(scratch, batch, W);
   const int xrows = (int)(ENC_XROWS * ceil_div(batch, (int64_t)ENC_XROWS * ENC_XBLOCKS));
   const int xblocks = (int)ceil_div(batch, xrows);
-  hipLaunchKernelGGL(enc_xstats_kernel, dim3(xblocks), dim3(256), 0, s, x, batch, xrows, e.xpart);
-  hipLaunchKernelGGL(enc_bn_finalize_kernel, dim3((unsigned)ceil_div(W, 16)), dim3(256), 0, s, e.xpart, xblocks, e.xs,
+  hipLaunchKernelGGL(enc_xstats_kernel<T>, dim3(xblocks), dim3(256), 0, s, x, batch, xrows, e.xpart);
+  hipLaunchKernelGGL(enc_bn_finalize_kernel<T>, dim3((unsigned)ceil_div(W, 16)), dim3(256), 0, s, e.xpart, xblocks, e.xs,
                      e.ttab, e.zs, W0, b0, batch, W, gamma, beta, running_mean, running_var, nbt, momentum, saved,
                      saved + W, saved + 2 * W, saved + 3 * W);
   const int rows = enc_fwd_rows(batch);
-  hipLaunchKernelGGL(enc_fwd_kernel, dim3(W / 256, (unsigned)ceil_div(batch, rows)), dim3(256), 0, s, x, W0, b0,
+  hipLaunchKernelGGL(enc_fwd_kernel<H>, dim3(W / (H ? 512 : 256), (unsigned)ceil_div(batch, rows)), dim3(256), 0, s, x, W0, b0,
                      saved + 2 * W, saved + 3 * W, A, keepbits, batch, W, rows, drop, nbt);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
 
+template <bool H>
+static int enc_backward_t(hipStream_t s, const typename EncT<H>::T* dA, const typename EncT<H>::T* x,
+                          const typename EncT<H>::T* W0, const float* b0, const float* saved, const uint32_t* gatebits,
+                          float* scratch, int64_t batch, int W, float* dW0, float* dgamma, float* dbeta,
+                          float* db_rows, int db_nrows, double* sq_w, double* sq_gb) {
+  typedef typename EncT<H>::T T;
+  const EncScratch e = enc_scratch(scratch, batch, W);
+  const int rows = enc_bwd_rows(batch);
+  hipLaunchKernelGGL(enc_bwd_kernel<H>, dim3(W / (H ? 128 : 64), (unsigned)ceil_div(batch, rows)), dim3(256), 0, s, dA, x, gatebits,
+                     e.s2part, e.ppart, batch, W, rows);
+  hipLaunchKernelGGL(enc_bwd_finish_kernel<T>, dim3((unsigned)enc_bwd_finish_blocks(W)), dim3(512), 0, s, e.ppart,
+                     e.s2part, enc_bwd_row_blocks(batch), e.xs, e.ttab, e.zs, W0, b0, saved, batch, W, dW0, dgamma, dbeta,
+                     db_rows, db_nrows, sq_w, sq_gb);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+int launch_enc_forward(hipStream_t s, const float* x, const float* W0, const float* b0, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, int64_t* nbt, float momentum,
+                       float* saved, float* z0_scratch, float* A, uint32_t* keepbits, int64_t batch, int W,
+                       const DropoutSrc& drop) {
+  if (!enc_fused_supported(batch, W, ENC_IF)) return BLH_ERR_SHAPE;
+  return enc_forward_t<false>(s, x, W0, b0, gamma, beta, running_mean, running_var, nbt, momentum, saved, z0_scratch, A,
+                              keepbits, batch, W, drop);
+}
 int launch_enc_backward(hipStream_t s, const float* dA, const float* x, const float* W0, const float* b0,
                         const float* saved, const uint32_t* gatebits, float* z0_scratch, int64_t batch, int W,
                         float* dW0, float* dgamma, float* dbeta, float* db_rows, int db_nrows, double* sq_w,
                         double* sq_gb) {
-  const EncScratch e = enc_scratch(z0_scratch, batch, W);
-  const int rows = enc_bwd_rows(batch);
-  hipLaunchKernelGGL(enc_bwd_kernel, dim3(W / 64, (unsigned)ceil_div(batch, rows)), dim3(256), 0, s, dA, x, gatebits,
-                     e.s2part, e.ppart, batch, W, rows);
-  hipLaunchKernelGGL(enc_bwd_finish_kernel, dim3((unsigned)enc_bwd_finish_blocks(W)), dim3(512), 0, s, e.ppart, e.s2part,
-                     enc_bwd_row_blocks(batch), e.xs, e.ttab, e.zs, W0, b0, saved, batch, W, dW0, dgamma, dbeta, db_rows,
-                     db_nrows, sq_w, sq_gb);
-  BLH_HIP_TRY(hipGetLastError());
-  return BLH_OK;
+  return enc_backward_t<false>(s, dA, x, W0, b0, saved, gatebits, z0_scratch, batch, W, dW0, dgamma, dbeta, db_rows,
+                               db_nrows, sq_w, sq_gb);
+}
+
+// bf16 storage: the scratch is the stage's (unused) bf16 Z0 buffer, batch * W / 2 floats
+bool enc_fused_supported_h(int64_t batch, int W, int in_features) {
+  return in_features == ENC_IF && W % 512 == 0 && batch >= 64 &&
+         enc_scratch(nullptr, batch, W).floats <= batch * (int64_t)W / 2;
+}
+int launch_enc_forward_h(hipStream_t s, const uint16_t* xh, const uint16_t* W0h, const float* b0, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, int64_t* nbt, float momentum,
+                         float* saved, uint16_t* z0_scratch, uint16_t* A, uint32_t* keepbits, int64_t batch, int W,
+                         const DropoutSrc& drop) {
+  if (!enc_fused_supported_h(batch, W, ENC_IF)) return BLH_ERR_SHAPE;
+  return enc_forward_t<true>(s, xh, W0h, b0, gamma, beta, running_mean, running_var, nbt, momentum, saved,
+                             reinterpret_cast<float*>(z0_scratch), A, keepbits, batch, W, drop);
+}
+int launch_enc_backward_h(hipStream_t s, const uint16_t* dA, const uint16_t* xh, const uint16_t* W0h, const float* b0,
+                          const float* saved, const uint32_t* gatebits, uint16_t* z0_scratch, int64_t batch, int W,
+                          float* dW0, float* dgamma, float* dbeta, float* db_rows, int db_nrows) {
+  return enc_backward_t<true>(s, dA, xh, W0h, b0, saved, gatebits, reinterpret_cast<float*>(z0_scratch), batch, W, dW0,
+                              dgamma, dbeta, db_rows, db_nrows, nullptr, nullptr);
 }
 
 }  // namespace blh

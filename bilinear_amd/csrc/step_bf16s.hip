@@ -11,6 +11,13 @@ namespace blh {
 // rounding), the parameters, their gradients (fp32 slabs of the weight-gradient GEMM), Adam and
 // the loss stay fp32.  Gradients need no loss scaling: bf16 keeps fp32's exponent range.
 // =================================================================================================
+// The encode stage without its pre-BatchNorm tensor (encode_f32.hip, bf16-storage form): per-rank statistics (SyncBN
+// exchanges tile sums of Z).  The same predicate in forward_h and backward_h: the forward leaves keep AND gate bits
+// and the sums of x where the backward expects them.
+static bool enc_fused_ok_h(const blh_context* ctx, const blh_model_desc* d, int64_t batch) {
+  return !ctx->sync.fn && !ctx->knob(KNOB_NO_ENCODE_FUSE) && enc_fused_supported_h(batch, d->width, d->in_features);
+}
+
 int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
                      float* bn_running, int64_t* nbt, const float* x, const blh_dropout* drop,
                      float momentum, const WorkspaceH& ws, float* pred, int64_t batch, bool train,
@@ -25,6 +32,13 @@ int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const fl
   else BLH_TRY(launch_cast_f32_bf16(s, x, ws.xh, batch * IF));
   for (int i = 0; i < nh; ++i) {
     const HeavyOffsets& h = L.heavy[i];
+    if (i == 0 && train && enc_fused_ok_h(ctx, d, batch)) {
+      // x statistics -> BatchNorm statistics -> A0 and the keep-and-gate bits; Z0's buffer serves as scratch
+      BLH_TRY(launch_enc_forward_h(s, ws.xh, ws.wsh + h.w, params + h.b, params + h.gamma, params + h.beta, bn_running,
+                                   bn_running + W, nbt, momentum, ws.bn_saved[0], ws.Z[0], ws.A[0], ws.keep[0], batch, W,
+                                   layer_drop(ctx, drop, 0, batch, W)));
+      continue;
+    }
     GemmParamsH g{};
     g.A = (i == 0) ? ws.xh : ws.A[i - 1]; g.lda = h.fan_in;
     g.B = ws.wsh + h.w; g.ldb = h.fan_in;
@@ -246,9 +260,24 @@ int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const f
   // epilogue (EPI_BN_BWD, big-tile kernels only): the stage below then skips bn_bwd_reduce_h2 and its
   // bn_bwd_apply_h2 reads no keep bits.  k9_chunks > 0: stage i's dA arrived that way, with that many partial rows.
   const bool k9_enabled = !ctx->knob(KNOB_NO_K9);
+  const bool enc_fused = enc_fused_ok_h(ctx, d, batch);
   int k9_chunks = 0;
   for (int i = nh - 1; i >= 0; --i) {
     const HeavyOffsets& h = L.heavy[i];
+    if (i == 0 && enc_fused) {
+      // Encode stage without Z0 (encode_f32.hip): one pass over dA0 (bf16) + the finish kernel, on the main stream
+      BLH_TRY(launch_enc_backward_h(s, ws.G0, ws.xh, ws.wsh + h.w, params + h.b, ws.bn_saved[0], ws.keep[0], ws.Z[0], batch,
+                                    W, grads + h.w, grads + h.gamma, grads + h.beta,
+                                    on_ready ? grads + h.b : ws.dz_colsum_part, on_ready ? 1 : chunks));
+      if (on_ready) {
+        if (ctx->two_stream) {     // (the range has to be complete on the side stream)
+          BLH_HIP_TRY(hipEventRecord(ctx->ev_r[0], s));
+          BLH_HIP_TRY(hipStreamWaitEvent(ctx->s2, ctx->ev_r[0], 0));
+        }
+        on_ready(user, h.w, ((1 < nh) ? L.heavy[1].w : L.dec_w) - h.w);
+      }
+      continue;
+    }
     const bool first_of_block = (i >= 1) && (i % 2 == 1);
     const uint16_t* dA = first_of_block ? ws.G1 : ws.G0;
     const float* sv = ws.bn_saved[i];
@@ -313,7 +342,8 @@ int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const f
       const int64_t k9_rows = ceil_div(batch, gemm_bf16s_tile_rows(tile));
       // (the addend form — stage 1 only — spills in the 256 x 256 kernel, which holds 128 accumulator registers
       //  through its epilogue: there stage 0 keeps the streaming reduction)
-      const bool k9 = k9_enabled && tile != H_TILE_128 && k9_rows <= chunks &&
+      // (stage 0 without Z0: nothing for the epilogue to gate against)
+      const bool k9 = k9_enabled && tile != H_TILE_128 && k9_rows <= chunks && !(i == 1 && enc_fused) &&
                       (!first_of_block || (i == 1 && tile == H_TILE_128x256));
       if (k9) {
         const float* svd = ws.bn_saved[i - 1];

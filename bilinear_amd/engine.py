@@ -612,4 +612,26 @@ class Engine:
         self._saved_batch = None
         if self.masks is None:
             self.rng_step += 1
+        self._barrier_watch(batch)
         return pred, loss
+
+    BARRIER_CHECK_EVERY = 512      # steps between two checks of the grid-barrier timeout counter (each one synchronises)
+
+    def _barrier_watch(self, batch):
+        """The persistent small-batch launches (set_small_step(2)) and the opt-in fused bf16 forward stage
+        (BLH_FWD_FUSE) synchronise their workgroups with grid barriers that give up after ~0.3 s when the grid is not
+        resident (another process, a side-stream GEMM or a collective holding CUs) — the step then continues with
+        wrong data.  The count is only readable with a device synchronisation, so it is checked on a cadence: a
+        non-zero count raises; the staged form (the default) has no barrier and is never checked."""
+        import os
+        if not ((self.ctx.get_option(N.OPT_SMALL_STEP) == 2 and batch <= 64) or os.environ.get("BLH_FWD_FUSE")):
+            return
+        self._barrier_steps = getattr(self, "_barrier_steps", 0) + 1
+        if self._barrier_steps % self.BARRIER_CHECK_EVERY:
+            return
+        n = int(N.lib().blh_context_grid_barrier_timeouts(self.ctx.handle))
+        if n:
+            raise RuntimeError("bilinear_amd: %d grid-barrier timeouts since the context was created: a persistent "
+                               "launch was not fully resident and its results are wrong.  Do not combine "
+                               "set_small_step(2) / BLH_FWD_FUSE with DataParallel, side-stream work or other "
+                               "processes on the device; the default staged kernels have no barrier." % n)

@@ -539,3 +539,57 @@ def test_persistent_shadow_is_bit_identical_and_invalidated_by_parameter_writes(
         b = run(True, captured)
         assert a[0] == b[0], (captured, a[0], b[0])
         assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), captured
+
+
+@pytest.mark.parametrize("nb,width,batch", [(2, 1024, 8192), (1, 1024, 4104), (1, 2048, 2048)])
+def test_bf16s_encode_stage_without_z0_matches_the_materialised_path(nb, width, batch):
+    """Round 5, bf16 storage: the encode stage runs without its pre-BatchNorm tensor (encode_f32.hip, bf16 form: x and
+    the W0 shadow are bf16, the batch statistics come from the sums of x, z is rounded to bf16 before BatchNorm
+    normalises it, A0 and the keep-and-gate bits go out in the bf16 layouts; the backward needs dA0, the bits and x).
+    Against BLH_NO_ENCODE_FUSE=1 (bf16 GEMM -> bn_fwd_finalize -> bn_apply_h2, streaming BatchNorm backward,
+    weight-gradient GEMM) on the same explicit masks: the two contract the same bf16 operands in another order, so a
+    few z round to the neighbouring bf16 value — predictions agree to 2e-3, gradients to the bf16 path's 2e-2, running
+    statistics to 1e-5 (they come from the unrounded z in both)."""
+    import os
+
+    import bilinear_amd
+    dev = _dev()
+    x = torch.randn(batch, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    t = torch.randn(batch, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    g = torch.Generator(device=dev).manual_seed(9)
+    masks = [(torch.rand(batch, width, device=dev, generator=g) < 0.5).to(torch.uint8) for _ in range(1 + 2 * nb)]
+    out = {}
+    for fused in (True, False):
+        if not fused:
+            os.environ["BLH_NO_ENCODE_FUSE"] = "1"
+        try:
+            torch.manual_seed(0)
+            net, opt, _, _ = bilinear_amd.load(dev, num_blocks=nb, width=width, gemm_dtype="bf16s")
+            net.train()
+            net.engine.ensure(dev)
+            net.engine.set_dropout_masks(masks)
+            opt.zero_grad()
+            pred = net(x)
+            torch.nn.functional.mse_loss(pred, t).backward()
+            torch.cuda.synchronize()
+            first = (pred.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()},
+                     net.engine.bn_running.clone(), net.engine.bn_nbt.clone())
+            for _ in range(2):
+                p2, loss = net.train_step(opt, x, t, max_norm=1.0)
+            torch.cuda.synchronize()
+            out[fused] = first + (p2.clone(), loss.clone(), net.engine.bn_running.clone())
+        finally:
+            os.environ.pop("BLH_NO_ENCODE_FUSE", None)
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+    a, b = out[True], out[False]
+    assert rel(a[0], b[0]) <= 2e-3, ("pred", rel(a[0], b[0]))
+    for k in a[1]:
+        if k.endswith(".0.bias") and not k.startswith("decode"):
+            continue
+        assert rel(a[1][k], b[1][k]) <= 2e-2, (k, rel(a[1][k], b[1][k]))
+    assert rel(a[2][0], b[2][0]) <= 1e-5 and torch.equal(a[3], b[3])        # stage 0's running statistics
+    assert abs(float(a[5]) - float(b[5])) <= 2e-3 * abs(float(b[5]))
+    assert torch.isfinite(a[4]).all() and rel(a[6][0], b[6][0]) <= 1e-4
