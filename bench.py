@@ -241,14 +241,14 @@ def skinny_rooflines(batch, width, reps):
     dropd = N2.Dropout(None, 1, 0, 0, 0, 0)
     db0, dg0, dbe0 = (torch.empty(W, device=dev) for _ in range(3))
     ops = [
-        ("encode_fused_fwd (x -> A0 + keep bits, BatchNorm statistics from the sums of x: 3 launches, no Z0: the "
-         "fp32 step's encode forward)", 4.0 * B * (IF + W) + B * W / 8.0,
+        ("encode_fused_fwd (x -> A0 + keep bits, BatchNorm statistics from the sums of x: 3 launches, no Z0; fp32 operands: the "
+         "exact-fp32 step's encode forward)", 4.0 * B * (IF + W) + B * W / 8.0,
          lambda: lib.blh_skinny_encode_fused_fwd(st, x.data_ptr(), W0.data_ptr(), b0.data_ptr(), gam.data_ptr(),
                                                  bet.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), nbt1.data_ptr(), 0.1,
                                                  saved.data_ptr(), scratch.data_ptr(), A0.data_ptr(), bits.data_ptr(),
                                                  ctypes.byref(dropd), B, W, IF)),
-        ("encode_fused_bwd (dA0 -> dW0, db0, dgamma, dbeta from dA0, the bits and x: 2 launches: the fp32 step's "
-         "encode backward)", 4.0 * B * (W + IF) + B * W / 8.0,
+        ("encode_fused_bwd (dA0 -> dW0, db0, dgamma, dbeta from dA0, the bits and x: 2 launches: fp32 operands; the exact-fp32 "
+         "step's encode backward)", 4.0 * B * (W + IF) + B * W / 8.0,
          lambda: lib.blh_skinny_encode_fused_bwd(st, A.data_ptr(), x.data_ptr(), W0.data_ptr(), b0.data_ptr(),
                                                  saved.data_ptr(), bits.data_ptr(), scratch.data_ptr(), dW0.data_ptr(),
                                                  db0.data_ptr(), dg0.data_ptr(), dbe0.data_ptr(), B, W, IF)),
@@ -259,7 +259,7 @@ def skinny_rooflines(batch, width, reps):
          lambda: lib.blh_skinny_decode_fwd_mse(st, A.data_ptr(), Wd.data_ptr(), bd.data_ptr(), t.data_ptr(),
                                                pred.data_ptr(), dpred.data_ptr(), None,
                                                ws.data_ptr(), wsb, B, W, OF)),
-        ("decode_fused (Linear %d->48 + MSE + dpred + dA = dP Wd from one read of A: the fused step's decode)" % W,
+        ("decode_fused (Linear %d->48 + MSE + dpred + dA = dP Wd from one read of A; fp32 operands: the exact-fp32 step's decode)" % W,
          4.0 * B * (2 * W + 3 * OF),
          lambda: lib.blh_skinny_decode_fused(st, A.data_ptr(), Wd.data_ptr(), bd.data_ptr(), t.data_ptr(),
                                              pred.data_ptr(), dpred.data_ptr(), dA.data_ptr(), None,

@@ -70,8 +70,11 @@ static constexpr int ENC_XBLOCKS = 64;                   // at most this many ro
 static constexpr int ENC_XROWS = 256;                    // rows per block of enc_xstats (a multiple of 128)
 
 // ---- x statistics -------------------------------------------------------------------------------------------
-// xpart[b][0 .. 31] = sum_r x[r][f], xpart[b][32 + a * 32 + c] = sum_r x[r][a] x[r][c] over the block's rows (fp32
-// sums of exact products over at most a few hundred rows; the partials are added in fp64).  X^T X on the matrix
+// Moments of y = x - c with c = row 0 of the batch (the shifted-data form: the variance below is a difference of
+// second moments, and moments of the raw x lose log2(1 + mean^2 / var) bits to that difference — inputs that are not
+// standardised would pay for it; any row of the batch is within a few standard deviations of the mean):
+// xpart[b][0 .. 31] = sum_r y[r][f], xpart[b][32 + a * 32 + c] = sum_r y[r][a] y[r][c] over the block's rows (fp32
+// sums over at most a few hundred rows; the partials are added in fp64).  Y^T Y on the matrix
 // cores: per 4 rows both operands are the same registers — A = x^T (lane: feature n + 16 h, row 4 s + q), B = x
 // (lane: row 4 s + q, feature n + 16 h') — 4 MFMAs per 4 rows.  (The first form used fp64 vector FMAs from an LDS
 // copy, four dependent staging rounds per block: 21-28 us.)
@@ -86,6 +89,7 @@ __global__ __launch_bounds__(256) void enc_xstats_kernel(const TX* __restrict__ 
   encf4 acc[2][2];
   acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = encf4{0.f, 0.f, 0.f, 0.f};
   float cs0 = 0.f, cs1 = 0.f;
+  const float c0 = enc_ld1(x + n), c1 = enc_ld1(x + 16 + n);          // the shift: row 0
   for (int64_t base = r0 + 32 * wave; base < r1; base += 128) {      // 8 steps of 4 rows per round, all loads first
     float xv[8][2];
 #pragma unroll
@@ -93,8 +97,8 @@ __global__ __launch_bounds__(256) void enc_xstats_kernel(const TX* __restrict__ 
       const int64_t row = base + 4 * st + q;
       const TX* xr = x + min(row, batch - 1) * ENC_IF + n;
       const bool ok = row < r1;
-      xv[st][0] = ok ? enc_ld1(xr) : 0.f;
-      xv[st][1] = ok ? enc_ld1(xr + 16) : 0.f;
+      xv[st][0] = ok ? enc_ld1(xr) - c0 : 0.f;
+      xv[st][1] = ok ? enc_ld1(xr + 16) - c1 : 0.f;
     }
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
@@ -124,14 +128,18 @@ __global__ __launch_bounds__(256) void enc_xstats_kernel(const TX* __restrict__ 
 // Sums the partials and finishes BatchNorm's forward statistics of 16 columns per block (thread = column t >> 4,
 // features g = t & 15 and g + 16); leaves for the backward, per column, T[col][f] = (z^T X)[col][f] =
 // sum_k W0[col][k] XtX[k][f] + b0[col] xs[f] and zs[col] = sum of z over the batch, and xs[32] (block 0).
+// With d = sum y, S = Y^T Y (y = x - c, enc_xstats):  xs = d + B c,  XtX = S + c d^T + d c^T + B c c^T,
+// sum (z - mean)^2 = w^T S w - (w . d)^2 / B  (neither c nor the bias appears in it).
 template <typename TW>
 __global__ __launch_bounds__(256) void enc_bn_finalize_kernel(
-    const float* __restrict__ xpart, int nparts, float* __restrict__ xs_out, float* __restrict__ ttab,
+    const TW* __restrict__ x, const float* __restrict__ xpart, int nparts, float* __restrict__ xs_out, float* __restrict__ ttab,
     float* __restrict__ zs_out, const TW* __restrict__ W0, const float* __restrict__ b0, int64_t batch, int W,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean, float* running_var,
     const int64_t* nbt, float momentum, float* saved_mean, float* saved_invstd, float* scale, float* shift) {
-  __shared__ double xs[ENC_XN];
+  __shared__ double xs[ENC_XN];      // d | S
+  __shared__ double cc[ENC_IF];      // c
   const int t = threadIdx.x;
+  if (t < ENC_IF) cc[t] = (double)enc_ld1(x + t);
   {
     // (the loads of 16 partials of all of the thread's entries are requested together: nparts / 16 round trips)
     constexpr int NE = (ENC_XN + 255) / 256;
@@ -157,7 +165,8 @@ __global__ __launch_bounds__(256) void enc_bn_finalize_kernel(
     }
   }
   __syncthreads();
-  if (blockIdx.x == 0 && t < ENC_IF) xs_out[t] = (float)xs[t];
+  const double B = (double)batch;
+  if (blockIdx.x == 0 && t < ENC_IF) xs_out[t] = (float)(xs[t] + B * cc[t]);
   const int col = blockIdx.x * 16 + (t >> 4), g = t & 15;
   const bool ok = col < W;
   const TW* w = W0 + (int64_t)(ok ? col : 0) * ENC_IF;
@@ -167,8 +176,8 @@ __global__ __launch_bounds__(256) void enc_bn_finalize_kernel(
     const float4 v = enc_ld4(w + k);
     wr[k] = v.x; wr[k + 1] = v.y; wr[k + 2] = v.z; wr[k + 3] = v.w;
   }
-  const double b = ok ? (double)b0[col] : 0.0, B = (double)batch;
-  // u[f] = sum_k w[k] XtX[k][f] for f = g, g + 16;   w^T XtX w = sum_f w[f] u[f];   w . xs
+  const double b = ok ? (double)b0[col] : 0.0;
+  // u[f] = sum_k w[k] S[k][f] for f = g, g + 16;   w^T S w = sum_f w[f] u[f];   w . d;   w . c
   double u0 = 0.0, u1 = 0.0;
 #pragma unroll
   for (int k = 0; k < ENC_IF; ++k) {
@@ -176,18 +185,21 @@ __global__ __launch_bounds__(256) void enc_bn_finalize_kernel(
     u1 = fma((double)wr[k], xs[ENC_IF + k * ENC_IF + g + 16], u1);
   }
   const double wf0 = ok ? (double)enc_ld1(w + g) : 0.0, wf1 = ok ? (double)enc_ld1(w + g + 16) : 0.0;     // this thread's features
-  double quad = wf0 * u0 + wf1 * u1, dot = wf0 * xs[g] + wf1 * xs[g + 16];
+  double quad = wf0 * u0 + wf1 * u1, dotd = wf0 * xs[g] + wf1 * xs[g + 16], dotc = wf0 * cc[g] + wf1 * cc[g + 16];
 #pragma unroll
-  for (int o = 8; o >= 1; o >>= 1) { quad += __shfl_xor(quad, o); dot += __shfl_xor(dot, o); }
+  for (int o = 8; o >= 1; o >>= 1) {
+    quad += __shfl_xor(quad, o); dotd += __shfl_xor(dotd, o); dotc += __shfl_xor(dotc, o);
+  }
   if (ok) {
-    ttab[(int64_t)col * ENC_IF + g] = (float)(u0 + b * xs[g]);
-    ttab[(int64_t)col * ENC_IF + g + 16] = (float)(u1 + b * xs[g + 16]);
+    // T[f] = (w XtX)[f] + b xs[f] = u[f] + (w.c) d[f] + (w.d) c[f] + B (w.c) c[f] + b (d[f] + B c[f])
+    const double kc = dotd + B * dotc + B * b;               // = sum of z: multiplies c[f]
+    ttab[(int64_t)col * ENC_IF + g] = (float)(u0 + (dotc + b) * xs[g] + kc * cc[g]);
+    ttab[(int64_t)col * ENC_IF + g + 16] = (float)(u1 + (dotc + b) * xs[g + 16] + kc * cc[g + 16]);
     if (g == 0) {
-      zs_out[col] = (float)(dot + B * b);
-      const double mean_wx = dot / B;                       // mean of w . x
-      const double m2 = quad - B * mean_wx * mean_wx;       // sum (z - mean)^2: the bias drops out
-      bn_finalize_store(mean_wx + b, m2 > 0.0 ? m2 : 0.0, batch, col, gamma, beta, running_mean, running_var, nbt,
-                        momentum, saved_mean, saved_invstd, scale, shift);
+      zs_out[col] = (float)kc;
+      const double m2 = quad - dotd * dotd / B;              // sum (z - mean)^2
+      bn_finalize_store(dotd / B + dotc + b, m2 > 0.0 ? m2 : 0.0, batch, col, gamma, beta, running_mean, running_var,
+                        nbt, momentum, saved_mean, saved_invstd, scale, shift);
     }
   }
 }
@@ -528,7 +540,7 @@ static int enc_forward_t(hipStream_t s, const typename EncT<H>::T* x, const type
   const int xrows = (int)(ENC_XROWS * ceil_div(batch, (int64_t)ENC_XROWS * ENC_XBLOCKS));
   const int xblocks = (int)ceil_div(batch, xrows);
   hipLaunchKernelGGL(enc_xstats_kernel<T>, dim3(xblocks), dim3(256), 0, s, x, batch, xrows, e.xpart);
-  hipLaunchKernelGGL(enc_bn_finalize_kernel<T>, dim3((unsigned)ceil_div(W, 16)), dim3(256), 0, s, e.xpart, xblocks, e.xs,
+  hipLaunchKernelGGL(enc_bn_finalize_kernel<T>, dim3((unsigned)ceil_div(W, 16)), dim3(256), 0, s, x, e.xpart, xblocks, e.xs,
                      e.ttab, e.zs, W0, b0, batch, W, gamma, beta, running_mean, running_var, nbt, momentum, saved,
                      saved + W, saved + 2 * W, saved + 3 * W);
   const int rows = enc_fwd_rows(batch);

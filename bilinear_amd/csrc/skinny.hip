@@ -490,10 +490,10 @@ int launch_decode_fused(hipStream_t s, const float* A, const float* Wd, const fl
     done.fetch_or(bit, std::memory_order_release);
   }
   if (W == 1024)
-    hipLaunchKernelGGL(decode_fused_kernel<128>, dim3(blocks), dim3(512), lds, s, A, Wd, bd, target, pred, dpred, dA,
+    launch_kernel(decode_fused_kernel<128>, dim3(blocks), dim3(512), lds, s, A, Wd, bd, target, pred, dpred, dA,
                        loss_part, dbias_part, batch, scale);
   else
-    hipLaunchKernelGGL(decode_fused_kernel<64>, dim3(blocks), dim3(512), lds, s, A, Wd, bd, target, pred, dpred, dA,
+    launch_kernel(decode_fused_kernel<64>, dim3(blocks), dim3(512), lds, s, A, Wd, bd, target, pred, dpred, dA,
                        loss_part, dbias_part, batch, scale);
   BLH_HIP_TRY(hipGetLastError());
   if (nparts) *nparts = blocks;

@@ -26,7 +26,8 @@ enum : int32_t {
   KNOB_NO_DECODE_FUSE = 64,        // BLH_NO_DECODE_FUSE: decode forward and backward as separate launches
   KNOB_NO_ENCODE_FUSE = 128,       // BLH_NO_ENCODE_FUSE: encode stage through the materialised Z0
   KNOB_MID_FUSE = 256,             // BLH_MID_FUSE: opt-in, 385..1024-row stages on the column-owner kernels (slower)
-  KNOB_ALL = 511
+  KNOB_NO_DEC_ATTACH = 512,        // BLH_NO_DEC_ATTACH: fork event of the one-pass decode as a marker packet (the r05 first form)
+  KNOB_ALL = 1023
 };
 static inline int32_t dev_knobs_from_env() {
   int32_t m = 0;
@@ -39,6 +40,7 @@ static inline int32_t dev_knobs_from_env() {
   if (std::getenv("BLH_NO_DECODE_FUSE")) m |= KNOB_NO_DECODE_FUSE;
   if (std::getenv("BLH_NO_ENCODE_FUSE")) m |= KNOB_NO_ENCODE_FUSE;
   if (std::getenv("BLH_MID_FUSE")) m |= KNOB_MID_FUSE;
+  if (std::getenv("BLH_NO_DEC_ATTACH")) m |= KNOB_NO_DEC_ATTACH;
   return m;
 }
 }  // namespace blh
@@ -92,6 +94,7 @@ struct blh_context {
   // one-pass decode (skinny.hip: decode_fused_kernel): the forward with a target also left the decode data gradient
   // dA = dP Wd in this workspace's G0 for this batch; the backward that consumes that forward skips the GEMM
   const void* dec_da_ws = nullptr;
+  bool dec_fork_attached = false;   // the one-pass decode launch carried ev_dz[nh] as its completion signal
   int64_t dec_da_batch = 0;
   // grid barrier of the fused forward stage (gemm_bf16s_bnfwd.h): arrivals, generation, timeouts; device memory
   // owned by the context, zeroed once here

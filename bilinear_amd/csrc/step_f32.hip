@@ -143,8 +143,17 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
     // one pass over the last activation: prediction, MSE, dpred, the loss / decode-bias partials AND the decode data
     // gradient dA = dP Wd (into G0, where backward expects the gradient of the last stage's output)
     int np = 0;
-    BLH_TRY(launch_decode_fused(s, ws.A[nh - 1], params + L.dec_w, params + L.dec_b, target, pred, ws.dpred, ws.G0,
-                                loss_part, ws.dec_bias_part, batch, W, OF, mse_scale, &np));
+    // (the two-stream backward forks its side stream behind this kernel: outside capture the fork event rides on
+    //  the launch's own completion signal — 3.3 against 5.3 us on this stream for a marker packet behind it,
+    //  tools/event_cost_bench, profiles/r05_fork_cost.md; an event nobody waits for costs nothing)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    ctx->dec_fork_attached = ctx->two_stream && cap == hipStreamCaptureStatusNone && !ctx->knob(KNOB_NO_DEC_ATTACH);
+    if (ctx->dec_fork_attached) tl_stop_event = ctx->ev_dz[nh];
+    const int rc = launch_decode_fused(s, ws.A[nh - 1], params + L.dec_w, params + L.dec_b, target, pred, ws.dpred, ws.G0,
+                                       loss_part, ws.dec_bias_part, batch, W, OF, mse_scale, &np);
+    tl_stop_event = nullptr;
+    BLH_TRY(rc);
     if (loss_nparts) *loss_nparts = np;
     ctx->dec_da_ws = ws.Z[0]; ctx->dec_da_batch = batch;
     return BLH_OK;
@@ -331,7 +340,7 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
     tl_stop_event = nullptr;
   }
   if (have_da && two) {
-    BLH_HIP_TRY(hipEventRecord(g_side.ev_dz[nh], s));
+    if (!(ctx->dec_fork_attached && attach)) BLH_HIP_TRY(hipEventRecord(g_side.ev_dz[nh], s));
     BLH_HIP_TRY(hipStreamWaitEvent(s2, g_side.ev_dz[nh], 0));
   } else {
     BLH_TRY(fork_wait(nh));

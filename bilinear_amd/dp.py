@@ -12,7 +12,7 @@ backward GEMMs of layers < l.  ``finish()`` makes the compute stream wait for al
 buckets and the (already averaged) gradients then feed the fused clip + Adam, which
 every rank runs identically (no parameter broadcast).
 
-The returned loss is the global batch's (a 1-float all-reduce behind the last bucket; every
+The returned loss is the global batch's (a 1-float all-reduce in front of backward; every
 rank computes the same clip coefficient from the identical averaged gradients, so the gradient
 norm needs no exchange of its own).
 
@@ -269,6 +269,14 @@ class DataParallel:
         # in the workspace for backward)
         pred, loss = eng.forward_train_loss(x, target, sync=sync, global_batch=gb)
         self._reducer.begin()
+        # the reported loss is the GLOBAL batch's: mean of the per-rank means (equal shards; the
+        # reference logs the loss of the whole batch, train_bilinear.py:86-88).  Its 1-float
+        # all-reduce goes out HERE, in front of backward (the forward finished the scalar), so it
+        # travels beside the backward GEMMs and the wait for the first gradient bucket covers it
+        # (one collective stream, in order).  Launched behind the last bucket and awaited after
+        # Adam — the round-3 order — it held the NEXT step's first kernel back by a collective
+        # plus a cross-queue hop: 23 us per step at configs[1] (profiles/r05_dp_overhead.md)
+        self._reducer.reduce_scalars(loss)
         eng.backward(x, None, on_ready=self._reducer.on_ready, sync=sync, global_batch=gb)
         # bf16 buckets on a HIP device stay bf16: norm, clip and Adam read them directly — when the
         # reducer really exchanged (its own state decides: ``force_collectives`` without a process
@@ -277,11 +285,6 @@ class DataParallel:
         exchanged = (self._reducer.world > 1 or self._reducer.force) and self._reducer._half is not None
         half_direct = self.compress == "bf16" and eng.grads.is_cuda and exchanged
         gscale = self._reducer.finish(cast_back=not half_direct)
-        # the reported loss is the GLOBAL batch's: mean of the per-rank means (equal shards; the
-        # reference logs the loss of the whole batch, train_bilinear.py:86-88).  Its 1-float
-        # all-reduce is launched behind the last gradient bucket and awaited AFTER clip + Adam, which
-        # do not need it: one small collective less on the critical path
-        self._reducer.reduce_scalars(loss)
         opt._ensure_moments(eng)
         g = opt.param_groups[0]
         opt._t += 1
@@ -291,7 +294,6 @@ class DataParallel:
         else:
             eng.clip_adam(opt._exp_avg, opt._exp_avg_sq, float(g["lr"]), g["betas"], g["eps"],
                           self.max_norm, opt._t, opt._stats)
-        self._reducer.finish()
         opt._sync_step_state(eng)
         return pred, loss
 
@@ -370,9 +372,9 @@ class CapturedDataParallelStep:
             eng.rng_step = 0                        # the device counter supplies the step
             pred, loss = eng.forward_train_loss(self.x, self.t)
             dp._reducer.begin()
+            dp._reducer.reduce_scalars(loss)       # (in front of backward: see DataParallel._train_step)
             eng.backward(self.x, None, on_ready=dp._reducer.on_ready)
             dp._reducer.finish()
-            dp._reducer.reduce_scalars(loss)
             eng.rng_step = saved_step
         finally:
             N.check(lib.blh_context_set_step_state(eng.ctx.handle, None), "blh_context_set_step_state")
@@ -381,7 +383,6 @@ class CapturedDataParallelStep:
             eng._stream(), N.ptr(eng.params), N.ptr(eng.grads), N.ptr(opt._exp_avg), N.ptr(opt._exp_avg_sq),
             eng.layout.total, N.ptr(self.state), N.ptr(sc), sc.numel(), N.ptr(opt._stats)),
             "blh_clip_adam_step_captured")
-        dp._reducer.finish()                        # (the loss all-reduce: behind clip + Adam)
         return pred, loss
 
     @torch.no_grad()

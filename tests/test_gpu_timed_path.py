@@ -893,6 +893,38 @@ def test_encode_stage_without_z0_other_shapes(nb, width, batch):
     assert abs(float(a[5]) - float(b[5])) <= 1e-3 * abs(float(b[5]))
 
 
+@pytest.mark.parametrize("storage", ["fp32", "bf16s"])
+def test_encode_stage_without_z0_on_inputs_that_are_not_standardised(storage):
+    """BatchNorm statistics from the moments of x are a difference of second moments: with raw moments, inputs whose
+    mean is 50 standard deviations from zero (pixel coordinates instead of the reference's standardised poses,
+    /root/reference/H36M/data.py:56-58) would lose 11 bits of the variance.  encode_f32.hip takes the moments of
+    x - x[0] instead; the predictions and the running statistics then agree with the materialised path (per-tile
+    mean / M2 merged with Chan's formula) as closely as on N(0, 1) inputs."""
+    import bilinear_amd
+    dev = _dev()
+    nb, width, batch = 1, 1024, 2048
+    g = torch.Generator(device=dev).manual_seed(5)
+    offs = torch.linspace(-50.0, 50.0, 32, device=dev)
+    x = offs + torch.randn(batch, 32, device=dev, generator=g)
+    t = torch.randn(batch, 48, device=dev, generator=g)
+    masks = [(torch.rand(batch, width, device=dev, generator=g) < 0.5).to(torch.uint8) for _ in range(1 + 2 * nb)]
+
+    def build():
+        torch.manual_seed(0)
+        net, opt, _, _ = bilinear_amd.load(dev, num_blocks=nb, width=width, gemm_dtype=storage)
+        net.train()
+        net.engine.ensure(dev)
+        return net, opt
+
+    a, b = _fused_and_materialised(build, x, t, masks)
+    tol = 1e-5 if storage == "fp32" else 2e-2          # (bf16 storage: a gate that opens differently moves 1e-3 .. 1e-2)
+    assert _rel(a[0], b[0]) <= tol, _rel(a[0], b[0])
+    # stage 0's running mean / variance: the statistics themselves (fp32 in both storage modes)
+    ra, rb = a[2].view(-1, 2, width)[0], b[2].view(-1, 2, width)[0]
+    assert _rel(ra[0], rb[0]) <= (1e-6 if storage == "fp32" else 1e-3), _rel(ra[0], rb[0])
+    assert _rel(ra[1], rb[1]) <= (1e-5 if storage == "fp32" else 1e-2), _rel(ra[1], rb[1])
+
+
 @pytest.mark.parametrize("nb,width,batch", [(2, 1024, 512), (2, 1024, 1024), (2, 1024, 777), (1, 512, 400), (3, 256, 640)])
 def test_column_owner_stages_match_the_multi_launch_path(nb, width, batch):
     """Round 5, 385 .. 1024 rows (the per-GPU shapes of the headline batch split over 4 / 8 GPUs): the hidden stages
