@@ -432,7 +432,9 @@ int blh_mse_loss_grad(void* stream, const float* pred, const float* target, int6
 }
 
 // BLH_OPT_BUCKET_FLOATS: adjacent ready ranges (backward walks the arena downwards) are merged until a bucket holds at
-// least `want` elements; what is pending when backward returns is reported then.
+// least `want` elements; what is pending when backward returns is reported then.  Ranges that complete together (the
+// stages of one batched weight-gradient launch) arrive as ONE range and are not cut into buckets: nothing could
+// overlap the cut.
 namespace {
 struct BucketMerger {
   blh_grad_ready_fn fn; void* user; int64_t want; int64_t lo = 0, hi = 0; bool pending = false;
@@ -444,7 +446,10 @@ struct BucketMerger {
     else if (hi == m->lo) m->lo = lo;
     else if (lo == m->hi) m->hi = hi;
     else { m->flush(); m->lo = lo; m->hi = hi; m->pending = true; }
-    if (m->hi - m->lo >= m->want) m->flush();
+    // (a full bucket is held back while what is left below it — the arena starts with the encode stage — is a small
+    //  fraction of a bucket: that remainder would be a collective of its own at the very end of backward, where
+    //  every collective costs its launch and a queue hop: 22 us at configs[2], profiles/r05_dp_overhead.md)
+    if (m->hi - m->lo >= m->want && !(m->lo > 0 && m->lo < m->want / 8)) m->flush();
   }
 };
 }  // namespace

@@ -294,7 +294,11 @@ static Splits wgrad_batched_plan_h(int64_t W, int64_t batch, int items) {
   // (each workgroup at least 4096 rows deep: below that the per-stage plan measured as fast or faster —
   //  0.434 against 0.441 ms per step at 2 x 1024, B = 4096; 1.109 against 1.125 ms for the data-parallel
   //  step at B = 8192 with groups of four stages x 4 slabs)
-  if (tiles * items * s < 224 || batch / s < 4096) return Splits{0, 0};
+  static const int64_t min_rows = [] {      // (developer knob, read once: rows per workgroup below which the plan is refused)
+    const char* e = std::getenv("BLH_WGRAD_BATCHED_MIN_ROWS");
+    return e ? (int64_t)std::atoll(e) : (int64_t)4096;
+  }();
+  if (tiles * items * s < 224 || batch / s < min_rows) return Splits{0, 0};
   return Splits{(int)s, (int)(batch / s)};
 }
 

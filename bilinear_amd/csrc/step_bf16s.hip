@@ -313,13 +313,21 @@ int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const f
     const bool late = forks && late_policy && i > 0 && !group_fork;
     if (forks && !late) BLH_TRY(fork_wait(i, false));     // behind bn_bwd_apply (marker event)
     if (group_fork) {
-      for (int k = grp->hi; k >= grp->lo; --k)
-        BLH_TRY(launch_colreduce(s2, ws.dz_colsum_part + (int64_t)k * chunks * W, chunks, W, W,
-                                 grads + L.heavy[k].b));
+      // the group's GEMM first, then the bias gradients of its stages in ONE launch: four column reductions in front
+      // of the GEMM held it back by 67 us on the low-priority side stream beside the main stream's data gradient,
+      // and the last group's GEMM is the tail of the data-parallel step (profiles/r05_dp_overhead.md)
       BLH_TRY(launch_group(*grp, s2));
-      for (int k = grp->hi; k >= grp->lo; --k) {
-        const int64_t end = (k + 1 < nh) ? L.heavy[k + 1].w : L.dec_w;
-        BLH_TRY(ready(k, L.heavy[k].w, end - L.heavy[k].w));
+      {
+        int64_t offs[32];
+        const int items = grp->hi - grp->lo + 1;
+        if (items > 32) return BLH_ERR_SHAPE;
+        for (int k = 0; k < items; ++k) offs[k] = L.heavy[grp->lo + k].b;
+        BLH_TRY(launch_bias_colreduce(s2, ws.dz_colsum_part + (int64_t)grp->lo * chunks * W, (int64_t)chunks * W, chunks,
+                                      W, items, offs, grads, nullptr, 0, OF, L.dec_b));
+      }
+      {   // the group's stages complete together: one range
+        const int64_t end = (grp->hi + 1 < nh) ? L.heavy[grp->hi + 1].w : L.dec_w;
+        BLH_TRY(ready(grp->lo, L.heavy[grp->lo].w, end - L.heavy[grp->lo].w));
       }
     }
     // (data parallel: the bucket hook needs this stage's bias gradient now — on the side stream, in
