@@ -596,12 +596,18 @@ def config_block(idx, dev, steps, ramp_ms):
     def one_step():
         return net.train_step(opt, x, t, max_norm=1.0)
     ramp, ramp_steps = pre_ramp(one_step, ramp_ms)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        _, loss = one_step()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    # three segments of ``steps`` steps, the median one reported (all three are in "segments_ms"): a block is 0.1-0.7 s
+    # of GPU time, and one segment of the round-5 record came out 21 % slow between two normal runs on the same box
+    # (profiles/r05_INDEX.md: configs[3] shape 1.109 against 0.912 ms)
+    seg = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            _, loss = one_step()
+        torch.cuda.synchronize()
+        seg.append(time.perf_counter() - t0)
+    el = sorted(seg)[1]
     final = float(loss.item())
     fwd, bwd = flops_per_pose(a.blocks, a.width)
     poses = a.batch * steps / el
@@ -609,6 +615,7 @@ def config_block(idx, dev, steps, ramp_ms):
     out = {
         "workload": workload_label(a, 1) + "; x~N(0,1)[B,32], t~N(0,1)[B,48], Kaiming-normal init",
         "value": poses, "unit": "poses/s", "ms_per_step": 1e3 * el / steps, "steps": steps,
+        "segments_ms": [1e3 * e / steps for e in seg], "timing": "median of three segments of `steps` steps",
         "pre_ramp_ms": ramp, "dtype": DTYPE_TEXT[a.dtype], "final_loss": final,
         "num_blocks": a.blocks, "width": a.width, "per_gpu_batch": a.batch,
         "step": "zero_grad+forward+MSE+backward+clip_grad_norm(1)+Adam",
