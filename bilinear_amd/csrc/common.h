@@ -246,6 +246,14 @@ int launch_decode_finish(hipStream_t s, const float* slabs, int splits, int64_t 
 bool decode_fwd_supported(int64_t batch, int W, int OF);
 // ---- column-owner BatchNorm kernels, 385 .. 1024 rows (colowner_f32.hip) ----
 bool colowner_supported(int64_t batch, int W);
+// 385 .. 2048 rows, fp32: launches of a hidden stage merged pairwise, bit-identical (midstage_f32.hip)
+bool mid_fwd_pair_supported(int64_t batch, int W, float momentum);
+int launch_mid_fwd_finish(hipStream_t s, const float* slabs, int splits, int64_t M, int N, const float* bias, float* Z,
+                          float* stat_part);
+int launch_mid_bn_apply(hipStream_t s, const float* Z, const float* stat_part, int tiles, int tile_rows,
+                        const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                        float* saved, const float* skip, float* A, uint32_t* keepbits, int64_t batch, int W,
+                        const DropoutSrc& drop, int64_t* nbt, float* amax_part);
 int launch_colowner_fwd(hipStream_t s, const float* slabs, int splits, int64_t slab_stride, const float* bias,
                         const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t* nbt,
                         uint32_t* ticket, float momentum, float* saved, const float* skip, float* Z, float* A,

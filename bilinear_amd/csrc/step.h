@@ -27,7 +27,9 @@ enum : int32_t {
   KNOB_NO_ENCODE_FUSE = 128,       // BLH_NO_ENCODE_FUSE: encode stage through the materialised Z0
   KNOB_MID_FUSE = 256,             // BLH_MID_FUSE: opt-in, 385..1024-row stages on the column-owner kernels (slower)
   KNOB_NO_DEC_ATTACH = 512,        // BLH_NO_DEC_ATTACH: fork event of the one-pass decode as a marker packet (the r05 first form)
-  KNOB_ALL = 1023
+  KNOB_MID_PAIR = 1024,            // BLH_MID_PAIR: opt-in, <= 2048 rows, fp32: slab sum + bias + chunk statistics in one launch (no gain)
+  KNOB_MID_PAIR_APPLY = 2048,      // BLH_MID_PAIR_APPLY: with BLH_MID_PAIR: the statistics merge inside the BatchNorm-apply launch (slower)
+  KNOB_ALL = 4095
 };
 static inline int32_t dev_knobs_from_env() {
   int32_t m = 0;
@@ -41,6 +43,8 @@ static inline int32_t dev_knobs_from_env() {
   if (std::getenv("BLH_NO_ENCODE_FUSE")) m |= KNOB_NO_ENCODE_FUSE;
   if (std::getenv("BLH_MID_FUSE")) m |= KNOB_MID_FUSE;
   if (std::getenv("BLH_NO_DEC_ATTACH")) m |= KNOB_NO_DEC_ATTACH;
+  if (std::getenv("BLH_MID_PAIR")) m |= KNOB_MID_PAIR;
+  if (std::getenv("BLH_MID_PAIR_APPLY")) m |= KNOB_MID_PAIR_APPLY;
   return m;
 }
 }  // namespace blh

@@ -35,6 +35,10 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
   const int W = d->width;
   const bool enc_fused = train && enc_fused_ok(ctx, d, batch);
   const bool colown = colowner_ok(ctx, d, batch);
+  // <= 2048 rows, opt-in: the finishing / BatchNorm launches of a hidden stage merged pairwise (midstage_f32.hip:
+  // bit-identical, and no faster — profiles/r05_mid_pair.md)
+  const bool midpair = train && d->gemm_dtype == 0 && !ctx->sync.fn && batch <= 2048 && !colown &&
+                       ctx->knob(KNOB_MID_PAIR) && mid_fwd_pair_supported(batch, W, momentum);
   if (train) ctx->note_saved(ws.Z[0], batch, enc_fused ? 3 : 0);     // (ws.Z[0] is the workspace base, api_layout.h carve)
   if (ws.amax_W)   // gemm_dtype 3: max |w| of every hidden Linear weight, once per forward
     for (int i = 1; i < nh; ++i)
@@ -82,8 +86,11 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
                                     layer_drop(ctx, drop, i, batch, W)));
         continue;
       }
-      BLH_TRY(launch_fwd_finish(s, ws.slabs, fs.splits, batch, W, params + h.b, ws.Z[i],
-                                train ? ws.stat_part : nullptr));
+      if (midpair)
+        BLH_TRY(launch_mid_fwd_finish(s, ws.slabs, fs.splits, batch, W, params + h.b, ws.Z[i], ws.stat_part));
+      else
+        BLH_TRY(launch_fwd_finish(s, ws.slabs, fs.splits, batch, W, params + h.b, ws.Z[i],
+                                  train ? ws.stat_part : nullptr));
     } else if (!train && d->gemm_dtype != 3) {
       // eval: the whole heavy_linear in one kernel — bias, BatchNorm with the running statistics,
       // ReLU and the block skip sit in the GEMM epilogue (the BN "folded into the Linear" of
@@ -114,6 +121,13 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
       // (the small-batch path produced statistics tiles of fwd_finish_stat_rows() rows)
       const int st_rows = fs.splits > 1 ? fwd_finish_stat_rows() : (enc64 ? 64 : 128);
       const int st_tiles = (int)ceil_div(batch, st_rows);
+      if (midpair && st_tiles <= 64 && ctx->knob(KNOB_MID_PAIR_APPLY)) {
+        // statistics merge + BatchNorm / ReLU / dropout in one launch (every block merges its own 256 columns)
+        BLH_TRY(launch_mid_bn_apply(s, ws.Z[i], ws.stat_part, st_tiles, st_rows, params + h.gamma, params + h.beta, rm, rv,
+                                    momentum, sv, skip, ws.A[i], ws.keep[i], batch, W, layer_drop(ctx, drop, i, batch, W),
+                                    nbt + i, ws.amax_A[i]));
+        continue;
+      }
       if (ctx->sync.fn) {
         BLH_TRY(launch_bn_fwd_local_sums(s, ws.stat_part, st_tiles, st_rows, batch, W, ws.sync_buf));
         ctx->sync.fn(ctx->sync.user, ws.sync_buf, 2 * (int64_t)W, 1);

@@ -973,3 +973,54 @@ def test_column_owner_stages_match_the_multi_launch_path(nb, width, batch):
     assert _rel(a[2], b[2]) <= 1e-5 and torch.equal(a[3], b[3]) and int(a[3][1]) == 1
     assert abs(float(a[5]) - float(b[5])) <= 1e-3 * abs(float(b[5]))
     assert _rel(a[6], b[6]) <= 1e-4 and torch.equal(a[7], b[7]) and int(a[7][1]) == 3
+
+
+@pytest.mark.parametrize("nb,width,batch", [(2, 1024, 512), (2, 1024, 1024), (2, 1024, 777), (2, 1024, 1536),
+                                            (2, 1024, 2048), (1, 512, 400), (3, 256, 640)])
+def test_mid_batch_pair_fusions_are_bit_identical(nb, width, batch):
+    """Round 5, 385 .. 2048 rows (the per-GPU shapes of the headline batch under strong scaling): the finishing and
+    BatchNorm launches of a hidden stage merged PAIRWISE (midstage_f32.hip: slab sum + bias + chunk statistics;
+    statistics merge + BatchNorm / ReLU / dropout; opt-in BLH_MID_PAIR=1 BLH_MID_PAIR_APPLY=1 — measured no faster
+    than the launches they replace, profiles/r05_mid_pair.md) use the multi-launch path's arithmetic in its order, so
+    every tensor the step writes is bit-identical to the default path: predictions, gradients, running statistics, counters
+    of the drop-in step, and loss / parameters / Adam state after two fused steps (Philox dropout; ragged 777 and 400:
+    partial statistics chunks and row groups; 1536 / 2048: the 64-row-tile GEMMs without split-K).
+    (/root/reference/model/bilinear.py:7-13,31-41; train_bilinear.py:75-83.)"""
+    import os
+
+    import bilinear_amd
+    dev = _dev()
+    x = torch.randn(batch, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    t = torch.randn(batch, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    out = {}
+    for fused in (True, False):
+        if fused:
+            os.environ["BLH_MID_PAIR"] = "1"
+            os.environ["BLH_MID_PAIR_APPLY"] = "1"
+        try:
+            torch.manual_seed(0)
+            net, opt, _, _ = bilinear_amd.load(dev, num_blocks=nb, width=width, gemm_dtype="fp32")
+            net.train()
+            net.engine.ensure(dev)
+            opt.zero_grad()
+            pred = net(x)
+            torch.nn.functional.mse_loss(pred, t).backward()
+            torch.cuda.synchronize()
+            first = (pred.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()},
+                     net.engine.bn_running.clone(), net.engine.bn_nbt.clone())
+            for _ in range(2):
+                p2, loss = net.train_step(opt, x, t, max_norm=1.0)
+            torch.cuda.synchronize()
+            out[fused] = first + (p2.clone(), loss.clone(), net.engine.params.clone(), net.engine.bn_running.clone(),
+                                  opt._exp_avg.clone(), opt._exp_avg_sq.clone())
+        finally:
+            os.environ.pop("BLH_MID_PAIR", None)
+            os.environ.pop("BLH_MID_PAIR_APPLY", None)
+    a, b = out[True], out[False]
+    assert torch.equal(a[0], b[0]), "predictions"
+    for k in a[1]:
+        assert torch.equal(a[1][k], b[1][k]), k
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and int(a[3][1]) == 1
+    assert torch.equal(a[4], b[4]) and torch.equal(a[5], b[5]), "fused step: prediction / loss"
+    for i in (6, 7, 8, 9):
+        assert torch.equal(a[i], b[i]), i
