@@ -247,6 +247,7 @@ struct WorkspaceH {
   float* loss_part; double* sumsq_part; float* colsum_part;
   double* sync_buf;                 // [2][W] fp64 (SyncBN exchange; its first 2W floats in backward)
   float* dec_bias_part;             // [blocks][out] partial sums of dpred (fused decode + MSE kernel)
+  uint16_t* wdT;                    // [W][64]: the decode weight's image for the one-pass decode's second phase (decode_wdT_dev.h)
   int64_t bytes;
 };
 
@@ -352,6 +353,7 @@ static WorkspaceH carve_h(const blh_model_desc* d, int64_t batch, void* base) {
   ws.colsum_part = (float*)take(ceil_div(batch, 256) * d->out_features * sizeof(float));
   ws.sync_buf = (double*)take(2 * W * sizeof(double));
   ws.dec_bias_part = (float*)take(1026 * d->out_features * sizeof(float));
+  ws.wdT = (uint16_t*)take(W * 64 * 2);
   ws.bytes = off;
   return ws;
 }

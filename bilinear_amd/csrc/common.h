@@ -293,6 +293,12 @@ int launch_decode_fwd_mse_h(hipStream_t s, const uint16_t* A, const uint16_t* Wd
                             const float* target, float* pred, float* dpred, uint16_t* dpred_h,
                             float* loss_part, float* dbias_part, int64_t batch, int W, int OF, float scale,
                             int* nparts);
+// one-pass decode, bf16 storage (skinny.hip): the kernel above + dA = dP Wd (bf16 [batch][W]) from the dP tile and the
+// decode weight's image WdT (decode_wdT_dev.h; written by launch_cast2_f32_bf16)
+bool decode_fused_h_supported(int64_t batch, int W, int OF);
+int launch_decode_fused_h(hipStream_t s, const uint16_t* A, const uint16_t* Wd, const uint16_t* WdT, const float* bd,
+                          const float* target, float* pred, float* dpred, uint16_t* dpred_h, uint16_t* dA,
+                          float* loss_part, float* dbias_part, int64_t batch, int W, int OF, float scale, int* nparts);
 int launch_mpjpe(hipStream_t s, const float* pred, const float* target, const float* mean,
                  const float* stddev, int64_t batch, int joints, float* dist);
 int launch_segment_sum(hipStream_t s, const float* dist, const int32_t* ids, int64_t batch,

@@ -5,6 +5,7 @@
 #include <cstdlib>
 
 #include "gemm_bf16s_kernel.h"
+#include "decode_wdT_dev.h"
 #include "gemm_bf16s_256.h"
 #include "gemm_bf16s_128x256.h"
 
@@ -228,14 +229,21 @@ int launch_cast_f32_bf16(hipStream_t s, const float* src, uint16_t* dst, int64_t
 
 // two tensors in one launch (the parameter arena and the network input at the head of the bf16-storage forward:
 // a launch of its own costs the 1 MB input cast 4.9 us): blocks [0, b0) take the first, the rest the second
+// (blocks behind the first b01 = b0 + b1: the decode weight's phase-2 image, decode_wdT_dev.h — wd_src != nullptr)
 __global__ __launch_bounds__(256) void cast2_f32_bf16_kernel(const float* __restrict__ src0, bf16_bits* __restrict__ dst0,
                                                              int64_t n0, int b0, const float* __restrict__ src1,
-                                                             bf16_bits* __restrict__ dst1, int64_t n1) {
+                                                             bf16_bits* __restrict__ dst1, int64_t n1, int b01,
+                                                             const float* __restrict__ wd_src, bf16_bits* __restrict__ wdT,
+                                                             int wd_W, int wd_OF) {
+  if ((int)blockIdx.x >= b01) {
+    wdT_image_block(wd_src, wdT, wd_W, wd_OF, (int)blockIdx.x - b01);
+    return;
+  }
   const bool first = (int)blockIdx.x < b0;
   const float* __restrict__ src = first ? src0 : src1;
   bf16_bits* __restrict__ dst = first ? dst0 : dst1;
   const int64_t n4 = (first ? n0 : n1) >> 2;
-  const int64_t blk = first ? blockIdx.x : blockIdx.x - b0, nblk = first ? b0 : (int64_t)gridDim.x - b0;
+  const int64_t blk = first ? blockIdx.x : blockIdx.x - b0, nblk = first ? b0 : (int64_t)b01 - b0;
   for (int64_t i = blk * (int64_t)blockDim.x + threadIdx.x; i < n4; i += nblk * blockDim.x) {
     const float4 v = *reinterpret_cast<const float4*>(src + i * 4);
     uint2 o;
@@ -246,11 +254,13 @@ __global__ __launch_bounds__(256) void cast2_f32_bf16_kernel(const float* __rest
 }
 
 int launch_cast2_f32_bf16(hipStream_t s, const float* src0, uint16_t* dst0, int64_t n0, const float* src1,
-                          uint16_t* dst1, int64_t n1) {
+                          uint16_t* dst1, int64_t n1, const float* wd_src, uint16_t* wdT, int wd_W, int wd_OF) {
   if (n0 % 4 != 0 || n1 % 4 != 0 || n0 <= 0 || n1 <= 0) return BLH_ERR_SHAPE;
+  if (wd_src && (wd_W % 128 != 0 || wd_OF > 64 || !wdT)) return BLH_ERR_SHAPE;
   const int64_t b0 = std::min<int64_t>(ceil_div(n0 / 4, 256), 4096), b1 = std::min<int64_t>(ceil_div(n1 / 4, 256), 1024);
-  hipLaunchKernelGGL(cast2_f32_bf16_kernel, dim3((unsigned)(b0 + b1)), dim3(256), 0, s, src0, dst0, n0, (int)b0, src1,
-                     dst1, n1);
+  const int64_t b2 = wd_src ? ceil_div((int64_t)wd_W * 8, 256) : 0;
+  hipLaunchKernelGGL(cast2_f32_bf16_kernel, dim3((unsigned)(b0 + b1 + b2)), dim3(256), 0, s, src0, dst0, n0, (int)b0, src1,
+                     dst1, n1, (int)(b0 + b1), wd_src, wdT, wd_W, wd_OF);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }

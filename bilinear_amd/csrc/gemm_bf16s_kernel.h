@@ -208,7 +208,8 @@ void gemm_bf16s_force_tile(int tile);  // 0: automatic; -1: re-read BLH_BF16S_TI
 int gemm_bf16s_fused_forward_max_wgs();   // CUs of the current device (EPI_BN_FWD: one resident workgroup each)
 int launch_cast_f32_bf16(hipStream_t s, const float* src, uint16_t* dst, int64_t n);
 int launch_cast2_f32_bf16(hipStream_t s, const float* src0, uint16_t* dst0, int64_t n0, const float* src1,
-                          uint16_t* dst1, int64_t n1);   // two tensors, one launch
+                          uint16_t* dst1, int64_t n1, const float* wd_src = nullptr, uint16_t* wdT = nullptr,
+                          int wd_W = 0, int wd_OF = 0);   // two tensors, one launch
 int launch_cast_bf16_f32(hipStream_t s, const uint16_t* src, float* dst, int64_t n);
 
 template <int BKE, int STAGES>

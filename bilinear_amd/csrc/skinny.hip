@@ -156,16 +156,24 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void decode_fwd_mse_kernel(
 // Besides pred / dpred (fp32) it writes dpred as bf16, the operand of the decode backward GEMMs.
 typedef __bf16 dec_bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int RT>
+// FUSE (round 5, one-pass decode in bf16 storage): the block also forms dA = dP Wd for its rows — the decode data
+// gradient the backward would otherwise compute with a K = 48 GEMM that re-reads nothing of A but costs a launch,
+// a fork and 13 us (B = 16384) — from the dP tile it has just produced (bf16, in LDS: the A operand of
+// v_mfma_f32_16x16x32_bf16, k = output feature padded to 64) and WdT[W][64], the decode weight's bf16 image with
+// the output feature contiguous (written by the forward's cast launch).  A wave takes 128-column groups; its lane
+// (n, q) feeds MFMA j with column 8 n + j, so that after 8 MFMAs it holds 8 consecutive columns of 4 rows: one
+// 16-byte store per row.
+template <int RT, bool FUSE>
 __global__ __launch_bounds__(64 * DEC_WAVES) void decode_fwd_mse_h_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ Wd, const float* __restrict__ bd,
     const float* __restrict__ target, float* __restrict__ pred, float* __restrict__ dpred,
     uint16_t* __restrict__ dpred_h, float* __restrict__ loss_part, float* __restrict__ dbias_part,
-    int64_t batch, int W, int OF, float scale) {
+    int64_t batch, int W, int OF, float scale, const uint16_t* __restrict__ WdT, uint16_t* __restrict__ dA) {
   constexpr int ROWS = 16 * RT, NT = 4;
   __shared__ __attribute__((aligned(16))) float red[DEC_WAVES][ROWS][64];
   __shared__ float colred[16][64];
   __shared__ float lossred[DEC_WAVES];
+  __shared__ __attribute__((aligned(16))) uint16_t dps[FUSE ? ROWS : 1][FUSE ? 72 : 8];   // dP tile, bf16, rows 144 B apart
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * ROWS;
@@ -263,9 +271,16 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void decode_fwd_mse_h_kernel(
           o.x = *reinterpret_cast<const uint32_t*>(&lo);
           o.y = *reinterpret_cast<const uint32_t*>(&hi);
           *reinterpret_cast<uint2*>(dpred_h + row * OF + col) = o;
+          if (FUSE) *reinterpret_cast<uint2*>(&dps[lr][col]) = o;
         }
+      } else if (FUSE) {
+        *reinterpret_cast<uint2*>(&dps[lr][col]) = make_uint2(0u, 0u);       // rows beyond the batch: zero gradient
       }
     }
+  }
+  if (FUSE && tid < 256 && col >= OF) {      // output features 48 .. 63 of the padded contraction: zero
+#pragma unroll
+    for (int pass = 0; pass < RT; ++pass) *reinterpret_cast<uint2*>(&dps[pass * 16 + rr][col]) = make_uint2(0u, 0u);
   }
   if (target) {
 #pragma unroll
@@ -279,6 +294,44 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void decode_fwd_mse_h_kernel(
 #pragma unroll
       for (int k2 = 0; k2 < 16; ++k2) s += colred[k2][tid];
       dbias_part[(int64_t)blockIdx.x * OF + tid] = s;
+    }
+  }
+  if (FUSE) {
+    // phase 2 (behind the barrier above: the dP tile is complete).  WdT image: for column group g, MFMA j, k-step ks
+    // one 1 KiB block of 64 x 16 bytes, lane (q, n) -> Wd[32 ks + 8 q .. + 7][128 g + 8 n + j] (wdT_image_kernel)
+    const int ngroups = W >> 7;
+    for (int g = wave; g < ngroups; g += DEC_WAVES) {
+      uint4 bw[8][2];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          bw[j][ks] = *reinterpret_cast<const uint4*>(WdT + ((((int64_t)g * 8 + j) * 2 + ks) * 64 + lane) * 8);
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        union { uint4 u4; dec_bf16x8 v; } a0, a1;
+        a0.u4 = *reinterpret_cast<const uint4*>(&dps[i * 16 + r][8 * q]);
+        a1.u4 = *reinterpret_cast<const uint4*>(&dps[i * 16 + r][32 + 8 * q]);
+        f32x4_t o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          union { uint4 u4; dec_bf16x8 v; } b0, b1;
+          b0.u4 = bw[j][0]; b1.u4 = bw[j][1];
+          o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.v, b0.v, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v, b1.v, o[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int64_t row = row0 + i * 16 + 4 * q + gq;
+          typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+          const bf2 p0 = {(__bf16)o[0][gq], (__bf16)o[1][gq]}, p1 = {(__bf16)o[2][gq], (__bf16)o[3][gq]},
+                    p2 = {(__bf16)o[4][gq], (__bf16)o[5][gq]}, p3 = {(__bf16)o[6][gq], (__bf16)o[7][gq]};
+          uint4 st;
+          st.x = *reinterpret_cast<const uint32_t*>(&p0); st.y = *reinterpret_cast<const uint32_t*>(&p1);
+          st.z = *reinterpret_cast<const uint32_t*>(&p2); st.w = *reinterpret_cast<const uint32_t*>(&p3);
+          if (row < batch) *reinterpret_cast<uint4*>(dA + row * (int64_t)W + 128 * g + 8 * r) = st;
+        }
+      }
     }
   }
 }
@@ -549,14 +602,40 @@ int launch_decode_fwd_mse_h(hipStream_t s, const uint16_t* A, const uint16_t* Wd
   const int rows = decode_fwd_rows_per_block_h(batch);
   const int blocks = (int)ceil_div(batch, rows);
   if (rows == 16)
-    hipLaunchKernelGGL(decode_fwd_mse_h_kernel<1>, dim3(blocks), dim3(64 * DEC_WAVES), 0, s, A, Wd, bd, target,
-                       pred, dpred, dpred_h, loss_part, dbias_part, batch, W, OF, scale);
+    hipLaunchKernelGGL((decode_fwd_mse_h_kernel<1, false>), dim3(blocks), dim3(64 * DEC_WAVES), 0, s, A, Wd, bd, target,
+                       pred, dpred, dpred_h, loss_part, dbias_part, batch, W, OF, scale, nullptr, nullptr);
   else if (rows == 32)
-    hipLaunchKernelGGL(decode_fwd_mse_h_kernel<2>, dim3(blocks), dim3(64 * DEC_WAVES), 0, s, A, Wd, bd, target,
-                       pred, dpred, dpred_h, loss_part, dbias_part, batch, W, OF, scale);
+    hipLaunchKernelGGL((decode_fwd_mse_h_kernel<2, false>), dim3(blocks), dim3(64 * DEC_WAVES), 0, s, A, Wd, bd, target,
+                       pred, dpred, dpred_h, loss_part, dbias_part, batch, W, OF, scale, nullptr, nullptr);
   else
-    hipLaunchKernelGGL(decode_fwd_mse_h_kernel<4>, dim3(blocks), dim3(64 * DEC_WAVES), 0, s, A, Wd, bd, target,
-                       pred, dpred, dpred_h, loss_part, dbias_part, batch, W, OF, scale);
+    hipLaunchKernelGGL((decode_fwd_mse_h_kernel<4, false>), dim3(blocks), dim3(64 * DEC_WAVES), 0, s, A, Wd, bd, target,
+                       pred, dpred, dpred_h, loss_part, dbias_part, batch, W, OF, scale, nullptr, nullptr);
+  BLH_HIP_TRY(hipGetLastError());
+  if (nparts) *nparts = blocks;
+  return BLH_OK;
+}
+
+// one-pass decode, bf16 storage: the kernel above with its phase 2 (dA = dP Wd into `dA`, bf16 [batch][W])
+bool decode_fused_h_supported(int64_t batch, int W, int OF) {
+  return OF == 48 && W % 128 == 0 && batch % 4 == 0 && decode_fwd_supported(batch, W, OF);
+}
+int64_t decode_wdT_elems(int W) { return (int64_t)W * 64; }
+
+int launch_decode_fused_h(hipStream_t s, const uint16_t* A, const uint16_t* Wd, const uint16_t* WdT, const float* bd,
+                          const float* target, float* pred, float* dpred, uint16_t* dpred_h, uint16_t* dA,
+                          float* loss_part, float* dbias_part, int64_t batch, int W, int OF, float scale, int* nparts) {
+  if (!decode_fused_h_supported(batch, W, OF) || !target || !WdT || !dA) return BLH_ERR_SHAPE;
+  const int rows = decode_fwd_rows_per_block_h(batch);
+  const int blocks = (int)ceil_div(batch, rows);
+  if (rows == 16)
+    launch_kernel(decode_fwd_mse_h_kernel<1, true>, dim3(blocks), dim3(64 * DEC_WAVES), 0, s, A, Wd, bd, target, pred,
+                  dpred, dpred_h, loss_part, dbias_part, batch, W, OF, scale, WdT, dA);
+  else if (rows == 32)
+    launch_kernel(decode_fwd_mse_h_kernel<2, true>, dim3(blocks), dim3(64 * DEC_WAVES), 0, s, A, Wd, bd, target, pred,
+                  dpred, dpred_h, loss_part, dbias_part, batch, W, OF, scale, WdT, dA);
+  else
+    launch_kernel(decode_fwd_mse_h_kernel<4, true>, dim3(blocks), dim3(64 * DEC_WAVES), 0, s, A, Wd, bd, target, pred,
+                  dpred, dpred_h, loss_part, dbias_part, batch, W, OF, scale, WdT, dA);
   BLH_HIP_TRY(hipGetLastError());
   if (nparts) *nparts = blocks;
   return BLH_OK;

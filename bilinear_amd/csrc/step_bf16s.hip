@@ -28,7 +28,15 @@ int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const fl
   // bf16 images of the parameters (the GEMMs read the weights from it) and of the input
   // (shadow_valid: the previous fused step's Adam kernel wrote it, BLH_OPT_PERSISTENT_SHADOW)
   ctx->shadow_params = ctx->shadow_ws = nullptr;
-  if (!shadow_valid) BLH_TRY(launch_cast2_f32_bf16(s, params, ws.wsh, L.total, x, ws.xh, batch * IF));
+  // one-pass decode (skinny.hip): forward + MSE + the decode data gradient from one read of the last activation; its
+  // second phase reads the decode weight through an image the cast launch below writes (not with a persistent shadow:
+  // Adam's pass writes the plain image only)
+  const bool dec_fused = train && target && !shadow_valid && !ctx->knob(KNOB_NO_DECODE_FUSE) &&
+                         decode_fused_h_supported(batch, W, OF);
+  ctx->dec_da_ws = nullptr;
+  if (!shadow_valid)
+    BLH_TRY(launch_cast2_f32_bf16(s, params, ws.wsh, L.total, x, ws.xh, batch * IF, dec_fused ? params + L.dec_w : nullptr,
+                                  dec_fused ? ws.wdT : nullptr, W, OF));
   else BLH_TRY(launch_cast_f32_bf16(s, x, ws.xh, batch * IF));
   for (int i = 0; i < nh; ++i) {
     const HeavyOffsets& h = L.heavy[i];
@@ -98,6 +106,14 @@ int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const fl
   // skinny.hip's purpose-built kernel reads A once and writes pred, dpred (fp32 and bf16), the loss
   // partials and the decode-bias partials; *loss_nparts = their row count (0: the generic path ran)
   if (loss_nparts) *loss_nparts = 0;
+  if (dec_fused) {
+    int np = 0;
+    BLH_TRY(launch_decode_fused_h(s, ws.A[nh - 1], ws.wsh + L.dec_w, ws.wdT, params + L.dec_b, target, pred, ws.dpred,
+                                  ws.dpredh, ws.G0, ws.loss_part, ws.dec_bias_part, batch, W, OF, mse_scale, &np));
+    if (loss_nparts) *loss_nparts = np;
+    ctx->dec_da_ws = ws.wsh; ctx->dec_da_batch = batch;     // (the backward that follows finds dA in G0)
+    return BLH_OK;
+  }
   if (decode_fwd_supported(batch, W, OF)) {
     int np = 0;
     BLH_TRY(launch_decode_fwd_mse_h(s, ws.A[nh - 1], ws.wsh + L.dec_w, params + L.dec_b, target, pred,
@@ -192,8 +208,13 @@ int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const f
     return BLH_OK;
   };
   // decode: dA_last = dP W_d (carries the first fork), dW = dP^T A_last, db = colsum(dP)
+  // (one-pass decode: the forward that produced this dpred already left dA in G0)
+  const bool have_da = dec_bias_S > 0 && dpred == ws.dpred && ctx->dec_da_ws == ws.wsh && ctx->dec_da_batch == batch;
+  ctx->dec_da_ws = nullptr;
   if (dec_bias_S == 0) BLH_TRY(launch_cast_f32_bf16(s, dpred, ws.dpredh, batch * OF));
-  {
+  if (have_da) {
+    if (two) BLH_HIP_TRY(hipEventRecord(ctx->ev_dz[nh], s));     // (fork_wait below waits for it)
+  } else {
     GemmParamsH g{};
     g.A = ws.dpredh; g.lda = OF;
     g.B = ws.wsh + L.dec_w; g.ldb = W;
