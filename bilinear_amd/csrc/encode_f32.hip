@@ -97,9 +97,14 @@ __global__ __launch_bounds__(256) void enc_xstats_kernel(const TX* __restrict__ 
       const int64_t row = base + 4 * st + q;
       const TX* xr = x + min(row, batch - 1) * ENC_IF + n;
       const bool ok = row < r1;
-      xv[st][0] = ok ? enc_ld1(xr) - c0 : 0.f;
-      xv[st][1] = ok ? enc_ld1(xr + 16) - c1 : 0.f;
+      // (unconditional loads — the row is clamped — and a select afterwards: a load under a lane mask compiles to
+      //  branch + load + full wait, sixteen dependent round trips here: 8.7 instead of 5 us)
+      const float v0 = enc_ld1(xr), v1 = enc_ld1(xr + 16);
+      xv[st][0] = ok ? v0 : c0;
+      xv[st][1] = ok ? v1 : c1;
     }
+#pragma unroll
+    for (int st = 0; st < 8; ++st) { xv[st][0] -= c0; xv[st][1] -= c1; }
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
       cs0 += xv[st][0]; cs1 += xv[st][1];

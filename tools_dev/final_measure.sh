@@ -18,4 +18,6 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/prof_driver -o f -- python3 $root/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $root/$out/prof_driver.json 2> $root/$out/prof_driver.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/prof_cfg2 -o f -- python3 $root/bench.py --config 2 --no-configs --no-cpu-baseline --no-alt --no-strong-line --steps 30 --warmup 10 > $root/$out/prof_cfg2.json 2> $root/$out/prof_cfg2.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/prof_cfg1 -o f -- python3 $root/bench.py --no-configs --no-cpu-baseline --no-alt --no-strong-line --steps 30 --warmup 10 > $root/$out/prof_cfg1.json 2> $root/$out/prof_cfg1.err
+# (the driver-form trace is tens of MB — gpurun merges at most 64 MiB back: its per-kernel statistics are what is kept)
+rm -f $root/$out/prof_driver/f_kernel_trace.csv
 echo "profiles done"
