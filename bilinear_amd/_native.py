@@ -136,6 +136,8 @@ _SIGNATURES = {
                                       POINTER(c_int32), c_int64, c_int32, c_int32]),
     "blh_skinny_decode_fwd_mse": (c_int, [c_void_p] * 9 + [c_int64, c_int64, c_int32, c_int32]),
     "blh_skinny_decode_fused": (c_int, [c_void_p] * 10 + [c_int64, c_int64, c_int32, c_int32]),
+    "blh_skinny_decode_fused_bf16_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32]),
+    "blh_skinny_decode_fused_bf16": (c_int, [c_void_p] * 10 + [c_int64, c_int64, c_int32, c_int32]),
     "blh_skinny_encode_fused_fwd": (c_int, [c_void_p] * 9 + [c_float] + [c_void_p] * 5 + [c_int64, c_int32, c_int32]),
     "blh_skinny_encode_fused_bwd": (c_int, [c_void_p] * 12 + [c_int64, c_int32, c_int32]),
     "blh_skinny_decode_bwd": (c_int, [c_void_p] * 7 + [c_int64, c_int64, c_int32, c_int32]),

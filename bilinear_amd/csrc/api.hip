@@ -1133,6 +1133,49 @@ int blh_skinny_decode_fused(void* stream, const float* A, const float* Wd, const
   return loss_out ? launch_loss_finalize((hipStream_t)stream, loss_part, np, denom, loss_out) : BLH_OK;
 }
 
+// bf16 storage: workspace = [Wd bf16 | 64 pad | WdT image | dpred bf16 | decode-bias partials | loss partials]
+static int64_t dec_h_ws_off(int64_t batch, int W, int OF, int which) {
+  int64_t off[6];
+  off[0] = 0;                                                        // Wd image, OF * W bf16
+  off[1] = off[0] + round_up((int64_t)OF * W * 2, 256);              // scratch for the second tensor of the cast launch
+  off[2] = off[1] + 256;                                             // WdT image, W * 64 bf16
+  off[3] = off[2] + round_up((int64_t)W * 64 * 2, 256);              // dpred bf16
+  off[4] = off[3] + round_up(batch * OF * 2, 256);                   // decode-bias partials (1026 * OF floats)
+  off[5] = off[4] + round_up((int64_t)1026 * OF * 4 + 4096 * 4, 256);   // end
+  return off[which];
+}
+
+int64_t blh_skinny_decode_fused_bf16_workspace_bytes(int64_t batch, int32_t width, int32_t out_features) {
+  if (batch <= 0 || width <= 0 || out_features <= 0) return BLH_ERR_INVALID_ARGUMENT;
+  return dec_h_ws_off(batch, width, out_features, 5);
+}
+
+int blh_skinny_decode_fused_bf16(void* stream, const uint16_t* A, const float* Wd, const float* bd,
+                                 const float* target, float* pred, float* dpred, uint16_t* dA, float* loss_out,
+                                 void* workspace, int64_t workspace_bytes, int64_t batch, int32_t width,
+                                 int32_t out_features) {
+  if (!A || !Wd || !bd || !target || !pred || !dpred || !dA || !workspace || batch <= 0)
+    return BLH_ERR_INVALID_ARGUMENT;
+  if (!decode_fused_h_supported(batch, width, out_features)) return BLH_ERR_SHAPE;
+  if (workspace_bytes < dec_h_ws_off(batch, width, out_features, 5)) return BLH_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  char* w = (char*)workspace;
+  const int W = width, OF = out_features;
+  uint16_t* wdh = (uint16_t*)(w + dec_h_ws_off(batch, W, OF, 0));
+  uint16_t* pad = (uint16_t*)(w + dec_h_ws_off(batch, W, OF, 1));
+  uint16_t* wdT = (uint16_t*)(w + dec_h_ws_off(batch, W, OF, 2));
+  uint16_t* dph = (uint16_t*)(w + dec_h_ws_off(batch, W, OF, 3));
+  float* part = (float*)(w + dec_h_ws_off(batch, W, OF, 4));
+  float* loss_part = part + 1026 * (int64_t)OF;
+  // the decode weight's two bf16 images in one launch (the bias rides along as the launch's second tensor)
+  BLH_TRY(launch_cast2_f32_bf16(s, Wd, wdh, (int64_t)OF * W, bd, pad, OF, Wd, wdT, W, OF));
+  const double denom = (double)batch * OF;
+  int np = 0;
+  BLH_TRY(launch_decode_fused_h(s, A, wdh, wdT, bd, target, pred, dpred, dph, dA, loss_part, part, batch, W, OF,
+                                (float)(2.0 / denom), &np));
+  return loss_out ? launch_loss_finalize(s, loss_part, np, denom, loss_out) : BLH_OK;
+}
+
 int blh_skinny_decode_bwd(void* stream, const float* dpred, const float* A, const float* Wd,
                           float* dWd, float* dA, void* workspace, int64_t workspace_bytes,
                           int64_t batch, int32_t width, int32_t out_features) {

@@ -569,6 +569,16 @@ int blh_skinny_decode_fused(void* stream, const float* A, const float* Wd, const
                             const float* target, float* pred, float* dpred, float* dA, float* loss_out,
                             void* workspace, int64_t workspace_bytes, int64_t batch, int32_t width,
                             int32_t out_features);
+/* The same for bf16 storage (r05; what the bf16-storage step launches: out_features == 48, width % 256 == 0):
+ * A and dA are bf16 [B][W] (raw uint16 bit patterns), Wd / bd / target / pred / dpred fp32; Wd is rounded to bf16
+ * inside (the step reads its bf16 parameter image), dpred is also rounded to bf16 before dA = dpred Wd is formed
+ * (fp32 accumulation), as the bf16 backward GEMM it replaces did.  `workspace`: at least
+ * blh_skinny_decode_fused_bf16_workspace_bytes(batch, width, out_features) bytes.                                   */
+int64_t blh_skinny_decode_fused_bf16_workspace_bytes(int64_t batch, int32_t width, int32_t out_features);
+int blh_skinny_decode_fused_bf16(void* stream, const uint16_t* A, const float* Wd, const float* bd,
+                                 const float* target, float* pred, float* dpred, uint16_t* dA, float* loss_out,
+                                 void* workspace, int64_t workspace_bytes, int64_t batch, int32_t width,
+                                 int32_t out_features);
 int blh_skinny_decode_bwd(void* stream, const float* dpred, const float* A, const float* Wd,
                           float* dWd, float* dA, void* workspace, int64_t workspace_bytes,
                           int64_t batch, int32_t width, int32_t out_features);

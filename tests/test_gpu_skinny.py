@@ -142,6 +142,63 @@ def test_decode_one_pass_forward_mse_and_data_gradient(native, batch, width):
                                           width, 32) != 0
 
 
+def _bf16_round(a):
+    """fp32 -> nearest-even bf16, as fp32 values and as raw uint16 bit patterns."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32)
+    return (r << 16).astype(np.uint32).view(np.float32), r.astype(np.uint16)
+
+
+@pytest.mark.parametrize("batch,width", [(4096, 1024), (4104, 1024), (16384, 2048), (40, 256)])
+def test_decode_one_pass_bf16_storage(native, batch, width):
+    """decode_fwd_mse_h_kernel<RT, FUSE> (round 5, what the bf16-storage step launches): prediction, MSE, dpred, loss and
+    the decode data gradient dA = dP Wd (bf16) from one read of the bf16 activation, through the C entry point against
+    fp64 NumPy on the same bf16-rounded operands (A, Wd; dP is rounded to bf16 before the second contraction, as the
+    backward GEMM this replaces did).  (16384, 2048) is configs[4]'s per-GPU decode; 4104 and 40 leave a ragged last
+    row block.  /root/reference/model/bilinear.py:29,39; train_bilinear.py:78-79."""
+    dev = _dev()
+    rng = np.random.RandomState(batch + width + 11)
+    OF = 48
+    A32, Abits = _bf16_round(rng.standard_normal((batch, width)).astype(np.float32))
+    Wd = (rng.standard_normal((OF, width)) * 0.05).astype(np.float32)
+    Wd32, _ = _bf16_round(Wd)
+    bd = rng.standard_normal(OF).astype(np.float32)
+    t = rng.standard_normal((batch, OF)).astype(np.float32)
+    a = torch.from_numpy(Abits.view(np.int16)).to(dev)
+    w, b, tt = (torch.from_numpy(v).to(dev) for v in (Wd, bd, t))
+    pred = torch.full((batch + 3, OF), float("nan"), device=dev)
+    dpred = torch.full((batch + 3, OF), float("nan"), device=dev)
+    dA = torch.full((batch + 3, width), -1, dtype=torch.int16, device=dev)
+    loss = torch.zeros((), device=dev)
+    wsb = native.blh_skinny_decode_fused_bf16_workspace_bytes(batch, width, OF)
+    assert wsb > 0
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = native.blh_skinny_decode_fused_bf16(st, a.data_ptr(), w.data_ptr(), b.data_ptr(), tt.data_ptr(), pred.data_ptr(),
+                                             dpred.data_ptr(), dA.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsb, batch,
+                                             width, OF)
+    assert rc == 0, native.blh_status_string(rc)
+    torch.cuda.synchronize()
+    ref = A32.astype(np.float64) @ Wd32.T.astype(np.float64) + bd
+    _close(pred[:batch].cpu().numpy(), ref, 2e-5, "pred")
+    d = ref - t
+    dp = 2 * d / d.size
+    _close(dpred[:batch].cpu().numpy(), dp, 1e-4, "dpred")
+    assert abs(loss.item() - (d ** 2).mean()) <= 1e-5 * (d ** 2).mean()
+    # dA: the kernel's own fp32 dpred rounded to bf16, times the bf16 weight, fp32 accumulation, one bf16 rounding
+    dph, _ = _bf16_round(dpred[:batch].cpu().numpy())
+    want = dph.astype(np.float64) @ Wd32.astype(np.float64)
+    got = (dA[:batch].cpu().numpy().view(np.uint16).astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 2.0 ** -8 * scale * 1.01 + 1e-12, np.abs(got - want).max() / scale   # half a bf16 ulp
+    rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert rel <= 3e-3, rel
+    assert torch.isnan(pred[batch:]).all() and torch.isnan(dpred[batch:]).all() and (dA[batch:] == -1).all()
+    assert native.blh_skinny_decode_fused_bf16(st, a.data_ptr(), w.data_ptr(), b.data_ptr(), tt.data_ptr(), pred.data_ptr(),
+                                               dpred.data_ptr(), dA.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsb, batch,
+                                               width, 32) != 0
+
+
 @pytest.mark.parametrize("batch,width", [(4096, 1024), (4100, 1024), (900, 256), (16384, 1024)])
 def test_encode_stage_without_its_pre_batchnorm_tensor(native, batch, width):
     """encode_f32.hip (round 5) through its C entry points against fp64 NumPy: forward x -> A0 = 2 keep relu(BN(x W0^T +
