@@ -285,21 +285,28 @@ static Splits wgrad_plan_h(int64_t M, int64_t N, int64_t batch) {
 // BatchNorm chain, which cannot run beside one: 7.73 -> 7.40 ms).  Under a bucket hook `items` is a group of
 // WGRAD_HOOK_GROUP stages (api.hip: backward_h).  {0, 0}: not applicable (the per-stage plan above is used).
 static constexpr int WGRAD_HOOK_GROUP = 4;     // stages per batched launch under a bucket hook
-static Splits wgrad_batched_plan_h(int64_t W, int64_t batch, int items) {
+static Splits wgrad_batched_plan_h(int64_t W, int64_t batch, int items, bool hook = false) {
   static const bool off = std::getenv("BLH_NO_BATCHED_WGRAD") != nullptr;     // (developer knob, read once)
   if (items < 2 || W % 256 != 0 || batch % 128 != 0 || off) return Splits{0, 0};
   const int64_t tiles = (W / 256) * (W / 256);
   int64_t s = 1;
   while (s < 8 && tiles * items * (s * 2) <= 256) s *= 2;
   while (s > 1 && batch % (s * 128) != 0) s >>= 1;
-  // (each workgroup at least 4096 rows deep: below that the per-stage plan measured as fast or faster —
-  //  0.434 against 0.441 ms per step at 2 x 1024, B = 4096; 1.109 against 1.125 ms for the data-parallel
-  //  step at B = 8192 with groups of four stages x 4 slabs)
+  // (round 4 asked for workgroups at least 4096 rows deep and >= 224 of them; round 5's sweep of 2 x 1024 and 4 x 1024
+  //  at 1024 .. 6144 rows — tools_dev/bf16_small_batch_ab.sh, profiles/r05_bf16_small_batch.md — has ONE launch beat the
+  //  per-stage launches + slab sums down to 512 rows per workgroup (every winning case had 256 workgroups): 4 x 1024 at 1024 / 2048 / 3072 /
+  //  4096 rows 0.659 / 0.692 / 0.720 / 0.736 -> 0.611 / 0.644 / 0.673 / 0.719 ms; 2 x 1024 at 4096 rows +1 %)
   static const int64_t min_rows = [] {      // (developer knob, read once: rows per workgroup below which the plan is refused)
     const char* e = std::getenv("BLH_WGRAD_BATCHED_MIN_ROWS");
-    return e ? (int64_t)std::atoll(e) : (int64_t)4096;
+    return e ? (int64_t)std::atoll(e) : (int64_t)512;
   }();
-  if (tiles * items * s < 224 || batch / s < min_rows) return Splits{0, 0};
+  static const int64_t min_wgs = [] {       // (developer knob, read once: workgroups below which the plan is refused)
+    const char* e = std::getenv("BLH_WGRAD_BATCHED_MIN_WGS");
+    return e ? (int64_t)std::atoll(e) : (int64_t)224;     // (what gemm_bf16s_pick_tile asks of a 256 x 256 launch)
+  }();
+  // (under a bucket hook the round-4 depth stays: groups become ready together, and a 2-block model whose four hidden
+  //  stages form ONE group would put the whole arena on the wire after the last stage — no overlap left)
+  if (tiles * items * s < min_wgs || batch / s < (hook ? std::max<int64_t>(min_rows, 4096) : min_rows)) return Splits{0, 0};
   return Splits{(int)s, (int)(batch / s)};
 }
 
@@ -341,8 +348,10 @@ static WorkspaceH carve_h(const blh_model_desc* d, int64_t batch, void* base) {
     const int hidden = 2 * d->num_blocks;
     int64_t need = 0;
     for (int items : {hidden, std::min(hidden, WGRAD_HOOK_GROUP), hidden % WGRAD_HOOK_GROUP}) {
-      const Splits bp = wgrad_batched_plan_h(W, batch, items);
-      if (bp.splits > 1) need = std::max(need, (int64_t)items * bp.splits * W * W);
+      for (bool hook : {false, true}) {
+        const Splits bp = wgrad_batched_plan_h(W, batch, items, hook);
+        if (bp.splits > 1) need = std::max(need, (int64_t)items * bp.splits * W * W);
+      }
     }
     ws.bslabs = need ? (float*)take(need * sizeof(float)) : nullptr;
   }

@@ -242,7 +242,7 @@ int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const f
     } else {
       for (int hi = nh - 1; hi >= 1; hi -= WGRAD_HOOK_GROUP) {
         const int lo = std::max(1, hi - (WGRAD_HOOK_GROUP - 1));
-        wgroups.push_back(WGroup{lo, hi, wgrad_batched_plan_h(W, batch, hi - lo + 1)});
+        wgroups.push_back(WGroup{lo, hi, wgrad_batched_plan_h(W, batch, hi - lo + 1, true)});
       }
     }
   }

@@ -196,7 +196,9 @@ def _entry_with_masks(nb, width, batch, dev, rounding=None, thr=1e-4, safe=True)
 
 
 @pytest.mark.parametrize("mode", FP32_MODES)
-@pytest.mark.parametrize("batch", [1536, 2048, 4096, 4100])      # (1536, 2048: fp32 runs 64-row GEMM tiles, mid_tile64)
+# (512, 1024: the split-K forward / data gradient with its finishing kernels — the per-GPU shapes of the headline batch
+#  split 8 / 4 ways; 1536, 2048: fp32 runs 64-row GEMM tiles, mid_tile64; 2304: 128-row tiles on a partial round)
+@pytest.mark.parametrize("batch", [512, 1024, 1536, 2048, 2304, 4096, 4100])
 def test_timed_path_step_matches_oracle(batch, mode):
     """blh_train_step exactly as bench.py runs it (non-split-K forward, two-stream backward)
     against the fp64 oracle; then the drop-in forward / backward (raw gradients) from the same
