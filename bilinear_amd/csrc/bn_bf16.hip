@@ -234,6 +234,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_h2_kernel(const float* __
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int col = blockIdx.x * 16 + cl;
   double a1 = 0.0, a2 = 0.0;
+  // (what the storing thread needs at the end: requested with the partials, not in a round trip of its own)
+  float p_mean = 0.f, p_invstd = 0.f;
+  if (sl == 0 && col < W) { p_mean = mean[col]; p_invstd = invstd[col]; }
   if (col < W)
     for (int s0 = sl; s0 < S; s0 += 16 * 8) {
       float v1[8], v2[8];
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_h2_kernel(const float* __
     double t1 = 0.0, t2 = 0.0;
 #pragma unroll
     for (int s = 0; s < 16; ++s) { t1 += r1[s][cl]; t2 += r2[s][cl]; }
-    const float dg = (float)((double)invstd[col] * (t1 - (double)mean[col] * t2)), db = (float)t2;
+    const float dg = (float)((double)p_invstd * (t1 - (double)p_mean * t2)), db = (float)t2;
     dgamma[col] = dg;
     dbeta[col] = db;
     if (sq) {   // sum of squares of the 32 gradients this block wrote (lanes 0-15 of wave 0 hold them)

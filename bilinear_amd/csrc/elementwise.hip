@@ -124,6 +124,8 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
   // both passes read every tile partial of this column with the loads of 8 tiles in flight
   constexpr int U = 8;
   const int cc = ok ? col : 0;
+  BnColumnIn pre{};
+  if (sl == 0) pre = bn_finalize_prefetch(cc, gamma, beta, running_mean, running_var);
   auto fast = [&](auto uc) {
     // every partial this thread needs — (mean, M2) of up to UF tiles — is requested at once and
     // kept in registers for the second step: one memory round trip instead of two (this kernel is
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
       double m2 = 0.0;
 #pragma unroll
       for (int s = 0; s < 8; ++s) m2 += red[s][cl];
-      bn_finalize_store(mean1, m2, batch, col, gamma, beta, running_mean, running_var, nbt, momentum,
+      bn_finalize_store(mean1, m2, batch, col, pre, running_mean, running_var, nbt, momentum,
                         saved_mean, saved_invstd, scale, shift);
     }
   };
@@ -716,9 +718,24 @@ __device__ __forceinline__ void clip_adam_body(float* __restrict__ p, const TG* 
                                                const double* __restrict__ sumsq_part, int nparts,
                                                float* stats_out, const LossFinish& lf,
                                                bf16_bits* __restrict__ shadow, double* sh) {
+  // The first elements of this thread and ALL of its norm partials are requested before anything waits: the norm
+  // reduction (up to sixteen partials per thread, then a tree with eight barriers) used to be a chain of dependent
+  // round trips in front of a kernel that is otherwise a pure stream.  Same sums in the same order.
+  const int64_t n4 = count >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t i0 = i < n4 ? i : 0;                   // (clamped: an unconditional load, selected below)
+  float4 gv = ld4(gin + i0 * 4), mv = ld4(m + i0 * 4), vv = ld4(v + i0 * 4), pv = ld4(p + i0 * 4);
+  constexpr int NP = 16;                               // 256 threads x 16 = 4096 partials at most (SUMSQ_*_PARTS)
+  double part_v[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) part_v[k] = sumsq_part[min((int)threadIdx.x + 256 * k, max(nparts - 1, 0))];
   finish_loss(lf, sh);
   double a = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += 256) a += sumsq_part[i];
+#pragma unroll
+  for (int k = 0; k < NP; ++k)
+    if ((int)threadIdx.x + 256 * k < nparts) a += part_v[k];
+  for (int k = (int)threadIdx.x + 256 * NP; k < nparts; k += 256) a += sumsq_part[k];      // (never taken today)
   sh[threadIdx.x] = a;
   __syncthreads();
   for (int o = 128; o >= 1; o >>= 1) {
@@ -733,10 +750,7 @@ __device__ __forceinline__ void clip_adam_body(float* __restrict__ p, const TG* 
     stats_out[1] = coef;
   }
   const float gmul = coef * gscale;      // (gscale == 1 on the fp32 path: bit-identical to coef)
-  const int64_t n4 = count >> 2;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    float4 gv = ld4(gin + i * 4), mv = ld4(m + i * 4), vv = ld4(v + i * 4), pv = ld4(p + i * 4);
+  while (i < n4) {
     float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x; float* pp = &pv.x;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -749,6 +763,8 @@ __device__ __forceinline__ void clip_adam_body(float* __restrict__ p, const TG* 
     }
     st4(gout + i * 4, gv); st4(m + i * 4, mv); st4(v + i * 4, vv); st4(p + i * 4, pv);
     if (shadow) st4(shadow + i * 4, pv);
+    i += stride;
+    if (i < n4) { gv = ld4(gin + i * 4); mv = ld4(m + i * 4); vv = ld4(v + i * 4); pv = ld4(p + i * 4); }
   }
 }
 
