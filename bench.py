@@ -484,14 +484,16 @@ BASELINE_CONFIGS = {
 }
 
 
-def workload_label(args, world):
-    """Names the BASELINE.json config only when the run really is that config."""
+def workload_label(args, n_devices, rehearsal=None):
+    """Names the BASELINE.json config only when the run really is that config.  ``n_devices`` is the number of
+    DISTINCT GPUs the ranks hold (comm_block), not WORLD_SIZE; a rehearsal is labelled as one."""
+    tail = "" if rehearsal is None else " [REHEARSAL: %s]" % rehearsal
     for idx, c in BASELINE_CONFIGS.items():
         if (args.blocks, args.width, args.batch, args.dtype) == (c["blocks"], c["width"], c["batch"], c["dtype"]):
-            per_gpu = "" if world == c["gpus"] else " [per-GPU shape of the config, run on %d GPU%s]" % (
-                world, "" if world == 1 else "s")
-            return "BASELINE configs[%d]: %s%s" % (idx, c["text"], per_gpu)
-    return "custom: %d-block width %d, batch %d per GPU, %s" % (args.blocks, args.width, args.batch, args.dtype)
+            per_gpu = "" if (n_devices == c["gpus"] and rehearsal is None) else (
+                " [per-GPU shape of the config, run on %d GPU%s]" % (n_devices, "" if n_devices == 1 else "s"))
+            return "BASELINE configs[%d]: %s%s%s" % (idx, c["text"], per_gpu, tail)
+    return "custom: %d-block width %d, batch %d per GPU, %s%s" % (args.blocks, args.width, args.batch, args.dtype, tail)
 
 
 def log(msg):
@@ -514,6 +516,77 @@ def host_cores():
     except (OSError, ValueError):
         pass
     return max(1, min(n, 16))
+
+
+def device_identity(dev):
+    """What THIS rank holds, for the ``comm`` block of an N > 1 line: hostname, pid, HIP device index, PCI bus id
+    (hipDeviceGetPCIBusId of the runtime torch loaded), UUID and name as torch reports them.  Two ranks hold
+    DISTINCT GPUs exactly when their (hostname, pci_bus_id) differ."""
+    ident = {"hostname": socket.gethostname(), "pid": os.getpid(), "device_index": int(dev.index or 0),
+             "visible": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES")),
+             "pci_bus_id": None, "uuid": None, "name": None}
+    try:
+        props = torch.cuda.get_device_properties(dev)
+        ident["name"] = props.name
+        uuid = getattr(props, "uuid", None)
+        ident["uuid"] = None if uuid is None else str(uuid)
+    except Exception as exc:   # noqa: BLE001  (identity only)
+        ident["name"] = "unknown (%s)" % type(exc).__name__
+    try:
+        hip = ctypes.CDLL("libamdhip64.so.7")     # same soname as the runtime torch loaded: resolves to it
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, ctypes.c_int(ident["device_index"])) == 0:
+            ident["pci_bus_id"] = buf.value.decode()
+    except (OSError, AttributeError):
+        pass
+    return ident
+
+
+def distinct_devices(ranks):
+    """Number of distinct GPUs behind a list of device_identity() records: (hostname, PCI bus id), falling back to
+    the UUID, then to (hostname, visible-devices string, device index) when the runtime gave neither."""
+    keys = set()
+    for r in ranks:
+        if r.get("pci_bus_id"):
+            keys.add((r.get("hostname"), "pci", r["pci_bus_id"]))
+        elif r.get("uuid"):
+            keys.add((r.get("hostname"), "uuid", r["uuid"]))
+        else:
+            keys.add((r.get("hostname"), "index", r.get("visible"), r.get("device_index")))
+    return len(keys)
+
+
+def comm_block(ident, rehearse, native=False):
+    """COLLECTIVE (every rank calls it): the record that lets an N > 1 line prove what it ran on.  Backend and world
+    size as the process group reports them, the RCCL version torch was built against and the one the loaded
+    librccl answers with, and every rank's device identity (all-gathered).  ``n_distinct_devices`` is what the
+    line's ``n_gpus`` reports; a rehearsal (N ranks time-slicing one GPU over gloo) says so in ``rehearsal``."""
+    world = dist.get_world_size()
+    ranks = [None] * world
+    dist.all_gather_object(ranks, dict(ident, rank=dist.get_rank()))
+    backend = str(dist.get_backend())
+    out = {"backend": backend, "world_size": world, "ranks": ranks, "n_distinct_devices": distinct_devices(ranks),
+           "n_hosts": len({r.get("hostname") for r in ranks}),
+           "collectives": "bilinear_amd native RCCL (ncclAllReduce from blh_backward)" if native
+                          else "torch.distributed process group",
+           "rccl_version_torch_built_with": None, "rccl_version_loaded": None, "rehearsal": None}
+    try:
+        out["rccl_version_torch_built_with"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:   # noqa: BLE001
+        pass
+    try:
+        rccl = ctypes.CDLL("librccl.so.1")
+        v = ctypes.c_int(0)
+        if rccl.ncclGetVersion(ctypes.byref(v)) == 0:
+            out["rccl_version_loaded"] = int(v.value)
+    except (OSError, AttributeError):
+        pass
+    if rehearse:
+        out["rehearsal"] = "%d ranks on %d GPU%s over %s: control flow only, NOT a multi-GPU measurement" % (
+            world, out["n_distinct_devices"], "" if out["n_distinct_devices"] == 1 else "s", backend)
+    elif backend == "nccl" and out["n_distinct_devices"] != world:
+        out["warning"] = "%d ranks share %d device(s): not one rank per GPU" % (world, out["n_distinct_devices"])
+    return out
 
 
 def _free_port():
@@ -543,14 +616,63 @@ def self_launch(n):
     log("self-launch: %s" % " ".join(cmd))
     # rank 0's JSON line goes to stdout; anything else a library printed there (gloo / RCCL banners)
     # goes to stderr, so that stdout carries exactly the one line of the contract
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
-    for line in proc.stdout:
-        if line.startswith('{"metric"'):
-            sys.stdout.write(line)
-            sys.stdout.flush()
-        else:
-            sys.stderr.write(line)
-    raise SystemExit(proc.wait())
+    # the launcher and its ranks get a session (= process group) of their own, so that whatever happens here — a rank
+    # that raised, an interrupt, a launcher that died — every descendant can be signalled by group id and none is
+    # left holding the GPU
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1, start_new_session=True)
+    rc = 1
+    try:
+        for line in proc.stdout:
+            if line.startswith('{"metric"'):
+                sys.stdout.write(line)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write(line)
+        rc = proc.wait()
+    finally:
+        left = reap_process_group(proc.pid)
+        if left:
+            log("self-launch: %d process(es) of the launch group outlived the launcher and were killed" % left)
+            rc = rc or 1
+    log("self-launch: children exited with code %d" % rc)
+    raise SystemExit(rc)
+
+
+def reap_process_group(pgid, grace_s=5.0):
+    """SIGTERM, then SIGKILL after ``grace_s``, to whatever is still alive in process group ``pgid`` (the session
+    self_launch started).  Returns how many processes had to be signalled (0 = the group had exited by itself)."""
+    import signal
+
+    def members():
+        out = []
+        for name in os.listdir("/proc"):
+            if not name.isdigit():
+                continue
+            try:
+                with open("/proc/%s/stat" % name) as f:
+                    fields = f.read().rsplit(")", 1)[1].split()
+                if int(fields[2]) == pgid and fields[0] != "Z":
+                    out.append(int(name))
+            except (OSError, IndexError, ValueError):
+                pass
+        return out
+    alive = members()
+    if not alive:
+        return 0
+    n = len(alive)
+    try:
+        os.killpg(pgid, signal.SIGTERM)
+    except (ProcessLookupError, PermissionError):
+        return n
+    deadline = time.time() + grace_s
+    while time.time() < deadline and members():
+        time.sleep(0.1)
+    if members():
+        try:
+            os.killpg(pgid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError):
+            pass
+    return n
 
 
 def pre_ramp(one_step, min_ms, agree=None):
@@ -738,6 +860,9 @@ def main():
                          "(SURVEY.md 8(d)); default is weak scaling, --batch per GPU")
     ap.add_argument("--no-strong-line", action="store_true",
                     help="with --gpus N > 1: skip the extra strong-scaling measurement")
+    ap.add_argument("--strong-global-batch", type=int, default=None,
+                    help="with --gpus N > 1: global batch of the strong-scaling sub-measurement (default: the "
+                         "config's batch, e.g. 4096 -> 512 rows per rank at N = 8); must divide by 32 * N")
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the extra timing of the bf16x3 GEMM mode (reported beside the headline)")
@@ -814,14 +939,15 @@ def main():
         net.engine.workspace(args.batch)      # activations / gradient staging for this batch
         opt._ensure_moments(net.engine)       # exp_avg / exp_avg_sq arenas
         strong_pre = None
-        if not args.strong and not args.no_strong_line and cfg["batch"] % (32 * world) == 0:
+        strong_global = args.strong_global_batch or cfg["batch"]
+        if not args.strong and not args.no_strong_line and strong_global % (32 * world) == 0:
             # (the second model of the strong-scaling sub-measurement, for the same reason)
             torch.manual_seed(1)
             net_s, opt_s, _, _ = bilinear_amd.load(dev, num_blocks=args.blocks, width=args.width,
                                                    gemm_dtype=args.dtype)
             net_s.train()
             net_s.engine.ensure(dev)
-            net_s.engine.workspace(cfg["batch"] // world)
+            net_s.engine.workspace(strong_global // world)
             opt_s._ensure_moments(net_s.engine)
             strong_pre = (net_s, opt_s)
         torch.cuda.synchronize()
@@ -859,6 +985,9 @@ def main():
         dp.stream.wait_stream(torch.cuda.current_stream(dev))
         torch.cuda.set_stream(dp.stream)
     log("model built, pre-ramp + warm-up")
+    if os.environ.get("BLH_BENCH_FAIL_RANK") == str(rank):
+        # developer: rehearse a rank that raises (the launcher must end the other ranks and the parent must exit non-zero)
+        raise RuntimeError("BLH_BENCH_FAIL_RANK=%d: injected failure on this rank" % rank)
     def slowest_rank(ms):
         v = torch.tensor([ms], device=dev, dtype=torch.float64)
         dist.all_reduce(v, op=dist.ReduceOp.MAX)
@@ -889,10 +1018,14 @@ def main():
     # reported as a sub-object, so one driver run per N yields both curves.
     strong = None
     if multi and strong_pre is not None:
-        sb = cfg["batch"] // world
+        sb = strong_global // world
         net_s, opt_s = strong_pre
         dp_s = DataParallel(net_s, opt_s, sync_bn=args.sync_bn, force_collectives=args.rehearse_rccl)
-        xs, ts = x[:sb].contiguous(), t[:sb].contiguous()
+        if sb <= args.batch:
+            xs, ts = x[:sb].contiguous(), t[:sb].contiguous()
+        else:                                   # (a rehearsal with a tiny --batch)
+            xs = torch.randn(sb, 32, device=dev, generator=g)
+            ts = torch.randn(sb, 48, device=dev, generator=g)
         n_s = max(20, min(args.steps, 300))
         for _ in range(max(5, min(args.warmup, 50))):
             dp_s.train_step(xs, ts)
@@ -914,6 +1047,12 @@ def main():
     if dp is not None and dp.stream is not None:
         torch.cuda.synchronize()
         torch.cuda.set_stream(torch.cuda.default_stream(dev))
+
+    # what the ranks ran on (collective: every rank takes part); N = 1 without a process group has nothing to gather
+    comm = comm_block(device_identity(dev), rehearse, native=bool(getattr(args, "native_rccl", False))) \
+        if (multi and dist.is_initialized()) else None
+    n_devices = comm["n_distinct_devices"] if comm is not None else 1
+    rehearsal = comm["rehearsal"] if comm is not None else None
 
     # fwd+bwd only (no optimiser), single rank view, for the record
     def fwd_bwd():
@@ -938,9 +1077,12 @@ def main():
         dom = kern["linear_fwd"]
         result = {
             "metric": "poses/sec (fwd+bwd, 16-joint, batch 4096) at 1/2/4/8 MI355X",
-            "value": poses,
+            # a rehearsal (N ranks time-slicing one GPU over gloo) measures control flow, not throughput: no value
+            "value": None if rehearsal else poses,
             "unit": "poses/s",
-            "n_gpus": world,
+            # DISTINCT devices the ranks held (comm.ranks[*].pci_bus_id), not WORLD_SIZE
+            "n_gpus": n_devices,
+            "n_ranks": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms,
@@ -956,14 +1098,16 @@ def main():
                         "--pre-ramp-ms 0" % (ramp_steps, ramp_ms),
             "data": "synthetic",
             "config": {
-                "workload": workload_label(args, world) + "; x~N(0,1)[B,32], t~N(0,1)[B,48], "
+                "workload": workload_label(args, n_devices, rehearsal) + "; x~N(0,1)[B,32], t~N(0,1)[B,48], "
                             "Kaiming-normal init",
                 "num_blocks": args.blocks, "width": args.width, "per_gpu_batch": args.batch,
                 "step": "zero_grad+forward+MSE+backward%s+clip_grad_norm(1)+Adam" % (
                     "+allreduce(grad)" if multi else ""),
                 "global_batch": args.batch * world,
                 "parallelism": "dp%d%s" % (world, " (RCCL group of one rank, every collective issued)"
-                                           if args.rehearse_rccl else ""),
+                                           if args.rehearse_rccl else (
+                                               " (REHEARSAL: %d ranks time-slicing %d GPU over %s)" % (
+                                                   world, n_devices, comm["backend"]) if rehearsal else "")),
                 "dropout": "philox",
                 "batchnorm": ("sync (global batch)" if args.sync_bn else "per-rank statistics") if world > 1 else "single device",
                 "launch": ("hipGraph replay (1 launch/step)" if (use_graph or dp_captured is not None)
@@ -979,12 +1123,21 @@ def main():
             "step_tflops": poses * (fwd + bwd) / 1e12,
             ("step_frac_of_bf16_mfma_peak" if args.dtype == "bf16s" else "step_frac_of_fp32_mfma_peak"):
                 poses * (fwd + bwd) / 1e12 / ((BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16s"
-                                               else FP32_MFMA_PEAK_TFLOPS) * world),
+                                               else FP32_MFMA_PEAK_TFLOPS) * max(1, n_devices)),
             "roofline": roofline_block(args, dom),
             "roofline_hbm": skinny_rooflines(args.batch, args.width, reps=300),
             "kernels": kern,
         }
+        if comm is not None:
+            result["comm"] = comm
+        if rehearsal:
+            result["rehearsal"] = rehearsal
+            result["control_flow_figure"] = {"poses_per_s_all_ranks_on_shared_gpu": poses,
+                                             "note": "ranks time-slice the device(s) listed in comm.ranks: this is "
+                                                     "neither a 1-GPU nor an N-GPU throughput"}
         if strong is not None:
+            if rehearsal:
+                strong = dict(strong, value=None, control_flow_value=strong["value"], rehearsal=rehearsal)
             result["strong_scaling"] = strong
         if world == 1 and args.dtype == "fp32" and not args.no_alt:
             result["fp32_on_16bit_mfma"] = {m: alt_mode_block(args, dev, x, t, m) for m in ("bf16x3", "fp16x2")}

@@ -64,3 +64,100 @@ def test_pre_ramp_leaves_on_the_agreed_clock(monkeypatch):
     steps.clear()
     el, n = b.pre_ramp(lambda: steps.append(1), 1e-6)       # one rank: its own clock
     assert n == 10 and len(steps) == 10
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# N > 1 lines must prove what they ran on: the ``comm`` block, distinct devices, rehearsal labels
+def _ident(host, pci, index=0, uuid=None):
+    return {"hostname": host, "pid": 1, "device_index": index, "visible": None, "pci_bus_id": pci, "uuid": uuid,
+            "name": "AMD Instinct MI355X"}
+
+
+def test_n_gpus_counts_distinct_devices_not_ranks():
+    b = _bench()
+    eight = [_ident("node", "0000:%02x:00.0" % (5 + 16 * i), i) for i in range(8)]
+    assert b.distinct_devices(eight) == 8
+    assert b.distinct_devices([_ident("node", "0000:05:00.0")] * 8) == 1           # 8 ranks time-slicing one GPU
+    assert b.distinct_devices([_ident("a", "0000:05:00.0"), _ident("b", "0000:05:00.0")]) == 2    # two hosts
+    assert b.distinct_devices([_ident("a", None, 0, "GPU-1"), _ident("a", None, 1, "GPU-1")]) == 1   # UUID fallback
+    assert b.distinct_devices([_ident("a", None, 0), _ident("a", None, 1)]) == 2   # index fallback
+
+
+def test_workload_label_never_claims_gpus_it_did_not_hold():
+    b = _bench()
+    a = argparse.Namespace(blocks=2, width=1024, batch=4096, dtype="fp32")
+    assert b.workload_label(a, 1).startswith("BASELINE configs[1]") and "run on" not in b.workload_label(a, 1)
+    reh = "8 ranks on 1 GPU over gloo: control flow only, NOT a multi-GPU measurement"
+    lab = b.workload_label(a, 1, reh)
+    assert "REHEARSAL" in lab and "run on 1 GPU" in lab and "run on 8 GPUs" not in lab
+    a3 = argparse.Namespace(blocks=4, width=1024, batch=8192, dtype="bf16s")
+    assert "run on" not in b.workload_label(a3, 8)                 # configs[3] really on 8 GPUs
+    assert "run on 2 GPUs" in b.workload_label(a3, 2)
+    assert "REHEARSAL" in b.workload_label(a3, 8, reh)             # even with a matching count a rehearsal says so
+
+
+def _comm_worker(rank, world, port, out_dir, rehearse):
+    import json
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b = _bench()
+        # rehearsal: both ranks hold the same device; otherwise one device each
+        ident = _ident("box", "0000:05:00.0" if rehearse else "0000:%02x:00.0" % (5 + rank), 0 if rehearse else rank)
+        comm = b.comm_block(ident, rehearse)
+        with open(os.path.join(out_dir, "comm%d.json" % rank), "w") as f:
+            json.dump(comm, f)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rehearse", [False, True])
+def test_comm_block_world2_gloo(tmp_path, rehearse):
+    """Every rank ends with the same record: backend and world size as the group reports them, every rank's device,
+    the number of DISTINCT devices; a rehearsal is labelled as such."""
+    import json
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    mp.spawn(_comm_worker, args=(2, port, str(tmp_path), rehearse), nprocs=2, join=True)
+    c0, c1 = (json.load(open(tmp_path / ("comm%d.json" % r))) for r in (0, 1))
+    assert c0 == c1
+    assert c0["backend"] == "gloo" and c0["world_size"] == 2
+    assert [r["rank"] for r in c0["ranks"]] == [0, 1]
+    for key in ("hostname", "pid", "device_index", "pci_bus_id", "uuid", "name"):
+        assert all(key in r for r in c0["ranks"])
+    assert c0["n_distinct_devices"] == (1 if rehearse else 2) and c0["n_hosts"] == 1
+    assert "rccl_version_torch_built_with" in c0 and "rccl_version_loaded" in c0
+    if rehearse:
+        assert c0["rehearsal"].startswith("2 ranks on 1 GPU over gloo")
+    else:
+        assert c0["rehearsal"] is None
+
+
+def test_bench_source_reports_distinct_devices_and_nulls_a_rehearsal_value():
+    """The line's n_gpus is comm.n_distinct_devices (never WORLD_SIZE) and a rehearsal carries no `value`."""
+    src = open(os.path.join(REPO, "bench.py")).read()
+    assert '"n_gpus": n_devices' in src and '"n_gpus": world' not in src
+    assert '"value": None if rehearsal else poses' in src
+    assert "os.exec" not in src and "execv" not in src             # a process that touched the GPU is never replaced
+
+
+def test_reap_process_group_leaves_no_children(tmp_path):
+    """self_launch starts the launcher in a session of its own; whatever is still alive in that group when the
+    launcher has exited is terminated (a rank stuck in a collective after another rank raised)."""
+    import subprocess
+    import sys
+    import time
+    b = _bench()
+    # a "launcher" that starts a sleeping "rank" and exits at once with a failure code
+    code = ("import subprocess, sys; subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(600)']); "
+            "sys.exit(3)")
+    proc = subprocess.Popen([sys.executable, "-c", code], start_new_session=True)
+    assert proc.wait() == 3
+    time.sleep(0.2)
+    assert b.reap_process_group(proc.pid, grace_s=3.0) == 1        # the orphaned sleeper was found and ended
+    assert b.reap_process_group(proc.pid, grace_s=0.5) == 0        # nothing left
