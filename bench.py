@@ -603,7 +603,7 @@ def self_launch(n):
     rehearse = os.environ.get("BLH_BENCH_REHEARSE") == "1"
     # (device_count() may call hipGetDeviceCount on builds without amdsmi, i.e. initialise the HIP
     #  runtime in THIS process; harmless: the ranks are fresh children and nothing is exec'ed)
-    have = torch.cuda.device_count()
+    have = n if rehearse else torch.cuda.device_count()     # (a rehearsal does not even count devices here)
     if have < n and not rehearse:
         raise SystemExit("bench.py --gpus %d: this node exposes %d GPU%s (set BLH_BENCH_REHEARSE=1 to "
                          "rehearse the multi-rank control flow on one GPU over gloo)" % (n, have, "" if have == 1 else "s"))
@@ -753,9 +753,8 @@ def config_block(idx, dev, steps, ramp_ms):
 
 def batch64_block(dev, steps, ramp_ms):
     """The reference's own batch size (util/config.py:15: 64 poses; BASELINE configs[0]'s shape) on the GPU, fp32,
-    2 blocks x 1024, three forms of the same step: one launch per stage (csrc/small_step.hip, "staged": the DEFAULT at
-    <= 384 rows), the whole step as ONE persistent launch with grid barriers ("one_launch", option 2) and the
-    multi-launch path every larger batch takes; then the reference's five-call loop on the drop-in surface."""
+    2 blocks x 1024, two forms of the same step: one launch per stage (csrc/small_step.hip: the DEFAULT at <= 384 rows)
+    and the multi-launch path every larger batch takes; then the reference's five-call loop on the drop-in surface."""
     import bilinear_amd
     torch.manual_seed(1)
     net, opt, _, _ = bilinear_amd.load(dev, num_blocks=2, width=1024, gemm_dtype="fp32")
@@ -768,7 +767,7 @@ def batch64_block(dev, steps, ramp_ms):
     def one_step():
         return net.train_step(opt, x, t, max_norm=1.0)
     out = {}
-    for name, small in (("staged", 1), ("one_launch", 2), ("multi_launch", 0)):
+    for name, small in (("staged", 1), ("multi_launch", 0)):
         net.engine.set_small_step(small)
         pre_ramp(one_step, ramp_ms)
         torch.cuda.synchronize()
@@ -805,14 +804,12 @@ def batch64_block(dev, steps, ramp_ms):
     # thread): a setting of the caller's, not of this package — reported beside the default
     with torch.autograd.set_multithreading_enabled(False):
         five_st_ms = time_five()
-    timeouts = net.engine.ctx.grid_barrier_timeouts()
     del net, opt
     torch.cuda.empty_cache()
     return {"workload": "2 blocks x 1024, batch 64 (the reference's batch_size), fp32, whole training step",
             "value": out["staged"]["poses_per_s"], "unit": "poses/s",
             "ms_per_step": out["staged"]["ms_per_step"], "steps": steps,
             "launch": "small_step.hip, one launch per stage (the default of the fused step): 2 nh + 3 = 13 launches per step",
-            "one_persistent_launch": out["one_launch"], "grid_barrier_timeouts": timeouts,
             "multi_launch": out["multi_launch"], "final_loss": out["staged"]["final_loss"],
             "five_call_drop_in": {"ms_per_step": five_ms, "poses_per_s": 64e3 / five_ms,
                                   "step": "zero_grad, forward, nn.MSELoss, backward, clip_grad_norm_, Adam.step as "
@@ -1152,9 +1149,8 @@ def main():
                     idx, b["ms_per_step"], b["value"], b["roofline"]["achieved"]))
             result["configs"] = blocks
             result["batch_64"] = batch64_block(dev, 10 * args.config_steps, args.pre_ramp_ms)
-            log("batch 64: %.3f ms/step (one launch per stage), %.3f one persistent launch, %.3f multi-launch" % (
-                result["batch_64"]["ms_per_step"], result["batch_64"]["one_persistent_launch"]["ms_per_step"],
-                result["batch_64"]["multi_launch"]["ms_per_step"]))
+            log("batch 64: %.3f ms/step (one launch per stage), %.3f multi-launch" % (
+                result["batch_64"]["ms_per_step"], result["batch_64"]["multi_launch"]["ms_per_step"]))
         if world == 1 and not args.no_cpu_baseline:
             from oracle import torch_port as TP
             cores = host_cores()

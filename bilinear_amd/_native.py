@@ -110,7 +110,6 @@ _SIGNATURES = {
                                             c_void_p, c_void_p, c_int64, c_void_p]),
     "blh_gemm_bf16s_tile": (c_int32, [c_int64, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32]),
     "blh_gemm_bf16s_force_tile": (c_int, [c_int32]),
-    "blh_context_grid_barrier_timeouts": (c_int64, [c_void_p]),
     "blh_side_stream_renew": (c_int, []),
     "blh_side_stream_generation": (c_int32, []),
     "blh_tune_streams": (c_int, [c_void_p, c_int32, POINTER(c_float)]),
@@ -187,7 +186,6 @@ def lib():
 
 
 OPT_TWO_STREAM = 0
-OPT_DEFER_SLABS = 1
 OPT_LATE_FORK = 2
 OPT_PERSISTENT_SHADOW = 3
 OPT_SMALL_STEP = 4
@@ -215,14 +213,6 @@ class Context:
 
     def side_stream(self):
         return lib().blh_context_side_stream(self.handle)
-
-    def grid_barrier_timeouts(self):
-        """Grid barriers of this context's persistent launches that gave up waiting (0 unless a launch could not
-        be fully resident; its results are then wrong).  Synchronises."""
-        n = int(lib().blh_context_grid_barrier_timeouts(self.handle))
-        if n < 0:
-            check(n, "blh_context_grid_barrier_timeouts")
-        return n
 
     def __del__(self):
         try:

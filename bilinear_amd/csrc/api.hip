@@ -89,10 +89,7 @@ int blh_context_create(blh_context** out) {
     if ((e = hipEventCreateWithFlags(&c->ev_r[i], hipEventDisableTiming)) != hipSuccess) return fail(e);
   }
   // A/B switches for experiments (the documented way is blh_context_set_option)
-  if ((e = hipMalloc(reinterpret_cast<void**>(&c->grid_bar), 64)) != hipSuccess) return fail(e);
-  if ((e = hipMemset(c->grid_bar, 0, 64)) != hipSuccess) return fail(e);
   c->two_stream = getenv("BLH_ONE_STREAM") == nullptr;
-  c->defer_slabs = getenv("BLH_DEFER_SLABS") != nullptr;
   c->late_fork = getenv("BLH_EARLY_FORK") ? 0 : (getenv("BLH_LATE_FORK") ? 1 : 2);
   c->knobs = blh::dev_knobs_from_env();
   *out = c;
@@ -107,7 +104,6 @@ int blh_context_destroy(blh_context* c) {
     if (c->ev_r[i]) (void)hipEventDestroy(c->ev_r[i]);
   }
   if (c->s2) side_stream_release(c->device);
-  if (c->grid_bar) (void)hipFree(c->grid_bar);
   delete c;
   return BLH_OK;
 }
@@ -116,13 +112,12 @@ int blh_context_set_option(blh_context* c, int32_t option, int32_t value) {
   if (!c) return BLH_ERR_INVALID_ARGUMENT;
   switch (option) {
     case BLH_OPT_TWO_STREAM: c->two_stream = value != 0; return BLH_OK;
-    case BLH_OPT_DEFER_SLABS: c->defer_slabs = value != 0; return BLH_OK;
     case BLH_OPT_LATE_FORK:
       if (value < 0 || value > 2) return BLH_ERR_INVALID_ARGUMENT;
       c->late_fork = value;
       return BLH_OK;
     case BLH_OPT_SMALL_STEP:
-      if (value < 0 || value > 2) return BLH_ERR_INVALID_ARGUMENT;
+      if (value < 0 || value > 1) return BLH_ERR_INVALID_ARGUMENT;
       c->small_step = value;
       return BLH_OK;
     case BLH_OPT_PERSISTENT_SHADOW:
@@ -130,7 +125,7 @@ int blh_context_set_option(blh_context* c, int32_t option, int32_t value) {
       c->shadow_params = c->shadow_ws = nullptr;
       return BLH_OK;
     case BLH_OPT_DEV_KNOBS:
-      if (value < 0 || value > blh::KNOB_ALL) return BLH_ERR_INVALID_ARGUMENT;
+      if (value < 0 || (value & ~blh::KNOB_ALL) != 0) return BLH_ERR_INVALID_ARGUMENT;
       c->knobs = value;
       return BLH_OK;
     case BLH_OPT_BUCKET_FLOATS:
@@ -145,7 +140,6 @@ int blh_context_get_option(const blh_context* c, int32_t option) {
   if (!c) return BLH_ERR_INVALID_ARGUMENT;
   switch (option) {
     case BLH_OPT_TWO_STREAM: return c->two_stream ? 1 : 0;
-    case BLH_OPT_DEFER_SLABS: return c->defer_slabs ? 1 : 0;
     case BLH_OPT_LATE_FORK: return c->late_fork;
     case BLH_OPT_PERSISTENT_SHADOW: return c->persistent_shadow ? 1 : 0;
     case BLH_OPT_SMALL_STEP: return c->small_step;
@@ -153,13 +147,6 @@ int blh_context_get_option(const blh_context* c, int32_t option) {
     case BLH_OPT_BUCKET_FLOATS: return c->bucket_floats;
   }
   return BLH_ERR_INVALID_ARGUMENT;
-}
-
-int64_t blh_context_grid_barrier_timeouts(blh_context* c) {
-  if (!c || !c->grid_bar) return BLH_ERR_INVALID_ARGUMENT;
-  uint32_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  BLH_HIP_TRY(hipMemcpy(words, c->grid_bar, sizeof(words), hipMemcpyDeviceToHost));
-  return (int64_t)words[2] + (int64_t)words[6];      // fused bf16 forward stage + one-launch small-batch step
 }
 
 void* blh_context_side_stream(blh_context* c) {
@@ -224,24 +211,15 @@ static int check_drop(const blh_dropout* drop) {
   return BLH_OK;
 }
 
-// Batches of at most 384 rows in exact fp32 take the small-batch kernels (small_step.hip).  BLH_OPT_SMALL_STEP: 1 (default)
-// = one launch per stage (the fused step 0.153 ms against 0.200 for the persistent form; the host-bound drop-in loop
-// the same within its noise, tools_dev/dropin_b64_ab.py: medians 0.31 / 0.36 ms) — no grid barrier, no residency
-// requirement; 2 = persistent launches (one for the fused step, one each for the drop-in forward and backward);
-// 0 or BLH_NO_SMALL_STEP=1 = the multi-launch path of every other batch size.  The persistent form needs the whole
-// grid resident: where the device cannot hold it, the staged form is taken.
-// Returns 0 (not applicable), 1 (staged) or 2 (persistent).
+// Batches of at most 384 rows in exact fp32 take the small-batch kernels (small_step.hip): one launch per stage, no
+// grid barrier, no residency requirement.  BLH_OPT_SMALL_STEP 0 or BLH_NO_SMALL_STEP=1 = the multi-launch path of every
+// other batch size.  Returns 0 (not applicable) or 1 (staged).
 static int small_step_mode(const blh_context* ctx, const blh_model_desc* d, int64_t batch, bool drop_in) {
   // (gemm_dtype 2 / 3 — fp32 accuracy on the 16-bit matrix cores — take the same exact-fp32 kernels here: at 64
   //  rows there is nothing for a matrix core to win, and exact fp32 is what those modes approximate)
   if (!ctx->small_step || d->gemm_dtype == 4 || batch > 384 || ctx->sync.fn) return 0;
   if (ctx->knob(blh::KNOB_NO_SMALL_STEP) || d->width > 1024 || d->in_features > 1024) return 0;
   (void)drop_in;
-  const bool want_persistent = ctx->small_step == 2 && batch <= 64;     // (the persistent kernel holds 64 rows)
-  if (want_persistent && ctx->grid_bar) {
-    const int grid = small_step_max_grid(nullptr);
-    if (grid > 0 && d->width / 4 <= grid) return 2;
-  }
   return 1;
 }
 
@@ -264,7 +242,7 @@ static int small_params(SmallStepParams& p, blh_context* ctx, const blh_model_de
   p.bn_running = bn_running; p.nbt = bn_nbt; p.x = x; p.target = target;
   p.dpred = dpred ? const_cast<float*>(dpred) : ws.dpred; p.pred = pred; p.loss_out = loss_out; p.stats_out = stats_out;
   p.loss_part = ws.loss_part; p.sumsq_part = ws.sumsq_fold;      // (SUMSQ_FOLD_PARTS slots)
-  p.bar = ctx->grid_bar ? ctx->grid_bar + 4 : nullptr;      // (words 0-2: the bf16 fused forward stage's barrier)
+  p.bar = nullptr;
   p.drop = layer_drop(ctx, drop, 0, batch, d->width);
   p.momentum = momentum;
   p.denom = (double)batch * d->out_features;
@@ -314,8 +292,7 @@ static int small_train_step(int mode, blh_context* ctx, const blh_model_desc* d,
   SmallStepParams p;
   BLH_TRY(small_params(p, ctx, d, params, grads, exp_avg, exp_avg_sq, bn_running, bn_nbt, x, target, drop, momentum,
                        hyper, dev_state, ws, pred, loss_out, stats_out, batch, nullptr));
-  ctx->note_saved(ws.Z[0], batch, 0);     // (nothing a later blh_backward could use)
-  if (mode == 2) return launch_small_step(s, p, SS_ALL);
+  ctx->note_saved(ws.Z[0], batch, blh_context::SAVED_NONE);     // (nothing a later blh_backward could use)
   BLH_TRY(launch_small_forward_staged(s, p, true));
   const ArenaLayout L = make_layout(d);
   // gradient-norm partials: [0, W/4) the stage kernels (accumulated over the stages), [W/4, W/4 + out/4) decode, then
@@ -348,14 +325,13 @@ int blh_forward_train(blh_context* ctx, const blh_model_desc* d, void* stream, c
     return forward_h(ctx, d, (hipStream_t)stream, params, bn_running, bn_nbt, x, drop, momentum,
                      carve_h(d, batch, workspace), pred, batch, true);
   const Workspace ws = carve(d, batch, workspace);
-  if (const int mode = small_step_mode(ctx, d, batch, true)) {
+  if (small_step_mode(ctx, d, batch, true)) {
     // the drop-in forward at small batch; what it saves for backward is in the small-batch format
     SmallStepParams p;
     BLH_TRY(small_params(p, ctx, d, const_cast<float*>(params), nullptr, nullptr, nullptr, bn_running, bn_nbt, x, nullptr,
                          drop, momentum, nullptr, nullptr, ws, pred, nullptr, nullptr, batch, nullptr));
-    if (mode == 2) BLH_TRY(launch_small_step((hipStream_t)stream, p, SS_FWD));
-    else BLH_TRY(launch_small_forward_staged((hipStream_t)stream, p, false));
-    ctx->note_saved(workspace, batch, mode);
+    BLH_TRY(launch_small_forward_staged((hipStream_t)stream, p, false));
+    ctx->note_saved(workspace, batch, blh_context::SAVED_SMALL);
     return BLH_OK;
   }
   return forward_impl(ctx, d, (hipStream_t)stream, params, bn_running, bn_nbt, x, drop, momentum, ws,
@@ -400,6 +376,7 @@ int blh_forward_eval(blh_context* ctx, const blh_model_desc* d, void* stream, co
   BLH_TRY(check_common(ctx, d, workspace, workspace_bytes, batch));
   if (!params || !bn_running || !x || !pred) return BLH_ERR_INVALID_ARGUMENT;
   blh_dropout none{nullptr, 0, 0, 0, 0, 0};
+  ctx->note_saved(workspace, batch, blh_context::SAVED_NONE);      // (the activation buffers are overwritten)
   if (d->gemm_dtype == 4)
     return forward_h(ctx, d, (hipStream_t)stream, params, const_cast<float*>(bn_running), nullptr, x,
                      &none, 0.f, carve_h(d, batch, workspace), pred, batch, false);
@@ -409,7 +386,6 @@ int blh_forward_eval(blh_context* ctx, const blh_model_desc* d, void* stream, co
     SmallStepParams p;
     BLH_TRY(small_params(p, ctx, d, const_cast<float*>(params), nullptr, nullptr, nullptr, const_cast<float*>(bn_running),
                          nullptr, x, nullptr, &none, 0.f, nullptr, nullptr, ws, pred, nullptr, nullptr, batch, nullptr));
-    ctx->note_saved(workspace, batch, 0);          // (the activation buffers are overwritten)
     return launch_small_eval_staged((hipStream_t)stream, p);
   }
   return forward_impl(ctx, d, (hipStream_t)stream, params, const_cast<float*>(bn_running), nullptr, x,
@@ -486,37 +462,44 @@ static int backward_unmerged(blh_context* ctx, const blh_model_desc* d, void* st
   if (from_loss && ctx->loss_batch != batch) return BLH_ERR_INVALID_ARGUMENT;
   const int loss_nparts = ctx->loss_nparts;
   ctx->loss_batch = 0;
+  // which forward saved what is in this workspace (step.h: the record of this workspace, else what a forward with the
+  // context's present options would save — refused when that is ambiguous).  A format whose backward has no SyncBN
+  // form (the encode stage without Z0, the small-batch kernels) is refused under a SyncBN call.
   if (d->gemm_dtype == 4) {
+    const int fmt = ctx->saved_format(workspace, batch, enc_fused_ok_h(ctx, d, batch) ? blh_context::SAVED_ENC_FUSED
+                                                                                     : blh_context::SAVED_MULTI);
+    if (fmt == blh_context::SAVED_NONE || (fmt == blh_context::SAVED_ENC_FUSED && ctx->sync.fn))
+      return BLH_ERR_INVALID_ARGUMENT;
     const WorkspaceH wh = carve_h(d, batch, workspace);
     return backward_h(ctx, d, (hipStream_t)stream, params, drop, wh, from_loss ? wh.dpred : dpred, grads,
-                      batch, on_ready, user, from_loss ? loss_nparts : 0);
+                      batch, on_ready, user, fmt, from_loss ? loss_nparts : 0);
   }
   const Workspace ws = carve(d, batch, workspace);
-  // which forward saved what is in this workspace (step.h: by workspace address, else the context's last forward)
-  const blh_context::SavedFormat* saved = ctx->find_saved(workspace);
-  if (saved && (saved->mode == 1 || saved->mode == 2)) {
+  const int predicted = small_step_mode(ctx, d, batch, true) ? blh_context::SAVED_SMALL
+                        : (enc_fused_ok(ctx, d, batch) ? blh_context::SAVED_ENC_FUSED : blh_context::SAVED_MULTI);
+  const int fmt = ctx->saved_format(workspace, batch, predicted);
+  if (fmt == blh_context::SAVED_NONE || (fmt == blh_context::SAVED_ENC_FUSED && ctx->sync.fn))
+    return BLH_ERR_INVALID_ARGUMENT;
+  if (fmt == blh_context::SAVED_SMALL) {
     // the activations in this workspace were saved by the small-batch forward: only its backward can read them
-    if (from_loss || saved->batch != batch || ctx->sync.fn) return BLH_ERR_INVALID_ARGUMENT;
+    if (from_loss || ctx->sync.fn) return BLH_ERR_INVALID_ARGUMENT;
     SmallStepParams p;
     BLH_TRY(small_params(p, ctx, d, const_cast<float*>(params), grads, nullptr, nullptr, nullptr, nullptr, x, nullptr, drop,
                          0.f, nullptr, nullptr, ws, nullptr, nullptr, nullptr, batch, dpred));
-    if (saved->mode == 2) BLH_TRY(launch_small_step((hipStream_t)stream, p, SS_BWD));
-    else {
-      const ArenaLayout L = make_layout(d);
-      const bool batched = small_wgrad_batched_ok(d, L, ws, batch);
-      BLH_TRY(launch_small_backward_staged((hipStream_t)stream, p, true, !batched));
-      if (batched) BLH_TRY(small_wgrad_batched((hipStream_t)stream, d, L, ws, grads, batch));
-    }
+    const ArenaLayout L = make_layout(d);
+    const bool batched = small_wgrad_batched_ok(d, L, ws, batch);
+    BLH_TRY(launch_small_backward_staged((hipStream_t)stream, p, true, !batched));
+    if (batched) BLH_TRY(small_wgrad_batched((hipStream_t)stream, d, L, ws, grads, batch));
     if (on_ready) on_ready(user, 0, make_layout(d).total);     // every range at once
     return BLH_OK;
   }
   if (from_loss && loss_nparts > 0) {   // decode-bias partials of the fused decode kernel
     const FusedBackward fb{loss_nparts, nullptr, nullptr, nullptr};
     return backward_impl(ctx, d, (hipStream_t)stream, params, x, drop, ws, ws.dpred, grads, batch,
-                         on_ready, user, &fb);
+                         on_ready, user, fmt, &fb);
   }
   return backward_impl(ctx, d, (hipStream_t)stream, params, x, drop, ws, from_loss ? ws.dpred : dpred,
-                       grads, batch, on_ready, user);
+                       grads, batch, on_ready, user, fmt);
 }
 
 int blh_clip_adam_step(void* stream, float* params, float* grads, float* exp_avg,
@@ -593,7 +576,8 @@ int blh_train_step(blh_context* ctx, const blh_model_desc* d, void* stream, floa
     if (dec_S > 0) nparts = dec_S;
     else BLH_TRY(launch_mse(s, pred, target, batch * d->out_features, (float)(2.0 / denom), wh.dpred,
                             wh.loss_part, &nparts));
-    BLH_TRY(backward_h(ctx, d, s, params, drop, wh, wh.dpred, grads, batch, nullptr, nullptr, dec_S));
+    BLH_TRY(backward_h(ctx, d, s, params, drop, wh, wh.dpred, grads, batch, nullptr, nullptr, ctx->fwd_mode, dec_S));
+    ctx->note_saved(workspace, batch, blh_context::SAVED_NONE);
     BLH_TRY(launch_sumsq(s, grads, count, wh.sumsq_part, &np));
     BLH_TRY(launch_clip_adam(s, params, grads, exp_avg, exp_avg_sq, count, *hyper, wh.sumsq_part, np,
                              stats_out, LossFinish{wh.loss_part, nparts, denom, loss_out},
@@ -610,7 +594,8 @@ int blh_train_step(blh_context* ctx, const blh_model_desc* d, void* stream, floa
   int np = 0;
   double* sq_src = ws.sumsq_part;
   const FusedBackward fb{nparts, ws.sumsq_part, &np, &sq_src};
-  BLH_TRY(backward_impl(ctx, d, s, params, x, drop, ws, ws.dpred, grads, batch, nullptr, nullptr, &fb));
+  BLH_TRY(backward_impl(ctx, d, s, params, x, drop, ws, ws.dpred, grads, batch, nullptr, nullptr, ctx->fwd_mode, &fb));
+  ctx->note_saved(workspace, batch, blh_context::SAVED_NONE);
   const int64_t count = make_layout(d).total;
   return launch_clip_adam(s, params, grads, exp_avg, exp_avg_sq, count, *hyper, sq_src, np,
                           stats_out, LossFinish{ws.loss_part, nparts, denom, loss_out});
@@ -841,7 +826,8 @@ int blh_train_step_captured(blh_context* ctx, const blh_model_desc* d, void* str
     if (dec_S > 0) nparts = dec_S;
     else BLH_TRY(launch_mse(s, pred, target, batch * d->out_features, (float)(2.0 / denom), wh.dpred,
                             wh.loss_part, &nparts));
-    BLH_TRY(backward_h(ctx, d, s, params, drop, wh, wh.dpred, grads, batch, nullptr, nullptr, dec_S));
+    BLH_TRY(backward_h(ctx, d, s, params, drop, wh, wh.dpred, grads, batch, nullptr, nullptr, ctx->fwd_mode, dec_S));
+    ctx->note_saved(workspace, batch, blh_context::SAVED_NONE);
     BLH_TRY(launch_sumsq(s, grads, count, wh.sumsq_part, &np));
     return launch_clip_adam_dev(s, params, grads, exp_avg, exp_avg_sq, count, dev_state,
                                 wh.sumsq_part, np, stats_out,
@@ -855,7 +841,8 @@ int blh_train_step_captured(blh_context* ctx, const blh_model_desc* d, void* str
                        target, (float)(2.0 / denom), ws.loss_part, &nparts));
   double* sq_src = ws.sumsq_part;
   const FusedBackward fb{nparts, ws.sumsq_part, &np, &sq_src};
-  BLH_TRY(backward_impl(ctx, d, s, params, x, drop, ws, ws.dpred, grads, batch, nullptr, nullptr, &fb));
+  BLH_TRY(backward_impl(ctx, d, s, params, x, drop, ws, ws.dpred, grads, batch, nullptr, nullptr, ctx->fwd_mode, &fb));
+  ctx->note_saved(workspace, batch, blh_context::SAVED_NONE);
   const int64_t count = make_layout(d).total;
   return launch_clip_adam_dev(s, params, grads, exp_avg, exp_avg_sq, count, dev_state,
                               sq_src, np, stats_out,

@@ -99,7 +99,7 @@ struct Workspace {
   double* sumsq_fold;             // [SUMSQ_FOLD_PARTS]: partials written by the gradient producers (fused step)
   float* colsum_part;             // [ceil(B/256)][out]
   double* sync_buf;               // [2][W] fp64 (SyncBN exchange; also used as float [2][W])
-  std::vector<float*> stage_slabs; // per stage (+ decode): split-K wgrad slabs kept until grads_finish
+  float* enc_slabs;                // split-K slabs of the encode weight gradient (main stream beside the side stream)
   float* dec_bias_part;           // [blocks][out] partial sums of dpred (fused step)
   // gemm_dtype 3: max |value| partials of the GEMM operand tensors (see gemm_f16x2_kernel.h)
   std::vector<float*> amax_A;     // per heavy stage: activation A_l (written by bn_apply)
@@ -195,13 +195,11 @@ static Workspace carve(const blh_model_desc* d, int64_t batch, void* base) {
   ws.sumsq_fold = (double*)take(SUMSQ_FOLD_PARTS * sizeof(double));
   ws.colsum_part = (float*)take(ceil_div(batch, 256) * d->out_features * sizeof(float));
   ws.sync_buf = (double*)take(2 * W * sizeof(double));
-  for (int i = 0; i <= nh; ++i) {
-    int64_t M, N, tiles;
-    if (i == nh) { M = d->out_features; N = W; tiles = ceil_div(M, 64) * ceil_div(N, 128); }
-    else if (i == 0) { M = W; N = d->in_features; tiles = ceil_div(M, 128) * ceil_div(N, 32); }
-    else { M = W; N = W; tiles = ceil_div(M, 128) * ceil_div(N, 128); }
-    const Splits sp = pick_splits(batch, tiles);
-    ws.stage_slabs.push_back(sp.splits > 1 ? (float*)take(sp.splits * M * N * sizeof(float)) : nullptr);
+  {   // the encode weight gradient runs on the main stream while the shared slab buffer may still be in use by
+      // wgrad(1) on the side stream: it takes slabs of its own
+    const int64_t M = W, N = d->in_features;
+    const Splits sp = pick_splits(batch, ceil_div(M, 128) * ceil_div(N, 32));
+    ws.enc_slabs = sp.splits > 1 ? (float*)take(sp.splits * M * N * sizeof(float)) : nullptr;
   }
   ws.dec_bias_part = (float*)take(1026 * d->out_features * sizeof(float));
   ws.amax_parts = 0;

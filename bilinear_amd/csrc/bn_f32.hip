@@ -156,9 +156,6 @@ __global__ __launch_bounds__(F2_THREADS) void bn_bwd_reduce_f2_kernel(
   f2_block_colsum(s2, red, part + ((int64_t)blockIdx.y * 2 + 1) * W, col0, W);
 }
 
-// PREGATED: dA already is dY' = 2 keep [y > 0] dA (left by the data-gradient GEMM's EPI_BN_BWD epilogue,
-// gemm_epilogue.h): neither the keep bits nor the gate are needed
-template <bool PREGATED>
 __global__ __launch_bounds__(F2_THREADS) void bn_bwd_apply_f2_kernel(
     const float* __restrict__ dA, const float* __restrict__ Z, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -190,7 +187,7 @@ __global__ __launch_bounds__(F2_THREADS) void bn_bwd_apply_f2_kernel(
   const int64_t r1 = min(batch, r0 + row_chunk);
   if (ok)
     for (int64_t rg = r0 + 8 * w; rg < r1; rg += 32) {
-      const uint32_t kw = PREGATED ? 0u : keepbits[(rg >> 3) * W4 + (col >> 2)];
+      const uint32_t kw = keepbits[(rg >> 3) * W4 + (col >> 2)];
       float4 z[8], g[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -201,10 +198,10 @@ __global__ __launch_bounds__(F2_THREADS) void bn_bwd_apply_f2_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const uint32_t nib = kw >> (4 * j);
-        const float dx = PREGATED ? g[j].x : ((nib & 1u) && (fmaf(z[j].x, sc.x, sh.x) > 0.f)) ? g[j].x * 2.f : 0.f;
-        const float dy = PREGATED ? g[j].y : ((nib & 2u) && (fmaf(z[j].y, sc.y, sh.y) > 0.f)) ? g[j].y * 2.f : 0.f;
-        const float dz = PREGATED ? g[j].z : ((nib & 4u) && (fmaf(z[j].z, sc.z, sh.z) > 0.f)) ? g[j].z * 2.f : 0.f;
-        const float dw = PREGATED ? g[j].w : ((nib & 8u) && (fmaf(z[j].w, sc.w, sh.w) > 0.f)) ? g[j].w * 2.f : 0.f;
+        const float dx = ((nib & 1u) && (fmaf(z[j].x, sc.x, sh.x) > 0.f)) ? g[j].x * 2.f : 0.f;
+        const float dy = ((nib & 2u) && (fmaf(z[j].y, sc.y, sh.y) > 0.f)) ? g[j].y * 2.f : 0.f;
+        const float dz = ((nib & 4u) && (fmaf(z[j].z, sc.z, sh.z) > 0.f)) ? g[j].z * 2.f : 0.f;
+        const float dw = ((nib & 8u) && (fmaf(z[j].w, sc.w, sh.w) > 0.f)) ? g[j].w * 2.f : 0.f;
         float4 o;
         o.x = fmaf(sc.x, dx, fmaf(ca.x, z[j].x, cb.x)); o.y = fmaf(sc.y, dy, fmaf(ca.y, z[j].y, cb.y));
         o.z = fmaf(sc.z, dz, fmaf(ca.z, z[j].z, cb.z)); o.w = fmaf(sc.w, dw, fmaf(ca.w, z[j].w, cb.w));
@@ -257,16 +254,11 @@ int launch_bn_bwd_reduce_f2(hipStream_t s, const float* dA, const float* Z, cons
 int launch_bn_bwd_apply_f2(hipStream_t s, const float* dA, const float* Z, const float* scale,
                            const float* shift, const float* mean, const float* invstd, const float* dgamma,
                            const float* dbeta, const uint32_t* keepbits, float* dZ, float* colsum_part,
-                           int64_t batch, int W, int64_t norm_batch, float* amax_part, bool pregated) {
+                           int64_t batch, int W, int64_t norm_batch, float* amax_part) {
   if (W % 4 != 0) return BLH_ERR_SHAPE;
-  if (pregated)
-    launch_kernel(bn_bwd_apply_f2_kernel<true>, f2_grid(batch, W), dim3(F2_THREADS), 0, s, dA, Z, scale, shift, mean,
-                  invstd, dgamma, dbeta, keepbits, dZ, colsum_part, batch, W, ew_row_chunk(batch), norm_batch,
-                  amax_part);
-  else
-    launch_kernel(bn_bwd_apply_f2_kernel<false>, f2_grid(batch, W), dim3(F2_THREADS), 0, s, dA, Z, scale, shift, mean,
-                  invstd, dgamma, dbeta, keepbits, dZ, colsum_part, batch, W, ew_row_chunk(batch), norm_batch,
-                  amax_part);
+  launch_kernel(bn_bwd_apply_f2_kernel, f2_grid(batch, W), dim3(F2_THREADS), 0, s, dA, Z, scale, shift, mean,
+                invstd, dgamma, dbeta, keepbits, dZ, colsum_part, batch, W, ew_row_chunk(batch), norm_batch,
+                amax_part);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }

@@ -55,11 +55,11 @@ enum Epilogue : int {
   EPI_BIAS_STATS = 2,  // C = acc + bias[n]; per-tile column (mean, M2) partials
   EPI_ADD = 3,         // C = acc + addend[m][n]
   EPI_BN_RELU = 4,     // eval forward: C = relu(bn_eval(acc + bias[n])) (+ addend[m][n], the block skip)
-  EPI_BN_BWD = 5,      // data gradient feeding a BatchNorm backward (gemm_bf16s_256.h; fp32: gemm_epilogue.h): C = the gated
+  EPI_BN_BWD = 5,      // bf16 storage: data gradient feeding a BatchNorm backward (gemm_bf16s_256.h): C = the gated
                        // gradient dY' = 2 keep [y > 0] acc, per-row-tile column sums of dY' z and dY'
   EPI_BN_BWD_ADD = 6,  // the same with acc + addend[m][n] (the block-skip gradient)
-  EPI_BN_FWD = 7,      // bf16-storage forward stage in one launch (gemm_bf16s_bnfwd.h): Z = acc + bias, batch statistics
-                       // behind a grid barrier, A = 2 keep relu(bn(Z)) (+ skip), keep bits
+  // (7 was EPI_BN_FWD, the bf16 forward stage in one launch behind a grid barrier: measured slower and removed in
+  //  round 6, profiles/r04_fused_forward.md)
   EPI_STORE_SQ = 8     // C = acc, and one fp64 sum of squares of the stored tile per workgroup (sq_part[z * tiles + x]):
                        // the gradient-norm partials of a weight gradient without another pass over it
 };
@@ -83,13 +83,6 @@ struct GemmParams {
   const float* a_amax; int a_namax;
   const float* b_amax; int b_namax;
   double* sq_part;          // EPI_STORE_SQ: [splits][tiles]
-  // EPI_BN_BWD (fp32 data gradient feeding only the BatchNorm backward of the stage below, gemm_epilogue.h):
-  // that stage's pre-BN output [M][ldc-shaped, leading dimension bnb_ldz], its keep bits (bn_f32.hip layout),
-  // scale / shift [N], and the per-row-tile column sums it leaves: [tiles_m][2][N] (S1 = sum dY' z, S2 = sum dY')
-  const float* bnb_z; int64_t bnb_ldz;
-  const uint32_t* bnb_keep;
-  const float* bnb_scale; const float* bnb_shift;
-  float* bnb_part;
 };
 
 enum GemmTile : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_128x32 = 3 };
@@ -162,8 +155,7 @@ int launch_bn_bwd_reduce_f2(hipStream_t s, const float* dA, const float* Z, cons
 int launch_bn_bwd_apply_f2(hipStream_t s, const float* dA, const float* Z, const float* scale,
                            const float* shift, const float* mean, const float* invstd, const float* dgamma,
                            const float* dbeta, const uint32_t* keepbits, float* dZ, float* colsum_part,
-                           int64_t batch, int W, int64_t norm_batch, float* amax_part = nullptr,
-                           bool pregated = false);   // pregated: dA is dY' already (EPI_BN_BWD), no bits read
+                           int64_t batch, int W, int64_t norm_batch, float* amax_part = nullptr);
 // SyncBN: local fp64 column sums [sum z | sum z^2] -> (host all-reduce) -> finalize
 int launch_bn_fwd_local_sums(hipStream_t s, const float* stat_part, int tiles, int tile_rows,
                              int64_t batch, int W, double* sums);
@@ -222,13 +214,6 @@ int launch_sumsq_bf16(hipStream_t s, const uint16_t* g, int64_t count, float gsc
 int launch_clip_adam_bf16(hipStream_t s, float* p, const uint16_t* g_bf16, float gscale, float* gout, float* m,
                           float* v, int64_t count, const blh_adam_hyper& h, const double* sumsq_part,
                           int nparts, float* stats_out, uint16_t* shadow = nullptr);
-// one launch at the end of backward: sum every stage's split-K weight-gradient slabs into the
-// arena and produce the sum-of-squares partials of the whole arena
-struct GradRegion { int64_t off4, cnt4; const float* slabs; int splits; int first_block; };
-static constexpr int MAX_GRAD_REGIONS = 72;
-struct GradRegions { int n; int64_t items_per_block; GradRegion r[MAX_GRAD_REGIONS]; };
-int launch_grads_finish(hipStream_t s, float* grads, GradRegions& R, int64_t total4,
-                        double* sumsq_part, int* nparts);
 // device-state variants (graph replay): hyper-parameters and step counters read on the device
 int launch_step_state_advance(hipStream_t s, blh_step_state* st);
 int launch_clip_adam_dev(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count,
@@ -244,23 +229,6 @@ int launch_decode_finish(hipStream_t s, const float* slabs, int splits, int64_t 
                          float* dbias_part = nullptr);
 // skinny.hip: decode forward fused with the MSE loss (pred, dpred, loss / decode-bias partials)
 bool decode_fwd_supported(int64_t batch, int W, int OF);
-// ---- column-owner BatchNorm kernels, 385 .. 1024 rows (colowner_f32.hip) ----
-bool colowner_supported(int64_t batch, int W);
-// 385 .. 2048 rows, fp32: launches of a hidden stage merged pairwise, bit-identical (midstage_f32.hip)
-bool mid_fwd_pair_supported(int64_t batch, int W, float momentum);
-int launch_mid_fwd_finish(hipStream_t s, const float* slabs, int splits, int64_t M, int N, const float* bias, float* Z,
-                          float* stat_part);
-int launch_mid_bn_apply(hipStream_t s, const float* Z, const float* stat_part, int tiles, int tile_rows,
-                        const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
-                        float* saved, const float* skip, float* A, uint32_t* keepbits, int64_t batch, int W,
-                        const DropoutSrc& drop, int64_t* nbt, float* amax_part);
-int launch_colowner_fwd(hipStream_t s, const float* slabs, int splits, int64_t slab_stride, const float* bias,
-                        const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t* nbt,
-                        uint32_t* ticket, float momentum, float* saved, const float* skip, float* Z, float* A,
-                        uint32_t* keepbits, int64_t batch, int W, const DropoutSrc& drop);
-int launch_colowner_bwd(hipStream_t s, const float* dA_src, int splits, int64_t slab_stride, const float* addend,
-                        float* dA_out, const float* Z, const float* saved, const uint32_t* keepbits, float* dZ,
-                        float* dgamma, float* dbeta, float* db_rows, int db_nrows, double* sq_gb, int64_t batch, int W);
 // ---- encode stage without its pre-BatchNorm tensor (encode_f32.hip) ----
 bool enc_fused_supported(int64_t batch, int W, int in_features);
 int enc_bwd_finish_blocks(int W);

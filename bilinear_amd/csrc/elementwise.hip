@@ -1164,97 +1164,6 @@ int launch_bn_fwd_finalize_sums(hipStream_t s, const double* sums, int64_t n_glo
 }  // namespace blh
 
 // ---------------------------------------------------------------------------
-// end of backward on the fused path: every weight gradient whose wgrad was split over the
-// batch is still a set of partial slabs; this ONE launch sums the slabs of all stages into
-// the gradient arena and, in the same pass, produces the partial sums of squares of the
-// WHOLE arena for clip_grad_norm_ (replaces one sum_slabs launch per stage + the sumsq
-// launch).  Regions tile the arena; a region without slabs is read as is.
-// ---------------------------------------------------------------------------
-namespace blh {
-
-__global__ __launch_bounds__(256) void grads_finish_kernel(float* __restrict__ grads, GradRegions R,
-                                                           double* __restrict__ sumsq_part) {
-  __shared__ double sh[256];
-  // select this block's region with compile-time indices only: a runtime index into the
-  // by-value argument struct would make the compiler copy it to scratch memory
-  GradRegion reg = R.r[0];
-#pragma unroll
-  for (int k = 1; k < MAX_GRAD_REGIONS; ++k)
-    if (k < R.n && (int)blockIdx.x >= R.r[k].first_block) reg = R.r[k];
-  const int64_t base = (int64_t)(blockIdx.x - reg.first_block) * R.items_per_block;
-  double acc = 0.0;
-  const int64_t end = min(reg.cnt4, base + R.items_per_block);
-  float facc = 0.f;
-  if (reg.splits == 0) {
-    // plain region (the default: slabs were summed right after each weight-gradient GEMM): the
-    // loads of 8 strides are requested together — one memory round trip per 8 float4, not 8
-    double dacc = 0.0;
-    for (int64_t i0 = base + threadIdx.x; i0 < end; i0 += 8 * 256) {
-      float4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = ld4(grads + (reg.off4 + min(i0 + u * 256, end - 1)) * 4);
-      float f = 0.f;
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (i0 + u * 256 < end) f += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
-      dacc += (double)f;
-    }
-    acc = dacc;
-  } else {
-  for (int64_t i = base + threadIdx.x; i < end; i += 256) {
-    float4 v;
-    if (reg.splits > 0) {
-      v = ld4(reg.slabs + i * 4);
-      int s = 1;
-      for (; s + 3 <= reg.splits; s += 3) {
-        const float4 u0 = ld4(reg.slabs + ((int64_t)(s + 0) * reg.cnt4 + i) * 4);
-        const float4 u1 = ld4(reg.slabs + ((int64_t)(s + 1) * reg.cnt4 + i) * 4);
-        const float4 u2 = ld4(reg.slabs + ((int64_t)(s + 2) * reg.cnt4 + i) * 4);
-        v.x += u0.x; v.y += u0.y; v.z += u0.z; v.w += u0.w;
-        v.x += u1.x; v.y += u1.y; v.z += u1.z; v.w += u1.w;
-        v.x += u2.x; v.y += u2.y; v.z += u2.z; v.w += u2.w;
-      }
-      for (; s < reg.splits; ++s) {
-        const float4 u = ld4(reg.slabs + ((int64_t)s * reg.cnt4 + i) * 4);
-        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-      }
-      st4(grads + (reg.off4 + i) * 4, v);
-    } else {
-      v = ld4(grads + (reg.off4 + i) * 4);
-    }
-    facc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-  }
-  acc = (double)facc;   // <= 8 float4 per thread: fp32 partial, fp64 from here on
-  }
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  for (int o = 128; o >= 1; o >>= 1) {
-    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0 && sumsq_part) sumsq_part[blockIdx.x] = sh[0];
-}
-
-// regions: n entries with off4/cnt4/slabs/splits filled in ascending arena order, covering
-// [0, total4); first_block / items_per_block are computed here.  Returns the block count.
-int launch_grads_finish(hipStream_t s, float* grads, GradRegions& R, int64_t total4,
-                        double* sumsq_part, int* nparts) {
-  R.items_per_block = std::max<int64_t>(2048, round_up(ceil_div(total4, 900), 256));
-  int blocks = 0;
-  for (int i = 0; i < R.n; ++i) {
-    R.r[i].first_block = blocks;
-    blocks += (int)ceil_div(R.r[i].cnt4, R.items_per_block);
-  }
-  if (blocks > SUMSQ_MAX_PARTS || blocks == 0) return BLH_ERR_SHAPE;
-  hipLaunchKernelGGL(grads_finish_kernel, dim3(blocks), dim3(256), 0, s, grads, R, sumsq_part);
-  BLH_HIP_TRY(hipGetLastError());
-  if (nparts) *nparts = blocks;
-  return BLH_OK;
-}
-
-}  // namespace blh
-
-// ---------------------------------------------------------------------------
 // gemm_dtype = 3 (fp16 two-piece split): max |w| of each hidden Linear weight, as 64 partials
 // per layer that the GEMM reduces in its prologue.  W [layers][count] with layer stride w_stride.
 // ---------------------------------------------------------------------------

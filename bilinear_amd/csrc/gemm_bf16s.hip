@@ -123,20 +123,6 @@ int gemm_bf16s_pick_tile(int la, int lb, bool out_bf16, const GemmParamsH& p, in
   return H_TILE_128;
 }
 
-// How many workgroups a launch with a grid-wide barrier may have: one per CU (each holds 128-144 KiB of LDS),
-// all of them resident at once.
-int gemm_bf16s_fused_forward_max_wgs() {
-  static std::atomic<int> cus[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-  int v = cus[dev].load(std::memory_order_relaxed);
-  if (v == 0) {
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = -1;
-    cus[dev].store(v, std::memory_order_relaxed);
-  }
-  return v > 0 ? v : 0;
-}
-
 int gemm_bf16s_tile_rows(int tile) { return tile == H_TILE_256 ? 256 : 128; }
 int gemm_bf16s_tile_cols(int tile) { return tile == H_TILE_128 ? 128 : 256; }
 
@@ -168,16 +154,6 @@ int launch_gemm_bf16s(hipStream_t s, int la, int lb, int epi, bool out_bf16, con
   BLH_CASEH(ROWK, KROW, EPI_ADD, true)           // dgrad + block-skip gradient
   BLH_CASEH(ROWK, KROW, EPI_STORE, false)
   BLH_CASEH(KROW, KROW, EPI_STORE, false)        // wgrad: fp32 slabs
-  if (epi == EPI_BN_FWD) {   // forward stage in one launch: every workgroup must be resident (grid barrier)
-    const int64_t wgs = ceil_div(p.M, gemm_bf16s_tile_rows(tile)) * (p.N / 256);
-    if (tile == H_TILE_128 || la != ROWK || lb != ROWK || !out_bf16 || splits != 1 || !p.bias || !p.stat_part ||
-        !p.fwd.bar || !p.fwd.A || !p.fwd.saved || !p.fwd.gamma || !p.fwd.beta || !p.fwd.running_mean ||
-        !p.fwd.running_var || wgs > gemm_bf16s_fused_forward_max_wgs() ||
-        ceil_div(p.M, gemm_bf16s_tile_rows(tile)) > 128 || p.fwd.tile_rows != gemm_bf16s_tile_rows(tile))
-      return BLH_ERR_SHAPE;
-    return tile == H_TILE_256 ? launch_h256<ROWK, ROWK, EPI_BN_FWD, true>(s, p, 1)
-                              : launch_h128x256<ROWK, ROWK, EPI_BN_FWD, true>(s, p, 1);
-  }
   if (epi == EPI_BN_BWD || epi == EPI_BN_BWD_ADD) {   // dgrad + the BatchNorm-backward reductions of the stage below
     if (tile == H_TILE_128 || la != ROWK || lb != KROW || !out_bf16 || splits != 1 || !p.bn_z || !p.bn_keep ||
         !p.bn_scale || !p.bn_shift || !p.stat_part || (p.ldz % 8) != 0 || (epi == EPI_BN_BWD_ADD && !p.addend))

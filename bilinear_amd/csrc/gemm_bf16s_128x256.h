@@ -220,8 +220,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16s_128x256_kernel(GemmParamsH 
     }
     return;
   }
-  if constexpr (EPI == EPI_BN_FWD) gemm_epilogue_256_bnfwd<1>(acc, p, smem, m0, n0, tile_m, tile_n);
-  else if constexpr (EPI == EPI_BN_BWD) gemm_epilogue_256_bnbwd_packed<1>(acc, p, C, smem, m0, n0, tile_m);
+  if constexpr (EPI == EPI_BN_BWD) gemm_epilogue_256_bnbwd_packed<1>(acc, p, C, smem, m0, n0, tile_m);
   else if constexpr (EPI == EPI_BN_BWD_ADD) gemm_epilogue_256_bnbwd<1, true>(acc, p, C, smem, m0, n0, tile_m);
   else gemm_epilogue_256<EPI, OUT_BF16, 1>(acc, p, C, smem, m0, n0, tile_m);
 }

@@ -576,7 +576,6 @@ __device__ inline void gemm_epilogue_256_bnbwd_packed(f32x4 (&acc)[NQM][2][4][2]
 }
 
 }  // namespace blh
-#include "gemm_bf16s_bnfwd.h"
 namespace blh {
 
 // ---- kernel ----------------------------------------------------------------------------------------
@@ -713,8 +712,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16s_256_kernel(GemmParamsH p) {
 #undef BLH_WAIT_LGKM
 #undef BLH_SB
   __syncthreads();
-  if constexpr (EPI == EPI_BN_FWD) gemm_epilogue_256_bnfwd<2>(acc, p, smem, m0, n0, tile_m, tile_n);
-  else if constexpr (EPI == EPI_BN_BWD) gemm_epilogue_256_bnbwd_packed<2>(acc, p, C, smem, m0, n0, tile_m);
+  if constexpr (EPI == EPI_BN_BWD) gemm_epilogue_256_bnbwd_packed<2>(acc, p, C, smem, m0, n0, tile_m);
   else if constexpr (EPI == EPI_BN_BWD_ADD) gemm_epilogue_256_bnbwd<2, true>(acc, p, C, smem, m0, n0, tile_m);
   else gemm_epilogue_256<EPI, OUT_BF16>(acc, p, C, smem, m0, n0, tile_m);
 }

@@ -45,21 +45,6 @@ typedef uint16_t bf16_bits_t;
 #define BLH_H_STAGES_DEFAULT 2
 #endif
 
-// EPI_BN_FWD (gemm_bf16s_bnfwd.h): what bn_fwd_finalize + bn_apply_h2 take, and the grid barrier's words
-struct BnFwdParams {
-  const float* gamma; const float* beta;
-  float* running_mean; float* running_var;
-  int64_t* nbt;
-  float momentum;
-  float* saved;              // [4][N]: mean, invstd, scale, shift
-  const bf16_bits_t* skip; int64_t ldskip;
-  bf16_bits_t* A; int64_t lda_out;
-  uint32_t* keepbits;
-  DropoutSrc drop;
-  uint32_t* bar;             // [3]: arrivals, generation, timeouts (zeroed once by the owner)
-  int tile_rows;             // rows per statistics tile (the kernel's BM)
-};
-
 struct GemmParamsH {
   const bf16_bits* A;
   const bf16_bits* B;
@@ -85,7 +70,6 @@ struct GemmParamsH {
   const uint32_t* bn_keep;
   const float* bn_scale;
   const float* bn_shift;
-  BnFwdParams fwd;           // EPI_BN_FWD
 };
 
 __device__ __forceinline__ float bf16_to_f32(bf16_bits v) { return __uint_as_float((uint32_t)v << 16); }
@@ -205,7 +189,6 @@ int gemm_bf16s_pick_tile(int la, int lb, bool out_bf16, const GemmParamsH& p, in
 int gemm_bf16s_tile_rows(int tile);   // rows of one tile = rows per BatchNorm-partials record
 int gemm_bf16s_tile_cols(int tile);
 void gemm_bf16s_force_tile(int tile);  // 0: automatic; -1: re-read BLH_BF16S_TILE
-int gemm_bf16s_fused_forward_max_wgs();   // CUs of the current device (EPI_BN_FWD: one resident workgroup each)
 int launch_cast_f32_bf16(hipStream_t s, const float* src, uint16_t* dst, int64_t n);
 int launch_cast2_f32_bf16(hipStream_t s, const float* src0, uint16_t* dst0, int64_t n0, const float* src1,
                           uint16_t* dst1, int64_t n1, const float* wd_src = nullptr, uint16_t* wdT = nullptr,

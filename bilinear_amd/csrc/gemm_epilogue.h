@@ -1,7 +1,6 @@
 // Shared epilogue of the MFMA GEMM kernels (fp32 accumulators of 32x32 MFMA tiles; the C/D
 // register layout is the same for the f32 and bf16 MFMA shapes on gfx950):
 //   EPI_STORE / EPI_BIAS / EPI_ADD, EPI_BIAS_STATS (per-128-row-tile BatchNorm partials),
-//   EPI_BN_BWD (the gated gradient and the BatchNorm-backward column sums of the stage below),
 //   EPI_BN_RELU (eval-mode heavy_linear in one kernel: bias, BatchNorm with running statistics,
 //   ReLU, optional block skip).
 //   See gemm_f32_ring.h for the contractions it serves.
@@ -56,56 +55,6 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], 
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][jn][r] += bv;
-    }
-  }
-
-  // the tile is the gradient with respect to the OUTPUT of the stage below, and nothing but that stage's
-  // BatchNorm backward reads it: form dY' = 2 keep [y > 0] acc here (the same expression, operand for operand, as
-  // bn_bwd_reduce_f2 / bn_bwd_apply_f2: identical values), store dY' in its place and leave the column sums
-  // S1 = sum dY' z, S2 = sum dY' of the tile's rows — the stage below skips its reduce kernel and reads no keep bits.
-  float bnb_s1[TN], bnb_s2[TN];
-  if (EPI == EPI_BN_BWD) {
-    float zv[TM][TN][16];
-    uint32_t kw[TM][TN][4];
-    float sc[TN], sh[TN];
-    const int N4 = p.N >> 2;
-#pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-      const int cc = min(col_w + jn * 32, p.N - 1);
-      sc[jn] = p.bnb_scale[cc]; sh[jn] = p.bnb_shift[cc];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int rg = min(row_w + i * 32 + 8 * g, p.M - 1);
-          kw[i][jn][g] = p.bnb_keep[(int64_t)(rg >> 3) * N4 + (cc >> 2)];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = min(row_w + i * 32 + (r & 3) + 8 * (r >> 2), p.M - 1);
-          zv[i][jn][r] = p.bnb_z[(int64_t)row * p.bnb_ldz + cc];
-        }
-      }
-    }
-#pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-      const int col = col_w + jn * 32;
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row_w + i * 32 + (r & 3) + 8 * (r >> 2);
-          // keep[row / 8][col / 4]: nibble = row % 8 (= 4 h + (r & 3): the tile rows start on multiples of 32)
-          const uint32_t bit = (kw[i][jn][r >> 2] >> (4 * (4 * h + (r & 3)) + (col & 3))) & 1u;
-          const float z = zv[i][jn][r];
-          const bool on = bit && (fmaf(z, sc[jn], sh[jn]) > 0.f) && row < p.M && col < p.N;
-          const float dy = on ? acc[i][jn][r] * 2.f : 0.f;
-          acc[i][jn][r] = dy;
-          s2 += dy;
-          s1 = fmaf(dy, z, s1);
-        }
-      bnb_s1[jn] = s1; bnb_s2[jn] = s2;
     }
   }
 
@@ -167,35 +116,6 @@ __device__ inline void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], 
       double t = 0.0;
       for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
       p.sq_part[(int64_t)blockIdx.z * gridDim.x + blockIdx.x] = t;
-    }
-  }
-  if (EPI == EPI_BN_BWD) {
-    float* red = smem;   // [WM][2][BN]; stage buffers are dead (barrier closed the main loop)
-#pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-      const float s1 = bnb_s1[jn] + __shfl_xor(bnb_s1[jn], 32);
-      const float s2 = bnb_s2[jn] + __shfl_xor(bnb_s2[jn], 32);
-      if (h == 0 && is_cons) {
-        red[(wm * 2 + 0) * BN + wn * (TN * 32) + jn * 32 + lc] = s1;
-        red[(wm * 2 + 1) * BN + wn * (TN * 32) + jn * 32 + lc] = s2;
-      }
-    }
-    lds_barrier();
-    if (wm == 0 && h == 0 && is_cons) {
-#pragma unroll
-      for (int jn = 0; jn < TN; ++jn) {
-        const int col = col_w + jn * 32;
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) {
-          t1 += red[(w * 2 + 0) * BN + wn * (TN * 32) + jn * 32 + lc];
-          t2 += red[(w * 2 + 1) * BN + wn * (TN * 32) + jn * 32 + lc];
-        }
-        if (col < p.N) {
-          p.bnb_part[((int64_t)tile_m * 2 + 0) * p.N + col] = t1;
-          p.bnb_part[((int64_t)tile_m * 2 + 1) * p.N + col] = t2;
-        }
-      }
     }
   }
   if (EPI == EPI_BIAS_STATS) {

@@ -96,7 +96,6 @@ static int launch_128x128(hipStream_t s, int la, int lb, int epi, const GemmPara
   BLH_CASE(128, 128, 4, 2, ROWK, ROWK, EPI_STORE)
   BLH_CASE(128, 128, 4, 2, ROWK, KROW, EPI_STORE)        // dgrad
   BLH_CASE(128, 128, 4, 2, ROWK, KROW, EPI_ADD)          // dgrad + residual gradient
-  BLH_CASE(128, 128, 4, 2, ROWK, KROW, EPI_BN_BWD)       // dgrad + the BatchNorm-backward sums of the stage below
   BLH_CASE(128, 128, 4, 2, KROW, KROW, EPI_STORE)        // wgrad (split over the batch)
   BLH_CASE(128, 128, 4, 2, KROW, KROW, EPI_STORE_SQ)     // batched small-batch wgrad + its norm partials
   BLH_CASE(128, 128, 4, 2, KROW, ROWK, EPI_STORE)
@@ -117,7 +116,6 @@ static int launch_64x128(hipStream_t s, int la, int lb, int epi, const GemmParam
   BLH_CASE(64, 128, 2, 2, ROWK, ROWK, EPI_BIAS)
   BLH_CASE(64, 128, 2, 2, ROWK, KROW, EPI_STORE)         // data gradient of a half-chip batch (step_f32.hip: mid64)
   BLH_CASE(64, 128, 2, 2, ROWK, KROW, EPI_ADD)
-  BLH_CASE(64, 128, 2, 2, ROWK, KROW, EPI_BN_BWD)
   return BLH_ERR_INVALID_ARGUMENT;
 }
 static int launch_128x32(hipStream_t s, int la, int lb, int epi, const GemmParams& p, int splits) {

@@ -1,11 +1,10 @@
-// The small-batch kernels (small_step.hip): one launch per stage (up to 384 rows), one persistent launch (up to 64).
+// The small-batch kernels (small_step.hip): one launch per stage, up to 384 rows.
 #pragma once
 #include "common.h"
 
 namespace blh {
 
 constexpr int SS_MAX_STAGES = 33;        // 1 + 2 * num_blocks (api_layout.h: check_desc)
-enum SmallStepPhase { SS_ALL = 0, SS_FWD = 1, SS_BWD = 2 };
 
 struct SmallStepParams {
   int nh, W, in_f, out_f, batch;
@@ -16,14 +15,14 @@ struct SmallStepParams {
   const float* x; const float* target;
   float* A[SS_MAX_STAGES];               // [batch][W] per stage (workspace)
   float* dZ[SS_MAX_STAGES];
-  float* Z[SS_MAX_STAGES];               // SS_FWD / SS_BWD: x-hat crosses the two launches here (the gate in dZ)
+  float* Z[SS_MAX_STAGES];               // x-hat crosses from the forward to the backward launches here (the gate in dZ)
   float* bn_saved[SS_MAX_STAGES];        // [4][W] mean, invstd, scale, shift
   float* gskip[2];                       // staged launches: gradient w.r.t. the output of an even stage, for stage i - 2
   float* dpred;                          // [batch][out_f]
   float* pred; float* loss_out; float* stats_out;
   float* loss_part;                      // [out_f / 4]
   double* sumsq_part;                    // [grid]
-  uint32_t* bar;                         // grid barrier words (context)
+  uint32_t* bar;                         // (tools/small_step_persistent.h only: grid barrier words)
   DropoutSrc drop;                       // of stage 0 (keep: base of the [nh][batch][W] masks)
   float momentum, mse_scale;
   double denom;
@@ -32,9 +31,6 @@ struct SmallStepParams {
   unsigned long long* stamps;            // developer tool only (tools/small_step_bench.hip): [grid][64] s_memrealtime
 };
 
-// number of workgroups of the launch (= CUs of the device) if all of them can be resident at once, else 0
-int small_step_max_grid(int* num_cus_out);
-int launch_small_step(hipStream_t s, const SmallStepParams& p, int phase = SS_ALL);
 // one launch per stage (no grid barrier, no residency requirement): forward stages + decode (mse: + MSE, dpred,
 // decode gradients, loss / norm partials), backward stages (dec_here: decode gradients from the caller's dpred);
 // the gradient-norm partials are sumsq_part[0 .. W / 4 + out_f / 4)

@@ -12,9 +12,9 @@ namespace blh {
 // the loss stay fp32.  Gradients need no loss scaling: bf16 keeps fp32's exponent range.
 // =================================================================================================
 // The encode stage without its pre-BatchNorm tensor (encode_f32.hip, bf16-storage form): per-rank statistics (SyncBN
-// exchanges tile sums of Z).  The same predicate in forward_h and backward_h: the forward leaves keep AND gate bits
-// and the sums of x where the backward expects them.
-static bool enc_fused_ok_h(const blh_context* ctx, const blh_model_desc* d, int64_t batch) {
+// exchanges tile sums of Z).  The forward records what it saved (blh_context::note_saved); the backward reads the
+// record of its workspace, so a knob or SyncBN state that changed in between cannot pair them wrongly.
+bool enc_fused_ok_h(const blh_context* ctx, const blh_model_desc* d, int64_t batch) {
   return !ctx->sync.fn && !ctx->knob(KNOB_NO_ENCODE_FUSE) && enc_fused_supported_h(batch, d->width, d->in_features);
 }
 
@@ -25,6 +25,9 @@ int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const fl
   const ArenaLayout L = make_layout(d);
   const int nh = (int)L.heavy.size();
   const int W = d->width, OF = d->out_features, IF = d->in_features;
+  const bool enc_fused_fwd = train && enc_fused_ok_h(ctx, d, batch);
+  if (train)     // (ws.wsh is the workspace base, api_layout.h carve_h)
+    ctx->note_saved(ws.wsh, batch, enc_fused_fwd ? blh_context::SAVED_ENC_FUSED : blh_context::SAVED_MULTI);
   // bf16 images of the parameters (the GEMMs read the weights from it) and of the input
   // (shadow_valid: the previous fused step's Adam kernel wrote it, BLH_OPT_PERSISTENT_SHADOW)
   ctx->shadow_params = ctx->shadow_ws = nullptr;
@@ -40,7 +43,7 @@ int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const fl
   else BLH_TRY(launch_cast_f32_bf16(s, x, ws.xh, batch * IF));
   for (int i = 0; i < nh; ++i) {
     const HeavyOffsets& h = L.heavy[i];
-    if (i == 0 && train && enc_fused_ok_h(ctx, d, batch)) {
+    if (i == 0 && enc_fused_fwd) {
       // x statistics -> BatchNorm statistics -> A0 and the keep-and-gate bits; Z0's buffer serves as scratch
       BLH_TRY(launch_enc_forward_h(s, ws.xh, ws.wsh + h.w, params + h.b, params + h.gamma, params + h.beta, bn_running,
                                    bn_running + W, nbt, momentum, ws.bn_saved[0], ws.Z[0], ws.A[0], ws.keep[0], batch, W,
@@ -60,25 +63,8 @@ int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const fl
     const uint16_t* skip = (i >= 2 && (i % 2) == 0) ? ws.A[i - 2] : nullptr;
     float* rm = bn_running + ((int64_t)i * 2 + 0) * W;
     float* rv = bn_running + ((int64_t)i * 2 + 1) * W;
-    // The whole stage in ONE launch (gemm_bf16s_bnfwd.h: statistics merged behind a grid barrier, BatchNorm +
-    // ReLU + dropout + skip applied to the tile the workgroup still holds): big-tile kernels whose grid fits the
-    // chip one workgroup per CU (configs[2]: 256 tiles of 256 x 256; configs[3] per GPU: 256 of 128 x 256), per-rank
-    // statistics.  Bit-identical to the three-launch form and MEASURED SLOWER (configs[2] 1.59 against 1.47 ms,
-    // configs[3] per-GPU shape 1.10 against 0.95: profiles/r04_fused_forward.md), so it is opt-in: BLH_FWD_FUSE=1.
-    if (train && !ctx->sync.fn && tile != H_TILE_128 && ctx->grid_bar && ctx->knob(KNOB_FWD_FUSE) &&
-        (int64_t)st_tiles * (W / 256) <= gemm_bf16s_fused_forward_max_wgs() && st_tiles <= 128) {
-      g.fwd.gamma = params + h.gamma; g.fwd.beta = params + h.beta;
-      g.fwd.running_mean = rm; g.fwd.running_var = rv; g.fwd.nbt = nbt + i; g.fwd.momentum = momentum;
-      g.fwd.saved = ws.bn_saved[i];
-      g.fwd.skip = skip; g.fwd.ldskip = W;
-      g.fwd.A = ws.A[i]; g.fwd.lda_out = W;
-      g.fwd.keepbits = ws.keep[i];
-      g.fwd.drop = layer_drop(ctx, drop, i, batch, W);
-      g.fwd.bar = ctx->grid_bar;
-      g.fwd.tile_rows = st_rows;
-      BLH_TRY(launch_gemm_bf16s(s, ROWK, ROWK, EPI_BN_FWD, true, g, 1));
-      continue;
-    }
+    // (the whole stage in ONE launch behind a grid barrier was built, bit-identical, measured slower and removed:
+    //  profiles/r04_fused_forward.md)
     BLH_TRY(launch_gemm_bf16s(s, ROWK, ROWK, train ? EPI_BIAS_STATS : EPI_BIAS, true, g, 1));
     if (train) {
       float* sv = ws.bn_saved[i];
@@ -152,7 +138,7 @@ static int wgrad_h(hipStream_t s, const uint16_t* dZ, int64_t ld_dz, int M, cons
 // partials (dec_bias_S rows of ws.dec_bias_part) are already there
 int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
                       const blh_dropout* drop, const WorkspaceH& ws, const float* dpred,
-                      float* grads, int64_t batch, blh_grad_ready_fn on_ready, void* user,
+                      float* grads, int64_t batch, blh_grad_ready_fn on_ready, void* user, int saved_mode,
                       int dec_bias_S) {
   const ArenaLayout L = make_layout(d);
   const int nh = (int)L.heavy.size();
@@ -281,7 +267,7 @@ int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const f
   // epilogue (EPI_BN_BWD, big-tile kernels only): the stage below then skips bn_bwd_reduce_h2 and its
   // bn_bwd_apply_h2 reads no keep bits.  k9_chunks > 0: stage i's dA arrived that way, with that many partial rows.
   const bool k9_enabled = !ctx->knob(KNOB_NO_K9);
-  const bool enc_fused = enc_fused_ok_h(ctx, d, batch);
+  const bool enc_fused = saved_mode == blh_context::SAVED_ENC_FUSED;
   int k9_chunks = 0;
   for (int i = nh - 1; i >= 0; --i) {
     const HeavyOffsets& h = L.heavy[i];

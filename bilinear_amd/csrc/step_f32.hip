@@ -9,20 +9,9 @@ namespace blh {
 // The encode stage without its pre-BatchNorm tensor (encode_f32.hip): exact-fp32 mode, per-rank statistics (SyncBN
 // exchanges tile sums of Z), the multi-launch path's batch sizes.  A train-mode forward that takes it records saved
 // format 3 for the workspace; the backward that consumes that forward reads the record.
-static bool enc_fused_ok(const blh_context* ctx, const blh_model_desc* d, int64_t batch) {
+bool enc_fused_ok(const blh_context* ctx, const blh_model_desc* d, int64_t batch) {
   return d->gemm_dtype == 0 && !ctx->sync.fn && !ctx->knob(KNOB_NO_ENCODE_FUSE) && batch > 384 &&
          enc_fused_supported(batch, d->width, d->in_features);
-}
-
-// Column-owner BatchNorm kernels (colowner_f32.hip) for the hidden stages at 385 .. 1024 rows: exact-fp32 mode,
-// per-rank statistics.  Same results as the multi-launch form up to the order of fp32 sums; nothing about the saved
-// activations changes (Z, A, keep bits, saved statistics), so forward and backward decide independently.
-// OPT-IN (BLH_MID_FUSE=1): built, verified and MEASURED SLOWER than the launches they replace — 32 workgroups cannot
-// stream the 16.8 MB of split-K slabs of a stage as fast as four full-chip launches pay their launch latency
-// (profiles/r05_colowner.md: 512 rows 0.554 against 0.485 ms per step, 1024 rows 0.636 against 0.616).
-static bool colowner_ok(const blh_context* ctx, const blh_model_desc* d, int64_t batch) {
-  return d->gemm_dtype == 0 && !ctx->sync.fn && ctx->knob(KNOB_MID_FUSE) && ctx->grid_bar != nullptr &&
-         colowner_supported(batch, d->width);
 }
 
 int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
@@ -34,12 +23,8 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
   const int nh = (int)L.heavy.size();
   const int W = d->width;
   const bool enc_fused = train && enc_fused_ok(ctx, d, batch);
-  const bool colown = colowner_ok(ctx, d, batch);
-  // <= 2048 rows, opt-in: the finishing / BatchNorm launches of a hidden stage merged pairwise (midstage_f32.hip:
-  // bit-identical, and no faster — profiles/r05_mid_pair.md)
-  const bool midpair = train && d->gemm_dtype == 0 && !ctx->sync.fn && batch <= 2048 && !colown &&
-                       ctx->knob(KNOB_MID_PAIR) && mid_fwd_pair_supported(batch, W, momentum);
-  if (train) ctx->note_saved(ws.Z[0], batch, enc_fused ? 3 : 0);     // (ws.Z[0] is the workspace base, api_layout.h carve)
+  if (train)     // (ws.Z[0] is the workspace base, api_layout.h carve)
+    ctx->note_saved(ws.Z[0], batch, enc_fused ? blh_context::SAVED_ENC_FUSED : blh_context::SAVED_MULTI);
   if (ws.amax_W)   // gemm_dtype 3: max |w| of every hidden Linear weight, once per forward
     for (int i = 1; i < nh; ++i)
       BLH_TRY(launch_wamax(s, params + L.heavy[i].w, 0, 1, (int64_t)W * W, ws.amax_W + (int64_t)i * WAMAX_PARTS));
@@ -75,22 +60,8 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
       // finish (slab sum + bias + BN tile statistics) in a streaming kernel
       g.C = ws.slabs; g.c_split_stride = batch * (int64_t)W; g.k_per_split = fs.k_per;
       BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, ROWK, EPI_STORE, g, fs.splits, d->gemm_dtype));
-      if (train && colown) {
-        // 385 .. 1024 rows: ONE finishing launch — a workgroup owns 32 columns for all rows (colowner_f32.hip):
-        // slab sum + bias, batch statistics, running statistics, BatchNorm + ReLU + dropout (+ skip), keep bits
-        const float* skip_c = (i >= 2 && (i % 2) == 0) ? ws.A[i - 2] : nullptr;
-        BLH_TRY(launch_colowner_fwd(s, ws.slabs, fs.splits, batch * (int64_t)W, params + h.b, params + h.gamma,
-                                    params + h.beta, bn_running + ((int64_t)i * 2 + 0) * W,
-                                    bn_running + ((int64_t)i * 2 + 1) * W, nbt + i, ctx->grid_bar + 8, momentum,
-                                    ws.bn_saved[i], skip_c, ws.Z[i], ws.A[i], ws.keep[i], batch, W,
-                                    layer_drop(ctx, drop, i, batch, W)));
-        continue;
-      }
-      if (midpair)
-        BLH_TRY(launch_mid_fwd_finish(s, ws.slabs, fs.splits, batch, W, params + h.b, ws.Z[i], ws.stat_part));
-      else
-        BLH_TRY(launch_fwd_finish(s, ws.slabs, fs.splits, batch, W, params + h.b, ws.Z[i],
-                                  train ? ws.stat_part : nullptr));
+      BLH_TRY(launch_fwd_finish(s, ws.slabs, fs.splits, batch, W, params + h.b, ws.Z[i],
+                                train ? ws.stat_part : nullptr));
     } else if (!train && d->gemm_dtype != 3) {
       // eval: the whole heavy_linear in one kernel — bias, BatchNorm with the running statistics,
       // ReLU and the block skip sit in the GEMM epilogue (the BN "folded into the Linear" of
@@ -121,13 +92,6 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
       // (the small-batch path produced statistics tiles of fwd_finish_stat_rows() rows)
       const int st_rows = fs.splits > 1 ? fwd_finish_stat_rows() : (enc64 ? 64 : 128);
       const int st_tiles = (int)ceil_div(batch, st_rows);
-      if (midpair && st_tiles <= 64 && ctx->knob(KNOB_MID_PAIR_APPLY)) {
-        // statistics merge + BatchNorm / ReLU / dropout in one launch (every block merges its own 256 columns)
-        BLH_TRY(launch_mid_bn_apply(s, ws.Z[i], ws.stat_part, st_tiles, st_rows, params + h.gamma, params + h.beta, rm, rv,
-                                    momentum, sv, skip, ws.A[i], ws.keep[i], batch, W, layer_drop(ctx, drop, i, batch, W),
-                                    nbt + i, ws.amax_A[i]));
-        continue;
-      }
       if (ctx->sync.fn) {
         BLH_TRY(launch_bn_fwd_local_sums(s, ws.stat_part, st_tiles, st_rows, batch, W, ws.sync_buf));
         ctx->sync.fn(ctx->sync.user, ws.sync_buf, 2 * (int64_t)W, 1);
@@ -162,7 +126,7 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
     //  tools/event_cost_bench, profiles/r05_fork_cost.md; an event nobody waits for costs nothing)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
-    ctx->dec_fork_attached = ctx->two_stream && cap == hipStreamCaptureStatusNone && !ctx->knob(KNOB_NO_DEC_ATTACH);
+    ctx->dec_fork_attached = ctx->two_stream && cap == hipStreamCaptureStatusNone;
     if (ctx->dec_fork_attached) tl_stop_event = ctx->ev_dz[nh];
     const int rc = launch_decode_fused(s, ws.A[nh - 1], params + L.dec_w, params + L.dec_b, target, pred, ws.dpred, ws.G0,
                                        loss_part, ws.dec_bias_part, batch, W, OF, mse_scale, &np);
@@ -195,12 +159,12 @@ int forward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const
 }
 
 // ------------------------------------------------------------ backward -----
-// dW = dZ^T act, the reduction over the batch split across workgroups.  With `defer` the
-// partial slabs stay in `slabs` (a per-stage buffer) and *region records them for the single
-// grads_finish launch at the end of backward; otherwise they are summed right away.
+// dW = dZ^T act, the reduction over the batch split across workgroups; the partial slabs are summed right away, while
+// they are still in L2 / Infinity Cache (one deferred sum of all stages' slabs at the end of backward saved six launches
+// and read 68 MB of cold slabs: 1.268 against 1.253 ms per step in round 1, removed in round 6).
 int wgrad(int dtype, hipStream_t s, GemmTile tile, const float* dZ, int64_t ld_dz, int M,
                  const float* act, int64_t ld_act, int N, int64_t batch, int64_t tiles,
-          float* slabs, float* out, GradRegion* region, const float* amax_dz, const float* amax_act,
+          float* slabs, float* out, const float* amax_dz, const float* amax_act,
           int amax_parts, double* sq, int sq_blocks) {
   const Splits sp = pick_splits(batch, tiles);
   GemmParams g{};
@@ -212,17 +176,12 @@ int wgrad(int dtype, hipStream_t s, GemmTile tile, const float* dZ, int64_t ld_d
   }
   g.M = M; g.N = N; g.K = (int)batch; g.k_per_split = sp.k_per;
   g.ldc = N;
-  if (region) { region->slabs = nullptr; region->splits = 0; }
   if (sp.splits == 1) {
     g.C = out; g.c_split_stride = 0;
     return launch_gemm(s, tile, KROW, KROW, EPI_STORE, g, 1, dtype);
   }
   g.C = slabs; g.c_split_stride = (int64_t)M * N;
   BLH_TRY(launch_gemm(s, tile, KROW, KROW, EPI_STORE, g, sp.splits, dtype));
-  if (region) {
-    region->slabs = slabs; region->splits = sp.splits;
-    return BLH_OK;
-  }
   if (sq) return launch_sum_slabs_sq(s, slabs, (int64_t)M * N, sp.splits, out, sq, sq_blocks);
   return launch_sum_slabs(s, slabs, (int64_t)M * N, sp.splits, out);
 }
@@ -236,7 +195,7 @@ int wgrad(int dtype, hipStream_t s, GemmTile tile, const float* dZ, int64_t ld_d
 int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
                          const float* x, const blh_dropout* drop, const Workspace& ws,
                          const float* dpred, float* grads, int64_t batch,
-                         blh_grad_ready_fn on_ready, void* user,
+                         blh_grad_ready_fn on_ready, void* user, int saved_mode,
                          const FusedBackward* fused) {
   const ArenaLayout L = make_layout(d);
   const int nh = (int)L.heavy.size();
@@ -244,13 +203,7 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
   const int OF = d->out_features;
   const int chunks = ew_num_row_chunks(batch);
 
-  // The split-K slabs of each stage are summed right after its wgrad, while they are still in
-  // L2 / Infinity Cache.  Deferring all of them to the single grads_finish launch at the end
-  // (BLH_DEFER_SLABS=1, kept for experiments) saves six launches but reads 68 MB of by then
-  // cold slabs: measured 1.268 vs 1.253 ms/step, so it is off.
   tl_stop_event = nullptr;
-  const bool defer = (on_ready == nullptr) && ctx->defer_slabs;
-  std::vector<GradRegion> wreg(nh + 1);
   // Fused step, gradient norm (clip_grad_norm_, train_bilinear.py:81): the kernels that WRITE the gradient ranges
   // — slab sums of the weight gradients, the gamma / beta finalize, the bias reduction — also emit the
   // sum-of-squares partials of what they write (ws.sumsq_fold: a dense array, every launch fills exactly its
@@ -258,15 +211,14 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
   // clip + Adam (grads_finish: 9 us + its launch gap at configs[1]).  Needs every weight gradient to come out
   // of a slab sum, and the slots to fit.
   struct Fold { bool on = false; int per_w = 0; std::vector<int> w_off; int gb0 = 0, bias0 = 0, total = 0; } fold;
-  if (fused && fused->sumsq_part && !on_ready && !defer && !ctx->knob(KNOB_NO_SUMSQ_FOLD) && W % 16 == 0 &&
+  if (fused && fused->sumsq_part && !on_ready && !ctx->knob(KNOB_NO_SUMSQ_FOLD) && W % 16 == 0 &&
       fused->dec_bias_S > 0) {
     const bool slabbed = pick_splits(batch, ceil_div(W, 128) * ceil_div(W, 128)).splits > 1 &&
                          pick_splits(batch, ceil_div(W, 128) * ceil_div(d->in_features, 32)).splits > 1 &&
                          pick_splits(batch, ceil_div(OF, 64) * ceil_div(W, 128)).splits > 1;
     fold.per_w = (int)std::min<int64_t>(256, std::max<int64_t>(8, 2048 / (nh + 1)));
     int off = 0;
-    const blh_context::SavedFormat* sf = ctx->find_saved(ws.Z[0]);
-    const bool enc0 = sf && sf->mode == 3 && sf->batch == batch;      // (stage 0: enc_wgrad_finish writes dW0)
+    const bool enc0 = saved_mode == blh_context::SAVED_ENC_FUSED;      // (stage 0: enc_wgrad_finish writes dW0)
     for (int i = 0; i <= nh; ++i) {
       fold.w_off.push_back(off);
       const int64_t cnt = i == nh ? (int64_t)OF * W : (int64_t)W * L.heavy[i].fan_in;
@@ -279,7 +231,7 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
   }
   auto fold_w = [&](int i) -> double* { return fold.on ? ws.sumsq_fold + fold.w_off[i] : nullptr; };
   // two streams: on by default (-3 % step)
-  const bool two = ctx->two_stream && !ctx->sync.fn && !defer && small_m_splits(batch, W, W, d->gemm_dtype).splits == 1;
+  const bool two = ctx->two_stream && !ctx->sync.fn && small_m_splits(batch, W, W, d->gemm_dtype).splits == 1;
   hipStream_t s2 = two ? ctx->s2 : s;
   // auto (fp32 kernels): early.  The data-gradient launch fills the chip's LDS — 256 workgroups of the
   // 128 KB form (gemm_f32_backward_exclusive) or >= 512 of the 64 KB form — so the weight gradient
@@ -360,8 +312,8 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
     BLH_TRY(fork_wait(nh));
   }
   BLH_TRY(wgrad(d->gemm_dtype, s2, TILE_64x128, dpred, OF, OF, ws.A[nh - 1], W, W, batch,
-                ceil_div(OF, 64) * ceil_div(W, 128), defer ? ws.stage_slabs[nh] : ws.slabs,
-                grads + L.dec_w, defer ? &wreg[nh] : nullptr, nullptr, nullptr, 0, fold_w(nh), fold.per_w));
+                ceil_div(OF, 64) * ceil_div(W, 128), ws.slabs, grads + L.dec_w, nullptr, nullptr, 0, fold_w(nh),
+                fold.per_w));
   BLH_TRY(wdone(nh));
   // (decode bias: on the side stream under a hook — behind the fork, its inputs are older than that)
   if (!fused) BLH_TRY(launch_colsum(on_ready ? s2 : s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
@@ -369,21 +321,10 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
     BLH_TRY(launch_colreduce(s2, ws.dec_bias_part, fused->dec_bias_S, OF, OF, grads + L.dec_b));
   BLH_TRY(ready(nh, L.dec_w, L.total - L.dec_w));
 
-  // SURVEY K9 on the exact-fp32 path — OPT-IN (BLH_K9_F32=1), measured slower than the streaming reduce kernel it
-  // replaces (profiles/r04_k9_f32.md: headline 1.029 against 1.020 ms; the reduce kernel runs beside the weight
-  // gradient of the side stream, the epilogue's read of Z is on the data gradient's critical path).  The data gradient
-  // of a block's SECOND stage is read by nothing but the BatchNorm backward of the block's first stage: its GEMM
-  // epilogue (EPI_BN_BWD, gemm_epilogue.h) leaves the gated gradient dY' and the column sums per row tile, and the
-  // stage below skips bn_bwd_reduce_f2.  (The first stage's data gradient is the block-input gradient, a skip
-  // operand: the raw value has to be stored.)  Exact-fp32 GEMMs, one launch per tile.
-  const bool k9 = ctx->knob(KNOB_K9_F32) && d->gemm_dtype == 0 &&
-                  small_m_splits(batch, W, W, d->gemm_dtype).splits == 1;
-  int pregated_tiles = 0;     // > 0: this stage's dA is dY' and ws.stat_part holds that many rows of partials
-  const blh_context::SavedFormat* saved_fmt = ctx->find_saved(ws.Z[0]);
-  const bool enc_fused = saved_fmt && saved_fmt->mode == 3 && saved_fmt->batch == batch;
-  const bool colown_b = colowner_ok(ctx, d, batch) && !k9 && !defer;
-  struct PendingDA { const float* src = nullptr; int splits = 1; int64_t stride = 0; const float* addend = nullptr;
-                     float* out = nullptr; } pend;
+  // (the BatchNorm-backward sums in the fp32 data-gradient epilogue — SURVEY K9 on the exact-fp32 path — were built,
+  //  measured slower than the streaming reduce kernel beside the side stream's weight gradient and removed:
+  //  profiles/r04_k9_f32.md; the bf16-storage step keeps its K9, step_bf16s.hip)
+  const bool enc_fused = saved_mode == blh_context::SAVED_ENC_FUSED;
   for (int i = nh - 1; i >= 0; --i) {
     const HeavyOffsets& h = L.heavy[i];
     if (i == 0 && enc_fused) {
@@ -394,7 +335,6 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
                                   grads + h.w, grads + h.gamma, grads + h.beta,
                                   on_ready ? grads + h.b : ws.dz_colsum_part, on_ready ? 1 : chunks, fold_w(0),
                                   fold.on ? ws.sumsq_fold + fold.gb0 : nullptr));
-      wreg[0].slabs = nullptr; wreg[0].splits = 0;
       if (on_ready) {
         if (ctx->two_stream) {
           BLH_HIP_TRY(hipEventRecord(g_side.ev_r[0], s));
@@ -411,25 +351,9 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
     const float* dA = first_of_block ? ws.G1 : ws.G0;
     const float* sv = ws.bn_saved[i];
     // (dropout: the keep bits the forward wrote, ws.keep[i])
-    const bool pregated = pregated_tiles > 0;
-    // 385 .. 1024 rows: the whole BatchNorm backward of the stage in one launch (colowner_f32.hip); its input is the
-    // gradient tensor, or — when the stage above left its data gradient as split-K slabs — the slabs themselves
-    // (+ the block-skip gradient; the sum is written out where it is an operand again: `pend.out`)
-    const bool co_stage = colown_b && !pregated;
-    if (co_stage) {
-      BLH_TRY(launch_colowner_bwd(s, pend.src ? pend.src : dA, pend.src ? pend.splits : 1, pend.stride, pend.addend,
-                                  pend.out, ws.Z[i], sv, ws.keep[i], ws.dZ[i], grads + h.gamma, grads + h.beta,
-                                  ws.dz_colsum_part + (int64_t)i * chunks * W, chunks,
-                                  fold.on ? ws.sumsq_fold + fold.gb0 + i * bn_bwd_finalize_blocks(W) : nullptr, batch, W));
-      pend = PendingDA{};
-    } else {
-    if (!pregated)
-      BLH_TRY(launch_bn_bwd_reduce_f2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, ws.keep[i], ws.bn_part, batch, W));
-    BLH_TRY(launch_bn_bwd_finalize_h2(s, pregated ? ws.stat_part : ws.bn_part, pregated ? pregated_tiles : chunks, W,
-                                      sv, sv + W, grads + h.gamma, grads + h.beta,
+    BLH_TRY(launch_bn_bwd_reduce_f2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, ws.keep[i], ws.bn_part, batch, W));
+    BLH_TRY(launch_bn_bwd_finalize_h2(s, ws.bn_part, chunks, W, sv, sv + W, grads + h.gamma, grads + h.beta,
                                       fold.on ? ws.sumsq_fold + fold.gb0 + i * bn_bwd_finalize_blocks(W) : nullptr));
-    }
-    pregated_tiles = 0;
     const float* dg = grads + h.gamma;
     const float* db = grads + h.beta;
     int64_t norm_batch = batch;
@@ -463,10 +387,9 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
     const bool fork_late = side && late_policy && i > 0 && small_m_splits(batch, W, W, d->gemm_dtype).splits == 1;
     hipStream_t sw = side ? s2 : s;
     if (side && !fork_late) arm_fork(i);
-    if (!co_stage)
     BLH_TRY(launch_bn_bwd_apply_f2(s, dA, ws.Z[i], sv + 2 * W, sv + 3 * W, sv, sv + W, dg, db, ws.keep[i],
                                    dzbuf, ws.dz_colsum_part + (int64_t)i * chunks * W, batch, W,
-                                   norm_batch, dz_amax, pregated));
+                                   norm_batch, dz_amax));
     tl_stop_event = nullptr;
     if (side && !fork_late) BLH_TRY(fork_wait(i));
     if (fork_late) arm_fork(i);
@@ -486,13 +409,6 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
       if (ds2.splits > 1) {
         g.C = ws.slabs; g.c_split_stride = batch * (int64_t)W; g.k_per_split = ds2.k_per;
         BLH_TRY(launch_gemm(s, TILE_128x128, ROWK, KROW, EPI_STORE, g, ds2.splits, d->gemm_dtype));
-        // (the stage below is a column-owner stage: it sums the slabs itself — and the weight gradient of THIS stage,
-        //  next on the stream, takes its own slab buffer)
-        const bool consumer_co = colown_b && ws.stage_slabs[i] != nullptr && (i - 1 >= 1 || !enc_fused);
-        if (consumer_co)
-          pend = PendingDA{ws.slabs, ds2.splits, batch * (int64_t)W, first_of_block ? ws.G0 : nullptr,
-                           first_of_block ? ws.G0 : nullptr};
-        else
         BLH_TRY(launch_sum_slabs_add(s, ws.slabs, batch * (int64_t)W, ds2.splits,
                                      first_of_block ? ws.G0 : nullptr, dst));
       } else {
@@ -501,14 +417,6 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
           // d(block input) = dZ W + d(block output)   (skip path), in place in G0
           g.C = ws.G0; g.addend = ws.G0; g.ldadd = W;
           BLH_TRY(launch_gemm(s, dtile, ROWK, KROW, EPI_ADD, g, 1, d->gemm_dtype));
-        } else if (k9) {
-          // (the forward's statistics partials are dead by now: ws.stat_part holds ceil(batch / 64) rows)
-          const float* svb = ws.bn_saved[i - 1];
-          g.C = ws.G1;
-          g.bnb_z = ws.Z[i - 1]; g.bnb_ldz = W; g.bnb_keep = ws.keep[i - 1];
-          g.bnb_scale = svb + 2 * W; g.bnb_shift = svb + 3 * W; g.bnb_part = ws.stat_part;
-          BLH_TRY(launch_gemm(s, dtile, ROWK, KROW, EPI_BN_BWD, g, 1, d->gemm_dtype));
-          pregated_tiles = (int)ceil_div(batch, gemm_stat_tile_rows(dtile));
         } else {
           g.C = ws.G1;
           BLH_TRY(launch_gemm(s, dtile, ROWK, KROW, EPI_STORE, g, 1, d->gemm_dtype));
@@ -528,13 +436,12 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
       //  at the very end of backward)
       BLH_TRY(wgrad(d->gemm_dtype, sw, TILE_128x32, dzbuf, W, W, x, d->in_features,
                     d->in_features, batch, ceil_div(W, 128) * ceil_div(d->in_features, 32),
-                    (defer || (two && !side)) ? ws.stage_slabs[0] : ws.slabs, grads + h.w,
-                    defer ? &wreg[0] : nullptr, nullptr, nullptr, 0, fold_w(0), fold.per_w));
+                    (two && !side) ? ws.enc_slabs : ws.slabs, grads + h.w, nullptr, nullptr, 0, fold_w(0),
+                    fold.per_w));
       if (side) BLH_TRY(wdone(0));
     } else {
       BLH_TRY(wgrad(d->gemm_dtype, sw, TILE_128x128, dzbuf, W, W, ws.A[i - 1], W, W, batch,
-                    ceil_div(W, 128) * ceil_div(W, 128), (defer || pend.src) ? ws.stage_slabs[i] : ws.slabs,
-                    grads + h.w, defer ? &wreg[i] : nullptr, dz_amax, ws.amax_A[i - 1],
+                    ceil_div(W, 128) * ceil_div(W, 128), ws.slabs, grads + h.w, dz_amax, ws.amax_A[i - 1],
                     ws.amax_parts, fold_w(i), fold.per_w));
       BLH_TRY(wdone(i));
     }
@@ -559,25 +466,9 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
   if (fold.on) {     // the producers left the partials: hand them to clip + Adam
     fused->sumsq_src[0] = ws.sumsq_fold;
     *fused->sumsq_nparts = fold.total;
-  } else if (!on_ready) {   // (covers the no_defer A/B mode too: its regions are all plain)
-    // regions in arena order: [weight (slabs or plain)] [bias, gamma, beta (plain)] per stage,
-    // then decode weight and decode bias (+ tail padding)
-    GradRegions R{};
-    auto push = [&](int64_t off, int64_t end, const GradRegion* w) {
-      GradRegion& r = R.r[R.n++];
-      r.off4 = off / 4; r.cnt4 = (end - off) / 4;
-      r.slabs = w ? w->slabs : nullptr; r.splits = w ? w->splits : 0; r.first_block = 0;
-    };
-    for (int i = 0; i < nh; ++i) {
-      const HeavyOffsets& h = L.heavy[i];
-      const int64_t wend = h.w + (int64_t)W * h.fan_in;
-      push(h.w, wend, &wreg[i]);
-      push(wend, (i + 1 < nh) ? L.heavy[i + 1].w : L.dec_w, nullptr);
-    }
-    push(L.dec_w, L.dec_w + (int64_t)OF * W, &wreg[nh]);
-    push(L.dec_w + (int64_t)OF * W, L.total, nullptr);
-    BLH_TRY(launch_grads_finish(s, grads, R, L.total / 4, fused ? fused->sumsq_part : nullptr,
-                                fused ? fused->sumsq_nparts : nullptr));
+  } else if (!on_ready && fused && fused->sumsq_part) {
+    // (the producers' partials were not available — small shapes, BLH_NO_SUMSQ_FOLD: one pass over the arena)
+    BLH_TRY(launch_sumsq(s, grads, L.total, fused->sumsq_part, fused->sumsq_nparts));
   }
   return BLH_OK;
 }

@@ -7,6 +7,7 @@
 #include <algorithm>
 
 #include "../small_step.hip"
+#include "small_step_persistent.h"
 #include "../api_layout.h"
 using namespace blh;
 thread_local int blh::g_last_hip_error = 0;

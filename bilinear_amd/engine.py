@@ -181,7 +181,7 @@ class Engine:
             old = self.ctx
             self.ctx = N.Context(device)
             if old is not None:    # keep the options across a device move
-                for opt in (N.OPT_TWO_STREAM, N.OPT_DEFER_SLABS, N.OPT_LATE_FORK, N.OPT_PERSISTENT_SHADOW,
+                for opt in (N.OPT_TWO_STREAM, N.OPT_LATE_FORK, N.OPT_PERSISTENT_SHADOW,
                             N.OPT_SMALL_STEP):
                     self.ctx.set_option(opt, old.get_option(opt))
         self.device = device
@@ -395,6 +395,10 @@ class Engine:
             raise ValueError("Expected more than 1 value per channel when training, got input size %s"
                              % (tuple(x.shape),))
         named = self._named_params()
+        # explicit dropout masks: moved to this device and shape-checked HERE — the operator's Python implementation
+        # hands masks.data_ptr() to the kernels as it is (a host pointer or a mask built for another batch would be a
+        # GPU memory fault, not an exception)
+        self._drop_struct(batch)
         _ops.ENGINES[int(self.ctx.handle.value)] = self
         pred, _saved, new_running, new_nbt = torch.ops.bilinear_hip.lifter_train(
             x, [p for _, p, _, _ in named], self.params, self.bn_running, self.bn_nbt, self.masks,
@@ -495,11 +499,10 @@ class Engine:
 
     def set_small_step(self, mode):
         """The small-batch kernels (at most 384 rows, fp32, BLH_OPT_SMALL_STEP): True / 1 / "staged" (default) = one
-        launch per stage; 2 / "persistent" = persistent launches with grid barriers; False / 0 = the multi-launch path
-        every other batch size takes."""
+        launch per stage; False / 0 / "off" = the multi-launch path every other batch size takes."""
         if self.ctx is None:
             raise RuntimeError("the engine is not on a device yet")
-        value = {"staged": 1, "persistent": 2, "off": 0}.get(mode, mode)
+        value = {"staged": 1, "off": 0}.get(mode, mode)
         self.ctx.set_option(N.OPT_SMALL_STEP, int(value))
 
     def backward(self, x, dpred, on_ready=None, sync=None, global_batch=None, generation=None):
@@ -612,26 +615,4 @@ class Engine:
         self._saved_batch = None
         if self.masks is None:
             self.rng_step += 1
-        self._barrier_watch(batch)
         return pred, loss
-
-    BARRIER_CHECK_EVERY = 512      # steps between two checks of the grid-barrier timeout counter (each one synchronises)
-
-    def _barrier_watch(self, batch):
-        """The persistent small-batch launches (set_small_step(2)) and the opt-in fused bf16 forward stage
-        (BLH_FWD_FUSE) synchronise their workgroups with grid barriers that give up after ~0.3 s when the grid is not
-        resident (another process, a side-stream GEMM or a collective holding CUs) — the step then continues with
-        wrong data.  The count is only readable with a device synchronisation, so it is checked on a cadence: a
-        non-zero count raises; the staged form (the default) has no barrier and is never checked."""
-        import os
-        if not ((self.ctx.get_option(N.OPT_SMALL_STEP) == 2 and batch <= 64) or os.environ.get("BLH_FWD_FUSE")):
-            return
-        self._barrier_steps = getattr(self, "_barrier_steps", 0) + 1
-        if self._barrier_steps % self.BARRIER_CHECK_EVERY:
-            return
-        n = int(N.lib().blh_context_grid_barrier_timeouts(self.ctx.handle))
-        if n:
-            raise RuntimeError("bilinear_amd: %d grid-barrier timeouts since the context was created: a persistent "
-                               "launch was not fully resident and its results are wrong.  Do not combine "
-                               "set_small_step(2) / BLH_FWD_FUSE with DataParallel, side-stream work or other "
-                               "processes on the device; the default staged kernels have no barrier." % n)

@@ -40,7 +40,9 @@
 extern "C" {
 #endif
 
-#define BLH_ABI_VERSION 4
+/* 5 (round 6): blh_context_grid_barrier_timeouts, BLH_OPT_DEFER_SLABS and BLH_OPT_SMALL_STEP = 2 (the persistent
+ * small-batch launches) were removed with the slower opt-in variants they served; blh_rccl_* added.        */
+#define BLH_ABI_VERSION 5
 
 typedef enum {
   BLH_OK = 0,
@@ -89,8 +91,7 @@ int blh_context_destroy(blh_context* ctx);
 typedef enum {
   BLH_OPT_TWO_STREAM = 0, /* 1 (default): weight-gradient GEMMs on the context's side stream;
                              0: single-stream order.  Results are bit-identical either way.  */
-  BLH_OPT_DEFER_SLABS = 1, /* 1: sum all split-K weight-gradient slabs in one launch at the end
-                              of backward (default 0: right after each GEMM)                 */
+  /* (1 was BLH_OPT_DEFER_SLABS until ABI 4: one deferred slab sum at the end of backward, measured slower) */
   BLH_OPT_LATE_FORK = 2,  /* when a stage's weight-gradient GEMM is handed to the side stream.
                              1: behind its data-gradient GEMM (it runs beside the next stage's
                              BatchNorm backward); 0: behind bn_bwd_apply, together with the
@@ -98,25 +99,18 @@ typedef enum {
                              at most one 128 KB-LDS workgroup per CU — the dispatcher then runs
                              them one after the other without a cross-queue latency — else 1.
                              Scheduling only: results are bit-identical.                     */
-  BLH_OPT_SMALL_STEP = 4, /* gemm_dtype 0 (and 2 / 3, which approximate it), at most 384 rows (the persistent form:
-                             64), width <= 1024 — the reference's own batch size is 64,
-                             /root/reference/util/config.py:15 — run on purpose-built
-                             kernels (small_step.hip) in which a workgroup owns four columns of a stage for all
-                             rows, so BatchNorm, dropout and the BatchNorm backward are local to it, instead of
-                             ~50 launch-bound launches.  Applies to blh_train_step(_captured), blh_forward_train,
-                             blh_backward and blh_forward_eval:
-                               1 (default) one launch per stage (the fused step: 2 stages + 3 launches, 0.153 ms
-                                 at 2 x 1024 against 0.316; no residency requirement);
-                               2 persistent launches with grid barriers between the stages (the fused step: one
-                                 launch, 0.200 ms; forward / backward: one each);   0 the multi-launch path.
+  BLH_OPT_SMALL_STEP = 4, /* gemm_dtype 0 (and 2 / 3, which approximate it), at most 384 rows, width <= 1024 — the
+                             reference's own batch size is 64, /root/reference/util/config.py:15 — run on
+                             purpose-built kernels (small_step.hip) in which a workgroup owns four columns of a
+                             stage for all rows, so BatchNorm, dropout and the BatchNorm backward are local to it,
+                             instead of ~50 launch-bound launches.  Applies to blh_train_step(_captured),
+                             blh_forward_train, blh_backward and blh_forward_eval:
+                               1 (default) one launch per stage (the fused step: 2 nh + 3 launches, 0.150 ms at
+                                 2 x 1024 against 0.316; no residency requirement);   0 the multi-launch path.
                              Same arithmetic up to the order of fp32 sums (all within the fp32 parity tolerance).
                              The saved activations of such a forward are in the small-batch format: the context
-                             pairs blh_backward with them.  A persistent launch (2) fills the device (one
-                             workgroup per CU, all resident): do not run two of them at the same time on one
-                             device (two contexts on two streams) — neither could become resident, their barriers
-                             would give up after ~0.3 s each and the results would be wrong
-                             (blh_context_grid_barrier_timeouts() counts that); where the device cannot hold the
-                             grid at all the staged form is taken.                                          */
+                             pairs blh_backward with them.  (Until ABI 4 the value 2 selected persistent launches
+                             with grid barriers: slower, and wrong when not fully resident — removed.)          */
   BLH_OPT_BUCKET_FLOATS = 6, /* default 0.  > 0: blh_backward / blh_backward_sync merge the contiguous gradient ranges
                              they would report (one per stage, decode first) and call the hook once per BUCKET of at
                              least this many elements, plus once for what is left at the end — the merging the
@@ -142,15 +136,6 @@ int blh_context_get_option(const blh_context* ctx, int32_t option);
 /* The side stream (hipStream_t as void*) the weight-gradient GEMMs run on; NULL when
  * BLH_OPT_TWO_STREAM is 0.  See blh_backward.                                            */
 void* blh_context_side_stream(blh_context* ctx);
-/* The fused forward stage of gemm_dtype 4 (Linear + BatchNorm + ReLU + Dropout in one launch, statistics merged
- * behind a grid-wide barrier) needs every workgroup of its launch resident at once; the library only takes it
- * when the grid has at most one workgroup per CU, and its barrier spin is bounded (0.3 s), so a launch that was
- * denied the whole device (another training forward running beside it) ends with wrong results instead of
- * hanging.  This returns how many workgroups ever gave up waiting on this context's barrier (0 = never;
- * synchronous: one small device-to-host copy).  The fused stage is bit-identical to the three-launch form and
- * measured slower (profiles/r04_fused_forward.md): it is opt-in, BLH_FWD_FUSE=1.  The persistent small-batch
- * launches (BLH_OPT_SMALL_STEP = 2) use barriers of the same kind and are counted here too.                  */
-int64_t blh_context_grid_barrier_timeouts(blh_context* ctx);
 /* Replace the current device's process-wide side stream by a freshly created one; every context of
  * the device uses the new one from its next call on (the old one is drained and destroyed: call it
  * between steps, never under stream capture).  Why it exists: on this stack the two streams of the

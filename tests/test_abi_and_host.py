@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(native):
         assert hasattr(native, name), "libbilinear_hip.so does not export %s" % name
     from bilinear_amd import _native
     assert sorted(_native.exported_names()) == decl, "ctypes table and header disagree"
-    assert native.blh_abi_version() == 4
+    assert native.blh_abi_version() == 5
     assert native.blh_status_string(0) == b"ok"
     assert native.blh_status_string(-4) == b"workspace too small"
 

@@ -445,59 +445,6 @@ def test_bn_backward_reductions_in_the_dgrad_epilogue_match_the_streaming_kernel
         assert rel <= 2e-3, (k, rel)
 
 
-@pytest.mark.parametrize("nb,batch,explicit", [(2, 8192, False), (2, 16384, False), (1, 8192, True), (2, 8104, False)])
-def test_fused_forward_stage_is_bit_identical_to_the_three_launch_form(nb, batch, explicit):
-    """gemm_bf16s_bnfwd.h: Linear + BatchNorm (batch statistics behind a grid barrier) + ReLU + Dropout + skip in
-    the GEMM's epilogue (opt-in: BLH_FWD_FUSE=1) against GEMM -> bn_fwd_finalize -> bn_apply_h2: the statistics are merged
-    in the same order in fp64 and the stored bf16 Z is what gets normalised in both, so predictions, running
-    statistics, every gradient and the parameters after fused steps are bit-identical — with Philox dropout
-    (8192 rows: the 128 x 256 kernel; 16384: the 256 x 256 kernel; 8104: a ragged last row tile) and with
-    explicit masks."""
-    import os
-
-    import bilinear_amd
-    from bilinear_amd import _native as N
-    dev = _dev()
-    x, t = (torch.randn(batch, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(3)),
-            torch.randn(batch, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(4)))
-    masks = None
-    if explicit:
-        g = torch.Generator(device=dev).manual_seed(9)
-        masks = [(torch.rand(batch, 1024, device=dev, generator=g) < 0.5).to(torch.uint8) for _ in range(1 + 2 * nb)]
-    out = {}
-    for fused in (True, False):
-        if fused:
-            os.environ["BLH_FWD_FUSE"] = "1"
-        try:
-            torch.manual_seed(0)
-            net, opt, _, _ = bilinear_amd.load(dev, num_blocks=nb, width=1024, gemm_dtype="bf16s")
-            net.train()
-            net.engine.ensure(dev)
-            net.engine.seed = 11
-            if masks is not None:
-                net.engine.set_dropout_masks(masks)
-            opt.zero_grad()
-            pred = net(x)
-            torch.nn.functional.mse_loss(pred, t).backward()
-            torch.cuda.synchronize()
-            first = (pred.detach().clone(), net.engine.grads.clone(), net.engine.bn_running.clone(),
-                     net.engine.bn_nbt.clone())
-            for _ in range(2):
-                p2, loss = net.train_step(opt, x, t, max_norm=1.0)
-            torch.cuda.synchronize()
-            out[fused] = first + (p2.clone(), net.engine.params.clone(), net.engine.bn_running.clone(),
-                                  net.engine.bn_nbt.clone())
-            assert N.lib().blh_context_grid_barrier_timeouts(net.engine.ctx.handle) == 0
-        finally:
-            os.environ.pop("BLH_FWD_FUSE", None)
-    names = ("pred", "grads", "running statistics", "num_batches_tracked", "pred after two fused steps", "params",
-             "running statistics after", "num_batches_tracked after")
-    for a, b, what in zip(out[True], out[False], names):
-        assert torch.equal(a, b), what
-    assert torch.isfinite(out[True][5]).all()
-    assert int(out[True][7][1]) == 3
-
-
 def test_persistent_shadow_is_bit_identical_and_invalidated_by_parameter_writes():
     """BLH_OPT_PERSISTENT_SHADOW (fused Adam -> bf16 weight image): the same steps with
     and without it are bit-identical — through plain fused steps, a load_state_dict between two

@@ -1169,3 +1169,131 @@ def test_contexts_of_one_device_share_the_side_stream_and_outlive_each_other():
     torch.cuda.synchronize()
     assert torch.isfinite(loss).item() and torch.isfinite(net.engine.params).all().item()
     assert b.side_stream() == sb
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the operator path with explicit masks, and many outstanding forwards of mixed formats
+def _op_net(dev, nb=1, width=256, seed=3):
+    import bilinear_amd
+    torch.manual_seed(seed)
+    net, opt, _, _ = bilinear_amd.load(dev, num_blocks=nb, width=width)
+    net.train()
+    net.engine.ensure(dev)
+    net.engine.seed = 11
+    return net, opt
+
+
+def test_operator_path_moves_or_refuses_explicit_masks(monkeypatch):
+    """EAGER_AUTOGRAD = "op": explicit dropout masks handed over as NumPy arrays (host memory) are moved to the device
+    before the operator sees them, and masks built for another batch raise — neither reaches the kernels as a bad
+    pointer (forward_train_autograd had lost the _drop_struct call)."""
+    import bilinear_amd.model.bilinear as MB
+    dev = _dev()
+    monkeypatch.setattr(MB, "EAGER_AUTOGRAD", "op")
+    nb, width, batch = 1, 256, 512
+    rng = np.random.RandomState(5)
+    masks = [(rng.rand(batch, width) < 0.5).astype(np.uint8) for _ in range(1 + 2 * nb)]
+    x = torch.randn(batch, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    outs = []
+    for as_numpy in (True, False):
+        net, _ = _op_net(dev, nb, width)
+        net.engine.set_dropout_masks(masks if as_numpy else [torch.from_numpy(m).to(dev) for m in masks])
+        if as_numpy:
+            assert net.engine.masks.device.type == "cpu"          # (the hazard: still host memory here)
+        pred = net(x)
+        assert type(pred.grad_fn).__name__ != "_LifterFunctionBackward"
+        assert net.engine.masks.device == x.device
+        g = torch.autograd.grad(pred.square().mean(), [p for _, p, _, _ in net.engine._named_params()])
+        torch.cuda.synchronize()
+        outs.append((pred.detach().clone(), torch.cat([t.reshape(-1) for t in g])))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    net, _ = _op_net(dev, nb, width)
+    net.engine.set_dropout_masks(masks)
+    with pytest.raises(RuntimeError, match="dropout masks have shape"):
+        net(x[:256])                                              # masks of 512 rows, batch of 256
+
+
+def test_many_outstanding_forwards_of_mixed_batch_sizes_each_get_their_own_backward(monkeypatch):
+    """Operator path, one context: five forwards outstanding at once — 4096, 4096, 64, 4096, 1000 rows, i.e. the
+    encode-without-Z0 format, the small-batch format and again — then their backwards in forward order.  Every
+    backward must read its activations in the format its forward wrote (the context keeps a record per workspace);
+    compared with the same forward + backward run alone.  ADVICE r05: the old table of four fell back to "the last
+    forward" and silently produced wrong gradients."""
+    import bilinear_amd.model.bilinear as MB
+    dev = _dev()
+    monkeypatch.setattr(MB, "EAGER_AUTOGRAD", "op")
+    sizes = [4096, 4096, 64, 4096, 1000, 640, 4096]
+    gen = torch.Generator(device=dev).manual_seed(9)
+    xs = [torch.randn(b, 32, device=dev, generator=gen) for b in sizes]
+
+    def alone(i):
+        net, _ = _op_net(dev, 1, 256)
+        net.engine.rng_step = i                    # the same Philox step the shared model uses for forward i
+        pred = net(xs[i])
+        g = torch.autograd.grad(pred.square().mean(), [p for _, p, _, _ in net.engine._named_params()])
+        torch.cuda.synchronize()
+        return pred.detach().clone(), torch.cat([t.reshape(-1) for t in g])
+
+    want = [alone(i) for i in range(len(sizes))]
+    net, _ = _op_net(dev, 1, 256)
+    running0 = net.engine.bn_running.clone()
+    preds = []
+    for i, x in enumerate(xs):
+        net.engine.bn_running.copy_(running0)      # (the running statistics do not enter a train-mode forward)
+        preds.append(net(x))
+    params = [p for _, p, _, _ in net.engine._named_params()]
+    for i, pred in enumerate(preds):
+        g = torch.autograd.grad(pred.square().mean(), params)
+        torch.cuda.synchronize()
+        assert torch.equal(pred.detach(), want[i][0]), i
+        assert torch.equal(torch.cat([t.reshape(-1) for t in g]), want[i][1]), (i, sizes[i])
+
+
+def test_second_backward_with_retain_graph_matches_the_first(monkeypatch):
+    """loss.backward(retain_graph=True) twice on the operator path: lifter_backward works inside the saved workspace
+    (gradient buffers only — the activations, keep bits and statistics it reads are never overwritten), so the second
+    pass gives the same gradients, in every saved format (small-batch, multi-launch with and without Z0)."""
+    import bilinear_amd.model.bilinear as MB
+    dev = _dev()
+    monkeypatch.setattr(MB, "EAGER_AUTOGRAD", "op")
+    gen = torch.Generator(device=dev).manual_seed(4)
+    for batch in (64, 300, 1000, 4096):
+        net, _ = _op_net(dev, 1, 256)
+        x = torch.randn(batch, 32, device=dev, generator=gen)
+        params = [p for _, p, _, _ in net.engine._named_params()]
+        loss = net(x).square().mean()
+        g1 = torch.autograd.grad(loss, params, retain_graph=True)
+        g1 = torch.cat([t.reshape(-1) for t in g1]).clone()
+        g2 = torch.autograd.grad(loss, params)
+        torch.cuda.synchronize()
+        assert torch.equal(g1, torch.cat([t.reshape(-1) for t in g2])), batch
+
+
+def test_backward_refuses_a_workspace_whose_record_says_another_batch(native):
+    """C ABI: blh_backward on a workspace whose last forward saved another batch size (or nothing usable: an eval
+    forward overwrote it) returns BLH_ERR_INVALID_ARGUMENT instead of reading the buffers in a wrong layout."""
+    from bilinear_amd import _native as N
+    dev = _dev()
+    net, _ = _op_net(dev, 1, 256)
+    eng = net.engine
+    ws = eng.workspace(4096)
+    x = torch.randn(4096, 32, device=dev)
+    grads = torch.empty_like(eng.params)
+    dpred = torch.zeros(1024, 48, device=dev)
+    st = N.current_stream()
+
+    def backward(batch):
+        drop = N.Dropout(None, 1, 0, 0, 0, 0)
+        return N.lib().blh_backward(eng.ctx.handle, ctypes.byref(eng.layout.desc), st, N.ptr(eng.params), N.ptr(x),
+                                    ctypes.byref(drop), N.ptr(ws), ws.numel(), N.ptr(dpred), N.ptr(grads), batch,
+                                    ctypes.cast(None, N.GradReadyFn), None)
+    eng.forward_train(x)                                           # saves 4096 rows (encode stage without Z0)
+    assert backward(1024) == -1                                    # BLH_ERR_INVALID_ARGUMENT
+    with torch.no_grad():
+        net.eval()
+        eng.forward_eval(x[:1024])                                 # overwrites the buffers: nothing left to back-propagate
+        net.train()
+    assert backward(1024) == -1
+    eng.forward_train(x[:1024])
+    assert backward(1024) == 0
+    torch.cuda.synchronize()

@@ -763,51 +763,6 @@ def test_standalone_stages_draw_different_masks():
     both = ~za & ~zb
     assert torch.equal(ya[both], yb[both])
 
-
-@pytest.mark.parametrize("nb,width,batch", [(2, 1024, 4096), (2, 1024, 4100), (1, 1024, 1500), (3, 512, 2500),
-                                            (2, 1024, 16384)])
-def test_fp32_bn_backward_reductions_in_the_dgrad_epilogue_match_the_streaming_kernel(nb, width, batch):
-    """SURVEY K9 on the exact-fp32 path (round 4, gemm_epilogue.h EPI_BN_BWD): the data gradient of a block's second
-    stage is read by nothing but the BatchNorm backward of the block's first stage, so its GEMM epilogue forms that
-    stage's gated gradient dY' = 2 keep [y > 0] dA — the same expression on the same operands as bn_bwd_reduce_f2 —
-    and the per-row-tile column sums (dY' z, dY'); the stage below skips the reduce kernel and reads no keep bits.
-    Only the order of the column sums differs from the default run: every gradient agrees to summation rounding.
-    128-row tiles with a ragged last tile (4100), 64-row tiles (1500, 2500: mid_tile64).  Opt-in (BLH_K9_F32=1):
-    correct, but slower than the streaming reduce kernel it replaces (profiles/r04_k9_f32.md)."""
-    import os
-
-    import bilinear_amd
-    dev = _dev()
-    x = torch.randn(batch, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
-    t = torch.randn(batch, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
-    out = {}
-    for k9 in (True, False):
-        if k9:
-            os.environ["BLH_K9_F32"] = "1"
-        try:
-            torch.manual_seed(0)
-            net, opt, _, _ = bilinear_amd.load(dev, num_blocks=nb, width=width, gemm_dtype="fp32")
-            net.train()
-            net.engine.ensure(dev)
-            net.engine.seed = 11
-            opt.zero_grad()
-            pred = net(x)
-            torch.nn.functional.mse_loss(pred, t).backward()
-            torch.cuda.synchronize()
-            out[k9] = (pred.detach().clone(), net.engine.grads.clone(),
-                       {k: p.grad.detach().clone() for k, p in net.named_parameters()})
-        finally:
-            os.environ.pop("BLH_K9_F32", None)
-    assert torch.equal(out[True][0], out[False][0])              # the forward is untouched
-    assert not torch.equal(out[True][1], out[False][1])          # ... and the backward really took another path
-    for k in out[True][2]:
-        a, b = out[True][2][k].double(), out[False][2][k].double()
-        if k.endswith(".0.bias") and not k.startswith("decode"):
-            continue                                             # pre-BatchNorm biases: rounding noise (SURVEY H2)
-        rel = float((a - b).norm() / b.norm())
-        assert rel <= 2e-5, (k, rel)
-
-
 def _fused_and_materialised(build, x, t, masks):
     """The drop-in step (forward without a target, backward from MSELoss's gradient) and two fused steps (forward
     with the target: one-pass decode), with the round-5 encode / decode kernels and with both switched off."""
@@ -925,104 +880,3 @@ def test_encode_stage_without_z0_on_inputs_that_are_not_standardised(storage):
     ra, rb = a[2].view(-1, 2, width)[0], b[2].view(-1, 2, width)[0]
     assert _rel(ra[0], rb[0]) <= (1e-6 if storage == "fp32" else 1e-3), _rel(ra[0], rb[0])
     assert _rel(ra[1], rb[1]) <= (1e-5 if storage == "fp32" else 1e-2), _rel(ra[1], rb[1])
-
-
-@pytest.mark.parametrize("nb,width,batch", [(2, 1024, 512), (2, 1024, 1024), (2, 1024, 777), (1, 512, 400), (3, 256, 640)])
-def test_column_owner_stages_match_the_multi_launch_path(nb, width, batch):
-    """Round 5, 385 .. 1024 rows (the per-GPU shapes of the headline batch split over 4 / 8 GPUs): the hidden stages
-    run their BatchNorm forward (slab sum + bias, statistics, apply, dropout, skip) and backward (reductions, dgamma /
-    dbeta, dZ, bias sums — reading the data-gradient slabs of the stage above directly) in ONE launch each
-    (colowner_f32.hip: a workgroup owns 32 columns for all rows; opt-in, BLH_MID_FUSE=1: correct, and slower than the
-    launches it replaces — profiles/r05_colowner.md).  Against the default multi-launch form (4-5 launches per stage)
-    on the same explicit masks: running statistics, counters, the drop-in step's gradients and
-    two fused steps agree to fp32 summation rounding (ragged batch 777: a partial last pass and 8-row group)."""
-    import os
-
-    import bilinear_amd
-    dev = _dev()
-    x = torch.randn(batch, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
-    t = torch.randn(batch, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
-    g = torch.Generator(device=dev).manual_seed(9)
-    masks = [(torch.rand(batch, width, device=dev, generator=g) < 0.5).to(torch.uint8) for _ in range(1 + 2 * nb)]
-    out = {}
-    for fused in (True, False):
-        if fused:
-            os.environ["BLH_MID_FUSE"] = "1"
-        try:
-            torch.manual_seed(0)
-            net, opt, _, _ = bilinear_amd.load(dev, num_blocks=nb, width=width, gemm_dtype="fp32")
-            net.train()
-            net.engine.ensure(dev)
-            net.engine.set_dropout_masks(masks)
-            opt.zero_grad()
-            pred = net(x)
-            torch.nn.functional.mse_loss(pred, t).backward()
-            torch.cuda.synchronize()
-            first = (pred.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()},
-                     net.engine.bn_running.clone(), net.engine.bn_nbt.clone())
-            for _ in range(2):
-                p2, loss = net.train_step(opt, x, t, max_norm=1.0)
-            torch.cuda.synchronize()
-            out[fused] = first + (p2.clone(), loss.clone(), net.engine.bn_running.clone(), net.engine.bn_nbt.clone())
-        finally:
-            os.environ.pop("BLH_MID_FUSE", None)
-    a, b = out[True], out[False]
-    assert _rel(a[0], b[0]) <= 1e-5, ("pred", _rel(a[0], b[0]))
-    for k in a[1]:
-        if k.endswith(".0.bias") and not k.startswith("decode"):
-            continue                              # pre-BatchNorm biases: rounding noise around zero (SURVEY H2)
-        assert _rel(a[1][k], b[1][k]) <= 2e-2, (k, _rel(a[1][k], b[1][k]))      # (a ReLU gate that opened differently: ~1e-3)
-    assert _rel(a[2], b[2]) <= 1e-5 and torch.equal(a[3], b[3]) and int(a[3][1]) == 1
-    assert abs(float(a[5]) - float(b[5])) <= 1e-3 * abs(float(b[5]))
-    assert _rel(a[6], b[6]) <= 1e-4 and torch.equal(a[7], b[7]) and int(a[7][1]) == 3
-
-
-@pytest.mark.parametrize("nb,width,batch", [(2, 1024, 512), (2, 1024, 1024), (2, 1024, 777), (2, 1024, 1536),
-                                            (2, 1024, 2048), (1, 512, 400), (3, 256, 640)])
-def test_mid_batch_pair_fusions_are_bit_identical(nb, width, batch):
-    """Round 5, 385 .. 2048 rows (the per-GPU shapes of the headline batch under strong scaling): the finishing and
-    BatchNorm launches of a hidden stage merged PAIRWISE (midstage_f32.hip: slab sum + bias + chunk statistics;
-    statistics merge + BatchNorm / ReLU / dropout; opt-in BLH_MID_PAIR=1 BLH_MID_PAIR_APPLY=1 — measured no faster
-    than the launches they replace, profiles/r05_mid_pair.md) use the multi-launch path's arithmetic in its order, so
-    every tensor the step writes is bit-identical to the default path: predictions, gradients, running statistics, counters
-    of the drop-in step, and loss / parameters / Adam state after two fused steps (Philox dropout; ragged 777 and 400:
-    partial statistics chunks and row groups; 1536 / 2048: the 64-row-tile GEMMs without split-K).
-    (/root/reference/model/bilinear.py:7-13,31-41; train_bilinear.py:75-83.)"""
-    import os
-
-    import bilinear_amd
-    dev = _dev()
-    x = torch.randn(batch, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
-    t = torch.randn(batch, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
-    out = {}
-    for fused in (True, False):
-        if fused:
-            os.environ["BLH_MID_PAIR"] = "1"
-            os.environ["BLH_MID_PAIR_APPLY"] = "1"
-        try:
-            torch.manual_seed(0)
-            net, opt, _, _ = bilinear_amd.load(dev, num_blocks=nb, width=width, gemm_dtype="fp32")
-            net.train()
-            net.engine.ensure(dev)
-            opt.zero_grad()
-            pred = net(x)
-            torch.nn.functional.mse_loss(pred, t).backward()
-            torch.cuda.synchronize()
-            first = (pred.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()},
-                     net.engine.bn_running.clone(), net.engine.bn_nbt.clone())
-            for _ in range(2):
-                p2, loss = net.train_step(opt, x, t, max_norm=1.0)
-            torch.cuda.synchronize()
-            out[fused] = first + (p2.clone(), loss.clone(), net.engine.params.clone(), net.engine.bn_running.clone(),
-                                  opt._exp_avg.clone(), opt._exp_avg_sq.clone())
-        finally:
-            os.environ.pop("BLH_MID_PAIR", None)
-            os.environ.pop("BLH_MID_PAIR_APPLY", None)
-    a, b = out[True], out[False]
-    assert torch.equal(a[0], b[0]), "predictions"
-    for k in a[1]:
-        assert torch.equal(a[1][k], b[1][k]), k
-    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and int(a[3][1]) == 1
-    assert torch.equal(a[4], b[4]) and torch.equal(a[5], b[5]), "fused step: prediction / loss"
-    for i in (6, 7, 8, 9):
-        assert torch.equal(a[i], b[i]), i

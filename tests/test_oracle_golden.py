@@ -133,3 +133,22 @@ def test_lr_decay_schedule():
     assert O.lr_decay_condition(1) and O.lr_decay_condition(200000)
     assert not O.lr_decay_condition(2) and not O.lr_decay_condition(99999)
     assert abs(O.lr_decay_function(100000) - 0.96e-3) < 1e-18
+
+
+def test_fast_bf16_rounding_is_bit_identical_to_its_defining_form():
+    """oracle.numpy_oracle.round_bf16 (32-bit arithmetic, chunks on a thread pool, transposed views rounded through
+    their base) against _round_bf16_reference (the 64-bit form it replaced) on random patterns, special values, both
+    dtypes, contiguous and transposed operands, below and above the chunk size."""
+    from oracle import numpy_oracle as O
+    rng = np.random.RandomState(0)
+    for dt, ut in ((np.float32, np.uint32), (np.float64, np.uint64)):
+        a = (rng.standard_normal((2100, 1031)) * np.exp(5 * rng.standard_normal((2100, 1031)))).astype(dt)
+        sp = np.array([0.0, -0.0, np.inf, -np.inf, 1e-45, -1e-45, 3.4e38, -3.4e38, 1.0039062, 1.0117188, 65504.0], dt)
+        a.reshape(-1)[:sp.size] = sp
+        bits = rng.randint(0, 2 ** 32, size=50000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+        bits = bits[np.isfinite(bits)].astype(dt)
+        for arr in (a, a.T, a[:7], bits, sp):
+            got, want = O.round_bf16(arr), O._round_bf16_reference(arr)
+            assert got.dtype == arr.dtype and got.shape == arr.shape
+            assert np.array_equal(np.ascontiguousarray(got).view(ut), np.ascontiguousarray(want).view(ut))
+    assert np.isnan(O.round_bf16(np.array([np.nan], np.float32))[0])
