@@ -139,6 +139,8 @@ _SIGNATURES = {
     "blh_skinny_decode_fused_bf16": (c_int, [c_void_p] * 10 + [c_int64, c_int64, c_int32, c_int32]),
     "blh_skinny_encode_fused_fwd": (c_int, [c_void_p] * 9 + [c_float] + [c_void_p] * 5 + [c_int64, c_int32, c_int32]),
     "blh_skinny_encode_fused_bwd": (c_int, [c_void_p] * 12 + [c_int64, c_int32, c_int32]),
+    "blh_skinny_encode_fused_fwd_bf16": (c_int, [c_void_p] * 9 + [c_float] + [c_void_p] * 5 + [c_int64, c_int32, c_int32]),
+    "blh_skinny_encode_fused_bwd_bf16": (c_int, [c_void_p] * 12 + [c_int64, c_int32, c_int32]),
     "blh_skinny_decode_bwd": (c_int, [c_void_p] * 7 + [c_int64, c_int64, c_int32, c_int32]),
     "blh_skinny_encode_wgrad": (c_int, [c_void_p] * 5 + [c_int64, c_int64, c_int32, c_int32]),
     "blh_gemm_bf16s": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,

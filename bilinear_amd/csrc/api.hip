@@ -483,6 +483,9 @@ static int backward_unmerged(blh_context* ctx, const blh_model_desc* d, void* st
   if (fmt == blh_context::SAVED_SMALL) {
     // the activations in this workspace were saved by the small-batch forward: only its backward can read them
     if (from_loss || ctx->sync.fn) return BLH_ERR_INVALID_ARGUMENT;
+    // (the small-batch backward works IN the buffers it reads — x-hat, the gates: a second backward of the same
+    //  forward, e.g. retain_graph, would read its own output; it is refused instead)
+    ctx->note_saved(workspace, batch, blh_context::SAVED_NONE);
     SmallStepParams p;
     BLH_TRY(small_params(p, ctx, d, const_cast<float*>(params), grads, nullptr, nullptr, nullptr, nullptr, x, nullptr, drop,
                          0.f, nullptr, nullptr, ws, nullptr, nullptr, nullptr, batch, dpred));
@@ -1101,6 +1104,33 @@ int blh_skinny_encode_fused_bwd(void* stream, const float* dA, const float* x, c
   if (!enc_fused_supported(batch, width, in_features)) return BLH_ERR_SHAPE;
   return launch_enc_backward((hipStream_t)stream, dA, x, W0, b0, saved, keepbits, scratch, batch, width, dW0, dgamma,
                              dbeta, db0, 1, nullptr, nullptr);
+}
+
+int blh_skinny_encode_fused_fwd_bf16(void* stream, const uint16_t* x, const uint16_t* W0, const float* b0,
+                                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                     int64_t* nbt, float momentum, float* saved, uint16_t* scratch, uint16_t* A,
+                                     uint32_t* keepbits, const blh_dropout* drop, int64_t batch, int32_t width,
+                                     int32_t in_features) {
+  if (!x || !W0 || !b0 || !gamma || !beta || !running_mean || !running_var || !nbt || !saved || !scratch || !A ||
+      !keepbits || !drop || batch < 2)
+    return BLH_ERR_INVALID_ARGUMENT;
+  if (!enc_fused_supported_h(batch, width, in_features)) return BLH_ERR_SHAPE;
+  DropoutSrc d;
+  d.step_dev = nullptr; d.keep = drop->keep_mask; d.seed = drop->seed; d.step = drop->step;
+  d.row_offset = drop->row_offset; d.layer = drop->layer_base;
+  return launch_enc_forward_h((hipStream_t)stream, x, W0, b0, gamma, beta, running_mean, running_var, nbt, momentum,
+                              saved, scratch, A, keepbits, batch, width, d);
+}
+
+int blh_skinny_encode_fused_bwd_bf16(void* stream, const uint16_t* dA, const uint16_t* x, const uint16_t* W0,
+                                     const float* b0, const float* saved, const uint32_t* keepbits, uint16_t* scratch,
+                                     float* dW0, float* db0, float* dgamma, float* dbeta, int64_t batch, int32_t width,
+                                     int32_t in_features) {
+  if (!dA || !x || !W0 || !b0 || !saved || !keepbits || !scratch || !dW0 || !db0 || !dgamma || !dbeta || batch < 2)
+    return BLH_ERR_INVALID_ARGUMENT;
+  if (!enc_fused_supported_h(batch, width, in_features)) return BLH_ERR_SHAPE;
+  return launch_enc_backward_h((hipStream_t)stream, dA, x, W0, b0, saved, keepbits, scratch, batch, width, dW0, dgamma,
+                               dbeta, db0, 1);
 }
 
 int blh_skinny_decode_fused(void* stream, const float* A, const float* Wd, const float* bd,

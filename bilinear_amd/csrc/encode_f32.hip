@@ -27,6 +27,8 @@
 //     contraction index is the row (cdna_hip_programming.md 3, "An accumulator tile as the next MFMA's operand"):
 //     step reg contracts rows 4 q + reg; A operand = x^T (lane: feature 16 h + n, row 4 q + reg).  The result holds
 //     features 16 h + 4 q + reg' of column c0 + 4 n + jj: 16-byte stores into the [col][32] partial.
+#include <type_traits>
+
 #include "common.h"
 #include "philox.h"
 #include "bn_f32_dev.h"
@@ -66,22 +68,26 @@ __device__ __forceinline__ void enc_st4(enc_bf16* p, const float4& a) {
 
 static constexpr int ENC_IF = 32;                        // input features (16 joints x 2)
 static constexpr int ENC_XN = ENC_IF + ENC_IF * ENC_IF;  // colsum(x) | X^T X
-static constexpr int ENC_XBLOCKS = 64;                   // at most this many row blocks of enc_xstats
-static constexpr int ENC_XROWS = 256;                    // rows per block of enc_xstats (a multiple of 128)
+static constexpr int ENC_XBLOCKS = 32;                   // at most this many row blocks of enc_xstats: every block of
+                                                         // enc_bn_finalize adds them all, 16 per round trip (64 at
+                                                         // B = 16384 were four rounds: 12.8 us against 6 at B = 4096)
+static constexpr int ENC_XWAVES = 4;                     // waves per block of enc_xstats
+static constexpr int ENC_XROWS = 64 * ENC_XWAVES;        // rows per block of enc_xstats: a multiple of this (two rounds of
+                                                         // 32 rows per wave, requested together)
 
 // ---- x statistics -------------------------------------------------------------------------------------------
 // Moments of y = x - c with c = row 0 of the batch (the shifted-data form: the variance below is a difference of
 // second moments, and moments of the raw x lose log2(1 + mean^2 / var) bits to that difference — inputs that are not
 // standardised would pay for it; any row of the batch is within a few standard deviations of the mean):
 // xpart[b][0 .. 31] = sum_r y[r][f], xpart[b][32 + a * 32 + c] = sum_r y[r][a] y[r][c] over the block's rows (fp32
-// sums over at most a few hundred rows; the partials are added in fp64).  Y^T Y on the matrix
+// sums over at most a few hundred rows per wave; the partials are added in fp64).  Y^T Y on the matrix
 // cores: per 4 rows both operands are the same registers — A = x^T (lane: feature n + 16 h, row 4 s + q), B = x
-// (lane: row 4 s + q, feature n + 16 h') — 4 MFMAs per 4 rows.  (The first form used fp64 vector FMAs from an LDS
-// copy, four dependent staging rounds per block: 21-28 us.)
+// (lane: row 4 s + q, feature n + 16 h') — 4 MFMAs per 4 rows.  (Sixteen waves per block and at most 16 blocks — so
+// that the finalize kernel had one round of partials — measured 7-12 us against 5: r06, profiles/r06_encode.md.)
 template <typename TX>
-__global__ __launch_bounds__(256) void enc_xstats_kernel(const TX* __restrict__ x, int64_t batch, int rows_per_block,
-                                                         float* __restrict__ xpart) {
-  __shared__ float red[4][ENC_XN];
+__global__ __launch_bounds__(64 * ENC_XWAVES) void enc_xstats_kernel(const TX* __restrict__ x, int64_t batch,
+                                                                     int rows_per_block, float* __restrict__ xpart) {
+  __shared__ float red[ENC_XWAVES][ENC_XN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
@@ -90,30 +96,37 @@ __global__ __launch_bounds__(256) void enc_xstats_kernel(const TX* __restrict__ 
   acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = encf4{0.f, 0.f, 0.f, 0.f};
   float cs0 = 0.f, cs1 = 0.f;
   const float c0 = enc_ld1(x + n), c1 = enc_ld1(x + 16 + n);          // the shift: row 0
-  for (int64_t base = r0 + 32 * wave; base < r1; base += 128) {      // 8 steps of 4 rows per round, all loads first
-    float xv[8][2];
+  // rounds of 8 steps of 4 rows, TWO rounds per trip with all their loads first (the launch plans at most two rounds
+  // per wave up to 16384 rows: one memory round trip for the whole kernel)
+  for (int64_t base = r0 + 64 * wave; base < r1; base += ENC_XROWS) {
+    float xv[2][8][2];
 #pragma unroll
-    for (int st = 0; st < 8; ++st) {
-      const int64_t row = base + 4 * st + q;
-      const TX* xr = x + min(row, batch - 1) * ENC_IF + n;
-      const bool ok = row < r1;
-      // (unconditional loads — the row is clamped — and a select afterwards: a load under a lane mask compiles to
-      //  branch + load + full wait, sixteen dependent round trips here: 8.7 instead of 5 us)
-      const float v0 = enc_ld1(xr), v1 = enc_ld1(xr + 16);
-      xv[st][0] = ok ? v0 : c0;
-      xv[st][1] = ok ? v1 : c1;
-    }
+    for (int rd = 0; rd < 2; ++rd)
 #pragma unroll
-    for (int st = 0; st < 8; ++st) { xv[st][0] -= c0; xv[st][1] -= c1; }
+      for (int st = 0; st < 8; ++st) {
+        // (unconditional loads — the row is clamped — and a select afterwards: a load under a lane mask compiles to
+        //  branch + load + full wait, sixteen dependent round trips: 8.7 instead of 5 us)
+        const TX* xr = x + min(base + 32 * rd + 4 * st + q, batch - 1) * ENC_IF + n;
+        xv[rd][st][0] = enc_ld1(xr);
+        xv[rd][st][1] = enc_ld1(xr + 16);
+      }
+    // (nothing below may move above this line: left to itself the scheduler sinks each load to its use and waits for
+    //  it there — 32 dependent round trips, 12 us)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int st = 0; st < 8; ++st) {
-      cs0 += xv[st][0]; cs1 += xv[st][1];
+    for (int rd = 0; rd < 2; ++rd)
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int st = 0; st < 8; ++st) {
+        const bool ok = base + 32 * rd + 4 * st + q < r1;
+        const float y0 = ok ? xv[rd][st][0] - c0 : 0.f, y1 = ok ? xv[rd][st][1] - c1 : 0.f;
+        const float yy[2] = {y0, y1};
+        cs0 += y0; cs1 += y1;
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2)
-          acc[h][h2] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[st][h], xv[st][h2], acc[h][h2], 0, 0, 0);
-    }
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2)
+            acc[h][h2] = __builtin_amdgcn_mfma_f32_16x16x4f32(yy[h], yy[h2], acc[h][h2], 0, 0, 0);
+      }
   }
   cs0 += __shfl_xor(cs0, 16); cs0 += __shfl_xor(cs0, 32);
   cs1 += __shfl_xor(cs1, 16); cs1 += __shfl_xor(cs1, 32);
@@ -266,6 +279,32 @@ __device__ __forceinline__ void enc_z_tile(encf4 (&zt)[CPL], const EncCols<CPL>&
     zt[jj] = a;
   }
 }
+__device__ __forceinline__ void enc_ld_f8(const float* p, float (&f)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+__device__ __forceinline__ uint32_t enc_pack2(float lo, float hi) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  const bf2 b = {(__bf16)lo, (__bf16)hi};          // v_cvt_pk_bf16_f32: RNE
+  return *reinterpret_cast<const uint32_t*>(&b);
+}
+// the same from x operands already in registers
+template <int CPL>
+__device__ __forceinline__ void enc_z_tile_x(encf4 (&zt)[CPL], const EncCols<CPL>& c, const float4& xa0, const float4& xa1) {
+#pragma unroll
+  for (int jj = 0; jj < CPL; ++jj) {
+    encf4 a = encf4{0.f, 0.f, 0.f, 0.f};
+    a = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0.x, c.wb[jj][0].x, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0.y, c.wb[jj][0].y, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0.z, c.wb[jj][0].z, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x4f32(xa0.w, c.wb[jj][0].w, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x4f32(xa1.x, c.wb[jj][1].x, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x4f32(xa1.y, c.wb[jj][1].y, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x4f32(xa1.z, c.wb[jj][1].z, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x4f32(xa1.w, c.wb[jj][1].w, a, 0, 0, 0);
+    zt[jj] = a;
+  }
+}
 // CPL values of one row, 16 bytes: a float4 (fp32 storage) or 8 bf16 (bf16 storage)
 __device__ __forceinline__ void enc_st_row(float* p, const float (&a)[4]) {
   *reinterpret_cast<float4*>(p) = make_float4(a[0], a[1], a[2], a[3]);
@@ -292,85 +331,216 @@ __device__ __forceinline__ void enc_ld_row(const enc_bf16* p, float (&a)[8]) {
 }
 
 // ---- forward: x -> A0 (+ keep bits) ----------------------------------------------------------------------------
-// block = 4 waves x 16 CPL columns; the block's rows [blockIdx.y * rows_per_block, ...) in 16-row tiles.
+// block = 4 waves x 16 CPL columns, ONE 32-row Philox patch of rows (two 16-row tiles).  Blocks are numbered so that
+// the column blocks of one row block sit on the same XCD (the hardware deals consecutive workgroup ids round-robin
+// over the 8 XCDs): x — re-read by every column block — then comes from HBM once, not once per XCD L2 (PMC, r05:
+// 1.20 x the algorithmic bytes in the forward, 1.48 x in the backward, most of it these re-reads).
+//   id -> xcd = id & 7, slot = id >> 3, column block cb = slot % ncb, row block rb = 8 (slot / ncb) + xcd
+__device__ __forceinline__ bool enc_block(int ncb, int64_t nrb, int& cb, int64_t& rb) {
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  cb = slot % ncb;
+  rb = (int64_t)(slot / ncb) * 8 + xcd;
+  return rb < nrb;
+}
+static unsigned enc_grid(int ncb, int64_t nrb) { return (unsigned)(ncb * round_up(nrb, 8)); }
+
 // Keep-bit words: fp32 storage [B/8][W/4] (nibble j = row 8 g + j, bit c = column 4 (col/4) + c: bn_f32.hip) — a lane's
-// 4 rows x 4 columns are half a word, the other half is lane l ^ 16; bf16 storage [B/4][W/8] (byte j = row 4 g + j,
-// bit c = column 8 (col/8) + c: bn_bf16.hip) — a lane's 4 rows x 8 columns are exactly one word.
-template <bool H>
-__global__ __launch_bounds__(256) void enc_fwd_kernel(const typename EncT<H>::T* __restrict__ x,
-                                                      const typename EncT<H>::T* __restrict__ W0,
+// 4 rows x 4 columns are half a word, the other half is lane l ^ 16.
+__global__ __launch_bounds__(256) void enc_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W0,
                                                       const float* __restrict__ b0, const float* __restrict__ scale,
-                                                      const float* __restrict__ shift,
-                                                      typename EncT<H>::T* __restrict__ A,
-                                                      uint32_t* __restrict__ keepbits, int64_t batch, int W,
-                                                      int rows_per_block, DropoutSrc drop, int64_t* nbt) {
-  constexpr int CPL = H ? 8 : 4;
+                                                      const float* __restrict__ shift, float* __restrict__ A,
+                                                      uint32_t* __restrict__ keepbits, int64_t batch, int W, int ncb,
+                                                      DropoutSrc drop, int64_t* nbt) {
+  constexpr int CPL = 4;
+  int cb; int64_t rb;
+  if (!enc_block(ncb, (batch + 31) >> 5, cb, rb)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
-  const int col = (blockIdx.x * 4 + wave) * (16 * CPL) + CPL * n;
-  if (nbt && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) nbt[0] += 1;
+  const int col = (cb * 4 + wave) * (16 * CPL) + CPL * n;
+  if (nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;
   EncCols<CPL> c;
   enc_load_cols<CPL>(c, W0, b0, scale, shift, col, q);
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;      // a multiple of 32
-  const int64_t r1 = min(batch, r0 + rows_per_block);
-  for (int64_t base = r0; base < r1; base += 16) {
-    encf4 zt[CPL];
-    enc_z_tile<CPL>(zt, c, x, base, batch, n, q);
-    // Philox / mask bits of the 8-row group this lane's rows belong to (nibble 4 (q & 1) + reg = row base + 4 q + reg),
-    // one word per 4 columns
-    const int64_t rg = base + 8 * (q >> 1);
-    uint32_t kw[CPL / 4];
 #pragma unroll
-    for (int w4 = 0; w4 < CPL / 4; ++w4)
-      kw[w4] = f2_keep_word(drop, base & ~(int64_t)31, (int)((rg >> 3) & 3), col + 4 * w4, W, batch);
-    uint32_t word = 0;            // keep AND [y > 0]: fp32: nibble reg of this lane's half word; bf16: byte reg
+  for (int jj = 0; jj < CPL; ++jj) { c.sc[jj] *= 2.f; c.sh[jj] *= 2.f; }      // a = 2 y: exact, folded into the FMA
+  const int64_t r0 = rb * 32;
+  // both tiles' x rows are requested before the first MFMA
+  float4 xa[2][2];
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int64_t row = base + 4 * q + reg;
-      uint32_t keep = 0, gate = 0;
-      float a[CPL];
+  for (int t = 0; t < 2; ++t) {
+    const float* xr = x + min(r0 + 16 * t + n, batch - 1) * ENC_IF + 4 * q;
+    xa[t][0] = enc_ld4(xr); xa[t][1] = enc_ld4(xr + 16);
+  }
+  // FULL: every row of the block exists (all blocks but the last of a ragged batch): no per-row predicates
+  auto tiles = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-      for (int jj = 0; jj < CPL; ++jj) {
-        float z = zt[jj][reg] + c.bias[jj];
-        if (H) z = enc_round_bf16(z);
-        const float y = fmaxf(fmaf(z, c.sc[jj], c.sh[jj]), 0.f);
-        const uint32_t k = (kw[jj >> 2] >> (4 * (4 * (q & 1) + reg) + (jj & 3))) & 1u;
-        keep |= k << jj;
-        gate |= (y > 0.f ? 1u : 0u) << jj;
-        a[jj] = k ? y * 2.f : 0.f;
+    for (int t = 0; t < 2; ++t) {
+      const int64_t base = r0 + 16 * t;
+      if (!FULL && base >= batch) break;
+      encf4 zt[CPL];
+      enc_z_tile_x<CPL>(zt, c, xa[t][0], xa[t][1]);
+      // Philox / mask bits of the 8-row group this lane's rows belong to (nibble 4 (q & 1) + reg = row base + 4 q + reg),
+      // one word per 4 columns
+      const int64_t rg = base + 8 * (q >> 1);
+      const uint32_t kw = f2_keep_word(drop, r0, 2 * t + (q >> 1), col, W, batch) >> (16 * (q & 1));
+      uint32_t word = 0;            // keep AND [y > 0]: nibble reg of this lane's half word
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int64_t row = base + 4 * q + reg;
+        float a[CPL];
+        uint32_t bits = 0;
+#pragma unroll
+        for (int jj = 0; jj < CPL; ++jj) {
+          const float z = zt[jj][reg] + c.bias[jj];
+          const float y2 = fmaxf(fmaf(z, c.sc[jj], c.sh[jj]), 0.f);      // (scale and shift carry dropout's factor 2)
+          const uint32_t av = __float_as_uint(y2) & (uint32_t)__builtin_amdgcn_sbfe(kw, 4 * reg + jj, 1);
+          a[jj] = __uint_as_float(av);
+          bits |= min(av, 1u) << jj;                                     // keep AND [y > 0] = [a != 0]
+        }
+        word |= bits << (CPL * reg);
+        if (FULL || row < batch) enc_st_row(A + row * W + col, a);
       }
-      word |= (keep & gate) << (CPL * reg);
-      if (row < batch) enc_st_row(A + row * W + col, a);
-    }
-    if (!H) {
       const uint32_t full = (word << (16 * (q & 1))) | (__shfl_xor(word, 16) << (16 * ((q & 1) ^ 1)));
-      if ((q & 1) == 0 && rg < batch) keepbits[(rg >> 3) * (W >> 2) + (col >> 2)] = full;
-    } else {
-      const int64_t rg4 = base + 4 * q;
-      if (rg4 < batch) keepbits[(rg4 >> 2) * (W >> 3) + (col >> 3)] = word;
+      if ((q & 1) == 0 && (FULL || rg < batch)) keepbits[(rg >> 3) * (W >> 2) + (col >> 2)] = full;
+    }
+  };
+  if (r0 + 32 <= batch) tiles(std::true_type{});
+  else tiles(std::false_type{});
+}
+
+// bf16 storage (gemm_dtype 4).  A lane owns 8 consecutive columns (16 bytes per row); z comes from ONE
+// v_mfma_f32_16x16x32_bf16 per 16 rows x 16 columns (K = 32 is the whole contraction: A operand = 8 bf16 of an x row,
+// B operand = 8 bf16 of a W0 row — the products are the exact products of the stored values, summed in fp32, which is
+// what the bf16 GEMM of the materialised path computes; the first form ran eight exact-fp32 MFMAs per tile on the
+// converted values: 16 x the matrix-pipe cycles, 30 us at B = 16384 with one workgroup per CU).  MFMA group jj produces
+// columns col + jj of the lane (B operand = W0 row c0 + 8 n + jj), so acc[jj][reg] are rows 4 q + reg x the lane's 8
+// columns.  z is rounded to bf16 before BatchNorm normalises it (the stored Z of the GEMM path is what bn_apply_h2
+// reads).  Keep bits [B/4][W/8] (byte j = row 4 g + j, bit c = column 8 (col/8) + c: bn_bf16.hip): a lane's 4 rows x 8
+// columns are exactly one word; the stage stores keep AND [y > 0] (= [a != 0]: a = keep ? 2 y : 0 with y >= 0).
+// The block of column block 0 also leaves xT[feature][row] (zero beyond the batch), the K-major image of x the
+// backward's MFMAs want as their A operand.
+typedef __bf16 enc_bf16x8 __attribute__((ext_vector_type(8)));
+union EncFrag { uint4 u; enc_bf16x8 v; };
+
+__global__ __launch_bounds__(256) void enc_fwd_h_kernel(const enc_bf16* __restrict__ x, const enc_bf16* __restrict__ W0,
+                                                        const float* __restrict__ b0, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, enc_bf16* __restrict__ A,
+                                                        uint32_t* __restrict__ keepbits, enc_bf16* __restrict__ xT,
+                                                        int64_t xt_ld, int64_t batch, int W, int ncb, DropoutSrc drop,
+                                                        int64_t* nbt) {
+  int cb; int64_t rb;
+  if (!enc_block(ncb, (batch + 31) >> 5, cb, rb)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int col = (cb * 4 + wave) * 128 + 8 * n;
+  if (nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;
+  const int64_t base = rb * 32;
+  // operands: both tiles' x rows, the eight W0 rows of the lane's columns
+  EncFrag xa[2], wb[8];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+    xa[t].u = *reinterpret_cast<const uint4*>(x + min(base + 16 * t + n, batch - 1) * ENC_IF + 8 * q);
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) wb[jj].u = *reinterpret_cast<const uint4*>(W0 + (int64_t)(col + jj) * ENC_IF + 8 * q);
+  float bias[8], sc2[8], sh2[8];
+  enc_ld_f8(b0 + col, bias);
+  enc_ld_f8(scale + col, sc2);
+  enc_ld_f8(shift + col, sh2);
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) { sc2[jj] *= 2.f; sh2[jj] *= 2.f; }      // a = 2 y: exact, folded into the FMA
+  // dropout: the block is one 32-row patch of rows; the lane's columns are two 4-column patches
+  Philox128 p0{}, p1{};
+  if (!drop.keep) {
+    p0 = dropout_patch(drop.seed, dropout_step(drop), drop.layer, base + drop.row_offset, col);
+    p1 = dropout_patch(drop.seed, dropout_step(drop), drop.layer, base + drop.row_offset, col + 4);
+  }
+  if (cb == 0 && wave == 0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int64_t row = base + 16 * t + n;
+      const uint32_t w[4] = {xa[t].u.x, xa[t].u.y, xa[t].u.z, xa[t].u.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t v = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xFFFFu);
+        xT[(int64_t)(8 * q + e) * xt_ld + row] = row < batch ? (enc_bf16)v : (enc_bf16)0;
+      }
     }
   }
+  // FULL: every row of the block exists (all blocks but the last of a ragged batch): no per-row predicates
+  auto tiles = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      encf4 acc[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj)
+        acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[t].v, wb[jj].v, encf4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      // keep words of the 8-row group the lane's rows belong to: word 2 t + (q >> 1) of the patch
+      uint32_t kw0, kw1;
+      if (drop.keep) {
+        kw0 = f2_keep_word(drop, base, 2 * t + (q >> 1), col, W, batch);
+        kw1 = f2_keep_word(drop, base, 2 * t + (q >> 1), col + 4, W, batch);
+      } else {
+        kw0 = (q >> 1) ? p0.w[2 * t + 1] : p0.w[2 * t];
+        kw1 = (q >> 1) ? p1.w[2 * t + 1] : p1.w[2 * t];
+      }
+      // the lane's 16 + 16 keep bits: nibble reg of each
+      kw0 >>= 16 * (q & 1); kw1 >>= 16 * (q & 1);
+      uint32_t word = 0;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int64_t row = base + 16 * t + 4 * q + reg;
+        const uint32_t kb = ((kw0 >> (4 * reg)) & 0xFu) | (((kw1 >> (4 * reg)) & 0xFu) << 4);   // keep bits of the row's 8 columns
+        float a[8];
+        uint32_t rowbits = 0;
+#pragma unroll
+        for (int jj = 0; jj < 8; jj += 2) {
+          // (two columns at a time: one v_cvt_pk_bf16_f32 rounds both)
+          const uint32_t zz = enc_pack2(acc[jj][reg] + bias[jj], acc[jj + 1][reg] + bias[jj + 1]);
+          const float z0 = __uint_as_float(zz << 16), z1 = __uint_as_float(zz & 0xffff0000u);
+          const float y0 = fmaxf(fmaf(z0, sc2[jj], sh2[jj]), 0.f), y1 = fmaxf(fmaf(z1, sc2[jj + 1], sh2[jj + 1]), 0.f);
+          const int m0 = __builtin_amdgcn_sbfe(kb, jj, 1), m1 = __builtin_amdgcn_sbfe(kb, jj + 1, 1);      // 0 or ~0
+          const uint32_t a0 = __float_as_uint(y0) & (uint32_t)m0, a1 = __float_as_uint(y1) & (uint32_t)m1;
+          a[jj] = __uint_as_float(a0); a[jj + 1] = __uint_as_float(a1);
+          rowbits |= (min(a0, 1u) << jj) | (min(a1, 1u) << (jj + 1));
+        }
+        if (FULL || row < batch) {
+          enc_st_row(A + row * W + col, a);
+          word |= rowbits << (8 * reg);
+        }
+      }
+      const int64_t rg4 = base + 16 * t + 4 * q;
+      if (FULL || rg4 < batch) keepbits[(rg4 >> 2) * (W >> 3) + (col >> 3)] = word;
+    }
+  };
+  if (base + 32 <= batch) tiles(std::true_type{});
+  else tiles(std::false_type{});
 }
 
 // ---- backward: dA0 -> S2 = sum dY' and P = dY'^T X, partials per row block ------------------------------------------
-// block = 4 waves on the SAME 16 CPL columns, wave w takes the 16-row tiles w, w + 4, ... of the block's rows
-template <bool H>
-__global__ __launch_bounds__(256) void enc_bwd_kernel(const typename EncT<H>::T* __restrict__ dA,
-                                                      const typename EncT<H>::T* __restrict__ x,
-                                                      const uint32_t* __restrict__ gatebits, float* __restrict__ s2part,
-                                                      float* __restrict__ ppart, int64_t batch, int W,
-                                                      int rows_per_block) {
-  constexpr int CPL = H ? 8 : 4, BC = 16 * CPL;
+// block = NW waves on the SAME 16 CPL columns, wave w takes the tiles w, w + NW, ... of the block's rows; blocks are
+// numbered as in the forward (the column blocks of a row block on one XCD: x comes from HBM once).  The partials cost
+// 2 x 33 floats per column and row block (written here, read by the finish kernel): rows_per_block is as large as the
+// launch still fills the chip with (host side: enc_bwd_plan) — at 128 rows per block they were half of the kernel's
+// traffic (PMC r05: 1.48 x its algorithmic bytes, 1.76 x with the finish kernel).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void enc_bwd_kernel(const float* __restrict__ dA, const float* __restrict__ x,
+                                                          const uint32_t* __restrict__ gatebits,
+                                                          float* __restrict__ s2part, float* __restrict__ ppart,
+                                                          int64_t batch, int W, int rows_per_block, int ncb, int nrb) {
+  constexpr int CPL = 4, BC = 16 * CPL;
   __builtin_amdgcn_s_setprio(3);
-  // 9 KiB of LDS (fp32 storage): the kernel has to fit BESIDE a workgroup of the side stream's weight-gradient GEMM
+  // 9 KiB of LDS: the kernel has to fit BESIDE a workgroup of the side stream's weight-gradient GEMM
   // (128 KiB of the CU's 160) — with a 32 KiB buffer per block its workgroups waited for the GEMM's to retire: 75 us
   __shared__ __attribute__((aligned(16))) float red[BC * ENC_IF];        // [columns][32 features], waves add in turn
-  __shared__ float sred[4][BC];
+  __shared__ float sred[NW][BC];
+  int cb; int64_t rb;
+  if (!enc_block(ncb, nrb, cb, rb)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
-  const int c0 = blockIdx.x * BC;
+  const int c0 = cb * BC;
   const int col = c0 + CPL * n;
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r0 = rb * rows_per_block;
   const int64_t r1 = min(batch, r0 + rows_per_block);
   encf4 pacc[CPL][2];
 #pragma unroll
@@ -378,56 +548,60 @@ __global__ __launch_bounds__(256) void enc_bwd_kernel(const typename EncT<H>::T*
   float s2[CPL];
 #pragma unroll
   for (int jj = 0; jj < CPL; ++jj) s2[jj] = 0.f;
-  for (int64_t base = r0 + 16 * wave; base < r1; base += 64) {
-    float g[4][CPL];
+  // one 16-row tile: the lane's 4 rows x 4 columns of dA0, its half keep-and-gate word, the x^T operand
+  struct Tile { float g[4][CPL]; uint32_t bits; float xt[4][2]; };
+  auto load = [&](int64_t base) {
+    Tile t;
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) enc_ld_row(dA + min(base + 4 * q + reg, batch - 1) * W + col, g[reg]);
-    // this lane's keep-and-gate bits: CPL bits per row at bit CPL * reg
-    uint32_t bits = 0;
-    if (!H) {
-      const int64_t rg = base + 8 * (q >> 1);
-      const uint32_t kw = rg < batch ? gatebits[(rg >> 3) * (W >> 2) + (col >> 2)] : 0u;
-      bits = (kw >> (16 * (q & 1))) & 0xFFFFu;
-    } else {
-      const int64_t rg4 = base + 4 * q;
-      bits = rg4 < batch ? gatebits[(rg4 >> 2) * (W >> 3) + (col >> 3)] : 0u;
+    for (int reg = 0; reg < 4; ++reg) enc_ld_row(dA + min(base + 4 * q + reg, batch - 1) * W + col, t.g[reg]);
+    const int64_t rg = base + 8 * (q >> 1);
+    const uint32_t kw = rg < batch ? gatebits[(rg >> 3) * (W >> 2) + (col >> 2)] : 0u;
+    t.bits = (kw >> (16 * (q & 1))) & 0xFFFFu;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {      // feature 16 h + n of row base + 4 q + reg
+      const float* xr = x + min(base + 4 * q + reg, batch - 1) * ENC_IF + n;
+      t.xt[reg][0] = xr[0]; t.xt[reg][1] = xr[16];
     }
-    // x^T operand: feature 16 h + n of row base + 4 q + reg
-    float xt[4][2];
+    return t;
+  };
+  int64_t base = r0 + 16 * wave;
+  if (base < r1) {
+    Tile cur = load(base);
+    for (; base < r1; base += 16 * NW) {
+      // (the next tile is requested before this one's 32 MFMAs: one memory round trip per tile was the kernel's time)
+      const int64_t nb = base + 16 * NW;
+      Tile nxt = load(nb < r1 ? nb : base);
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const typename EncT<H>::T* xr = x + min(base + 4 * q + reg, batch - 1) * ENC_IF + n;
-      xt[reg][0] = enc_ld1(xr); xt[reg][1] = enc_ld1(xr + 16);
-    }
+      for (int reg = 0; reg < 4; ++reg) {
+        const uint32_t rbits = (base + 4 * q + reg < batch) ? (cur.bits >> (CPL * reg)) : 0u;
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const uint32_t rb = (base + 4 * q + reg < batch) ? (bits >> (CPL * reg)) : 0u;
-#pragma unroll
-      for (int jj = 0; jj < CPL; ++jj) {
-        const float dy = ((rb >> jj) & 1u) ? g[reg][jj] * 2.f : 0.f;     // dY' = 2 keep [y > 0] dA
-        s2[jj] += dy;
-        g[reg][jj] = dy;
+        for (int jj = 0; jj < CPL; ++jj) {
+          const float dy = ((rbits >> jj) & 1u) ? cur.g[reg][jj] * 2.f : 0.f;     // dY' = 2 keep [y > 0] dA
+          s2[jj] += dy;
+          cur.g[reg][jj] = dy;
+        }
       }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+        for (int jj = 0; jj < CPL; ++jj) {
+          pacc[jj][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.xt[reg][0], cur.g[reg][jj], pacc[jj][0], 0, 0, 0);
+          pacc[jj][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.xt[reg][1], cur.g[reg][jj], pacc[jj][1], 0, 0, 0);
+        }
+      cur = nxt;
     }
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg)
-#pragma unroll
-      for (int jj = 0; jj < CPL; ++jj) {
-        pacc[jj][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[reg][0], g[reg][jj], pacc[jj][0], 0, 0, 0);
-        pacc[jj][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[reg][1], g[reg][jj], pacc[jj][1], 0, 0, 0);
-      }
   }
-  // column sums over the lane groups q (rows), then over the four waves
+  // column sums over the lane groups q (rows), then over the waves
 #pragma unroll
   for (int jj = 0; jj < CPL; ++jj) {
     s2[jj] += __shfl_xor(s2[jj], 16);
     s2[jj] += __shfl_xor(s2[jj], 32);
     if (q == 0) sred[wave][CPL * n + jj] = s2[jj];
   }
-  // pacc[jj][h][reg'] = (dY'^T X)[column col + jj][feature 16 h + 4 q + reg']: the four waves add their tiles
-  // into one LDS image in a fixed order (every lane owns the same float4s of it in each wave)
+  // pacc[jj][h][reg'] = (dY'^T X)[column col + jj][feature 16 h + 4 q + reg']: the waves add their tiles into one
+  // LDS image in a fixed order (every lane owns the same float4s of it in each wave)
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < NW; ++w) {
     if (wave == w) {
 #pragma unroll
       for (int jj = 0; jj < CPL; ++jj)
@@ -442,18 +616,140 @@ __global__ __launch_bounds__(256) void enc_bwd_kernel(const typename EncT<H>::T*
     __syncthreads();
   }
   const int t = threadIdx.x;
-  if (t < BC) s2part[(int64_t)blockIdx.y * W + c0 + t] = (sred[0][t] + sred[1][t]) + (sred[2][t] + sred[3][t]);
-  float* pp = ppart + ((int64_t)blockIdx.y * W + c0) * ENC_IF;
-  for (int e = t; e < BC * ENC_IF / 4; e += 256)
+  if (t < BC) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += sred[w][t];
+    s2part[rb * W + c0 + t] = v;
+  }
+  float* pp = ppart + (rb * W + c0) * ENC_IF;
+  for (int e = t; e < BC * ENC_IF / 4; e += 64 * NW)
+    *reinterpret_cast<float4*>(pp + 4 * e) = *reinterpret_cast<const float4*>(&red[4 * e]);
+}
+
+// bf16 storage.  The contraction P = dY'^T X runs over the ROWS, 32 of them per v_mfma_f32_16x16x32_bf16: B operand =
+// 8 rows of one column (k = 8 q + j), A operand = 8 rows of one feature of x — the K-major image xT[feature][row] the
+// forward left (16 bytes per lane).  A lane loads rows 8 q .. 8 q + 7 x its 8 columns (eight 16-byte loads), gates them
+// with the stage's keep-and-gate bits (v_pk_mul_lo_u16 by 0 / 1 per half word), transposes the 8 x 8 block of 16-bit
+// values in its own registers (32 v_perm_b32) and feeds column jj's four registers to MFMA group jj.  dY' = 2 dA keep':
+// the factor 2 is applied to the accumulators at the end (exact).  S2 = sum dY' comes from a third MFMA per column
+// whose A operand is a row of ones (feature 32 of an augmented x): 24 MFMAs of 16 cycles per 32 rows x 128 columns,
+// where the first form issued 128 exact-fp32 MFMAs of 32 cycles on the converted values.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void enc_bwd_h_kernel(const enc_bf16* __restrict__ dA, const enc_bf16* __restrict__ xT,
+                                                            int64_t xt_ld, const uint32_t* __restrict__ gatebits,
+                                                            float* __restrict__ s2part, float* __restrict__ ppart,
+                                                            int64_t batch, int W, int rows_per_block, int ncb, int nrb) {
+  constexpr int BC = 128;
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ __attribute__((aligned(16))) float red[BC * ENC_IF];        // 16 KiB: [columns][32 features]
+  __shared__ float sred[NW][BC];
+  int cb; int64_t rb;
+  if (!enc_block(ncb, nrb, cb, rb)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int c0 = cb * BC;
+  const int col = c0 + 8 * n;
+  const int64_t r0 = rb * rows_per_block;                       // a multiple of 32
+  const int64_t r1 = min(batch, r0 + rows_per_block);
+  encf4 pacc[8][3];
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) pacc[jj][0] = pacc[jj][1] = pacc[jj][2] = encf4{0.f, 0.f, 0.f, 0.f};
+  EncFrag ones;
+  ones.u = (n == 0) ? make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u) : make_uint4(0, 0, 0, 0);
+  struct Tile { uint4 g[8]; uint32_t w0, w1; EncFrag xa[2]; };
+  auto load = [&](int64_t base) {
+    Tile t;
+    const int64_t rg = base + 8 * q;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t.g[j] = *reinterpret_cast<const uint4*>(dA + min(rg + j, batch - 1) * W + col);
+    // keep-and-gate words of rows rg .. rg + 3 and rg + 4 .. rg + 7 (the forward wrote zero bits beyond the batch)
+    t.w0 = rg < batch ? gatebits[(rg >> 2) * (W >> 3) + (col >> 3)] : 0u;
+    t.w1 = rg + 4 < batch ? gatebits[((rg >> 2) + 1) * (W >> 3) + (col >> 3)] : 0u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) t.xa[h].u = *reinterpret_cast<const uint4*>(xT + (int64_t)(16 * h + n) * xt_ld + rg);
+    return t;
+  };
+  int64_t base = r0 + 32 * wave;
+  if (base < r1) {
+    Tile cur = load(base);
+    for (; base < r1; base += 32 * NW) {
+      const int64_t nb = base + 32 * NW;
+      Tile nxt = load(nb < r1 ? nb : base);
+      // gate: row j's byte of the word -> 0 / 1 per 16-bit half of each of its four registers
+      uint32_t r[8][4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t byte = ((j < 4 ? cur.w0 : cur.w1) >> (8 * (j & 3))) & 0xFFu;
+        const uint32_t sp = byte | (byte << 15);                  // bit c at c (even c) and bit c at c + 15 (odd c)
+        const uint32_t gw[4] = {cur.g[j].x, cur.g[j].y, cur.g[j].z, cur.g[j].w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+          union { uint32_t u; u16x2 v; } a, m, o;
+          a.u = gw[d];
+          m.u = (sp >> (2 * d)) & 0x00010001u;
+          o.v = a.v * m.v;                                        // v_pk_mul_lo_u16
+          r[j][d] = o.u;
+        }
+      }
+      // transpose the lane's 8 rows x 8 columns: column c = 2 d + e -> its rows (0,1), (2,3), (4,5), (6,7)
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int d = jj >> 1;
+        const uint32_t sel = (jj & 1) ? 0x07060302u : 0x05040100u;
+        EncFrag b;
+        b.u.x = __builtin_amdgcn_perm(r[1][d], r[0][d], sel);
+        b.u.y = __builtin_amdgcn_perm(r[3][d], r[2][d], sel);
+        b.u.z = __builtin_amdgcn_perm(r[5][d], r[4][d], sel);
+        b.u.w = __builtin_amdgcn_perm(r[7][d], r[6][d], sel);
+        pacc[jj][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.xa[0].v, b.v, pacc[jj][0], 0, 0, 0);
+        pacc[jj][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.xa[1].v, b.v, pacc[jj][1], 0, 0, 0);
+        pacc[jj][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, b.v, pacc[jj][2], 0, 0, 0);
+      }
+      cur = nxt;
+    }
+  }
+  // S2: feature 32 = accumulator row 0 (q == 0, register 0) of the third group; dY' = 2 (gated dA)
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj)
+    if (q == 0) sred[wave][8 * n + jj] = 2.f * pacc[jj][2][0];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float4* dst = reinterpret_cast<float4*>(&red[(8 * n + jj) * ENC_IF + 16 * h + 4 * q]);
+          float4 v = make_float4(2.f * pacc[jj][h][0], 2.f * pacc[jj][h][1], 2.f * pacc[jj][h][2], 2.f * pacc[jj][h][3]);
+          if (w > 0) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+          *dst = v;
+        }
+    }
+    __syncthreads();
+  }
+  const int t = threadIdx.x;
+  if (t < BC) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += sred[w][t];
+    s2part[rb * W + c0 + t] = v;
+  }
+  float* pp = ppart + (rb * W + c0) * ENC_IF;
+  for (int e = t; e < BC * ENC_IF / 4; e += 64 * NW)
     *reinterpret_cast<float4*>(pp + 4 * e) = *reinterpret_cast<const float4*>(&red[4 * e]);
 }
 
 // ---- backward finish: dgamma, dbeta, dW0, db0 (+ the sums of squares of what it writes) ---------------------------
-// block = 16 columns x 32 features.  It runs beside the side stream's weight-gradient GEMM, where every vector
-// instruction waits for an issue slot the GEMM leaves: everything that does not depend on the gradient — z^T X, the
-// sum of z — was left by the forward (enc_bn_finalize); the first form computed it here and took 50 us.
+// block = 16 columns x 32 features x 2 halves of the row-block partials (1024 threads: each thread requests its share
+// of the partials in one round where 512 threads went round and round; the halves meet in LDS in a fixed order).  It
+// runs beside the side stream's weight-gradient GEMM, where every vector instruction waits for an issue slot the GEMM
+// leaves: everything that does not depend on the gradient — z^T X, the sum of z — was left by the forward
+// (enc_bn_finalize); the first form computed it here and took 50 us.
+static constexpr int ENC_FIN_MAXRB = 64;      // row blocks the finish kernel sums without a second round per thread
 template <typename TW>
-__global__ __launch_bounds__(512) void enc_bwd_finish_kernel(
+__global__ __launch_bounds__(1024) void enc_bwd_finish_kernel(
     const float* __restrict__ ppart, const float* __restrict__ s2part, int nrb, const float* __restrict__ xs,
     const float* __restrict__ ttab, const float* __restrict__ zs, const TW* __restrict__ W0,
     const float* __restrict__ b0, const float* __restrict__ saved, int64_t batch, int W, float* __restrict__ dW0,
@@ -461,26 +757,36 @@ __global__ __launch_bounds__(512) void enc_bwd_finish_kernel(
     double* __restrict__ sq_w, double* __restrict__ sq_gb) {
   __builtin_amdgcn_s_setprio(3);
   __shared__ double sqred[2][8];
-  const int t = threadIdx.x;
+  __shared__ double hP[512], hS[512];
+  const int half = threadIdx.x >> 9, t = threadIdx.x & 511;
   const int col = blockIdx.x * 16 + (t >> 5), f = t & 31;
-  double q2w = 0.0, q2g = 0.0;
-  if (col < W) {        // (whole 32-lane groups: the shuffles below stay inside a column)
-    const float wf = enc_ld1(W0 + (int64_t)col * ENC_IF + f), tf = ttab[(int64_t)col * ENC_IF + f], xf = xs[f];
-    const float bcol = b0[col], zsc = zs[col];
-    const float mean_f = saved[col], invstd_f = saved[W + col], scale_f = saved[2 * W + col];
-    double P = 0.0, S2 = 0.0;
-    for (int rb0 = 0; rb0 < nrb; rb0 += 16) {             // 2 x 16 loads in flight per round trip
+  const bool ok = col < W;        // (whole 32-lane groups: the shuffles below stay inside a column)
+  const int cc = ok ? col : 0;
+  // what does not depend on the partials is requested first
+  const float wf = enc_ld1(W0 + (int64_t)cc * ENC_IF + f), tf = ttab[(int64_t)cc * ENC_IF + f], xf = xs[f];
+  const float bcol = b0[cc], zsc = zs[cc];
+  const float mean_f = saved[cc], invstd_f = saved[W + cc], scale_f = saved[2 * W + cc];
+  double P = 0.0, S2 = 0.0;
+  {
+    const int per = (nrb + 1) >> 1, lo = half * per, hi = min(nrb, lo + per);
+    for (int rb0 = lo; rb0 < hi; rb0 += 16) {               // 2 x 16 loads in flight per round trip
       float v[16], u2[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int64_t rb = min(rb0 + u, nrb - 1);
-        v[u] = ppart[(rb * W + col) * ENC_IF + f];
-        u2[u] = s2part[rb * W + col];
+        v[u] = ppart[(rb * W + cc) * ENC_IF + f];
+        u2[u] = s2part[rb * W + cc];
       }
 #pragma unroll
       for (int u = 0; u < 16; ++u)
-        if (rb0 + u < nrb) { P += (double)v[u]; S2 += (double)u2[u]; }
+        if (rb0 + u < hi) { P += (double)v[u]; S2 += (double)u2[u]; }
     }
+  }
+  if (half == 1) { hP[t] = P; hS[t] = S2; }
+  __syncthreads();
+  double q2w = 0.0, q2g = 0.0;
+  if (half == 0 && ok) {
+    P += hP[t]; S2 += hS[t];
     const double B = (double)batch, b = (double)bcol;
     double s1 = (double)wf * P;                           // S1 = sum dY' z = W0[col] . P[col] + b0 S2
 #pragma unroll
@@ -501,67 +807,103 @@ __global__ __launch_bounds__(512) void enc_bwd_finish_kernel(
     }
   }
   // (db_rows: the stage's slot of the bias column-sum partials, [db_nrows][W]: row 0 carries db0, the others zero)
-  for (int r = 1 + (t >> 4); r < db_nrows; r += 32) {
-    const int cc = blockIdx.x * 16 + (t & 15);
-    if (cc < W) db_rows[(int64_t)r * W + cc] = 0.f;
+  for (int r = 1 + (threadIdx.x >> 4); r < db_nrows; r += 64) {
+    const int c16 = blockIdx.x * 16 + (threadIdx.x & 15);
+    if (c16 < W) db_rows[(int64_t)r * W + c16] = 0.f;
   }
   if (sq_w) {
+    if (half == 0) {
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { q2w += __shfl_xor(q2w, o); q2g += __shfl_xor(q2g, o); }
-    if ((t & 63) == 0) { sqred[0][t >> 6] = q2w; sqred[1][t >> 6] = q2g; }
+      for (int o = 32; o >= 1; o >>= 1) { q2w += __shfl_xor(q2w, o); q2g += __shfl_xor(q2g, o); }
+      if ((t & 63) == 0) { sqred[0][t >> 6] = q2w; sqred[1][t >> 6] = q2g; }
+    }
     __syncthreads();
-    if (t < 2) {
+    if (threadIdx.x < 2) {
       double tt = 0.0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) tt += sqred[t][k];
-      (t == 0 ? sq_w : sq_gb)[blockIdx.x] = tt;
+      for (int k = 0; k < 8; ++k) tt += sqred[threadIdx.x][k];
+      (threadIdx.x == 0 ? sq_w : sq_gb)[blockIdx.x] = tt;
     }
   }
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------
-// rows per block of enc_fwd / enc_bwd: whole 32-row Philox patches, at most 128 row blocks (the partials of
-// enc_bwd go where bn_bwd_reduce_f2's go: [ew_num_row_chunks][2][W])
-static int enc_fwd_rows(int64_t batch) { return (int)(32 * std::max<int64_t>(1, ceil_div(batch, 32 * 128))); }
-static int enc_bwd_rows(int64_t batch) { return (int)(128 * std::max<int64_t>(1, ceil_div(batch, 128 * 128))); }
-int enc_bwd_row_blocks(int64_t batch) { return (int)ceil_div(batch, enc_bwd_rows(batch)); }
+// Rows per block of enc_bwd: whole Philox patches (multiples of 128), as many as leave `min_wgs` workgroups in the
+// launch (the partials cost 2 x 33 floats per column and row block), at most ENC_FIN_MAXRB row blocks.
+struct EncBwdPlan { int rows, nrb, waves; };
+static EncBwdPlan enc_bwd_plan(int64_t batch, int W, bool h) {
+  const int ncb = W / (h ? 128 : 64);
+  // fp32 storage: the kernel runs beside the side stream's weight-gradient GEMM, which owns the CUs anyway — its
+  // partials, not its occupancy, are what the launch is planned for; bf16 storage: alone on the chip, a full launch
+  const int min_wgs = h ? 256 : 128;
+  int rows = 128;
+  while (rows < 1024 && (int64_t)ncb * ceil_div(batch, 2 * rows) >= min_wgs) rows *= 2;
+  while (ceil_div(batch, rows) > ENC_FIN_MAXRB) rows *= 2;
+  EncBwdPlan p;
+  p.rows = rows;
+  p.nrb = (int)ceil_div(batch, rows);
+  const int tile = h ? 32 : 16;
+  p.waves = rows / tile >= 8 ? 8 : 4;          // (each wave at least one tile)
+  return p;
+}
+int enc_bwd_row_blocks(int64_t batch, int W, bool h) { return enc_bwd_plan(batch, W, h).nrb; }
 int enc_bwd_finish_blocks(int W) { return (int)ceil_div(W, 16); }      // = bn_bwd_finalize_blocks(W)
 
-// scratch inside the (unused) Z0 buffer of the stage, floats: [xs 32 | zs W | T W x 32 | xpart | ppart | s2part]
-struct EncScratch { float *xs, *zs, *ttab, *xpart, *ppart, *s2part; int64_t floats; };
-static EncScratch enc_scratch(float* z0, int64_t batch, int W) {
+// scratch inside the (unused) Z0 buffer of the stage, floats: [xs 32 | zs W | T W x 32 | xpart | ppart | s2part | xT]
+struct EncScratch { float *xs, *zs, *ttab, *xpart, *ppart, *s2part; enc_bf16* xT; int64_t xt_ld; int64_t floats; };
+static EncScratch enc_scratch(float* z0, int64_t batch, int W, bool h) {
   EncScratch e;
   int64_t off = 0;
   auto take = [&](int64_t n) { float* p = z0 ? z0 + off : nullptr; off += (n + 63) / 64 * 64; return p; };
+  const int nrb = enc_bwd_row_blocks(batch, W, h);
   e.xs = take(ENC_IF);
   e.zs = take(W);
   e.ttab = take((int64_t)W * ENC_IF);
   e.xpart = take((int64_t)ENC_XBLOCKS * ENC_XN);
-  e.ppart = take((int64_t)enc_bwd_row_blocks(batch) * W * ENC_IF);
-  e.s2part = take((int64_t)enc_bwd_row_blocks(batch) * W);
+  e.ppart = take((int64_t)nrb * W * ENC_IF);
+  e.s2part = take((int64_t)nrb * W);
+  e.xt_ld = round_up(batch, 32);
+  e.xT = h ? reinterpret_cast<enc_bf16*>(take(ENC_IF * e.xt_ld / 2)) : nullptr;     // (bf16 storage: x^T for the backward)
   e.floats = off;
   return e;
 }
 bool enc_fused_supported(int64_t batch, int W, int in_features) {
-  return in_features == ENC_IF && W % 256 == 0 && batch >= 64 && enc_scratch(nullptr, batch, W).floats <= batch * (int64_t)W;
+  return in_features == ENC_IF && W % 256 == 0 && batch >= 64 &&
+         enc_scratch(nullptr, batch, W, false).floats <= batch * (int64_t)W;
 }
 
-template <bool H>
-static int enc_forward_t(hipStream_t s, const typename EncT<H>::T* x, const typename EncT<H>::T* W0, const float* b0,
-                         const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t* nbt,
-                         float momentum, float* saved, float* scratch, typename EncT<H>::T* A, uint32_t* keepbits,
-                         int64_t batch, int W, const DropoutSrc& drop) {
-  typedef typename EncT<H>::T T;
-  const EncScratch e = enc_scratch(scratch, batch, W);
+static int enc_forward_f(hipStream_t s, const float* x, const float* W0, const float* b0, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, int64_t* nbt, float momentum,
+                         float* saved, float* scratch, float* A, uint32_t* keepbits, int64_t batch, int W,
+                         const DropoutSrc& drop) {
+  const EncScratch e = enc_scratch(scratch, batch, W, false);
   const int xrows = (int)(ENC_XROWS * ceil_div(batch, (int64_t)ENC_XROWS * ENC_XBLOCKS));
   const int xblocks = (int)ceil_div(batch, xrows);
-  hipLaunchKernelGGL(enc_xstats_kernel<T>, dim3(xblocks), dim3(256), 0, s, x, batch, xrows, e.xpart);
-  hipLaunchKernelGGL(enc_bn_finalize_kernel<T>, dim3((unsigned)ceil_div(W, 16)), dim3(256), 0, s, x, e.xpart, xblocks, e.xs,
-                     e.ttab, e.zs, W0, b0, batch, W, gamma, beta, running_mean, running_var, nbt, momentum, saved,
+  hipLaunchKernelGGL(enc_xstats_kernel<float>, dim3(xblocks), dim3(64 * ENC_XWAVES), 0, s, x, batch, xrows, e.xpart);
+  hipLaunchKernelGGL(enc_bn_finalize_kernel<float>, dim3((unsigned)ceil_div(W, 16)), dim3(256), 0, s, x, e.xpart, xblocks,
+                     e.xs, e.ttab, e.zs, W0, b0, batch, W, gamma, beta, running_mean, running_var, nbt, momentum, saved,
                      saved + W, saved + 2 * W, saved + 3 * W);
-  const int rows = enc_fwd_rows(batch);
-  hipLaunchKernelGGL(enc_fwd_kernel<H>, dim3(W / (H ? 512 : 256), (unsigned)ceil_div(batch, rows)), dim3(256), 0, s, x, W0, b0,
-                     saved + 2 * W, saved + 3 * W, A, keepbits, batch, W, rows, drop, nbt);
+  const int ncb = W / 256;
+  hipLaunchKernelGGL(enc_fwd_kernel, dim3(enc_grid(ncb, ceil_div(batch, 32))), dim3(256), 0, s, x, W0, b0, saved + 2 * W,
+                     saved + 3 * W, A, keepbits, batch, W, ncb, drop, nbt);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
+static int enc_forward_h(hipStream_t s, const enc_bf16* x, const enc_bf16* W0, const float* b0, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, int64_t* nbt, float momentum,
+                         float* saved, float* scratch, enc_bf16* A, uint32_t* keepbits, int64_t batch, int W,
+                         const DropoutSrc& drop) {
+  const EncScratch e = enc_scratch(scratch, batch, W, true);
+  const int xrows = (int)(ENC_XROWS * ceil_div(batch, (int64_t)ENC_XROWS * ENC_XBLOCKS));
+  const int xblocks = (int)ceil_div(batch, xrows);
+  hipLaunchKernelGGL(enc_xstats_kernel<enc_bf16>, dim3(xblocks), dim3(64 * ENC_XWAVES), 0, s, x, batch, xrows, e.xpart);
+  hipLaunchKernelGGL(enc_bn_finalize_kernel<enc_bf16>, dim3((unsigned)ceil_div(W, 16)), dim3(256), 0, s, x, e.xpart, xblocks,
+                     e.xs, e.ttab, e.zs, W0, b0, batch, W, gamma, beta, running_mean, running_var, nbt, momentum, saved,
+                     saved + W, saved + 2 * W, saved + 3 * W);
+  const int ncb = W / 512;
+  hipLaunchKernelGGL(enc_fwd_h_kernel, dim3(enc_grid(ncb, ceil_div(batch, 32))), dim3(256), 0, s, x, W0, b0, saved + 2 * W,
+                     saved + 3 * W, A, keepbits, e.xT, e.xt_ld, batch, W, ncb, drop, nbt);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
 }
@@ -572,12 +914,28 @@ static int enc_backward_t(hipStream_t s, const typename EncT<H>::T* dA, const ty
                           float* scratch, int64_t batch, int W, float* dW0, float* dgamma, float* dbeta,
                           float* db_rows, int db_nrows, double* sq_w, double* sq_gb) {
   typedef typename EncT<H>::T T;
-  const EncScratch e = enc_scratch(scratch, batch, W);
-  const int rows = enc_bwd_rows(batch);
-  hipLaunchKernelGGL(enc_bwd_kernel<H>, dim3(W / (H ? 128 : 64), (unsigned)ceil_div(batch, rows)), dim3(256), 0, s, dA, x, gatebits,
-                     e.s2part, e.ppart, batch, W, rows);
-  hipLaunchKernelGGL(enc_bwd_finish_kernel<T>, dim3((unsigned)enc_bwd_finish_blocks(W)), dim3(512), 0, s, e.ppart,
-                     e.s2part, enc_bwd_row_blocks(batch), e.xs, e.ttab, e.zs, W0, b0, saved, batch, W, dW0, dgamma, dbeta,
+  const EncScratch e = enc_scratch(scratch, batch, W, H);
+  const EncBwdPlan pl = enc_bwd_plan(batch, W, H);
+  const int ncb = W / (H ? 128 : 64);
+  const dim3 grid(enc_grid(ncb, pl.nrb));
+  if constexpr (H) {
+    (void)x;
+    if (pl.waves == 8)
+      hipLaunchKernelGGL(enc_bwd_h_kernel<8>, grid, dim3(512), 0, s, dA, e.xT, e.xt_ld, gatebits, e.s2part, e.ppart, batch, W,
+                         pl.rows, ncb, pl.nrb);
+    else
+      hipLaunchKernelGGL(enc_bwd_h_kernel<4>, grid, dim3(256), 0, s, dA, e.xT, e.xt_ld, gatebits, e.s2part, e.ppart, batch, W,
+                         pl.rows, ncb, pl.nrb);
+  } else {
+    if (pl.waves == 8)
+      hipLaunchKernelGGL(enc_bwd_kernel<8>, grid, dim3(512), 0, s, dA, x, gatebits, e.s2part, e.ppart, batch, W, pl.rows, ncb,
+                         pl.nrb);
+    else
+      hipLaunchKernelGGL(enc_bwd_kernel<4>, grid, dim3(256), 0, s, dA, x, gatebits, e.s2part, e.ppart, batch, W, pl.rows, ncb,
+                         pl.nrb);
+  }
+  hipLaunchKernelGGL(enc_bwd_finish_kernel<T>, dim3((unsigned)enc_bwd_finish_blocks(W)), dim3(1024), 0, s, e.ppart,
+                     e.s2part, pl.nrb, e.xs, e.ttab, e.zs, W0, b0, saved, batch, W, dW0, dgamma, dbeta,
                      db_rows, db_nrows, sq_w, sq_gb);
   BLH_HIP_TRY(hipGetLastError());
   return BLH_OK;
@@ -588,8 +946,8 @@ int launch_enc_forward(hipStream_t s, const float* x, const float* W0, const flo
                        float* saved, float* z0_scratch, float* A, uint32_t* keepbits, int64_t batch, int W,
                        const DropoutSrc& drop) {
   if (!enc_fused_supported(batch, W, ENC_IF)) return BLH_ERR_SHAPE;
-  return enc_forward_t<false>(s, x, W0, b0, gamma, beta, running_mean, running_var, nbt, momentum, saved, z0_scratch, A,
-                              keepbits, batch, W, drop);
+  return enc_forward_f(s, x, W0, b0, gamma, beta, running_mean, running_var, nbt, momentum, saved, z0_scratch, A,
+                       keepbits, batch, W, drop);
 }
 int launch_enc_backward(hipStream_t s, const float* dA, const float* x, const float* W0, const float* b0,
                         const float* saved, const uint32_t* gatebits, float* z0_scratch, int64_t batch, int W,
@@ -602,15 +960,15 @@ int launch_enc_backward(hipStream_t s, const float* dA, const float* x, const fl
 // bf16 storage: the scratch is the stage's (unused) bf16 Z0 buffer, batch * W / 2 floats
 bool enc_fused_supported_h(int64_t batch, int W, int in_features) {
   return in_features == ENC_IF && W % 512 == 0 && batch >= 64 &&
-         enc_scratch(nullptr, batch, W).floats <= batch * (int64_t)W / 2;
+         enc_scratch(nullptr, batch, W, true).floats <= batch * (int64_t)W / 2;
 }
 int launch_enc_forward_h(hipStream_t s, const uint16_t* xh, const uint16_t* W0h, const float* b0, const float* gamma,
                          const float* beta, float* running_mean, float* running_var, int64_t* nbt, float momentum,
                          float* saved, uint16_t* z0_scratch, uint16_t* A, uint32_t* keepbits, int64_t batch, int W,
                          const DropoutSrc& drop) {
   if (!enc_fused_supported_h(batch, W, ENC_IF)) return BLH_ERR_SHAPE;
-  return enc_forward_t<true>(s, xh, W0h, b0, gamma, beta, running_mean, running_var, nbt, momentum, saved,
-                             reinterpret_cast<float*>(z0_scratch), A, keepbits, batch, W, drop);
+  return enc_forward_h(s, xh, W0h, b0, gamma, beta, running_mean, running_var, nbt, momentum, saved,
+                       reinterpret_cast<float*>(z0_scratch), A, keepbits, batch, W, drop);
 }
 int launch_enc_backward_h(hipStream_t s, const uint16_t* dA, const uint16_t* xh, const uint16_t* W0h, const float* b0,
                           const float* saved, const uint32_t* gatebits, uint16_t* z0_scratch, int64_t batch, int W,

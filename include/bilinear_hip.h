@@ -547,6 +547,19 @@ int blh_skinny_encode_fused_fwd(void* stream, const float* x, const float* W0, c
 int blh_skinny_encode_fused_bwd(void* stream, const float* dA, const float* x, const float* W0, const float* b0,
                                 const float* saved, const uint32_t* keepbits, float* scratch, float* dW0, float* db0,
                                 float* dgamma, float* dbeta, int64_t batch, int32_t width, int32_t in_features);
+/* The same stage in bf16 storage (gemm_dtype 4; r06: bf16 MFMAs, x^T left by the forward for the backward): `x` [B][32],
+ * `W0` [W][32], `A` / `dA` [B][W] are bf16 bit patterns; `keepbits` [ceil(B/4)][W/8] words (bn_bf16.hip's layout);
+ * `scratch`: batch * width bf16 values (the stage's unused Z0 buffer), kept between the two calls.  width % 512 == 0.
+ * What the bf16-storage step launches for stage 0 (/root/reference/model/bilinear.py:22,34).                      */
+int blh_skinny_encode_fused_fwd_bf16(void* stream, const uint16_t* x, const uint16_t* W0, const float* b0,
+                                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                     int64_t* nbt, float momentum, float* saved, uint16_t* scratch, uint16_t* A,
+                                     uint32_t* keepbits, const blh_dropout* drop, int64_t batch, int32_t width,
+                                     int32_t in_features);
+int blh_skinny_encode_fused_bwd_bf16(void* stream, const uint16_t* dA, const uint16_t* x, const uint16_t* W0,
+                                     const float* b0, const float* saved, const uint32_t* keepbits, uint16_t* scratch,
+                                     float* dW0, float* db0, float* dgamma, float* dbeta, int64_t batch, int32_t width,
+                                     int32_t in_features);
 /* One-pass decode (r05): blh_skinny_decode_fwd_mse AND the data gradient dA[B,W] = dpred Wd from one read of A
  * (/root/reference/model/bilinear.py:29,39; train_bilinear.py:78-79: the loss is row-local).  What the fused
  * training step launches at out_features == 48, width 512 / 1024, batch <= 16384; BLH_ERR_SHAPE otherwise.      */

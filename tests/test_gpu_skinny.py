@@ -269,3 +269,97 @@ def test_encode_stage_without_its_pre_batchnorm_tensor(native, batch, width):
                                               bet.data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), 0.1,
                                               saved.data_ptr(), scratch.data_ptr(), A.data_ptr(), bits.data_ptr(),
                                               ctypes.byref(drop), batch, width, 48) != 0
+
+
+def _bf16_round(a):
+    """fp32 array -> (values rounded to bf16 as fp32, their uint16 bit patterns)."""
+    t = torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16)
+    return t.float().numpy(), t.view(torch.int16).numpy().view(np.uint16)
+
+
+@pytest.mark.parametrize("batch,width", [(16384, 1024), (8192, 1024), (4100, 512), (2048, 2048), (1000, 512)])
+def test_encode_stage_without_its_pre_batchnorm_tensor_bf16_storage(native, batch, width):
+    """The bf16-storage form of encode_f32.hip (r06: z from ONE v_mfma_f32_16x16x32_bf16 per tile, the backward's
+    dY'^T X on bf16 MFMAs over x^T left by the forward, keep-and-gate bits in bn_bf16.hip's [B/4][W/8] layout) through
+    its C entry points against fp64 NumPy on the SAME stored values: x, W0 and dA0 are bf16, z is rounded to bf16 before
+    BatchNorm normalises it (statistics from the un-rounded z), A0 is stored in bf16.  Elements within 2e-2 of the ReLU
+    kink are masked out (one bf16 step of z decides their gate).  /root/reference/model/bilinear.py:7-13,22,34."""
+    from bilinear_amd import _native as N
+    dev = _dev()
+    rng = np.random.RandomState(batch + width)
+    IF = 32
+    x, xb = _bf16_round(rng.standard_normal((batch, IF)))
+    x[:, 3] += 0.5
+    x, xb = _bf16_round(x)
+    W0, W0b = _bf16_round(rng.standard_normal((width, IF)) * 0.25)
+    b0 = (rng.standard_normal(width) * 0.1).astype(np.float32)
+    gamma = (1.0 + 0.1 * rng.standard_normal(width)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(width)).astype(np.float32)
+    dA, dAb = _bf16_round(rng.standard_normal((batch, width)) * 1e-3)
+    z = x.astype(np.float64) @ W0.T.astype(np.float64) + b0
+    mean, var = z.mean(0), z.var(0)
+    invstd = 1.0 / np.sqrt(var + 1e-5)
+    zr = _bf16_round(z)[0].astype(np.float64)                      # what BatchNorm normalises
+    y = (zr - mean) * invstd * gamma + beta
+    keep = (rng.random_sample((batch, width)) < 0.5)
+    keep &= np.abs(y) > 2e-2
+    A_ref = 2.0 * keep * np.maximum(y, 0.0)
+    dt = lambda v: torch.from_numpy(v).to(dev)
+    xt, w0 = dt(xb.view(np.int16)), dt(W0b.view(np.int16))
+    bt, gt, bet, dat = dt(b0), dt(gamma), dt(beta), dt(dAb.view(np.int16))
+    km = dt(keep.astype(np.uint8))
+    rm, rv = torch.zeros(width, device=dev), torch.ones(width, device=dev)
+    nbt = torch.zeros(1, dtype=torch.int64, device=dev)
+    saved = torch.full((4, width), float("nan"), device=dev)
+    scratch = torch.empty(batch * width, dtype=torch.int16, device=dev)
+    A = torch.full((batch + 1, width), -1, dtype=torch.int16, device=dev)
+    bits = torch.zeros(((batch + 3) // 4) * (width // 8), dtype=torch.int32, device=dev)
+    drop = N.Dropout(km.data_ptr(), 0, 0, 0, 0, 0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = native.blh_skinny_encode_fused_fwd_bf16(st, xt.data_ptr(), w0.data_ptr(), bt.data_ptr(), gt.data_ptr(),
+                                                 bet.data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), 0.1,
+                                                 saved.data_ptr(), scratch.data_ptr(), A.data_ptr(), bits.data_ptr(),
+                                                 ctypes.byref(drop), batch, width, IF)
+    assert rc == 0, native.blh_status_string(rc)
+    torch.cuda.synchronize()
+    got = A[:batch].view(torch.bfloat16).float().cpu().numpy()
+    assert (A[batch:] == -1).all() and int(nbt) == 1               # nothing written past the batch
+    # bf16 storage of A0: half an ulp (2^-9 relative) + the fp32 statistics
+    # (a z whose fp32 sum lands on the other side of a bf16 rounding boundary moves by 2^-8 |z|)
+    assert (np.abs(got - A_ref) <= 2.0 ** -7 * (np.abs(A_ref) + 1.0)).all(), np.abs(got - A_ref).max()
+    sv = saved.cpu().numpy().astype(np.float64)
+    _close(sv[0], mean, 1e-6, "saved mean")
+    _close(sv[1], invstd, 1e-6, "saved invstd")
+    _close(rv.cpu().numpy(), 0.9 + 0.1 * var * batch / (batch - 1), 1e-6, "running var")
+    # the bits: keep AND gate, byte j of word [row / 4][col / 8] = row 4 g + j
+    bw = bits.cpu().numpy().view(np.uint32).reshape(-1, width // 8)
+    want = keep & (y > 0)
+    rows = np.arange(batch)
+    for c in (0, 3, 7):                                              # three of the eight bit positions, all rows
+        cols = np.arange(c, width, 8)
+        gotb = (bw[(rows // 4)[:, None], (cols // 8)[None, :]] >> (8 * (rows % 4)[:, None] + c)) & 1
+        assert np.array_equal(gotb.astype(bool), want[:, cols]), c
+    # backward (BatchNorm1d backward with batch statistics on the stored, rounded z)
+    # (the kernels form S1 = sum dY' z and z^T X analytically from the UN-rounded z = x W0^T + b0 — the gates come from
+    #  the stored, rounded z — so the tight reference uses z; with the rounded z in its place every element of z is off
+    #  by up to 2^-9 relative, which averages out over the batch: checked at 1e-2)
+    dY = 2.0 * want * dA.astype(np.float64)
+    zhat = (z - mean) * invstd
+    dgamma_ref, dbeta_ref = (dY * zhat).sum(0), dY.sum(0)
+    dZ = gamma * invstd * (dY - dbeta_ref / batch - zhat * dgamma_ref / batch)
+    dgamma_rounded = (dY * ((zr - mean) * invstd)).sum(0)
+    dW0 = torch.full((width, IF), float("nan"), device=dev)
+    db0, dg, db = (torch.full((width,), float("nan"), device=dev) for _ in range(3))
+    rc = native.blh_skinny_encode_fused_bwd_bf16(st, dat.data_ptr(), xt.data_ptr(), w0.data_ptr(), bt.data_ptr(),
+                                                 saved.data_ptr(), bits.data_ptr(), scratch.data_ptr(), dW0.data_ptr(),
+                                                 db0.data_ptr(), dg.data_ptr(), db.data_ptr(), batch, width, IF)
+    assert rc == 0, native.blh_status_string(rc)
+    torch.cuda.synchronize()
+    _close(db.cpu().numpy(), dbeta_ref, 1e-4, "dbeta")
+    _close(dg.cpu().numpy(), dgamma_ref, 1e-4, "dgamma")
+    _close(dg.cpu().numpy(), dgamma_rounded, 1e-2, "dgamma (stored z)")
+    _close(dW0.cpu().numpy(), dZ.T @ x.astype(np.float64), 1e-4, "dW0")
+    assert native.blh_skinny_encode_fused_fwd_bf16(st, xt.data_ptr(), w0.data_ptr(), bt.data_ptr(), gt.data_ptr(),
+                                                   bet.data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), 0.1,
+                                                   saved.data_ptr(), scratch.data_ptr(), A.data_ptr(), bits.data_ptr(),
+                                                   ctypes.byref(drop), batch, 768, IF) != 0      # width % 512
