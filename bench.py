@@ -863,9 +863,10 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the extra timing of the bf16x3 GEMM mode (reported beside the headline)")
-    ap.add_argument("--persistent-shadow", action="store_true",
-                    help="bf16s: Adam writes the bf16 weight image, the next step skips the arena re-cast "
-                         "(Engine.set_persistent_shadow; opt-in contract, see its docstring)")
+    ap.add_argument("--persistent-shadow", action="store_true", help=argparse.SUPPRESS)     # (the default since r06)
+    ap.add_argument("--no-persistent-shadow", action="store_true",
+                    help="bf16s A/B: re-cast the fp32 arena to bf16 every step instead of letting Adam write the bf16 "
+                         "weight image (Engine.set_persistent_shadow(False); the image is the default since round 6)")
     ap.add_argument("--rehearse-rccl", action="store_true",
                     help="developer: at --gpus 1, run the multi-GPU code path (RCCL group of one rank, "
                          "data-parallel driver with every collective issued) — what the step costs before "
@@ -927,8 +928,9 @@ def main():
     net.engine.ensure(dev)
     if args.one_stream:
         net.engine.set_two_stream(False)
-    if args.persistent_shadow and args.dtype == "bf16s":
-        net.engine.set_persistent_shadow(True)
+    args.persistent_shadow = args.dtype == "bf16s" and not args.no_persistent_shadow
+    if args.dtype == "bf16s":
+        net.engine.set_persistent_shadow(args.persistent_shadow)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     x = torch.randn(args.batch, 32, device=dev, generator=g)
     t = torch.randn(args.batch, 48, device=dev, generator=g)

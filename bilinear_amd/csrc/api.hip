@@ -123,6 +123,7 @@ int blh_context_set_option(blh_context* c, int32_t option, int32_t value) {
     case BLH_OPT_PERSISTENT_SHADOW:
       c->persistent_shadow = value != 0;
       c->shadow_params = c->shadow_ws = nullptr;
+      c->shadow_wdT = false;
       return BLH_OK;
     case BLH_OPT_DEV_KNOBS:
       if (value < 0 || (value & ~blh::KNOB_ALL) != 0) return BLH_ERR_INVALID_ARGUMENT;
@@ -537,8 +538,13 @@ int blh_refresh_param_shadow(blh_context* ctx, const blh_model_desc* d, void* st
   BLH_TRY(check_common(ctx, d, workspace, workspace_bytes, batch));
   if (!params || d->gemm_dtype != 4) return BLH_ERR_INVALID_ARGUMENT;
   const WorkspaceH wh = carve_h(d, batch, workspace);
-  BLH_TRY(launch_cast_f32_bf16((hipStream_t)stream, params, wh.wsh, make_layout(d).total));
-  if (ctx->persistent_shadow) { ctx->shadow_params = params; ctx->shadow_ws = workspace; }
+  const ArenaLayout L = make_layout(d);
+  const bool wdT = !ctx->knob(blh::KNOB_NO_DECODE_FUSE) && decode_fused_h_supported(batch, d->width, d->out_features);
+  // (with the decode weight's K-major image when this shape takes the one-pass decode; the second source of the
+  //  launch is a dummy: the first 4 parameters onto themselves)
+  BLH_TRY(launch_cast2_f32_bf16((hipStream_t)stream, params, wh.wsh, L.total, params, wh.wsh, 4,
+                                wdT ? params + L.dec_w : nullptr, wdT ? wh.wdT : nullptr, d->width, d->out_features));
+  if (ctx->persistent_shadow) { ctx->shadow_params = params; ctx->shadow_ws = workspace; ctx->shadow_wdT = wdT; }
   return BLH_OK;
 }
 
@@ -573,6 +579,7 @@ int blh_train_step(blh_context* ctx, const blh_model_desc* d, void* stream, floa
     int np = 0;
     const bool keep = ctx->persistent_shadow;
     const bool valid = keep && ctx->shadow_params == params && ctx->shadow_ws == workspace;
+    const bool wdT_was = ctx->shadow_wdT;
     int dec_S = 0;
     BLH_TRY(forward_h(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, wh, pred, batch, true, valid,
                       target, (float)(2.0 / denom), &dec_S));
@@ -582,10 +589,14 @@ int blh_train_step(blh_context* ctx, const blh_model_desc* d, void* stream, floa
     BLH_TRY(backward_h(ctx, d, s, params, drop, wh, wh.dpred, grads, batch, nullptr, nullptr, ctx->fwd_mode, dec_S));
     ctx->note_saved(workspace, batch, blh_context::SAVED_NONE);
     BLH_TRY(launch_sumsq(s, grads, count, wh.sumsq_part, &np));
+    const bool wdT = keep && !ctx->knob(blh::KNOB_NO_DECODE_FUSE) &&
+                     decode_fused_h_supported(batch, d->width, d->out_features);
+    const ShadowDst sd = keep ? ShadowDst{wh.wsh, wdT ? wh.wdT : nullptr, make_layout(d).dec_w, d->width, d->out_features}
+                              : NO_SHADOW;
     BLH_TRY(launch_clip_adam(s, params, grads, exp_avg, exp_avg_sq, count, *hyper, wh.sumsq_part, np,
-                             stats_out, LossFinish{wh.loss_part, nparts, denom, loss_out},
-                             keep ? wh.wsh : nullptr));
-    if (keep) { ctx->shadow_params = params; ctx->shadow_ws = workspace; }
+                             stats_out, LossFinish{wh.loss_part, nparts, denom, loss_out}, sd));
+    // (the K-major image is complete only if an earlier launch zeroed its padding rows: the first step's cast does)
+    if (keep) { ctx->shadow_params = params; ctx->shadow_ws = workspace; ctx->shadow_wdT = wdT && (valid ? wdT_was : true); }
     return BLH_OK;
   }
   const Workspace ws = carve(d, batch, workspace);
@@ -823,6 +834,8 @@ int blh_train_step_captured(blh_context* ctx, const blh_model_desc* d, void* str
     //  no arena re-cast — the caller refreshes the image before the first replay and after any
     //  out-of-band parameter change with blh_refresh_param_shadow)
     const bool keep = ctx->persistent_shadow;
+    const bool wdT_was = ctx->shadow_wdT && ctx->shadow_params == params && ctx->shadow_ws == workspace;
+    if (keep && !wdT_was) ctx->shadow_wdT = false;
     int dec_S = 0;
     BLH_TRY(forward_h(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, wh, pred, batch, true, keep,
                       target, (float)(2.0 / denom), &dec_S));
@@ -832,9 +845,15 @@ int blh_train_step_captured(blh_context* ctx, const blh_model_desc* d, void* str
     BLH_TRY(backward_h(ctx, d, s, params, drop, wh, wh.dpred, grads, batch, nullptr, nullptr, ctx->fwd_mode, dec_S));
     ctx->note_saved(workspace, batch, blh_context::SAVED_NONE);
     BLH_TRY(launch_sumsq(s, grads, count, wh.sumsq_part, &np));
-    return launch_clip_adam_dev(s, params, grads, exp_avg, exp_avg_sq, count, dev_state,
-                                wh.sumsq_part, np, stats_out,
-                                LossFinish{wh.loss_part, nparts, denom, loss_out}, keep ? wh.wsh : nullptr);
+    // (captured: the image state is what blh_refresh_param_shadow left — plain + K-major decode weight — and every
+    //  replay keeps both up to date)
+    const bool wdT = keep && wdT_was;
+    const ShadowDst sd = keep ? ShadowDst{wh.wsh, wdT ? wh.wdT : nullptr, make_layout(d).dec_w, d->width, d->out_features}
+                              : NO_SHADOW;
+    const int rc = launch_clip_adam_dev(s, params, grads, exp_avg, exp_avg_sq, count, dev_state, wh.sumsq_part, np,
+                                        stats_out, LossFinish{wh.loss_part, nparts, denom, loss_out}, sd);
+    if (keep) { ctx->shadow_params = params; ctx->shadow_ws = workspace; ctx->shadow_wdT = wdT; }
+    return rc;
   }
   const Workspace ws = carve(d, batch, workspace);
   if (const int mode = small_step_mode(ctx, d, batch, false))
@@ -1118,7 +1137,7 @@ int blh_skinny_encode_fused_fwd_bf16(void* stream, const uint16_t* x, const uint
   DropoutSrc d;
   d.step_dev = nullptr; d.keep = drop->keep_mask; d.seed = drop->seed; d.step = drop->step;
   d.row_offset = drop->row_offset; d.layer = drop->layer_base;
-  return launch_enc_forward_h((hipStream_t)stream, x, W0, b0, gamma, beta, running_mean, running_var, nbt, momentum,
+  return launch_enc_forward_h((hipStream_t)stream, const_cast<uint16_t*>(x), nullptr, W0, b0, gamma, beta, running_mean, running_var, nbt, momentum,
                               saved, scratch, A, keepbits, batch, width, d);
 }
 

@@ -203,23 +203,27 @@ struct LossFinish { const float* part; int n; double denom; float* out; };
 struct AdamConsts { float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, max_norm; };
 AdamConsts adam_consts(const blh_adam_hyper& h);
 int launch_sumsq(hipStream_t s, const float* g, int64_t count, double* part, int* nparts);
-// shadow (optional): bf16 image of the updated parameters (the bf16-storage forward's weights)
+// shadow (optional): bf16 images of the updated parameters for the next bf16-storage forward — `plain`: the arena
+// element for element (the GEMMs' weights); `wdT` (optional): the decode weight [OF][W] at arena offset dec_w in the
+// one-pass decode's K-major layout (decode_wdT_dev.h; rows >= OF of that image are zero and never written here)
+struct ShadowDst { uint16_t* plain; uint16_t* wdT; int64_t dec_w; int W, OF; };
+static constexpr ShadowDst NO_SHADOW = {nullptr, nullptr, 0, 0, 0};
 int launch_clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count,
                      const blh_adam_hyper& h, const double* sumsq_part, int nparts,
                      float* stats_out, LossFinish lf = LossFinish{nullptr, 0, 1.0, nullptr},
-                     uint16_t* shadow = nullptr);
+                     ShadowDst shadow = NO_SHADOW);
 // the gradient arrives as bf16 (compressed data-parallel buckets) times gscale; gout (fp32 arena)
 // receives the clipped gradient
 int launch_sumsq_bf16(hipStream_t s, const uint16_t* g, int64_t count, float gscale, double* part, int* nparts);
 int launch_clip_adam_bf16(hipStream_t s, float* p, const uint16_t* g_bf16, float gscale, float* gout, float* m,
                           float* v, int64_t count, const blh_adam_hyper& h, const double* sumsq_part,
-                          int nparts, float* stats_out, uint16_t* shadow = nullptr);
+                          int nparts, float* stats_out, ShadowDst shadow = NO_SHADOW);
 // device-state variants (graph replay): hyper-parameters and step counters read on the device
 int launch_step_state_advance(hipStream_t s, blh_step_state* st);
 int launch_clip_adam_dev(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count,
                          const blh_step_state* st, const double* sumsq_part, int nparts,
                          float* stats_out, LossFinish lf = LossFinish{nullptr, 0, 1.0, nullptr},
-                         uint16_t* shadow = nullptr);
+                         ShadowDst shadow = NO_SHADOW);
 int launch_clip_scale(hipStream_t s, float* g, int64_t count, float max_norm,
                       const double* sumsq_part, int nparts, float* stats_out);
 // pred = sum(slabs) + bias (+ fused MSE when target != nullptr)
@@ -242,7 +246,8 @@ int launch_enc_backward(hipStream_t s, const float* dA, const float* x, const fl
                         float* dW0, float* dgamma, float* dbeta, float* db_rows, int db_nrows, double* sq_w,
                         double* sq_gb);
 bool enc_fused_supported_h(int64_t batch, int W, int in_features);
-int launch_enc_forward_h(hipStream_t s, const uint16_t* xh, const uint16_t* W0h, const float* b0, const float* gamma,
+// x_f32 != nullptr: xh has not been written yet; the stage's statistics kernel casts x on the way
+int launch_enc_forward_h(hipStream_t s, uint16_t* xh, const float* x_f32, const uint16_t* W0h, const float* b0, const float* gamma,
                          const float* beta, float* running_mean, float* running_var, int64_t* nbt, float momentum,
                          float* saved, uint16_t* z0_scratch, uint16_t* A, uint32_t* keepbits, int64_t batch, int W,
                          const DropoutSrc& drop);

@@ -717,7 +717,7 @@ __device__ __forceinline__ void clip_adam_body(float* __restrict__ p, const TG* 
                                                const AdamConsts c, float gscale,
                                                const double* __restrict__ sumsq_part, int nparts,
                                                float* stats_out, const LossFinish& lf,
-                                               bf16_bits* __restrict__ shadow, double* sh) {
+                                               const ShadowDst shadow, double* sh) {
   // The first elements of this thread and ALL of its norm partials are requested before anything waits: the norm
   // reduction (up to sixteen partials per thread, then a tree with eight barriers) used to be a chain of dependent
   // round trips in front of a kernel that is otherwise a pure stream.  Same sums in the same order.
@@ -762,7 +762,21 @@ __device__ __forceinline__ void clip_adam_body(float* __restrict__ p, const TG* 
       pp[k] = pp[k] - c.step_size * (mp[k] / denom);
     }
     st4(gout + i * 4, gv); st4(m + i * 4, mv); st4(v + i * 4, vv); st4(p + i * 4, pv);
-    if (shadow) st4(shadow + i * 4, pv);
+    if (shadow.plain) {
+      st4(shadow.plain + i * 4, pv);
+      // the decode weight's K-major image (one-pass decode, decode_wdT_dev.h): element (o, col) of Wd goes to
+      // 16-byte block ((col / 128 * 8 + col % 8) * 2 + o / 32) * 64 + 16 (o / 8 % 4) + col / 8 % 16, half word o % 8
+      const int64_t e = i * 4 - shadow.dec_w;
+      if (shadow.wdT && e >= 0 && e < (int64_t)shadow.OF * shadow.W) {
+        const int o = (int)(e / shadow.W), col0 = (int)(e % shadow.W);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int col = col0 + k;
+          const int idx = (((col >> 7) * 8 + (col & 7)) * 2 + (o >> 5)) * 64 + 16 * ((o >> 3) & 3) + ((col >> 3) & 15);
+          shadow.wdT[(int64_t)idx * 8 + (o & 7)] = (bf16_bits)(pack_bf16x2(pp[k], 0.f) & 0xFFFFu);
+        }
+      }
+    }
     i += stride;
     if (i < n4) { gv = ld4(gin + i * 4); mv = ld4(m + i * 4); vv = ld4(v + i * 4); pv = ld4(p + i * 4); }
   }
@@ -772,7 +786,7 @@ template <typename TG>
 __global__ __launch_bounds__(256) void clip_adam_kernel(
     float* __restrict__ p, const TG* gin, float* gout, float* __restrict__ m, float* __restrict__ v,
     int64_t count, AdamConsts c, float gscale, const double* __restrict__ sumsq_part, int nparts,
-    float* stats_out, LossFinish lf, bf16_bits* __restrict__ shadow) {
+    float* stats_out, LossFinish lf, ShadowDst shadow) {
   __shared__ double sh[256];
   clip_adam_body<TG>(p, gin, gout, m, v, count, c, gscale, sumsq_part, nparts, stats_out, lf, shadow, sh);
 }
@@ -787,7 +801,7 @@ AdamConsts adam_consts(const blh_adam_hyper& h) {
 
 int launch_clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count,
                      const blh_adam_hyper& h, const double* sumsq_part, int nparts,
-                     float* stats_out, LossFinish lf, uint16_t* shadow) {
+                     float* stats_out, LossFinish lf, ShadowDst shadow) {
   if (count % 4 != 0) return BLH_ERR_SHAPE;
   if (h.step < 1) return BLH_ERR_INVALID_ARGUMENT;
   const int blocks = (int)std::min<int64_t>(ceil_div(count / 4, 256), 2048);
@@ -799,7 +813,7 @@ int launch_clip_adam(hipStream_t s, float* p, float* g, float* m, float* v, int6
 
 int launch_clip_adam_bf16(hipStream_t s, float* p, const uint16_t* g_bf16, float gscale, float* gout, float* m,
                           float* v, int64_t count, const blh_adam_hyper& h, const double* sumsq_part,
-                          int nparts, float* stats_out, uint16_t* shadow) {
+                          int nparts, float* stats_out, ShadowDst shadow) {
   if (count % 4 != 0) return BLH_ERR_SHAPE;
   if (h.step < 1) return BLH_ERR_INVALID_ARGUMENT;
   const int blocks = (int)std::min<int64_t>(ceil_div(count / 4, 256), 2048);
@@ -993,7 +1007,7 @@ int launch_step_state_advance(hipStream_t s, blh_step_state* st) {
 __global__ __launch_bounds__(256) void clip_adam_dev_kernel(
     float* __restrict__ p, float* g, float* __restrict__ m, float* __restrict__ v,
     int64_t count, const blh_step_state* __restrict__ st, const double* __restrict__ sumsq_part,
-    int nparts, float* stats_out, LossFinish lf, bf16_bits* __restrict__ shadow) {
+    int nparts, float* stats_out, LossFinish lf, ShadowDst shadow) {
   __shared__ double sh[256];
   const AdamConsts c{(float)(1.0 - st->beta1), (float)st->beta2, (float)(1.0 - st->beta2), st->step_size,
                      st->bc2_sqrt, (float)st->eps, (float)st->max_norm};
@@ -1002,7 +1016,7 @@ __global__ __launch_bounds__(256) void clip_adam_dev_kernel(
 
 int launch_clip_adam_dev(hipStream_t s, float* p, float* g, float* m, float* v, int64_t count,
                          const blh_step_state* st, const double* sumsq_part, int nparts,
-                         float* stats_out, LossFinish lf, uint16_t* shadow) {
+                         float* stats_out, LossFinish lf, ShadowDst shadow) {
   if (count % 4 != 0) return BLH_ERR_SHAPE;
   const int blocks = (int)std::min<int64_t>(ceil_div(count / 4, 256), 2048);
   hipLaunchKernelGGL(clip_adam_dev_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, count, st,

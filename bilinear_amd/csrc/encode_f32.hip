@@ -57,6 +57,11 @@ __device__ __forceinline__ float enc_round_bf16(float v) {
   const __bf16 b = (__bf16)v;
   return __uint_as_float((uint32_t)(*reinterpret_cast<const uint16_t*>(&b)) << 16);
 }
+__device__ __forceinline__ uint32_t enc_pack2(float lo, float hi) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  const bf2 b = {(__bf16)lo, (__bf16)hi};          // v_cvt_pk_bf16_f32: RNE
+  return *reinterpret_cast<const uint32_t*>(&b);
+}
 __device__ __forceinline__ void enc_st4(float* p, const float4& a) { *reinterpret_cast<float4*>(p) = a; }
 __device__ __forceinline__ void enc_st4(enc_bf16* p, const float4& a) {
   typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
@@ -84,9 +89,13 @@ static constexpr int ENC_XROWS = 64 * ENC_XWAVES;        // rows per block of en
 // cores: per 4 rows both operands are the same registers — A = x^T (lane: feature n + 16 h, row 4 s + q), B = x
 // (lane: row 4 s + q, feature n + 16 h') — 4 MFMAs per 4 rows.  (Sixteen waves per block and at most 16 blocks — so
 // that the finalize kernel had one round of partials — measured 7-12 us against 5: r06, profiles/r06_encode.md.)
-template <typename TX>
+// CAST (bf16 storage with the weight image kept by Adam: no cast launch in front of the forward): x is the caller's fp32
+// input; every element is rounded to bf16 here, the statistics are those of the rounded values and the bf16 image
+// xh — what every later kernel of the stage reads — is written on the way (each element is touched exactly once).
+template <typename TX, bool CAST = false>
 __global__ __launch_bounds__(64 * ENC_XWAVES) void enc_xstats_kernel(const TX* __restrict__ x, int64_t batch,
-                                                                     int rows_per_block, float* __restrict__ xpart) {
+                                                                     int rows_per_block, float* __restrict__ xpart,
+                                                                     enc_bf16* __restrict__ xh = nullptr) {
   __shared__ float red[ENC_XWAVES][ENC_XN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
@@ -95,7 +104,8 @@ __global__ __launch_bounds__(64 * ENC_XWAVES) void enc_xstats_kernel(const TX* _
   encf4 acc[2][2];
   acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = encf4{0.f, 0.f, 0.f, 0.f};
   float cs0 = 0.f, cs1 = 0.f;
-  const float c0 = enc_ld1(x + n), c1 = enc_ld1(x + 16 + n);          // the shift: row 0
+  float c0 = enc_ld1(x + n), c1 = enc_ld1(x + 16 + n);                // the shift: row 0
+  if (CAST) { c0 = enc_round_bf16(c0); c1 = enc_round_bf16(c1); }
   // rounds of 8 steps of 4 rows, TWO rounds per trip with all their loads first (the launch plans at most two rounds
   // per wave up to 16384 rows: one memory round trip for the whole kernel)
   for (int64_t base = r0 + 64 * wave; base < r1; base += ENC_XROWS) {
@@ -117,7 +127,13 @@ __global__ __launch_bounds__(64 * ENC_XWAVES) void enc_xstats_kernel(const TX* _
     for (int rd = 0; rd < 2; ++rd)
 #pragma unroll
       for (int st = 0; st < 8; ++st) {
-        const bool ok = base + 32 * rd + 4 * st + q < r1;
+        const int64_t row = base + 32 * rd + 4 * st + q;
+        const bool ok = row < r1;
+        if (CAST) {
+          const uint32_t pk = enc_pack2(xv[rd][st][0], xv[rd][st][1]);
+          xv[rd][st][0] = __uint_as_float(pk << 16); xv[rd][st][1] = __uint_as_float(pk & 0xffff0000u);
+          if (ok) { xh[row * ENC_IF + n] = (enc_bf16)(pk & 0xFFFFu); xh[row * ENC_IF + 16 + n] = (enc_bf16)(pk >> 16); }
+        }
         const float y0 = ok ? xv[rd][st][0] - c0 : 0.f, y1 = ok ? xv[rd][st][1] - c1 : 0.f;
         const float yy[2] = {y0, y1};
         cs0 += y0; cs1 += y1;
@@ -282,11 +298,6 @@ __device__ __forceinline__ void enc_z_tile(encf4 (&zt)[CPL], const EncCols<CPL>&
 __device__ __forceinline__ void enc_ld_f8(const float* p, float (&f)[8]) {
   const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
   f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
-}
-__device__ __forceinline__ uint32_t enc_pack2(float lo, float hi) {
-  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-  const bf2 b = {(__bf16)lo, (__bf16)hi};          // v_cvt_pk_bf16_f32: RNE
-  return *reinterpret_cast<const uint32_t*>(&b);
 }
 // the same from x operands already in registers
 template <int CPL>
@@ -879,7 +890,8 @@ static int enc_forward_f(hipStream_t s, const float* x, const float* W0, const f
   const EncScratch e = enc_scratch(scratch, batch, W, false);
   const int xrows = (int)(ENC_XROWS * ceil_div(batch, (int64_t)ENC_XROWS * ENC_XBLOCKS));
   const int xblocks = (int)ceil_div(batch, xrows);
-  hipLaunchKernelGGL(enc_xstats_kernel<float>, dim3(xblocks), dim3(64 * ENC_XWAVES), 0, s, x, batch, xrows, e.xpart);
+  hipLaunchKernelGGL(enc_xstats_kernel<float>, dim3(xblocks), dim3(64 * ENC_XWAVES), 0, s, x, batch, xrows, e.xpart,
+                     (enc_bf16*)nullptr);
   hipLaunchKernelGGL(enc_bn_finalize_kernel<float>, dim3((unsigned)ceil_div(W, 16)), dim3(256), 0, s, x, e.xpart, xblocks,
                      e.xs, e.ttab, e.zs, W0, b0, batch, W, gamma, beta, running_mean, running_var, nbt, momentum, saved,
                      saved + W, saved + 2 * W, saved + 3 * W);
@@ -890,14 +902,20 @@ static int enc_forward_f(hipStream_t s, const float* x, const float* W0, const f
   return BLH_OK;
 }
 
-static int enc_forward_h(hipStream_t s, const enc_bf16* x, const enc_bf16* W0, const float* b0, const float* gamma,
-                         const float* beta, float* running_mean, float* running_var, int64_t* nbt, float momentum,
-                         float* saved, float* scratch, enc_bf16* A, uint32_t* keepbits, int64_t batch, int W,
-                         const DropoutSrc& drop) {
+static int enc_forward_h(hipStream_t s, enc_bf16* x, const float* x_f32, const enc_bf16* W0, const float* b0,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t* nbt,
+                         float momentum, float* saved, float* scratch, enc_bf16* A, uint32_t* keepbits, int64_t batch,
+                         int W, const DropoutSrc& drop) {
   const EncScratch e = enc_scratch(scratch, batch, W, true);
   const int xrows = (int)(ENC_XROWS * ceil_div(batch, (int64_t)ENC_XROWS * ENC_XBLOCKS));
   const int xblocks = (int)ceil_div(batch, xrows);
-  hipLaunchKernelGGL(enc_xstats_kernel<enc_bf16>, dim3(xblocks), dim3(64 * ENC_XWAVES), 0, s, x, batch, xrows, e.xpart);
+  // x_f32: the bf16 image `x` has not been written yet — the statistics kernel casts on the way
+  if (x_f32)
+    hipLaunchKernelGGL((enc_xstats_kernel<float, true>), dim3(xblocks), dim3(64 * ENC_XWAVES), 0, s, x_f32, batch, xrows,
+                       e.xpart, x);
+  else
+    hipLaunchKernelGGL(enc_xstats_kernel<enc_bf16>, dim3(xblocks), dim3(64 * ENC_XWAVES), 0, s, (const enc_bf16*)x, batch,
+                       xrows, e.xpart, (enc_bf16*)nullptr);
   hipLaunchKernelGGL(enc_bn_finalize_kernel<enc_bf16>, dim3((unsigned)ceil_div(W, 16)), dim3(256), 0, s, x, e.xpart, xblocks,
                      e.xs, e.ttab, e.zs, W0, b0, batch, W, gamma, beta, running_mean, running_var, nbt, momentum, saved,
                      saved + W, saved + 2 * W, saved + 3 * W);
@@ -962,12 +980,12 @@ bool enc_fused_supported_h(int64_t batch, int W, int in_features) {
   return in_features == ENC_IF && W % 512 == 0 && batch >= 64 &&
          enc_scratch(nullptr, batch, W, true).floats <= batch * (int64_t)W / 2;
 }
-int launch_enc_forward_h(hipStream_t s, const uint16_t* xh, const uint16_t* W0h, const float* b0, const float* gamma,
-                         const float* beta, float* running_mean, float* running_var, int64_t* nbt, float momentum,
-                         float* saved, uint16_t* z0_scratch, uint16_t* A, uint32_t* keepbits, int64_t batch, int W,
-                         const DropoutSrc& drop) {
+int launch_enc_forward_h(hipStream_t s, uint16_t* xh, const float* x_f32, const uint16_t* W0h, const float* b0,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t* nbt,
+                         float momentum, float* saved, uint16_t* z0_scratch, uint16_t* A, uint32_t* keepbits,
+                         int64_t batch, int W, const DropoutSrc& drop) {
   if (!enc_fused_supported_h(batch, W, ENC_IF)) return BLH_ERR_SHAPE;
-  return enc_forward_h(s, xh, W0h, b0, gamma, beta, running_mean, running_var, nbt, momentum, saved,
+  return enc_forward_h(s, xh, x_f32, W0h, b0, gamma, beta, running_mean, running_var, nbt, momentum, saved,
                        reinterpret_cast<float*>(z0_scratch), A, keepbits, batch, W, drop);
 }
 int launch_enc_backward_h(hipStream_t s, const uint16_t* dA, const uint16_t* xh, const uint16_t* W0h, const float* b0,

@@ -102,6 +102,7 @@ struct blh_context {
   }
   const void* shadow_params = nullptr;
   const void* shadow_ws = nullptr;
+  bool shadow_wdT = false;            // ... and the decode weight's K-major image (one-pass decode) with it
   // one-pass decode (skinny.hip: decode_fused_kernel): the forward with a target also left the decode data gradient
   // dA = dP Wd in this workspace's G0 for this batch; the backward that consumes that forward skips the GEMM
   const void* dec_da_ws = nullptr;

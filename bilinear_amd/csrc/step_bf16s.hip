@@ -30,22 +30,26 @@ int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const fl
     ctx->note_saved(ws.wsh, batch, enc_fused_fwd ? blh_context::SAVED_ENC_FUSED : blh_context::SAVED_MULTI);
   // bf16 images of the parameters (the GEMMs read the weights from it) and of the input
   // (shadow_valid: the previous fused step's Adam kernel wrote it, BLH_OPT_PERSISTENT_SHADOW)
+  const bool wdT_valid = shadow_valid && ctx->shadow_wdT;
   ctx->shadow_params = ctx->shadow_ws = nullptr;
+  ctx->shadow_wdT = false;
   // one-pass decode (skinny.hip): forward + MSE + the decode data gradient from one read of the last activation; its
-  // second phase reads the decode weight through an image the cast launch below writes (not with a persistent shadow:
-  // Adam's pass writes the plain image only)
-  const bool dec_fused = train && target && !shadow_valid && !ctx->knob(KNOB_NO_DECODE_FUSE) &&
+  // second phase reads the decode weight through an image the cast launch below writes — or, with a persistent
+  // shadow, the previous step's Adam kernel wrote (elementwise.hip: ShadowDst.wdT)
+  const bool dec_fused = train && target && (!shadow_valid || wdT_valid) && !ctx->knob(KNOB_NO_DECODE_FUSE) &&
                          decode_fused_h_supported(batch, W, OF);
   ctx->dec_da_ws = nullptr;
   if (!shadow_valid)
     BLH_TRY(launch_cast2_f32_bf16(s, params, ws.wsh, L.total, x, ws.xh, batch * IF, dec_fused ? params + L.dec_w : nullptr,
                                   dec_fused ? ws.wdT : nullptr, W, OF));
-  else BLH_TRY(launch_cast_f32_bf16(s, x, ws.xh, batch * IF));
+  // (weight image kept by Adam: only x is left to cast — the encode stage's statistics kernel does it on the way)
+  const bool x_cast_in_stage = shadow_valid && enc_fused_fwd;
+  if (shadow_valid && !x_cast_in_stage) BLH_TRY(launch_cast_f32_bf16(s, x, ws.xh, batch * IF));
   for (int i = 0; i < nh; ++i) {
     const HeavyOffsets& h = L.heavy[i];
     if (i == 0 && enc_fused_fwd) {
       // x statistics -> BatchNorm statistics -> A0 and the keep-and-gate bits; Z0's buffer serves as scratch
-      BLH_TRY(launch_enc_forward_h(s, ws.xh, ws.wsh + h.w, params + h.b, params + h.gamma, params + h.beta, bn_running,
+      BLH_TRY(launch_enc_forward_h(s, ws.xh, x_cast_in_stage ? x : nullptr, ws.wsh + h.w, params + h.b, params + h.gamma, params + h.beta, bn_running,
                                    bn_running + W, nbt, momentum, ws.bn_saved[0], ws.Z[0], ws.A[0], ws.keep[0], batch, W,
                                    layer_drop(ctx, drop, 0, batch, W)));
       continue;

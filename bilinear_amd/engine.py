@@ -86,6 +86,7 @@ class Engine:
         self.ctx = None                # N.Context on self.device (side stream, events, options)
         self.generation = 0            # counts train-mode forwards (guards backward, see _LifterFunction)
         self.shadow_epoch = 0          # counts invalidations of the persistent bf16 weight image
+        self._param_versions = None    # sum of the Parameters' autograd version counters at the last fused step
         self._grad_ptr_cache = None
         self._grad_view_cache = None
         self._np_cache = None          # (_named_params list, module links, parameter links, BatchNorm modules)
@@ -180,6 +181,11 @@ class Engine:
         if self.ctx is None or self.ctx.device != device:
             old = self.ctx
             self.ctx = N.Context(device)
+            if old is None and self.layout.desc.gemm_dtype == 4:
+                # bf16 storage: the fused step's Adam kernel keeps the bf16 weight image up to date and the next step
+                # skips its re-cast of the arena (r06: -0.6 % at configs[2], -0.7 % at configs[4]'s shape,
+                # profiles/r06_shadow_ab.txt).  Guarded by the Parameters' version counters, see train_step.
+                self.ctx.set_option(N.OPT_PERSISTENT_SHADOW, 1)
             if old is not None:    # keep the options across a device move
                 for opt in (N.OPT_TWO_STREAM, N.OPT_LATE_FORK, N.OPT_PERSISTENT_SHADOW,
                             N.OPT_SMALL_STEP):
@@ -461,13 +467,15 @@ class Engine:
         return self._native("eval_fwd", x, self.params, self.bn_running, ws, *self._op_args())
 
     def set_persistent_shadow(self, enabled):
-        """gemm_dtype "bf16s" only (BLH_OPT_PERSISTENT_SHADOW; default off): the fused train step's
-        Adam kernel also writes the bf16 image of the updated weights and the next fused step skips
-        re-casting the whole fp32 arena.  CONTRACT: between two ``train_step`` calls the parameters
-        are written by nothing else — checkpoint loads, ``.apply(init)``, ``optimizer.step()`` and
-        moving the module are handled here (they drop the image); code that edits parameter
-        storage behind PyTorch's back (``p.data.mul_()``, raw pointers) must call
-        ``invalidate_shadow()``."""
+        """gemm_dtype "bf16s" only (BLH_OPT_PERSISTENT_SHADOW; ON by default in this host layer since round 6, off in
+        the C ABI): the fused train step's Adam kernel also writes the bf16 image of the updated weights (and the
+        decode weight's K-major image of the one-pass decode) and the next fused step skips re-casting the whole fp32
+        arena.  Between two ``train_step`` calls the parameters must be written by nothing the engine cannot see:
+        checkpoint loads, ``.apply(init)``, ``optimizer.step()`` and moving the module drop the image explicitly, and
+        ANY in-place operation on a Parameter (``p.mul_()``, ``p.copy_()``, ``nn.init.*``) is caught through the
+        Parameters' autograd version counters in front of every fused step.  What is invisible to both — edits
+        through ``p.data`` or raw pointers — must be followed by ``invalidate_shadow()`` (or switch the image off
+        here)."""
         if self.ctx is None:
             raise RuntimeError("the engine is not on a device yet")
         self.ctx.set_option(N.OPT_PERSISTENT_SHADOW, 1 if enabled else 0)
@@ -606,6 +614,12 @@ class Engine:
         ws = self.workspace(batch)
         self._drop_struct(batch)          # validates explicit masks (shape, device)
         self._tune_streams()
+        if self.layout.desc.gemm_dtype == 4:
+            # a Parameter written in place since the last fused step (its version counter moved): the bf16 image is stale
+            versions = sum(p._version for _, p, _, _ in self._named_params())
+            if versions != self._param_versions:
+                self._param_versions = versions
+                self.invalidate_shadow()
         pred, loss = self._native(
             "train_step", x, target, self.params, self.grads, exp_avg, exp_avg_sq, self.bn_running, self.bn_nbt,
             ws, stats, self.masks, *self._op_args(), self.seed, self.rng_step, self.row_offset,

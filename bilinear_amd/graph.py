@@ -29,7 +29,7 @@ class CapturedTrainStep:
     """
 
     def __init__(self, module, optimizer, batch, max_norm=1.0, device=None, two_stream=False,
-                 persistent_shadow=False):
+                 persistent_shadow=None):
         """``two_stream=False`` (default): the graph is captured in the single-stream kernel order.
         Measured on MI355X (profiles/r02_step_timeline.md): hipGraph replay spreads the forked
         weight-gradient branch over up to four hardware queues and every cross-queue edge costs
@@ -45,9 +45,15 @@ class CapturedTrainStep:
         # gemm_dtype "bf16s": Adam writes the bf16 weight image, the graph holds no arena re-cast
         # (Engine.set_persistent_shadow; the image is refreshed here whenever the host-side mirror
         # shows that something else moved the training state)
-        self.persistent_shadow = bool(persistent_shadow) and eng.layout.desc.gemm_dtype == 4
-        if self.persistent_shadow:
-            eng.set_persistent_shadow(True)
+        # ``persistent_shadow``: None = the engine's current setting (on by default for bf16 storage); True / False
+        # set it for the engine (a graph replays what was captured: the option is fixed at capture time)
+        if eng.layout.desc.gemm_dtype != 4:
+            self.persistent_shadow = False
+        else:
+            if persistent_shadow is not None:
+                eng.set_persistent_shadow(bool(persistent_shadow))
+            self.persistent_shadow = bool(eng.ctx.get_option(N.OPT_PERSISTENT_SHADOW))
+        self._param_versions = None
         if eng.masks is not None:
             raise RuntimeError("explicit dropout masks cannot be captured; use the Philox stream")
         self.module, self.opt, self.eng, self.batch = module, optimizer, eng, int(batch)
@@ -144,6 +150,12 @@ class CapturedTrainStep:
         # the device-resident (lr, Adam step, dropout step) must be what the host expects: an
         # eager step, optimizer.step() or another captured step in between moves the host side
         want = (float(self.opt.param_groups[0]["lr"]), int(self.opt._t), int(self.eng.rng_step))
+        if self.persistent_shadow:
+            # a Parameter written in place since the last replay (its version counter moved): the image is stale
+            versions = sum(p._version for _, p, _, _ in self.eng._named_params())
+            if versions != self._param_versions:
+                self._param_versions = versions
+                self.eng.invalidate_shadow()
         if want != self._mirror:
             self._write_state()
             self._refresh_shadow()          # an out-of-band step moved the parameters too

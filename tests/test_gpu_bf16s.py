@@ -446,11 +446,13 @@ def test_bn_backward_reductions_in_the_dgrad_epilogue_match_the_streaming_kernel
 
 
 def test_persistent_shadow_is_bit_identical_and_invalidated_by_parameter_writes():
-    """BLH_OPT_PERSISTENT_SHADOW (fused Adam -> bf16 weight image): the same steps with
-    and without it are bit-identical — through plain fused steps, a load_state_dict between two
-    steps (the module drops the image), an unfused optimizer.step, and a captured graph that
-    holds no arena re-cast."""
+    """BLH_OPT_PERSISTENT_SHADOW (fused Adam -> bf16 weight image + the decode weight's K-major image of the
+    one-pass decode; the host layer's default for bf16 storage since round 6): the same steps with and
+    without it are bit-identical — through plain fused steps, a load_state_dict between two steps (the module drops the
+    image), an in-place write to a Parameter (caught through its version counter), an unfused optimizer.step, and a
+    captured graph that holds no arena re-cast."""
     import bilinear_amd
+    from bilinear_amd import _native as N
     dev = _dev()
     x, t = (torch.randn(2048, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(3)),
             torch.randn(2048, 48, device=dev, generator=torch.Generator(device=dev).manual_seed(4)))
@@ -462,12 +464,17 @@ def test_persistent_shadow_is_bit_identical_and_invalidated_by_parameter_writes(
         net.engine.ensure(dev)
         net.engine.seed = 5
         step = None
+        assert net.engine.ctx.get_option(N.OPT_PERSISTENT_SHADOW) == 1          # the default for bf16 storage
         if captured:
             step = bilinear_amd.CapturedTrainStep(net, opt, 2048, persistent_shadow=persistent)
-        elif persistent:
-            net.engine.set_persistent_shadow(True)
+        else:
+            net.engine.set_persistent_shadow(persistent)
         losses = []
-        for i in range(6):
+        for i in range(7):
+            if i == 5:          # an in-place write the engine is not told about: seen through the version counter
+                with torch.no_grad():
+                    net.decode.weight.mul_(0.75)
+                    net.bilinear[0][0][0].weight.add_(0.01)
             if i == 2:          # a checkpoint load between two steps: scaled weights
                 sd = {k: (v * 0.5 if v.dtype.is_floating_point and k.endswith("0.weight") else v)
                       for k, v in net.state_dict().items()}
