@@ -241,6 +241,34 @@ int launch_cast2_f32_bf16(hipStream_t s, const float* src0, uint16_t* dst0, int6
   return BLH_OK;
 }
 
+// thread = 4 consecutive columns n of one row m of dW; products of two bf16 values are exact in fp32
+__global__ __launch_bounds__(256) void wgrad_tail_h_kernel(const bf16_bits* __restrict__ dz, int64_t ld_dz,
+                                                           const bf16_bits* __restrict__ act, int64_t ld_act, int rows,
+                                                           int M, int N, float* __restrict__ out, int accumulate) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = N >> 2;
+  if (idx >= (int64_t)M * n4) return;
+  const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
+  float4 acc = accumulate ? *reinterpret_cast<const float4*>(out + (int64_t)m * N + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = 0; r < rows; ++r) {
+    const float d = bf16_to_f32(dz[r * ld_dz + m]);
+    const uint2 a = *reinterpret_cast<const uint2*>(act + r * ld_act + n);
+    acc.x = fmaf(d, __uint_as_float(a.x << 16), acc.x); acc.y = fmaf(d, __uint_as_float(a.x & 0xffff0000u), acc.y);
+    acc.z = fmaf(d, __uint_as_float(a.y << 16), acc.z); acc.w = fmaf(d, __uint_as_float(a.y & 0xffff0000u), acc.w);
+  }
+  *reinterpret_cast<float4*>(out + (int64_t)m * N + n) = acc;
+}
+
+int launch_wgrad_tail_h(hipStream_t s, const uint16_t* dz, int64_t ld_dz, const uint16_t* act, int64_t ld_act, int rows,
+                        int M, int N, float* out, bool accumulate) {
+  if (rows <= 0 || rows > 7 || M <= 0 || N <= 0 || N % 4 != 0 || ld_act % 4 != 0) return BLH_ERR_SHAPE;
+  const int64_t threads = (int64_t)M * (N / 4);
+  hipLaunchKernelGGL(wgrad_tail_h_kernel, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, s, dz, ld_dz, act, ld_act,
+                     rows, M, N, out, accumulate ? 1 : 0);
+  BLH_HIP_TRY(hipGetLastError());
+  return BLH_OK;
+}
+
 int launch_cast_bf16_f32(hipStream_t s, const uint16_t* src, float* dst, int64_t n) {
   if (n % 4 != 0) return BLH_ERR_SHAPE;
   const int64_t blocks = std::min<int64_t>(ceil_div(n / 4, 256), 4096);

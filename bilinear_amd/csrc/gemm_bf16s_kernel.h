@@ -190,6 +190,10 @@ int gemm_bf16s_tile_rows(int tile);   // rows of one tile = rows per BatchNorm-p
 int gemm_bf16s_tile_cols(int tile);
 void gemm_bf16s_force_tile(int tile);  // 0: automatic; -1: re-read BLH_BF16S_TILE
 int launch_cast_f32_bf16(hipStream_t s, const float* src, uint16_t* dst, int64_t n);
+// out[m][n] (+)= sum_{r < rows} dz[r][m] * act[r][n]  (rows <= 7: the rows a ragged batch leaves behind the 8-row
+// groups of the weight-gradient GEMM); accumulate: add to what `out` holds, else overwrite
+int launch_wgrad_tail_h(hipStream_t s, const uint16_t* dz, int64_t ld_dz, const uint16_t* act, int64_t ld_act, int rows,
+                        int M, int N, float* out, bool accumulate);
 int launch_cast2_f32_bf16(hipStream_t s, const float* src0, uint16_t* dst0, int64_t n0, const float* src1,
                           uint16_t* dst1, int64_t n1, const float* wd_src = nullptr, uint16_t* wdT = nullptr,
                           int wd_W = 0, int wd_OF = 0);   // two tensors, one launch

@@ -123,19 +123,30 @@ int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const fl
 }
 
 // dW = dZ^T act (both bf16, reduction over the batch split into fp32 slabs), summed into `out`
+// dW[M][N] = dZ^T act over `batch` rows.  The GEMM moves 16-byte chunks along the contraction index, i.e. whole groups
+// of 8 rows; a batch that is not a multiple of 8 — the last batch of an epoch of the reference's DataLoader,
+// /root/reference/train_bilinear.py:33-43 (drop_last unset) — runs the GEMM over the first batch - batch % 8 rows and a
+// small kernel adds the outer products of the up to seven rows that are left (r06; such a batch used to be refused).
 static int wgrad_h(hipStream_t s, const uint16_t* dZ, int64_t ld_dz, int M, const uint16_t* act,
                    int64_t ld_act, int N, int64_t batch, float* slabs, float* out) {
-  const Splits sp = wgrad_plan_h(M, N, batch);
-  GemmParamsH g{};
-  g.A = dZ; g.lda = ld_dz; g.B = act; g.ldb = ld_act;
-  g.M = M; g.N = N; g.K = (int)batch; g.k_per_split = sp.k_per; g.ldc = N;
-  if (sp.splits == 1) {
-    g.C = out;
-    return launch_gemm_bf16s(s, KROW, KROW, EPI_STORE, false, g, 1);
+  const int64_t kmain = batch & ~(int64_t)7;
+  const int tail = (int)(batch - kmain);
+  if (kmain > 0) {
+    const Splits sp = wgrad_plan_h(M, N, kmain);
+    GemmParamsH g{};
+    g.A = dZ; g.lda = ld_dz; g.B = act; g.ldb = ld_act;
+    g.M = M; g.N = N; g.K = (int)kmain; g.k_per_split = sp.k_per; g.ldc = N;
+    if (sp.splits == 1) {
+      g.C = out;
+      BLH_TRY(launch_gemm_bf16s(s, KROW, KROW, EPI_STORE, false, g, 1));
+    } else {
+      g.C = slabs; g.c_split_stride = (int64_t)M * N;
+      BLH_TRY(launch_gemm_bf16s(s, KROW, KROW, EPI_STORE, false, g, sp.splits));
+      BLH_TRY(launch_sum_slabs(s, slabs, (int64_t)M * N, sp.splits, out));
+    }
   }
-  g.C = slabs; g.c_split_stride = (int64_t)M * N;
-  BLH_TRY(launch_gemm_bf16s(s, KROW, KROW, EPI_STORE, false, g, sp.splits));
-  return launch_sum_slabs(s, slabs, (int64_t)M * N, sp.splits, out);
+  if (tail) return launch_wgrad_tail_h(s, dZ + kmain * ld_dz, ld_dz, act + kmain * ld_act, ld_act, tail, M, N, out, kmain > 0);
+  return BLH_OK;
 }
 
 // dec_bias_S > 0: the forward ran the fused decode + MSE kernel: ws.dpredh and the decode-bias
