@@ -12,6 +12,8 @@ from . import _native  # noqa: F401
 from .model.bilinear import Bilinear, BilinearUnit, heavy_linear, load  # noqa: F401
 from .graph import CapturedTrainStep  # noqa: F401
 from .optim import Adam, clip_grad_norm_  # noqa: F401
+from .loss_log import LossRing  # noqa: F401
+from . import config  # noqa: F401
 
 __all__ = ["BilinearUnit", "Bilinear", "heavy_linear", "load", "Adam", "clip_grad_norm_",
-           "CapturedTrainStep"]
+           "CapturedTrainStep", "LossRing", "config"]

@@ -601,8 +601,9 @@ class Engine:
             N.ptr(exp_avg_sq), self.layout.total, ctypes.byref(hyper), N.ptr(sc), sc.numel(),
             N.ptr(stats)), "blh_clip_adam_step")
 
-    def train_step(self, x, target, exp_avg, exp_avg_sq, lr, betas, eps, max_norm, step, stats=None):
-        """Whole step body of train_bilinear.py:75-83 as one native enqueue."""
+    def train_step(self, x, target, exp_avg, exp_avg_sq, lr, betas, eps, max_norm, step, stats=None, loss_out=None):
+        """Whole step body of train_bilinear.py:75-83 as one native enqueue.  ``loss_out``: a 0-dim float32 device
+        tensor that receives the loss (e.g. a slot of a loss ring, bilinear_amd.loss_log) instead of a fresh one."""
         x = self._check_input(x)
         self.ensure(x.device)
         batch = x.shape[0]
@@ -620,11 +621,16 @@ class Engine:
             if versions != self._param_versions:
                 self._param_versions = versions
                 self.invalidate_shadow()
-        pred, loss = self._native(
-            "train_step", x, target, self.params, self.grads, exp_avg, exp_avg_sq, self.bn_running, self.bn_nbt,
-            ws, stats, self.masks, *self._op_args(), self.seed, self.rng_step, self.row_offset,
-            self._momentum(), float(lr), float(betas[0]), float(betas[1]), float(eps),
-            0.0 if max_norm is None else float(max_norm), int(step))
+        args = (x, target, self.params, self.grads, exp_avg, exp_avg_sq, self.bn_running, self.bn_nbt,
+                ws, stats, self.masks, *self._op_args(), self.seed, self.rng_step, self.row_offset,
+                self._momentum(), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                0.0 if max_norm is None else float(max_norm), int(step))
+        if loss_out is not None and not torch.compiler.is_compiling():
+            if loss_out.dim() != 0 or loss_out.dtype != torch.float32 or loss_out.device != x.device:
+                raise RuntimeError("loss_out must be a 0-dim float32 tensor on the input's device")
+            pred, loss = _ops.train_step_into(loss_out, *args)
+        else:
+            pred, loss = self._native("train_step", *args)
         self.generation += 1
         self._saved_batch = None
         if self.masks is None:

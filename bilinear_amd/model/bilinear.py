@@ -259,11 +259,12 @@ class BilinearUnit(nn.Module):
                 layer.reset_running_stats()
                 layer.momentum = None
 
-    def train_step(self, optimizer, x, target, max_norm=1.0):
+    def train_step(self, optimizer, x, target, max_norm=1.0, loss_out=None):
         """Fast path for the step body of train_bilinear.py:75-83: zero_grad, forward,
         MSELoss, backward, clip_grad_norm_(max_norm), Adam.step as ONE native enqueue
-        (no autograd graph, no host synchronisation).  Returns (prediction, loss)."""
-        return optimizer.fused_train_step(self, x, target, max_norm)
+        (no autograd graph, no host synchronisation).  Returns (prediction, loss); ``loss_out``
+        (a 0-dim float32 device tensor, e.g. ``bilinear_amd.LossRing.slot()``) receives the loss."""
+        return optimizer.fused_train_step(self, x, target, max_norm, loss_out=loss_out)
 
 
 Bilinear = BilinearUnit   # BASELINE.json names the class `Bilinear`; the reference calls it BilinearUnit

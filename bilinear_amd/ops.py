@@ -133,10 +133,10 @@ def _backward(x, dpred, params, workspace, grads, masks, ctx, num_blocks, width,
 
 def _train_step(x, target, params, grads, exp_avg, exp_avg_sq, bn_running, bn_nbt, workspace,
                 stats, masks, ctx, num_blocks, width, gemm_dtype, seed, step, row_offset, momentum,
-                lr, beta1, beta2, eps, max_norm, adam_step):
+                lr, beta1, beta2, eps, max_norm, adam_step, loss_out=None):
     batch = x.shape[0]
     pred = torch.empty(batch, OUT_FEATURES, dtype=torch.float32, device=x.device)
-    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    loss = torch.empty((), dtype=torch.float32, device=x.device) if loss_out is None else loss_out
     d = _desc(num_blocks, width, gemm_dtype)
     drop = _drop(masks, seed, step, row_offset)
     hyper = N.AdamHyper(lr, beta1, beta2, eps, max_norm, int(adam_step), 0)
@@ -210,6 +210,11 @@ def _lifter_formula(ctx, dpred, dsaved, drunning, dnbt):
 
 
 torch.library.register_autograd("bilinear_hip::lifter_train", _lifter_formula, setup_context=_lifter_setup, lib=_LIB)
+
+def train_step_into(loss_out, *args):
+    """The eager fused step with the loss written into ``loss_out`` (a slot of a loss ring: no extra launch)."""
+    return _train_step(*args, loss_out=loss_out)
+
 
 OPS = ("eval_fwd", "forward_train", "lifter_train", "lifter_backward", "backward", "train_step")
 

@@ -120,7 +120,7 @@ class Adam(torch.optim.Optimizer):
         return None
 
     @torch.no_grad()
-    def fused_train_step(self, module, x, target, max_norm=1.0):
+    def fused_train_step(self, module, x, target, max_norm=1.0, loss_out=None):
         """zero_grad + forward + MSELoss + backward + clip_grad_norm_ + step
         (train_bilinear.py:75-83) as one native enqueue; see BilinearUnit.train_step."""
         engine = _engine_of(module)
@@ -130,7 +130,7 @@ class Adam(torch.optim.Optimizer):
         g = self.param_groups[0]
         self._t += 1
         pred, loss = engine.train_step(x, target, self._exp_avg, self._exp_avg_sq, float(g["lr"]),
-                                       g["betas"], g["eps"], max_norm, self._t, self._stats)
+                                       g["betas"], g["eps"], max_norm, self._t, self._stats, loss_out=loss_out)
         self._sync_step_state(engine)
         for (_, p, _, _), view in zip(engine._named_params(), engine.grad_views()):
             if p.grad is None:

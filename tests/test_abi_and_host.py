@@ -230,3 +230,36 @@ def test_cached_parameter_list_follows_module_surgery():
     with torch.no_grad():
         net.decode.weight.mul_(2.0)
     assert eng._named_params() is d
+
+
+def test_product_lr_decay_hook_is_the_reference_one():
+    """bilinear_amd.config (what train_bilinear.py imports) restates /root/reference/util/config.py:19-23: the hook fires
+    on the pre-increment step at step 1 and every 100000 steps, lr = 1e-3 * 0.96 ** (step / 100000); checked against the
+    oracle's restatement (pinned by the reference's own fixtures: the golden lr values) and by value."""
+    from bilinear_amd import config
+    from oracle import numpy_oracle as O
+    hook = config.bilinear.lr_decay
+    assert hook.activate is True and config.bilinear.batch_size == 64 and config.bilinear.comment == "Bilinear GT"
+    for step in (1, 2, 99999, 100000, 100001, 200000, 250000, 300000, 12345678):
+        assert hook.condition(step) == O.lr_decay_condition(step), step
+        assert hook.function(step) == O.lr_decay_function(step), step
+    assert hook.function(1) == 1.0e-3 * 0.96 ** (1 / 100000) and hook.function(100000) == 1.0e-3 * 0.96
+    assert [s for s in range(1, 200002) if hook.condition(s)] == [1, 100000, 200000]
+
+
+def test_loss_ring_reports_every_step_with_one_readback_per_window():
+    """bilinear_amd.LossRing on the CPU (host logic only): every step's loss reaches the sink in order, read back in
+    windows of `every` steps and at flush(); push() copies a scalar, slot() hands out the tensor to write into."""
+    import torch
+    from bilinear_amd import LossRing
+    got = []
+    ring = LossRing(torch.device("cpu"), every=4, sink=lambda s, v: got.append((s, v)))
+    for step in range(1, 11):
+        if step % 2:
+            ring.slot().fill_(float(step))           # (the fused step writes its loss here)
+        else:
+            ring.push(torch.tensor(float(step)))     # (the five-call loop copies its loss tensor)
+        ring.advance(step)
+        assert len(got) == 4 * (step // 4)           # nothing is read back between two windows
+    ring.flush()
+    assert got == [(s, float(s)) for s in range(1, 11)] and ring.last == 10.0

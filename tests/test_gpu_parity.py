@@ -383,9 +383,9 @@ def test_dropin_steps_match_reference(fname, mode):
     step = 1
     for s in range(g.steps):
         x, t = g.batch_xy(s)
-        if O.lr_decay_condition(step):
+        if bilinear_amd.config.bilinear.lr_decay.condition(step):      # the PRODUCT's hook (what train_bilinear.py runs)
             for pg in opt.param_groups:
-                pg["lr"] = O.lr_decay_function(step)
+                pg["lr"] = bilinear_amd.config.bilinear.lr_decay.function(step)
         net.engine.set_dropout_masks(g.masks(s))
         xt, tt = torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev)
         opt.zero_grad()
@@ -411,15 +411,16 @@ def test_dropin_steps_match_reference(fname, mode):
 @pytest.mark.parametrize("fname", FIXTURES)
 def test_fused_train_step_matches_reference(fname, mode):
     """The same steps through the one-enqueue fast path (blh_train_step)."""
+    import bilinear_amd
     dev = _dev()
     g = Golden(fname)
     net, opt = _build(g, dev, gemm_dtype=mode)
     step = 1
     for s in range(g.steps):
         x, t = g.batch_xy(s)
-        if O.lr_decay_condition(step):
+        if bilinear_amd.config.bilinear.lr_decay.condition(step):
             for pg in opt.param_groups:
-                pg["lr"] = O.lr_decay_function(step)
+                pg["lr"] = bilinear_amd.config.bilinear.lr_decay.function(step)
         net.engine.set_dropout_masks(g.masks(s))
         pred, loss = net.train_step(opt, torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev),
                                     max_norm=1.0)

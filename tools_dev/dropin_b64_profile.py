@@ -1,5 +1,8 @@
 """cProfile of the five-call drop-in step at batch 64 (host-bound: where do the host microseconds go?)."""
 import cProfile
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pstats
 import time
 import torch

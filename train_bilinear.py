@@ -9,10 +9,15 @@ come from a synthetic loader with the real loader's output contract (z-scored fp
 [B,32] / [B,48], H36M/data.py:108-110) and the config values of util/config.py:13-25
 are plain constants below.
 
-    python train_bilinear.py [--fast] [--epochs N] [--steps-per-epoch N]
+    python train_bilinear.py [--fast] [--epochs N] [--steps-per-epoch N] [--log-every N]
 
 --fast uses BilinearUnit.train_step (one native enqueue per step) instead of the
 reference's five separate calls; the numerics are the same.
+
+Every step's loss is reported, as the reference does (:86-88: add_scalar + set_postfix) — but
+through a device ring read back once per --log-every steps (bilinear_amd.LossRing), not with a
+``loss.item()`` synchronisation per step: the lines "step N loss L" go to
+{save-root}/{comment}/loss.log (tensorboardX is not available here).
 """
 import argparse
 import logging
@@ -22,20 +27,11 @@ import torch
 import torch.nn as nn
 
 import bilinear_amd
+from bilinear_amd import config          # util/config.py:13-25 (one place: the tests import the same lambdas)
 from bilinear_amd.data import DevicePoseDataset, SyntheticPoses, synthetic_raw
 
-# util/config.py:13-25
-COMMENT = "Bilinear GT"
-BATCH_SIZE = 64
-LR_DECAY_ACTIVATE = True
-
-
-def lr_decay_condition(step):
-    return step % 100000 == 0 or step == 1
-
-
-def lr_decay_function(step):
-    return 1.0e-3 * 0.96 ** (step / 100000)
+COMMENT = config.bilinear.comment
+BATCH_SIZE = config.bilinear.batch_size
 
 
 def main():
@@ -53,6 +49,8 @@ def main():
                          "stacked-hourglass detections, fine-tuned detections; selects {task}_{protocol}.bin")
     ap.add_argument("--synthetic-poses", type=int, default=0,
                     help="no dataset: N synthetic raw annotations through the same device pipeline")
+    ap.add_argument("--log-every", type=int, default=100,
+                    help="steps between two read-backs of the per-step losses (0: no per-step log)")
     args = ap.parse_args()
 
     logging.basicConfig(level=logging.INFO, format="[%(levelname)s|%(filename)s:%(lineno)s] %(asctime)s > %(message)s")
@@ -79,19 +77,26 @@ def main():
     # that hand-off is the largest single host cost of the step and the noisiest (0.30-0.56 ms per step measured on
     # different boxes against a steady 0.28 on the calling thread, bench.py batch_64.five_call_drop_in).
     torch.autograd.set_multithreading_enabled(False)
+    os.makedirs(log_dir, exist_ok=True)
+    loss_file = open(os.path.join(log_dir, "loss.log"), "a")
+    ring = bilinear_amd.LossRing(device, every=args.log_every,
+                                 sink=lambda s, v: loss_file.write("step %d loss %.9g\n" % (s, v))) \
+        if args.log_every > 0 else None
+    logger.info("Training resumes at epoch %d (step %d)", train_epoch + 1, step)
 
     for epoch in range(train_epoch + 1, train_epoch + args.epochs + 1):
         loss = None
         batches = (dataset.epoch(epoch, args.batch_size, shuffle=True) if dataset is not None
                    else data.epoch(epoch))
         for in_image_space, in_camera_space in batches:
-            if LR_DECAY_ACTIVATE and lr_decay_condition(step):
-                lr = lr_decay_function(step)
+            if config.bilinear.lr_decay.activate and config.bilinear.lr_decay.condition(step):
+                lr = config.bilinear.lr_decay.function(step)
                 logger.info("Learning rate decay to %s (step: %d)", lr, step)
                 for param_group in optimizer.param_groups:
                     param_group["lr"] = lr
             if args.fast:
-                _, loss = bilinear.train_step(optimizer, in_image_space, in_camera_space, max_norm=1.0)
+                _, loss = bilinear.train_step(optimizer, in_image_space, in_camera_space, max_norm=1.0,
+                                              loss_out=ring.slot() if ring is not None else None)
             else:
                 optimizer.zero_grad()
                 prediction = bilinear(in_image_space)
@@ -99,7 +104,14 @@ def main():
                 loss.backward()
                 bilinear_amd.clip_grad_norm_(bilinear.parameters(), max_norm=1, module=bilinear)
                 optimizer.step()
+                if ring is not None:
+                    ring.push(loss)
+            if ring is not None:
+                ring.advance(step)
             step = step + 1
+        if ring is not None:
+            ring.flush()
+            loss_file.flush()
         os.makedirs(parameter_dir, exist_ok=True)
         torch.save({"epoch": epoch, "step": step, "state": bilinear.state_dict(),
                     "optimizer": optimizer.state_dict()},
