@@ -90,14 +90,19 @@ class Engine:
         self._grad_ptr_cache = None
         self._grad_view_cache = None
         self._np_cache = None          # (_named_params list, module links, parameter links, BatchNorm modules)
+        self._packed_cache = None      # (arena pointers, [(tensor owner, attribute or None, expected address)])
 
     # ---------------------------------------------------------------- arenas --
-    def _named_params(self):
+    def _named_params(self, validate=True):
         """[(name, Parameter, arena offset, shape)] in arena order.  Walking ``named_parameters()`` costs ~25 us
         and the drop-in step asks seven times per step (at the reference's batch of 64 the five-call step is
         host-bound), so the list is cached together with the module-tree links it was resolved through; the links
-        (~50 dict lookups) are re-checked on every call, so replacing a submodule or a Parameter object is seen."""
+        (~50 dict lookups) are re-checked on every validating call, so replacing a submodule or a Parameter object is
+        seen.  ``validate=False``: the callers that run BEHIND a forward of the same step (backward, clip_grad_norm_,
+        optimizer.step — the forward validated) take the cached list as it is."""
         c = self._np_cache
+        if c is not None and not validate:
+            return c[0]
         if c is not None:
             ok = True
             for parent, key, child in c[1]:
@@ -128,27 +133,37 @@ class Engine:
         for pair in self.module._modules["bilinear"]._modules.values():
             bns += [pair._modules["0"]._modules["1"], pair._modules["1"]._modules["1"]]
         self._np_cache = (entries, mod_links, par_links, bns)
+        self._packed_cache = None
         return entries
 
     def _bn_modules(self):
         self._named_params()               # (validates / rebuilds the cache the BatchNorm list lives in)
         return self._np_cache[3]
 
-    def is_packed(self, device):
+    def is_packed(self, device, validate=True):
+        """Do every Parameter and BatchNorm buffer still live in the arenas?  (A device address is unique to the device:
+        comparing addresses covers the device check.)  The expected addresses are cached per arena: the per-call work is
+        one data_ptr() per tensor — this runs in every forward, and the five-call step at batch 64 is host-bound."""
         if self.params is None or self.device != device:
             return False
-        base = self.params.data_ptr()
-        for _, p, off, _ in self._named_params():
-            if p.data_ptr() != base + 4 * off or p.device != device:
+        named = self._named_params(validate)
+        key = (self.params.data_ptr(), self.bn_running.data_ptr(), self.bn_nbt.data_ptr())
+        c = self._packed_cache
+        if c is None or c[0] != key:
+            W = self.width
+            par = [(p, key[0] + 4 * off) for _, p, off, _ in named]
+            buf = []
+            for i, bn in enumerate(self._bn_modules()):
+                buf += [(bn._buffers, "running_mean", key[1] + 4 * (2 * i) * W),
+                        (bn._buffers, "running_var", key[1] + 4 * (2 * i + 1) * W),
+                        (bn._buffers, "num_batches_tracked", key[2] + 8 * i)]
+            c = self._packed_cache = (key, par, buf)
+        for p, want in c[1]:
+            if p.data_ptr() != want:
                 return False
-        W = self.width
-        rbase = self.bn_running.data_ptr()
-        for i, bn in enumerate(self._bn_modules()):
-            if bn.running_mean.data_ptr() != rbase + 4 * (2 * i) * W:
-                return False
-            if bn.running_var.data_ptr() != rbase + 4 * (2 * i + 1) * W:
-                return False
-            if bn.num_batches_tracked.data_ptr() != self.bn_nbt.data_ptr() + 8 * i:
+        for owner, name, want in c[2]:
+            t = owner.get(name)
+            if t is None or t.data_ptr() != want:
                 return False
         return True
 
@@ -195,9 +210,9 @@ class Engine:
         self._saved_batch = None
         self.invalidate_shadow()
 
-    def ensure(self, device):
+    def ensure(self, device, validate=True):
         _require_hip(device)
-        if not self.is_packed(device):
+        if not self.is_packed(device, validate):
             self.pack(device)
 
     def grad_view(self, off, shape):
@@ -214,6 +229,15 @@ class Engine:
             c = (self.grads.data_ptr(), [self.grad_view(off, shape) for _, off, shape in self.layout.entries])
             self._grad_view_cache = c
         return c[1]
+
+    def grads_in_arena(self):
+        """True when every Parameter's ``.grad`` IS the cached view of its arena slot (what backward hands out): the
+        usual state between ``loss.backward()`` and ``optimizer.step()``; then nothing has to be gathered."""
+        views = self.grad_views()
+        for (_, p, _, _), v in zip(self._named_params(validate=False), views):
+            if p.grad is not v:
+                return False
+        return True
 
     def grad_ptrs(self):
         """Device addresses of the arena slots, in _named_params() order (cached per gradient arena)."""
@@ -353,11 +377,12 @@ class Engine:
                 errors.append(exc)
         return N.SyncFn(_cb)
 
-    def forward_train(self, x, sync=None, global_batch=None):
+    def forward_train(self, x, sync=None, global_batch=None, validated=False):
         """``sync`` (callable(tensor) -> in-place SUM all-reduce) selects SyncBN: batch
-        statistics over ``global_batch`` rows across ranks."""
+        statistics over ``global_batch`` rows across ranks.  ``validated``: the caller has just walked
+        ``_named_params()`` (BilinearUnit.forward): the module-tree links are not re-checked."""
         x = self._check_input(x)
-        self.ensure(x.device)
+        self.ensure(x.device, validate=not validated)
         batch = x.shape[0]
         if batch < 2:
             raise ValueError("Expected more than 1 value per channel when training, got input size %s"

@@ -145,7 +145,7 @@ class _LifterFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, engine, *params):
-        pred = engine.forward_train(x)
+        pred = engine.forward_train(x, validated=True)      # (BilinearUnit.forward walked _named_params() for *params)
         ctx.engine = engine
         ctx.generation = engine.generation
         ctx.x = x
@@ -159,7 +159,7 @@ class _LifterFunction(torch.autograd.Function):
         old = engine.grads.clone() if accumulate else None
         hook = engine.grad_ready_hook
         engine.backward(ctx.x, dpred, on_ready=hook, generation=ctx.generation)
-        for (_, p, off, shape), view in zip(engine._named_params(), engine.grad_views()):
+        for (_, p, off, shape), view in zip(engine._named_params(validate=False), engine.grad_views()):
             if p.grad is None:
                 p.grad = view
             elif p.grad.data_ptr() == view.data_ptr():

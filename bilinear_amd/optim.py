@@ -88,6 +88,8 @@ class Adam(torch.optim.Optimizer):
     # ------------------------------------------------------------------ steps --
     def _gather_grads(self, engine):
         """Make sure every parameter's gradient sits in the arena slot."""
+        if engine.grads_in_arena():
+            return 0
         missing = 0
         for (_, p, off, shape), ptr in zip(engine._named_params(), engine.grad_ptrs()):
             g = p.grad
@@ -132,7 +134,7 @@ class Adam(torch.optim.Optimizer):
         pred, loss = engine.train_step(x, target, self._exp_avg, self._exp_avg_sq, float(g["lr"]),
                                        g["betas"], g["eps"], max_norm, self._t, self._stats, loss_out=loss_out)
         self._sync_step_state(engine)
-        for (_, p, _, _), view in zip(engine._named_params(), engine.grad_views()):
+        for (_, p, _, _), view in zip(engine._named_params(validate=False), engine.grad_views()):
             if p.grad is None:
                 p.grad = view
         return pred, loss
@@ -157,14 +159,15 @@ def clip_grad_norm_(module_or_parameters, max_norm, module=None):
     engine = _engine_of(module)
     if engine.params is None:
         raise RuntimeError("no gradients: run a forward/backward first")
-    for (_, p, off, shape), ptr in zip(engine._named_params(), engine.grad_ptrs()):
-        g = p.grad
-        if g is None:
-            raise RuntimeError("clip_grad_norm_: a parameter has no gradient")
-        if g.data_ptr() != ptr:
-            view = engine.grad_view(off, shape)
-            view.copy_(g)
-            p.grad = view
+    if not engine.grads_in_arena():
+        for (_, p, off, shape), ptr in zip(engine._named_params(), engine.grad_ptrs()):
+            g = p.grad
+            if g is None:
+                raise RuntimeError("clip_grad_norm_: a parameter has no gradient")
+            if g.data_ptr() != ptr:
+                view = engine.grad_view(off, shape)
+                view.copy_(g)
+                p.grad = view
     stats = torch.empty(2, dtype=torch.float32, device=engine.device)
     sc = engine.scratch()
     N.check(N.lib().blh_clip_grad_norm(engine._stream(), N.ptr(engine.grads), engine.layout.total,

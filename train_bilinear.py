@@ -76,7 +76,7 @@ def main():
     # backward normally hands the graph to the autograd engine's device thread and waits for it; one operator deep,
     # that hand-off is the largest single host cost of the step and the noisiest (0.30-0.56 ms per step measured on
     # different boxes against a steady 0.28 on the calling thread, bench.py batch_64.five_call_drop_in).
-    torch.autograd.set_multithreading_enabled(False)
+    bilinear_amd.configure_for_small_batches()
     os.makedirs(log_dir, exist_ok=True)
     loss_file = open(os.path.join(log_dir, "loss.log"), "a")
     ring = bilinear_amd.LossRing(device, every=args.log_every,
