@@ -274,9 +274,14 @@ class Engine:
         two-stream backward 2x slower, and which pairs are bad depends on what the process created in
         which order — e.g. an RCCL communicator between the two streams (profiles/r04_dp_setup_order.md).
         BLH_NO_STREAM_TUNE=1 switches it off."""
+        lib = N.lib()
+        dev_index = torch._C._cuda_getDevice()
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        if raw is not None:          # (the fast check: no Stream object; this runs in every backward)
+            if Engine._tuned.get((dev_index, raw(dev_index))) == lib.blh_side_stream_generation():
+                return
         st = torch.cuda.current_stream()
         key = (st.device.index, st.cuda_stream)
-        lib = N.lib()
         gen = lib.blh_side_stream_generation()
         if Engine._tuned.get(key) == gen:
             return

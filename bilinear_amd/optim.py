@@ -99,9 +99,35 @@ class Adam(torch.optim.Optimizer):
                 engine.grad_view(off, shape).copy_(g)
         return missing
 
-    @torch.no_grad()
+    def zero_grad(self, set_to_none=True):
+        """optimizer.zero_grad() of train_bilinear.py:75.  torch's version walks the groups through a foreach grouping
+        under a dynamo-disable wrapper (20 us of host time; the five-call step at batch 64 is host-bound): here the
+        22 ``.grad`` fields are dropped (``set_to_none=True``, torch's default) or the gradient arena is zeroed in
+        one launch."""
+        engine = getattr(self._module, "_engine", None)
+        if engine is None or engine.grads is None or torch.compiler.is_compiling():
+            return super().zero_grad(set_to_none)
+        if set_to_none:
+            for _, p, _, _ in engine._named_params(validate=False):
+                p.grad = None
+        elif engine.grads_in_arena():
+            engine.grads.zero_()
+        else:
+            super().zero_grad(False)
+
     def step(self, closure=None):
-        """optimizer.step() of train_bilinear.py:83."""
+        """optimizer.step() of train_bilinear.py:83.  torch wraps every Optimizer.step in a profiler record + hook
+        loop (Optimizer.profile_hook_step: 25 us of host time per call); that wrapper is taken only when a step hook
+        is registered — with none, which is the reference's case, the step runs bare."""
+        from torch.optim import optimizer as _O
+        if (self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks or _O._global_optimizer_pre_hooks
+                or _O._global_optimizer_post_hooks):
+            return Adam._step_with_hooks(self, closure)
+        return self._step_impl(closure)
+    step.hooked = True          # (Optimizer._patch_step_function: do not wrap this one)
+
+    @torch.no_grad()
+    def _step_impl(self, closure=None):
         if closure is not None:
             raise RuntimeError("closures are not supported")
         engine = _engine_of(self._module)
@@ -143,6 +169,9 @@ class Adam(torch.optim.Optimizer):
     def last_grad_norm_stats(self):
         """Device tensor [total_norm, clip_coef] of the last fused step."""
         return self._stats
+
+
+Adam._step_with_hooks = torch.optim.Optimizer.profile_hook_step(Adam._step_impl)
 
 
 @torch.no_grad()

@@ -263,3 +263,31 @@ def test_loss_ring_reports_every_step_with_one_readback_per_window():
         assert len(got) == 4 * (step // 4)           # nothing is read back between two windows
     ring.flush()
     assert got == [(s, float(s)) for s in range(1, 11)] and ring.last == 10.0
+
+
+def test_optimizer_step_hooks_and_zero_grad_survive_the_lean_wrappers():
+    """bilinear_amd.Adam.step skips torch's per-call profiler / hook wrapper when no step hook is registered (host
+    time of the five-call loop) and takes it when one is: pre and post hooks registered the torch way still fire, in
+    order, around the step; zero_grad() keeps torch's semantics (set_to_none default)."""
+    import torch
+    import bilinear_amd
+    net = bilinear_amd.BilinearUnit(num_blocks=1, width=64)
+    opt = bilinear_amd.Adam(net.parameters(), lr=1e-3, module=net)
+    assert getattr(type(opt).step, "hooked", False) is True            # torch did not wrap the class's step
+    calls = []
+    assert opt.step() is None                                           # (no device arenas yet: nothing to do, no hook)
+    h1 = opt.register_step_pre_hook(lambda o, a, k: calls.append("pre"))
+    h2 = opt.register_step_post_hook(lambda o, a, k: calls.append("post"))
+    opt.step()
+    assert calls == ["pre", "post"]
+    h1.remove(); h2.remove()
+    opt.step()
+    assert calls == ["pre", "post"]
+    for p in net.parameters():
+        p.grad = torch.zeros_like(p)
+    opt.zero_grad()
+    assert all(p.grad is None for p in net.parameters())
+    for p in net.parameters():
+        p.grad = torch.ones_like(p)
+    opt.zero_grad(set_to_none=False)
+    assert all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in net.parameters())
