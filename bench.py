@@ -871,6 +871,12 @@ def main():
                     help="developer: at --gpus 1, run the multi-GPU code path (RCCL group of one rank, "
                          "data-parallel driver with every collective issued) — what the step costs before "
                          "the wire; the line says so in config.parallelism")
+    ap.add_argument("--native-rccl", action="store_true",
+                    help="data-parallel step with the collectives issued by the library itself "
+                         "(DataParallel(collectives='native'): blh_train_step_dp, csrc/comm.hip) instead of "
+                         "torch.distributed's process group; opt-in, the line's comm.collectives says which ran")
+    ap.add_argument("--native-tail", choices=("producer", "comm"), default="producer",
+                    help="with --native-rccl: the stream the last bucket and the optimiser run on")
     ap.add_argument("--no-configs", action="store_true",
                     help="N=1, default config: skip the per-config blocks (configs[2], per-GPU shapes of "
                          "configs[3] and configs[4])")
@@ -953,7 +959,10 @@ def main():
         if not init_first:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo") if rehearse else dist.init_process_group("nccl", device_id=dev)
-    dp = DataParallel(net, opt, sync_bn=args.sync_bn, force_collectives=args.rehearse_rccl) if multi else None
+    if args.native_rccl and rehearse:
+        raise SystemExit("--native-rccl needs RCCL (BLH_BENCH_REHEARSE runs over gloo)")
+    dp_kw = dict(collectives="native", native_tail=args.native_tail) if args.native_rccl else {}
+    dp = DataParallel(net, opt, sync_bn=args.sync_bn, force_collectives=args.rehearse_rccl, **dp_kw) if multi else None
     use_graph = (not multi) and args.graph and not args.no_graph
     captured = None
     if use_graph:
@@ -1019,7 +1028,7 @@ def main():
     if multi and strong_pre is not None:
         sb = strong_global // world
         net_s, opt_s = strong_pre
-        dp_s = DataParallel(net_s, opt_s, sync_bn=args.sync_bn, force_collectives=args.rehearse_rccl)
+        dp_s = DataParallel(net_s, opt_s, sync_bn=args.sync_bn, force_collectives=args.rehearse_rccl, **dp_kw)
         if sb <= args.batch:
             xs, ts = x[:sb].contiguous(), t[:sb].contiguous()
         else:                                   # (a rehearsal with a tiny --batch)
@@ -1050,6 +1059,9 @@ def main():
     # what the ranks ran on (collective: every rank takes part); N = 1 without a process group has nothing to gather
     comm = comm_block(device_identity(dev), rehearse, native=bool(getattr(args, "native_rccl", False))) \
         if (multi and dist.is_initialized()) else None
+    if comm is not None and args.native_rccl and dp is not None:
+        # the library's own communicator, as it reports itself: world, RCCL version, collectives issued so far
+        comm["native_comm"] = dict(dp.native_comm().info(), tail=args.native_tail)
     n_devices = comm["n_distinct_devices"] if comm is not None else 1
     rehearsal = comm["rehearsal"] if comm is not None else None
 

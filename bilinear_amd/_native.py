@@ -154,6 +154,20 @@ _SIGNATURES = {
     "blh_linear_fwd_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int64, c_int64, c_int64]),
     "blh_dropout_mask": (c_int, [c_void_p, POINTER(Dropout), c_int32, c_int64, c_int32, c_void_p]),
+    # collectives issued by the library (opt-in data-parallel path, csrc/comm.hip)
+    "blh_rccl_version": (c_int, []),
+    "blh_rccl_unique_id": (c_int, [c_void_p, c_int64]),
+    "blh_comm_create": (c_int, [POINTER(c_void_p), c_void_p, c_int64, c_int32, c_int32]),
+    "blh_comm_destroy": (c_int, [c_void_p]),
+    "blh_comm_info": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
+    "blh_comm_stream": (c_void_p, [c_void_p]),
+    "blh_comm_all_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32]),
+    "blh_comm_broadcast": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32]),
+    "blh_comm_last_error": (c_char_p, []),
+    "blh_train_step_dp": (c_int, [c_void_p, c_void_p, POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Dropout), c_float,
+                                  POINTER(AdamHyper), c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                  c_int64, c_int64, SyncFn, c_void_p, c_int32]),
 }
 
 _lib = None
@@ -225,6 +239,69 @@ class Context:
             pass
 
 
+DP_TAIL_ON_COMM_STREAM = 1     # blh_train_step_dp flag (include/bilinear_hip.h)
+UNIQUE_ID_BYTES = 128
+
+
+class Comm:
+    """Owner of one ``blh_comm`` (include/bilinear_hip.h): an RCCL communicator the LIBRARY drives, with its own
+    collective stream, on the current device.  ``unique_id``: the 128 bytes rank 0 got from ``rccl_unique_id()``.
+    Creating it is a collective call (every rank of the communicator)."""
+
+    def __init__(self, device, unique_id, world, rank):
+        import torch
+        self.device = torch.device(device)
+        if len(unique_id) != UNIQUE_ID_BYTES:
+            raise ValueError("an RCCL unique id has %d bytes" % UNIQUE_ID_BYTES)
+        handle = c_void_p()
+        buf = ctypes.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
+        with torch.cuda.device(self.device):
+            check(lib().blh_comm_create(ctypes.byref(handle), buf, UNIQUE_ID_BYTES, int(world), int(rank)),
+                  "blh_comm_create")
+        self.handle = handle
+        self.world, self.rank = int(world), int(rank)
+
+    def info(self):
+        w, r, v, n = c_int32(), c_int32(), c_int32(), c_int64()
+        check(lib().blh_comm_info(self.handle, ctypes.byref(w), ctypes.byref(r), ctypes.byref(v), ctypes.byref(n)),
+              "blh_comm_info")
+        return {"world": w.value, "rank": r.value, "rccl_version": v.value, "collectives_issued": n.value}
+
+    def all_reduce(self, tensor, average=False):
+        """In place, on torch's current stream."""
+        import torch
+        dt = {torch.float32: 0, torch.float64: 1, torch.bfloat16: 2}[tensor.dtype]
+        if not tensor.is_contiguous():
+            raise RuntimeError("all_reduce needs a contiguous tensor")
+        check(lib().blh_comm_all_reduce(self.handle, current_stream(), ptr(tensor), tensor.numel(), dt,
+                                        1 if average else 0), "blh_comm_all_reduce")
+
+    def broadcast(self, tensor, root=0):
+        if not tensor.is_contiguous():
+            raise RuntimeError("broadcast needs a contiguous tensor")
+        check(lib().blh_comm_broadcast(self.handle, current_stream(), ptr(tensor),
+                                       tensor.numel() * tensor.element_size(), int(root)), "blh_comm_broadcast")
+
+    def destroy(self):
+        if self.handle and _lib is not None:
+            h, self.handle = self.handle, None
+            check(_lib.blh_comm_destroy(h), "blh_comm_destroy")
+
+    def __del__(self):
+        try:
+            if self.handle and _lib is not None:
+                _lib.blh_comm_destroy(self.handle)
+                self.handle = None
+        except Exception:   # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+def rccl_unique_id():
+    buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
+    check(lib().blh_rccl_unique_id(buf, UNIQUE_ID_BYTES), "blh_rccl_unique_id")
+    return bytes(buf.raw)
+
+
 _contexts = {}
 
 
@@ -250,6 +327,8 @@ def check(status, what):
         msg = l.blh_status_string(int(status)).decode()
         if status == -3:
             msg += " (hipError_t %d)" % l.blh_last_hip_error()
+        if status == -5:
+            msg += ": " + l.blh_comm_last_error().decode()
         raise RuntimeError("bilinear_amd: %s failed: %s" % (what, msg))
 
 

@@ -46,6 +46,7 @@ const char* blh_status_string(int status) {
     case BLH_ERR_SHAPE: return "unsupported shape";
     case BLH_ERR_HIP: return "HIP runtime error";
     case BLH_ERR_WORKSPACE: return "workspace too small";
+    case BLH_ERR_COMM: return "RCCL unavailable or an RCCL call failed (blh_comm_last_error)";
   }
   return "unknown status";
 }

@@ -186,7 +186,27 @@ class DataParallel:
     """
 
     def __init__(self, module, optimizer, group=None, bucket_floats=None, max_norm=1.0,
-                 sync_bn=False, force_collectives=False, compress=None):
+                 sync_bn=False, force_collectives=False, compress=None, collectives="torch",
+                 native_tail="producer"):
+        """``collectives``: ``"torch"`` (default) — every bucket all-reduce is launched from blh_backward's hook
+        through ``torch.distributed``; ``"native"`` (opt-in, HIP devices, fp32 buckets) — the LIBRARY owns an RCCL
+        communicator of its own (``blh_comm``: created here from a unique id broadcast over ``group``) and the whole
+        step is one call, ``blh_train_step_dp``: bucket all-reduces enqueued by backward itself behind the kernel that
+        completes each bucket, norm + clip + Adam right behind the last one, one join (csrc/comm.hip,
+        profiles/r06_dp_overhead.md).  Same buckets, same arithmetic: the two modes give bit-identical parameters.
+        N > 1 ranks were never available to this repository — both modes are executed at world size 1 with every
+        collective issued (``force_collectives``) and over gloo on the CPU (torch mode only).
+        ``native_tail``: ``"producer"`` (the last bucket and the optimiser ride the stream that produced the last
+        gradient) or ``"comm"`` (they run on the communicator's stream)."""
+        if collectives not in ("torch", "native"):
+            raise ValueError("collectives must be 'torch' or 'native'")
+        if native_tail not in ("producer", "comm"):
+            raise ValueError("native_tail must be 'producer' or 'comm'")
+        if collectives == "native" and compress is not None:
+            raise ValueError("collectives='native' exchanges fp32 buckets (compress is a torch-mode option)")
+        self.collectives = collectives
+        self.native_tail = native_tail
+        self._comm = None
         self.force_collectives = bool(force_collectives)
         self.compress = compress
         self.module = module
@@ -229,6 +249,30 @@ class DataParallel:
     def _all_reduce_sum(self, tensor):
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
 
+    def native_comm(self):
+        """The library-owned communicator of ``collectives="native"`` (created at the first step: a collective call).
+        Rank 0 draws the RCCL unique id, the existing process group carries its 128 bytes to the other ranks."""
+        if self._comm is None:
+            from . import _native as N
+            eng = self.module.engine
+            dev = eng.device if eng.device is not None else next(self.module.parameters()).device
+            if dev.type != "cuda":
+                raise RuntimeError("collectives='native' needs a HIP device (RCCL); use the torch mode over gloo")
+            if dev.index is None:
+                dev = torch.device("cuda", torch.cuda.current_device())
+            if dist.is_initialized() and self.world > 1:
+                on_dev = dist.get_backend(self.group) == "nccl"
+                buf = torch.zeros(N.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev if on_dev else "cpu")
+                if self.rank == 0:
+                    buf.copy_(torch.frombuffer(bytearray(N.rccl_unique_id()), dtype=torch.uint8))
+                src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+                dist.broadcast(buf, src=src, group=self.group)
+                uid = bytes(buf.cpu().numpy().tobytes())
+            else:
+                uid = N.rccl_unique_id()
+            self._comm = N.Comm(dev, uid, self.world, self.rank)
+        return self._comm
+
     def broadcast_parameters(self):
         eng = self.module.engine
         if self.world > 1:
@@ -248,7 +292,59 @@ class DataParallel:
         cur.wait_stream(st)
         return out
 
+    def _train_step_native(self, x, target):
+        """The whole data-parallel step as one native call (blh_train_step_dp)."""
+        import ctypes
+
+        from . import _native as N
+        from .engine import OUT_FEATURES
+        eng, opt = self.module.engine, self.optimizer
+        comm = self.native_comm()
+        x = eng._check_input(x)
+        batch = x.shape[0]
+        if batch < 2:
+            raise ValueError("Expected more than 1 value per channel when training")
+        target = target.contiguous()
+        if tuple(target.shape) != (batch, OUT_FEATURES) or target.dtype != torch.float32:
+            raise RuntimeError("bad target: %s %s" % (tuple(target.shape), target.dtype))
+        want = self.bucket_floats if self.bucket_floats else max(1 << 20, eng.layout.total // 4)
+        if getattr(eng, "_bucket_floats_set", None) != want:
+            eng.ctx.set_option(N.OPT_BUCKET_FLOATS, min(int(want), (1 << 31) - 1))
+            eng._bucket_floats_set = want
+        eng.row_offset = self.rank * batch
+        ws = eng.workspace(batch)
+        drop = eng._drop_struct(batch)
+        eng._tune_streams()
+        opt._ensure_moments(eng)
+        g = opt.param_groups[0]
+        opt._t += 1
+        hyper = N.AdamHyper(float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
+                            0.0 if self.max_norm is None else float(self.max_norm), opt._t, 0)
+        pred = torch.empty(batch, OUT_FEATURES, dtype=torch.float32, device=x.device)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        errors = []
+        use_sync = self.sync_bn and (self.world > 1 or self.force_collectives)
+        scb = eng._sync_callback(ws, self._all_reduce_sum, errors) if use_sync else ctypes.cast(None, N.SyncFn)
+        flags = N.DP_TAIL_ON_COMM_STREAM if self.native_tail == "comm" else 0
+        eng.invalidate_shadow()
+        N.check(N.lib().blh_train_step_dp(
+            eng.ctx.handle, comm.handle, ctypes.byref(eng.layout.desc), eng._stream(), N.ptr(eng.params),
+            N.ptr(eng.grads), N.ptr(opt._exp_avg), N.ptr(opt._exp_avg_sq), N.ptr(eng.bn_running), N.ptr(eng.bn_nbt),
+            N.ptr(x), N.ptr(target), ctypes.byref(drop), eng._momentum(), ctypes.byref(hyper), None, N.ptr(ws),
+            ws.numel(), N.ptr(pred), N.ptr(loss), N.ptr(opt._stats), batch, batch * self.world, scb, None, flags),
+            "blh_train_step_dp")
+        if errors:
+            raise errors[0]
+        eng.generation += 1
+        eng._saved_batch = None
+        if eng.masks is None:
+            eng.rng_step += 1
+        opt._sync_step_state(eng)
+        return pred, loss
+
     def _train_step(self, x, target):
+        if self.collectives == "native":
+            return self._train_step_native(x, target)
         eng = self.module.engine
         opt = self.optimizer
         if self._reducer is None or self._reducer.flat.data_ptr() != eng.grads.data_ptr():

@@ -41,15 +41,18 @@ extern "C" {
 #endif
 
 /* 5 (round 6): blh_context_grid_barrier_timeouts, BLH_OPT_DEFER_SLABS and BLH_OPT_SMALL_STEP = 2 (the persistent
- * small-batch launches) were removed with the slower opt-in variants they served; blh_rccl_* added.        */
-#define BLH_ABI_VERSION 5
+ * small-batch launches) were removed with the slower opt-in variants they served.
+ * 6 (round 6): blh_comm_* / blh_rccl_* / blh_train_step_dp (collectives issued by the library) and BLH_ERR_COMM added;
+ * nothing removed or changed.                                                                              */
+#define BLH_ABI_VERSION 6
 
 typedef enum {
   BLH_OK = 0,
   BLH_ERR_INVALID_ARGUMENT = -1, /* NULL pointer, non-positive size, bad enum   */
   BLH_ERR_SHAPE = -2,            /* shape the kernels do not support            */
   BLH_ERR_HIP = -3,              /* a HIP runtime call failed                   */
-  BLH_ERR_WORKSPACE = -4         /* workspace smaller than blh_workspace_bytes  */
+  BLH_ERR_WORKSPACE = -4,        /* workspace smaller than blh_workspace_bytes  */
+  BLH_ERR_COMM = -5              /* librccl.so missing or an RCCL call failed: blh_comm_last_error() */
 } blh_status;
 
 const char* blh_status_string(int status);
@@ -410,6 +413,51 @@ int blh_context_set_step_state(blh_context* ctx, const blh_step_state* dev_state
 int blh_clip_adam_step_captured(void* stream, float* params, float* grads, float* exp_avg,
                                 float* exp_avg_sq, int64_t count, const blh_step_state* dev_state,
                                 void* workspace, int64_t workspace_bytes, float* stats_out);
+
+/* ---- data parallel with collectives issued by the library (round 6, opt-in) -----------------------------
+ * New work: the reference is single-device (util/config.py:17); the step body is train_bilinear.py:75-83 on this
+ * rank's rows.  The default data-parallel driver launches the bucket all-reduces from blh_backward's host hook
+ * through torch.distributed; these entry points let the library call RCCL itself (librccl.so is resolved with
+ * dlopen at the first call — the copy the process already holds, i.e. torch's inside a PyTorch process; the library
+ * loads and every other entry point works without it).
+ *   blh_rccl_version: ncclGetVersion of the library found (0: none).
+ *   blh_rccl_unique_id: ncclGetUniqueId into id_out (id_bytes must be 128); rank 0 calls it and hands the bytes
+ *     to the other ranks by any means (the shipped host code: a broadcast over the existing process group).
+ *   blh_comm_create: ncclCommInitRank on the CURRENT device + a collective stream and events of its own.  Collective
+ *     call: every rank of the communicator.  blh_comm_destroy waits for the collective stream, then destroys.
+ *   blh_comm_all_reduce / blh_comm_broadcast: one in-place collective enqueued on `stream` (dtype 0 fp32, 1 fp64,
+ *     2 bf16; average != 0: ncclAvg, else ncclSum; broadcast counts bytes).
+ *   blh_comm_last_error: text of the last BLH_ERR_COMM on this thread.                                             */
+typedef struct blh_comm blh_comm;
+int blh_rccl_version(void);
+int blh_rccl_unique_id(void* id_out, int64_t id_bytes);
+int blh_comm_create(blh_comm** out, const void* unique_id, int64_t id_bytes, int32_t world, int32_t rank);
+int blh_comm_destroy(blh_comm* comm);
+int blh_comm_info(const blh_comm* comm, int32_t* world, int32_t* rank, int32_t* rccl_version,
+                  int64_t* collectives_issued);
+void* blh_comm_stream(blh_comm* comm);
+int blh_comm_all_reduce(blh_comm* comm, void* stream, void* buf, int64_t count, int32_t dtype, int32_t average);
+int blh_comm_broadcast(blh_comm* comm, void* stream, void* buf, int64_t bytes, int32_t root);
+const char* blh_comm_last_error(void);
+/* The data-parallel step as ONE enqueue: blh_forward_train_loss on this rank's `batch` rows, blh_backward with every
+ * bucket (the ranges blh_backward reports, merged as BLH_OPT_BUCKET_FLOATS says) all-reduced (ncclAvg, fp32, in place
+ * in `grads`) behind the kernel that completes it — on the communicator's own stream, so the exchange of stage l
+ * overlaps the backward GEMMs of the stages below — then the norm of the AVERAGED gradients, clip and Adam
+ * (blh_clip_adam_step) right behind the last bucket, and `stream` joined once at the end.  The LAST bucket (it holds
+ * the encode stage) and the optimiser run on the stream that produced the last gradient (no queue hop in the tail);
+ * BLH_DP_TAIL_ON_COMM_STREAM puts them on the communicator's stream instead.  loss_out: the GLOBAL batch's loss (mean
+ * of the per-rank means; exchanged together with the last bucket).  global_batch must be batch * world.  Exactly one
+ * of `hyper` / `dev_state` is given: dev_state selects the capturable form (as blh_train_step_captured; RCCL calls
+ * are captured like kernels).  sync != NULL: SyncBN through the caller's callback (blh_forward_train_loss_sync).
+ * Results equal blh_forward_train_loss + blh_backward + all-reduce(avg) per bucket + blh_clip_adam_step.           */
+#define BLH_DP_TAIL_ON_COMM_STREAM 1
+int blh_train_step_dp(blh_context* ctx, blh_comm* comm, const blh_model_desc* d, void* stream, float* params,
+                      float* grads, float* exp_avg, float* exp_avg_sq, float* bn_running,
+                      int64_t* bn_num_batches_tracked, const float* x, const float* target,
+                      const blh_dropout* drop, float momentum, const blh_adam_hyper* hyper,
+                      blh_step_state* dev_state, void* workspace, int64_t workspace_bytes, float* pred,
+                      float* loss_out, float* stats_out, int64_t batch, int64_t global_batch, blh_sync_fn sync,
+                      void* sync_user, int32_t flags);
 
 /* ---- one heavy_linear stage on its own --------------------------------------------------
  * model/bilinear.py:7-13 as a stand-alone module: a_out = Dropout(ReLU(BN(a_in W^T + b))).

@@ -31,9 +31,31 @@ def test_library_exports_every_declared_symbol(native):
         assert hasattr(native, name), "libbilinear_hip.so does not export %s" % name
     from bilinear_amd import _native
     assert sorted(_native.exported_names()) == decl, "ctypes table and header disagree"
-    assert native.blh_abi_version() == 5
+    assert native.blh_abi_version() == 6
     assert native.blh_status_string(0) == b"ok"
     assert native.blh_status_string(-4) == b"workspace too small"
+    assert b"RCCL" in native.blh_status_string(-5)
+
+
+def test_comm_entry_points_validate_without_gpu(native):
+    """csrc/comm.hip: librccl is resolved with dlopen (torch's copy is in the process), nothing is called on a device
+    here — argument checks only."""
+    from bilinear_amd import _native as N
+    assert native.blh_rccl_version() >= 20000          # an NCCL-style version code, e.g. 22606
+    buf = ctypes.create_string_buffer(128)
+    assert native.blh_rccl_unique_id(buf, 64) == -1    # an id has 128 bytes
+    assert native.blh_rccl_unique_id(None, 128) == -1
+    h = ctypes.c_void_p()
+    assert native.blh_comm_create(ctypes.byref(h), buf, 128, 0, 0) == -1       # world < 1
+    assert native.blh_comm_create(ctypes.byref(h), buf, 128, 2, 2) == -1       # rank out of range
+    assert native.blh_comm_create(ctypes.byref(h), buf, 100, 1, 0) == -1
+    assert not h.value
+    assert native.blh_comm_destroy(None) == 0
+    assert native.blh_comm_info(None, None, None, None, None) == -1
+    assert native.blh_comm_all_reduce(None, None, None, 4, 0, 0) == -1
+    assert native.blh_comm_stream(None) is None
+    with pytest.raises(ValueError):
+        N.Comm("cuda:0", b"x" * 5, 1, 0)
 
 
 def test_arena_layout_matches_reference_parameter_order(native):

@@ -484,6 +484,112 @@ def test_rccl_world1_runs_every_collective_of_the_step(tmp_path):
     assert os.path.exists(tmp_path / "rccl_ok")
 
 
+# ----------------------------------------------------------------------------
+# Collectives issued by the LIBRARY (DataParallel(collectives="native"), csrc/comm.hip: blh_comm + blh_train_step_dp):
+# RCCL reached through dlopen, one communicator of the library's own, every bucket all-reduce enqueued by backward
+# itself, norm + clip + Adam behind the last bucket.  World size 1 with every collective issued (the only RCCL world
+# this pool offers): same buckets, same arithmetic as the torch-driven step => bit-identical state after 3 steps.
+# ----------------------------------------------------------------------------
+def _worker_native(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from bilinear_amd import _native as N
+        from bilinear_amd.dp import DataParallel
+        assert N.lib().blh_rccl_version() > 0
+        for cfg, bucket in (((1, 1024, 2048, "fp32"), 200000), ((2, 1024, 4096, "fp32"), 1 << 20),
+                            ((2, 1024, 4096, "bf16s"), 1 << 20), ((2, 1024, 4100, "bf16s"), 1 << 20)):
+            x, t = _data(dev, cfg)
+            x, t = x[:cfg[2]].contiguous(), t[:cfg[2]].contiguous()
+            out = {}
+            for name, kw in (("torch", dict()), ("native", dict(collectives="native")),
+                             ("native_comm_tail", dict(collectives="native", native_tail="comm"))):
+                net, opt = _make(dev, cfg)
+                dp = DataParallel(net, opt, bucket_floats=bucket, force_collectives=True, **kw)
+                losses = []
+                for i in range(3):
+                    if i == 2:
+                        opt.param_groups[0]["lr"] = 5e-4          # the lr-decay hook between steps
+                    pred, loss = dp.train_step(x, t)
+                    losses.append(float(loss.item()))
+                torch.cuda.synchronize()
+                if name == "torch":
+                    nbuckets = len(dp._reducer.launched)
+                    assert nbuckets >= 2
+                else:
+                    info = dp.native_comm().info()
+                    assert info["world"] == 1 and info["rccl_version"] > 0
+                    # every bucket + the loss, three times
+                    assert info["collectives_issued"] == 3 * (nbuckets + 1), (info, nbuckets)
+                st = opt.last_grad_norm_stats().clone()
+                out[name] = (net.engine.params.clone(), net.engine.bn_running.clone(), opt._exp_avg.clone(),
+                             opt._exp_avg_sq.clone(), net.engine.grads.clone(), losses, pred.clone(), st)
+            for name in ("native", "native_comm_tail"):
+                for a, b in zip(out["torch"][:5], out[name][:5]):
+                    assert torch.equal(a, b), (cfg, name)
+                assert out["torch"][5] == out[name][5], (cfg, name, out["torch"][5], out[name][5])
+                assert torch.equal(out["torch"][6], out[name][6]) and torch.equal(out["torch"][7], out[name][7])
+            assert out["torch"][5][-1] < out["torch"][5][0]
+
+        # SyncBN rides the caller's callback (torch's process group) beside the library's buckets
+        cfg = (1, 1024, 2048, "fp32")
+        x, t = _data(dev, cfg)
+        x, t = x[:cfg[2]].contiguous(), t[:cfg[2]].contiguous()
+        res = []
+        for kw in (dict(), dict(collectives="native")):
+            net, opt = _make(dev, cfg)
+            dp = DataParallel(net, opt, bucket_floats=200000, force_collectives=True, sync_bn=True, **kw)
+            for _ in range(2):
+                dp.train_step(x, t)
+            torch.cuda.synchronize()
+            res.append((net.engine.params.clone(), net.engine.bn_running.clone()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+        # the communicator on its own: in-place all-reduce / broadcast on the current stream
+        comm = dp.native_comm()
+        v = torch.arange(1000, dtype=torch.float32, device=dev)
+        comm.all_reduce(v, average=True)
+        comm.all_reduce(v)
+        w = torch.arange(64, dtype=torch.float64, device=dev)
+        comm.all_reduce(w)
+        b = torch.arange(100, dtype=torch.int64, device=dev)
+        comm.broadcast(b, root=0)
+        torch.cuda.synchronize()
+        assert torch.equal(v, torch.arange(1000, dtype=torch.float32, device=dev))
+        assert torch.equal(w, torch.arange(64, dtype=torch.float64, device=dev))
+        assert torch.equal(b, torch.arange(100, dtype=torch.int64, device=dev))
+        # refusals: a global batch that is not batch * world, a bad unique id
+        import ctypes
+        eng = net.engine
+        ws = eng.workspace(cfg[2])
+        drop = eng._drop_struct(cfg[2])
+        hyper = N.AdamHyper(1e-3, 0.9, 0.999, 1e-8, 1.0, 1, 0)
+        pred = torch.empty(cfg[2], 48, device=dev)
+        loss = torch.empty((), device=dev)
+        rc = N.lib().blh_train_step_dp(
+            eng.ctx.handle, comm.handle, ctypes.byref(eng.layout.desc), eng._stream(), N.ptr(eng.params),
+            N.ptr(eng.grads), N.ptr(opt._exp_avg), N.ptr(opt._exp_avg_sq), N.ptr(eng.bn_running), N.ptr(eng.bn_nbt),
+            N.ptr(x), N.ptr(t), ctypes.byref(drop), 0.1, ctypes.byref(hyper), None, N.ptr(ws), ws.numel(),
+            N.ptr(pred), N.ptr(loss), None, cfg[2], 2 * cfg[2], ctypes.cast(None, N.SyncFn), None, 0)
+        assert rc == -1, rc
+        with pytest.raises(ValueError):
+            N.Comm(dev, b"short", 1, 0)
+        comm.destroy()
+        dp._comm = None
+        open(os.path.join(out_dir, "native_ok"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_native_collectives_world1_equal_the_torch_driven_step(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_native, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    assert os.path.exists(tmp_path / "native_ok")
+
+
 def test_set_up_order_does_not_change_the_step_time():
     """Round 3 found the data-parallel step 2.3-3.0 ms instead of 1.1 ms when the model was built before
     the RCCL process group; round 4 found the cause (the compute stream and the library's side stream
