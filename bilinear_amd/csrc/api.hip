@@ -340,36 +340,53 @@ int blh_forward_train(blh_context* ctx, const blh_model_desc* d, void* stream, c
                       pred, batch, true, nullptr, 0.f, nullptr, nullptr);
 }
 
-int blh_forward_train_loss(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params,
-                           float* bn_running, int64_t* bn_nbt, const float* x, const float* target,
-                           const blh_dropout* drop, float momentum, void* workspace,
-                           int64_t workspace_bytes, float* pred, float* loss_out, int64_t batch) {
+}  // extern "C"
+
+// blh_forward_train_loss with two switches for the step that owns the whole call sequence (comm.hip: blh_train_step_dp):
+// shadow_valid — bf16 storage: the bf16 parameter image in the workspace is up to date (the previous step's Adam
+// kernel wrote it), skip the re-cast; pending != NULL — do NOT launch loss_finalize: the partial sums, their count and
+// the denominator are returned for the caller to finalise where it costs nothing (off the main stream).
+int blh::forward_train_loss_core(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
+                                 float* bn_running, int64_t* bn_nbt, const float* x, const float* target,
+                                 const blh_dropout* drop, float momentum, void* workspace, int64_t workspace_bytes,
+                                 float* pred, float* loss_out, int64_t batch, bool shadow_valid, PendingLoss* pending) {
   BLH_TRY(check_common(ctx, d, workspace, workspace_bytes, batch));
   BLH_TRY(check_drop(drop));
   if (!params || !bn_running || !bn_nbt || !x || !target || !pred || !loss_out) return BLH_ERR_INVALID_ARGUMENT;
   if (batch < 2) return BLH_ERR_SHAPE;
-  hipStream_t s = (hipStream_t)stream;
   const double denom = (double)batch * d->out_features;
   int nparts = 0;
   ctx->loss_batch = 0;
   if (d->gemm_dtype == 4) {
     const WorkspaceH wh = carve_h(d, batch, workspace);
     int dec_S = 0;
-    BLH_TRY(forward_h(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, wh, pred, batch, true, false,
+    BLH_TRY(forward_h(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, wh, pred, batch, true, shadow_valid,
                       target, (float)(2.0 / denom), &dec_S));
     if (dec_S > 0) nparts = dec_S;
     else BLH_TRY(launch_mse(s, pred, target, batch * d->out_features, (float)(2.0 / denom), wh.dpred,
                             wh.loss_part, &nparts));
-    BLH_TRY(launch_loss_finalize(s, wh.loss_part, nparts, denom, loss_out));
+    if (pending) *pending = PendingLoss{wh.loss_part, nparts, denom};
+    else BLH_TRY(launch_loss_finalize(s, wh.loss_part, nparts, denom, loss_out));
     ctx->loss_batch = batch; ctx->loss_nparts = dec_S;
     return BLH_OK;
   }
   const Workspace ws = carve(d, batch, workspace);
   BLH_TRY(forward_impl(ctx, d, s, params, bn_running, bn_nbt, x, drop, momentum, ws, pred, batch, true,
                        target, (float)(2.0 / denom), ws.loss_part, &nparts));
-  BLH_TRY(launch_loss_finalize(s, ws.loss_part, nparts, denom, loss_out));
+  if (pending) *pending = PendingLoss{ws.loss_part, nparts, denom};
+  else BLH_TRY(launch_loss_finalize(s, ws.loss_part, nparts, denom, loss_out));
   ctx->loss_batch = batch; ctx->loss_nparts = nparts;
   return BLH_OK;
+}
+
+extern "C" {
+
+int blh_forward_train_loss(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params,
+                           float* bn_running, int64_t* bn_nbt, const float* x, const float* target,
+                           const blh_dropout* drop, float momentum, void* workspace,
+                           int64_t workspace_bytes, float* pred, float* loss_out, int64_t batch) {
+  return forward_train_loss_core(ctx, d, (hipStream_t)stream, params, bn_running, bn_nbt, x, target, drop, momentum,
+                                 workspace, workspace_bytes, pred, loss_out, batch, false, nullptr);
 }
 
 int blh_forward_eval(blh_context* ctx, const blh_model_desc* d, void* stream, const float* params,

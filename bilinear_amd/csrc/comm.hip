@@ -134,6 +134,8 @@ struct DpCall {
                             // everything the main stream ran, the first is not (the one-pass decode carries the
                             // side stream's fork as its completion signal, loss_finalize runs behind it)
   bool tail_on_producer;    // the last bucket (offset 0) rides the producer stream itself
+  PendingLoss pend;         // the forward's loss partials, not yet finalised: the first bucket's turn on the producer
+  float* loss_dst;          // stream does it (behind the decode kernel that wrote them; nothing waits for it there)
   bool used_cs = false;
   bool last_seen = false;
   int status = BLH_OK;
@@ -154,6 +156,10 @@ int all_reduce_avg_f32(blh_comm* c, hipStream_t st, float* buf, int64_t count, f
 int bucket_ready(DpCall* k, int64_t off, int64_t cnt) {
   blh_comm* c = k->c;
   const bool last = off == 0;            // backward walks the arena downwards: the encode stage closes it
+  if (k->pend.part) {
+    BLH_TRY(launch_loss_finalize(k->producer, k->pend.part, k->pend.n, k->pend.denom, k->loss_dst));
+    k->pend.part = nullptr;
+  }
   float* extra = last ? k->loss : nullptr;
   if (last) { k->last_seen = true; k->loss = nullptr; }
   if (last && k->tail_on_producer) {
@@ -292,16 +298,31 @@ int blh_train_step_dp(blh_context* ctx, blh_comm* comm, const blh_model_desc* d,
   };
   if (dev_state) BLH_TRY(launch_step_state_advance(s, dev_state));
   StepDevGuard guard(ctx, dev_state ? &dev_state->rng_step : nullptr);
-  // forward + MSE (the local batch's mean loss in loss_out, its gradient in the workspace)
-  if (sync)
-    BLH_TRY(blh_forward_train_loss_sync(ctx, d, s, params, bn_running, bn_nbt, x, target, drop, momentum, workspace,
-                                        workspace_bytes, pred, loss_out, batch, global_batch, sync, sync_user));
-  else
-    BLH_TRY(blh_forward_train_loss(ctx, d, s, params, bn_running, bn_nbt, x, target, drop, momentum, workspace,
-                                   workspace_bytes, pred, loss_out, batch));
+  // forward + MSE: the loss gradient and the loss partial sums stay in the workspace.  bf16 storage with
+  // BLH_OPT_PERSISTENT_SHADOW: the bf16 parameter image the previous call's Adam kernel left is used as it is.
+  const bool keep = d->gemm_dtype == 4 && ctx->persistent_shadow;
+  const bool valid = keep && ctx->shadow_params == params && ctx->shadow_ws == workspace;
+  const bool wdT_was = ctx->shadow_wdT;
+  struct SyncGuard {
+    blh_context* c; bool on;
+    SyncGuard(blh_context* c_, blh_sync_fn f, void* u, int64_t g) : c(c_), on(f != nullptr) { if (on) c->sync = SyncCtx{f, u, g}; }
+    ~SyncGuard() { if (on) c->sync = SyncCtx{nullptr, nullptr, 0}; }
+  };
+  PendingLoss pend{nullptr, 0, 0.0};
+  {
+    SyncGuard sg(ctx, sync, sync_user, global_batch);
+    BLH_TRY(forward_train_loss_core(ctx, d, s, params, bn_running, bn_nbt, x, target, drop, momentum, workspace,
+                                    workspace_bytes, pred, loss_out, batch, valid, &pend));
+  }
   // backward: every bucket's all-reduce behind the kernel that completes it.  A range is complete on the side stream
   // of a two-stream context (include/bilinear_hip.h: blh_backward), else on `stream`.
-  DpCall call{comm, ctx->two_stream ? ctx->s2 : s, grads, loss_out, !(flags & BLH_DP_TAIL_ON_COMM_STREAM)};
+  // (under stream capture every collective of the step goes through the communicator's ONE stream: RCCL launches of
+  //  one communicator from two streams inside one capture end in a segmentation fault at hipStreamEndCapture —
+  //  RCCL 2.26.6 / HIP 7.0, tools_dev/native_capture_debug.py)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  BLH_HIP_TRY(hipStreamIsCapturing(s, &cap));
+  const bool tail_on_producer = !(flags & BLH_DP_TAIL_ON_COMM_STREAM) && cap == hipStreamCaptureStatusNone;
+  DpCall call{comm, ctx->two_stream ? ctx->s2 : s, grads, loss_out, tail_on_producer, pend, loss_out};
   int rc = sync ? blh_backward_sync(ctx, d, s, params, x, drop, workspace, workspace_bytes, nullptr, grads, batch,
                                     bucket_thunk, &call, global_batch, sync, sync_user)
                 : blh_backward(ctx, d, s, params, x, drop, workspace, workspace_bytes, nullptr, grads, batch,
@@ -320,12 +341,25 @@ int blh_train_step_dp(blh_context* ctx, blh_comm* comm, const blh_model_desc* d,
     double* sumsq_part = d->gemm_dtype == 4 ? carve_h(d, batch, workspace).sumsq_part : carve(d, batch, workspace).sumsq_part;
     int np = 0;
     rc = launch_sumsq(tail, grads, count, sumsq_part, &np);
+    // bf16 storage under BLH_OPT_PERSISTENT_SHADOW: Adam also writes the bf16 image of the updated weights (and the
+    // decode weight's K-major image when this shape takes the one-pass decode), as blh_train_step does
+    const bool wdT = keep && !ctx->knob(KNOB_NO_DECODE_FUSE) && decode_fused_h_supported(batch, d->width, d->out_features);
+    ShadowDst sd = NO_SHADOW;
+    if (keep) {
+      const WorkspaceH wh = carve_h(d, batch, workspace);
+      sd = ShadowDst{wh.wsh, wdT ? wh.wdT : nullptr, make_layout(d).dec_w, d->width, d->out_features};
+    }
     if (rc == BLH_OK)
       rc = dev_state ? launch_clip_adam_dev(tail, params, grads, exp_avg, exp_avg_sq, count, dev_state, sumsq_part, np,
-                                            stats_out)
-                     : launch_clip_adam(tail, params, grads, exp_avg, exp_avg_sq, count, *hyper, sumsq_part, np, stats_out);
-    // (the parameters changed behind any bf16 image a fused step kept)
-    ctx->shadow_params = nullptr; ctx->shadow_ws = nullptr; ctx->shadow_wdT = false;
+                                            stats_out, LossFinish{nullptr, 0, 1.0, nullptr}, sd)
+                     : launch_clip_adam(tail, params, grads, exp_avg, exp_avg_sq, count, *hyper, sumsq_part, np, stats_out,
+                                        LossFinish{nullptr, 0, 1.0, nullptr}, sd);
+    if (keep && rc == BLH_OK) {
+      // (the K-major image is complete only if an earlier launch zeroed its padding rows: a step's cast does)
+      ctx->shadow_params = params; ctx->shadow_ws = workspace; ctx->shadow_wdT = wdT && (valid ? wdT_was : true);
+    } else {
+      ctx->shadow_params = nullptr; ctx->shadow_ws = nullptr; ctx->shadow_wdT = false;
+    }
   }
   if (tail != s) {
     if (rc != BLH_OK && call.used_cs && tail != comm->cs) {   // (error path: the collective stream is still to be joined)

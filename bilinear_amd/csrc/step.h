@@ -146,6 +146,12 @@ int backward_impl(blh_context* ctx, const blh_model_desc* d, hipStream_t s, cons
 // would a train-mode forward of this batch on this context take the encode stage without Z0?
 bool enc_fused_ok(const blh_context* ctx, const blh_model_desc* d, int64_t batch);
 bool enc_fused_ok_h(const blh_context* ctx, const blh_model_desc* d, int64_t batch);
+// ---- api.hip (for comm.hip)
+struct PendingLoss { const float* part; int n; double denom; };
+int forward_train_loss_core(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
+                            float* bn_running, int64_t* bn_nbt, const float* x, const float* target,
+                            const blh_dropout* drop, float momentum, void* workspace, int64_t workspace_bytes,
+                            float* pred, float* loss_out, int64_t batch, bool shadow_valid, PendingLoss* pending);
 // ---- step_bf16s.hip
 int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
               float* bn_running, int64_t* nbt, const float* x, const blh_dropout* drop,

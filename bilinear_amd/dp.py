@@ -326,7 +326,7 @@ class DataParallel:
         use_sync = self.sync_bn and (self.world > 1 or self.force_collectives)
         scb = eng._sync_callback(ws, self._all_reduce_sum, errors) if use_sync else ctypes.cast(None, N.SyncFn)
         flags = N.DP_TAIL_ON_COMM_STREAM if self.native_tail == "comm" else 0
-        eng.invalidate_shadow()
+        eng._check_shadow_versions()     # (bf16 storage: the step's Adam keeps the bf16 weight image, as the fused step's)
         N.check(N.lib().blh_train_step_dp(
             eng.ctx.handle, comm.handle, ctypes.byref(eng.layout.desc), eng._stream(), N.ptr(eng.params),
             N.ptr(eng.grads), N.ptr(opt._exp_avg), N.ptr(opt._exp_avg_sq), N.ptr(eng.bn_running), N.ptr(eng.bn_nbt),
@@ -427,18 +427,30 @@ class CapturedDataParallelStep:
         eng.workspace(batch)
         eng.scratch()
         snap = [t.clone() for t in (eng.params, opt._exp_avg, opt._exp_avg_sq, eng.bn_running, eng.bn_nbt)]
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):              # warm-up (kernel attributes, RCCL channels)
-            self._enqueue()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        for dst, src in zip((eng.params, opt._exp_avg, opt._exp_avg_sq, eng.bn_running, eng.bn_nbt), snap):
-            dst.copy_(src)
-        self._write_state()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.pred, self.loss = self._enqueue()
+        # collectives="native", bf16 storage: the captured form re-casts the parameter image in every replay (a
+        # replay is invisible to the context's record of whose image is current; the eager native step keeps it)
+        keep_image = None
+        if dp.collectives == "native":
+            dp.native_comm()
+            if eng.layout.desc.gemm_dtype == 4:
+                keep_image = eng.ctx.get_option(N.OPT_PERSISTENT_SHADOW)
+                eng.ctx.set_option(N.OPT_PERSISTENT_SHADOW, 0)
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):              # warm-up (kernel attributes, RCCL channels)
+                self._enqueue()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            for dst, src in zip((eng.params, opt._exp_avg, opt._exp_avg_sq, eng.bn_running, eng.bn_nbt), snap):
+                dst.copy_(src)
+            self._write_state()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.pred, self.loss = self._enqueue()
+        finally:
+            if keep_image is not None:
+                eng.ctx.set_option(N.OPT_PERSISTENT_SHADOW, keep_image)
 
     def _write_state(self):
         from . import _native as N
@@ -457,6 +469,8 @@ class CapturedDataParallelStep:
         from . import _native as N
         dp, eng, opt = self.dp, self.eng, self.opt
         lib = N.lib()
+        if dp.collectives == "native":
+            return self._enqueue_native()
         if dp._reducer is None or dp._reducer.flat.data_ptr() != eng.grads.data_ptr():
             dp._reducer = GradBucketReducer(eng.grads, dp.group, dp.bucket_floats,
                                             force_collectives=dp.force_collectives, compress=dp.compress)
@@ -481,6 +495,38 @@ class CapturedDataParallelStep:
             "blh_clip_adam_step_captured")
         return pred, loss
 
+    def _enqueue_native(self):
+        """The step as ONE library call with the per-step scalars read from ``self.state`` (blh_train_step_dp with
+        dev_state: it advances the state itself; the RCCL launches are captured like kernels)."""
+        import ctypes
+
+        from . import _native as N
+        from .engine import OUT_FEATURES
+        dp, eng, opt = self.dp, self.eng, self.opt
+        want = dp.bucket_floats if dp.bucket_floats else max(1 << 20, eng.layout.total // 4)
+        if getattr(eng, "_bucket_floats_set", None) != want:
+            eng.ctx.set_option(N.OPT_BUCKET_FLOATS, min(int(want), (1 << 31) - 1))
+            eng._bucket_floats_set = want
+        ws = eng.workspace(self.batch)
+        eng.row_offset = dp.rank * self.batch
+        saved_step = eng.rng_step
+        eng.rng_step = 0                            # the device counter supplies the step
+        try:
+            drop = eng._drop_struct(self.batch)
+        finally:
+            eng.rng_step = saved_step
+        eng._tune_streams()
+        pred = torch.empty(self.batch, OUT_FEATURES, dtype=torch.float32, device=self.x.device)
+        loss = torch.empty((), dtype=torch.float32, device=self.x.device)
+        flags = N.DP_TAIL_ON_COMM_STREAM if dp.native_tail == "comm" else 0
+        N.check(N.lib().blh_train_step_dp(
+            eng.ctx.handle, dp.native_comm().handle, ctypes.byref(eng.layout.desc), eng._stream(), N.ptr(eng.params),
+            N.ptr(eng.grads), N.ptr(opt._exp_avg), N.ptr(opt._exp_avg_sq), N.ptr(eng.bn_running), N.ptr(eng.bn_nbt),
+            N.ptr(self.x), N.ptr(self.t), ctypes.byref(drop), eng._momentum(), None, N.ptr(self.state), N.ptr(ws),
+            ws.numel(), N.ptr(pred), N.ptr(loss), N.ptr(opt._stats), self.batch, self.batch * dp.world,
+            ctypes.cast(None, N.SyncFn), None, flags), "blh_train_step_dp")
+        return pred, loss
+
     @torch.no_grad()
     def __call__(self, x, target):
         want = (float(self.opt.param_groups[0]["lr"]), int(self.opt._t), int(self.eng.rng_step))
@@ -496,5 +542,6 @@ class CapturedDataParallelStep:
         self.eng.rng_step += 1
         self.eng._saved_batch = None
         self.eng.generation += 1
+        self.eng.invalidate_shadow()        # (the replay's Adam moved the parameters behind any bf16 image a fused step kept)
         self._mirror = (self._mirror[0], int(self.opt._t), int(self.eng.rng_step))
         return self.pred, self.loss

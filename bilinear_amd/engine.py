@@ -631,6 +631,15 @@ class Engine:
             N.ptr(exp_avg_sq), self.layout.total, ctypes.byref(hyper), N.ptr(sc), sc.numel(),
             N.ptr(stats)), "blh_clip_adam_step")
 
+    def _check_shadow_versions(self):
+        """bf16 storage: a Parameter written in place since the last fused step (its autograd version counter moved)
+        makes the bf16 weight image stale — drop it."""
+        if self.layout.desc.gemm_dtype == 4:
+            versions = sum(p._version for _, p, _, _ in self._named_params())
+            if versions != self._param_versions:
+                self._param_versions = versions
+                self.invalidate_shadow()
+
     def train_step(self, x, target, exp_avg, exp_avg_sq, lr, betas, eps, max_norm, step, stats=None, loss_out=None):
         """Whole step body of train_bilinear.py:75-83 as one native enqueue.  ``loss_out``: a 0-dim float32 device
         tensor that receives the loss (e.g. a slot of a loss ring, bilinear_amd.loss_log) instead of a fresh one."""
@@ -645,12 +654,7 @@ class Engine:
         ws = self.workspace(batch)
         self._drop_struct(batch)          # validates explicit masks (shape, device)
         self._tune_streams()
-        if self.layout.desc.gemm_dtype == 4:
-            # a Parameter written in place since the last fused step (its version counter moved): the bf16 image is stale
-            versions = sum(p._version for _, p, _, _ in self._named_params())
-            if versions != self._param_versions:
-                self._param_versions = versions
-                self.invalidate_shadow()
+        self._check_shadow_versions()
         args = (x, target, self.params, self.grads, exp_avg, exp_avg_sq, self.bn_running, self.bn_nbt,
                 ws, stats, self.masks, *self._op_args(), self.seed, self.rng_step, self.row_offset,
                 self._momentum(), float(lr), float(betas[0]), float(betas[1]), float(eps),

@@ -445,7 +445,8 @@ const char* blh_comm_last_error(void);
  * overlaps the backward GEMMs of the stages below — then the norm of the AVERAGED gradients, clip and Adam
  * (blh_clip_adam_step) right behind the last bucket, and `stream` joined once at the end.  The LAST bucket (it holds
  * the encode stage) and the optimiser run on the stream that produced the last gradient (no queue hop in the tail);
- * BLH_DP_TAIL_ON_COMM_STREAM puts them on the communicator's stream instead.  loss_out: the GLOBAL batch's loss (mean
+ * BLH_DP_TAIL_ON_COMM_STREAM puts them on the communicator's stream instead (always the case while `stream` is
+ * being captured).  loss_out: the GLOBAL batch's loss (mean
  * of the per-rank means; exchanged together with the last bucket).  global_batch must be batch * world.  Exactly one
  * of `hyper` / `dev_state` is given: dev_state selects the capturable form (as blh_train_step_captured; RCCL calls
  * are captured like kernels).  sync != NULL: SyncBN through the caller's callback (blh_forward_train_loss_sync).

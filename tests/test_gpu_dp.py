@@ -524,7 +524,7 @@ def _worker_native(rank, world, port, out_dir):
                     assert info["world"] == 1 and info["rccl_version"] > 0
                     # every bucket + the loss, three times
                     assert info["collectives_issued"] == 3 * (nbuckets + 1), (info, nbuckets)
-                st = opt.last_grad_norm_stats().clone()
+                st = opt.last_grad_norm_stats.clone()
                 out[name] = (net.engine.params.clone(), net.engine.bn_running.clone(), opt._exp_avg.clone(),
                              opt._exp_avg_sq.clone(), net.engine.grads.clone(), losses, pred.clone(), st)
             for name in ("native", "native_comm_tail"):
@@ -533,6 +533,35 @@ def _worker_native(rank, world, port, out_dir):
                 assert out["torch"][5] == out[name][5], (cfg, name, out["torch"][5], out[name][5])
                 assert torch.equal(out["torch"][6], out[name][6]) and torch.equal(out["torch"][7], out[name][7])
             assert out["torch"][5][-1] < out["torch"][5][0]
+
+        # ... and captured: the library-driven step as one hipGraph (blh_train_step_dp with the device step state, the
+        # RCCL launches captured with it) == the eager torch-driven step, bit for bit, with an lr change between replays
+        from bilinear_amd.dp import CapturedDataParallelStep
+        for cfg, bucket in (((1, 1024, 2048, "fp32"), 200000), ((2, 1024, 4096, "bf16s"), 1 << 20)):
+            x, t = _data(dev, cfg)
+            x, t = x[:cfg[2]].contiguous(), t[:cfg[2]].contiguous()
+            net_c, opt_c = _make(dev, cfg)
+            dpc = DataParallel(net_c, opt_c, bucket_floats=bucket, force_collectives=True, collectives="native")
+            cap = CapturedDataParallelStep(dpc, cfg[2])
+            net_e, opt_e = _make(dev, cfg)
+            dpe = DataParallel(net_e, opt_e, bucket_floats=bucket, force_collectives=True)
+            cl, el = [], []
+            for i in range(3):
+                if i == 2:
+                    opt_c.param_groups[0]["lr"] = 5e-4
+                    opt_e.param_groups[0]["lr"] = 5e-4
+                cl.append(float(cap(x, t)[1].item()))
+                el.append(float(dpe.train_step(x, t)[1].item()))
+            torch.cuda.synchronize()
+            assert cl == el, (cfg, cl, el)
+            assert torch.equal(net_c.engine.params, net_e.engine.params), cfg
+            assert torch.equal(opt_c._exp_avg_sq, opt_e._exp_avg_sq) and torch.equal(net_c.engine.bn_running, net_e.engine.bn_running)
+            assert opt_c._t == 3 and int(net_c.encode[1].num_batches_tracked) == 3
+            # an eager library-driven step behind the replays (bf16 storage: the image is re-cast, not trusted)
+            cl.append(float(dpc.train_step(x, t)[1].item()))
+            el.append(float(dpe.train_step(x, t)[1].item()))
+            torch.cuda.synchronize()
+            assert cl[-1] == el[-1] and torch.equal(net_c.engine.params, net_e.engine.params), cfg
 
         # SyncBN rides the caller's callback (torch's process group) beside the library's buckets
         cfg = (1, 1024, 2048, "fp32")
