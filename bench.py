@@ -202,6 +202,107 @@ def gemm_rooflines_bf16s(batch, width, reps, hidden=0):
     return out
 
 
+def _hbm_record(batch, width, elem_bytes):
+    """{kernel name: record} of the newest committed rocprofv3 --pmc record (tools_dev/pmc_hbm.sh ->
+    profiles/r06_hbm_traffic.json, else r05) that holds this shape and storage type; {} when none does."""
+    for name in ("r06_hbm_traffic.json", "r05_hbm_traffic.json"):
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as f:
+                cfgs = json.load(f)["configs"]
+        except (OSError, KeyError, ValueError):
+            continue
+        for cfg in cfgs.values():
+            sh = cfg.get("shape", {})
+            if sh.get("B") == batch and sh.get("W") == width and sh.get("s") == elem_bytes:
+                return dict(cfg["kernels"], _source="profiles/" + name)
+    return {}
+
+
+def _traffic_sum(rec, prefixes):
+    """Sum of traffic_bytes over the kernels named by ``prefixes`` (each a prefix or a (prefix, substring) pair);
+    None when one of them is not in the record."""
+    total = 0
+    for pre in prefixes:
+        sub = ""
+        if isinstance(pre, tuple):
+            pre, sub = pre
+        hit = [v["traffic_bytes"] for k, v in rec.items() if k.startswith(pre) and sub in k]
+        if not hit:
+            return None
+        total += hit[0]
+    return total or None
+
+
+def skinny_rooflines_bf16(batch, width, reps):
+    """The same for bf16 storage (BASELINE configs[2..4]): the encode stage without Z0 and the one-pass decode as the
+    bf16-storage step launches them (blh_skinny_*_bf16), timed live with HIP events.  Algorithmic bytes per pose
+    (element size 2): encode forward / backward 32 s + W s + W / 8 (x, A0 or dA0, keep + gate bits), one-pass
+    decode 2 W s + 3 * 48 * 4 + 48 * 2 (A, dA; target, pred, dpred in fp32; dpred's bf16 copy).  ``traffic``: PMC bytes
+    of the kernels behind the entry point from profiles/r06_hbm_traffic.json when it holds this shape."""
+    from bilinear_amd import _native as N
+    lib = N.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    IF, OF, W, B = 32, 48, width, batch
+
+    def bf(*shape, scale=1.0):
+        return (torch.randn(*shape, device=dev) * scale).to(torch.bfloat16).view(torch.int16)
+    x, W0, A, dAin = bf(B, IF), bf(W, IF, scale=0.25), bf(B, W), bf(B, W, scale=1e-3)
+    b0 = torch.randn(W, device=dev)
+    gam, bet = torch.ones(W, device=dev), torch.zeros(W, device=dev)
+    rmean, rvar = torch.zeros(W, device=dev), torch.ones(W, device=dev)
+    nbt1 = torch.zeros(1, dtype=torch.int64, device=dev)
+    saved = torch.empty(4, W, device=dev)
+    scratch = torch.empty(B * W, dtype=torch.int16, device=dev)
+    A0 = torch.empty(B, W, dtype=torch.int16, device=dev)
+    bits = torch.zeros(((B + 3) // 4) * (W // 8), dtype=torch.int32, device=dev)
+    dropd = N.Dropout(None, 1, 0, 0, 0, 0)
+    dW0 = torch.empty(W, IF, device=dev)
+    db0, dg0, dbe0 = (torch.empty(W, device=dev) for _ in range(3))
+    Wd = torch.randn(OF, W, device=dev) * 0.05
+    bd = torch.randn(OF, device=dev)
+    t = torch.randn(B, OF, device=dev)
+    pred, dpred = torch.empty(B, OF, device=dev), torch.empty(B, OF, device=dev)
+    dA = torch.empty(B, W, dtype=torch.int16, device=dev)
+    wsb = lib.blh_skinny_decode_fused_bf16_workspace_bytes(B, W, OF)
+    ws = torch.empty(max(int(wsb), 16), dtype=torch.uint8, device=dev)
+    enc_bytes = 2.0 * B * (IF + W) + B * W / 8.0
+    ops = [
+        ("encode_fused_fwd_bf16 (x -> A0 + keep bits, BatchNorm statistics from the sums of x: 3 launches, no Z0; the "
+         "bf16-storage step's encode forward)", enc_bytes,
+         lambda: lib.blh_skinny_encode_fused_fwd_bf16(st, x.data_ptr(), W0.data_ptr(), b0.data_ptr(), gam.data_ptr(),
+                                                      bet.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), nbt1.data_ptr(),
+                                                      0.1, saved.data_ptr(), scratch.data_ptr(), A0.data_ptr(),
+                                                      bits.data_ptr(), ctypes.byref(dropd), B, W, IF),
+         [("enc_xstats_kernel<unsigned short",), "enc_bn_finalize_kernel<unsigned short>", "enc_fwd_h_kernel"]),
+        ("encode_fused_bwd_bf16 (dA0 -> dW0, db0, dgamma, dbeta from dA0, the bits and x: 2 launches; the bf16-storage "
+         "step's encode backward)", enc_bytes,
+         lambda: lib.blh_skinny_encode_fused_bwd_bf16(st, dAin.data_ptr(), x.data_ptr(), W0.data_ptr(), b0.data_ptr(),
+                                                      saved.data_ptr(), bits.data_ptr(), scratch.data_ptr(),
+                                                      dW0.data_ptr(), db0.data_ptr(), dg0.data_ptr(), dbe0.data_ptr(),
+                                                      B, W, IF),
+         ["enc_bwd_h_kernel", "enc_bwd_finish_kernel<unsigned short>"]),
+        ("decode_fused_bf16 (Linear %d->48 + MSE + dpred + dA = dP Wd from one read of A; the bf16-storage step's "
+         "decode)" % W, B * (2.0 * 2 * W + 3 * OF * 4 + OF * 2),
+         lambda: lib.blh_skinny_decode_fused_bf16(st, A.data_ptr(), Wd.data_ptr(), bd.data_ptr(), t.data_ptr(),
+                                                  pred.data_ptr(), dpred.data_ptr(), dA.data_ptr(), None, ws.data_ptr(),
+                                                  ws.numel(), B, W, OF),
+         [("decode_fwd_mse_h_kernel", "true>")]),
+    ]
+    rec = _hbm_record(B, W, 2)
+    out = []
+    for name, nbytes, fn, kernels in ops:
+        if fn() != 0:          # (a shape this entry point does not serve: the step takes the materialised path there)
+            continue
+        ms = time_kernel(fn, reps)
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        pre = [(k[0], "") if isinstance(k, tuple) and len(k) == 1 else k for k in kernels]
+        out.append({"op": name, "algorithmic_bytes": nbytes, "avg_us": 1e3 * ms, "achieved": gbs,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bound": "hbm",
+                    "traffic": _traffic_sum(rec, pre), "traffic_source": rec.get("_source")})
+    return out
+
+
 def skinny_rooflines(batch, width, reps):
     """HBM roofline of the skinny projections (BASELINE north_star: "achieved HBM GB/s on the skinny
     32-wide input / output projections"), each exactly as the step launches it (blh_skinny_*), timed
@@ -272,7 +373,7 @@ def skinny_rooflines(batch, width, reps):
                                              wsb, B, W, IF)),
     ]
     # HBM-side traffic of the kernels behind each entry point, from the committed rocprofv3 --pmc record of THIS
-    # shape (tools_dev/pmc_hbm.sh -> profiles/r05_hbm_traffic.json: 2 * FETCH_SIZE + WRITE_SIZE per launch; slab sums
+    # shape (tools_dev/pmc_hbm.sh -> profiles/r06_hbm_traffic.json: 2 * FETCH_SIZE + WRITE_SIZE per launch; slab sums
     # are shared between entry points and not attributed); None where no record covers the shape
     kernels_of = {
         "encode_fused_fwd": ["enc_xstats_kernel", "enc_bn_finalize_kernel", "enc_fwd_kernel"],
@@ -283,23 +384,10 @@ def skinny_rooflines(batch, width, reps):
         "decode_bwd": ["gemm_f32_ring_kernel<64, 128, 2, 2, 0, 1, 0, 32, 3", "gemm_f32_ring_kernel<64, 128, 2, 2, 1, 1, 0, 32, 3"],
         "encode_wgrad": ["gemm_f32_ring_kernel<128, 32, 4, 1, 1, 1, 0, 32, 3"],
     }
-    rec = {}
-    try:
-        with open(os.path.join(REPO, "profiles", "r05_hbm_traffic.json")) as f:
-            cfg = json.load(f)["configs"]["configs[1]"]
-        if cfg["shape"]["B"] == B and cfg["shape"]["W"] == W:
-            rec = cfg["kernels"]
-    except (OSError, KeyError, ValueError):
-        pass
+    rec = _hbm_record(B, W, 4)
 
     def traffic_of(opname):
-        total = 0
-        for sub in kernels_of.get(opname.split(" ")[0], []):
-            hit = [v["traffic_bytes"] for k, v in rec.items() if k.startswith(sub)]
-            if not hit:
-                return None
-            total += hit[0]
-        return total or None
+        return _traffic_sum(rec, kernels_of.get(opname.split(" ")[0], []))
 
     out = []
     for name, nbytes, fn in ops:
@@ -309,14 +397,20 @@ def skinny_rooflines(batch, width, reps):
         gbs = nbytes / (ms * 1e-3) / 1e9
         out.append({"op": name, "algorithmic_bytes": nbytes, "avg_us": 1e3 * ms, "achieved": gbs,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bound": "hbm",
-                    "traffic": traffic_of(name)})
+                    "traffic": traffic_of(name), "traffic_source": rec.get("_source")})
     return out
 
 
-def _traffic_record(batch, width, kernel_substr):
+def _traffic_record(batch, width, kernel_substr, elem_bytes=4):
     """HBM traffic (bytes per launch) of a shipped GEMM from the newest committed rocprofv3 --pmc record that
-    has this shape (profiles/r04_traffic.json, this round's binary: tools_dev/pmc_r04.sh).  bench.py cannot
-    run the PMC passes itself (separate profiler runs); None for shapes that were not profiled."""
+    has this shape: profiles/r06_hbm_traffic.json (tools_dev/pmc_hbm.sh over this round's binary; its "code" field
+    names the commit), else profiles/r04_traffic.json (tools_dev/pmc_r04.sh).  bench.py cannot run the PMC passes
+    itself (separate profiler runs); None for shapes that were not profiled."""
+    rec = _hbm_record(batch, width, elem_bytes)
+    if rec.get("_source", "").endswith("r06_hbm_traffic.json"):
+        for kernel, r in rec.items():
+            if kernel_substr in kernel:
+                return r["traffic_bytes"], rec["_source"]
     try:
         with open(os.path.join(REPO, "profiles", "r04_traffic.json")) as f:
             shape = json.load(f)["shapes"].get("%dx%d" % (batch, width), {})
@@ -345,7 +439,7 @@ def recorded_traffic(batch, width):
 def recorded_traffic_bf16s(batch, width):
     """bf16-storage forward GEMM (<ROWK, ROWK, bias + BatchNorm partials, bf16 out> of whichever kernel the
     dispatcher picks at this shape); falls back to the round-3 record."""
-    t, src = _traffic_record(batch, width, "<0, 0, 2, true")
+    t, src = _traffic_record(batch, width, "<0, 0, 2, true", elem_bytes=2)
     if t is not None:
         return t, src
     try:
@@ -744,6 +838,8 @@ def config_block(idx, dev, steps, ramp_ms):
         "step_tflops": poses * (fwd + bwd) / 1e12,
         "step_frac_of_bf16_mfma_peak": poses * (fwd + bwd) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
         "roofline": roofline_block(a, kern["linear_fwd"]),
+        "roofline_hbm": skinny_rooflines_bf16(a.batch, a.width, reps=200) if a.dtype == "bf16s"
+                        else skinny_rooflines(a.batch, a.width, reps=200),
         "kernels": kern,
     }
     del net, opt, x, t
@@ -1136,7 +1232,8 @@ def main():
                 poses * (fwd + bwd) / 1e12 / ((BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16s"
                                                else FP32_MFMA_PEAK_TFLOPS) * max(1, n_devices)),
             "roofline": roofline_block(args, dom),
-            "roofline_hbm": skinny_rooflines(args.batch, args.width, reps=300),
+            "roofline_hbm": skinny_rooflines_bf16(args.batch, args.width, reps=300) if args.dtype == "bf16s"
+                            else skinny_rooflines(args.batch, args.width, reps=300),
             "kernels": kern,
         }
         if comm is not None:
