@@ -604,9 +604,10 @@ int blh_train_step(blh_context* ctx, const blh_model_desc* d, void* stream, floa
     if (dec_S > 0) nparts = dec_S;
     else BLH_TRY(launch_mse(s, pred, target, batch * d->out_features, (float)(2.0 / denom), wh.dpred,
                             wh.loss_part, &nparts));
-    BLH_TRY(backward_h(ctx, d, s, params, drop, wh, wh.dpred, grads, batch, nullptr, nullptr, ctx->fwd_mode, dec_S));
+    BLH_TRY(backward_h(ctx, d, s, params, drop, wh, wh.dpred, grads, batch, nullptr, nullptr, ctx->fwd_mode, dec_S, &np));
     ctx->note_saved(workspace, batch, blh_context::SAVED_NONE);
-    BLH_TRY(launch_sumsq(s, grads, count, wh.sumsq_part, &np));
+    // (np > 0: the batched slab sum left the norm's partials — step_bf16s.hip; else one pass over the arena)
+    if (np == 0) BLH_TRY(launch_sumsq(s, grads, count, wh.sumsq_part, &np));
     const bool wdT = keep && !ctx->knob(blh::KNOB_NO_DECODE_FUSE) &&
                      decode_fused_h_supported(batch, d->width, d->out_features);
     const ShadowDst sd = keep ? ShadowDst{wh.wsh, wdT ? wh.wdT : nullptr, make_layout(d).dec_w, d->width, d->out_features}
@@ -860,9 +861,10 @@ int blh_train_step_captured(blh_context* ctx, const blh_model_desc* d, void* str
     if (dec_S > 0) nparts = dec_S;
     else BLH_TRY(launch_mse(s, pred, target, batch * d->out_features, (float)(2.0 / denom), wh.dpred,
                             wh.loss_part, &nparts));
-    BLH_TRY(backward_h(ctx, d, s, params, drop, wh, wh.dpred, grads, batch, nullptr, nullptr, ctx->fwd_mode, dec_S));
+    BLH_TRY(backward_h(ctx, d, s, params, drop, wh, wh.dpred, grads, batch, nullptr, nullptr, ctx->fwd_mode, dec_S, &np));
     ctx->note_saved(workspace, batch, blh_context::SAVED_NONE);
-    BLH_TRY(launch_sumsq(s, grads, count, wh.sumsq_part, &np));
+    // (np > 0: the batched slab sum left the norm's partials — step_bf16s.hip; else one pass over the arena)
+    if (np == 0) BLH_TRY(launch_sumsq(s, grads, count, wh.sumsq_part, &np));
     // (captured: the image state is what blh_refresh_param_shadow left — plain + K-major decode weight — and every
     //  replay keeps both up to date)
     const bool wdT = keep && wdT_was;

@@ -356,7 +356,8 @@ static WorkspaceH carve_h(const blh_model_desc* d, int64_t batch, void* base) {
   ws.dpred = (float*)take(batch * d->out_features * sizeof(float));
   ws.dpredh = (uint16_t*)take(batch * d->out_features * 2);
   ws.loss_part = (float*)take(4096 * sizeof(float));
-  ws.sumsq_part = (double*)take(SUMSQ_MAX_PARTS * sizeof(double));
+  // (SUMSQ_FOLD_PARTS_H slots: the fused step's batched slab sum leaves up to that many norm partials here, r06)
+  ws.sumsq_part = (double*)take(SUMSQ_FOLD_PARTS_H * sizeof(double));
   ws.colsum_part = (float*)take(ceil_div(batch, 256) * d->out_features * sizeof(float));
   ws.sync_buf = (double*)take(2 * W * sizeof(double));
   ws.dec_bias_part = (float*)take(1026 * d->out_features * sizeof(float));

@@ -179,6 +179,12 @@ int launch_sum_slabs(hipStream_t s, const float* slabs, int64_t count, int split
 int launch_sum_slabs_sq(hipStream_t s, const float* slabs, int64_t count, int splits, float* out, double* sq,
                         int max_blocks);
 int sum_slabs_sq_blocks(int64_t count, int max_blocks);
+// the batched slab sum that also leaves the gradient norm's partials (elementwise.hip): `ranges` = every part of the
+// gradient arena the items do NOT cover; *nparts partials in sq (at most max_parts, else BLH_ERR_SHAPE)
+struct SqRanges { int n; int64_t total4; int64_t off[36]; int64_t cnt[36]; };   // total4: sum of cnt / 4 (set by the launcher)
+int launch_sum_slabs_batched_sq(hipStream_t s, const float* slabs, int64_t count, int splits, int items,
+                                int64_t slab_item_stride, float* out, int64_t out_item_stride, const float* arena,
+                                const SqRanges& ranges, double* sq, int max_parts, int* nparts);
 int launch_sum_slabs_batched(hipStream_t s, const float* slabs, int64_t count, int splits, int items,
                              int64_t slab_item_stride, float* out, int64_t out_item_stride);
 int launch_sum_slabs_add(hipStream_t s, const float* slabs, int64_t count, int splits,

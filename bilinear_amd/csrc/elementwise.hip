@@ -449,6 +449,107 @@ int launch_sum_slabs_batched(hipStream_t s, const float* slabs, int64_t count, i
   return BLH_OK;
 }
 
+// ... and the gradient norm's partials on the way (bf16-storage fused step, r06): block (x, y) sums its share of item
+// y's slabs and leaves the sum of squares of what it wrote, plus that of its share of every OTHER range of the gradient
+// arena (stage 0, the biases / gamma / beta of the stages, the decode layer: all final when this kernel runs — the
+// caller orders the bias reduction in front of it), so that no pass over the arena is left between the last gradient
+// and clip + Adam.  One partial per block, sq[y * gridDim.x + x]: dense, every slot written by exactly one block.
+// (The other ranges as a grid slice of their own — (items + 1) x blocks — made the launch 2304 blocks: one full round
+//  of 2048 resident blocks and a straggling eighth, 21.2 us against 15.7 for the plain kernel.)
+__device__ __forceinline__ int64_t sq_range_offset(const SqRanges& rg, int64_t idx) {
+  int64_t off = 0;
+  bool found = false;
+#pragma unroll
+  for (int r = 0; r < 36; ++r) {
+    if (r < rg.n) {
+      const int64_t n4 = rg.cnt[r] >> 2;
+      if (!found && idx < n4) { found = true; off = rg.off[r] + idx * 4; }
+      else if (!found) idx -= n4;
+    }
+  }
+  return off;
+}
+
+__global__ __launch_bounds__(256) void sum_slabs_batched_sq_kernel(const float* __restrict__ slabs, int64_t count,
+                                                                   int splits, int64_t slab_item_stride,
+                                                                   float* __restrict__ out, int64_t out_item_stride,
+                                                                   const float* __restrict__ arena, SqRanges rg,
+                                                                   double* __restrict__ sq) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // the other ranges as ONE index space (their float4 counts laid end to end): a thread finds the range of its element
+  // with the (uniform, unrolled) table walk and requests it HERE, in front of the slab loop; it is squared at the end.
+  // (A loop over the ranges with a load inside was ten dependent round trips for the first blocks — 20.5 us for the
+  //  kernel against 16.5 without this part; one load behind the slab loop 18.6.)
+  const int64_t xfirst = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t xall = stride * gridDim.y;
+  float4 ex = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (xfirst < rg.total4) ex = ld4(arena + sq_range_offset(rg, xfirst));
+  {
+    const float* sl = slabs + (int64_t)blockIdx.y * slab_item_stride;
+    float* o = out + (int64_t)blockIdx.y * out_item_stride;
+    const int64_t n4 = count >> 2;
+    // (two elements per trip, all their loads first: as many requests in flight per thread as the plain kernel's
+    //  larger grid has)
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+      float4 a = ld4(sl + i * 4), c = ld4(sl + (i + stride) * 4);
+      for (int s = 1; s < splits; ++s) {
+        const float4 b = ld4(sl + (int64_t)s * count + i * 4), e = ld4(sl + (int64_t)s * count + (i + stride) * 4);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        c.x += e.x; c.y += e.y; c.z += e.z; c.w += e.w;
+      }
+      st4(o + i * 4, a);
+      st4(o + (i + stride) * 4, c);
+      acc += (double)((a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w));
+      acc += (double)((c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w));
+    }
+    for (; i < n4; i += stride) {
+      float4 a = ld4(sl + i * 4);
+      for (int s = 1; s < splits; ++s) {
+        const float4 b = ld4(sl + (int64_t)s * count + i * 4);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      st4(o + i * 4, a);
+      acc += (double)((a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w));
+    }
+  }
+  acc += (double)((ex.x * ex.x + ex.y * ex.y) + (ex.z * ex.z + ex.w * ex.w));
+  for (int64_t idx0 = xfirst + xall; idx0 < rg.total4; idx0 += xall) {     // (never taken at the shapes of the step)
+    const float4 a = ld4(arena + sq_range_offset(rg, idx0));
+    acc += (double)((a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) sq[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+int launch_sum_slabs_batched_sq(hipStream_t s, const float* slabs, int64_t count, int splits, int items,
+                                int64_t slab_item_stride, float* out, int64_t out_item_stride, const float* arena,
+                                const SqRanges& ranges, double* sq, int max_parts, int* nparts) {
+  if (count % 4 != 0 || slab_item_stride % 4 != 0 || out_item_stride % 4 != 0 || items < 1 || !sq || !nparts)
+    return BLH_ERR_SHAPE;
+  SqRanges rg = ranges;
+  rg.total4 = 0;
+  for (int r = 0; r < rg.n; ++r) {
+    if (rg.off[r] % 4 != 0 || rg.cnt[r] % 4 != 0 || rg.cnt[r] < 0) return BLH_ERR_SHAPE;
+    rg.total4 += rg.cnt[r] >> 2;
+  }
+  // at most 2048 blocks in all (one round of resident blocks: 8 per CU), a power of two per item (even trips)
+  int64_t blocks = 1;
+  while (blocks * 2 <= std::min<int64_t>(ceil_div(count / 4, 256), std::max<int64_t>(1, std::min(max_parts, 2048) / items)))
+    blocks *= 2;
+  if (blocks * items > max_parts) return BLH_ERR_SHAPE;
+  hipLaunchKernelGGL(sum_slabs_batched_sq_kernel, dim3((unsigned)blocks, (unsigned)items), dim3(256), 0, s, slabs,
+                     count, splits, slab_item_stride, out, out_item_stride, arena, rg, sq);
+  BLH_HIP_TRY(hipGetLastError());
+  *nparts = (int)(blocks * items);
+  return BLH_OK;
+}
+
 // ---------------------------------------------------------------------------
 // small-batch forward: Z = sum of split-K slabs + bias (streaming, fully parallel), then the
 // column (mean, M2) over all M rows as ONE statistics tile (Welford per thread, Chan merge

@@ -17,6 +17,8 @@ static constexpr int SUMSQ_MAX_PARTS = 1024;
 // sum-of-squares partials written by the kernels that PRODUCE the gradient ranges of the fp32 backward
 // (slab sums, bias reduction, gamma / beta finalize): the fused step then needs no pass over the arena
 static constexpr int SUMSQ_FOLD_PARTS = 4096;
+// bf16 storage: the batched slab sum leaves (items + 1) x blocks partials (elementwise.hip: launch_sum_slabs_batched_sq)
+static constexpr int SUMSQ_FOLD_PARTS_H = 4096;   // (clip_adam requests up to 4096 partials in one round trip)
 
 // rows handled by one block of the streaming BatchNorm kernels: whole 32-row Philox patches,
 // at most 128 row chunks (= partials of the column sums)

@@ -161,6 +161,6 @@ int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const fl
 int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
                const blh_dropout* drop, const WorkspaceH& ws, const float* dpred,
                float* grads, int64_t batch, blh_grad_ready_fn on_ready, void* user, int saved_mode,
-               int dec_bias_S = 0);
+               int dec_bias_S = 0, int* fold_nparts = nullptr);
 
 }  // namespace blh

@@ -154,7 +154,11 @@ static int wgrad_h(hipStream_t s, const uint16_t* dZ, int64_t ld_dz, int M, cons
 int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const float* params,
                       const blh_dropout* drop, const WorkspaceH& ws, const float* dpred,
                       float* grads, int64_t batch, blh_grad_ready_fn on_ready, void* user, int saved_mode,
-                      int dec_bias_S) {
+                      int dec_bias_S, int* fold_nparts) {
+  // fold_nparts != NULL (the fused step): when the hidden weight gradients leave through ONE batched slab sum, that
+  // kernel also takes the gradient norm's partials — of its own output and of every other range of the arena — into
+  // ws.sumsq_part and reports how many; 0: the caller runs its pass over the arena (launch_sumsq)
+  if (fold_nparts) *fold_nparts = 0;
   const ArenaLayout L = make_layout(d);
   const int nh = (int)L.heavy.size();
   const int W = d->width, OF = d->out_features, IF = d->in_features;
@@ -254,7 +258,7 @@ int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const f
   };
   // dW_k = dZ_k^T A_{k-1} for k = lo .. hi in one launch: the stages' dZ, A and gradient tensors lie one
   // fixed stride apart (carve_h, make_layout)
-  auto launch_group = [&](const WGroup& grp, hipStream_t st) -> int {
+  auto launch_group = [&](const WGroup& grp, hipStream_t st, bool fold = false) -> int {
     const int items = grp.hi - grp.lo + 1;
     if (nh < 3 || (ws.dZ[2] - ws.dZ[1]) != (ws.A[1] - ws.A[0])) return BLH_ERR_SHAPE;
     const int64_t gstride = L.heavy[2].w - L.heavy[1].w;
@@ -273,6 +277,18 @@ int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const f
     }
     g.C = ws.bslabs; g.c_split_stride = (int64_t)W * W; g.c_batch_stride = (int64_t)grp.plan.splits * W * W;
     BLH_TRY(launch_gemm_bf16s(st, KROW, KROW, EPI_STORE, false, g, items * grp.plan.splits));
+    if (fold) {
+      // every range of the arena outside the group's weights (the group is ALL hidden stages here)
+      SqRanges rg{};
+      int64_t at = 0;
+      for (int k = grp.lo; k <= grp.hi; ++k) {
+        if (L.heavy[k].w > at) { rg.off[rg.n] = at; rg.cnt[rg.n] = L.heavy[k].w - at; ++rg.n; }
+        at = L.heavy[k].w + (int64_t)W * W;
+      }
+      if (L.total > at) { rg.off[rg.n] = at; rg.cnt[rg.n] = L.total - at; ++rg.n; }
+      return launch_sum_slabs_batched_sq(st, ws.bslabs, (int64_t)W * W, grp.plan.splits, items, g.c_batch_stride, out,
+                                         gstride, grads, rg, ws.sumsq_part, SUMSQ_FOLD_PARTS_H, fold_nparts);
+    }
     return launch_sum_slabs_batched(st, ws.bslabs, (int64_t)W * W, grp.plan.splits, items, g.c_batch_stride, out,
                                     gstride);
   };
@@ -402,16 +418,22 @@ int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const f
       BLH_TRY(ready(i, h.w, end - h.w));
     }
   }
-  if (on_ready == nullptr && !wgroups.empty() && wgroups[0].plan.splits > 0) {
-    BLH_TRY(launch_group(wgroups[0], s));   // (everything is on `s` in this plan: batched_main above)
-  }
-  if (!on_ready) {
+  // the norm's partials from the batched slab sum: the group must be all hidden stages through slabs, on `s`, with
+  // every other gradient final in front of it — the bias reduction then goes FIRST (it needs nothing from the group)
+  const bool fold = fold_nparts != nullptr && on_ready == nullptr && batched_main && !wgroups.empty() &&
+                    wgroups[0].plan.splits > 1 && nh - 1 <= 34 && !ctx->knob(KNOB_NO_SUMSQ_FOLD);
+  auto bias_all = [&]() -> int {
     int64_t offs[32];
     if (nh > 32) return BLH_ERR_SHAPE;
     for (int i = 0; i < nh; ++i) offs[i] = L.heavy[i].b;
-    BLH_TRY(launch_bias_colreduce(s, ws.dz_colsum_part, (int64_t)chunks * W, chunks, W, nh, offs, grads,
-                                  dec_bias_S > 0 ? ws.dec_bias_part : nullptr, dec_bias_S, OF, L.dec_b));
+    return launch_bias_colreduce(s, ws.dz_colsum_part, (int64_t)chunks * W, chunks, W, nh, offs, grads,
+                                 dec_bias_S > 0 ? ws.dec_bias_part : nullptr, dec_bias_S, OF, L.dec_b);
+  };
+  if (!on_ready && fold) BLH_TRY(bias_all());
+  if (on_ready == nullptr && !wgroups.empty() && wgroups[0].plan.splits > 0) {
+    BLH_TRY(launch_group(wgroups[0], s, fold));   // (everything is on `s` in this plan: batched_main above)
   }
+  if (!on_ready && !fold) BLH_TRY(bias_all());
   if (two) {   // join: the side stream is in order, its last kernel is stage 0's slab sum
     BLH_HIP_TRY(hipEventRecord(ctx->ev_w[0], s2));
     BLH_HIP_TRY(hipStreamWaitEvent(s, ctx->ev_w[0], 0));

@@ -448,6 +448,44 @@ def test_bn_backward_reductions_in_the_dgrad_epilogue_match_the_streaming_kernel
         assert rel <= 2e-3, (k, rel)
 
 
+@pytest.mark.parametrize("nb,batch", [(2, 4096), (4, 16384), (4, 2048)])
+def test_gradient_norm_partials_from_the_batched_slab_sum(nb, batch):
+    """r06: when the hidden weight gradients of the bf16-storage fused step leave through ONE batched slab sum, that
+    kernel also takes the partials of the gradient norm (clip_grad_norm_, /root/reference/train_bilinear.py:81) — of
+    its own output and of every other range of the arena — and the step runs no pass of its own over the arena.  The
+    gradients are the same bits as with BLH_NO_SUMSQ_FOLD=1; the norm is the same sum in another order (fp64 partials):
+    equal to 1e-6, and so is everything Adam makes of it."""
+    import os
+
+    import bilinear_amd
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(5)
+    x, t = torch.randn(batch, 32, device=dev, generator=g), torch.randn(batch, 48, device=dev, generator=g)
+    out = {}
+    for fold in (True, False):
+        if not fold:
+            os.environ["BLH_NO_SUMSQ_FOLD"] = "1"
+        try:
+            torch.manual_seed(0)
+            net, opt, _, _ = bilinear_amd.load(dev, num_blocks=nb, width=1024, gemm_dtype="bf16s")
+            net.train()
+            net.engine.seed = 3
+            stats = []
+            for _ in range(2):
+                net.train_step(opt, x, t, max_norm=1.0)
+                stats.append(opt.last_grad_norm_stats.clone())
+            torch.cuda.synchronize()
+            out[fold] = (torch.stack(stats).cpu().double(), net.engine.grads.clone(), net.engine.params.clone())
+        finally:
+            os.environ.pop("BLH_NO_SUMSQ_FOLD", None)
+    a, b = out[True][0], out[False][0]
+    assert (a[:, 0] > 0).all() and ((a - b).abs() <= 1e-6 * b.abs()).all(), (a, b)
+    # the first step's clipped gradient = the same raw gradient times coefficients that agree to 1e-6; the second
+    # step starts from parameters that agree to Adam's rounding
+    rel = float((out[True][2] - out[False][2]).double().norm() / out[False][2].double().norm())
+    assert rel <= 1e-6, rel
+
+
 def test_persistent_shadow_is_bit_identical_and_invalidated_by_parameter_writes():
     """BLH_OPT_PERSISTENT_SHADOW (fused Adam -> bf16 weight image + the decode weight's K-major image of the
     one-pass decode; the host layer's default for bf16 storage since round 6): the same steps with and
