@@ -480,7 +480,7 @@ def roofline_block(args, dom):
             "avg_launch_ms": dom["ms"], "flop_per_launch": flop,
             "avg_launch_ms_how": "HIP events around %d back-to-back launches on the launch stream; the rocprofv3 "
                                  "--kernel-trace average of the same kernel inside the step is in "
-                                 "profiles/r05_final_kernel_stats.md" % dom.get("reps", GEMM_REPS),
+                                 "profiles/r06_final_kernel_stats.md" % dom.get("reps", GEMM_REPS),
             # what a kernel of this launch shape (one 128x128 tile per CU) can reach at all: the
             # same kernel with its loop reduced to the MFMAs, measured (profiles/r02_traffic.json)
             "shape_ceiling": recorded_ceiling(args.batch, args.width),
