@@ -4,7 +4,7 @@ out=${1:-gpurun_out/shadow_ab}
 for rep in 1 2; do
   for cfg in 2 3 4; do
     for mode in off on; do
-      flag=""; [ $mode = on ] && flag="--persistent-shadow"
+      flag="--no-persistent-shadow"; [ $mode = on ] && flag=""
       python bench.py --config $cfg --no-cpu-baseline --steps 300 --warmup 50 $flag > ${out}_cfg${cfg}_${mode}_$rep.json 2> ${out}_cfg${cfg}_${mode}_$rep.log
       echo "cfg$cfg $mode rep$rep: $(grep -h 'timed' ${out}_cfg${cfg}_${mode}_$rep.log)" | tee -a ${out}.txt
     done
