@@ -48,6 +48,7 @@ struct Rccl {
 
 std::once_flag g_rccl_once;
 Rccl g_rccl;
+char g_rccl_load_error[256] = "";        // why librccl could not be used (written once, inside call_once)
 thread_local char tl_comm_error[256] = "";
 
 void set_error(const char* what, int code) {
@@ -67,7 +68,7 @@ void load_rccl() {
       h = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
       if (h) break;
     }
-  if (!h) { snprintf(tl_comm_error, sizeof(tl_comm_error), "librccl.so not found (%s)", dlerror()); return; }
+  if (!h) { snprintf(g_rccl_load_error, sizeof(g_rccl_load_error), "librccl.so not found (%s)", dlerror()); return; }
   Rccl r;
   r.handle = h;
   bool all = true;
@@ -81,14 +82,16 @@ void load_rccl() {
   r.GroupStart = (int (*)())sym("ncclGroupStart");
   r.GroupEnd = (int (*)())sym("ncclGroupEnd");
   r.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
-  if (!all) { snprintf(tl_comm_error, sizeof(tl_comm_error), "librccl.so lacks a required symbol"); return; }
+  if (!all) { snprintf(g_rccl_load_error, sizeof(g_rccl_load_error), "librccl.so lacks a required symbol"); return; }
   r.ok = true;
   g_rccl = r;
 }
 
 const Rccl* rccl() {
   std::call_once(g_rccl_once, load_rccl);
-  return g_rccl.ok ? &g_rccl : nullptr;
+  if (g_rccl.ok) return &g_rccl;
+  snprintf(tl_comm_error, sizeof(tl_comm_error), "%s", g_rccl_load_error);     // (every thread that asks gets the text)
+  return nullptr;
 }
 
 #define BLH_NCCL_TRY(what, expr)                                  \

@@ -317,9 +317,8 @@ class DataParallel:
         eng._tune_streams()
         opt._ensure_moments(eng)
         g = opt.param_groups[0]
-        opt._t += 1
         hyper = N.AdamHyper(float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"],
-                            0.0 if self.max_norm is None else float(self.max_norm), opt._t, 0)
+                            0.0 if self.max_norm is None else float(self.max_norm), opt._t + 1, 0)
         pred = torch.empty(batch, OUT_FEATURES, dtype=torch.float32, device=x.device)
         loss = torch.empty((), dtype=torch.float32, device=x.device)
         errors = []
@@ -335,6 +334,7 @@ class DataParallel:
             "blh_train_step_dp")
         if errors:
             raise errors[0]
+        opt._t += 1                         # (only a step that was enqueued counts)
         eng.generation += 1
         eng._saved_batch = None
         if eng.masks is None:

@@ -161,3 +161,30 @@ def test_bf16_compressed_buckets_world2_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_worker_bf16, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "bf16_ok0") and os.path.exists(tmp_path / "bf16_ok1")
+
+
+def test_collectives_argument_of_the_data_parallel_driver():
+    """``collectives="native"`` (the library issues the RCCL calls itself, csrc/comm.hip) is an opt-in of HIP devices with
+    fp32 buckets: the constructor refuses what it cannot do, and the communicator is not created on a CPU module."""
+    from bilinear_amd.dp import DataParallel
+
+    class _Eng:
+        device = torch.device("cpu")
+
+    class _Mod:
+        engine = _Eng()
+
+        def parameters(self):
+            return iter([torch.zeros(1)])
+
+    with pytest.raises(ValueError):
+        DataParallel(_Mod(), None, collectives="rccl")
+    with pytest.raises(ValueError):
+        DataParallel(_Mod(), None, collectives="native", compress="bf16")
+    with pytest.raises(ValueError):
+        DataParallel(_Mod(), None, collectives="native", native_tail="main")
+    dp = DataParallel(_Mod(), None, collectives="native")
+    assert dp.collectives == "native" and dp.native_tail == "producer" and dp._comm is None
+    with pytest.raises(RuntimeError, match="HIP device"):
+        dp.native_comm()
+    assert DataParallel(_Mod(), None).collectives == "torch"        # the default stays torch.distributed
