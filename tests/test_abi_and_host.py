@@ -37,6 +37,18 @@ def test_library_exports_every_declared_symbol(native):
     assert b"RCCL" in native.blh_status_string(-5)
 
 
+def test_every_abi_version_check_names_the_header_version(native):
+    """The header's BLH_ABI_VERSION, the library's answer, build()'s assertion (__graft_entry__.py: the driver's "does it
+    build" check) and the stub in INTEGRATION.md must agree — a bump that misses one of them fails HERE, not on the driver."""
+    hdr = open(os.path.join(REPO, "include", "bilinear_hip.h")).read()
+    ver = int(re.search(r"#define\s+BLH_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert native.blh_abi_version() == ver
+    entry = open(os.path.join(REPO, "__graft_entry__.py")).read()
+    assert re.findall(r"blh_abi_version\(\)\s*==\s*(\d+)", entry) == [str(ver)]
+    integ = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    assert re.findall(r"assert _lib\.blh_abi_version\(\)\s*==\s*(\d+)", integ) == [str(ver)]      # (the stub)
+
+
 def test_comm_entry_points_validate_without_gpu(native):
     """csrc/comm.hip: librccl is resolved with dlopen (torch's copy is in the process), nothing is called on a device
     here — argument checks only."""
