@@ -209,7 +209,13 @@ int blh_rccl_unique_id(void* id_out, int64_t id_bytes) {
 int blh_comm_destroy(blh_comm* c) {
   if (!c) return BLH_OK;
   int rc = BLH_OK;
-  if (c->cs) (void)hipStreamSynchronize(c->cs);
+  // (collectives of this communicator may still be in flight on its own stream, on a context's side stream — the tail
+  //  of blh_train_step_dp — or on a caller's stream — blh_comm_all_reduce: wait for the device, destroying is rare)
+  if (c->device >= 0) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == c->device) (void)hipDeviceSynchronize();
+    else if (c->cs) (void)hipStreamSynchronize(c->cs);
+  }
   if (c->comm && rccl()) {
     const int r = rccl()->CommDestroy(c->comm);
     if (r != NCCL_SUCCESS) { set_error("ncclCommDestroy", r); rc = BLH_ERR_COMM; }

@@ -424,7 +424,9 @@ int blh_clip_adam_step_captured(void* stream, float* params, float* grads, float
  *   blh_rccl_unique_id: ncclGetUniqueId into id_out (id_bytes must be 128); rank 0 calls it and hands the bytes
  *     to the other ranks by any means (the shipped host code: a broadcast over the existing process group).
  *   blh_comm_create: ncclCommInitRank on the CURRENT device + a collective stream and events of its own.  Collective
- *     call: every rank of the communicator.  blh_comm_destroy waits for the collective stream, then destroys.
+ *     call: every rank of the communicator.  blh_comm_destroy waits for the device (called with the communicator's
+ *     device current), then destroys.  A communicator serves ONE call at a time (like a blh_context), and every rank
+ *     must issue the same calls on it in the same order (RCCL's rule).
  *   blh_comm_all_reduce / blh_comm_broadcast: one in-place collective enqueued on `stream` (dtype 0 fp32, 1 fp64,
  *     2 bf16; average != 0: ncclAvg, else ncclSum; broadcast counts bytes).
  *   blh_comm_last_error: text of the last BLH_ERR_COMM on this thread.                                             */
