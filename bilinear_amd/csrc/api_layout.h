@@ -240,6 +240,7 @@ struct WorkspaceH {
   std::vector<uint32_t*> keep;      // per heavy stage: dropout keep bits [ceil(B/4)][W/8] (bn_bf16.hip)
   uint16_t* G0; uint16_t* G1;
   float* stat_part; float* bn_part; float* dz_colsum_part; float* slabs;
+  int64_t slab_cap;                 // floats in `slabs` (every split launch is checked against it)
   float* bslabs;                    // [hidden stages][slabs][W][W]: the batched weight gradient (null: not planned)
   float* dpred; uint16_t* dpredh;   // [B][out] fp32 and its bf16 image
   float* loss_part; double* sumsq_part; float* colsum_part;
@@ -308,11 +309,20 @@ static Splits wgrad_batched_plan_h(int64_t W, int64_t batch, int items, bool hoo
   return Splits{(int)s, (int)(batch / s)};
 }
 
+// (for the batch AND for its multiple-of-8 part, which is what a ragged batch launches — step_bf16s.hip: wgrad_h.  The two
+//  plans differ: 385 rows round their slab depth up to 256 and need 2 slabs, the 384 rows actually launched keep 128 and
+//  need 3 — sized for the first, the slabs of every ragged batch above 384 rows ran 262 KB (W = 256) .. 8 MB (W = 1024)
+//  past this buffer, over the loss / decode-bias partials behind it and, at the end of the workspace, out of it: found by
+//  tests/shape_fuzz.py in round 6, the fused step returned a zero loss and a wrong decode-bias gradient at such batches)
 static int64_t slab_floats_h(const blh_model_desc* d, int64_t batch) {
   const int64_t W = d->width;
-  int64_t m = wgrad_plan_h(W, W, batch).splits * W * W;
-  m = std::max(m, wgrad_plan_h(W, d->in_features, batch).splits * W * (int64_t)d->in_features);
-  m = std::max(m, wgrad_plan_h(d->out_features, W, batch).splits * (int64_t)d->out_features * W);
+  int64_t m = 0;
+  for (const int64_t b : {batch, batch & ~(int64_t)7}) {
+    if (b <= 0) continue;
+    m = std::max(m, wgrad_plan_h(W, W, b).splits * W * W);
+    m = std::max(m, wgrad_plan_h(W, d->in_features, b).splits * W * (int64_t)d->in_features);
+    m = std::max(m, wgrad_plan_h(d->out_features, W, b).splits * (int64_t)d->out_features * W);
+  }
   return m;
 }
 
@@ -341,7 +351,8 @@ static WorkspaceH carve_h(const blh_model_desc* d, int64_t batch, void* base) {
   const int64_t chunks = ew_num_row_chunks_h(batch);
   ws.bn_part = (float*)take(chunks * 2 * W * sizeof(float));
   ws.dz_colsum_part = (float*)take((int64_t)nh * chunks * W * sizeof(float));
-  ws.slabs = (float*)take(slab_floats_h(d, batch) * sizeof(float));
+  ws.slab_cap = slab_floats_h(d, batch);
+  ws.slabs = (float*)take(ws.slab_cap * sizeof(float));
   {   // slabs of the batched weight gradient: all hidden stages (no hook) or a group of up to four (hook)
     const int hidden = 2 * d->num_blocks;
     int64_t need = 0;

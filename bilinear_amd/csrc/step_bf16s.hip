@@ -128,7 +128,7 @@ int forward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const fl
 // /root/reference/train_bilinear.py:33-43 (drop_last unset) — runs the GEMM over the first batch - batch % 8 rows and a
 // small kernel adds the outer products of the up to seven rows that are left (r06; such a batch used to be refused).
 static int wgrad_h(hipStream_t s, const uint16_t* dZ, int64_t ld_dz, int M, const uint16_t* act,
-                   int64_t ld_act, int N, int64_t batch, float* slabs, float* out) {
+                   int64_t ld_act, int N, int64_t batch, float* slabs, int64_t slab_cap, float* out) {
   const int64_t kmain = batch & ~(int64_t)7;
   const int tail = (int)(batch - kmain);
   if (kmain > 0) {
@@ -140,6 +140,7 @@ static int wgrad_h(hipStream_t s, const uint16_t* dZ, int64_t ld_dz, int M, cons
       g.C = out;
       BLH_TRY(launch_gemm_bf16s(s, KROW, KROW, EPI_STORE, false, g, 1));
     } else {
+      if ((int64_t)sp.splits * M * N > slab_cap) return BLH_ERR_WORKSPACE;     // (never: api_layout.h sizes for this plan)
       g.C = slabs; g.c_split_stride = (int64_t)M * N;
       BLH_TRY(launch_gemm_bf16s(s, KROW, KROW, EPI_STORE, false, g, sp.splits));
       BLH_TRY(launch_sum_slabs(s, slabs, (int64_t)M * N, sp.splits, out));
@@ -230,7 +231,7 @@ int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const f
     tl_stop_event = nullptr;
   }
   BLH_TRY(fork_wait(nh, true));
-  BLH_TRY(wgrad_h(s2, ws.dpredh, OF, OF, ws.A[nh - 1], W, W, batch, ws.slabs, grads + L.dec_w));
+  BLH_TRY(wgrad_h(s2, ws.dpredh, OF, OF, ws.A[nh - 1], W, W, batch, ws.slabs, ws.slab_cap, grads + L.dec_w));
   if (dec_bias_S == 0) BLH_TRY(launch_colsum(on_ready ? s2 : s, dpred, batch, OF, OF, ws.colsum_part, grads + L.dec_b));
   else if (on_ready) BLH_TRY(launch_colreduce(s2, ws.dec_bias_part, dec_bias_S, OF, OF, grads + L.dec_b));
   BLH_TRY(ready(nh, L.dec_w, L.total - L.dec_w));
@@ -409,9 +410,9 @@ int backward_h(blh_context* ctx, const blh_model_desc* d, hipStream_t s, const f
         BLH_TRY(fork_wait(i, true));
         BLH_TRY(bias_now());
       }
-      if (!batched_w) BLH_TRY(wgrad_h(s2, ws.dZ[i], W, W, ws.A[i - 1], W, W, batch, ws.slabs, grads + h.w));
+      if (!batched_w) BLH_TRY(wgrad_h(s2, ws.dZ[i], W, W, ws.A[i - 1], W, W, batch, ws.slabs, ws.slab_cap, grads + h.w));
     } else {
-      BLH_TRY(wgrad_h(s2, ws.dZ[0], W, W, ws.xh, IF, IF, batch, ws.slabs, grads + h.w));
+      BLH_TRY(wgrad_h(s2, ws.dZ[0], W, W, ws.xh, IF, IF, batch, ws.slabs, ws.slab_cap, grads + h.w));
     }
     if (on_ready && !batched_w) {
       const int64_t end = (i + 1 < nh) ? L.heavy[i + 1].w : L.dec_w;

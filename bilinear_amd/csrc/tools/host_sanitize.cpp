@@ -30,7 +30,26 @@ static bool spans_ok(std::vector<Span>& v, const char* base, int64_t total) {
   return true;
 }
 
+// bf16 storage: a ragged batch launches its weight-gradient GEMMs over batch & ~7 rows (step_bf16s.hip: wgrad_h); the slab
+// buffer must hold THAT plan's slabs as well as the full batch's (round 6: it held only the latter — 385 rows need 2
+// slabs, the 384 launched 3 — and every ragged batch above 384 rows wrote past it)
+static int check_ragged_slab_plans() {
+  for (int w : {128, 256, 512, 1024, 2048})
+    for (int64_t b = 2; b <= 20000; b += (b < 4200 ? 1 : 97)) {
+      blh_model_desc d{2, w, 32, 48, 4};
+      const int64_t cap = slab_floats_h(&d, b);
+      for (const int64_t rows : {b, b & ~(int64_t)7}) {
+        if (rows <= 0) continue;
+        CHECK(wgrad_plan_h(w, w, rows).splits * (int64_t)w * w <= cap);
+        CHECK(wgrad_plan_h(w, 32, rows).splits * (int64_t)w * 32 <= cap);
+        CHECK(wgrad_plan_h(48, w, rows).splits * (int64_t)48 * w <= cap);
+      }
+    }
+  return 0;
+}
+
 int main() {
+  if (check_ragged_slab_plans()) return 1;
   const int widths[] = {64, 128, 256, 1024, 2048, 4096};
   const int64_t batches[] = {2, 30, 64, 257, 4096, 4100, 16384, 131072};
   char* const base = reinterpret_cast<char*>(uintptr_t(1) << 40);   // never dereferenced
@@ -71,6 +90,7 @@ int main() {
             v.push_back({(char*)ws.bn_part, (int64_t)ew_num_row_chunks_h(b) * 2 * w * 4});
             v.push_back({(char*)ws.dz_colsum_part, (int64_t)nh * ew_num_row_chunks_h(b) * w * 4});
             v.push_back({(char*)ws.slabs, slab_floats_h(&d, b) * 4});
+            CHECK(ws.slab_cap == slab_floats_h(&d, b));
             v.push_back({(char*)ws.dpred, b * 48 * 4});
             v.push_back({(char*)ws.dpredh, b * 48 * 2});
             CHECK(spans_ok(v, base, ws.bytes));
