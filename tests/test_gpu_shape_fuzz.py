@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("dtype,nb,width,batch", [
-    ("bf16s", 1, 256, 37), ("bf16s", 1, 256, 385), ("bf16s", 1, 256, 1025), ("bf16s", 1, 256, 4100),
-    ("bf16s", 2, 512, 386), ("bf16s", 2, 512, 2049), ("bf16s", 2, 512, 4100), ("bf16s", 2, 1024, 388),
-    ("fp32", 2, 512, 3), ("fp32", 2, 512, 385), ("fp32", 2, 512, 1025), ("fp32", 2, 1024, 2049), ("fp32", 1, 256, 4100),
+    ("bf16s", 1, 256, 37), ("bf16s", 1, 256, 385), ("bf16s", 1, 256, 4100), ("bf16s", 2, 512, 1025),
+    ("bf16s", 2, 512, 4100), ("bf16s", 2, 1024, 388),
+    ("fp32", 2, 512, 3), ("fp32", 2, 512, 1025), ("fp32", 1, 256, 4100),
 ])
 def test_fused_steps_at_ragged_batches_match_the_oracle(dtype, nb, width, batch):
     w = F.case(torch.device("cuda", 0), dtype, nb, width, batch, seed=1000 + batch)
