@@ -3,7 +3,8 @@ device against the fp64 NumPy oracle over a grid of ODD shapes — batches aroun
 (small-batch kernels <= 384 rows, split-K <= 1024, 64-row tiles <= 2048, ragged row tiles, batches that are not
 multiples of 8 / 32 / 128), widths 256 / 512 / 1024, 1-3 blocks, fp32 and bf16 storage, explicit masks.
 
-    python tests/shape_fuzz.py [quick]      -> one line per case, exit code 1 if any case is outside its tolerance
+    python tests/shape_fuzz.py [quick] [big] [fused] [dropin] [dp]   -> one line per case, exit code 1 if any case is
+                                                                    outside its tolerance
 
 Masks are gate-safe (golden_util.safe_masks: elements whose ReLU gate sits within rounding of zero are dropped, so no
 gradient depends on which way a correct implementation rounds).  Tolerances: fp32 — predictions 1e-4, loss 1e-5,
@@ -33,7 +34,9 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-def case(dev, dtype, nb, width, batch, seed):
+def case(dev, dtype, nb, width, batch, seed, mode="fused"):
+    """mode: "fused" (blh_train_step), "dropin" (the reference's five calls on the drop-in surface) or "dp" (the
+    data-parallel driver at one rank: blh_forward_train_loss + blh_backward under the bucket hook + clip + Adam)."""
     st = O.init_state(seed, nb, width)
     net = bilinear_amd.BilinearUnit(nb, width, gemm_dtype=dtype)
     sd = net.state_dict()
@@ -47,6 +50,10 @@ def case(dev, dtype, nb, width, batch, seed):
     oopt = O.adam_init(ost, keys)
     worst = dict(pred=0.0, loss=0.0, grad=0.0, gname="")
     xt, tt = torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev)
+    dp = None
+    if mode == "dp":
+        from bilinear_amd.dp import DataParallel
+        dp = DataParallel(net, opt, bucket_floats=max(1 << 16, net.engine.layout.total // 4))
     for step in range(2):
         masks = safe_masks(ost, x, O.random_masks(seed + 10 + step, batch, nb, width),
                            "bf16s" if dtype == "bf16s" else None, thr=2e-2 if dtype == "bf16s" else 1e-4)
@@ -54,7 +61,18 @@ def case(dev, dtype, nb, width, batch, seed):
         # re-synchronise the device with the oracle's state (two correct runs drift apart by lr * sign flips)
         sd = net.state_dict()
         net.load_state_dict({k: torch.from_numpy(np.array(ost[k])).reshape(sd[k].shape) for k in sd})
-        pred, loss = net.train_step(opt, xt, tt, max_norm=1.0)
+        if mode == "fused":
+            pred, loss = net.train_step(opt, xt, tt, max_norm=1.0)
+        elif mode == "dp":
+            pred, loss = dp.train_step(xt, tt)
+        else:
+            opt.zero_grad()
+            pred = net(xt)
+            loss = torch.nn.functional.mse_loss(pred, tt)
+            loss.backward()
+            bilinear_amd.clip_grad_norm_(net.parameters(), max_norm=1, module=net)
+            opt.step()
+            pred = pred.detach()
         torch.cuda.synchronize()
         if dtype == "bf16s":
             O.set_gemm_rounding("bf16s")
@@ -80,34 +98,43 @@ TOLERANCES = {"fp32": (1e-4, 1e-5, 1e-3), "bf16s": (1.5e-2, 1e-3, 6e-2)}       #
 
 
 def main():
-    quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+    args = sys.argv[1:]
+    quick = "quick" in args
+    big = "big" in args
+    modes = [m for m in ("fused", "dropin", "dp") if m in args] or ["fused"]
     dev = torch.device("cuda", 0)
     batches = [3, 37, 64, 129, 384, 385, 386, 388, 511, 1000, 1024, 1025, 1536, 2047, 2049, 2176, 3000, 4100, 4104]
     if quick:
         batches = [3, 37, 385, 1025, 2049, 4100]
     grid = []
-    for dtype in ("fp32", "bf16s"):
-        for nb, width in ((1, 256), (2, 512), (2, 1024), (3, 1024)):
-            if quick and (nb, width) not in ((2, 512), (2, 1024)):
+    for mode in modes:
+        for dtype in ("fp32", "bf16s"):
+            if big:      # the big-tile kernels with ragged row tiles (bf16 storage: 256 x 256 / 128 x 256 tiles; W = 2048)
+                shapes = [(4, 1024, 8200), (4, 1024, 16392), (2, 2048, 4100), (2, 2048, 8200)] if dtype == "bf16s" \
+                    else [(2, 1024, 8200), (1, 2048, 4100)]
+                grid += [(mode, dtype, nb, w, b) for nb, w, b in shapes]
                 continue
-            for b in batches:
-                if b < 8 and nb >= 3:      # (BatchNorm over three samples, seven stages deep: rounding noise in any arithmetic —
-                    continue               #  fp32 2.3e-3, bf16 storage > 1 against the fp64 oracle)
-                grid.append((dtype, nb, width, b))
+            for nb, width in ((1, 256), (2, 512), (2, 1024), (3, 1024)):
+                if (quick or mode != "fused") and (nb, width) not in ((2, 512), (2, 1024)):
+                    continue
+                for b in batches:
+                    if b < 8 and nb >= 3:      # (BatchNorm over three samples, seven stages deep: rounding noise in any arithmetic —
+                        continue               #  fp32 2.3e-3, bf16 storage > 1 against the fp64 oracle)
+                    grid.append((mode, dtype, nb, width, b))
     tol = TOLERANCES
     bad = 0
     t0 = time.time()
-    for i, (dtype, nb, width, b) in enumerate(grid):
+    for i, (mode, dtype, nb, width, b) in enumerate(grid):
         try:
-            w = case(dev, dtype, nb, width, b, seed=100 + i)
+            w = case(dev, dtype, nb, width, b, seed=100 + i, mode=mode)
             tp, tl, tg = tol[dtype]
             ok = w["pred"] <= tp and w["loss"] <= tl and w["grad"] <= tg
             note = ""
         except Exception as exc:       # noqa: BLE001  (a refused shape is a finding too)
             ok, w, note = False, dict(pred=-1, loss=-1, grad=-1, gname=""), " EXC %s: %s" % (type(exc).__name__, str(exc)[:100])
         bad += 0 if ok else 1
-        print("%-5s %d x %4d  B = %5d: pred %.2e loss %.2e grad %.2e (%s)%s%s  [%.0fs]" % (
-            dtype, nb, width, b, w["pred"], w["loss"], w["grad"], w["gname"], "" if ok else "  <-- OUT OF TOLERANCE", note,
+        print("%-6s %-5s %d x %4d  B = %5d: pred %.2e loss %.2e grad %.2e (%s)%s%s  [%.0fs]" % (
+            mode, dtype, nb, width, b, w["pred"], w["loss"], w["grad"], w["gname"], "" if ok else "  <-- OUT OF TOLERANCE", note,
             time.time() - t0), flush=True)
     print("%d cases, %d out of tolerance" % (len(grid), bad), flush=True)
     sys.exit(1 if bad else 0)
