@@ -339,6 +339,12 @@ static WorkspaceH carve_h(const blh_model_desc* d, int64_t batch, void* base) {
   };
   const int64_t act = batch * W * 2;
   ws.wsh = (uint16_t*)take(make_layout(d).total * 2);
+  // (the two parameter images FIRST, at offsets that do not depend on the batch: a caller may run batches of different
+  //  sizes in one workspace, and an image the previous step's Adam kernel left — BLH_OPT_PERSISTENT_SHADOW — must be
+  //  where the next step looks for it.  Round 6 found wdT behind the batch-sized buffers: after a change of the batch
+  //  size the one-pass decode read its weight from wherever the OTHER batch size had put it — a stale or never-written
+  //  image, silently wrong decode data gradients: 3e-2 of the parameters after seven steps, tools_dev/shadow_batch_change.py)
+  ws.wdT = (uint16_t*)take(W * 64 * 2);
   ws.xh = (uint16_t*)take(batch * d->in_features * 2);
   for (int i = 0; i < nh; ++i) ws.Z.push_back((uint16_t*)take(act));
   for (int i = 0; i < nh; ++i) ws.A.push_back((uint16_t*)take(act));
@@ -372,7 +378,6 @@ static WorkspaceH carve_h(const blh_model_desc* d, int64_t batch, void* base) {
   ws.colsum_part = (float*)take(ceil_div(batch, 256) * d->out_features * sizeof(float));
   ws.sync_buf = (double*)take(2 * W * sizeof(double));
   ws.dec_bias_part = (float*)take(1026 * d->out_features * sizeof(float));
-  ws.wdT = (uint16_t*)take(W * 64 * 2);
   ws.bytes = off;
   return ws;
 }

@@ -79,6 +79,10 @@ int main() {
             CHECK(ws.bytes == carve_h(&d, b, nullptr).bytes && ws.bytes > 0);
             std::vector<Span> v;
             v.push_back({(char*)ws.wsh, L.total * 2});
+            v.push_back({(char*)ws.wdT, (int64_t)w * 64 * 2});
+            // the parameter images sit where every batch size finds them (an image kept across steps must survive a
+            // change of the batch size on one workspace)
+            CHECK((char*)ws.wsh == base && ws.wdT == carve_h(&d, 2, base).wdT && ws.wdT == carve_h(&d, 65536, base).wdT);
             v.push_back({(char*)ws.xh, b * 32 * 2});
             for (int i = 0; i < nh; ++i) v.push_back({(char*)ws.Z[i], b * w * 2});
             for (int i = 0; i < nh; ++i) v.push_back({(char*)ws.A[i], b * w * 2});

@@ -588,3 +588,33 @@ def test_bf16s_encode_stage_without_z0_matches_the_materialised_path(nb, width, 
     assert rel(a[2][0], b[2][0]) <= 1e-5 and torch.equal(a[3], b[3])        # stage 0's running statistics
     assert abs(float(a[5]) - float(b[5])) <= 2e-3 * abs(float(b[5]))
     assert torch.isfinite(a[4]).all() and rel(a[6][0], b[6][0]) <= 1e-4
+
+
+def test_weight_image_kept_by_adam_survives_a_change_of_the_batch_size():
+    """bf16 storage keeps the bf16 weight image (and the one-pass decode's K-major decode weight) that the fused step's
+    Adam kernel writes, and the next step skips the re-cast (default since round 6).  The reference's loader ends an epoch
+    with a smaller batch (/root/reference/train_bilinear.py:33-43) and the engine runs it in the SAME workspace: the
+    images must sit at offsets that do not depend on the batch.  Round 6 found the decode image behind the batch-sized
+    buffers — after a batch-size change the decode read a stale or never-written image and the parameters drifted by
+    3e-2 in seven steps.  With the image and without it: bit-identical, through 4096 / 2048 / 1236-row steps."""
+    import bilinear_amd
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(1)
+    xs = {b: (torch.randn(b, 32, device=dev, generator=g), torch.randn(b, 48, device=dev, generator=g))
+          for b in (4096, 2048, 1236)}
+    out = {}
+    for keep in (True, False):
+        torch.manual_seed(0)
+        net, opt, _, _ = bilinear_amd.load(dev, num_blocks=2, width=1024, gemm_dtype="bf16s")
+        net.train()
+        net.engine.seed = 5
+        net.engine.ensure(dev)
+        net.engine.set_persistent_shadow(keep)
+        losses = []
+        for b in (4096, 4096, 2048, 2048, 4096, 1236, 4096):
+            x, t = xs[b]
+            losses.append(float(net.train_step(opt, x, t, max_norm=1.0)[1].item()))
+        torch.cuda.synchronize()
+        out[keep] = (net.engine.params.clone(), net.engine.bn_running.clone(), losses)
+    assert out[True][2] == out[False][2], (out[True][2], out[False][2])
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
