@@ -35,8 +35,9 @@ def rel(a, b):
 
 
 def case(dev, dtype, nb, width, batch, seed, mode="fused"):
-    """mode: "fused" (blh_train_step), "dropin" (the reference's five calls on the drop-in surface) or "dp" (the
-    data-parallel driver at one rank: blh_forward_train_loss + blh_backward under the bucket hook + clip + Adam)."""
+    """mode: "fused" (blh_train_step), "dropin" (the reference's five calls on the drop-in surface), "dp" (the
+    data-parallel driver at one rank: blh_forward_train_loss + blh_backward under the bucket hook + clip + Adam) or
+    "dpsync" (the same with SyncBN, every exchange issued over a one-rank gloo group)."""
     st = O.init_state(seed, nb, width)
     net = bilinear_amd.BilinearUnit(nb, width, gemm_dtype=dtype)
     sd = net.state_dict()
@@ -51,9 +52,17 @@ def case(dev, dtype, nb, width, batch, seed, mode="fused"):
     worst = dict(pred=0.0, loss=0.0, grad=0.0, gname="")
     xt, tt = torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev)
     dp = None
-    if mode == "dp":
+    if mode in ("dp", "dpsync"):
         from bilinear_amd.dp import DataParallel
-        dp = DataParallel(net, opt, bucket_floats=max(1 << 16, net.engine.layout.total // 4))
+        kw = {}
+        if mode == "dpsync":     # SyncBN at one rank with every exchange issued (gloo): the materialised kernels, statistics
+            import torch.distributed as dist      # through sum / sum of squares
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29577")
+                dist.init_process_group("gloo", rank=0, world_size=1)
+            kw = dict(sync_bn=True, force_collectives=True)
+        dp = DataParallel(net, opt, bucket_floats=max(1 << 16, net.engine.layout.total // 4), **kw)
     for step in range(2):
         masks = safe_masks(ost, x, O.random_masks(seed + 10 + step, batch, nb, width),
                            "bf16s" if dtype == "bf16s" else None, thr=2e-2 if dtype == "bf16s" else 1e-4)
@@ -63,7 +72,7 @@ def case(dev, dtype, nb, width, batch, seed, mode="fused"):
         net.load_state_dict({k: torch.from_numpy(np.array(ost[k])).reshape(sd[k].shape) for k in sd})
         if mode == "fused":
             pred, loss = net.train_step(opt, xt, tt, max_norm=1.0)
-        elif mode == "dp":
+        elif mode in ("dp", "dpsync"):
             pred, loss = dp.train_step(xt, tt)
         else:
             opt.zero_grad()
@@ -101,7 +110,7 @@ def main():
     args = sys.argv[1:]
     quick = "quick" in args
     big = "big" in args
-    modes = [m for m in ("fused", "dropin", "dp") if m in args] or ["fused"]
+    modes = [m for m in ("fused", "dropin", "dp", "dpsync") if m in args] or ["fused"]
     dev = torch.device("cuda", 0)
     batches = [3, 37, 64, 129, 384, 385, 386, 388, 511, 1000, 1024, 1025, 1536, 2047, 2049, 2176, 3000, 4100, 4104]
     if quick:
