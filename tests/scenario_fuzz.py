@@ -5,7 +5,7 @@ The image is an optimisation that must never change a bit: after every operation
 BatchNorm statistics are compared with torch.equal.  (Round 6: this is the kind of test that would have caught the
 decode-weight image behind the batch-sized buffers — tests/test_gpu_bf16s.py pins that one sequence; this tool draws many.)
 
-    python tests/scenario_fuzz.py [sequences] [ops per sequence] [shadow | streams]"""
+    python tests/scenario_fuzz.py [sequences] [ops per sequence] [shadow | streams | native]"""
 import os
 import random
 import sys
@@ -30,8 +30,15 @@ def make(first, nb, width, twin="shadow", dtype="bf16s"):
     net.engine.ensure(dev)
     if twin == "shadow":
         net.engine.set_persistent_shadow(first)
-    else:
+    elif twin == "streams":
         net.engine.set_two_stream(first)
+    if twin == "native":     # the data-parallel driver's collectives: torch's process group against the library's own RCCL calls
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29579")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        return net, opt, DataParallel(net, opt, force_collectives=True, collectives="torch" if first else "native")
     return net, opt, DataParallel(net, opt)
 
 
@@ -96,6 +103,8 @@ def run(nseq=6, nops=25, twin="shadow"):
             else:
                 ops.append(("scale", rnd.choice([0.99, 1.01])))
         dtype = "bf16s" if twin == "shadow" else rnd.choice(["fp32", "bf16s"])
+        if twin == "native":     # (mostly data-parallel steps)
+            ops = [("dp", o[1]) if o[0] in ("fused", "dropin") and rnd.random() < 0.7 else o for o in ops]
         twins = [make(True, nb, width, twin, dtype), make(False, nb, width, twin, dtype)]
         first_bad = None
         for i, op in enumerate(ops):
