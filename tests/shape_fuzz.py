@@ -3,7 +3,7 @@ device against the fp64 NumPy oracle over a grid of ODD shapes — batches aroun
 (small-batch kernels <= 384 rows, split-K <= 1024, 64-row tiles <= 2048, ragged row tiles, batches that are not
 multiples of 8 / 32 / 128), widths 256 / 512 / 1024, 1-3 blocks, fp32 and bf16 storage, explicit masks.
 
-    python tests/shape_fuzz.py [quick] [big] [fused] [dropin] [dp]   -> one line per case, exit code 1 if any case is
+    python tests/shape_fuzz.py [quick] [big] [wide] [split] [fused] [dropin] [dp] [dpsync]   -> one line per case, exit code 1 if any case is
                                                                     outside its tolerance
 
 Masks are gate-safe (golden_util.safe_masks: elements whose ReLU gate sits within rounding of zero are dropped, so no
@@ -103,13 +103,16 @@ def case(dev, dtype, nb, width, batch, seed, mode="fused"):
     return worst
 
 
-TOLERANCES = {"fp32": (1e-4, 1e-5, 1e-3), "bf16s": (1.5e-2, 1e-3, 6e-2)}       # (prediction, loss, gradient)
+TOLERANCES = {"fp32": (1e-4, 1e-5, 1e-3), "bf16s": (1.5e-2, 1e-3, 6e-2),        # (prediction, loss, gradient)
+              "bf16x3": (1e-4, 1e-5, 1e-3), "fp16x2": (1e-4, 1e-5, 1e-3)}
 
 
 def main():
     args = sys.argv[1:]
     quick = "quick" in args
     big = "big" in args
+    wide = "wide" in args        # widths off the beaten path (materialised encode / decode forms, other tile counts), 0-2 blocks
+    split = "split" in args      # the fp32-accurate split modes on the 16-bit matrix cores
     modes = [m for m in ("fused", "dropin", "dp", "dpsync") if m in args] or ["fused"]
     dev = torch.device("cuda", 0)
     batches = [3, 37, 64, 129, 384, 385, 386, 388, 511, 1000, 1024, 1025, 1536, 2047, 2049, 2176, 3000, 4100, 4104]
@@ -117,7 +120,17 @@ def main():
         batches = [3, 37, 385, 1025, 2049, 4100]
     grid = []
     for mode in modes:
-        for dtype in ("fp32", "bf16s"):
+        for dtype in (("bf16x3", "fp16x2") if split else ("fp32", "bf16s")):
+            if wide:
+                for nb, width in ((0, 256), (0, 1024), (1, 128), (1, 384), (2, 640), (1, 768), (1, 1536), (2, 2048)):
+                    for b in (37, 385, 1025, 2049, 4100):
+                        grid.append((mode, dtype, nb, width, b))
+                continue
+            if split:
+                for nb, width in ((2, 512), (2, 1024)):
+                    for b in (37, 385, 1025, 2049, 4100):
+                        grid.append((mode, dtype, nb, width, b))
+                continue
             if big:      # the big-tile kernels with ragged row tiles (bf16 storage: 256 x 256 / 128 x 256 tiles; W = 2048)
                 shapes = [(4, 1024, 8200), (4, 1024, 16392), (2, 2048, 4100), (2, 2048, 8200)] if dtype == "bf16s" \
                     else [(2, 1024, 8200), (1, 2048, 4100)]
