@@ -30,6 +30,15 @@ import torch.distributed as dist
 _COMPUTE_STREAMS = {}     # device -> the high-priority compute stream of DataParallel.stream
 
 
+def _row_stride(batch):
+    """Global index of a rank's first row = rank * this: the per-rank batch, rounded up to the 32 rows the Philox
+    generator's row blocks span (include/bilinear_hip.h: blh_dropout.row_offset must be a multiple of 32).  For the
+    usual per-rank batches (multiples of 32) a row's mask does not depend on the number of ranks; a ragged per-rank
+    batch — the reference loader's last batch split over the ranks — still gets distinct masks on every rank instead
+    of a refused call."""
+    return (int(batch) + 31) // 32 * 32
+
+
 class GradBucketReducer:
     """Bucketed, overlapped all-reduce (mean) over a flat gradient tensor.
 
@@ -311,7 +320,7 @@ class DataParallel:
         if getattr(eng, "_bucket_floats_set", None) != want:
             eng.ctx.set_option(N.OPT_BUCKET_FLOATS, min(int(want), (1 << 31) - 1))
             eng._bucket_floats_set = want
-        eng.row_offset = self.rank * batch
+        eng.row_offset = self.rank * _row_stride(batch)
         ws = eng.workspace(batch)
         drop = eng._drop_struct(batch)
         eng._tune_streams()
@@ -358,7 +367,7 @@ class DataParallel:
             eng.ctx.set_option(N.OPT_BUCKET_FLOATS, min(self._reducer.bucket_floats, (1 << 31) - 1))
             eng._bucket_floats_set = self._reducer.bucket_floats
         batch = x.shape[0]
-        eng.row_offset = self.rank * batch
+        eng.row_offset = self.rank * _row_stride(batch)
         sync = self._all_reduce_sum if (self.sync_bn and (self.world > 1 or self.force_collectives)) else None
         gb = batch * self.world
         # forward + MSE as the fused single-GPU step runs them (one enqueue; the loss gradient stays
@@ -477,7 +486,7 @@ class CapturedDataParallelStep:
         N.check(lib.blh_step_state_advance(eng._stream(), N.ptr(self.state)), "blh_step_state_advance")
         N.check(lib.blh_context_set_step_state(eng.ctx.handle, N.ptr(self.state)), "blh_context_set_step_state")
         try:
-            eng.row_offset = dp.rank * self.batch
+            eng.row_offset = dp.rank * _row_stride(self.batch)
             saved_step = eng.rng_step
             eng.rng_step = 0                        # the device counter supplies the step
             pred, loss = eng.forward_train_loss(self.x, self.t)
@@ -508,7 +517,7 @@ class CapturedDataParallelStep:
             eng.ctx.set_option(N.OPT_BUCKET_FLOATS, min(int(want), (1 << 31) - 1))
             eng._bucket_floats_set = want
         ws = eng.workspace(self.batch)
-        eng.row_offset = dp.rank * self.batch
+        eng.row_offset = dp.rank * _row_stride(self.batch)
         saved_step = eng.rng_step
         eng.rng_step = 0                            # the device counter supplies the step
         try:

@@ -29,7 +29,9 @@ def _free_port():
 # (num_blocks, width, rows per rank, gemm_dtype).  The second configuration is large enough for
 # the ordinary (not split-K) GEMM path, i.e. the side-stream weight gradients + the grad-ready
 # hook that runs with the side stream current; the third runs it in the fp16x2 arithmetic.
-CONFIGS = [(NB, WIDTH, LOCAL_B, "fp32"), (1, 1024, 2048, "fp32"), (1, 1024, 2048, "fp16x2")]
+# The last one: a per-rank batch that is NOT a multiple of 32 (the reference loader's ragged last batch split over the
+# ranks): rank r's first global row is r * 128 (dp._row_stride), where r * 100 used to be refused by the Philox check.
+CONFIGS = [(NB, WIDTH, LOCAL_B, "fp32"), (1, 1024, 2048, "fp32"), (1, 1024, 2048, "fp16x2"), (1, 256, 100, "fp32")]
 
 
 def _make(dev, cfg=CONFIGS[0]):
@@ -93,7 +95,8 @@ def test_data_parallel_two_ranks_match_manual_average(tmp_path, cfg):
         nbt0 = eng.bn_nbt.clone()
         for r in range(2):
             sl = slice(r * LOCAL_B, (r + 1) * LOCAL_B)
-            eng.row_offset = r * LOCAL_B
+            from bilinear_amd.dp import _row_stride
+            eng.row_offset = r * _row_stride(LOCAL_B)
             eng.rng_step = step
             if r == 1:                       # each rank updates its own copy of the BN buffers
                 eng.bn_running.copy_(bn0)
