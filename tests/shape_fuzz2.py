@@ -125,9 +125,38 @@ def fuzz_heavy():
                " ".join("%s %.1e" % kv for kv in errs.items()))
 
 
+def fuzz_mpjpe():
+    """blh_mpjpe (valid_bilinear.py:53-83 on the device) at odd batch sizes, missing actions, one-row updates."""
+    from bilinear_amd.metrics import MPJPE
+    rng = np.random.RandomState(3)
+    names = ["a%d" % i for i in range(15)]
+    for B in (1, 2, 15, 16, 17, 63, 64, 65, 255, 257, 777, 1000, 4097, 10000):
+        pred = rng.standard_normal((B, 48)).astype(np.float32)
+        tgt = rng.standard_normal((B, 48)).astype(np.float32)
+        mean = (rng.standard_normal(48) * 100).astype(np.float32)
+        std = (50 + 200 * rng.random_sample(48)).astype(np.float32)
+        ids = rng.randint(0, rng.randint(1, 16), size=B).astype(np.int32)        # (some actions may not occur)
+        m = MPJPE(names, torch.from_numpy(mean), torch.from_numpy(std), dev)
+        cuts = sorted(set([0, B] + [int(c) for c in rng.randint(0, B + 1, size=3)]))
+        got = []
+        for a, b in zip(cuts, cuts[1:]):
+            if b > a:
+                got.append(m.update(torch.from_numpy(pred[a:b]).to(dev), torch.from_numpy(tgt[a:b]).to(dev),
+                                    torch.from_numpy(ids[a:b])).cpu().numpy())
+        got = np.concatenate(got)
+        ref = O.mpjpe_sum(pred.astype(np.float64), tgt.astype(np.float64), mean.astype(np.float64), std.astype(np.float64))
+        per_action, avg = m.result()
+        ok = np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() and abs(avg - ref.sum() / (B * 16)) <= 1e-5 * avg
+        for i, n in enumerate(names):
+            sel = ids == i
+            if sel.sum():
+                ok = ok and abs(per_action[n] - ref[sel].sum() / (sel.sum() * 16)) <= 1e-5 * per_action[n]
+        report("mpjpe B = %5d in %d updates" % (B, len(cuts) - 1), bool(ok), "avg %.4f" % avg)
+
+
 if __name__ == "__main__":
-    which = [a for a in sys.argv[1:] if a in ("eval", "graph", "heavy")] or ["eval", "graph", "heavy"]
+    which = [a for a in sys.argv[1:] if a in ("eval", "graph", "heavy", "mpjpe")] or ["eval", "graph", "heavy", "mpjpe"]
     for w in which:
-        {"eval": fuzz_eval, "graph": fuzz_graph, "heavy": fuzz_heavy}[w]()
+        {"eval": fuzz_eval, "graph": fuzz_graph, "heavy": fuzz_heavy, "mpjpe": fuzz_mpjpe}[w]()
     print("%d failed" % bad, flush=True)
     sys.exit(1 if bad else 0)
