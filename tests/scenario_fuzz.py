@@ -5,7 +5,7 @@ The image is an optimisation that must never change a bit: after every operation
 BatchNorm statistics are compared with torch.equal.  (Round 6: this is the kind of test that would have caught the
 decode-weight image behind the batch-sized buffers — tests/test_gpu_bf16s.py pins that one sequence; this tool draws many.)
 
-    python tests/scenario_fuzz.py [sequences] [ops per sequence] [shadow | streams | native]"""
+    python tests/scenario_fuzz.py [sequences] [ops per sequence] [shadow | streams | native | graph]"""
 import os
 import random
 import sys
@@ -42,8 +42,14 @@ def make(first, nb, width, twin="shadow", dtype="bf16s"):
     return net, opt, DataParallel(net, opt)
 
 
-def apply(op, net, opt, dp, data):
+def apply(op, net, opt, dp, data, cap=None):
     kind, arg = op
+    if kind == "cap":        # a fused step at the sequence's captured batch: the hipGraph replay on the first twin, eager on the second
+        x, t = data[arg]
+        net.train()
+        if cap is not None:
+            return float(cap(x, t)[1].item())
+        return float(net.train_step(opt, x, t, max_norm=1.0)[1].item())
     if kind in ("fused", "dropin", "dp"):
         x, t = data[arg]
         net.train()
@@ -106,9 +112,17 @@ def run(nseq=6, nops=25, twin="shadow"):
         if twin == "native":     # (mostly data-parallel steps)
             ops = [("dp", o[1]) if o[0] in ("fused", "dropin") and rnd.random() < 0.7 else o for o in ops]
         twins = [make(True, nb, width, twin, dtype), make(False, nb, width, twin, dtype)]
+        caps = [None, None]
+        if twin == "graph":      # twin 0 replays a captured step (its device-resident lr / step counts / bf16 image must follow
+            b0 = rnd.choice([1024, 2048, 4096])        # every out-of-band change), twin 1 runs everything eagerly
+            small = [b for b in BATCHES if b <= b0]
+            ops = [("cap", b0) if o[0] in ("fused", "dropin", "dp") and rnd.random() < 0.6 else
+                   ((o[0], rnd.choice(small)) if o[0] in ("fused", "dropin", "dp", "eval") else o) for o in ops]
+            twins[0][0].engine.workspace(b0)
+            caps[0] = bilinear_amd.CapturedTrainStep(twins[0][0], twins[0][1], b0, max_norm=1.0)
         first_bad = None
         for i, op in enumerate(ops):
-            res = [apply(op, *tw, data) for tw in twins]
+            res = [apply(op, *tw, data, cap) for tw, cap in zip(twins, caps)]
             torch.cuda.synchronize()
             a, b = twins[0], twins[1]
             same = res[0] == res[1] and torch.equal(a[0].engine.params, b[0].engine.params) and \

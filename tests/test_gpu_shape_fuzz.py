@@ -23,11 +23,12 @@ def test_fused_steps_at_ragged_batches_match_the_oracle(dtype, nb, width, batch)
     assert w["pred"] <= tp and w["loss"] <= tl and w["grad"] <= tg, w
 
 
-@pytest.mark.parametrize("twin", ["shadow", "streams"])
+@pytest.mark.parametrize("twin", ["shadow", "streams", "graph"])
 def test_random_operation_sequences_leave_the_twins_bit_identical(twin):
     """tests/scenario_fuzz.py: random sequences of fused / drop-in / data-parallel steps at CHANGING batch sizes, eval
     forwards, lr changes, state_dict round trips and in-place parameter writes on two twins that differ only in an
     optimisation that must never change a bit — Adam keeping the bf16 weight image ("shadow"), the weight gradients on the
-    side stream ("streams").  After every operation: parameters, Adam moments, BatchNorm statistics torch.equal."""
+    side stream ("streams"), the fused steps replayed from a captured hipGraph whose device-resident state has to follow every
+    out-of-band change ("graph").  After every operation: parameters, Adam moments, BatchNorm statistics torch.equal."""
     import scenario_fuzz as S
     assert S.run(nseq=8, nops=30, twin=twin) == 0
