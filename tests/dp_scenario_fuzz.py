@@ -28,7 +28,7 @@ def worker(rank, world, port, out_dir, nseq, nsteps):
         from bilinear_amd.dp import DataParallel
         dev = torch.device("cuda:0")
         for seq in range(nseq):
-            rnd = random.Random(900 + seq)                  # (the same draw on both ranks)
+            rnd = random.Random(int(os.environ.get("FUZZ_SEED", "900")) + seq)                  # (the same draw on both ranks)
             dtype = rnd.choice(["fp32", "bf16s"])
             nb, width = rnd.choice([(1, 256), (2, 512), (2, 1024)])
             sync_bn = rnd.random() < 0.3

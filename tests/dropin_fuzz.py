@@ -39,7 +39,7 @@ def dropin_step(net, opt, x, t, masks=None):
 def run(nseq=10, nops=20):
     bad = 0
     for seq in range(nseq):
-        rnd = random.Random(500 + seq)
+        rnd = random.Random(int(os.environ.get("FUZZ_SEED", "500")) + seq)
         dtype = rnd.choice(["fp32", "bf16s"])
         nb, width = rnd.choice([(1, 256), (2, 512), (2, 1024)])
         torch.manual_seed(seq)
