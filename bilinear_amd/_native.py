@@ -161,6 +161,7 @@ _SIGNATURES = {
     "blh_comm_destroy": (c_int, [c_void_p]),
     "blh_comm_info": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
     "blh_comm_stream": (c_void_p, [c_void_p]),
+    "blh_comm_set_bf16_buffer": (c_int, [c_void_p, c_void_p, c_int64]),
     "blh_comm_all_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32]),
     "blh_comm_broadcast": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32]),
     "blh_comm_last_error": (c_char_p, []),
@@ -239,7 +240,8 @@ class Context:
             pass
 
 
-DP_TAIL_ON_COMM_STREAM = 1     # blh_train_step_dp flag (include/bilinear_hip.h)
+DP_TAIL_ON_COMM_STREAM = 1     # blh_train_step_dp flags (include/bilinear_hip.h)
+DP_BF16_BUCKETS = 2
 UNIQUE_ID_BYTES = 128
 
 

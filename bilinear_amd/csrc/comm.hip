@@ -124,6 +124,8 @@ struct blh_comm {
   hipEvent_t ev_cs = nullptr, ev_tail = nullptr;
   int next_ev = 0;
   int64_t collectives = 0;      // issued so far (tests: every bucket went out)
+  uint16_t* half = nullptr;     // blh_comm_set_bf16_buffer: the caller's bf16 image of the gradient arena (bf16 buckets)
+  int64_t half_count = 0;
 };
 
 namespace {
@@ -137,6 +139,7 @@ struct DpCall {
                             // everything the main stream ran, the first is not (the one-pass decode carries the
                             // side stream's fork as its completion signal, loss_finalize runs behind it)
   bool tail_on_producer;    // the last bucket (offset 0) rides the producer stream itself
+  uint16_t* half;           // bf16 buckets: a bucket is cast into this image and exchanged in bf16 (half the wire bytes)
   PendingLoss pend;         // the forward's loss partials, not yet finalised: the first bucket's turn on the producer
   float* loss_dst;          // stream does it (behind the decode kernel that wrote them; nothing waits for it there)
   bool used_cs = false;
@@ -144,12 +147,17 @@ struct DpCall {
   int status = BLH_OK;
 };
 
-int all_reduce_avg_f32(blh_comm* c, hipStream_t st, float* buf, int64_t count, float* extra) {
+// half != NULL: the bucket is rounded to bf16 (round to nearest even, the library's cast kernel) on the stream that carries
+// the collective and averaged in bf16; the fp32 values stay where they are (clip + Adam read the bf16 image)
+int all_reduce_avg_f32(blh_comm* c, hipStream_t st, float* buf, int64_t count, float* extra, uint16_t* half = nullptr) {
   const Rccl* r = rccl();
+  if (half) BLH_TRY(launch_cast_f32_bf16(st, buf, half, count));
   if (extra) {
     BLH_NCCL_TRY("ncclGroupStart", r->GroupStart());
     BLH_NCCL_TRY("ncclAllReduce", r->AllReduce(extra, extra, 1, NCCL_FLOAT32, NCCL_AVG, c->comm, st));
   }
+  if (half) BLH_NCCL_TRY("ncclAllReduce", r->AllReduce(half, half, (size_t)count, NCCL_BFLOAT16, NCCL_AVG, c->comm, st));
+  else
   BLH_NCCL_TRY("ncclAllReduce", r->AllReduce(buf, buf, (size_t)count, NCCL_FLOAT32, NCCL_AVG, c->comm, st));
   if (extra) BLH_NCCL_TRY("ncclGroupEnd", r->GroupEnd());
   c->collectives += extra ? 2 : 1;
@@ -167,14 +175,14 @@ int bucket_ready(DpCall* k, int64_t off, int64_t cnt) {
   if (last) { k->last_seen = true; k->loss = nullptr; }
   if (last && k->tail_on_producer) {
     // nothing else will follow on the producer stream but the optimiser: the collective goes in line, no event hop
-    return all_reduce_avg_f32(c, k->producer, k->grads + off, cnt, extra);
+    return all_reduce_avg_f32(c, k->producer, k->grads + off, cnt, extra, k->half ? k->half + off : nullptr);
   }
   hipEvent_t e = c->ev[c->next_ev];
   c->next_ev = (c->next_ev + 1) % COMM_EVENTS;
   BLH_HIP_TRY(hipEventRecord(e, k->producer));
   BLH_HIP_TRY(hipStreamWaitEvent(c->cs, e, 0));
   k->used_cs = true;
-  return all_reduce_avg_f32(c, c->cs, k->grads + off, cnt, extra);
+  return all_reduce_avg_f32(c, c->cs, k->grads + off, cnt, extra, k->half ? k->half + off : nullptr);
 }
 
 void bucket_thunk(void* user, int64_t off, int64_t cnt) {
@@ -266,6 +274,12 @@ int blh_comm_info(const blh_comm* c, int32_t* world, int32_t* rank, int32_t* rcc
 
 void* blh_comm_stream(blh_comm* c) { return c ? (void*)c->cs : nullptr; }
 
+int blh_comm_set_bf16_buffer(blh_comm* c, uint16_t* buf, int64_t count) {
+  if (!c || (buf && count <= 0)) return BLH_ERR_INVALID_ARGUMENT;
+  c->half = buf; c->half_count = buf ? count : 0;
+  return BLH_OK;
+}
+
 int blh_comm_all_reduce(blh_comm* c, void* stream, void* buf, int64_t count, int32_t dtype, int32_t average) {
   if (!c || !buf || count <= 0 || nccl_dtype(dtype) < 0) return BLH_ERR_INVALID_ARGUMENT;
   const Rccl* r = rccl();
@@ -293,7 +307,10 @@ int blh_train_step_dp(blh_context* ctx, blh_comm* comm, const blh_model_desc* d,
                       int64_t global_batch, blh_sync_fn sync, void* sync_user, int32_t flags) {
   if (!ctx || !comm || !d || !params || !grads || !exp_avg || !exp_avg_sq || !loss_out || (!hyper == !dev_state))
     return BLH_ERR_INVALID_ARGUMENT;
-  if (flags & ~(BLH_DP_TAIL_ON_COMM_STREAM)) return BLH_ERR_INVALID_ARGUMENT;
+  if (flags & ~(BLH_DP_TAIL_ON_COMM_STREAM | BLH_DP_BF16_BUCKETS)) return BLH_ERR_INVALID_ARGUMENT;
+  const bool bf16_buckets = (flags & BLH_DP_BF16_BUCKETS) != 0;
+  // (bf16 buckets: the caller's bf16 image must hold the arena; the capturable form has no bf16-reading optimiser)
+  if (bf16_buckets && (!comm->half || comm->half_count < make_layout(d).total || dev_state)) return BLH_ERR_INVALID_ARGUMENT;
   if (global_batch != batch * (int64_t)comm->world) return BLH_ERR_INVALID_ARGUMENT;
   int dev = -1;
   BLH_HIP_TRY(hipGetDevice(&dev));
@@ -331,7 +348,8 @@ int blh_train_step_dp(blh_context* ctx, blh_comm* comm, const blh_model_desc* d,
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   BLH_HIP_TRY(hipStreamIsCapturing(s, &cap));
   const bool tail_on_producer = !(flags & BLH_DP_TAIL_ON_COMM_STREAM) && cap == hipStreamCaptureStatusNone;
-  DpCall call{comm, ctx->two_stream ? ctx->s2 : s, grads, loss_out, tail_on_producer, pend, loss_out};
+  DpCall call{comm, ctx->two_stream ? ctx->s2 : s, grads, loss_out, tail_on_producer, bf16_buckets ? comm->half : nullptr,
+              pend, loss_out};
   int rc = sync ? blh_backward_sync(ctx, d, s, params, x, drop, workspace, workspace_bytes, nullptr, grads, batch,
                                     bucket_thunk, &call, global_batch, sync, sync_user)
                 : blh_backward(ctx, d, s, params, x, drop, workspace, workspace_bytes, nullptr, grads, batch,
@@ -349,7 +367,8 @@ int blh_train_step_dp(blh_context* ctx, blh_comm* comm, const blh_model_desc* d,
     const int64_t count = make_layout(d).total;
     double* sumsq_part = d->gemm_dtype == 4 ? carve_h(d, batch, workspace).sumsq_part : carve(d, batch, workspace).sumsq_part;
     int np = 0;
-    rc = launch_sumsq(tail, grads, count, sumsq_part, &np);
+    rc = bf16_buckets ? launch_sumsq_bf16(tail, comm->half, count, 1.0f, sumsq_part, &np)
+                      : launch_sumsq(tail, grads, count, sumsq_part, &np);
     // bf16 storage under BLH_OPT_PERSISTENT_SHADOW: Adam also writes the bf16 image of the updated weights (and the
     // decode weight's K-major image when this shape takes the one-pass decode), as blh_train_step does
     const bool wdT = keep && !ctx->knob(KNOB_NO_DECODE_FUSE) && decode_fused_h_supported(batch, d->width, d->out_features);
@@ -358,11 +377,16 @@ int blh_train_step_dp(blh_context* ctx, blh_comm* comm, const blh_model_desc* d,
       const WorkspaceH wh = carve_h(d, batch, workspace);
       sd = ShadowDst{wh.wsh, wdT ? wh.wdT : nullptr, make_layout(d).dec_w, d->width, d->out_features};
     }
-    if (rc == BLH_OK)
-      rc = dev_state ? launch_clip_adam_dev(tail, params, grads, exp_avg, exp_avg_sq, count, dev_state, sumsq_part, np,
-                                            stats_out, LossFinish{nullptr, 0, 1.0, nullptr}, sd)
-                     : launch_clip_adam(tail, params, grads, exp_avg, exp_avg_sq, count, *hyper, sumsq_part, np, stats_out,
-                                        LossFinish{nullptr, 0, 1.0, nullptr}, sd);
+    if (rc == BLH_OK) {
+      if (bf16_buckets)      // norm, clip and Adam read the averaged bf16 buckets; the fp32 arena receives the clipped gradient
+        rc = launch_clip_adam_bf16(tail, params, comm->half, 1.0f, grads, exp_avg, exp_avg_sq, count, *hyper, sumsq_part, np,
+                                   stats_out, sd);
+      else
+        rc = dev_state ? launch_clip_adam_dev(tail, params, grads, exp_avg, exp_avg_sq, count, dev_state, sumsq_part, np,
+                                              stats_out, LossFinish{nullptr, 0, 1.0, nullptr}, sd)
+                       : launch_clip_adam(tail, params, grads, exp_avg, exp_avg_sq, count, *hyper, sumsq_part, np, stats_out,
+                                          LossFinish{nullptr, 0, 1.0, nullptr}, sd);
+    }
     if (keep && rc == BLH_OK) {
       // (the K-major image is complete only if an earlier launch zeroed its padding rows: a step's cast does)
       ctx->shadow_params = params; ctx->shadow_ws = workspace; ctx->shadow_wdT = wdT && (valid ? wdT_was : true);

@@ -198,7 +198,7 @@ class DataParallel:
                  sync_bn=False, force_collectives=False, compress=None, collectives="torch",
                  native_tail="producer"):
         """``collectives``: ``"torch"`` (default) — every bucket all-reduce is launched from blh_backward's hook
-        through ``torch.distributed``; ``"native"`` (opt-in, HIP devices, fp32 buckets) — the LIBRARY owns an RCCL
+        through ``torch.distributed``; ``"native"`` (opt-in, HIP devices) — the LIBRARY owns an RCCL
         communicator of its own (``blh_comm``: created here from a unique id broadcast over ``group``) and the whole
         step is one call, ``blh_train_step_dp``: bucket all-reduces enqueued by backward itself behind the kernel that
         completes each bucket, norm + clip + Adam right behind the last one, one join (csrc/comm.hip,
@@ -211,11 +211,12 @@ class DataParallel:
             raise ValueError("collectives must be 'torch' or 'native'")
         if native_tail not in ("producer", "comm"):
             raise ValueError("native_tail must be 'producer' or 'comm'")
-        if collectives == "native" and compress is not None:
-            raise ValueError("collectives='native' exchanges fp32 buckets (compress is a torch-mode option)")
+        if compress not in (None, "bf16"):
+            raise ValueError("compress must be None or 'bf16'")
         self.collectives = collectives
         self.native_tail = native_tail
         self._comm = None
+        self._native_half = None
         self.force_collectives = bool(force_collectives)
         self.compress = compress
         self.module = module
@@ -334,6 +335,13 @@ class DataParallel:
         use_sync = self.sync_bn and (self.world > 1 or self.force_collectives)
         scb = eng._sync_callback(ws, self._all_reduce_sum, errors) if use_sync else ctypes.cast(None, N.SyncFn)
         flags = N.DP_TAIL_ON_COMM_STREAM if self.native_tail == "comm" else 0
+        if self.compress == "bf16":      # bf16 buckets: the library casts, exchanges and reads this image of the gradient arena
+            if self._native_half is None or self._native_half.device != x.device or \
+                    self._native_half.numel() != eng.layout.total:
+                self._native_half = torch.zeros(eng.layout.total, dtype=torch.bfloat16, device=x.device)
+                N.check(N.lib().blh_comm_set_bf16_buffer(comm.handle, N.ptr(self._native_half), eng.layout.total),
+                        "blh_comm_set_bf16_buffer")
+            flags |= N.DP_BF16_BUCKETS
         eng._check_shadow_versions()     # (bf16 storage: the step's Adam keeps the bf16 weight image, as the fused step's)
         N.check(N.lib().blh_train_step_dp(
             eng.ctx.handle, comm.handle, ctypes.byref(eng.layout.desc), eng._stream(), N.ptr(eng.params),
@@ -440,6 +448,9 @@ class CapturedDataParallelStep:
         # replay is invisible to the context's record of whose image is current; the eager native step keeps it)
         keep_image = None
         if dp.collectives == "native":
+            if dp.compress is not None:
+                raise RuntimeError("bf16 buckets are not capturable with the library-driven collectives "
+                                   "(blh_train_step_dp: BLH_DP_BF16_BUCKETS needs the host-side hyper-parameters)")
             dp.native_comm()
             if eng.layout.desc.gemm_dtype == 4:
                 keep_image = eng.ctx.get_option(N.OPT_PERSISTENT_SHADOW)

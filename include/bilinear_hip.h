@@ -438,6 +438,9 @@ int blh_comm_destroy(blh_comm* comm);
 int blh_comm_info(const blh_comm* comm, int32_t* world, int32_t* rank, int32_t* rccl_version,
                   int64_t* collectives_issued);
 void* blh_comm_stream(blh_comm* comm);
+/* bf16 buckets (BLH_DP_BF16_BUCKETS): a caller-owned device buffer of at least blh_param_arena_floats() bf16 values, in
+ * arena layout; NULL detaches it.                                                                                    */
+int blh_comm_set_bf16_buffer(blh_comm* comm, uint16_t* buf, int64_t count);
 int blh_comm_all_reduce(blh_comm* comm, void* stream, void* buf, int64_t count, int32_t dtype, int32_t average);
 int blh_comm_broadcast(blh_comm* comm, void* stream, void* buf, int64_t bytes, int32_t root);
 const char* blh_comm_last_error(void);
@@ -454,6 +457,9 @@ const char* blh_comm_last_error(void);
  * are captured like kernels).  sync != NULL: SyncBN through the caller's callback (blh_forward_train_loss_sync).
  * Results equal blh_forward_train_loss + blh_backward + all-reduce(avg) per bucket + blh_clip_adam_step.           */
 #define BLH_DP_TAIL_ON_COMM_STREAM 1
+#define BLH_DP_BF16_BUCKETS 2 /* every bucket is rounded to bf16 (the library's cast kernel), averaged on the wire in bf16 —
+                                 half the bytes on every xGMI link — and norm, clip and Adam read the bf16 values directly
+                                 (blh_clip_adam_step_bf16); needs blh_comm_set_bf16_buffer and `hyper` (not dev_state)  */
 int blh_train_step_dp(blh_context* ctx, blh_comm* comm, const blh_model_desc* d, void* stream, float* params,
                       float* grads, float* exp_avg, float* exp_avg_sq, float* bn_running,
                       int64_t* bn_num_batches_tracked, const float* x, const float* target,

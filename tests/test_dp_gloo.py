@@ -179,8 +179,9 @@ def test_collectives_argument_of_the_data_parallel_driver():
 
     with pytest.raises(ValueError):
         DataParallel(_Mod(), None, collectives="rccl")
+    assert DataParallel(_Mod(), None, collectives="native", compress="bf16").compress == "bf16"   # (bf16 buckets: both drivers)
     with pytest.raises(ValueError):
-        DataParallel(_Mod(), None, collectives="native", compress="bf16")
+        DataParallel(_Mod(), None, collectives="native", compress="fp8")
     with pytest.raises(ValueError):
         DataParallel(_Mod(), None, collectives="native", native_tail="main")
     dp = DataParallel(_Mod(), None, collectives="native")

@@ -501,7 +501,7 @@ def _worker_native(rank, world, port, out_dir):
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     try:
         from bilinear_amd import _native as N
-        from bilinear_amd.dp import DataParallel
+        from bilinear_amd.dp import CapturedDataParallelStep, DataParallel
         assert N.lib().blh_rccl_version() > 0
         for cfg, bucket in (((1, 1024, 2048, "fp32"), 200000), ((2, 1024, 4096, "fp32"), 1 << 20),
                             ((2, 1024, 4096, "bf16s"), 1 << 20), ((2, 1024, 4100, "bf16s"), 1 << 20)):
@@ -536,6 +536,25 @@ def _worker_native(rank, world, port, out_dir):
                 assert out["torch"][5] == out[name][5], (cfg, name, out["torch"][5], out[name][5])
                 assert torch.equal(out["torch"][6], out[name][6]) and torch.equal(out["torch"][7], out[name][7])
             assert out["torch"][5][-1] < out["torch"][5][0]
+
+        # bf16 buckets (half the wire bytes; norm, clip and Adam read the averaged bf16 values): both drivers cast with the
+        # same kernel, average in bf16 and run blh_clip_adam_step_bf16's kernels — bit-identical again
+        for cfg, bucket in (((1, 1024, 2048, "fp32"), 200000), ((2, 1024, 4096, "bf16s"), 1 << 20), ((2, 512, 1236, "bf16s"), 1 << 18)):
+            x, t = _data(dev, cfg)
+            x, t = x[:cfg[2]].contiguous(), t[:cfg[2]].contiguous()
+            res = {}
+            for name, kw in (("torch", dict()), ("native", dict(collectives="native"))):
+                net, opt = _make(dev, cfg)
+                dp = DataParallel(net, opt, bucket_floats=bucket, force_collectives=True, compress="bf16", **kw)
+                ls = [float(dp.train_step(x, t)[1].item()) for _ in range(3)]
+                torch.cuda.synchronize()
+                res[name] = (net.engine.params.clone(), opt._exp_avg.clone(), opt._exp_avg_sq.clone(), net.engine.grads.clone(),
+                             opt.last_grad_norm_stats.clone(), ls)
+            for a, b in zip(res["torch"][:5], res["native"][:5]):
+                assert torch.equal(a, b), cfg
+            assert res["torch"][5] == res["native"][5], (cfg, res["torch"][5], res["native"][5])
+            with pytest.raises(RuntimeError):
+                CapturedDataParallelStep(dp, cfg[2])            # (bf16 buckets + library-driven collectives: not capturable)
 
         # ... and captured: the library-driven step as one hipGraph (blh_train_step_dp with the device step state, the
         # RCCL launches captured with it) == the eager torch-driven step, bit for bit, with an lr change between replays
