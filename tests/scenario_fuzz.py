@@ -18,6 +18,7 @@ from bilinear_amd.dp import DataParallel  # noqa: E402
 
 dev = torch.device("cuda", 0)
 BATCHES = [37, 64, 100, 385, 1024, 1236, 2048, 2176, 4096, 4100]
+COMPRESS = [None]          # ("native" twins: drawn per sequence — bf16 gradient buckets or fp32)
 
 
 def make(first, nb, width, twin="shadow", dtype="bf16s"):
@@ -38,7 +39,8 @@ def make(first, nb, width, twin="shadow", dtype="bf16s"):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29579")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        return net, opt, DataParallel(net, opt, force_collectives=True, collectives="torch" if first else "native")
+        return net, opt, DataParallel(net, opt, force_collectives=True, collectives="torch" if first else "native",
+                                      compress=COMPRESS[0])
     return net, opt, DataParallel(net, opt)
 
 
@@ -109,6 +111,7 @@ def run(nseq=6, nops=25, twin="shadow"):
             else:
                 ops.append(("scale", rnd.choice([0.99, 1.01])))
         dtype = "bf16s" if twin == "shadow" else rnd.choice(["fp32", "bf16s"])
+        COMPRESS[0] = rnd.choice([None, "bf16"]) if twin == "native" else None
         if twin == "native":     # (mostly data-parallel steps)
             ops = [("dp", o[1]) if o[0] in ("fused", "dropin") and rnd.random() < 0.7 else o for o in ops]
         twins = [make(True, nb, width, twin, dtype), make(False, nb, width, twin, dtype)]
